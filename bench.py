@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X dashing2 hot paths.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Primary metric (BASELINE.json): all-pairs sketch comparison throughput, **pairs/s**, on
+BASELINE config 3 at N=1: 10 000 pre-built OPH sketches, S = 1024 (49 995 000 pairs), float32
+Jaccard output.  One step = one whole pass of the path over sketches already resident in HBM:
+prepare (transpose, per-column dense ids, bit planes) + the pair kernel with its fused epilogue.
+Secondary metric in the same JSON line: sketch construction **bases/s** (K1) on BASELINE config 2's
+shape (1 000 x 5 Mbp, k=31, S=1024) with the packed bases resident in HBM.
+
+N > 1 (weak scaling, constant pairs per GPU): N_sketches = round(10000 * sqrt(N)); rank 0 owns the
+sketches, each step broadcasts them over RCCL, every rank prepares the operand and computes its
+pair-balanced row range of the upper triangle.  No other collective on the data path.
+
+PyTorch is plumbing only (device memory, streams, torch.distributed); all computation goes through
+the C ABI of libd2g.so.  The oracle is used ONLY for the cpu_baseline leg.
+"""
+import argparse
+import json
+import math
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--algo", default="auto", choices=["auto", "direct", "bitslice"])
+    ap.add_argument("--sketches", type=int, default=10000, help="sketches at 1 GPU (config 3: 10000)")
+    ap.add_argument("--sketchsize", type=int, default=1024)
+    ap.add_argument("--no-sketch", action="store_true", help="skip the secondary K1 measurement")
+    ap.add_argument("--sketch-genomes", type=int, default=1000)
+    ap.add_argument("--sketch-len", type=int, default=5_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sig_np, cards_np, S, seconds):
+    """The oracle's OpenMP all-pairs (reference loop structure) on a bounded row sample."""
+    from oracle import oracle as O
+    so = None
+    try:   # native build for the box's host CPU; falls back to the portable x86-64-v3 build
+        so = O.build(march="native", out="/tmp/libd2oracle_native.so")
+    except Exception:
+        so = None
+    lib = O.load(so) if so else O.load()
+    import ctypes as C
+    ncores = os.cpu_count() or 1
+    N = sig_np.shape[0]
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    bs = lib.d2o_default_batchsize(0, S, ncores)
+
+    def run(r0, r1):
+        n = sum(N - r - 1 for r in range(r0, r1))
+        out = np.empty(n, np.float32)
+        t0 = time.perf_counter()
+        lib.d2o_allpairs_ut_rows(P(sig_np, C.c_double), P(cards_np, C.c_double), N, S, 0, 31, r0, r1,
+                                 P(out, C.c_float), ncores, bs)
+        return n, time.perf_counter() - t0
+
+    n, dt = run(0, min(N, 2 * ncores))                    # probe
+    rate = n / max(dt, 1e-9)
+    rows = int(min(N, max(2 * ncores, seconds * rate / max(N - 1, 1))))
+    rows = max(ncores, rows // ncores * ncores)
+    n, dt = run(0, min(rows, N))
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "pairs/s", "cores": ncores, "kind": "port",
+            "sample": f"rows [0,{min(rows, N)}) of the same {N}x{S} matrix = {n} pairs in {dt:.2f}s; "
+                      f"oracle OpenMP restatement of emit_rectangular+compare, batch={bs}, "
+                      f"{'-march=native' if so else '-march=x86-64-v3'}; cpu='{model}'"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import dashing2_amd as D
+    from dashing2_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = D.Context(local_rank)
+    algo = {"auto": D.CMP_AUTO, "direct": D.CMP_DIRECT, "bitslice": D.CMP_BITSLICE}[args.algo]
+    S = args.sketchsize
+    N = int(round(args.sketches * math.sqrt(world)))
+    pairs_total = N * (N - 1) // 2
+    bounds = D.ut_partition(N, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    my_pairs = D.ut_count(N, r0, r1)
+
+    # ---- synthetic pre-built sketches (rank 0), resident in HBM before the timed region
+    sig_np = cards_np = None
+    if rank == 0:
+        regs = synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928)
+        sig_np, cards_np = D.oph_finalize(regs, S, nthreads=os.cpu_count() or 1)
+        sig_dev = torch.from_numpy(sig_np.view(np.int64)).to(dev)
+    else:
+        sig_dev = torch.empty((N, S), dtype=torch.int64, device=dev)
+    lut = torch.from_numpy(D.epilogue_lut(S, D.SIMILARITY, 31)).to(dev)
+    out = torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    if world > 1:
+        dist.broadcast(sig_dev, 0)
+    cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
+
+    def step():
+        if world > 1:
+            dist.broadcast(sig_dev, 0)                      # the path's one exchange (RCCL over xGMI)
+        cs.update_dev(sig_dev.data_ptr(), stream)           # transpose + ids + planes (async)
+        cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), r0, r1, stream)   # pair kernel + fused epilogue
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.set_timing(True)
+    ctx.kernel_ms("k2"), ctx.kernel_ms("k2prep")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.set_timing(False)
+    nk2, k2_ms, _ = ctx.kernel_ms("k2")
+    _, prep_ms, _ = ctx.kernel_ms("k2prep")
+    max_distinct, nbits = cs.planes(stream)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = pairs_total / (dt / args.steps)
+
+    # ---- roofline of the dominant kernel (the pair kernel), rank 0's launch
+    alg_bytes = 8 * S * N + 4 * my_pairs          # each sketch read once + one float per pair
+    achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k2_bitslice_kernel" if cs.algo == D.CMP_BITSLICE else "k2_direct_kernel",
+                "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
+                "prep_ms": prep_ms,
+                "note": "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute"}
+    if cs.algo == D.CMP_BITSLICE:
+        ops = my_pairs * ((S + 31) // 32) * (nbits + 1)
+    else:
+        ops = my_pairs * S * 2
+    compute = {"bound": "valu", "unit": "lane-ops/s", "achieved": ops / (k2_ms * 1e-3) if k2_ms > 0 else 0.0,
+               "peak": VALU_PEAK_LANEOPS, "frac": (ops / (k2_ms * 1e-3) / VALU_PEAK_LANEOPS) if k2_ms > 0 else 0.0,
+               "bit_planes": nbits, "max_distinct_per_column": max_distinct}
+
+    # ---- secondary: K1 sketch construction, packed bases resident in HBM
+    sketch = None
+    if not args.no_sketch:
+        n_g, L, k = args.sketch_genomes, args.sketch_len, 31
+        n_g = max(1, n_g // world * world) // world          # genomes are sharded one-per-rank, no collectives
+        Lb = (L + 3) // 4
+        packed = torch.randint(0, 256, (n_g * Lb + 64,), dtype=torch.uint8, device=dev)   # uniform random 2-bit bases
+        run_start = (np.arange(n_g, dtype=np.uint64) * np.uint64(Lb * 4))
+        run_len = np.full(n_g, L, np.uint32)
+        goff = np.arange(n_g + 1, dtype=np.uint64)
+        plan = ctx.oph_plan(run_start, run_len, goff, k)
+        m = D.oph_m(S)
+        regs_dev = torch.empty((n_g, m), dtype=torch.int64, device=dev)
+        for _ in range(2):
+            ctx.oph_sketch_dev(plan, packed.data_ptr(), S, regs_dev.data_ptr(), stream=stream)
+        barrier()
+        ctx.set_timing(True)
+        ctx.kernel_ms("k1")
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.oph_sketch_dev(plan, packed.data_ptr(), S, regs_dev.data_ptr(), stream=stream)
+        barrier()
+        sdt = time.perf_counter() - t0
+        ctx.set_timing(False)
+        _, k1_ms, _ = ctx.kernel_ms("k1")
+        if world > 1:
+            t = torch.tensor([sdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sdt = float(t.item())
+        bases = n_g * L
+        k1_bytes = n_g * (Lb + 8 * m)
+        ach = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        sketch = {"metric": "sketch input bases/s (K1, packed bases resident in HBM)", "value": bases * world / (sdt / reps),
+                  "unit": "bases/s", "ms_per_step": sdt / reps * 1e3,
+                  "config": {"workload": f"{n_g * world} synthetic random genomes x {L} bp, k=31, S={S}, OPH, canonical"},
+                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k1_oph_kernel",
+                               "kernel_ms": k1_ms, "algorithmic_bytes": k1_bytes}}
+        # sanity: a sketch of random bases has no empty bucket and id % m == bucket
+        chk = regs_dev[0].cpu().numpy().view(np.uint64)
+        assert ((chk & np.uint64(m - 1)) == np.arange(m, dtype=np.uint64)).all()
+        del packed, regs_dev
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sig_np, cards_np, S, args.cpu_seconds)
+
+    if rank == 0:
+        line = {
+            "metric": "all-pairs sketch comparison throughput (pairs/s)", "value": value, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config 3 (x sqrt(n_gpus) sketches): {N} pre-built OPH sketches, S={S}, "
+                                   f"all-pairs cmp only, {pairs_total} pairs, float32 Jaccard",
+                       "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if cs.algo == D.CMP_BITSLICE else "direct",
+                       "step": "RCCL broadcast (n_gpus>1) + prepare + pair kernel w/ fused epilogue; inputs resident in HBM",
+                       "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count"},
+            "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "sketch": sketch,
+        }
+        print(json.dumps(line))
+    cs.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

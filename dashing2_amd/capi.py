@@ -1,0 +1,486 @@
+"""ctypes mirror of include/d2g.h.  No computation happens here: every method forwards to the
+C ABI of libd2g.so (HIP kernels + x86 host half).  Missing library => ImportError-like failure,
+never a silent fallback."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libd2g.so")
+_lib = None
+
+SIMILARITY, CONTAINMENT, SYMMETRIC_CONTAINMENT, POISSON_LLR, INTERSECTION, UNION_SIZE = range(6)
+CMP_AUTO, CMP_DIRECT, CMP_BITSLICE = 0, 1, 2
+
+
+class D2GError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        name = lib().d2g_strerror(status).decode() if _lib is not None else str(status)
+        super().__init__(f"d2g error {status} ({name}){': ' + detail if detail else ''}")
+
+
+def build(jobs=8):
+    """Compile libd2g.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", f"-j{jobs}", "-C", os.path.join(_HERE, "csrc")])
+    return LIB_PATH
+
+
+_u64, _sz, _dbl, _int, _f32 = C.c_uint64, C.c_size_t, C.c_double, C.c_int, C.c_float
+_vp, _cp = C.c_void_p, C.c_char_p
+_pu64, _pu32, _pdbl, _pf32, _pu8 = (C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_float), C.POINTER(C.c_uint8))
+
+# name: (restype, argtypes) -- must cover every d2g_* declared in include/d2g.h (tested)
+SIGNATURES = {
+    "d2g_version": (_int, []),
+    "d2g_strerror": (_cp, [_int]),
+    "d2g_device_count": (_int, []),
+    "d2g_ctx_create": (_int, [_int, C.POINTER(_vp)]),
+    "d2g_ctx_destroy": (None, [_vp]),
+    "d2g_last_error": (_cp, [_vp]),
+    "d2g_ctx_device": (_int, [_vp]),
+    "d2g_sync": (_int, [_vp, _vp]),
+    "d2g_malloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "d2g_free": (_int, [_vp, _vp]),
+    "d2g_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "d2g_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz, _vp]),
+    "d2g_set_timing": (_int, [_vp, _int]),
+    "d2g_kernel_ms": (_int, [_vp, _cp, _int, C.POINTER(_int), C.POINTER(_f32), C.POINTER(_f32)]),
+    "d2g_wang_hash": (_u64, [_u64]),
+    "d2g_seed_mask": (_u64, [_u64]),
+    "d2g_oph_xor_const": (_u64, []),
+    "d2g_oph_m": (_sz, [_sz]),
+    "d2g_oph_card": (_dbl, [_pu64, _sz]),
+    "d2g_oph_signatures": (_int, [_pu64, _sz, _pdbl]),
+    "d2g_oph_finalize": (_int, [_pu64, _sz, _sz, _sz, _pdbl, _pdbl, _int]),
+    "d2g_densify": (_int, [_pdbl, _sz, _sz, C.POINTER(_sz), _int]),
+    "d2g_epilogue_gtlt": (_f32, [_u64, _u64, _sz, _dbl, _dbl, _int, _int]),
+    "d2g_epilogue_neq": (_f32, [_u64, _sz, _dbl, _dbl, _int, _int]),
+    "d2g_epilogue_lut": (_int, [_sz, _int, _int, _int, _pf32]),
+    "d2g_seqpack_create": (_int, [_int, C.POINTER(_vp)]),
+    "d2g_seqpack_destroy": (None, [_vp]),
+    "d2g_seqpack_add_path": (_int, [_vp, _cp]),
+    "d2g_seqpack_add_fastx": (_int, [_vp, _cp, _sz]),
+    "d2g_seqpack_add_sequence": (_int, [_vp, _cp, _sz]),
+    "d2g_seqpack_ngenomes": (_sz, [_vp]),
+    "d2g_seqpack_nruns": (_sz, [_vp]),
+    "d2g_seqpack_packed_bytes": (_sz, [_vp]),
+    "d2g_seqpack_packed": (_pu8, [_vp]),
+    "d2g_seqpack_run_start": (_pu64, [_vp]),
+    "d2g_seqpack_run_len": (_pu32, [_vp]),
+    "d2g_seqpack_genome_run_off": (_pu64, [_vp]),
+    "d2g_seqpack_nkmers": (_u64, [_vp, _sz]),
+    "d2g_seqpack_nbases": (_u64, [_vp]),
+    "d2g_oph_sketch": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, _vp]),
+    "d2g_oph_plan_create": (_int, [_vp, _vp, _vp, _sz, _vp, _sz, _int, C.POINTER(_vp)]),
+    "d2g_oph_plan_destroy": (None, [_vp]),
+    "d2g_oph_plan_nkmers": (_u64, [_vp]),
+    "d2g_oph_plan_nbases": (_u64, [_vp]),
+    "d2g_oph_sketch_dev": (_int, [_vp, _vp, _vp, _int, _u64, _sz, _vp, _vp]),
+    "d2g_ut_count": (_sz, [_sz, _sz, _sz]),
+    "d2g_cmp_set_create_dev": (_int, [_vp, _vp, _sz, _sz, _int, _vp, C.POINTER(_vp)]),
+    "d2g_cmp_set_create": (_int, [_vp, _vp, _sz, _sz, _int, C.POINTER(_vp)]),
+    "d2g_cmp_set_update_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int)]),
+    "d2g_cmp_set_destroy": (None, [_vp]),
+    "d2g_cmp_set_algo": (_int, [_vp]),
+    "d2g_cmp_eqcount_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "d2g_cmp_lut_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "d2g_cmp_gtlt_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "d2g_cmp_eqcount_rect_dev": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    "d2g_cmp_eqcount_ut": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _int, _vp]),
+    "d2g_cmp_dist_ut": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _int, _int, _int, _int, _int, _vp]),
+    "d2g_ut_partition": (_int, [_sz, _int, C.POINTER(_sz)]),
+}
+
+
+def lib():
+    """Load libd2g.so (once).  Raises if the extension has not been built: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(dashing2_amd has no CPU fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def _np_ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+# ---------------------------------------------------------------- host-side primitives
+def wang_hash(x):
+    return int(lib().d2g_wang_hash(x & 0xFFFFFFFFFFFFFFFF))
+
+
+def seed_mask(seed):
+    return int(lib().d2g_seed_mask(seed))
+
+
+def oph_xor_const():
+    return int(lib().d2g_oph_xor_const())
+
+
+def oph_m(S):
+    return int(lib().d2g_oph_m(S))
+
+
+def oph_finalize(regs, S, nthreads=1):
+    """regs u64 [n][m] -> (sigs f64 [n][S], cards f64 [n])  (x87 host arithmetic in libd2g)"""
+    regs = np.ascontiguousarray(regs, np.uint64)
+    n, m = regs.shape
+    sigs = np.empty((n, S), np.float64)
+    cards = np.empty(n, np.float64)
+    rc = lib().d2g_oph_finalize(regs.ctypes.data_as(_pu64), n, m, S, sigs.ctypes.data_as(_pdbl),
+                                cards.ctypes.data_as(_pdbl), nthreads)
+    if rc:
+        raise D2GError(rc)
+    return sigs, cards
+
+
+def densify(sigs, nthreads=1):
+    sigs = np.ascontiguousarray(sigs, np.float64).copy()
+    n, S = sigs.shape
+    nf = _sz()
+    rc = lib().d2g_densify(sigs.ctypes.data_as(_pdbl), n, S, C.byref(nf), nthreads)
+    if rc:
+        raise D2GError(rc)
+    return sigs, nf.value
+
+
+def epilogue_lut(S, measure=SIMILARITY, k=31, multiset_space=False):
+    lut = np.empty(S + 1, np.float32)
+    rc = lib().d2g_epilogue_lut(S, measure, k, int(multiset_space), lut.ctypes.data_as(_pf32))
+    if rc:
+        raise D2GError(rc)
+    return lut
+
+
+def epilogue_gtlt(gt, lt, S, lhc, rhc, measure=SIMILARITY, k=31):
+    return float(lib().d2g_epilogue_gtlt(gt, lt, S, lhc, rhc, measure, k))
+
+
+def epilogue_neq(neq, S, lhc, rhc, measure=SIMILARITY, k=31):
+    return float(lib().d2g_epilogue_neq(neq, S, lhc, rhc, measure, k))
+
+
+def ut_count(N, r0=0, r1=None):
+    return int(lib().d2g_ut_count(N, r0, N if r1 is None else r1))
+
+
+def ut_partition(N, nparts):
+    b = (_sz * (nparts + 1))()
+    rc = lib().d2g_ut_partition(N, nparts, b)
+    if rc:
+        raise D2GError(rc)
+    return [int(x) for x in b]
+
+
+# ---------------------------------------------------------------- ingest
+class SeqPack:
+    """FASTA/FASTQ -> packed run stream (d2g_seqpack_*)."""
+
+    def __init__(self, k):
+        self.k = k
+        self._h = None
+        h = _vp()
+        rc = lib().d2g_seqpack_create(k, C.byref(h))
+        if rc:
+            raise D2GError(rc)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().d2g_seqpack_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def add_path(self, path):
+        rc = lib().d2g_seqpack_add_path(self._h, os.fsencode(path))
+        if rc:
+            raise D2GError(rc, str(path))
+
+    def add_fastx(self, data: bytes):
+        rc = lib().d2g_seqpack_add_fastx(self._h, data, len(data))
+        if rc:
+            raise D2GError(rc)
+
+    def add_sequence(self, seq: bytes):
+        rc = lib().d2g_seqpack_add_sequence(self._h, seq, len(seq))
+        if rc:
+            raise D2GError(rc)
+
+    @property
+    def ngenomes(self):
+        return int(lib().d2g_seqpack_ngenomes(self._h))
+
+    @property
+    def nruns(self):
+        return int(lib().d2g_seqpack_nruns(self._h))
+
+    @property
+    def nbases(self):
+        return int(lib().d2g_seqpack_nbases(self._h))
+
+    def nkmers(self, g):
+        return int(lib().d2g_seqpack_nkmers(self._h, g))
+
+    def arrays(self):
+        """-> (packed u8, run_start u64, run_len u32, genome_run_off u64) as numpy copies"""
+        l = lib()
+        nb = l.d2g_seqpack_packed_bytes(self._h)
+        nr, ng = self.nruns, self.ngenomes
+        packed = np.ctypeslib.as_array(l.d2g_seqpack_packed(self._h), shape=(nb,)).copy()
+        rs = np.ctypeslib.as_array(l.d2g_seqpack_run_start(self._h), shape=(nr,)).copy() if nr else np.empty(0, np.uint64)
+        rl = np.ctypeslib.as_array(l.d2g_seqpack_run_len(self._h), shape=(nr,)).copy() if nr else np.empty(0, np.uint32)
+        go = np.ctypeslib.as_array(l.d2g_seqpack_genome_run_off(self._h), shape=(ng + 1,)).copy()
+        return packed, rs, rl, go
+
+
+# ---------------------------------------------------------------- device context
+class Context:
+    """One GPU (d2g_ctx).  Raises D2GError when no gfx950 device is usable."""
+
+    def __init__(self, device=0):
+        self._h = None
+        h = _vp()
+        rc = lib().d2g_ctx_create(device, C.byref(h))
+        if rc:
+            raise D2GError(rc, f"d2g_ctx_create(device={device})")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().d2g_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc:
+            raise D2GError(rc, lib().d2g_last_error(self._h).decode())
+
+    def sync(self, stream=None):
+        self._check(lib().d2g_sync(self._h, stream))
+
+    def set_timing(self, on=True):
+        self._check(lib().d2g_set_timing(self._h, int(on)))
+
+    def kernel_ms(self, which, reset=True):
+        """-> (count, avg_ms, last_ms) of the launches logged since the last reset"""
+        n, avg, last = _int(), _f32(), _f32()
+        self._check(lib().d2g_kernel_ms(self._h, which.encode(), int(reset), C.byref(n), C.byref(avg), C.byref(last)))
+        return int(n.value), float(avg.value), float(last.value)
+
+    # -- K1 ------------------------------------------------------------------
+    def oph_sketch(self, packed, run_start, run_len, genome_run_off, k, S, canon=True, xormask=0):
+        """host arrays -> regs u64 [n][m]"""
+        packed = np.ascontiguousarray(packed, np.uint8)
+        run_start = np.ascontiguousarray(run_start, np.uint64)
+        run_len = np.ascontiguousarray(run_len, np.uint32)
+        genome_run_off = np.ascontiguousarray(genome_run_off, np.uint64)
+        n = genome_run_off.size - 1
+        m = oph_m(S)
+        regs = np.empty((n, m), np.uint64)
+        self._check(lib().d2g_oph_sketch(self._h, _np_ptr(packed), packed.size, _np_ptr(run_start), _np_ptr(run_len),
+                                         run_start.size, _np_ptr(genome_run_off), n, k, int(canon), xormask, S,
+                                         _np_ptr(regs)))
+        return regs
+
+    def oph_sketch_seqpack(self, sp: SeqPack, S, canon=True, xormask=0):
+        packed, rs, rl, go = sp.arrays()
+        return self.oph_sketch(packed, rs, rl, go, sp.k, S, canon, xormask)
+
+    def oph_plan(self, run_start, run_len, genome_run_off, k):
+        run_start = np.ascontiguousarray(run_start, np.uint64)
+        run_len = np.ascontiguousarray(run_len, np.uint32)
+        genome_run_off = np.ascontiguousarray(genome_run_off, np.uint64)
+        h = _vp()
+        self._check(lib().d2g_oph_plan_create(self._h, _np_ptr(run_start), _np_ptr(run_len), run_start.size,
+                                              _np_ptr(genome_run_off), genome_run_off.size - 1, k, C.byref(h)))
+        return OphPlan(self, h, genome_run_off.size - 1)
+
+    def oph_sketch_dev(self, plan, packed_dev_ptr, S, regs_dev_ptr, canon=True, xormask=0, stream=None):
+        self._check(lib().d2g_oph_sketch_dev(self._h, plan._h, packed_dev_ptr, int(canon), xormask, S, regs_dev_ptr, stream))
+
+    # -- K2 ------------------------------------------------------------------
+    def cmp_set(self, sig_bits_host, algo=CMP_AUTO):
+        a = np.ascontiguousarray(sig_bits_host)
+        assert a.dtype.itemsize == 8 and a.ndim == 2
+        h = _vp()
+        self._check(lib().d2g_cmp_set_create(self._h, _np_ptr(a), a.shape[0], a.shape[1], algo, C.byref(h)))
+        return CmpSet(self, h, a.shape[0], a.shape[1])
+
+    def cmp_set_dev(self, dev_ptr, N, S, algo=CMP_AUTO, stream=None):
+        h = _vp()
+        self._check(lib().d2g_cmp_set_create_dev(self._h, dev_ptr, N, S, algo, stream, C.byref(h)))
+        return CmpSet(self, h, N, S)
+
+    def cmp_eqcount_ut(self, sig_bits_host, r0=0, r1=None, algo=CMP_AUTO):
+        a = np.ascontiguousarray(sig_bits_host)
+        assert a.dtype.itemsize == 8 and a.ndim == 2
+        N, S = a.shape
+        r1 = N if r1 is None else r1
+        out = np.empty(ut_count(N, r0, r1), np.uint32)
+        self._check(lib().d2g_cmp_eqcount_ut(self._h, _np_ptr(a), N, S, r0, r1, algo, _np_ptr(out)))
+        return out
+
+    def cmp_dist_ut(self, sig_bits_host, cards, measure=SIMILARITY, k=31, multiset_space=False, r0=0, r1=None,
+                    algo=CMP_AUTO, nthreads=1):
+        a = np.ascontiguousarray(sig_bits_host)
+        assert a.dtype.itemsize == 8 and a.ndim == 2
+        cards = np.ascontiguousarray(cards, np.float64)
+        N, S = a.shape
+        r1 = N if r1 is None else r1
+        out = np.empty(ut_count(N, r0, r1), np.float32)
+        self._check(lib().d2g_cmp_dist_ut(self._h, _np_ptr(a), _np_ptr(cards), N, S, r0, r1, measure, k,
+                                          int(multiset_space), algo, nthreads, _np_ptr(out)))
+        return out
+
+    # -- raw device memory (tests / bench without torch) ------------------------
+    def malloc(self, nbytes):
+        p = _vp()
+        self._check(lib().d2g_malloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        self._check(lib().d2g_free(self._h, ptr))
+
+    def h2d(self, dptr, arr, stream=None):
+        arr = np.ascontiguousarray(arr)
+        self._check(lib().d2g_memcpy_h2d(self._h, dptr, _np_ptr(arr), arr.nbytes, stream))
+
+    def d2h(self, arr, dptr, stream=None):
+        assert arr.flags["C_CONTIGUOUS"]
+        self._check(lib().d2g_memcpy_d2h(self._h, _np_ptr(arr), dptr, arr.nbytes, stream))
+
+
+class OphPlan:
+    def __init__(self, ctx, h, n):
+        self.ctx, self._h, self.n = ctx, h, n
+
+    @property
+    def nkmers(self):
+        return int(lib().d2g_oph_plan_nkmers(self._h))
+
+    @property
+    def nbases(self):
+        return int(lib().d2g_oph_plan_nbases(self._h))
+
+    def close(self):
+        if self._h:
+            lib().d2g_oph_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class CmpSet:
+    """Device-resident prepared signature matrix (d2g_cmp_set)."""
+
+    def __init__(self, ctx, h, N, S):
+        self.ctx, self._h, self.N, self.S = ctx, h, N, S
+
+    @property
+    def algo(self):
+        return int(lib().d2g_cmp_set_algo(self._h))
+
+    def close(self):
+        if self._h:
+            lib().d2g_cmp_set_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def update_dev(self, dev_ptr, stream=None):
+        self.ctx._check(lib().d2g_cmp_set_update_dev(self.ctx._h, self._h, dev_ptr, stream))
+
+    def planes(self, stream=None):
+        """-> (max distinct values per register column, live bit planes); (0, 0) for a DIRECT set"""
+        md, nb = C.c_uint(), _int()
+        self.ctx._check(lib().d2g_cmp_set_planes(self.ctx._h, self._h, stream, C.byref(md), C.byref(nb)))
+        return int(md.value), int(nb.value)
+
+    def eqcount_ut_dev(self, out_dev_ptr, r0=0, r1=None, stream=None):
+        r1 = self.N if r1 is None else r1
+        self.ctx._check(lib().d2g_cmp_eqcount_ut_dev(self.ctx._h, self._h, r0, r1, out_dev_ptr, stream))
+
+    def lut_ut_dev(self, lut_dev_ptr, out_dev_ptr, r0=0, r1=None, stream=None):
+        r1 = self.N if r1 is None else r1
+        self.ctx._check(lib().d2g_cmp_lut_ut_dev(self.ctx._h, self._h, r0, r1, lut_dev_ptr, out_dev_ptr, stream))
+
+    def gtlt_ut_dev(self, gt_dev_ptr, lt_dev_ptr, r0=0, r1=None, stream=None):
+        r1 = self.N if r1 is None else r1
+        self.ctx._check(lib().d2g_cmp_gtlt_ut_dev(self.ctx._h, self._h, r0, r1, gt_dev_ptr, lt_dev_ptr, stream))
+
+    def eqcount_rect_dev(self, out_dev_ptr, a0, a1, b0, b1, stream=None):
+        self.ctx._check(lib().d2g_cmp_eqcount_rect_dev(self.ctx._h, self._h, a0, a1, b0, b1, out_dev_ptr, stream))
+
+    # host-returning helpers built on the raw device-memory calls
+    def eqcount_ut(self, r0=0, r1=None):
+        r1 = self.N if r1 is None else r1
+        out = np.empty(ut_count(self.N, r0, r1), np.uint32)
+        if out.size == 0:
+            return out
+        d = self.ctx.malloc(out.nbytes)
+        try:
+            self.eqcount_ut_dev(d, r0, r1)
+            self.ctx.d2h(out, d)
+        finally:
+            self.ctx.free(d)
+        return out
+
+    def gtlt_ut(self, r0=0, r1=None):
+        r1 = self.N if r1 is None else r1
+        n = ut_count(self.N, r0, r1)
+        gt, lt = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        if n == 0:
+            return gt, lt
+        dg, dl = self.ctx.malloc(gt.nbytes), self.ctx.malloc(lt.nbytes)
+        try:
+            self.gtlt_ut_dev(dg, dl, r0, r1)
+            self.ctx.d2h(gt, dg)
+            self.ctx.d2h(lt, dl)
+        finally:
+            self.ctx.free(dg)
+            self.ctx.free(dl)
+        return gt, lt
+
+    def eqcount_rect(self, a0, a1, b0, b1):
+        out = np.empty((a1 - a0, b1 - b0), np.uint32)
+        if out.size == 0:
+            return out
+        d = self.ctx.malloc(out.nbytes)
+        try:
+            self.eqcount_rect_dev(d, a0, a1, b0, b1)
+            self.ctx.d2h(out, d)
+        finally:
+            self.ctx.free(d)
+        return out
+
+    def lut_ut(self, lut, r0=0, r1=None):
+        r1 = self.N if r1 is None else r1
+        lut = np.ascontiguousarray(lut, np.float32)
+        out = np.empty(ut_count(self.N, r0, r1), np.float32)
+        if out.size == 0:
+            return out
+        dl, d = self.ctx.malloc(lut.nbytes), self.ctx.malloc(out.nbytes)
+        try:
+            self.ctx.h2d(dl, lut)
+            self.lut_ut_dev(dl, d, r0, r1)
+            self.ctx.d2h(out, d)
+        finally:
+            self.ctx.free(dl)
+            self.ctx.free(d)
+        return out

@@ -1,0 +1,466 @@
+// d2g_host.cpp -- x86 host half of libd2g: the O(S) / O(pairs) scalar arithmetic of the
+// path that must stay on the host to be bit-exact with the reference (x87 long double),
+// plus the FASTX -> packed-run-stream ingest.  Compiled with g++ (not hipcc) so that
+// `long double` is the 80-bit x87 type the reference's gcc build uses.
+//
+// Reference lines restated here are cited per function.
+#include "../../include/d2g.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <vector>
+#include <zlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+extern "C" {
+
+int d2g_version(void) { return D2G_VERSION_MAJOR * 1000 + D2G_VERSION_MINOR; }
+
+const char *d2g_strerror(int st) {
+    switch (st) {
+        case D2G_OK: return "ok";
+        case D2G_ERR_INVALID: return "invalid argument";
+        case D2G_ERR_NODEVICE: return "no usable HIP (gfx950) device";
+        case D2G_ERR_HIP: return "HIP runtime error";
+        case D2G_ERR_NOMEM: return "out of memory";
+        case D2G_ERR_UNSUPPORTED: return "unsupported configuration for the MI355X hot path";
+        case D2G_ERR_IO: return "I/O error";
+        default: return "unknown d2g status";
+    }
+}
+
+// sketch::hash::WangHash::hash (absent third-party source; Thomas Wang's published 64-bit mix).
+// Reference call sites: enums.h:138 (maskfn), oph.h:49 (BHasher).
+uint64_t d2g_wang_hash(uint64_t k) {
+    k = ~k + (k << 21);
+    k ^= k >> 24;
+    k = k + (k << 3) + (k << 8);
+    k ^= k >> 14;
+    k = k + (k << 2) + (k << 4);
+    k ^= k >> 28;
+    k += k << 31;
+    return k;
+}
+
+// enums.cpp:133-139
+uint64_t d2g_seed_mask(uint64_t seedseed) { return seedseed ? d2g_wang_hash(seedseed) : 0; }
+
+// oph.h:59 seed_ = std::mt19937_64(x)(), oph.h:142 x = 0x321b919a61cb41f7, oph.h:46 CEIXOR constant
+uint64_t d2g_oph_xor_const(void) {
+    static const uint64_t c = std::mt19937_64(0x321b919a61cb41f7ull)() ^ 0x533f8c2151b20f97ull;
+    return c;
+}
+
+size_t d2g_oph_m(size_t S) { return S + (S & 1); }   // oph.h:143-146
+
+// oph.h:240-247
+double d2g_oph_card(const uint64_t *regs, size_t m) {
+    long double sum = 0.L;
+    for (size_t i = 0; i < m; ++i) sum += regs[i] * 0x1p-64L;
+    if (!sum) return std::numeric_limits<double>::infinity();
+    return m * (m / sum);
+}
+
+// oph.h:248-263
+int d2g_oph_signatures(const uint64_t *regs, size_t m, double *sig) {
+    if (!regs || !sig) return D2G_ERR_INVALID;
+    constexpr uint64_t MAXV = std::numeric_limits<uint64_t>::max();
+    const size_t nmax = std::count(regs, regs + m, MAXV);
+    const long double mul = -double(1) / (m - nmax);          // double division, then widened
+    for (size_t i = 0; i < m; ++i) {
+        const uint64_t x = regs[i];
+        sig[i] = (x == MAXV || x == 0) ? 0. : double(mul * std::log(0x1p-64L * (MAXV - x + 1)));
+    }
+    return D2G_OK;
+}
+
+int d2g_oph_finalize(const uint64_t *regs, size_t n, size_t m, size_t S, double *sigs, double *cards, int nthreads) {
+    if (!regs || !sigs || !cards || S > m) return D2G_ERR_INVALID;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+    #pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        std::vector<double> tmp(m);
+#ifdef _OPENMP
+        #pragma omp for schedule(static)
+#endif
+        for (size_t g = 0; g < n; ++g) {
+            const uint64_t *r = regs + g * m;
+            cards[g] = d2g_oph_card(r, m);                      // fastxsketch.cpp:567
+            d2g_oph_signatures(r, m, tmp.data());               // fastxsketch.cpp:586
+            std::memcpy(sigs + g * S, tmp.data(), S * sizeof(double));  // :605,:610 (first S only)
+        }
+    }
+    return D2G_OK;
+}
+
+// ssi.h:26-36 (in-tree twin of wy::wyhash64_stateless used at cmp_core.cpp:597)
+static inline uint64_t wyhash64_stateless(uint64_t *seed) {
+    *seed += 0x60bee2bee120fc15ull;
+    __uint128_t l = *seed ^ 0xe7037ed1a0b428dbull;
+    l *= *seed;
+    return uint64_t(l ^ (l >> 64));
+}
+
+// cmp_core.cpp:577-613
+static size_t densify_one(double *sig, size_t S, std::vector<double> &tmp) {
+    if (size_t(std::count(sig, sig + S, 0.)) == S) return S;
+    size_t ne = 0;
+    tmp.assign(sig, sig + S);
+    for (size_t i = 0; i < S; ++i) {
+        if (sig[i] != 0.) continue;
+        ++ne;
+        uint64_t rng = i + 0x5bf2b8bdf07c06cull, j;
+        do j = wyhash64_stateless(&rng) % S; while (sig[j] == 0.);
+        tmp[i] = sig[j];
+    }
+    std::copy(tmp.begin(), tmp.end(), sig);
+    return ne;
+}
+
+int d2g_densify(double *sigs, size_t n, size_t S, size_t *nfilled, int nthreads) {
+    if (!sigs || !S) return D2G_ERR_INVALID;
+    if (nthreads < 1) nthreads = 1;
+    size_t total = 0;
+#ifdef _OPENMP
+    #pragma omp parallel num_threads(nthreads) reduction(+:total)
+#endif
+    {
+        std::vector<double> tmp;
+#ifdef _OPENMP
+        #pragma omp for schedule(dynamic, 32)                   // cmp_core.cpp:707
+#endif
+        for (size_t i = 0; i < n; ++i) total += densify_one(sigs + i * S, S, tmp);
+    }
+    if (nfilled) *nfilled = total;
+    return D2G_OK;
+}
+
+// cmp_core.cpp:361
+static inline double sim2dist_f(float x, int k) {
+    const double pm = -1. / std::max(1, k);
+    return x ? std::log(2. * x / (1. + x)) * pm : std::numeric_limits<double>::infinity();
+}
+// cmp_core.cpp:573-575
+static inline float finish(long double ret) {
+    if (std::isnan(ret) || std::isinf(ret)) ret = std::numeric_limits<long double>::max();
+    return float(ret);
+}
+
+// cmp_core.cpp:458-494
+float d2g_epilogue_gtlt(uint64_t gt, uint64_t lt, size_t S, double lhc, double rhc, int measure, int k) {
+    long double ret = std::numeric_limits<float>::max();
+    const long double invdenom = 1.L / S;
+    const long double alpha = gt * invdenom, beta = lt * invdenom;
+    const long double lhcard = lhc, rhcard = rhc;
+    long double eq = (1. - alpha - beta);
+    const long double ucard = std::max((lhcard + rhcard) / (2.L - alpha - beta), 0.L);
+    if (eq <= 0.)
+        return measure != D2G_POISSON_LLR ? 0.f : std::numeric_limits<float>::infinity();
+    static constexpr long double EPS = 1e-15;
+    if (eq <= EPS) eq = 0;
+    const float isz = ucard * eq, sim = eq;
+    switch (measure) {
+        case D2G_SIMILARITY: ret = sim; break;
+        case D2G_INTERSECTION: ret = isz; break;
+        case D2G_CONTAINMENT: ret = isz / rhcard; break;
+        case D2G_SYMMETRIC_CONTAINMENT: ret = isz / std::min(lhcard, rhcard); break;
+        case D2G_POISSON_LLR: ret = sim2dist_f(sim, k); break;
+        case D2G_UNION_SIZE: ret = lhcard + rhcard - isz; break;
+        default: ret = -1.f; break;
+    }
+    return finish(ret);
+}
+
+// cmp_core.cpp:495-517
+float d2g_epilogue_neq(uint64_t neq, size_t S, double lhc, double rhc, int measure, int k) {
+    const long double lhcard = lhc, rhcard = rhc, invdenom = 1.L / S;
+    long double ret = invdenom * neq;
+    auto ucard = [&]() { return std::max((lhcard + rhcard) / (1.L + ret), 0.L); };
+    if (measure == D2G_INTERSECTION) ret *= ucard();
+    else if (measure == D2G_SYMMETRIC_CONTAINMENT) ret *= ucard() / std::min(lhcard, rhcard);
+    else if (measure == D2G_CONTAINMENT) ret *= ucard() / lhcard;
+    else if (measure == D2G_POISSON_LLR) {
+        const double pm = -1. / std::max(1, k);
+        // sim2dist(auto x) with x = long double: logl and the product in x87, lambda returns double
+        ret = ret ? double(std::log(2. * ret / (1. + ret)) * pm) : std::numeric_limits<double>::infinity();
+    } else if (measure == D2G_UNION_SIZE) {
+        const long double isz = ret * ucard();
+        ret = lhcard + rhcard - isz;
+    }
+    return finish(ret);
+}
+
+int d2g_epilogue_lut(size_t S, int measure, int k, int multiset_space, float *lut) {
+    if (!lut || !S) return D2G_ERR_INVALID;
+    if (measure != D2G_SIMILARITY && measure != D2G_POISSON_LLR) return D2G_ERR_UNSUPPORTED;
+    if (multiset_space) {
+        for (size_t e = 0; e <= S; ++e) lut[e] = d2g_epilogue_neq(e, S, 1., 1., measure, k);
+        return D2G_OK;
+    }
+    // set space: the value is a function of gt and lt; it depends on gt+lt only when every
+    // product gt * (1.L/S) is exact, i.e. S is a power of two.
+    if (S & (S - 1)) return D2G_ERR_UNSUPPORTED;
+    for (size_t e = 0; e <= S; ++e) lut[e] = d2g_epilogue_gtlt(S - e, 0, S, 1., 1., measure, k);
+    return D2G_OK;
+}
+
+// epilogue over rows [r0,r1) of the condensed upper triangle from the device's integer counts.
+// ca = neq (or gt when cb != null), cb = lt.  Same arithmetic as compare(): cmp_core.cpp:458-517.
+void d2g_host_epilogue_ut(const uint32_t *ca, const uint32_t *cb, const double *cards, size_t N, size_t S,
+                          size_t r0, size_t r1, int measure, int k, int multiset_space, int nthreads, float *out) {
+    std::vector<size_t> off(r1 - r0 + 1, 0);
+    for (size_t i = r0; i < r1; ++i) off[i - r0 + 1] = off[i - r0] + (N - 1 - i);
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+    #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+    for (size_t i = r0; i < r1; ++i) {
+        const size_t base = off[i - r0];
+        for (size_t j = i + 1; j < N; ++j) {
+            const size_t p = base + (j - i - 1);
+            if (multiset_space) out[p] = d2g_epilogue_neq(ca[p], S, cards[i], cards[j], measure, k);
+            else if (cb) out[p] = d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], measure, k);
+            // power-of-two S: every multiple of 1/S is exact, so only gt+lt = S-neq matters
+            else out[p] = d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], measure, k);
+        }
+    }
+}
+
+size_t d2g_ut_count(size_t N, size_t r0, size_t r1) {
+    if (r1 > N) r1 = N;
+    if (r0 >= r1) return 0;
+    // sum_{r=r0}^{r1-1} (N-1-r)
+    const size_t n = r1 - r0;
+    const size_t tri1 = r1 * (r1 - 1) / 2, tri0 = r0 ? r0 * (r0 - 1) / 2 : 0;
+    return n * (N - 1) - (tri1 - tri0);
+}
+
+int d2g_ut_partition(size_t N, int nparts, size_t *bounds) {
+    if (nparts < 1 || !bounds) return D2G_ERR_INVALID;
+    const long double total = N ? (long double)N * (N - 1) / 2 : 0;
+    bounds[0] = 0;
+    size_t r = 0;
+    for (int p = 1; p < nparts; ++p) {
+        const long double target = total * p / nparts;
+        // pairs in rows [0,r) = r*(N-1) - r(r-1)/2 ; advance to the first r reaching the target
+        while (r < N && (long double)r * (N - 1) - (long double)r * (r - 1) / 2 < target) ++r;
+        bounds[p] = r;
+    }
+    bounds[nparts] = N;
+    return D2G_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// FASTX ingest -> packed run stream
+// ---------------------------------------------------------------------------
+struct d2g_seqpack {
+    int k;
+    std::vector<uint8_t> packed;       // 4 bases / byte
+    uint64_t nbases = 0;               // bases appended to the stream
+    std::vector<uint64_t> run_start;
+    std::vector<uint32_t> run_len;
+    std::vector<uint64_t> genome_run_off{0};
+    std::vector<uint64_t> genome_nkmers;
+    // open run state
+    uint64_t cur_start = 0, cur_len = 0;
+    uint64_t cur_kmers = 0;
+    uint8_t  accum = 0;                // partially filled byte lives in packed.back()
+    bool padded = false;
+
+    static constexpr uint32_t MAX_RUN = 1u << 30;
+
+    inline void push_base(unsigned code) {
+        const unsigned sh = (nbases & 3) * 2;
+        if (sh == 0) packed.push_back(uint8_t(code));
+        else packed.back() |= uint8_t(code << sh);
+        ++nbases;
+    }
+    // bases of a run shorter than k are useless: rewind the stream over them
+    inline void rewind_to(uint64_t nb) {
+        nbases = nb;
+        packed.resize((nb + 3) / 4);
+        if (nb & 3) packed.back() &= uint8_t((1u << ((nb & 3) * 2)) - 1);
+    }
+    void close_run() {
+        if (cur_len >= uint64_t(k)) {
+            // split very long runs; pieces overlap by k-1 bases in place
+            uint64_t s = cur_start, left = cur_len;
+            while (left > MAX_RUN) {
+                run_start.push_back(s); run_len.push_back(MAX_RUN);
+                const uint64_t adv = MAX_RUN - (k - 1);
+                s += adv; left -= adv;
+            }
+            run_start.push_back(s); run_len.push_back(uint32_t(left));
+            cur_kmers += cur_len - k + 1;
+        } else if (cur_len) {
+            rewind_to(cur_start);
+        }
+        cur_len = 0;
+    }
+    inline void feed(const char *s, size_t n) {
+        static const int8_t *lut = code_lut();
+        for (size_t i = 0; i < n; ++i) {
+            const int c = lut[(unsigned char)s[i]];
+            if (c < 0) { if (cur_len) close_run(); continue; }
+            if (!cur_len) cur_start = nbases;
+            push_base(unsigned(c));
+            ++cur_len;
+        }
+    }
+    void end_record() { if (cur_len) close_run(); }
+    void end_genome() {
+        end_record();
+        genome_run_off.push_back(run_start.size());
+        genome_nkmers.push_back(cur_kmers);
+        cur_kmers = 0;
+    }
+    static const int8_t *code_lut() {
+        static int8_t t[256];
+        static bool init = false;
+        if (!init) {
+            std::memset(t, -1, sizeof(t));
+            t['A'] = t['a'] = 0; t['C'] = t['c'] = 1; t['G'] = t['g'] = 2; t['T'] = t['t'] = 3;
+            init = true;
+        }
+        return t;
+    }
+    // kseq-style record walk over an in-memory FASTA/FASTQ buffer
+    void feed_fastx(const char *buf, size_t len) {
+        size_t pos = 0;
+        auto skip_line = [&]() {
+            const char *nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
+            pos = nl ? size_t(nl - buf) + 1 : len;
+        };
+        while (pos < len && buf[pos] != '>' && buf[pos] != '@') skip_line();
+        while (pos < len) {
+            skip_line();                                   // header
+            size_t seqlen = 0;
+            int c = -1;
+            while (pos < len) {
+                c = (unsigned char)buf[pos];
+                if (c == '>' || c == '+' || c == '@') break;
+                const char *nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
+                const size_t e = nl ? size_t(nl - buf) : len;
+                size_t ll = e - pos;
+                if (ll && buf[pos + ll - 1] == '\r') --ll;
+                feed(buf + pos, ll);
+                seqlen += ll;
+                pos = nl ? e + 1 : len;
+                c = -1;
+            }
+            end_record();
+            if (pos < len && c == '+') {
+                skip_line();
+                size_t ql = 0;
+                while (pos < len && ql < seqlen) {
+                    const char *nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
+                    const size_t e = nl ? size_t(nl - buf) : len;
+                    size_t ll = e - pos;
+                    if (ll && buf[pos + ll - 1] == '\r') --ll;
+                    ql += ll;
+                    pos = nl ? e + 1 : len;
+                }
+                while (pos < len && buf[pos] != '>' && buf[pos] != '@') skip_line();
+            }
+        }
+    }
+    void finalize_pad() {
+        if (padded) return;
+        packed.resize((nbases + 3) / 4 + 64, 0);
+        padded = true;
+    }
+    void unpad() {
+        if (!padded) return;
+        packed.resize((nbases + 3) / 4);
+        padded = false;
+    }
+};
+
+static bool slurp_gz(const char *path, std::vector<char> &out) {
+    gzFile fp = gzopen(path, "rb");
+    if (!fp) return false;
+    gzbuffer(fp, 1 << 20);
+    out.clear();
+    size_t len = 0;
+    for (;;) {
+        if (out.size() - len < (1u << 20)) out.resize(std::max<size_t>(out.size() * 2, 1u << 22));
+        const int n = gzread(fp, out.data() + len, unsigned(std::min<size_t>(out.size() - len, 1u << 30)));
+        if (n <= 0) break;
+        len += size_t(n);
+    }
+    gzclose(fp);
+    out.resize(len);
+    return true;
+}
+
+extern "C" {
+
+int d2g_seqpack_create(int k, d2g_seqpack **out) {
+    if (!out) return D2G_ERR_INVALID;
+    if (k < 1 || k > 32) return D2G_ERR_UNSUPPORTED;   // k > 32 is the reference's rolling-hash path (fastxsketch.cpp:420)
+    auto *sp = new (std::nothrow) d2g_seqpack();
+    if (!sp) return D2G_ERR_NOMEM;
+    sp->k = k;
+    *out = sp;
+    return D2G_OK;
+}
+void d2g_seqpack_destroy(d2g_seqpack *sp) { delete sp; }
+
+int d2g_seqpack_add_path(d2g_seqpack *sp, const char *line) {
+    if (!sp || !line) return D2G_ERR_INVALID;
+    sp->unpad();
+    // d2.h:52-71 for_each_substr: space-separated sub-paths feed one sketch
+    std::string s(line);
+    size_t b = 0;
+    std::vector<char> buf;
+    int rc = D2G_OK;
+    while (b <= s.size()) {
+        size_t e = s.find(' ', b);
+        if (e == std::string::npos) e = s.size();
+        if (e > b) {
+            const std::string sub = s.substr(b, e - b);
+            if (!slurp_gz(sub.c_str(), buf)) { rc = D2G_ERR_IO; break; }
+            sp->feed_fastx(buf.data(), buf.size());
+        }
+        b = e + 1;
+    }
+    sp->end_genome();
+    return rc;
+}
+int d2g_seqpack_add_fastx(d2g_seqpack *sp, const char *buf, size_t len) {
+    if (!sp || (!buf && len)) return D2G_ERR_INVALID;
+    sp->unpad();
+    sp->feed_fastx(buf, len);
+    sp->end_genome();
+    return D2G_OK;
+}
+int d2g_seqpack_add_sequence(d2g_seqpack *sp, const char *seq, size_t len) {
+    if (!sp || (!seq && len)) return D2G_ERR_INVALID;
+    sp->unpad();
+    sp->feed(seq, len);
+    sp->end_genome();
+    return D2G_OK;
+}
+size_t d2g_seqpack_ngenomes(const d2g_seqpack *sp) { return sp->genome_run_off.size() - 1; }
+size_t d2g_seqpack_nruns(const d2g_seqpack *sp) { return sp->run_start.size(); }
+size_t d2g_seqpack_packed_bytes(const d2g_seqpack *sp) { const_cast<d2g_seqpack *>(sp)->finalize_pad(); return sp->packed.size(); }
+const uint8_t *d2g_seqpack_packed(const d2g_seqpack *sp) { const_cast<d2g_seqpack *>(sp)->finalize_pad(); return sp->packed.data(); }
+const uint64_t *d2g_seqpack_run_start(const d2g_seqpack *sp) { return sp->run_start.data(); }
+const uint32_t *d2g_seqpack_run_len(const d2g_seqpack *sp) { return sp->run_len.data(); }
+const uint64_t *d2g_seqpack_genome_run_off(const d2g_seqpack *sp) { return sp->genome_run_off.data(); }
+uint64_t d2g_seqpack_nkmers(const d2g_seqpack *sp, size_t g) { return g < sp->genome_nkmers.size() ? sp->genome_nkmers[g] : 0; }
+uint64_t d2g_seqpack_nbases(const d2g_seqpack *sp) { return sp->nbases; }
+
+}  // extern "C"

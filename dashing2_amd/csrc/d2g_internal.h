@@ -1,0 +1,56 @@
+// d2g_internal.h -- shared between the HIP translation units of libd2g (not installed).
+#pragma once
+#include "../../include/d2g.h"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <string>
+
+#include <vector>
+// every timed launch appends a (start, stop) pair; nothing synchronises until the caller asks
+struct d2g_evlog {
+    std::vector<hipEvent_t> a, b;
+};
+
+struct d2g_ctx {
+    int device = -1;
+    int num_cus = 0;
+    std::string last_error;
+    bool timing = false;
+    d2g_evlog ev_k1, ev_k2, ev_k2prep;
+};
+
+#define D2G_HIP(ctx, call)                                                            \
+    do {                                                                              \
+        hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                      \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e__);   \
+            return e__ == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;          \
+        }                                                                             \
+    } while (0)
+
+#define D2G_CHECK(ctx, cond, msg)                      \
+    do {                                               \
+        if (!(cond)) {                                 \
+            (ctx)->last_error = (msg);                 \
+            return D2G_ERR_INVALID;                    \
+        }                                              \
+    } while (0)
+
+// hipEvent bracket around the dominant kernel of a path (enabled with d2g_set_timing);
+// elapsed times are read lazily by d2g_kernel_ms (which synchronises on the stop events).
+struct d2g_timer {
+    d2g_evlog *ev; hipStream_t s; bool on;
+    d2g_timer(d2g_ctx *c, d2g_evlog *e, hipStream_t st) : ev(e), s(st), on(c->timing) {
+        if (on) {
+            hipEvent_t x = nullptr, y = nullptr;
+            if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) { on = false; return; }
+            ev->a.push_back(x); ev->b.push_back(y);
+            (void)hipEventRecord(x, s);
+        }
+    }
+    void stop() { if (on) (void)hipEventRecord(ev->b.back(), s); }
+};
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <class T> static inline T div_up(T a, T b) { return (a + b - 1) / b; }

@@ -1,0 +1,37 @@
+// d2g_k2.h -- internal: the prepared comparison operand shared by the K2 translation units.
+#pragma once
+#include "d2g_internal.h"
+
+struct d2g_cmp_set {
+    d2g_ctx *ctx = nullptr;
+    size_t N = 0, S = 0;
+    size_t Npad = 0;              // N rounded up to the column tile (256)
+    int algo = D2G_CMP_DIRECT;    // algorithm actually prepared
+    uint64_t *d_rows = nullptr;   // [N][S]     row-major 64-bit patterns
+    uint64_t *d_cols = nullptr;   // [S][Npad]  register-major (transposed), zero padded
+    // bit-sliced operand (algo == D2G_CMP_BITSLICE); all buffers are allocated once per set
+    uint32_t *d_planes = nullptr; // [ntb][nbits_cap][Nstride]: bit x of word = bit b of id[32*tb+x][j]
+    size_t Nstride = 0;           // Npad + 64 (row tiles may read past Npad)
+    int nbits_cap = 0;            // plane slots per 32-register group = ceil(log2 N) (>= 1)
+    int ntb = 0;                  // ceil(S/32)
+    uint32_t *d_meta = nullptr;   // [0] = max distinct values per column (device side; the kernels
+                                  //       derive the live plane count from it, no host round trip)
+    uint32_t *d_owner = nullptr;  // workspace: [S][T] open-addressing owner table
+    uint32_t *d_ids = nullptr;    // workspace: [S][Npad] dense ids
+    uint32_t T = 0; int logT = 0;
+};
+
+// d2g_k2_bitslice part (same shared object)
+int  d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set);
+int  d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
+void d2g_bitslice_free(d2g_cmp_set *set);
+// exactly one of (eq_out) or (lut,fout) is non-null
+int  d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out,
+                     const float *lut, float *fout, hipStream_t s);
+int  d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1,
+                       uint32_t *eq_out, hipStream_t s);
+
+// host epilogue over a condensed row range (d2g_host.cpp; x87 arithmetic, OpenMP)
+extern "C" void d2g_host_epilogue_ut(const uint32_t *ca, const uint32_t *cb /* lt or null */, const double *cards,
+                                     size_t N, size_t S, size_t r0, size_t r1, int measure, int k,
+                                     int multiset_space, int nthreads, float *out);

@@ -1,0 +1,382 @@
+// d2g_k2.hip -- K2: dense all-pairs signature comparison (gfx950).
+//
+// Replaces HOT LOOP B of the reference: emit_rectangular's row loops (src/emitrect.cpp:211-323)
+// calling compare() (src/cmp_core.cpp:349-361) whose inner loop is
+// sketch::eq::count_gtlt / count_eq over S registers (src/cmp_core.cpp:461,506).
+//
+// DIRECT algorithm (this file, part 1)
+//   operands: the N x S matrix of 64-bit patterns, kept twice in HBM:
+//       rows [N][S]      row-major      -> the "A" operand, read with SCALAR loads (s_load_dwordx8)
+//       cols [S][Npad]   register-major -> the "B" operand, lane l reads column j0+l (+64c): 512 B
+//                                          contiguous per wave-instruction
+//   a wave owns IW rows x (64*JR) columns of the pair matrix; per register index t every lane
+//   does IW*JR  v_cmp_eq_u64 (SGPR pair vs VGPR pair) + v_addc_co_u32: all VALU issue is compare
+//   work, A costs no VGPR/LDS traffic, B is shared by the 4 waves of the workgroup through L1/L2.
+//   A workgroup (4 waves) owns a 32 x 256 tile; tiles are enumerated column-major and
+//   swizzled so that one XCD's L2 keeps the B columns (S*256*8 B = 2 MiB at S=1024) its
+//   workgroups share.
+//
+// BITSLICE algorithm (part 2, d2g_k2_bitslice.hip): per-column dense ids -> bit planes.
+#include "d2g_internal.h"
+#include "d2g_k2.h"
+#include "d2g_k2_shape.h"
+#include <algorithm>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int K2_THREADS = 256;
+constexpr int K2_IW = 8;                 // rows per wave
+constexpr int K2_JR = 4;                 // 64-column groups per lane
+constexpr int K2_RB = 4 * K2_IW;         // rows per workgroup tile (32)
+constexpr int K2_CB = 64 * K2_JR;        // cols per workgroup tile (256)
+constexpr int K2_TC = 2;                 // registers per inner step (IW*TC*2 SGPRs of A values)
+
+// ---------------------------------------------------------------- transpose [N][S] -> [S][Npad]
+__global__ __launch_bounds__(256) void k2_transpose_kernel(const uint64_t *__restrict__ rows, uint64_t *__restrict__ cols,
+                                                           size_t N, size_t S, size_t Npad) {
+    __shared__ uint64_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    const size_t n0 = (size_t)blockIdx.y * 32, s0 = (size_t)blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const size_t n = n0 + r, s = s0 + tx;
+        tile[r][tx] = (n < N && s < S) ? rows[n * S + s] : 0ull;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const size_t s = s0 + r, n = n0 + tx;
+        if (s < S && n < Npad) cols[s * Npad + n] = tile[tx][r];
+    }
+}
+
+// ---------------------------------------------------------------- direct compare kernel
+template <bool GTLT, class Store>
+__global__ __launch_bounds__(K2_THREADS) void k2_direct_kernel(const uint64_t *__restrict__ rows, const uint64_t *__restrict__ cols,
+                                                               size_t S, size_t Npad, PairShape sh, Store store) {
+    // XCD-aware logical tile id: workgroup b runs on XCD b%8; give each XCD a contiguous
+    // range of (column-major) tiles so its L2 holds the B columns they share.
+    const unsigned b = blockIdx.x;
+    const unsigned L = (b & 7u) * sh.per_xcd + (b >> 3);
+    if (L >= sh.nblk) return;
+    const unsigned ct = L / sh.nrt, rt = L % sh.nrt;
+    const size_t i0 = sh.i_lo + (size_t)rt * K2_RB;
+    const size_t j0 = (size_t)(sh.ct0 + ct) * K2_CB;
+    if (sh.ut && j0 + K2_CB - 1 <= i0) return;            // tile entirely on/below the diagonal
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const size_t iw0 = i0 + (size_t)wave * K2_IW;
+    if (iw0 >= sh.i_hi) return;
+    if (sh.ut && j0 + K2_CB - 1 <= iw0) return;
+
+    // rows is allocated with K2_RB zero rows of slack, so a partial last row tile reads in bounds
+    const uint64_t *arow0 = rows + iw0 * S;
+    const uint64_t *bcol = cols + j0 + lane;
+
+    uint32_t acc[K2_IW][K2_JR];
+    uint32_t accg[GTLT ? K2_IW : 1][GTLT ? K2_JR : 1];
+#pragma unroll
+    for (int i = 0; i < K2_IW; ++i)
+#pragma unroll
+        for (int c = 0; c < K2_JR; ++c) { acc[i][c] = 0; if (GTLT) accg[i][c] = 0; }
+
+    size_t t = 0;
+    for (; t + K2_TC <= S; t += K2_TC) {
+        uint64_t bv[K2_TC][K2_JR];
+#pragma unroll
+        for (int tt = 0; tt < K2_TC; ++tt)
+#pragma unroll
+            for (int c = 0; c < K2_JR; ++c) bv[tt][c] = bcol[(t + tt) * Npad + 64 * c];
+#pragma unroll
+        for (int i = 0; i < K2_IW; ++i) {
+#pragma unroll
+            for (int tt = 0; tt < K2_TC; ++tt) {
+                const uint64_t av = arow0[(size_t)i * S + t + tt];
+#pragma unroll
+                for (int c = 0; c < K2_JR; ++c) {
+                    acc[i][c] += (av == bv[tt][c]);
+                    if (GTLT) accg[i][c] += (av > bv[tt][c]);
+                }
+            }
+        }
+    }
+    for (; t < S; ++t) {
+        uint64_t bv[K2_JR];
+#pragma unroll
+        for (int c = 0; c < K2_JR; ++c) bv[c] = bcol[t * Npad + 64 * c];
+#pragma unroll
+        for (int i = 0; i < K2_IW; ++i) {
+            const uint64_t av = arow0[(size_t)i * S + t];
+#pragma unroll
+            for (int c = 0; c < K2_JR; ++c) {
+                acc[i][c] += (av == bv[c]);
+                if (GTLT) accg[i][c] += (av > bv[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K2_IW; ++i) {
+        const size_t ii = iw0 + i;
+        if (ii >= sh.i_hi) break;
+#pragma unroll
+        for (int c = 0; c < K2_JR; ++c) {
+            const size_t jj = j0 + lane + 64 * c;
+            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii))
+                store(out_pos(sh, ii, jj), acc[i][c], GTLT ? accg[i][c] : 0u);
+        }
+    }
+}
+
+template <bool GTLT, class Store>
+int launch_direct(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
+    sh.nrt = (unsigned)div_up<size_t>(sh.i_hi - sh.i_lo, K2_RB);
+    sh.ct0 = (unsigned)(sh.j_lo / K2_CB);
+    sh.nct = (unsigned)(div_up<size_t>(sh.j_hi, K2_CB) - sh.ct0);
+    const size_t nblk = (size_t)sh.nrt * sh.nct;
+    D2G_CHECK(ctx, nblk < (1ull << 31), "pair tile grid too large; shard rows");
+    sh.nblk = (unsigned)nblk;
+    sh.per_xcd = (unsigned)div_up<size_t>(nblk, 8);
+    d2g_timer tm(ctx, &ctx->ev_k2, s);
+    hipLaunchKernelGGL((k2_direct_kernel<GTLT, Store>), dim3(sh.per_xcd * 8), dim3(K2_THREADS), 0, s,
+                       set->d_rows, set->d_cols, set->S, set->Npad, sh, store);
+    tm.stop();
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+void d2g_cmp_set_destroy(d2g_cmp_set *set) {
+    if (!set) return;
+    (void)hipSetDevice(set->ctx->device);
+    (void)hipFree(set->d_rows);
+    (void)hipFree(set->d_cols);
+    d2g_bitslice_free(set);
+    delete set;
+}
+
+int d2g_cmp_set_algo(const d2g_cmp_set *set) { return set ? set->algo : D2G_ERR_INVALID; }
+
+// (re)load the operand: copy + transpose + (bitslice) ids/planes.  Everything is enqueued on `s`.
+static int cmp_set_load(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, hipStream_t s) {
+    const size_t N = set->N, S = set->S;
+    D2G_HIP(ctx, hipMemcpyAsync(set->d_rows, sig_bits_dev, N * S * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    d2g_timer tm(ctx, &ctx->ev_k2prep, s);
+    dim3 grid((unsigned)div_up<size_t>(S, 32), (unsigned)div_up<size_t>(set->Npad, 32));
+    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, set->d_rows, set->d_cols, N, S, set->Npad);
+    int rc = D2G_OK;
+    if (set->algo == D2G_CMP_BITSLICE) rc = d2g_bitslice_prepare(ctx, set, s);
+    tm.stop();
+    if (rc) return rc;
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+int d2g_cmp_set_create_dev(d2g_ctx *ctx, const uint64_t *sig_bits_dev, size_t N, size_t S, int algo,
+                           void *stream, d2g_cmp_set **out) {
+    if (!ctx || !out) return D2G_ERR_INVALID;
+    *out = nullptr;
+    D2G_CHECK(ctx, N >= 1 && S >= 1, "cmp_set: empty matrix");
+    D2G_CHECK(ctx, S < (1ull << 31), "cmp_set: sketchsize too large");
+    D2G_CHECK(ctx, sig_bits_dev != nullptr, "cmp_set: null signatures");
+    D2G_CHECK(ctx, algo == D2G_CMP_AUTO || algo == D2G_CMP_DIRECT || algo == D2G_CMP_BITSLICE, "cmp_set: bad algo");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = as_stream(stream);
+    d2g_cmp_set *set = new (std::nothrow) d2g_cmp_set();
+    if (!set) return D2G_ERR_NOMEM;
+    set->ctx = ctx; set->N = N; set->S = S;
+    set->Npad = div_up<size_t>(N, K2_CB) * K2_CB;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&set->d_rows, (N + K2_RB) * S * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_cols, set->Npad * S * sizeof(uint64_t))) != hipSuccess) {
+        ctx->last_error = hipGetErrorString(e);
+        d2g_cmp_set_destroy(set);
+        return D2G_ERR_NOMEM;
+    }
+    // slack rows past N are read (never stored) by a partial last row tile
+    (void)hipMemsetAsync(set->d_rows + N * S, 0, (size_t)K2_RB * S * sizeof(uint64_t), s);
+    set->algo = D2G_CMP_DIRECT;
+    if (algo != D2G_CMP_DIRECT) {
+        int rc = d2g_bitslice_alloc(ctx, set);
+        if (rc == D2G_OK) set->algo = D2G_CMP_BITSLICE;
+        else if (!(rc == D2G_ERR_UNSUPPORTED && algo == D2G_CMP_AUTO)) { d2g_cmp_set_destroy(set); return rc; }
+    }
+    int rc = cmp_set_load(ctx, set, sig_bits_dev, s);
+    if (rc) { d2g_cmp_set_destroy(set); return rc; }
+    *out = set;
+    return D2G_OK;
+}
+
+int d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, set && set->ctx == ctx, "cmp_set_update: set belongs to another context");
+    D2G_CHECK(ctx, sig_bits_dev != nullptr, "cmp_set_update: null signatures");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    return cmp_set_load(ctx, set, sig_bits_dev, as_stream(stream));
+}
+
+int d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, set && set->ctx == ctx, "cmp_set_planes: set belongs to another context");
+    unsigned md = 0; int nb = 0;
+    if (set->algo == D2G_CMP_BITSLICE) {
+        D2G_HIP(ctx, hipSetDevice(ctx->device));
+        D2G_HIP(ctx, hipMemcpyAsync(&md, set->d_meta, sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream)));
+        D2G_HIP(ctx, hipStreamSynchronize(as_stream(stream)));
+        nb = 1;
+        while ((1ull << nb) < md) ++nb;
+    }
+    if (max_distinct) *max_distinct = md;
+    if (nbits) *nbits = nb;
+    return D2G_OK;
+}
+
+int d2g_cmp_set_create(d2g_ctx *ctx, const uint64_t *sig_bits_host, size_t N, size_t S, int algo, d2g_cmp_set **out) {
+    if (!ctx || !out) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, sig_bits_host != nullptr && N >= 1 && S >= 1, "cmp_set: bad host matrix");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t *tmp = nullptr;
+    D2G_HIP(ctx, hipMalloc((void **)&tmp, N * S * sizeof(uint64_t)));
+    hipError_t e = hipMemcpy(tmp, sig_bits_host, N * S * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(tmp); ctx->last_error = hipGetErrorString(e); return D2G_ERR_HIP; }
+    int rc = d2g_cmp_set_create_dev(ctx, tmp, N, S, algo, nullptr, out);
+    (void)hipStreamSynchronize(nullptr);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+static int check_rows(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1) {
+    D2G_CHECK(ctx, set && set->ctx == ctx, "cmp: set belongs to another context");
+    D2G_CHECK(ctx, r0 <= r1 && r1 <= set->N, "cmp: row range out of bounds");
+    return D2G_OK;
+}
+
+static PairShape ut_shape(const d2g_cmp_set *set, size_t r0, size_t r1) {
+    PairShape sh{};
+    sh.N = set->N; sh.i_lo = r0; sh.i_hi = r1; sh.j_lo = r0 + 1 < set->N ? r0 + 1 : set->N; sh.j_hi = set->N; sh.ut = 1;
+    return sh;
+}
+
+int d2g_cmp_eqcount_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *out, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    if (int rc = check_rows(ctx, set, r0, r1)) return rc;
+    if (d2g_ut_count(set->N, r0, r1) == 0) return D2G_OK;
+    D2G_CHECK(ctx, out != nullptr, "cmp: null output");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    if (set->algo == D2G_CMP_BITSLICE) return d2g_bitslice_ut(ctx, set, r0, r1, out, nullptr, nullptr, as_stream(stream));
+    return launch_direct<false>(ctx, set, ut_shape(set, r0, r1), StoreEq{out}, as_stream(stream));
+}
+
+int d2g_cmp_lut_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, const float *lut, float *out, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    if (int rc = check_rows(ctx, set, r0, r1)) return rc;
+    if (d2g_ut_count(set->N, r0, r1) == 0) return D2G_OK;
+    D2G_CHECK(ctx, out != nullptr && lut != nullptr, "cmp: null output/lut");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    if (set->algo == D2G_CMP_BITSLICE) return d2g_bitslice_ut(ctx, set, r0, r1, nullptr, lut, out, as_stream(stream));
+    return launch_direct<false>(ctx, set, ut_shape(set, r0, r1), StoreLut{out, lut}, as_stream(stream));
+}
+
+int d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *gt, uint32_t *lt, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    if (int rc = check_rows(ctx, set, r0, r1)) return rc;
+    if (d2g_ut_count(set->N, r0, r1) == 0) return D2G_OK;
+    D2G_CHECK(ctx, gt != nullptr && lt != nullptr, "cmp: null output");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    // order needs the raw patterns: always the direct kernel (rows/cols are kept for every set)
+    return launch_direct<true>(ctx, set, ut_shape(set, r0, r1), StoreGtLt{gt, lt, (uint32_t)set->S}, as_stream(stream));
+}
+
+int d2g_cmp_eqcount_rect_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1,
+                             uint32_t *out, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, set && set->ctx == ctx, "cmp: set belongs to another context");
+    D2G_CHECK(ctx, a0 <= a1 && a1 <= set->N && b0 <= b1 && b1 <= set->N, "cmp: rect out of bounds");
+    if (a0 == a1 || b0 == b1) return D2G_OK;
+    D2G_CHECK(ctx, out != nullptr, "cmp: null output");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    PairShape sh{};
+    sh.N = set->N; sh.i_lo = a0; sh.i_hi = a1; sh.j_lo = b0; sh.j_hi = b1; sh.ut = 0;
+    if (set->algo == D2G_CMP_BITSLICE) return d2g_bitslice_rect(ctx, set, a0, a1, b0, b1, out, as_stream(stream));
+    return launch_direct<false>(ctx, set, sh, StoreEq{out}, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- host-pointer conveniences
+int d2g_cmp_eqcount_ut(d2g_ctx *ctx, const uint64_t *sig_bits, size_t N, size_t S, size_t r0, size_t r1, int algo,
+                       uint32_t *neq_out) {
+    if (!ctx) return D2G_ERR_INVALID;
+    d2g_cmp_set *set = nullptr;
+    int rc = d2g_cmp_set_create(ctx, sig_bits, N, S, algo, &set);
+    if (rc) return rc;
+    const size_t cnt = d2g_ut_count(N, r0, r1);
+    uint32_t *d_out = nullptr;
+    if (cnt) {
+        hipError_t e = hipMalloc((void **)&d_out, cnt * sizeof(uint32_t));
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); d2g_cmp_set_destroy(set); return D2G_ERR_NOMEM; }
+    }
+    rc = d2g_cmp_eqcount_ut_dev(ctx, set, r0, r1, d_out, nullptr);
+    if (rc == D2G_OK && cnt) {
+        hipError_t e = hipMemcpy(neq_out, d_out, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); rc = D2G_ERR_HIP; }
+    }
+    (void)hipFree(d_out);
+    d2g_cmp_set_destroy(set);
+    return rc;
+}
+
+int d2g_cmp_dist_ut(d2g_ctx *ctx, const uint64_t *sig_bits, const double *cards, size_t N, size_t S, size_t r0,
+                    size_t r1, int measure, int k, int multiset_space, int algo, int nthreads, float *out) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, measure >= D2G_SIMILARITY && measure <= D2G_UNION_SIZE, "cmp: unknown measure");
+    D2G_CHECK(ctx, r0 <= r1 && r1 <= N, "cmp: row range out of bounds");
+    const size_t cnt = d2g_ut_count(N, r0, r1);
+    if (!cnt) return D2G_OK;
+    D2G_CHECK(ctx, out != nullptr && cards != nullptr, "cmp: null output/cards");
+    if (nthreads < 1) nthreads = 1;
+    d2g_cmp_set *set = nullptr;
+    std::vector<float> lut(S + 1);
+    const bool have_lut = d2g_epilogue_lut(S, measure, k, multiset_space, lut.data()) == D2G_OK;
+    // (gt,lt) are only needed in set space when the value is not a function of neq alone
+    const bool need_gtlt = !multiset_space && (S & (S - 1)) != 0;
+    int rc = d2g_cmp_set_create(ctx, sig_bits, N, S, need_gtlt ? (int)D2G_CMP_DIRECT : algo, &set);
+    if (rc) return rc;
+    void *d_a = nullptr, *d_b = nullptr, *d_lut = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_lut); d2g_cmp_set_destroy(set); };
+#define D2G_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->last_error = hipGetErrorString(e__); cleanup(); return D2G_ERR_HIP; } } while (0)
+    D2G_TRY(hipMalloc(&d_a, cnt * 4));
+    if (have_lut) {
+        // card-independent measure, value = f(neq): fused table epilogue on the device
+        D2G_TRY(hipMalloc(&d_lut, (S + 1) * sizeof(float)));
+        D2G_TRY(hipMemcpy(d_lut, lut.data(), (S + 1) * sizeof(float), hipMemcpyHostToDevice));
+        rc = d2g_cmp_lut_ut_dev(ctx, set, r0, r1, (const float *)d_lut, (float *)d_a, nullptr);
+        if (rc == D2G_OK) D2G_TRY(hipMemcpy(out, d_a, cnt * 4, hipMemcpyDeviceToHost));
+        cleanup();
+        return rc;
+    }
+    // integer counts from the device, x87 epilogue on the host (bit-exact with cmp_core.cpp:458-517)
+    std::vector<uint32_t> ca(cnt), cb;
+    if (need_gtlt) {
+        D2G_TRY(hipMalloc(&d_b, cnt * 4));
+        rc = d2g_cmp_gtlt_ut_dev(ctx, set, r0, r1, (uint32_t *)d_a, (uint32_t *)d_b, nullptr);
+        if (rc == D2G_OK) {
+            cb.resize(cnt);
+            D2G_TRY(hipMemcpy(ca.data(), d_a, cnt * 4, hipMemcpyDeviceToHost));
+            D2G_TRY(hipMemcpy(cb.data(), d_b, cnt * 4, hipMemcpyDeviceToHost));
+        }
+    } else {
+        rc = d2g_cmp_eqcount_ut_dev(ctx, set, r0, r1, (uint32_t *)d_a, nullptr);
+        if (rc == D2G_OK) D2G_TRY(hipMemcpy(ca.data(), d_a, cnt * 4, hipMemcpyDeviceToHost));
+    }
+#undef D2G_TRY
+    cleanup();
+    if (rc) return rc;
+    d2g_host_epilogue_ut(ca.data(), need_gtlt ? cb.data() : nullptr, cards, N, S, r0, r1, measure, k,
+                         multiset_space, nthreads, out);
+    return D2G_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+// d2g_k2_bitslice.hip -- K2, BITSLICE algorithm (gfx950): exact equality counts from bit planes.
+//
+// Same contract as the direct kernel (reference src/cmp_core.cpp:461,506 count_gtlt/count_eq
+// inside src/emitrect.cpp:211-323), different arithmetic:
+//
+//   the count only needs EQUALITY of 64-bit patterns within one register index t, so each
+//   column t of the N x S matrix is first mapped to dense ids 0..D_t-1 (distinct value ->
+//   distinct id; D_t <= N), which takes nbits = ceil(log2(max_t D_t)) bits instead of 64.
+//   The ids are stored bit-sliced: word P[tb][b][j] holds bit b of the ids of sketch j for the
+//   32 registers t = 32*tb .. 32*tb+31.  For a pair (i,j) and a 32-register group
+//       z = OR_b ( P[tb][b][i] XOR P[tb][b][j] )          one v_bitop3_b32 per plane
+//       mismatches += popcount(z)                          one v_bcnt_u32_b32 (accumulating)
+//   i.e. (nbits+1)/32 VALU operations per register compare instead of 2 (v_cmp_eq_u64+v_addc):
+//   ~0.5 for N = 10 000 (14 planes).  Row operands come through SCALAR loads (one
+//   s_load_dwordx16 per plane serves 16 rows), column operands are one coalesced dword per lane.
+//
+// Prepare = 3 small kernels (timed as "k2prep"): per-column open-addressing insert into a
+// global u32 owner table, slot compaction to dense ranks, 32 x nbits bit transpose.
+#include "d2g_internal.h"
+#include "d2g_k2.h"
+#include "d2g_k2_shape.h"
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr uint32_t BS_EMPTY = 0xFFFFFFFFu;
+constexpr int BS_RANK_THREADS = 1024;
+
+// ------------------------------------------------------------------ 1. per-column dense ids
+// One workgroup per register index t.  owner[] (T slots, pre-set to EMPTY) records the first
+// sketch index that claimed a slot; equality is decided against that sketch's value, so no key
+// storage and no reserved sentinel value is needed.
+__global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
+                                                                  uint32_t *owner_all, uint32_t T, int logT,
+                                                                  uint32_t *ids_all, uint32_t *max_distinct) {
+    const size_t t = blockIdx.x;
+    const uint64_t *col = cols + t * Npad;
+    uint32_t *own = owner_all + t * (size_t)T;
+    uint32_t *ids = ids_all + t * Npad;
+    const int tid = threadIdx.x;
+    const uint32_t mask = T - 1;
+
+    for (size_t j = tid; j < N; j += BS_RANK_THREADS) {
+        const uint64_t v = col[j];
+        uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> (64 - logT));
+        for (;;) {
+            const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, (uint32_t)j);
+            if (cur == BS_EMPTY || col[cur] == v) break;
+            h = (h + 1) & mask;
+        }
+        ids[j] = h;
+    }
+    __syncthreads();
+
+    // compaction: exclusive scan over slot occupancy -> dense rank, written over the owner
+    __shared__ uint32_t wave_tot[BS_RANK_THREADS / 64];
+    __shared__ uint32_t running;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (uint32_t base = 0; base < T; base += BS_RANK_THREADS) {
+        const uint32_t h = base + tid;
+        const bool occ = h < T && __hip_atomic_load(&own[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BS_EMPTY;
+        const unsigned long long bal = __ballot(occ);
+        const uint32_t before = __popcll(bal & ((1ull << lane) - 1));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int w = 0; w < BS_RANK_THREADS / 64; ++w) {
+            const uint32_t x = wave_tot[w];
+            if (w < wave) woff += x;
+            tot += x;
+        }
+        const uint32_t r0 = running;
+        if (occ) own[h] = r0 + woff + before;
+        __syncthreads();
+        if (tid == 0) running = r0 + tot;
+        __syncthreads();
+    }
+    if (tid == 0) atomicMax(max_distinct, running);
+    for (size_t j = tid; j < N; j += BS_RANK_THREADS) ids[j] = own[ids[j]];
+}
+
+// ------------------------------------------------------------------ 2. 32 x nbits bit transpose
+// thread (tb, j): reads the ids of sketch j for 32 consecutive registers, writes nbits words.
+__device__ __forceinline__ int live_planes(const uint32_t *meta) {
+    const uint32_t md = meta[0];                       // max distinct values in any column
+    return md <= 2 ? 1 : 32 - __clz(md - 1);          // ceil(log2(md)), at least 1
+}
+
+__global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t S, size_t N, size_t Npad,
+                                                        uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
+                                                        const uint32_t *__restrict__ meta) {
+    const int nbits = live_planes(meta);
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t tb = blockIdx.y;
+    if (j >= Nstride) return;
+    uint32_t id[32];
+#pragma unroll
+    for (int x = 0; x < 32; ++x) {
+        const size_t t = tb * 32 + x;
+        id[x] = (t < S && j < N) ? ids[t * Npad + j] : 0u;     // padded registers/sketches: id 0
+    }
+    uint32_t *dst = planes + tb * (size_t)nbits_cap * Nstride + j;
+    for (int b = 0; b < nbits; ++b) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int x = 0; x < 32; ++x) w |= ((id[x] >> b) & 1u) << x;
+        dst[(size_t)b * Nstride] = w;
+    }
+}
+
+// ------------------------------------------------------------------ 3. the pair kernel
+constexpr int BS_THREADS = 256;
+constexpr int BS_IW = 16;                 // rows per wave (one s_load_dwordx16 per plane)
+constexpr int BS_JR = 4;                  // 64-column groups per lane
+constexpr int BS_RB = 4 * BS_IW;          // 64 rows per workgroup tile
+constexpr int BS_CB = 64 * BS_JR;         // 256 columns per workgroup tile
+
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef u32x16 __attribute__((aligned(4))) u32x16_u;
+// v_bitop3_b32 truth table: src0 = 0xF0, src1 = 0xCC, src2 = 0xAA  ->  src2 | (src0 ^ src1)
+constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);
+
+template <class Store>
+__global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
+                                                                 const uint32_t *__restrict__ meta, int ntb, uint32_t S,
+                                                                 PairShape sh, Store store) {
+    const unsigned b = blockIdx.x;
+    const unsigned L = (b & 7u) * sh.per_xcd + (b >> 3);      // XCD-contiguous, column-major tiles
+    if (L >= sh.nblk) return;
+    const unsigned ct = L / sh.nrt, rt = L % sh.nrt;
+    const size_t i0 = sh.i_lo + (size_t)rt * BS_RB;
+    const size_t j0 = (size_t)(sh.ct0 + ct) * BS_CB;
+    if (sh.ut && j0 + BS_CB - 1 <= i0) return;
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const size_t iw0 = i0 + (size_t)wave * BS_IW;
+    if (iw0 >= sh.i_hi) return;
+    if (sh.ut && j0 + BS_CB - 1 <= iw0) return;
+
+    const int nbits = live_planes(meta);             // uniform (scalar load)
+    uint32_t acc[BS_IW][BS_JR];
+#pragma unroll
+    for (int i = 0; i < BS_IW; ++i)
+#pragma unroll
+        for (int c = 0; c < BS_JR; ++c) acc[i][c] = 0;
+
+    const uint32_t *prow = planes + iw0;          // uniform: scalar loads
+    const uint32_t *pcol = planes + j0 + lane;    // per lane: coalesced dword loads
+    for (int tb = 0; tb < ntb; ++tb) {
+        uint32_t z[BS_IW][BS_JR];
+#pragma unroll
+        for (int i = 0; i < BS_IW; ++i)
+#pragma unroll
+            for (int c = 0; c < BS_JR; ++c) z[i][c] = 0;
+        const size_t base = (size_t)tb * nbits_cap * Nstride;
+#pragma unroll 2
+        for (int p = 0; p < nbits; ++p) {
+            const size_t off = base + (size_t)p * Nstride;
+            const u32x16_u sa = *reinterpret_cast<const u32x16_u *>(prow + off);   // s_load_dwordx16
+            uint32_t vb[BS_JR];
+#pragma unroll
+            for (int c = 0; c < BS_JR; ++c) vb[c] = pcol[off + 64 * c];
+#pragma unroll
+            for (int i = 0; i < BS_IW; ++i)
+#pragma unroll
+                for (int c = 0; c < BS_JR; ++c)
+                    z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+        }
+#pragma unroll
+        for (int i = 0; i < BS_IW; ++i)
+#pragma unroll
+            for (int c = 0; c < BS_JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);   // -> v_bcnt_u32_b32
+    }
+#pragma unroll
+    for (int i = 0; i < BS_IW; ++i) {
+        const size_t ii = iw0 + i;
+        if (ii >= sh.i_hi) break;
+#pragma unroll
+        for (int c = 0; c < BS_JR; ++c) {
+            const size_t jj = j0 + lane + 64 * c;
+            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii))
+                store(out_pos(sh, ii, jj), S - acc[i][c], 0u);      // padded registers never mismatch
+        }
+    }
+}
+
+template <class Store>
+int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
+    sh.nrt = (unsigned)div_up<size_t>(sh.i_hi - sh.i_lo, BS_RB);
+    sh.ct0 = (unsigned)(sh.j_lo / BS_CB);
+    sh.nct = (unsigned)(div_up<size_t>(sh.j_hi, BS_CB) - sh.ct0);
+    const size_t nblk = (size_t)sh.nrt * sh.nct;
+    D2G_CHECK(ctx, nblk < (1ull << 31), "pair tile grid too large; shard rows");
+    sh.nblk = (unsigned)nblk;
+    sh.per_xcd = (unsigned)div_up<size_t>(nblk, 8);
+    d2g_timer tm(ctx, &ctx->ev_k2, s);
+    hipLaunchKernelGGL((k2_bitslice_kernel<Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes,
+                       set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
+    tm.stop();
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+}  // namespace
+
+void d2g_bitslice_free(d2g_cmp_set *set) {
+    if (!set) return;
+    (void)hipFree(set->d_planes); (void)hipFree(set->d_meta); (void)hipFree(set->d_owner); (void)hipFree(set->d_ids);
+    set->d_planes = set->d_meta = set->d_owner = set->d_ids = nullptr;
+}
+
+// one-time allocation of the bit-sliced operand and its workspace
+int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
+    const size_t N = set->N, S = set->S, Npad = set->Npad;
+    if (N >= (1ull << 30)) { ctx->last_error = "bitslice: N too large"; return D2G_ERR_UNSUPPORTED; }
+    // owner table: power of two >= 1.5 N (load <= 2/3), at least 64 slots
+    set->T = 64; set->logT = 6;
+    while ((uint64_t)set->T * 2 < (uint64_t)N * 3) { set->T <<= 1; ++set->logT; }
+    set->nbits_cap = 1;
+    while ((1ull << set->nbits_cap) < N) ++set->nbits_cap;
+    set->ntb = (int)div_up<size_t>(S, 32);
+    set->Nstride = Npad + 64;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&set->d_owner, S * (size_t)set->T * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_ids, S * Npad * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_meta, 4 * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_planes, (size_t)set->ntb * set->nbits_cap * set->Nstride * sizeof(uint32_t))) != hipSuccess) {
+        ctx->last_error = std::string("bitslice alloc: ") + hipGetErrorString(e);
+        d2g_bitslice_free(set);
+        return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
+    }
+    return D2G_OK;
+}
+
+// ids + planes for the operand currently in set->d_cols.  Fully asynchronous on `s`.
+int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
+    const size_t N = set->N, S = set->S, Npad = set->Npad;
+    D2G_HIP(ctx, hipMemsetAsync(set->d_owner, 0xFF, S * (size_t)set->T * sizeof(uint32_t), s));
+    D2G_HIP(ctx, hipMemsetAsync(set->d_meta, 0, 4 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(bs_rank_kernel, dim3((unsigned)S), dim3(BS_RANK_THREADS), 0, s, set->d_cols, N, Npad, set->d_owner,
+                       set->T, set->logT, set->d_ids, set->d_meta);
+    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
+    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, S, N, Npad, set->d_planes, set->Nstride,
+                       set->nbits_cap, set->d_meta);
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+int d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut,
+                    float *fout, hipStream_t s) {
+    PairShape sh{};
+    sh.N = set->N; sh.i_lo = r0; sh.i_hi = r1; sh.j_lo = r0 + 1 < set->N ? r0 + 1 : set->N; sh.j_hi = set->N; sh.ut = 1;
+    if (eq_out) return launch_bitslice(ctx, set, sh, StoreEq{eq_out}, s);
+    return launch_bitslice(ctx, set, sh, StoreLut{fout, lut}, s);
+}
+
+int d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1, uint32_t *eq_out,
+                      hipStream_t s) {
+    PairShape sh{};
+    sh.N = set->N; sh.i_lo = a0; sh.i_hi = a1; sh.j_lo = b0; sh.j_hi = b1; sh.ut = 0;
+    return launch_bitslice(ctx, set, sh, StoreEq{eq_out}, s);
+}

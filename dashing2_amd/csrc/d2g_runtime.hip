@@ -1,0 +1,114 @@
+// d2g_runtime.hip -- context, device memory and timing plumbing of libd2g.
+#include "d2g_internal.h"
+#include <cstring>
+#include <new>
+
+extern "C" {
+
+int d2g_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int d2g_ctx_create(int device, d2g_ctx **out) {
+    if (!out) return D2G_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return D2G_ERR_NODEVICE;
+    if (device < 0 || device >= n) return D2G_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return D2G_ERR_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return D2G_ERR_NODEVICE;
+    // this library carries gfx950 code objects only
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return D2G_ERR_NODEVICE;
+    d2g_ctx *c = new (std::nothrow) d2g_ctx();
+    if (!c) return D2G_ERR_NOMEM;
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    *out = c;
+    return D2G_OK;
+}
+
+void d2g_ctx_destroy(d2g_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (d2g_evlog *e : {&c->ev_k1, &c->ev_k2, &c->ev_k2prep}) {
+        for (hipEvent_t x : e->a) (void)hipEventDestroy(x);
+        for (hipEvent_t x : e->b) (void)hipEventDestroy(x);
+    }
+    delete c;
+}
+
+const char *d2g_last_error(const d2g_ctx *c) { return c ? c->last_error.c_str() : "null ctx"; }
+int d2g_ctx_device(const d2g_ctx *c) { return c ? c->device : -1; }
+
+int d2g_sync(d2g_ctx *c, void *stream) {
+    if (!c) return D2G_ERR_INVALID;
+    D2G_HIP(c, hipSetDevice(c->device));
+    D2G_HIP(c, hipStreamSynchronize(as_stream(stream)));
+    return D2G_OK;
+}
+
+int d2g_malloc(d2g_ctx *c, size_t nbytes, void **dptr) {
+    if (!c || !dptr) return D2G_ERR_INVALID;
+    D2G_HIP(c, hipSetDevice(c->device));
+    D2G_HIP(c, hipMalloc(dptr, nbytes ? nbytes : 1));
+    return D2G_OK;
+}
+int d2g_free(d2g_ctx *c, void *dptr) {
+    if (!c) return D2G_ERR_INVALID;
+    if (!dptr) return D2G_OK;
+    D2G_HIP(c, hipSetDevice(c->device));
+    D2G_HIP(c, hipFree(dptr));
+    return D2G_OK;
+}
+int d2g_memcpy_h2d(d2g_ctx *c, void *dst, const void *src, size_t n, void *stream) {
+    if (!c || (n && (!dst || !src))) return D2G_ERR_INVALID;
+    D2G_HIP(c, hipSetDevice(c->device));
+    D2G_HIP(c, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, as_stream(stream)));
+    D2G_HIP(c, hipStreamSynchronize(as_stream(stream)));
+    return D2G_OK;
+}
+int d2g_memcpy_d2h(d2g_ctx *c, void *dst, const void *src, size_t n, void *stream) {
+    if (!c || (n && (!dst || !src))) return D2G_ERR_INVALID;
+    D2G_HIP(c, hipSetDevice(c->device));
+    D2G_HIP(c, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, as_stream(stream)));
+    D2G_HIP(c, hipStreamSynchronize(as_stream(stream)));
+    return D2G_OK;
+}
+
+int d2g_set_timing(d2g_ctx *c, int enabled) {
+    if (!c) return D2G_ERR_INVALID;
+    c->timing = enabled != 0;
+    return D2G_OK;
+}
+
+int d2g_kernel_ms(d2g_ctx *c, const char *which, int reset, int *count, float *avg_ms, float *last_ms) {
+    if (!c || !which) return D2G_ERR_INVALID;
+    d2g_evlog *e = nullptr;
+    if (!std::strcmp(which, "k1")) e = &c->ev_k1;
+    else if (!std::strcmp(which, "k2")) e = &c->ev_k2;
+    else if (!std::strcmp(which, "k2prep")) e = &c->ev_k2prep;
+    D2G_CHECK(c, e != nullptr, "d2g_kernel_ms: unknown kernel name");
+    D2G_HIP(c, hipSetDevice(c->device));
+    double sum = 0;
+    float last = 0.f;
+    for (size_t i = 0; i < e->a.size(); ++i) {
+        D2G_HIP(c, hipEventSynchronize(e->b[i]));
+        D2G_HIP(c, hipEventElapsedTime(&last, e->a[i], e->b[i]));
+        sum += last;
+    }
+    const int n = (int)e->a.size();
+    if (count) *count = n;
+    if (avg_ms) *avg_ms = n ? (float)(sum / n) : 0.f;
+    if (last_ms) *last_ms = last;
+    if (reset) {
+        for (hipEvent_t x : e->a) (void)hipEventDestroy(x);
+        for (hipEvent_t x : e->b) (void)hipEventDestroy(x);
+        e->a.clear(); e->b.clear();
+    }
+    return D2G_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+"""Deterministic synthetic inputs for tests and bench.py.
+
+* genomes: i.i.d. uniform ACGT from splitmix64(0xD2D2 + index), optional mutated families
+* sketches: valid One-Permutation register matrices with planted shared registers, so that
+  pairwise equality counts span 0..S (clustered collections look like this in practice)
+This module only produces INPUTS; it computes nothing that is part of the hot path.
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64_stream(seed, n):
+    """n uint64 values of the splitmix64 sequence started at `seed` (vectorised)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def random_genome(index, length, seed=0xD2D2):
+    """uint8 array of ASCII ACGT, 2 bits per base from splitmix64(seed + index)."""
+    nwords = (length + 31) // 32
+    w = splitmix64_stream(seed + index, nwords)
+    shifts = (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :]
+    codes = ((w[:, None] >> shifts) & np.uint64(3)).astype(np.uint8).reshape(-1)[:length]
+    return np.frombuffer(b"ACGT", np.uint8)[codes]
+
+
+def mutate(genome, rate, seed):
+    """per-base substitution with probability `rate` (always to a different base)."""
+    rng = np.random.default_rng(seed)
+    g = genome.copy()
+    hit = rng.random(g.size) < rate
+    lut = np.zeros(256, np.uint8)
+    lut[list(b"ACGT")] = [0, 1, 2, 3]
+    codes = lut[g[hit]]
+    codes = (codes + rng.integers(1, 4, codes.size).astype(np.uint8)) & 3
+    g[hit] = np.frombuffer(b"ACGT", np.uint8)[codes]
+    return g
+
+
+def fasta_bytes(name, genome, width=80):
+    body = genome.tobytes()
+    lines = [body[i:i + width] for i in range(0, len(body), width)]
+    return b">" + name.encode() + b"\n" + b"\n".join(lines) + b"\n"
+
+
+def write_fasta(path, name, genome, width=80):
+    with open(path, "wb") as f:
+        f.write(fasta_bytes(name, genome, width))
+
+
+def synthetic_registers(N, S, nclusters=64, seed=1234, expected_kmers_per_bucket=4883, share_lo=0.0, share_hi=0.98):
+    """OPH-like u64 register matrix [N][S] with planted equalities.
+
+    register value model: min of ~expected_kmers_per_bucket uniform 64-bit hashes whose
+    residue mod S is the bucket index (what K1 produces for a ~5 Mbp genome at S=1024).
+    Sketch j belongs to cluster j % nclusters and copies each register from its cluster parent
+    with probability f_j (f_j spread over [share_lo, share_hi]), else draws a fresh value.
+    """
+    rng = np.random.default_rng(seed)
+    S = int(S)
+
+    def draw(shape):
+        # min of n uniforms ~ Exp(n)/2^-64 ; quantise so that value % S == bucket when S | 2^64
+        u = rng.exponential(1.0 / expected_kmers_per_bucket, size=shape)
+        v = np.minimum(u, 0.999999) * float(2 ** 64)
+        v = v.astype(np.uint64)
+        t = np.arange(S, dtype=np.uint64)
+        t = np.broadcast_to(t, shape)
+        if S & (S - 1) == 0:
+            v = (v & ~np.uint64(S - 1)) | t
+        else:
+            v = v - (v % np.uint64(S)) + t
+        return v
+
+    parents = draw((nclusters, S))
+    regs = draw((N, S))
+    f = rng.uniform(share_lo, share_hi, size=N)
+    take = rng.random((N, S)) < f[:, None]
+    cl = np.arange(N) % nclusters
+    regs = np.where(take, parents[cl], regs)
+    return regs.astype(np.uint64)

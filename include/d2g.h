@@ -1,0 +1,219 @@
+/*
+ * d2g.h -- C ABI of libd2g.so: the MI355X (gfx950) implementation of dashing2's two
+ * data-parallel hot paths.  This is the drop-in boundary: plain pointers and sizes,
+ * no C++ / torch types, no exceptions across the ABI.
+ *
+ * dashing2 has no FFI of its own; the seams this library replaces are the C++ calls
+ *   fastx2sketch()      reference src/fastxsketch.h:66   (called at sketch_core.cpp:31)
+ *   cmp_core()/compare()/emit_rectangular()   reference src/cmp_main.h:130-132
+ * INTEGRATION.md shows the few lines a dashing2 maintainer would add at those seams.
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative d2g_status; d2g_strerror() names it and
+ *     d2g_last_error(ctx) carries the HIP/runtime detail.
+ *   - `_dev` entry points take DEVICE pointers (caller-owned, e.g. from d2g_malloc or a
+ *     torch tensor's data_ptr) and a hipStream_t passed as void* (NULL = default stream);
+ *     they enqueue work and do not synchronise.  Entry points without `_dev` take HOST
+ *     pointers, move the data, run, synchronise and copy results back.
+ *   - a d2g_ctx is bound to one GPU and is used by one host thread at a time
+ *     (multi-GPU = one process / one ctx per device).
+ *   - there is NO CPU fallback: without a usable gfx950 device d2g_ctx_create fails.
+ */
+#ifndef D2G_H
+#define D2G_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2G_VERSION_MAJOR 0
+#define D2G_VERSION_MINOR 1
+
+typedef struct d2g_ctx d2g_ctx;
+
+enum d2g_status {
+    D2G_OK = 0,
+    D2G_ERR_INVALID = -1,      /* bad argument (the reference would throw std::invalid_argument) */
+    D2G_ERR_NODEVICE = -2,     /* no usable HIP device */
+    D2G_ERR_HIP = -3,          /* HIP runtime error; see d2g_last_error */
+    D2G_ERR_NOMEM = -4,
+    D2G_ERR_UNSUPPORTED = -5,  /* outside the hot-path scope (e.g. k > 32) */
+    D2G_ERR_IO = -6
+};
+
+/* measures: order of enum Measure, reference src/cmp_main.h:8-17 */
+enum d2g_measure {
+    D2G_SIMILARITY = 0, D2G_CONTAINMENT = 1, D2G_SYMMETRIC_CONTAINMENT = 2,
+    D2G_POISSON_LLR = 3, D2G_INTERSECTION = 4, D2G_UNION_SIZE = 5
+};
+
+/* which all-pairs kernel family to use (d2g_cmp_* `algo` argument) */
+enum d2g_cmp_algo {
+    D2G_CMP_AUTO = 0,       /* bit-sliced when it applies, else direct */
+    D2G_CMP_DIRECT = 1,     /* 64-bit register compare, LDS-tiled */
+    D2G_CMP_BITSLICE = 2    /* per-column dense ids -> bit planes -> v_bitop3/v_bcnt */
+};
+
+/* ---- runtime ------------------------------------------------------------ */
+int         d2g_version(void);                       /* major*1000 + minor */
+const char *d2g_strerror(int status);
+int         d2g_device_count(void);
+int         d2g_ctx_create(int device, d2g_ctx **out);
+void        d2g_ctx_destroy(d2g_ctx *ctx);
+const char *d2g_last_error(const d2g_ctx *ctx);
+int         d2g_ctx_device(const d2g_ctx *ctx);
+int         d2g_sync(d2g_ctx *ctx, void *stream);
+int         d2g_malloc(d2g_ctx *ctx, size_t nbytes, void **dptr);
+int         d2g_free(d2g_ctx *ctx, void *dptr);
+int         d2g_memcpy_h2d(d2g_ctx *ctx, void *dst_dev, const void *src_host, size_t nbytes, void *stream);
+int         d2g_memcpy_d2h(d2g_ctx *ctx, void *dst_host, const void *src_dev, size_t nbytes, void *stream);
+/* Per-launch HIP-event timing of the dominant kernels.  With timing enabled every launch of
+ * the K1 kernel ("k1"), the K2 pair kernel ("k2") and the K2 prepare chain ("k2prep") is
+ * bracketed by events recorded on the launch stream; nothing synchronises until d2g_kernel_ms,
+ * which reports the number of logged launches, their average and the last duration (ms) and
+ * optionally clears the log. */
+int         d2g_set_timing(d2g_ctx *ctx, int enabled);
+int         d2g_kernel_ms(d2g_ctx *ctx, const char *which, int reset, int *count, float *avg_ms, float *last_ms);
+
+/* ---- host-side primitives of the path (x86, x87 long double where the reference uses it) ---- */
+/* sketch::hash::WangHash::hash -- reference call sites src/enums.h:136-140, src/oph.h:44-53 */
+uint64_t d2g_wang_hash(uint64_t x);
+/* seed_mask(): reference src/enums.cpp:131-140.  0 -> 0 (CLI default, sketch_main.cpp:112) */
+uint64_t d2g_seed_mask(uint64_t seedseed);
+/* DHasher xor constant seed_ ^ 0x533f8c2151b20f97: reference src/oph.h:44-53,59,142 */
+uint64_t d2g_oph_xor_const(void);
+/* LazyOnePermSetSketch ctor: m = S rounded up to even. reference src/oph.h:143-146 */
+size_t   d2g_oph_m(size_t sketchsize);
+/* getcard(): reference src/oph.h:240-247 */
+double   d2g_oph_card(const uint64_t *regs, size_t m);
+/* data(): u64 registers -> double signatures. reference src/oph.h:248-263 */
+int      d2g_oph_signatures(const uint64_t *regs, size_t m, double *sig_out /* [m] */);
+/* both, for n sketches; writes the first S of each m (reference src/fastxsketch.cpp:605,610) */
+int      d2g_oph_finalize(const uint64_t *regs /* [n][m] */, size_t n, size_t m, size_t sketchsize,
+                          double *sigs_out /* [n][S] */, double *cards_out /* [n] */, int nthreads);
+/* densify(): reference src/cmp_core.cpp:577-613 (caller 686-718). In place. Returns #filled via *nfilled. */
+int      d2g_densify(double *sigs /* [n][S] */, size_t n, size_t sketchsize, size_t *nfilled, int nthreads);
+/* compare() epilogues: reference src/cmp_core.cpp:458-494 (set space, from gt/lt) and
+ * 495-517 (multiset space, from neq), both followed by 573-575. */
+float    d2g_epilogue_gtlt(uint64_t gt, uint64_t lt, size_t sketchsize, double lhcard, double rhcard,
+                           int measure, int k);
+float    d2g_epilogue_neq(uint64_t neq, size_t sketchsize, double lhcard, double rhcard, int measure, int k);
+/* table t[neq] = epilogue for card-independent measures (SIMILARITY, POISSON_LLR) when the
+ * value depends on neq only (power-of-two S in set space; any S in multiset space).
+ * Returns D2G_ERR_UNSUPPORTED otherwise. lut_out has S+1 floats. */
+int      d2g_epilogue_lut(size_t sketchsize, int measure, int k, int multiset_space, float *lut_out);
+
+/* ---- host ingest: FASTA/FASTQ(.gz) -> packed run stream (input of K1) -------------
+ * Replaces the parsing half of bns::Encoder::for_each + kseq (reference call sites
+ * src/fastxsketch.cpp:383-424 ; src/d2.h:52-71 for_each_substr ; src/d2.h:273-305 KSeqHolder).
+ * One "genome" = one input line of the reference (a path, or several space-separated paths
+ * that feed the same sketch).  Records and non-ACGT bytes end a run; runs shorter than k
+ * are dropped (they contain no k-mer). */
+typedef struct d2g_seqpack d2g_seqpack;
+int  d2g_seqpack_create(int k, d2g_seqpack **out);
+void d2g_seqpack_destroy(d2g_seqpack *sp);
+/* appends one genome from a file "line" (gz transparently via zlib). */
+int  d2g_seqpack_add_path(d2g_seqpack *sp, const char *path_line);
+/* appends one genome from an in-memory FASTA/FASTQ buffer */
+int  d2g_seqpack_add_fastx(d2g_seqpack *sp, const char *buf, size_t len);
+/* appends one genome consisting of a single raw sequence (no header) */
+int  d2g_seqpack_add_sequence(d2g_seqpack *sp, const char *seq, size_t len);
+size_t          d2g_seqpack_ngenomes(const d2g_seqpack *sp);
+size_t          d2g_seqpack_nruns(const d2g_seqpack *sp);
+size_t          d2g_seqpack_packed_bytes(const d2g_seqpack *sp);   /* including the 64-byte pad */
+const uint8_t  *d2g_seqpack_packed(const d2g_seqpack *sp);
+const uint64_t *d2g_seqpack_run_start(const d2g_seqpack *sp);
+const uint32_t *d2g_seqpack_run_len(const d2g_seqpack *sp);
+const uint64_t *d2g_seqpack_genome_run_off(const d2g_seqpack *sp);  /* [ngenomes+1] */
+uint64_t        d2g_seqpack_nkmers(const d2g_seqpack *sp, size_t genome); /* = total_updates */
+uint64_t        d2g_seqpack_nbases(const d2g_seqpack *sp);           /* bases stored */
+
+/* ---- K1: 2-bit packed bases -> OPH registers ---------------------------------
+ * Replaces the per-k-mer chain bns::Encoder::for_each -> maskfn -> OPSetSketch::update
+ * (reference src/fastxsketch.cpp:383-424,565 ; src/enums.h:136-140 ; src/oph.h:176-211).
+ *
+ * Input layout ("packed run stream"):
+ *   packed      2 bits per base, A0 C1 G2 T3, base p at bits [2(p%4), 2(p%4)+2) of byte p/4.
+ *               Only the maximal ACGT runs of length >= k are stored, back to back; the
+ *               buffer must be padded with >= 64 readable bytes after the last base.
+ *   run_start   [nrun]   first base (index into the packed stream) of each run
+ *   run_len     [nrun]   run length in bases (>= k)
+ *   genome_run_off [n+1] runs of genome g are [genome_run_off[g], genome_run_off[g+1])
+ * k-mers never span runs (window resets at non-ACGT bytes and record boundaries).
+ * Output: regs_out[n][m] (m = d2g_oph_m(S)), each register = min OPH id of its bucket or ~0.
+ */
+int d2g_oph_sketch(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes,
+                   const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
+                   const uint64_t *genome_run_off, size_t n,
+                   int k, int canon, uint64_t xormask, size_t sketchsize,
+                   uint64_t *regs_out /* host [n][m] */);
+/* device-resident form. plan = host-built launch plan (d2g_oph_plan_*); all other pointers device. */
+typedef struct d2g_oph_plan d2g_oph_plan;
+int  d2g_oph_plan_create(d2g_ctx *ctx, const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
+                         const uint64_t *genome_run_off, size_t n, int k, d2g_oph_plan **out);
+void d2g_oph_plan_destroy(d2g_oph_plan *plan);
+uint64_t d2g_oph_plan_nkmers(const d2g_oph_plan *plan);   /* total k-mers the plan covers */
+uint64_t d2g_oph_plan_nbases(const d2g_oph_plan *plan);   /* total bases in the runs */
+int  d2g_oph_sketch_dev(d2g_ctx *ctx, const d2g_oph_plan *plan, const uint8_t *packed_dev,
+                        int canon, uint64_t xormask, size_t sketchsize,
+                        uint64_t *regs_out_dev /* [n][m] */, void *stream);
+
+/* ---- K2: dense all-pairs comparison -------------------------------------------
+ * Replaces HOT LOOP B: emit_rectangular's row loops calling compare()
+ * (reference src/emitrect.cpp:211-323 ; src/cmp_core.cpp:349-361,458-517).
+ * sig_bits = the N x S signature matrix as raw 64-bit patterns (the doubles of
+ * SketchingResult::signatures_, or u64 k-mer ids), row-major.  Equality of the bit
+ * patterns == equality of the doubles (all signatures are >= +0.0 and never NaN).
+ *
+ * "ut" = condensed upper triangle in the reference's order (0,1),(0,2)...(0,N-1),(1,2)...
+ * restricted to rows [r0, r1): out has sum_{r=r0}^{r1-1} (N-r-1) entries.
+ */
+size_t d2g_ut_count(size_t N, size_t r0, size_t r1);
+/* prepared operand for repeated / sharded comparisons (device resident) */
+typedef struct d2g_cmp_set d2g_cmp_set;
+int  d2g_cmp_set_create_dev(d2g_ctx *ctx, const uint64_t *sig_bits_dev, size_t N, size_t sketchsize,
+                            int algo, void *stream, d2g_cmp_set **out);
+int  d2g_cmp_set_create(d2g_ctx *ctx, const uint64_t *sig_bits_host, size_t N, size_t sketchsize,
+                        int algo, d2g_cmp_set **out);
+/* re-load an existing set with a new N x S matrix of the same shape, reusing every device
+ * buffer (no allocation, no host synchronisation: the whole prepare chain is enqueued on `stream`) */
+int  d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, void *stream);
+/* bit-sliced sets: max distinct values in any register column and the resulting plane count
+ * (synchronises `stream`); both 0 for a DIRECT set */
+int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits);
+void d2g_cmp_set_destroy(d2g_cmp_set *set);
+int  d2g_cmp_set_algo(const d2g_cmp_set *set);      /* the algorithm actually selected */
+/* equality counts (u32) for rows [r0,r1) of the upper triangle */
+int  d2g_cmp_eqcount_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
+                            uint32_t *neq_out_dev, void *stream);
+/* fused table epilogue: out = lut[neq] (lut_dev: S+1 floats, see d2g_epilogue_lut) */
+int  d2g_cmp_lut_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
+                        const float *lut_dev, float *out_dev, void *stream);
+/* (#a>b, #a<b) counts per pair (direct algorithm only; needed when S is not a power of two) */
+int  d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
+                         uint32_t *gt_out_dev, uint32_t *lt_out_dev, void *stream);
+/* rectangular block: rows [a0,a1) x cols [b0,b1) of the full N x N equality-count matrix,
+ * row-major (asymmetric all-pairs = [0,N)x[0,N); panel = refs x queries). emitrect.cpp:211-268 */
+int  d2g_cmp_eqcount_rect_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1,
+                              size_t b0, size_t b1, uint32_t *neq_out_dev, void *stream);
+
+/* host-pointer conveniences (H2D, run, D2H, sync) */
+int  d2g_cmp_eqcount_ut(d2g_ctx *ctx, const uint64_t *sig_bits, size_t N, size_t sketchsize,
+                        size_t r0, size_t r1, int algo, uint32_t *neq_out);
+/* full compare(): float distances for rows [r0,r1) with the reference's epilogue arithmetic.
+ * cards = SketchingResult::cardinalities_; multiset_space selects cmp_core.cpp:495-517. */
+int  d2g_cmp_dist_ut(d2g_ctx *ctx, const uint64_t *sig_bits, const double *cards, size_t N,
+                     size_t sketchsize, size_t r0, size_t r1, int measure, int k, int multiset_space,
+                     int algo, int nthreads, float *out);
+
+/* ---- multi-GPU row partition (host arithmetic; emitrect.cpp:290-323 row order) ----
+ * Splits rows [0,N) into `nparts` contiguous ranges with (near-)equal pair counts.
+ * bounds_out has nparts+1 entries. */
+int  d2g_ut_partition(size_t N, int nparts, size_t *bounds_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

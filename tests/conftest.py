@@ -1,0 +1,40 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU restatement of the reference (test infrastructure)."""
+    from oracle import oracle as O
+    O.load()
+    return O
+
+
+@pytest.fixture(scope="session")
+def d2g():
+    """The product: ctypes mirror of the C ABI of libd2g.so (built if absent)."""
+    import dashing2_amd as D
+    if not os.path.exists(D.LIB_PATH):
+        D.build()
+    D.lib()
+    return D
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(d2g):
+    """A device context; only used by -m gpu tests. Fails loudly without a gfx950 GPU."""
+    ctx = d2g.Context(0)
+    yield ctx
+    ctx.close()

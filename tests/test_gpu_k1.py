@@ -1,0 +1,113 @@
+"""GPU parity tests for K1 (2-bit packed bases -> OPH registers): the HIP kernel, called through
+the C ABI, must reproduce the oracle's uint64 registers BIT-EXACTLY."""
+import numpy as np
+import pytest
+
+from dashing2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _messy_fasta(rng, nrec, maxlen, with_n=True):
+    recs = []
+    for r in range(nrec):
+        L = int(rng.integers(0, maxlen))
+        g = synth.random_genome(int(rng.integers(0, 1 << 30)), max(L, 1))[:L].copy()
+        if with_n and L > 10:
+            for _ in range(int(rng.integers(0, 4))):
+                a = int(rng.integers(0, L - 1))
+                g[a:a + int(rng.integers(1, 40))] = ord("N")
+        if r % 3 == 1:
+            g = np.frombuffer(bytes(g).lower(), np.uint8)
+        recs.append(synth.fasta_bytes(f"rec{r}", g, width=int(rng.integers(20, 90))))
+    return b"".join(recs)
+
+
+@pytest.mark.parametrize("k,S,canon,xormask", [
+    (31, 1024, True, 0),              # BASELINE config (CLI default: XORMASK = 0, canon on)
+    (21, 2048, True, 0),
+    (32, 1024, True, 0),              # k = 32: full 64-bit k-mers
+    (31, 1024, False, 0),
+    (31, 1000, True, 0),              # non power-of-two m: (uint32_t)id % m
+    (15, 63, True, 0),                # odd S -> m = 64
+    (5, 16, True, 0x724526e320f9967d),  # library-default XORMASK (enums.cpp:131)
+    (1, 8, False, 0),
+    (27, 4096, True, 12345),
+])
+def test_k1_registers_bit_exact(gpu_ctx, d2g, oracle, k, S, canon, xormask):
+    rng = np.random.default_rng(k * 1000 + S)
+    genomes = [
+        _messy_fasta(rng, 5, 5000),
+        synth.fasta_bytes("clean", synth.random_genome(7, 200000)),     # > 1 workgroup of chunks
+        _messy_fasta(rng, 40, 300),                                     # many short runs (read-like)
+        b">tiny\nACG\n",                                                # shorter than k (mostly)
+        b"",                                                            # empty input
+        synth.fasta_bytes("b", synth.random_genome(9, 70000)) + synth.fasta_bytes("c", synth.random_genome(10, 1234)),
+    ]
+    sp = d2g.SeqPack(k)
+    for g in genomes:
+        sp.add_fastx(g)
+    regs = gpu_ctx.oph_sketch_seqpack(sp, S, canon=canon, xormask=xormask)
+    m = d2g.oph_m(S)
+    assert regs.shape == (len(genomes), m)
+    for gi, g in enumerate(genomes):
+        eregs, esig, ecard, enk = oracle.sketch_buffer(g, k=k, canon=canon, xormask=xormask, S=S)
+        assert sp.nkmers(gi) == enk
+        np.testing.assert_array_equal(regs[gi], eregs, err_msg=f"genome {gi}")
+    # host finalisation of the GPU registers == oracle doubles / cardinalities, bit for bit
+    sigs, cards = d2g.oph_finalize(regs, S)
+    for gi, g in enumerate(genomes):
+        _, esig, ecard, _ = oracle.sketch_buffer(g, k=k, canon=canon, xormask=xormask, S=S)
+        np.testing.assert_array_equal(sigs[gi].view(np.uint64), esig.view(np.uint64))
+        assert np.float64(cards[gi]).view(np.uint64) == np.float64(ecard).view(np.uint64)
+
+
+def test_k1_split_invariance(gpu_ctx, d2g):
+    """OPH min is associative/commutative: sketching a genome as one run or as overlapping pieces
+    (k-1 overlap) or with its records in another order gives identical registers."""
+    k, S = 31, 1024
+    g = synth.random_genome(42, 300000)
+    sp = d2g.SeqPack(k)
+    sp.add_sequence(g.tobytes())
+    # same bases presented as 3 records with k-1 overlap => same k-mer multiset
+    cut1, cut2 = 100000, 200007
+    fa = (synth.fasta_bytes("a", g[:cut1 + k - 1]) + synth.fasta_bytes("b", g[cut1:cut2 + k - 1]) +
+          synth.fasta_bytes("c", g[cut2:]))
+    sp.add_fastx(fa)
+    regs = gpu_ctx.oph_sketch_seqpack(sp, S)
+    np.testing.assert_array_equal(regs[0], regs[1])
+    # canonical k-mers: reverse complement gives the same sketch
+    rc = g[::-1].tobytes().translate(bytes.maketrans(b"ACGT", b"TGCA"))
+    sp2 = d2g.SeqPack(k)
+    sp2.add_sequence(rc)
+    regs2 = gpu_ctx.oph_sketch_seqpack(sp2, S)
+    np.testing.assert_array_equal(regs[0], regs2[0])
+
+
+def test_k1_full_size_cardinality(gpu_ctx, d2g):
+    """BASELINE-size genome (5 Mbp, k=31, S=1024): statistical known-answer of test/oph.cpp
+    (|card - n|/n ~ 1/sqrt(m)) on the GPU registers, plus idempotence of a second run."""
+    k, S, L = 31, 1024, 5_000_000
+    g = synth.random_genome(3, L)
+    sp = d2g.SeqPack(k)
+    sp.add_sequence(g.tobytes())
+    regs = gpu_ctx.oph_sketch_seqpack(sp, S)
+    regs_again = gpu_ctx.oph_sketch_seqpack(sp, S)
+    np.testing.assert_array_equal(regs, regs_again)
+    sigs, cards = d2g.oph_finalize(regs, S)
+    n = L - k + 1                      # random 31-mers: essentially all distinct
+    assert abs(cards[0] - n) / n < 4 / np.sqrt(S)
+    assert (regs[0] != np.uint64(2 ** 64 - 1)).all()
+    assert ((regs[0] & np.uint64(S - 1)) == np.arange(S, dtype=np.uint64)).all()   # id mod m == bucket
+
+
+def test_k1_rejects_bad_input(gpu_ctx, d2g):
+    sp = d2g.SeqPack(31)
+    sp.add_sequence(synth.random_genome(1, 1000).tobytes())
+    packed, rs, rl, go = sp.arrays()
+    with pytest.raises(d2g.D2GError):
+        gpu_ctx.oph_sketch(packed[:-64], rs, rl, go, 31, 1024)      # missing tail pad
+    with pytest.raises(d2g.D2GError):
+        gpu_ctx.oph_sketch(packed, rs, rl, go, 33, 1024)            # k > 32 unsupported
+    with pytest.raises(d2g.D2GError):
+        gpu_ctx.oph_sketch(packed, rs, (rl * 0 + 5).astype(np.uint32), go, 31, 1024)   # run shorter than k

@@ -1,0 +1,186 @@
+"""GPU parity tests for K2 (dense all-pairs comparison) through the C ABI.
+Integer counts are compared BIT-EXACTLY with the oracle and with the reference's own NumPy
+implementation (frozen golden vectors); float32 outputs are compared bit-exactly too
+(tolerance stated by north_star: 1e-6; we hold 0)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from dashing2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = ["direct", "bitslice"]
+
+
+def _algo(d2g, name):
+    return {"direct": d2g.CMP_DIRECT, "bitslice": d2g.CMP_BITSLICE, "auto": d2g.CMP_AUTO}[name]
+
+
+def _planted(rng, N, S, nvals=5, zero_frac=0.05):
+    vals = rng.random((nvals, S))
+    m = vals[rng.integers(0, nvals, (N, S)), np.arange(S)[None, :]]
+    m[rng.random((N, S)) < zero_frac] = 0.0
+    return m
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("name", ["eqcount_n7_s16", "eqcount_n33_s64", "eqcount_n64_s128", "eqcount_n40_s100"])
+def test_k2_golden_reference_numpy(gpu_ctx, d2g, algo, name):
+    """expected = python/parse.py:128-156 pairwise_equality_compare (the reference's own code)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    got = gpu_ctx.cmp_eqcount_ut(z["sigs"].view(np.uint64), algo=_algo(d2g, algo))
+    np.testing.assert_array_equal(got, z["expected"])
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("N,S", [(1, 16), (2, 2), (3, 1024), (65, 32), (257, 64), (300, 1000), (513, 96), (700, 33)])
+def test_k2_eqcount_vs_oracle(gpu_ctx, d2g, oracle, algo, N, S):
+    rng = np.random.default_rng(N * 7 + S)
+    sigs = _planted(rng, N, S, nvals=int(rng.integers(2, 9)))
+    exp = oracle.eqcounts_ut(sigs)
+    cs = gpu_ctx.cmp_set(sigs.view(np.uint64), algo=_algo(d2g, algo))
+    assert cs.algo == _algo(d2g, algo)
+    got = cs.eqcount_ut()
+    np.testing.assert_array_equal(got, exp)
+    # row ranges (what a rank computes when the triangle is sharded) concatenate to the full result
+    b = d2g.ut_partition(N, 3)
+    parts = [cs.eqcount_ut(b[i], b[i + 1]) for i in range(3)]
+    np.testing.assert_array_equal(np.concatenate(parts), exp)
+    # rectangular blocks (asymmetric all-pairs / panel: emitrect.cpp:211-268)
+    full = cs.eqcount_rect(0, N, 0, N)
+    iu = np.triu_indices(N, 1)
+    np.testing.assert_array_equal(full[iu], exp)
+    np.testing.assert_array_equal(full, full.T)
+    np.testing.assert_array_equal(np.diag(full), np.full(N, S, np.uint32))
+    if N > 10:
+        a0, a1, b0, b1 = 3, N // 2, N // 3, N - 1
+        np.testing.assert_array_equal(cs.eqcount_rect(a0, a1, b0, b1), full[a0:a1, b0:b1])
+    cs.close()
+
+
+def test_k2_gtlt_vs_oracle(gpu_ctx, d2g, oracle):
+    rng = np.random.default_rng(99)
+    for N, S in [(37, 100), (130, 64), (260, 1000)]:
+        sigs = _planted(rng, N, S, nvals=4)
+        cs = gpu_ctx.cmp_set(sigs.view(np.uint64), algo=d2g.CMP_DIRECT)
+        gt, lt = cs.gtlt_ut()
+        idx = 0
+        for i in range(N):
+            for j in range(i + 1, N):
+                if (idx % 37) == 0 or N < 50:
+                    eg, el = oracle.count_gtlt(sigs[i], sigs[j])
+                    assert (gt[idx], lt[idx]) == (eg, el)
+                idx += 1
+        eq = oracle.eqcounts_ut(sigs)
+        np.testing.assert_array_equal(S - gt - lt, eq)          # cmp_core.cpp:465 invariant
+        cs.close()
+
+
+@pytest.mark.parametrize("S,multiset", [(64, False), (100, False), (128, True), (100, True)])
+def test_k2_dist_all_measures_bit_exact(gpu_ctx, d2g, oracle, S, multiset):
+    """full compare(): every measure, power-of-two and non-power-of-two S, set and multiset space."""
+    rng = np.random.default_rng(S)
+    N = 61
+    sigs = _planted(rng, N, S, nvals=3, zero_frac=0.0)
+    sigs[7] = sigs[3]                                 # identical pair: sim 1, mash distance 0
+    sigs[9] = rng.random(S) + 2.0                     # disjoint from everything: sim 0, mash distance inf
+    cards = rng.random(N) * 1e6 + 10
+    for meas in range(6):
+        got = gpu_ctx.cmp_dist_ut(sigs.view(np.uint64), cards, measure=meas, k=31, multiset_space=multiset, nthreads=2)
+        if multiset:
+            eq = oracle.eqcounts_ut(sigs)
+            exp = np.empty(eq.size, np.float32)
+            idx = 0
+            for i in range(N):
+                for j in range(i + 1, N):
+                    exp[idx] = oracle.compare_from_neq(int(eq[idx]), S, cards[i], cards[j], meas, 31)
+                    idx += 1
+        else:
+            exp = oracle.allpairs_ut(sigs, cards, measure=meas, k=31, nthreads=2)
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=f"measure {meas}")
+
+
+def test_k2_lut_fused_epilogue(gpu_ctx, d2g, oracle):
+    rng = np.random.default_rng(4)
+    N, S = 300, 1024
+    sigs = _planted(rng, N, S, nvals=6)
+    cards = np.ones(N)
+    for algo in ALGOS:
+        cs = gpu_ctx.cmp_set(sigs.view(np.uint64), algo=_algo(d2g, algo))
+        for meas in (d2g.SIMILARITY, d2g.POISSON_LLR):
+            got = cs.lut_ut(d2g.epilogue_lut(S, meas, 31))
+            exp = oracle.allpairs_ut(sigs, cards, measure=meas, k=31, nthreads=4)
+            np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+        cs.close()
+
+
+def _column_pair_totals(bits):
+    """independent O(N S log N) check values: sum over all pairs of neq, and per-row sums."""
+    N, S = bits.shape
+    row = np.zeros(N, np.int64)
+    total = 0
+    for t in range(S):
+        _, inv, cnt = np.unique(bits[:, t], return_inverse=True, return_counts=True)
+        total += int((cnt.astype(np.int64) * (cnt - 1) // 2).sum())
+        row += cnt[inv] - 1
+    return total, row
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_k2_full_size_properties(gpu_ctx, d2g, algo):
+    """BASELINE config 3 size (N = 10 000, S = 1024): size-independent properties.
+    checksum of checksums: sum_pairs neq == sum_t sum_v C(count_v, 2); row sums likewise;
+    sharded rows == unsharded; symmetric rect block == transposed UT entries."""
+    N, S = 10_000, 1024
+    regs = synth.synthetic_registers(N, S, nclusters=50, seed=7)
+    sigs, _ = d2g.oph_finalize(regs, S, nthreads=8)
+    bits = sigs.view(np.uint64)
+    cs = gpu_ctx.cmp_set(bits, algo=_algo(d2g, algo))
+    neq = cs.eqcount_ut()
+    assert neq.size == N * (N - 1) // 2
+    total, rowsum = _column_pair_totals(bits)
+    assert int(neq.sum(dtype=np.int64)) == total
+    # per-row sums: row i of the symmetric matrix = UT row i + UT column i
+    off = np.concatenate([[0], np.cumsum(N - 1 - np.arange(N))])
+    got_row = np.zeros(N, np.int64)
+    for i in range(N - 1):
+        seg = neq[off[i]:off[i + 1]]
+        got_row[i] += int(seg.sum(dtype=np.int64))       # pairs (i, j>i)
+        got_row[i + 1:] += seg                            # the same pairs seen from j
+    np.testing.assert_array_equal(got_row, rowsum)
+    assert neq.max() <= S
+    # sharding invariance on a few row ranges
+    b = d2g.ut_partition(N, 8)
+    for p in (0, 3, 7):
+        part = cs.eqcount_ut(b[p], b[p + 1])
+        np.testing.assert_array_equal(part, neq[off[b[p]]:off[b[p + 1]]])
+    # rect block consistency
+    blk = cs.eqcount_rect(100, 164, 5000, 5300)
+    for ii in (100, 131, 163):
+        np.testing.assert_array_equal(blk[ii - 100], neq[off[ii] + (5000 - ii - 1): off[ii] + (5300 - ii - 1)])
+    cs.close()
+
+
+def test_k2_direct_equals_bitslice_midsize(gpu_ctx, d2g):
+    N, S = 3000, 2048
+    regs = synth.synthetic_registers(N, S, nclusters=10, seed=11, share_lo=0.5, share_hi=1.0)
+    bits = regs            # raw u64 ids are valid operands too (cmp_core.cpp:497-505 compares k-mers)
+    a = gpu_ctx.cmp_eqcount_ut(bits, algo=d2g.CMP_DIRECT)
+    b = gpu_ctx.cmp_eqcount_ut(bits, algo=d2g.CMP_BITSLICE)
+    np.testing.assert_array_equal(a, b)
+    assert a.max() > S // 2 and a.min() < S // 4
+
+
+def test_k2_rejects_bad_input(gpu_ctx, d2g):
+    sigs = np.zeros((4, 8), np.uint64)
+    cs = gpu_ctx.cmp_set(sigs)
+    with pytest.raises(d2g.D2GError):
+        cs.eqcount_ut(3, 2)
+    with pytest.raises(d2g.D2GError):
+        cs.eqcount_ut(0, 5)
+    with pytest.raises(d2g.D2GError):
+        gpu_ctx.cmp_dist_ut(sigs, np.ones(4), measure=17)
+    cs.close()

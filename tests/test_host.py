@@ -1,0 +1,204 @@
+"""CPU tests of the product's host half (libd2g.so loads without a GPU) against the oracle,
+and of the C-ABI surface: every symbol include/d2g.h declares is exported and bound."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "d2g.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(d2g_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_capi_exports_every_declared_symbol(d2g):
+    syms = _header_symbols()
+    assert len(syms) > 50
+    out = subprocess.check_output(["nm", "-D", "--defined-only", d2g.LIB_PATH], text=True)
+    exported = set(l.split()[-1] for l in out.splitlines() if " T " in l)
+    missing = [s for s in syms if s not in exported]
+    assert not missing, f"declared in d2g.h but not exported: {missing}"
+    from dashing2_amd import capi
+    unbound = [s for s in syms if s not in capi.SIGNATURES]
+    assert not unbound, f"declared in d2g.h but not bound in capi.py: {unbound}"
+    L = d2g.lib()
+    for s in syms:
+        assert hasattr(L, s)
+    assert L.d2g_version() == 1
+
+
+def test_no_gpu_means_loud_failure(d2g):
+    """Without a usable gfx950 device the product refuses to run: there is no CPU fallback."""
+    if d2g.lib().d2g_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(d2g.D2GError):
+        d2g.Context(0)
+
+
+def test_host_primitives_match_oracle(d2g, oracle):
+    lib = oracle.load()
+    for x in [0, 1, 133348, 2 ** 63, 2 ** 64 - 1, 0x0123456789abcdef]:
+        assert d2g.wang_hash(x) == oracle.wang_hash(x)
+    assert d2g.oph_xor_const() == lib.d2o_oph_xor_const() == 0xdc271ad2a9ecfb34
+    for s in [0, 1, 13, 2 ** 40 + 7]:
+        assert d2g.seed_mask(s) == lib.d2o_seed_mask(s)
+    for S in [1, 2, 15, 16, 1000, 1023, 1024]:
+        assert d2g.oph_m(S) == S + (S & 1)
+
+
+def test_oph_finalize_bit_exact(d2g, oracle):
+    rng = np.random.default_rng(3)
+    for S in [16, 15, 100, 1024]:
+        m = d2g.oph_m(S)
+        n = 7
+        regs = rng.integers(0, 2 ** 63, size=(n, m), dtype=np.uint64) >> np.uint64(rng.integers(0, 20))
+        regs[0, :3] = np.uint64(2 ** 64 - 1)           # empty buckets
+        regs[1, 0] = 0                                 # zero register -> 0 signature
+        regs[2, :] = np.uint64(2 ** 64 - 1)            # fully empty sketch -> card inf? (sum != 0) fine
+        sigs, cards = d2g.oph_finalize(regs, S, nthreads=2)
+        for g in range(n):
+            esig, ecard = oracle.regs_finalize(regs[g])
+            np.testing.assert_array_equal(sigs[g].view(np.uint64), esig[:S].view(np.uint64))
+            assert np.float64(cards[g]).view(np.uint64) == np.float64(ecard).view(np.uint64)
+
+
+def test_densify_matches_oracle(d2g, oracle):
+    rng = np.random.default_rng(8)
+    S, n = 128, 9
+    sigs = rng.random((n, S))
+    sigs[rng.random((n, S)) < 0.4] = 0.0
+    sigs[3] = 0.0
+    out, nf = d2g.densify(sigs, nthreads=2)
+    tot = 0
+    for g in range(n):
+        e, ne = oracle.densify(sigs[g])
+        np.testing.assert_array_equal(out[g], e)
+        tot += ne
+    assert nf == tot
+
+
+@pytest.mark.parametrize("S", [64, 100, 1024, 1000])
+def test_epilogues_match_oracle(d2g, oracle, S):
+    rng = np.random.default_rng(S)
+    for _ in range(300):
+        gt = int(rng.integers(0, S + 1))
+        lt = int(rng.integers(0, S - gt + 1))
+        lh, rh = float(rng.random() * 1e7 + 1), float(rng.random() * 1e7 + 1)
+        for meas in range(6):
+            a = d2g.epilogue_gtlt(gt, lt, S, lh, rh, meas, 31)
+            b = oracle.compare_from_gtlt(gt, lt, S, lh, rh, meas, 31)
+            assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), (gt, lt, meas)
+            a = d2g.epilogue_neq(S - gt - lt, S, lh, rh, meas, 21)
+            b = oracle.compare_from_neq(S - gt - lt, S, lh, rh, meas, 21)
+            assert np.float32(a).view(np.uint32) == np.float32(b).view(np.uint32), (gt, lt, meas, "neq")
+
+
+def test_epilogue_lut(d2g, oracle):
+    lut = d2g.epilogue_lut(1024, d2g.SIMILARITY, 31)
+    np.testing.assert_array_equal(lut, (np.arange(1025, dtype=np.float32) / np.float32(1024)))
+    lut = d2g.epilogue_lut(1024, d2g.POISSON_LLR, 31)
+    assert lut[0] == np.inf and lut[1024] == 0.0
+    for e in [1, 17, 512, 1000]:
+        assert lut[e] == np.float32(oracle.compare_from_gtlt(1024 - e, 0, 1024, 1., 1., oracle.POISSON_LLR, 31))
+    # set space, non power-of-two S: value depends on (gt, lt) separately -> no table
+    with pytest.raises(d2g.D2GError):
+        d2g.epilogue_lut(1000, d2g.SIMILARITY, 31)
+    # card-dependent measure -> no table
+    with pytest.raises(d2g.D2GError):
+        d2g.epilogue_lut(1024, d2g.INTERSECTION, 31)
+    lut = d2g.epilogue_lut(1000, d2g.SIMILARITY, 31, multiset_space=True)
+    for e in [0, 3, 999, 1000]:
+        assert lut[e] == np.float32(oracle.compare_from_neq(e, 1000, 1., 1., oracle.SIMILARITY, 31))
+
+
+def test_ut_count_and_partition(d2g):
+    for N in [0, 1, 2, 5, 100, 1001]:
+        assert d2g.ut_count(N) == N * (N - 1) // 2
+        for r0, r1 in [(0, 0), (0, 1), (1, N), (N // 3, N // 2), (N, N)]:
+            if r0 <= r1 <= N:
+                assert d2g.ut_count(N, r0, r1) == sum(N - 1 - r for r in range(r0, r1))
+    for N, P in [(10, 3), (1000, 8), (10000, 8), (50000, 8), (5, 8), (1, 2)]:
+        b = d2g.ut_partition(N, P)
+        assert b[0] == 0 and b[-1] == N and all(x <= y for x, y in zip(b, b[1:]))
+        cnt = [d2g.ut_count(N, b[i], b[i + 1]) for i in range(P)]
+        assert sum(cnt) == N * (N - 1) // 2
+        if N >= 1000:
+            assert max(cnt) <= 1.02 * (sum(cnt) / P) + N     # balanced to within one row
+
+
+def _decode_runs(packed, rs, rl):
+    out = []
+    for s, l in zip(rs.tolist(), rl.tolist()):
+        idx = np.arange(s, s + l)
+        codes = (packed[idx >> 2] >> ((idx & 3) * 2).astype(np.uint8)) & 3
+        out.append(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes())
+    return out
+
+
+def test_seqpack_runs_and_kmer_counts(d2g, oracle):
+    fa = (b">r1 desc\nACGTNNACGTACGTTTGA\nCCAGT\n>r2\nacgtgatcgatgctagctagc\r\n>r3\nAC\n"
+          b">r4\nGGGGGGGGGGGGNGGGGG\n")
+    for k in [3, 5, 11]:
+        sp = d2g.SeqPack(k)
+        sp.add_fastx(fa)
+        sp.add_sequence(b"ACGTTGCATTGACNNNNACGTAGCTAGCTAGCATCGATCGAT")
+        sp.add_fastx(b"")                     # empty genome
+        packed, rs, rl, go = sp.arrays()
+        assert sp.ngenomes == 3 and go[-1] == rs.size
+        assert (rl >= k).all()
+        # k-mer count equals the oracle's (== total_updates of the reference sketch)
+        assert sp.nkmers(0) == oracle.sketch_buffer(fa, k=k, S=8)[3]
+        assert sp.nkmers(2) == 0
+        runs = _decode_runs(packed, rs, rl)
+        import re as _re
+        exp = [r.upper() for rec in [b"ACGTNNACGTACGTTTGACCAGT", b"acgtgatcgatgctagctagc", b"AC", b"GGGGGGGGGGGGNGGGGG"]
+               for r in _re.split(rb"[^ACGTacgt]+", rec) if len(r) >= k]
+        assert runs[:int(go[1])] == exp
+        assert packed.size >= (sp.nbases + 3) // 4 + 64      # tail pad for the kernel's window reads
+        sp.close()
+    with pytest.raises(d2g.D2GError):
+        d2g.SeqPack(33)                        # k > 32 is the reference's rolling-hash path: unsupported
+
+
+def test_seqpack_gz_and_multipath(d2g, oracle, tmp_path):
+    import gzip
+    from dashing2_amd import synth
+    g1, g2 = synth.random_genome(1, 3000), synth.random_genome(2, 2500)
+    p1, p2 = tmp_path / "a.fa", tmp_path / "b.fa.gz"
+    synth.write_fasta(p1, "a", g1)
+    with gzip.open(p2, "wb") as f:
+        f.write(synth.fasta_bytes("b", g2))
+    sp = d2g.SeqPack(21)
+    sp.add_path(f"{p1} {p2}")                 # one "line" with two sub-paths feeds ONE sketch (d2.h:52-71)
+    sp.add_path(str(p2))
+    assert sp.ngenomes == 2
+    assert sp.nkmers(0) == (3000 - 20) + (2500 - 20)
+    assert sp.nkmers(1) == 2500 - 20
+    assert oracle.sketch_file(f"{p1} {p2}", k=21, S=64)[3] == sp.nkmers(0)
+    with pytest.raises(d2g.D2GError):
+        sp.add_path(str(tmp_path / "missing.fa"))
+
+
+def test_format_fixture_roundtrip():
+    """tests/golden/stacked_*.bin parsed by the reference's python/parse.py (frozen) has the layout
+    [u64 N][u64 S][f64 card x N][f64 x N*S]  (sketch_core.cpp:130-140, cmp_main.cpp:61-94)."""
+    raw = np.fromfile(os.path.join(GOLDEN, "stacked_n5_s32.bin"), np.uint8)
+    exp = np.load(os.path.join(GOLDEN, "stacked_n5_s32.expected.npz"))
+    n, s = raw[:16].view(np.uint64)
+    assert n == exp["nseqs"] == 5 and s == 32
+    np.testing.assert_array_equal(raw[16:16 + 8 * n].view(np.float64), exp["cardinalities"])
+    np.testing.assert_array_equal(raw[16 + 8 * n:].view(np.float64).reshape(n, s), exp["signatures"])
+    one = np.fromfile(os.path.join(GOLDEN, "sketch_s32.opss"), np.float64)
+    e1 = np.load(os.path.join(GOLDEN, "sketch_s32.expected.npz"))
+    assert one[0] == e1["cardinality"]
+    np.testing.assert_array_equal(one[1:], e1["signatures"])
+    # convert_sketches_to_packed_sketch output == the stacked layout of the first 3 sketches
+    pk = np.fromfile(os.path.join(GOLDEN, "packed_from_singles.bin"), np.uint8)
+    assert tuple(pk[:16].view(np.uint64)) == (3, 32)
+    np.testing.assert_array_equal(pk[16:16 + 24].view(np.float64), exp["cardinalities"][:3])
+    np.testing.assert_array_equal(pk[40:].view(np.float64).reshape(3, 32), exp["signatures"][:3])
