@@ -430,13 +430,12 @@ class CmpSet:
     # host-returning helpers built on the raw device-memory calls
     def eqcount_ut(self, r0=0, r1=None):
         r1 = self.N if r1 is None else r1
-        out = np.empty(ut_count(self.N, r0, r1), np.uint32)
-        if out.size == 0:
-            return out
-        d = self.ctx.malloc(out.nbytes)
+        out = np.empty(ut_count(self.N, r0, r1) if r0 <= r1 <= self.N else 0, np.uint32)
+        d = self.ctx.malloc(max(out.nbytes, 4))
         try:
             self.eqcount_ut_dev(d, r0, r1)
-            self.ctx.d2h(out, d)
+            if out.size:
+                self.ctx.d2h(out, d)
         finally:
             self.ctx.free(d)
         return out

@@ -20,6 +20,7 @@
 #include "d2g_k2.h"
 #include "d2g_k2_shape.h"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -31,16 +32,22 @@ constexpr int BS_RANK_THREADS = 1024;
 // One workgroup per register index t.  owner[] (T slots, pre-set to EMPTY) records the first
 // sketch index that claimed a slot; equality is decided against that sketch's value, so no key
 // storage and no reserved sentinel value is needed.
+template <bool LDS_TABLE>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
                                                                   uint32_t *owner_all, uint32_t T, int logT,
                                                                   uint32_t *ids_all, uint32_t *max_distinct) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];   // LDS_TABLE: T owner slots
     const size_t t = blockIdx.x;
     const uint64_t *col = cols + t * Npad;
-    uint32_t *own = owner_all + t * (size_t)T;
+    uint32_t *own = LDS_TABLE ? lds_tab : owner_all + t * (size_t)T;
     uint32_t *ids = ids_all + t * Npad;
     const int tid = threadIdx.x;
     const uint32_t mask = T - 1;
 
+    if (LDS_TABLE) {
+        for (uint32_t h = tid; h < T; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
+        __syncthreads();
+    }
     for (size_t j = tid; j < N; j += BS_RANK_THREADS) {
         const uint64_t v = col[j];
         uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> (64 - logT));
@@ -61,7 +68,9 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
     const int lane = tid & 63, wave = tid >> 6;
     for (uint32_t base = 0; base < T; base += BS_RANK_THREADS) {
         const uint32_t h = base + tid;
-        const bool occ = h < T && __hip_atomic_load(&own[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BS_EMPTY;
+        uint32_t cur = BS_EMPTY;
+        if (h < T) cur = LDS_TABLE ? own[h] : __hip_atomic_load(&own[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool occ = cur != BS_EMPTY;
         const unsigned long long bal = __ballot(occ);
         const uint32_t before = __popcll(bal & ((1ull << lane) - 1));
         if (lane == 0) wave_tot[wave] = __popcll(bal);
@@ -113,74 +122,116 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
 
 // ------------------------------------------------------------------ 3. the pair kernel
 constexpr int BS_THREADS = 256;
-constexpr int BS_IW = 16;                 // rows per wave (one s_load_dwordx16 per plane)
-constexpr int BS_JR = 4;                  // 64-column groups per lane
-constexpr int BS_RB = 4 * BS_IW;          // 64 rows per workgroup tile
-constexpr int BS_CB = 64 * BS_JR;         // 256 columns per workgroup tile
+constexpr int BS_CB = 256;                // columns per workgroup tile (all variants)
 
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef u32x16 __attribute__((aligned(4))) u32x16_u;
 // v_bitop3_b32 truth table: src0 = 0xF0, src1 = 0xCC, src2 = 0xAA  ->  src2 | (src0 ^ src1)
 constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);
 
-template <class Store>
+// IW = 16 rows per wave (one s_load_dwordx16 per plane), JR = 64-column groups per lane,
+// WC = waves side by side along the columns (WC * JR * 64 = 256), PF = software prefetch of the
+// next plane's operands (register double buffer).
+template <int JR, bool PF, class Store>
 __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
                                                                  const uint32_t *__restrict__ meta, int ntb, uint32_t S,
                                                                  PairShape sh, Store store) {
+    constexpr int IW = 16;
+    constexpr int WC = BS_CB / (64 * JR);          // waves along columns: 1 (JR=4) or 2 (JR=2)
+    constexpr int WR = 4 / WC;                     // waves along rows
+    constexpr int RB = WR * IW;                    // rows per workgroup tile
     const unsigned b = blockIdx.x;
     const unsigned L = (b & 7u) * sh.per_xcd + (b >> 3);      // XCD-contiguous, column-major tiles
     if (L >= sh.nblk) return;
     const unsigned ct = L / sh.nrt, rt = L % sh.nrt;
-    const size_t i0 = sh.i_lo + (size_t)rt * BS_RB;
-    const size_t j0 = (size_t)(sh.ct0 + ct) * BS_CB;
-    if (sh.ut && j0 + BS_CB - 1 <= i0) return;
+    const size_t i0 = sh.i_lo + (size_t)rt * RB;
+    const size_t jt0 = (size_t)(sh.ct0 + ct) * BS_CB;
+    if (sh.ut && jt0 + BS_CB - 1 <= i0) return;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const size_t iw0 = i0 + (size_t)wave * BS_IW;
+    const size_t iw0 = i0 + (size_t)(wave / WC) * IW;
+    const size_t j0 = jt0 + (size_t)(wave % WC) * (64 * JR);
     if (iw0 >= sh.i_hi) return;
-    if (sh.ut && j0 + BS_CB - 1 <= iw0) return;
+    if (sh.ut && j0 + 64 * JR - 1 <= iw0) return;
 
     const int nbits = live_planes(meta);             // uniform (scalar load)
-    uint32_t acc[BS_IW][BS_JR];
+    uint32_t acc[IW][JR];
 #pragma unroll
-    for (int i = 0; i < BS_IW; ++i)
+    for (int i = 0; i < IW; ++i)
 #pragma unroll
-        for (int c = 0; c < BS_JR; ++c) acc[i][c] = 0;
+        for (int c = 0; c < JR; ++c) acc[i][c] = 0;
 
     const uint32_t *prow = planes + iw0;          // uniform: scalar loads
     const uint32_t *pcol = planes + j0 + lane;    // per lane: coalesced dword loads
-    for (int tb = 0; tb < ntb; ++tb) {
-        uint32_t z[BS_IW][BS_JR];
+    const size_t tbstride = (size_t)nbits_cap * Nstride;
+    if (!PF) {
+        for (int tb = 0; tb < ntb; ++tb) {
+            uint32_t z[IW][JR];
 #pragma unroll
-        for (int i = 0; i < BS_IW; ++i)
+            for (int i = 0; i < IW; ++i)
 #pragma unroll
-            for (int c = 0; c < BS_JR; ++c) z[i][c] = 0;
-        const size_t base = (size_t)tb * nbits_cap * Nstride;
+                for (int c = 0; c < JR; ++c) z[i][c] = 0;
+            const size_t base = (size_t)tb * tbstride;
 #pragma unroll 2
-        for (int p = 0; p < nbits; ++p) {
-            const size_t off = base + (size_t)p * Nstride;
-            const u32x16_u sa = *reinterpret_cast<const u32x16_u *>(prow + off);   // s_load_dwordx16
-            uint32_t vb[BS_JR];
+            for (int p = 0; p < nbits; ++p) {
+                const size_t off = base + (size_t)p * Nstride;
+                const u32x16_u sa = *reinterpret_cast<const u32x16_u *>(prow + off);   // s_load_dwordx16
+                uint32_t vb[JR];
 #pragma unroll
-            for (int c = 0; c < BS_JR; ++c) vb[c] = pcol[off + 64 * c];
+                for (int c = 0; c < JR; ++c) vb[c] = pcol[off + 64 * c];
 #pragma unroll
-            for (int i = 0; i < BS_IW; ++i)
+                for (int i = 0; i < IW; ++i)
 #pragma unroll
-                for (int c = 0; c < BS_JR; ++c)
-                    z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+                    for (int c = 0; c < JR; ++c)
+                        z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+            }
+#pragma unroll
+            for (int i = 0; i < IW; ++i)
+#pragma unroll
+                for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);   // -> v_bcnt_u32_b32
         }
+    } else {
+        size_t off_n = 0;
+        u32x16_u sa_n = *reinterpret_cast<const u32x16_u *>(prow);
+        uint32_t vb_n[JR];
 #pragma unroll
-        for (int i = 0; i < BS_IW; ++i)
+        for (int c = 0; c < JR; ++c) vb_n[c] = pcol[64 * c];
+        for (int tb = 0; tb < ntb; ++tb) {
+            uint32_t z[IW][JR];
 #pragma unroll
-            for (int c = 0; c < BS_JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);   // -> v_bcnt_u32_b32
+            for (int i = 0; i < IW; ++i)
+#pragma unroll
+                for (int c = 0; c < JR; ++c) z[i][c] = 0;
+            const size_t next_base = (tb + 1 < ntb) ? (size_t)(tb + 1) * tbstride : 0;   // last: harmless reload of plane 0
+#pragma unroll 2
+            for (int p = 0; p < nbits; ++p) {
+                const u32x16_u sa = sa_n;
+                uint32_t vb[JR];
+#pragma unroll
+                for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
+                off_n = (p + 1 < nbits) ? off_n + Nstride : next_base;
+                sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
+#pragma unroll
+                for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
+#pragma unroll
+                for (int i = 0; i < IW; ++i)
+#pragma unroll
+                    for (int c = 0; c < JR; ++c)
+                        z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+            }
+#pragma unroll
+            for (int i = 0; i < IW; ++i)
+#pragma unroll
+                for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);
+        }
     }
 #pragma unroll
-    for (int i = 0; i < BS_IW; ++i) {
+    for (int i = 0; i < IW; ++i) {
         const size_t ii = iw0 + i;
         if (ii >= sh.i_hi) break;
 #pragma unroll
-        for (int c = 0; c < BS_JR; ++c) {
+        for (int c = 0; c < JR; ++c) {
             const size_t jj = j0 + lane + 64 * c;
             if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii))
                 store(out_pos(sh, ii, jj), S - acc[i][c], 0u);      // padded registers never mismatch
@@ -188,18 +239,35 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
     }
 }
 
+int bs_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("D2G_BS_VARIANT"); v = e ? atoi(e) : 3; }
+    return v;
+}
+
 template <class Store>
 int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
-    sh.nrt = (unsigned)div_up<size_t>(sh.i_hi - sh.i_lo, BS_RB);
+    const int var = bs_variant();            // 0: JR4  1: JR2  2: JR4+prefetch  3: JR2+prefetch
+    const int JR = (var & 1) ? 2 : 4;
+    const int RB = (var & 1) ? 32 : 64;
+    sh.nrt = (unsigned)div_up<size_t>(sh.i_hi - sh.i_lo, RB);
     sh.ct0 = (unsigned)(sh.j_lo / BS_CB);
     sh.nct = (unsigned)(div_up<size_t>(sh.j_hi, BS_CB) - sh.ct0);
     const size_t nblk = (size_t)sh.nrt * sh.nct;
     D2G_CHECK(ctx, nblk < (1ull << 31), "pair tile grid too large; shard rows");
     sh.nblk = (unsigned)nblk;
     sh.per_xcd = (unsigned)div_up<size_t>(nblk, 8);
+    (void)JR;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
-    hipLaunchKernelGGL((k2_bitslice_kernel<Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes,
-                       set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
+#define BS_LAUNCH(JRV, PFV) hipLaunchKernelGGL((k2_bitslice_kernel<JRV, PFV, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, \
+        set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store)
+    switch (var) {
+        case 1: BS_LAUNCH(2, false); break;
+        case 2: BS_LAUNCH(4, true); break;
+        case 3: BS_LAUNCH(2, true); break;
+        default: BS_LAUNCH(4, false); break;
+    }
+#undef BS_LAUNCH
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -225,7 +293,8 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     set->ntb = (int)div_up<size_t>(S, 32);
     set->Nstride = Npad + 64;
     hipError_t e;
-    if ((e = hipMalloc((void **)&set->d_owner, S * (size_t)set->T * sizeof(uint32_t))) != hipSuccess ||
+    const bool lds_table = (size_t)set->T * sizeof(uint32_t) <= 128 * 1024;
+    if ((!lds_table && (e = hipMalloc((void **)&set->d_owner, S * (size_t)set->T * sizeof(uint32_t))) != hipSuccess) ||
         (e = hipMalloc((void **)&set->d_ids, S * Npad * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_meta, 4 * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_planes, (size_t)set->ntb * set->nbits_cap * set->Nstride * sizeof(uint32_t))) != hipSuccess) {
@@ -239,10 +308,20 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 // ids + planes for the operand currently in set->d_cols.  Fully asynchronous on `s`.
 int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
-    D2G_HIP(ctx, hipMemsetAsync(set->d_owner, 0xFF, S * (size_t)set->T * sizeof(uint32_t), s));
     D2G_HIP(ctx, hipMemsetAsync(set->d_meta, 0, 4 * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(bs_rank_kernel, dim3((unsigned)S), dim3(BS_RANK_THREADS), 0, s, set->d_cols, N, Npad, set->d_owner,
-                       set->T, set->logT, set->d_ids, set->d_meta);
+    if (set->d_owner == nullptr) {
+        // owner table in LDS (T * 4 bytes <= 128 KiB): ds_cmpst instead of global CAS chains
+        const size_t lds = (size_t)set->T * sizeof(uint32_t);
+        auto kern = bs_rank_kernel<true>;
+        if (lds > 48 * 1024)
+            D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, (uint32_t *)nullptr,
+                           set->T, set->logT, set->d_ids, set->d_meta);
+    } else {
+        D2G_HIP(ctx, hipMemsetAsync(set->d_owner, 0xFF, S * (size_t)set->T * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(bs_rank_kernel<false>, dim3((unsigned)S), dim3(BS_RANK_THREADS), 0, s, set->d_cols, N, Npad,
+                           set->d_owner, set->T, set->logT, set->d_ids, set->d_meta);
+    }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, S, N, Npad, set->d_planes, set->Nstride,
                        set->nbits_cap, set->d_meta);
