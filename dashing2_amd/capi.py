@@ -91,6 +91,7 @@ SIGNATURES = {
     "d2g_cmp_lut_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "d2g_cmp_gtlt_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "d2g_cmp_eqcount_rect_dev": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    "d2g_cmp_gtlt_rect_dev": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
     "d2g_cmp_eqcount_ut": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _int, _vp]),
     "d2g_cmp_dist_ut": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _int, _int, _int, _int, _int, _vp]),
     "d2g_ut_partition": (_int, [_sz, _int, C.POINTER(_sz)]),
@@ -449,6 +450,20 @@ class CmpSet:
         dg, dl = self.ctx.malloc(gt.nbytes), self.ctx.malloc(lt.nbytes)
         try:
             self.gtlt_ut_dev(dg, dl, r0, r1)
+            self.ctx.d2h(gt, dg)
+            self.ctx.d2h(lt, dl)
+        finally:
+            self.ctx.free(dg)
+            self.ctx.free(dl)
+        return gt, lt
+
+    def gtlt_rect(self, a0, a1, b0, b1):
+        gt, lt = np.empty((a1 - a0, b1 - b0), np.uint32), np.empty((a1 - a0, b1 - b0), np.uint32)
+        if gt.size == 0:
+            return gt, lt
+        dg, dl = self.ctx.malloc(gt.nbytes), self.ctx.malloc(lt.nbytes)
+        try:
+            self.ctx._check(lib().d2g_cmp_gtlt_rect_dev(self.ctx._h, self._h, a0, a1, b0, b1, dg, dl, None))
             self.ctx.d2h(gt, dg)
             self.ctx.d2h(lt, dl)
         finally:

@@ -305,6 +305,19 @@ int d2g_cmp_eqcount_rect_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, si
     return launch_direct<false>(ctx, set, sh, StoreEq{out}, as_stream(stream));
 }
 
+int d2g_cmp_gtlt_rect_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1,
+                          uint32_t *gt, uint32_t *lt, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, set && set->ctx == ctx, "cmp: set belongs to another context");
+    D2G_CHECK(ctx, a0 <= a1 && a1 <= set->N && b0 <= b1 && b1 <= set->N, "cmp: rect out of bounds");
+    if (a0 == a1 || b0 == b1) return D2G_OK;
+    D2G_CHECK(ctx, gt != nullptr && lt != nullptr, "cmp: null output");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    PairShape sh{};
+    sh.N = set->N; sh.i_lo = a0; sh.i_hi = a1; sh.j_lo = b0; sh.j_hi = b1; sh.ut = 0;
+    return launch_direct<true>(ctx, set, sh, StoreGtLt{gt, lt, (uint32_t)set->S}, as_stream(stream));
+}
+
 // ---------------------------------------------------------------- host-pointer conveniences
 int d2g_cmp_eqcount_ut(d2g_ctx *ctx, const uint64_t *sig_bits, size_t N, size_t S, size_t r0, size_t r1, int algo,
                        uint32_t *neq_out) {

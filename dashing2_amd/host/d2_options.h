@@ -1,0 +1,45 @@
+// d2_options.h -- option structs and parsing of the drop-in `dashing2 sketch|cmp` CLI.
+// Flag names, defaults and validation mirror the reference: src/options.h:63-171 (SHARED_OPTS),
+// :175-304 (VALID_LONG_OPTION_STRINGS / validate_options), :308-449 (SHARED_FIELDS),
+// src/sketch_main.cpp:23-152, src/cmp_main.cpp:200-366.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace d2h {
+
+enum OutputKind { SYMMETRIC_ALL_PAIRS, PHYLIP, ASYMMETRIC_ALL_PAIRS, KNN_GRAPH, NN_GRAPH_THRESHOLD, PANEL, DEDUP };  // enums.h:86-94
+enum OutputFormat { MACHINE_READABLE, HUMAN_READABLE };                                                             // enums.h:96-100
+enum KmerResult { ONE_PERM = 0, FULL_SETSKETCH = 1 };                                                                // enums.h:70-84 (in scope)
+enum SketchSpace { SPACE_SET = 0, SPACE_MULTISET = 1, SPACE_PSET = 2 };                                              // enums.h:35-42
+
+struct Options {
+    bool is_cmp = false;
+    int k = -1, w = -1, nt = -1;
+    bool canon = true, cache = false, presketched = false;
+    size_t sketchsize = 1024;
+    uint64_t seedseed = 0;
+    size_t batch_size = 0;
+    std::string ffile, qfile, outfile, cmpout, outprefix;
+    OutputKind ok = SYMMETRIC_ALL_PAIRS;
+    OutputFormat of = HUMAN_READABLE;
+    int measure = 0;                      // d2g_measure / cmp_main.h:8-17
+    KmerResult kmer_result = ONE_PERM;
+    SketchSpace sspace = SPACE_SET;
+    int verbosity = 0;
+    std::vector<std::string> paths;       // references then queries
+    size_t nq = 0;                        // number of query paths (-Q)
+    int device = 0;                       // D2G_DEVICE env (not a reference flag)
+
+    unsigned nthreads() const { return nt < 1 ? 1u : unsigned(nt); }
+    std::string to_string() const;        // Dashing2Options::to_string, src/d2.cpp:10-43
+};
+
+// returns 0 to continue, or the process exit code (+1) when parsing decided to stop (usage/errors)
+int parse_options(int argc, char **argv, Options &o);
+void sketch_usage();
+void cmp_usage();
+
+}  // namespace d2h

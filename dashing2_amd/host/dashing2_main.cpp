@@ -1,0 +1,505 @@
+// dashing2_main.cpp -- drop-in `dashing2 sketch` / `dashing2 cmp` for the MI355X hot paths.
+// Host C++ over the C ABI of libd2g.so (include/d2g.h); mirrors, for the in-scope options,
+//   main / dispatch          src/d2.cpp:133-151
+//   sketch_main              src/sketch_main.cpp:23-152
+//   sketch_core + formats    src/sketch_core.cpp:14-31,108-161 ; src/fastxsketch.cpp:302-424,554-610
+//   makedest (cache names)   src/fastxmerge.cpp:70-120
+//   cmp_main / load_results  src/cmp_main.cpp:24-198,200-366
+//   cmp_core (densify)       src/cmp_core.cpp:686-718,746-751
+//   emit_rectangular         src/emitrect.cpp:108-403
+#include "../../include/d2g.h"
+#include "d2_options.h"
+#include "fmtfloat.h"
+#include <algorithm>
+#include <chrono>
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef DASHING2_VERSION
+#define DASHING2_VERSION "v2.1.20-mi355x"
+#endif
+
+using namespace d2h;
+
+namespace {
+
+struct Result {                              // SketchingResult, src/fastxsketch.h:23-58 (in-scope fields)
+    std::vector<std::string> names, destination_files;
+    std::vector<double> cardinalities;
+    std::vector<double> signatures;          // [N][S] row-major
+    size_t nq = 0;
+};
+
+[[noreturn]] void die(const std::string &msg) {          // THROW_EXCEPTION: src/enums.h:59-63
+    std::fprintf(stderr, "Exception %s\n", msg.c_str());
+    std::exit(1);
+}
+void check(d2g_ctx *ctx, int rc, const char *what) {
+    if (rc == D2G_OK) return;
+    die(std::string(what) + ": " + d2g_strerror(rc) + (ctx ? std::string(" (") + d2g_last_error(ctx) + ")" : std::string()));
+}
+bool isfile(const std::string &p) { struct stat st; return ::stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+size_t filesize(const std::string &p) { struct stat st; return ::stat(p.c_str(), &st) == 0 ? size_t(st.st_size) : 0; }
+std::string trim_folder(const std::string &s) {          // src/enums.cpp:22-26
+    const auto pos = s.find_last_of('/');
+    return pos == std::string::npos ? s : s.substr(pos + 1);
+}
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// src/fastxmerge.cpp:70-120 for SPACE_SET / ONE_PERM, DNA, unspaced
+std::string makedest(const Options &o, const std::string &path) {
+    std::string ret = path.substr(0, path.find_first_of(' '));
+    if (!o.outprefix.empty()) ret = o.outprefix + '/' + trim_folder(path);
+    if (o.seedseed != 0) ret += ".seed" + std::to_string(o.seedseed);
+    if (o.canon) ret += ".rc_canon";
+    ret += ".sketchsize" + std::to_string(o.sketchsize);
+    ret += ".k" + std::to_string(o.k);
+    ret += ".SetSpace";                                   // to_string(SPACE_SET), src/enums.cpp:40-46
+    ret += ".DNA";                                        // bns::to_string(rht_) (absent bonsai; expected "DNA")
+    ret += ".opss";                                       // to_suffix, src/enums.cpp:28-38
+    return ret;
+}
+
+// one cached sketch: [f64 card][f64 x S]   (src/fastxsketch.cpp:60-112,556-607)
+bool load_cached(const std::string &path, double *sig, double *card, size_t S) {
+    if (filesize(path) != 8 + 8 * S) {
+        if (isfile(path)) std::fprintf(stderr, "Expected %zu bytes of sketch, found %zu\n", S * 8, filesize(path) - 8);
+        return false;
+    }
+    std::FILE *fp = std::fopen(path.c_str(), "rb");
+    if (!fp) return false;
+    const bool ok = std::fread(card, 8, 1, fp) == 1 && std::fread(sig, 8, S, fp) == S;
+    std::fclose(fp);
+    return ok;
+}
+void write_cached(const std::string &path, const double *sig, double card, size_t S) {
+    std::FILE *fp = std::fopen(path.c_str(), "wb");
+    if (!fp) die("Failed to open file " + path + " for writing sketch.");
+    if (std::fwrite(&card, 8, 1, fp) != 1 || std::fwrite(sig, 8, S, fp) != S) die("Failed to write sketch " + path);
+    std::fclose(fp);
+}
+
+// ------------------------------------------------------------------------------------ sketch
+void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
+    const size_t N = o.paths.size(), S = o.sketchsize, m = d2g_oph_m(S);
+    if (!N) die("Can't sketch empty path set");
+    res.names = o.paths;                                                // fastxsketch.cpp:625
+    res.destination_files.resize(N);
+    res.cardinalities.assign(N, -1.);
+    res.signatures.assign(N * S, 0.);
+    const uint64_t xormask = d2g_seed_mask(o.seedseed);                 // d2.h:224 -> enums.cpp:131-140
+    std::vector<size_t> todo;
+    for (size_t i = 0; i < N; ++i) {
+        res.destination_files[i] = makedest(o, o.paths[i]);
+        if (o.cache && isfile(res.destination_files[i]) &&
+            load_cached(res.destination_files[i], &res.signatures[i * S], &res.cardinalities[i], S))
+            continue;                                                   // fastxsketch.cpp:327-373
+        todo.push_back(i);
+    }
+    // groups of files bounded by input bytes: parsed in parallel on the host, sketched one group per launch
+    std::vector<std::pair<size_t, size_t>> groups;                      // [begin,end) into todo
+    {
+        const size_t limit = size_t(128) << 20;
+        size_t b = 0, acc = 0;
+        for (size_t t = 0; t < todo.size(); ++t) {
+            size_t fs = 0;
+            const std::string &line = o.paths[todo[t]];
+            for (size_t s = 0; s <= line.size();) {
+                size_t e = line.find(' ', s);
+                if (e == std::string::npos) e = line.size();
+                if (e > s) fs += filesize(line.substr(s, e - s));
+                s = e + 1;
+            }
+            if (acc && acc + fs > limit) { groups.emplace_back(b, t); b = t; acc = 0; }
+            acc += fs;
+        }
+        if (b < todo.size()) groups.emplace_back(b, todo.size());
+    }
+    double t_parse = 0, t_gpu = 0, t_fin = 0;
+    uint64_t total_bases = 0;
+#ifdef _OPENMP
+    #pragma omp parallel for schedule(dynamic) num_threads(std::min<unsigned>(o.nthreads(), 8))
+#endif
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const size_t b = groups[g].first, e = groups[g].second, n = e - b;
+        d2g_seqpack *sp = nullptr;
+        check(ctx, d2g_seqpack_create(o.k, &sp), "d2g_seqpack_create");
+        const double t0 = now();
+        for (size_t t = b; t < e; ++t) {
+            const int rc = d2g_seqpack_add_path(sp, o.paths[todo[t]].c_str());
+            if (rc) die("Failed to open " + o.paths[todo[t]]);
+        }
+        const double t1 = now();
+        std::vector<uint64_t> regs(n * m);
+        int rc;
+#ifdef _OPENMP
+        #pragma omp critical(d2g_device)
+#endif
+        {
+            rc = d2g_oph_sketch(ctx, d2g_seqpack_packed(sp), d2g_seqpack_packed_bytes(sp), d2g_seqpack_run_start(sp),
+                                d2g_seqpack_run_len(sp), d2g_seqpack_nruns(sp), d2g_seqpack_genome_run_off(sp), n, o.k,
+                                o.canon, xormask, S, regs.data());
+        }
+        check(ctx, rc, "d2g_oph_sketch");
+        const double t2 = now();
+        std::vector<double> sigs(n * S), cards(n);
+        check(ctx, d2g_oph_finalize(regs.data(), n, m, S, sigs.data(), cards.data(), 1), "d2g_oph_finalize");
+        for (size_t t = b; t < e; ++t) {
+            const size_t i = todo[t];
+            std::memcpy(&res.signatures[i * S], &sigs[(t - b) * S], S * sizeof(double));   // fastxsketch.cpp:610
+            res.cardinalities[i] = cards[t - b];
+            if (o.cache) write_cached(res.destination_files[i], &sigs[(t - b) * S], cards[t - b], S);
+        }
+#ifdef _OPENMP
+        #pragma omp critical(d2g_stats)
+#endif
+        { t_parse += t1 - t0; t_gpu += t2 - t1; t_fin += now() - t2; total_bases += d2g_seqpack_nbases(sp); }
+        d2g_seqpack_destroy(sp);
+    }
+    if (o.verbosity) std::fprintf(stderr, "[d2g] sketched %zu inputs (%" PRIu64 " ACGT bases): host parse %.3fs, device (H2D+K1+D2H) %.3fs, finalise %.3fs (thread-seconds)\n",
+                                  todo.size(), total_bases, t_parse, t_gpu, t_fin);
+    // stacked output: [u64 N][u64 S][f64 card x N][f64 x N*S]   (sketch_core.cpp:130-140, fastxsketch.cpp:236-240)
+    if (!o.outfile.empty()) {
+        if (o.outfile == "-" || o.outfile == "/dev/stdout")
+            die("Not yet supported: writing stacked sketches to file streams. This may change.");     // sketch_core.cpp:141-144
+        std::FILE *fp = std::fopen(o.outfile.c_str(), "wb");
+        if (!fp) die("Failed to open file " + o.outfile + " for in-place modification");
+        const uint64_t hdr[2] = {uint64_t(N), uint64_t(S)};
+        if (std::fwrite(hdr, 8, 2, fp) != 2 || std::fwrite(res.cardinalities.data(), 8, N, fp) != N ||
+            std::fwrite(res.signatures.data(), 8, N * S, fp) != N * S) die("Failed to write " + o.outfile);
+        std::fclose(fp);
+        // <out>.names.txt (sketch_core.cpp:146-161, enums.h:160 "%0.24g")
+        const std::string nf = o.outfile + ".names.txt";
+        if (!(fp = std::fopen(nf.c_str(), "wb"))) die("Failed to open outfile at " + nf);
+        std::fputs("#Name\tCardinality\n", fp);
+        for (size_t i = 0; i < N; ++i) {
+            std::fwrite(res.names[i].data(), 1, res.names[i].size(), fp);
+            std::fprintf(fp, "\t%0.24g", res.cardinalities[i]);
+            std::fputc('\n', fp);
+        }
+        std::fclose(fp);
+    }
+}
+
+// ------------------------------------------------------------------------------------ cmp: load
+void load_results(Options &o, Result &res) {               // src/cmp_main.cpp:24-198
+    const auto &paths = o.paths;
+    if (paths.empty()) die("No paths provided to --presketched");
+    const std::string &pf = paths.front();
+    if (paths.size() == 1) {
+        const std::string namesf = pf + ".names.txt";
+        if (isfile(namesf)) {
+            std::ifstream ifs(namesf);
+            for (std::string l; std::getline(ifs, l);) {
+                if (l.empty() || l.front() == '#') continue;
+                res.names.emplace_back(l.substr(0, l.find_first_of('\t')));
+            }
+        }
+        std::FILE *fp = std::fopen(pf.c_str(), "rb");
+        if (!fp) die("Failed to open " + pf);
+        uint64_t hdr[2];
+        if (filesize(pf) < 16 || std::fread(hdr, 8, 2, fp) != 2)
+            die("Failed to read num_entities from file " + pf + " of size " + std::to_string(filesize(pf)));
+        const size_t N = hdr[0], S = hdr[1];
+        o.sketchsize = S;
+        if (res.names.empty()) for (size_t i = 0; i < N; ++i) res.names.push_back(std::to_string(i));
+        res.cardinalities.resize(N);
+        if (std::fread(res.cardinalities.data(), 8, N, fp) != N) die("Failed to read cardinalities from disk");
+        const size_t nreg = (filesize(pf) - (N + 2) * 8) / 8;
+        res.signatures.resize(nreg);
+        if (std::fread(res.signatures.data(), 8, nreg, fp) != nreg) die("Failed to read signatures from disk");
+        std::fclose(fp);
+        if (nreg != N * S) die("stacked sketch file " + pf + " has " + std::to_string(nreg) + " registers, expected " + std::to_string(N * S));
+    } else {
+        const size_t N = paths.size();
+        std::vector<size_t> fs(N);
+        for (size_t i = 0; i < N; ++i) {
+            if (!isfile(paths[i])) { std::fprintf(stderr, "File does not exist at %s/%zu\n", paths[i].c_str(), i); std::exit(EXIT_FAILURE); }
+            fs[i] = (filesize(paths[i]) - 8) / 8;
+        }
+        if (!std::all_of(fs.begin(), fs.end(), [&](size_t x) { return x == fs[0]; }))
+            die("presketched files have uneven sizes; only sketches (not k-mer sets) are in this build's scope");
+        o.sketchsize = fs[0];
+        std::fprintf(stderr, "Sketchsize is now %zd\n", o.sketchsize);
+        res.signatures.resize(N * fs[0]);
+        res.cardinalities.resize(N);
+        for (size_t i = 0; i < N; ++i) {
+            std::FILE *fp = std::fopen(paths[i].c_str(), "rb");
+            if (!fp || std::fread(&res.cardinalities[i], 8, 1, fp) != 1 ||
+                std::fread(&res.signatures[i * fs[0]], 8, fs[0], fp) != fs[0]) {
+                std::fprintf(stderr, "Failed to read at path %s\n", paths[i].c_str());
+                std::exit(1);
+            }
+            std::fclose(fp);
+        }
+        // the reference leaves names_ empty here, so rows/sources are printed as E<i> (emitrect.cpp:145,176)
+        for (size_t i = 0; i < N; ++i) res.names.push_back("E" + std::to_string(i));
+    }
+}
+
+// ------------------------------------------------------------------------------------ cmp: emit
+struct Emitter {
+    const Options &o;
+    const Result &res;
+    std::FILE *fp = nullptr;
+    bool own = false;
+    Emitter(const Options &oo, const Result &r) : o(oo), res(r) {
+        const std::string outp = (o.cmpout.empty() || o.cmpout.front() == '-') ? "/dev/stdout" : o.cmpout;   // emitrect.cpp:114-115
+        if (outp == "/dev/stdout") fp = stdout;
+        else { fp = std::fopen(outp.c_str(), "wb"); own = true; }
+        if (!fp) die("Failed to open path " + outp + " for writing");
+        static std::vector<char> buf(1 << 22);
+        std::setvbuf(fp, buf.data(), _IOFBF, buf.size());
+    }
+    ~Emitter() { if (fp) { std::fflush(fp); if (own) std::fclose(fp); } }
+    void header() {                                                     // emitrect.cpp:136-151
+        if (o.of != HUMAN_READABLE) return;
+        const size_t ns = res.names.size();
+        if (o.ok == PHYLIP) { std::fprintf(fp, "%zu\n", ns); return; }
+        const char *label = o.ok == ASYMMETRIC_ALL_PAIRS ? "Asymmetric pairwise" : o.ok == PANEL ? "Panel (Query/Refernce)" : "Symmetric pairwise";
+        std::fprintf(fp, "#Dashing2 %s Output\n", label);
+        std::fprintf(fp, "#Dashing2Options: %s\n", o.to_string().c_str());
+        std::fputs("#Sources", fp);
+        for (size_t i = 0; i < ns; ++i) { std::fputc('\t', fp); std::fwrite(res.names[i].data(), 1, res.names[i].size(), fp); }
+        std::fputc('\n', fp);
+    }
+    // rows [r0, r1); row i has nvals(i) values starting at data + off(i)
+    template <class NV> void rows(size_t r0, size_t r1, const float *data, NV nvals) {
+        if (o.of == MACHINE_READABLE) {                                  // emitrect.cpp:189-192
+            size_t tot = 0;
+            for (size_t i = r0; i < r1; ++i) tot += nvals(i);
+            if (std::fwrite(data, sizeof(float), tot, fp) != tot) die("Failed to write rows " + std::to_string(r0) + "-" + std::to_string(r1) + " to disk");
+            return;
+        }
+        const size_t n = r1 - r0;
+        std::vector<size_t> off(n + 1, 0);
+        for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + nvals(r0 + i);
+        std::vector<std::string> text(n);
+#ifdef _OPENMP
+        #pragma omp parallel for schedule(dynamic, 8) num_threads(o.nthreads())
+#endif
+        for (size_t r = 0; r < n; ++r) {                                 // emitrect.cpp:172-187
+            const size_t i = r0 + r;
+            std::string &s = text[r];
+            std::string fn = (res.names.size() > i && !res.names[i].empty()) ? res.names[i] : std::string("E") + std::to_string(i);
+            if (fn.size() < 9) fn.append(9 - fn.size(), ' ');
+            const size_t nv = off[r + 1] - off[r];
+            s.reserve(fn.size() + 2 * (i + 1) + nv * 12 + 2);
+            s = fn;
+            if (o.ok == SYMMETRIC_ALL_PAIRS) for (size_t t = 0; t < i + 1; ++t) s += "\t-";     // print_tabs, emitrect.cpp:40-66
+            char buf[FMT_MAX_FLOAT_CHARS + 1];
+            const float *p = data + off[r];
+            for (size_t j = 0; j < nv; ++j) {
+                buf[0] = '\t';
+                const size_t l = format_float(p[j], buf + 1);
+                s.append(buf, l + 1);
+            }
+            s += '\n';
+        }
+        for (const auto &s : text)
+            if (std::fwrite(s.data(), 1, s.size(), fp) != s.size()) die("Failed to write text rows");
+    }
+};
+
+struct DevBuf {
+    d2g_ctx *ctx; void *p = nullptr;
+    DevBuf(d2g_ctx *c, size_t n) : ctx(c) { check(c, d2g_malloc(c, n ? n : 4, &p), "d2g_malloc"); }
+    ~DevBuf() { d2g_free(ctx, p); }
+};
+
+void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_core.cpp:615-751 (dense outputs)
+    const size_t ns = res.names.size(), S = o.sketchsize;
+    if (res.signatures.size() != ns * S) die("Empty signatures; trying to compare but don't have any");
+    const bool multiset = o.sspace != SPACE_SET;
+    if (o.kmer_result == ONE_PERM) {                                // cmp_core.cpp:686-718
+        size_t nfilled = 0;
+        check(ctx, d2g_densify(res.signatures.data(), ns, S, &nfilled, int(o.nthreads())), "d2g_densify");
+        if (o.verbosity && nfilled) std::fprintf(stderr, "Densified a total of %zu/%zu entries\n", nfilled, S * ns);
+    }
+    const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.signatures.data());
+    const double *cards = res.cardinalities.data();
+    std::vector<float> lut(S + 1);
+    const bool have_lut = d2g_epilogue_lut(S, o.measure, o.k, multiset, lut.data()) == D2G_OK;
+    const bool need_gtlt = !multiset && (S & (S - 1)) != 0;
+    d2g_cmp_set *set = nullptr;
+    const double t0 = now();
+    check(ctx, d2g_cmp_set_create(ctx, bits, ns, S, need_gtlt ? int(D2G_CMP_DIRECT) : int(D2G_CMP_AUTO), &set), "d2g_cmp_set_create");
+    DevBuf dlut(ctx, (S + 1) * sizeof(float));
+    if (have_lut) check(ctx, d2g_memcpy_h2d(ctx, dlut.p, lut.data(), (S + 1) * sizeof(float), nullptr), "h2d lut");
+    Emitter em(o, res);
+    em.header();
+    const size_t max_vals = size_t(1) << 27;                        // values per device batch (512 MiB of floats)
+    double t_dev = 0, t_emit = 0;
+    if (o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP) {            // emitrect.cpp:290-323
+        for (size_t r0 = 0; r0 < ns;) {
+            size_t r1 = r0, cnt = 0;
+            while (r1 < ns && (cnt == 0 || cnt + (ns - 1 - r1) <= max_vals)) { cnt += ns - 1 - r1; ++r1; }
+            std::vector<float> out(cnt);
+            const double ta = now();
+            if (cnt) {
+                if (have_lut) {
+                    DevBuf d(ctx, cnt * 4);
+                    check(ctx, d2g_cmp_lut_ut_dev(ctx, set, r0, r1, (const float *)dlut.p, (float *)d.p, nullptr), "d2g_cmp_lut_ut_dev");
+                    check(ctx, d2g_memcpy_d2h(ctx, out.data(), d.p, cnt * 4, nullptr), "d2h");
+                } else {
+                    std::vector<uint32_t> ca(cnt), cb;
+                    DevBuf da(ctx, cnt * 4);
+                    if (need_gtlt) {
+                        DevBuf db(ctx, cnt * 4);
+                        cb.resize(cnt);
+                        check(ctx, d2g_cmp_gtlt_ut_dev(ctx, set, r0, r1, (uint32_t *)da.p, (uint32_t *)db.p, nullptr), "d2g_cmp_gtlt_ut_dev");
+                        check(ctx, d2g_memcpy_d2h(ctx, cb.data(), db.p, cnt * 4, nullptr), "d2h");
+                    } else {
+                        check(ctx, d2g_cmp_eqcount_ut_dev(ctx, set, r0, r1, (uint32_t *)da.p, nullptr), "d2g_cmp_eqcount_ut_dev");
+                    }
+                    check(ctx, d2g_memcpy_d2h(ctx, ca.data(), da.p, cnt * 4, nullptr), "d2h");
+                    // x87 epilogue on the host (cmp_core.cpp:458-517)
+                    std::vector<size_t> off(r1 - r0 + 1, 0);
+                    for (size_t i = r0; i < r1; ++i) off[i - r0 + 1] = off[i - r0] + (ns - 1 - i);
+#ifdef _OPENMP
+                    #pragma omp parallel for schedule(dynamic, 4) num_threads(o.nthreads())
+#endif
+                    for (size_t i = r0; i < r1; ++i)
+                        for (size_t j = i + 1; j < ns; ++j) {
+                            const size_t p = off[i - r0] + (j - i - 1);
+                            out[p] = multiset ? d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k)
+                                   : need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
+                                               : d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], o.measure, o.k);
+                        }
+                }
+            }
+            const double tb = now();
+            em.rows(r0, r1, out.data(), [&](size_t i) { return ns - 1 - i; });
+            t_dev += tb - ta; t_emit += now() - tb;
+            r0 = r1;
+        }
+    } else {                                                        // asymmetric / panel: emitrect.cpp:211-268
+        const size_t nq = res.nq, nf = o.ok == PANEL ? ns - nq : ns;
+        const size_t c0 = o.ok == PANEL ? nf : 0, c1 = ns, ncol = c1 - c0;
+        if (ncol == 0 || nf == 0) { check(ctx, D2G_OK, ""); }
+        const size_t rows_per = std::max<size_t>(1, max_vals / std::max<size_t>(ncol, 1));
+        for (size_t r0 = 0; r0 < nf; r0 += rows_per) {
+            const size_t r1 = std::min(nf, r0 + rows_per), cnt = (r1 - r0) * ncol;
+            std::vector<float> out(cnt);
+            std::vector<uint32_t> ca(cnt), cb;
+            const double ta = now();
+            if (cnt) {
+                DevBuf da(ctx, cnt * 4);
+                if (need_gtlt) {
+                    DevBuf db(ctx, cnt * 4);
+                    cb.resize(cnt);
+                    check(ctx, d2g_cmp_gtlt_rect_dev(ctx, set, r0, r1, c0, c1, (uint32_t *)da.p, (uint32_t *)db.p, nullptr), "d2g_cmp_gtlt_rect_dev");
+                    check(ctx, d2g_memcpy_d2h(ctx, cb.data(), db.p, cnt * 4, nullptr), "d2h");
+                } else {
+                    check(ctx, d2g_cmp_eqcount_rect_dev(ctx, set, r0, r1, c0, c1, (uint32_t *)da.p, nullptr), "d2g_cmp_eqcount_rect_dev");
+                }
+                check(ctx, d2g_memcpy_d2h(ctx, ca.data(), da.p, cnt * 4, nullptr), "d2h");
+#ifdef _OPENMP
+                #pragma omp parallel for schedule(dynamic, 4) num_threads(o.nthreads())
+#endif
+                for (size_t i = r0; i < r1; ++i)
+                    for (size_t j = c0; j < c1; ++j) {
+                        const size_t p = (i - r0) * ncol + (j - c0);
+                        out[p] = have_lut ? lut[ca[p]]
+                               : multiset ? d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k)
+                               : need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
+                                           : d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], o.measure, o.k);
+                    }
+            }
+            const double tb = now();
+            em.rows(r0, r1, out.data(), [&](size_t) { return ncol; });
+            t_dev += tb - ta; t_emit += now() - tb;
+        }
+    }
+    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp: %zu sketches x S=%zu: prepare %.3fs, device+epilogue %.3fs, emit %.3fs (algo %s)\n", ns, S,
+                                  0.0 + (now() - t0 - t_dev - t_emit), t_dev, t_emit, d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE ? "bitslice" : "direct");
+    d2g_cmp_set_destroy(set);
+}
+
+d2g_ctx *make_ctx(const Options &o) {
+    d2g_ctx *ctx = nullptr;
+    const int rc = d2g_ctx_create(o.device, &ctx);
+    if (rc) die(std::string("dashing2 (MI355X) needs a gfx950 GPU; d2g_ctx_create: ") + d2g_strerror(rc) + " (there is no CPU fallback)");
+    return ctx;
+}
+
+int sketch_main(int argc, char **argv) {                          // src/sketch_main.cpp:23-152
+    Options o;
+    if (int rc = parse_options(argc, argv, o)) return rc - 1;
+    if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); sketch_usage(); return 1; }
+    d2g_ctx *ctx = make_ctx(o);
+    Result res;
+    sketch_core(res, o, ctx);
+    res.nq = o.nq;
+    if (!o.cmpout.empty()) cmp_core(o, res, ctx);                  // sketch_main.cpp:144-148
+    d2g_ctx_destroy(ctx);
+    return 0;
+}
+
+int cmp_main(int argc, char **argv) {                             // src/cmp_main.cpp:200-366
+    Options o;
+    o.is_cmp = true;
+    if (int rc = parse_options(argc, argv, o)) return rc - 1;
+    d2g_ctx *ctx = make_ctx(o);
+    Result res;
+    if (o.presketched) {
+        // suffix sniffing, cmp_main.cpp:305-351
+        const std::string &p0 = o.paths.empty() ? std::string() : o.paths.front();
+        const auto dot = p0.find_last_of('.');
+        const std::string suf = dot == std::string::npos ? std::string() : p0.substr(dot);
+        if (suf == ".bmh") { o.sspace = SPACE_MULTISET; o.kmer_result = FULL_SETSKETCH; }
+        else if (suf == ".pmh") { o.sspace = SPACE_PSET; o.kmer_result = FULL_SETSKETCH; }
+        else if (suf == ".ss") { o.sspace = SPACE_SET; o.kmer_result = FULL_SETSKETCH; }
+        else if (suf == ".opss") { o.sspace = SPACE_SET; o.kmer_result = ONE_PERM; }
+        else if (suf == ".kmerset64" || suf == ".kmerset128")
+            die("k-mer set comparison is outside this build's hot-path scope");
+        load_results(o, res);
+    } else {
+        if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); cmp_usage(); return 1; }
+        sketch_core(res, o, ctx);
+        res.nq = o.nq;
+    }
+    cmp_core(o, res, ctx);
+    d2g_ctx_destroy(ctx);
+    return 0;
+}
+
+int main_usage() {                                                // src/d2.cpp:112-128
+    std::fprintf(stderr, "dashing2 has several subcommands: sketch, cmp, wsketch, and contain.\n");
+    std::fprintf(stderr, "Usage can be seen in those subcommands. (e.g., `dashing2 sketch -h`)\n\n");
+    std::fprintf(stderr, "\tsketch: converts FastX into k-mer sets/sketches; also contains functionality from cmp, for one-step sketch and comparisons\n");
+    std::fprintf(stderr, "\tcmp: compares previously sketched/decomposed k-mer sets and emits results. alias: dist\n\n");
+    std::fprintf(stderr, "This MI355X build implements the sketch and cmp hot paths only (wsketch/contain/printmin are out of scope).\n");
+    return 1;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {                                 // src/d2.cpp:133-151
+    char cwd[4096];
+    std::string cmd = argv[0][0] == '/' ? std::string(argv[0]) : (getcwd(cwd, sizeof cwd) ? std::string(cwd) + "/" + argv[0] : std::string(argv[0]));
+    for (char **s = argv + 1; *s; ++s) cmd += std::string(" ") + *s;
+    std::fprintf(stderr, "#Calling Dashing2 version %s with command '%s'\n", DASHING2_VERSION, cmd.c_str());
+    if (argc > 1) {
+        if (std::strcmp(argv[1], "sketch") == 0) return sketch_main(argc - 1, argv + 1);
+        if (std::strcmp(argv[1], "cmp") == 0 || std::strcmp(argv[1], "dist") == 0) return cmp_main(argc - 1, argv + 1);
+        if (std::strcmp(argv[1], "wsketch") == 0 || std::strcmp(argv[1], "contain") == 0 || std::strcmp(argv[1], "printmin") == 0) {
+            std::fprintf(stderr, "dashing2 (MI355X): subcommand %s is outside the hot-path scope of this build.\n", argv[1]);
+            return 1;
+        }
+    }
+    return main_usage();
+}

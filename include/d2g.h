@@ -199,6 +199,10 @@ int  d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t
 int  d2g_cmp_eqcount_rect_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1,
                               size_t b0, size_t b1, uint32_t *neq_out_dev, void *stream);
 
+/* (#a>b, #a<b) for a rectangular block, a = row sketch, b = column sketch (compare(i,j) order) */
+int  d2g_cmp_gtlt_rect_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1,
+                           uint32_t *gt_out_dev, uint32_t *lt_out_dev, void *stream);
+
 /* host-pointer conveniences (H2D, run, D2H, sync) */
 int  d2g_cmp_eqcount_ut(d2g_ctx *ctx, const uint64_t *sig_bits, size_t N, size_t sketchsize,
                         size_t r0, size_t r1, int algo, uint32_t *neq_out);

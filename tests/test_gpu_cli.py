@@ -1,0 +1,168 @@
+"""GPU end-to-end tests of the drop-in CLI (dashing2_amd/bin/dashing2): on-disk formats and text
+output must be byte-identical to what the oracle + the reference's layouts prescribe."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from dashing2_amd import synth
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "dashing2_amd", "bin", "dashing2")
+
+
+def _run(args, **kw):
+    r = subprocess.run([EXE] + args, capture_output=True, **kw)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    return r
+
+
+@pytest.fixture(scope="module")
+def genomes(tmp_path_factory):
+    d = tmp_path_factory.mktemp("fa")
+    base = synth.random_genome(100, 120000)
+    paths = []
+    for i, rate in enumerate([0.0, 0.001, 0.01, 0.05, 0.2]):
+        g = synth.mutate(base, rate, seed=i) if rate else base
+        p = d / f"g{i}.fa"
+        synth.write_fasta(p, f"g{i}", g)
+        paths.append(str(p))
+    p = d / "other.fa"
+    synth.write_fasta(p, "other", synth.random_genome(7, 90000))
+    paths.append(str(p))
+    p = d / "tiny.fa"            # fewer k-mers than buckets: exercises densify (cmp_core.cpp:577-613)
+    synth.write_fasta(p, "tiny", synth.random_genome(9, 400))
+    paths.append(str(p))
+    return paths
+
+
+def _oracle_result(oracle, paths, k, S, canon=True, seed=0):
+    xm = oracle.load().d2o_seed_mask(seed)
+    sigs, cards = oracle.sketch_files(paths, k=k, canon=canon, xormask=xm, S=S, nthreads=2)
+    return sigs, cards
+
+
+def _densified(oracle, sigs):
+    return np.stack([oracle.densify(s)[0] for s in sigs])
+
+
+OPTSTR = "Dashing2Options;k:{k};parsebyfile;trimchr;sketchsize:{S};sketchtype:onepermsetsketch;Fastx;canon"
+
+
+@pytest.mark.parametrize("k,S", [(31, 1024), (21, 256)])
+def test_cli_sketch_stacked_and_phylip(oracle, genomes, tmp_path, k, S):
+    from oracle import textfmt
+    out = tmp_path / "stack.bin"
+    phy = tmp_path / "dist.phylip"
+    r = _run(["sketch", "-k", str(k), "-S", str(S), "-p", "4", "-o", str(out), "--cmpout", str(phy), "--phylip"] + genomes)
+    assert r.stderr.decode().startswith("#Calling Dashing2 version")
+    esigs, ecards = _oracle_result(oracle, genomes, k, S)
+    N = len(genomes)
+    # F-b stacked file: [u64 N][u64 S][f64 card x N][f64 x N*S], sketches stored UN-densified
+    raw = np.fromfile(out, np.uint8)
+    exp = np.concatenate([np.array([N, S], np.uint64).view(np.uint8), ecards.view(np.uint8), esigs.reshape(-1).view(np.uint8)])
+    assert raw.tobytes() == exp.tobytes()
+    # F-c names file
+    lines = open(str(out) + ".names.txt").read().splitlines()
+    assert lines[0] == "#Name\tCardinality"
+    for i, l in enumerate(lines[1:]):
+        name, card = l.split("\t")
+        assert name == genomes[i] and card == "%0.24g" % ecards[i]
+    # F-e PHYLIP: byte-identical text
+    dens = _densified(oracle, esigs)
+    dist = oracle.allpairs_ut(dens, ecards, measure=oracle.SIMILARITY, k=k, nthreads=2)
+    assert open(phy).read() == textfmt.render_symmetric(genomes, dist, phylip=True)
+    assert dist.max() > 0.5 and dist.min() == 0.0
+
+
+def test_cli_cmp_presketched_all_outputs(oracle, genomes, tmp_path):
+    from oracle import textfmt
+    k, S = 31, 512
+    out = tmp_path / "s.bin"
+    _run(["sketch", "-k", str(k), "-S", str(S), "-o", str(out)] + genomes)
+    esigs, ecards = _oracle_result(oracle, genomes, k, S)
+    dens = _densified(oracle, esigs)
+    N = len(genomes)
+    iu = np.triu_indices(N, 1)
+    for flags, meas in [([], oracle.SIMILARITY), (["--distance"], oracle.POISSON_LLR), (["--intersection"], oracle.INTERSECTION),
+                        (["--containment"], oracle.CONTAINMENT), (["--symmetric-containment"], oracle.SYMMETRIC_CONTAINMENT),
+                        (["--union-size"], oracle.UNION_SIZE)]:
+        exp = oracle.allpairs_ut(dens, ecards, measure=meas, k=k, nthreads=2)
+        # F-d binary matrix
+        b = tmp_path / "d.bin"
+        _run(["cmp", "--presketched", "-k", str(k), "--binary-output", "--cmpout", str(b)] + flags + [str(out)])
+        got = np.fromfile(b, np.float32)
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32), err_msg=str(flags))
+        # F-f default TSV on stdout
+        r = _run(["cmp", "--presketched", "-k", str(k)] + flags + [str(out)])
+        opt = OPTSTR.format(k=k, S=S)
+        assert r.stdout.decode() == textfmt.render_symmetric(genomes, exp, phylip=False, options_string=opt), str(flags)
+    # asymmetric all-pairs (square): compare(i, j) for every ordered pair incl. the diagonal
+    full = np.empty((N, N), np.float32)
+    lib = oracle.load()
+    import ctypes as C
+    for i in range(N):
+        for j in range(N):
+            full[i, j] = lib.d2o_compare(dens.ctypes.data_as(C.POINTER(C.c_double)), ecards.ctypes.data_as(C.POINTER(C.c_double)),
+                                         S, i, j, oracle.CONTAINMENT, k)
+    b = tmp_path / "sq.bin"
+    _run(["cmp", "--presketched", "-k", str(k), "--binary-output", "--asymmetric-all-pairs", "--containment", "--cmpout", str(b), str(out)])
+    np.testing.assert_array_equal(np.fromfile(b, np.float32).view(np.uint32), full.reshape(-1).view(np.uint32))
+    r = _run(["cmp", "--presketched", "-k", str(k), "--square", "--containment", str(out)])
+    assert r.stdout.decode() == textfmt.render_rect(genomes, genomes, full, "Asymmetric pairwise", OPTSTR.format(k=k, S=S))
+
+
+def test_cli_nonpow2_sketchsize_and_nocanon(oracle, genomes, tmp_path):
+    k, S = 25, 1000                    # (gt, lt) path: the value depends on both counts
+    b = tmp_path / "d.bin"
+    _run(["sketch", "-k", str(k), "-S", str(S), "--no-canon", "--seed", "13", "--binary-output", "--cmpout", str(b), "--distance"] + genomes)
+    esigs, ecards = _oracle_result(oracle, genomes, k, S, canon=False, seed=13)
+    dens = _densified(oracle, esigs)
+    exp = oracle.allpairs_ut(dens, ecards, measure=oracle.POISSON_LLR, k=k, nthreads=2)
+    np.testing.assert_array_equal(np.fromfile(b, np.float32).view(np.uint32), exp.view(np.uint32))
+
+
+def test_cli_cache_and_panel(oracle, genomes, tmp_path):
+    k, S = 31, 256
+    pref = tmp_path / "cache"
+    pref.mkdir()
+    refs, qs = genomes[:4], genomes[4:]
+    ff, qf = tmp_path / "refs.txt", tmp_path / "qs.txt"
+    ff.write_text("\n".join(refs) + "\n")
+    qf.write_text("\n".join(qs) + "\n")
+    b1, b2 = tmp_path / "p1.bin", tmp_path / "p2.bin"
+    args = ["sketch", "-k", str(k), "-S", str(S), "--cache", "--outprefix", str(pref), "-F", str(ff), "-Q", str(qf), "--binary-output"]
+    _run(args + ["--cmpout", str(b1)])
+    esigs, ecards = _oracle_result(oracle, genomes, k, S)
+    # F-a cache files: [f64 card][f64 x S], reference naming (fastxmerge.cpp:70-120)
+    for i, p in enumerate(genomes):
+        name = f"{pref}/{os.path.basename(p)}.rc_canon.sketchsize{S}.k{k}.SetSpace.DNA.opss"
+        raw = np.fromfile(name, np.float64)
+        assert raw[0] == ecards[i]
+        np.testing.assert_array_equal(raw[1:].view(np.uint64), esigs[i].view(np.uint64))
+    # second run loads the caches (inputs may even be gone) and must give the same bytes
+    os.rename(genomes[0], genomes[0] + ".moved")
+    try:
+        _run(args + ["--cmpout", str(b2)])
+    finally:
+        os.rename(genomes[0] + ".moved", genomes[0])
+    assert open(b1, "rb").read() == open(b2, "rb").read()
+    # panel: rows = references, columns = queries (emitrect.cpp:211-247)
+    dens = _densified(oracle, esigs)
+    lib = oracle.load()
+    import ctypes as C
+    nf, nq = len(refs), len(qs)
+    exp = np.empty((nf, nq), np.float32)
+    for i in range(nf):
+        for j in range(nq):
+            exp[i, j] = lib.d2o_compare(dens.ctypes.data_as(C.POINTER(C.c_double)), ecards.ctypes.data_as(C.POINTER(C.c_double)),
+                                        S, i, nf + j, oracle.SIMILARITY, k)
+    np.testing.assert_array_equal(np.fromfile(b1, np.float32).view(np.uint32), exp.reshape(-1).view(np.uint32))
+    # cmp --presketched over the individual cache files (multi-file loader, cmp_main.cpp:95-197)
+    files = [f"{pref}/{os.path.basename(p)}.rc_canon.sketchsize{S}.k{k}.SetSpace.DNA.opss" for p in genomes]
+    b3 = tmp_path / "m.bin"
+    _run(["cmp", "--presketched", "-k", str(k), "--binary-output", "--cmpout", str(b3)] + files)
+    exp_ut = oracle.allpairs_ut(dens, ecards, measure=oracle.SIMILARITY, k=k, nthreads=2)
+    np.testing.assert_array_equal(np.fromfile(b3, np.float32).view(np.uint32), exp_ut.view(np.uint32))

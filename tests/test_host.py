@@ -202,3 +202,40 @@ def test_format_fixture_roundtrip():
     assert tuple(pk[:16].view(np.uint64)) == (3, 32)
     np.testing.assert_array_equal(pk[16:16 + 24].view(np.float64), exp["cardinalities"][:3])
     np.testing.assert_array_equal(pk[40:].view(np.float64).reshape(3, 32), exp["signatures"][:3])
+
+
+def test_cli_float_formatter_vs_fmt_golden():
+    """the CLI's text path (dashing2_amd/host/fmtfloat.cpp) against fmt 12.1.0 goldens"""
+    exe = os.path.join(ROOT, "dashing2_amd", "bin", "fmtcheck")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "dashing2_amd", "host")])
+    out = subprocess.run([exe, os.path.join(GOLDEN, "fmt_float.tsv")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "0 bad" in out.stdout
+
+
+def _cli():
+    exe = os.path.join(ROOT, "dashing2_amd", "bin", "dashing2")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "dashing2_amd", "host")])
+    return exe
+
+
+def test_cli_flag_validation_and_errors(tmp_path):
+    exe = _cli()
+    r = subprocess.run([exe, "sketch", "--no-such-flag", "x.fa"], capture_output=True, text=True)
+    assert r.returncode == 1 and "flag no-such-flag not found in expected set. See usage." in r.stderr   # options.h:298
+    assert r.stderr.startswith("#Calling Dashing2 version")                                              # d2.cpp:136
+    r = subprocess.run([exe, "sketch"], capture_output=True, text=True)
+    assert r.returncode == 1 and "No paths provided. See usage." in r.stderr                              # sketch_main.cpp:131-134
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "dashing2 has several subcommands" in r.stderr                           # d2.cpp:112
+    r = subprocess.run([exe, "sketch", "-h"], capture_output=True, text=True)
+    assert r.returncode == 1                                                                              # sketch_main.cpp:66
+    r = subprocess.run([exe, "cmp", "--presketched", "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "flag bogus not found" in r.stderr
+    r = subprocess.run([exe, "sketch", "--presketched", "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "flag presketched not found" in r.stderr      # only valid for cmp (options.h:287-289)
+    for flag in (["--prob"], ["--full"], ["-k", "40"], ["--edit-distance"], ["--topk", "3"]):
+        r = subprocess.run([exe, "sketch"] + flag + ["x.fa"], capture_output=True, text=True)
+        assert r.returncode == 1 and "outside" in r.stderr, flag

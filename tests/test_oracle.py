@@ -168,3 +168,16 @@ def test_allpairs_matches_pairwise(oracle):
         part = oracle.allpairs_ut(sigs, cards, measure=meas, k=21, nthreads=2, rows=(5, 11))
         off = sum(N - r - 1 for r in range(5))
         np.testing.assert_array_equal(part, full[off:off + part.size])
+
+
+def test_text_formatter_vs_fmt_golden():
+    """tests/golden/fmt_float.tsv was produced by fmt 12.1.0 `fmt::format("{}", float)`."""
+    from oracle import textfmt
+    import struct
+    n = 0
+    for line in open(os.path.join(GOLDEN, "fmt_float.tsv")):
+        bits, exp = line.rstrip("\n").split("\t")
+        v = struct.unpack("<f", struct.pack("<I", int(bits, 16)))[0]
+        assert textfmt.fmt_float(v) == exp, (bits, exp)
+        n += 1
+    assert n > 12000
