@@ -59,6 +59,7 @@ SIGNATURES = {
     "d2g_densify": (_int, [_pdbl, _sz, _sz, C.POINTER(_sz), _int]),
     "d2g_epilogue_gtlt": (_f32, [_u64, _u64, _sz, _dbl, _dbl, _int, _int]),
     "d2g_epilogue_neq": (_f32, [_u64, _sz, _dbl, _dbl, _int, _int]),
+    "d2g_epilogue_ut": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _int, _int, _int, _int, _vp]),
     "d2g_epilogue_lut": (_int, [_sz, _int, _int, _int, _pf32]),
     "d2g_seqpack_create": (_int, [_int, C.POINTER(_vp)]),
     "d2g_seqpack_destroy": (None, [_vp]),
@@ -164,6 +165,19 @@ def epilogue_lut(S, measure=SIMILARITY, k=31, multiset_space=False):
     if rc:
         raise D2GError(rc)
     return lut
+
+
+def host_epilogue_ut(ca, cb, cards, N, S, r0, r1, measure=SIMILARITY, k=31, multiset_space=False, nthreads=0):
+    """integer counts of rows [r0,r1) -> float32 values (libd2g x87 host arithmetic, OpenMP)"""
+    ca = np.ascontiguousarray(ca, np.uint32)
+    cb = None if cb is None else np.ascontiguousarray(cb, np.uint32)
+    cards = np.ascontiguousarray(cards, np.float64)
+    out = np.empty(ca.size, np.float32)
+    rc = lib().d2g_epilogue_ut(_np_ptr(ca), _np_ptr(cb), _np_ptr(cards), N, S, r0, r1, measure, k, int(multiset_space),
+                               nthreads or (os.cpu_count() or 1), _np_ptr(out))
+    if rc:
+        raise D2GError(rc)
+    return out
 
 
 def epilogue_gtlt(gt, lt, S, lhc, rhc, measure=SIMILARITY, k=31):

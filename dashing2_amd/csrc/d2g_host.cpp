@@ -216,8 +216,11 @@ int d2g_epilogue_lut(size_t S, int measure, int k, int multiset_space, float *lu
 
 // epilogue over rows [r0,r1) of the condensed upper triangle from the device's integer counts.
 // ca = neq (or gt when cb != null), cb = lt.  Same arithmetic as compare(): cmp_core.cpp:458-517.
-void d2g_host_epilogue_ut(const uint32_t *ca, const uint32_t *cb, const double *cards, size_t N, size_t S,
-                          size_t r0, size_t r1, int measure, int k, int multiset_space, int nthreads, float *out) {
+int d2g_epilogue_ut(const uint32_t *ca, const uint32_t *cb, const double *cards, size_t N, size_t S,
+                    size_t r0, size_t r1, int measure, int k, int multiset_space, int nthreads, float *out) {
+    if (r0 > r1 || r1 > N || !S) return D2G_ERR_INVALID;
+    if (d2g_ut_count(N, r0, r1) == 0) return D2G_OK;
+    if (!ca || !cards || !out) return D2G_ERR_INVALID;
     std::vector<size_t> off(r1 - r0 + 1, 0);
     for (size_t i = r0; i < r1; ++i) off[i - r0 + 1] = off[i - r0] + (N - 1 - i);
     if (nthreads < 1) nthreads = 1;
@@ -234,6 +237,7 @@ void d2g_host_epilogue_ut(const uint32_t *ca, const uint32_t *cb, const double *
             else out[p] = d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], measure, k);
         }
     }
+    return D2G_OK;
 }
 
 size_t d2g_ut_count(size_t N, size_t r0, size_t r1) {

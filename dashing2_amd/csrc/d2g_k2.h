@@ -31,7 +31,3 @@ int  d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
 int  d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1,
                        uint32_t *eq_out, hipStream_t s);
 
-// host epilogue over a condensed row range (d2g_host.cpp; x87 arithmetic, OpenMP)
-extern "C" void d2g_host_epilogue_ut(const uint32_t *ca, const uint32_t *cb /* lt or null */, const double *cards,
-                                     size_t N, size_t S, size_t r0, size_t r1, int measure, int k,
-                                     int multiset_space, int nthreads, float *out);

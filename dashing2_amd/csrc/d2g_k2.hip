@@ -387,7 +387,7 @@ int d2g_cmp_dist_ut(d2g_ctx *ctx, const uint64_t *sig_bits, const double *cards,
 #undef D2G_TRY
     cleanup();
     if (rc) return rc;
-    d2g_host_epilogue_ut(ca.data(), need_gtlt ? cb.data() : nullptr, cards, N, S, r0, r1, measure, k,
+    d2g_epilogue_ut(ca.data(), need_gtlt ? cb.data() : nullptr, cards, N, S, r0, r1, measure, k,
                          multiset_space, nthreads, out);
     return D2G_OK;
 }

@@ -100,6 +100,11 @@ int      d2g_densify(double *sigs /* [n][S] */, size_t n, size_t sketchsize, siz
 float    d2g_epilogue_gtlt(uint64_t gt, uint64_t lt, size_t sketchsize, double lhcard, double rhcard,
                            int measure, int k);
 float    d2g_epilogue_neq(uint64_t neq, size_t sketchsize, double lhcard, double rhcard, int measure, int k);
+/* the same epilogues over rows [r0,r1) of the condensed upper triangle from the device's integer
+ * counts (OpenMP): ca = neq, or gt when cb (= lt) is non-null.  With cb == NULL in set space the
+ * sketch size must be a power of two (then only gt+lt = S-neq matters: every multiple of 1/S is exact). */
+int      d2g_epilogue_ut(const uint32_t *ca, const uint32_t *cb, const double *cards, size_t N, size_t sketchsize,
+                         size_t r0, size_t r1, int measure, int k, int multiset_space, int nthreads, float *out);
 /* table t[neq] = epilogue for card-independent measures (SIMILARITY, POISSON_LLR) when the
  * value depends on neq only (power-of-two S in set space; any S in multiset space).
  * Returns D2G_ERR_UNSUPPORTED otherwise. lut_out has S+1 floats. */
