@@ -177,12 +177,12 @@ def main():
                 "prep_ms": prep_ms,
                 "note": "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute"}
     if cs.algo == D.CMP_BITSLICE:
-        ops = my_pairs * ((S + 31) // 32) * (nbits + 1)
+        ops = my_pairs * ((S + 31) // 32) * (nbits + 2)      # id planes + unique plane (v_bitop3) + v_bcnt
     else:
         ops = my_pairs * S * 2
     compute = {"bound": "valu", "unit": "lane-ops/s", "achieved": ops / (k2_ms * 1e-3) if k2_ms > 0 else 0.0,
                "peak": VALU_PEAK_LANEOPS, "frac": (ops / (k2_ms * 1e-3) / VALU_PEAK_LANEOPS) if k2_ms > 0 else 0.0,
-               "bit_planes": nbits, "max_distinct_per_column": max_distinct}
+               "bit_planes": nbits, "max_shared_values_per_column_plus1": max_distinct}
 
     # ---- secondary: K1 sketch construction, packed bases resident in HBM
     sketch = None

@@ -10,11 +10,11 @@ struct d2g_cmp_set {
     uint64_t *d_rows = nullptr;   // [N][S]     row-major 64-bit patterns
     uint64_t *d_cols = nullptr;   // [S][Npad]  register-major (transposed), zero padded
     // bit-sliced operand (algo == D2G_CMP_BITSLICE); all buffers are allocated once per set
-    uint32_t *d_planes = nullptr; // [ntb][nbits_cap][Nstride]: bit x of word = bit b of id[32*tb+x][j]
+    uint32_t *d_planes = nullptr; // [ntb][nbits_cap+1][Nstride]: bit x of word = bit b of id[32*tb+x][j]; last slot = "unique" plane
     size_t Nstride = 0;           // Npad + 64 (row tiles may read past Npad)
     int nbits_cap = 0;            // plane slots per 32-register group = ceil(log2 N) (>= 1)
     int ntb = 0;                  // ceil(S/32)
-    uint32_t *d_meta = nullptr;   // [0] = max distinct values per column (device side; the kernels
+    uint32_t *d_meta = nullptr;   // [0] = max over columns of (#values occurring >= 2 times) + 1 (device side; the kernels
                                   //       derive the live plane count from it, no host round trip)
     uint32_t *d_owner = nullptr;  // workspace: [S][T] open-addressing owner table
     uint32_t *d_ids = nullptr;    // workspace: [S][Npad] dense ids

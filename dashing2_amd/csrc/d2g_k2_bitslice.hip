@@ -32,6 +32,12 @@ constexpr int BS_RANK_THREADS = 1024;
 // One workgroup per register index t.  owner[] (T slots, pre-set to EMPTY) records the first
 // sketch index that claimed a slot; equality is decided against that sketch's value, so no key
 // storage and no reserved sentinel value is needed.
+constexpr uint32_t BS_DUP = 0x80000000u;       // owner-table flag: the value has been seen again
+constexpr uint32_t BS_UNIQ = 0x80000000u;      // id flag: value occurs once in its column (never equal)
+
+// Singleton folding: a value that occurs exactly once in its register column can never compare
+// equal to anything, so all such values share id 0 and set the "unique" bit instead; only values
+// occurring >= 2 times get dense ids 1..D2.  meta[0] = D2 + 1 (number of id values).
 template <bool LDS_TABLE>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
                                                                   uint32_t *owner_all, uint32_t T, int logT,
@@ -53,17 +59,21 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> (64 - logT));
         for (;;) {
             const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, (uint32_t)j);
-            if (cur == BS_EMPTY || col[cur] == v) break;
+            if (cur == BS_EMPTY) break;                                   // first occurrence: we own the slot
+            if (col[cur & ~BS_DUP] == v) {                                // same value seen again
+                if (!(cur & BS_DUP)) atomicOr(&own[h], BS_DUP);
+                break;
+            }
             h = (h + 1) & mask;
         }
         ids[j] = h;
     }
     __syncthreads();
 
-    // compaction: exclusive scan over slot occupancy -> dense rank, written over the owner
+    // compaction: slots whose value occurs >= 2 times get ranks 1..D2; singletons get BS_UNIQ
     __shared__ uint32_t wave_tot[BS_RANK_THREADS / 64];
     __shared__ uint32_t running;
-    if (tid == 0) running = 0;
+    if (tid == 0) running = 1;                                           // id 0 is reserved for singletons
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
     for (uint32_t base = 0; base < T; base += BS_RANK_THREADS) {
@@ -71,7 +81,8 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         uint32_t cur = BS_EMPTY;
         if (h < T) cur = LDS_TABLE ? own[h] : __hip_atomic_load(&own[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool occ = cur != BS_EMPTY;
-        const unsigned long long bal = __ballot(occ);
+        const bool dup = occ && (cur & BS_DUP);
+        const unsigned long long bal = __ballot(dup);
         const uint32_t before = __popcll(bal & ((1ull << lane) - 1));
         if (lane == 0) wave_tot[wave] = __popcll(bal);
         __syncthreads();
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
             tot += x;
         }
         const uint32_t r0 = running;
-        if (occ) own[h] = r0 + woff + before;
+        if (occ) own[h] = dup ? r0 + woff + before : BS_UNIQ;
         __syncthreads();
         if (tid == 0) running = r0 + tot;
         __syncthreads();
@@ -111,13 +122,17 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
         const size_t t = tb * 32 + x;
         id[x] = (t < S && j < N) ? ids[t * Npad + j] : 0u;     // padded registers/sketches: id 0
     }
-    uint32_t *dst = planes + tb * (size_t)nbits_cap * Nstride + j;
+    uint32_t *dst = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
     for (int b = 0; b < nbits; ++b) {
         uint32_t w = 0;
 #pragma unroll
         for (int x = 0; x < 32; ++x) w |= ((id[x] >> b) & 1u) << x;
         dst[(size_t)b * Nstride] = w;
     }
+    uint32_t u = 0;                                    // the "unique" plane lives in slot nbits_cap
+#pragma unroll
+    for (int x = 0; x < 32; ++x) u |= (id[x] >> 31) << x;
+    dst[(size_t)nbits_cap * Nstride] = u;
 }
 
 // ------------------------------------------------------------------ 3. the pair kernel
@@ -126,8 +141,9 @@ constexpr int BS_CB = 256;                // columns per workgroup tile (all var
 
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef u32x16 __attribute__((aligned(4))) u32x16_u;
-// v_bitop3_b32 truth table: src0 = 0xF0, src1 = 0xCC, src2 = 0xAA  ->  src2 | (src0 ^ src1)
-constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);
+// v_bitop3_b32 truth tables: src0 = 0xF0, src1 = 0xCC, src2 = 0xAA
+constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);   // mismatch accumulation
+constexpr unsigned BITOP3_C_OR_A_AND_B = 0xAA | (0xF0 & 0xCC);   // both values unique => never equal
 
 // IW = 16 rows per wave (one s_load_dwordx16 per plane), JR = 64-column groups per lane,
 // WC = waves side by side along the columns (WC * JR * 64 = 256), PF = software prefetch of the
@@ -164,7 +180,8 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
 
     const uint32_t *prow = planes + iw0;          // uniform: scalar loads
     const uint32_t *pcol = planes + j0 + lane;    // per lane: coalesced dword loads
-    const size_t tbstride = (size_t)nbits_cap * Nstride;
+    const size_t tbstride = (size_t)(nbits_cap + 1) * Nstride;
+    const size_t uoff = (size_t)nbits_cap * Nstride;          // slot of the "unique" plane within a group
     if (!PF) {
         for (int tb = 0; tb < ntb; ++tb) {
             uint32_t z[IW][JR];
@@ -186,10 +203,17 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
                     for (int c = 0; c < JR; ++c)
                         z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
             }
+            {
+                const u32x16_u sa = *reinterpret_cast<const u32x16_u *>(prow + base + uoff);
+                uint32_t vb[JR];
 #pragma unroll
-            for (int i = 0; i < IW; ++i)
+                for (int c = 0; c < JR; ++c) vb[c] = pcol[base + uoff + 64 * c];
 #pragma unroll
-                for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);   // -> v_bcnt_u32_b32
+                for (int i = 0; i < IW; ++i)
+#pragma unroll
+                    for (int c = 0; c < JR; ++c)
+                        acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_AND_B));
+            }
         }
     } else {
         size_t off_n = 0;
@@ -203,14 +227,15 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
             for (int i = 0; i < IW; ++i)
 #pragma unroll
                 for (int c = 0; c < JR; ++c) z[i][c] = 0;
-            const size_t next_base = (tb + 1 < ntb) ? (size_t)(tb + 1) * tbstride : 0;   // last: harmless reload of plane 0
+            const size_t base = (size_t)tb * tbstride;
+            const size_t next_base = (tb + 1 < ntb) ? base + tbstride : 0;   // last: harmless reload of plane 0
 #pragma unroll 2
             for (int p = 0; p < nbits; ++p) {
                 const u32x16_u sa = sa_n;
                 uint32_t vb[JR];
 #pragma unroll
                 for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
-                off_n = (p + 1 < nbits) ? off_n + Nstride : next_base;
+                off_n = (p + 1 < nbits) ? off_n + Nstride : base + uoff;      // after the last id plane: the unique plane
                 sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
 #pragma unroll
                 for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
@@ -220,10 +245,21 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
                     for (int c = 0; c < JR; ++c)
                         z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
             }
+            {
+                const u32x16_u sa = sa_n;
+                uint32_t vb[JR];
 #pragma unroll
-            for (int i = 0; i < IW; ++i)
+                for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
+                off_n = next_base;
+                sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
 #pragma unroll
-                for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);
+                for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
+#pragma unroll
+                for (int i = 0; i < IW; ++i)
+#pragma unroll
+                    for (int c = 0; c < JR; ++c)
+                        acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_AND_B));
+            }
         }
     }
 #pragma unroll
@@ -234,7 +270,9 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
         for (int c = 0; c < JR; ++c) {
             const size_t jj = j0 + lane + 64 * c;
             if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii))
-                store(out_pos(sh, ii, jj), S - acc[i][c], 0u);      // padded registers never mismatch
+                // padded registers never mismatch; a sketch equals itself even where its values are
+                // column-unique (the "unique" plane only separates DIFFERENT sketches)
+                store(out_pos(sh, ii, jj), ii == jj ? S : S - acc[i][c], 0u);
         }
     }
 }
@@ -297,7 +335,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     if ((!lds_table && (e = hipMalloc((void **)&set->d_owner, S * (size_t)set->T * sizeof(uint32_t))) != hipSuccess) ||
         (e = hipMalloc((void **)&set->d_ids, S * Npad * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_meta, 4 * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_planes, (size_t)set->ntb * set->nbits_cap * set->Nstride * sizeof(uint32_t))) != hipSuccess) {
+        (e = hipMalloc((void **)&set->d_planes, (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride * sizeof(uint32_t))) != hipSuccess) {
         ctx->last_error = std::string("bitslice alloc: ") + hipGetErrorString(e);
         d2g_bitslice_free(set);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;

@@ -185,8 +185,9 @@ int  d2g_cmp_set_create(d2g_ctx *ctx, const uint64_t *sig_bits_host, size_t N, s
 /* re-load an existing set with a new N x S matrix of the same shape, reusing every device
  * buffer (no allocation, no host synchronisation: the whole prepare chain is enqueued on `stream`) */
 int  d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, void *stream);
-/* bit-sliced sets: max distinct values in any register column and the resulting plane count
- * (synchronises `stream`); both 0 for a DIRECT set */
+/* bit-sliced sets: max over register columns of (#values occurring >= 2 times) + 1 (values that
+ * occur once share id 0 + a "unique" plane) and the resulting id-plane count (synchronises
+ * `stream`); both 0 for a DIRECT set */
 int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits);
 void d2g_cmp_set_destroy(d2g_cmp_set *set);
 int  d2g_cmp_set_algo(const d2g_cmp_set *set);      /* the algorithm actually selected */
