@@ -21,6 +21,9 @@ struct d2g_cmp_set {
     uint32_t T = 0; int logT = 0;
 };
 
+struct PairShape;
+int  finish_shape(d2g_ctx *ctx, PairShape &sh, unsigned rb);   // d2g_k2.hip
+
 // d2g_k2_bitslice part (same shared object)
 int  d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);

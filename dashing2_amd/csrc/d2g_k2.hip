@@ -33,6 +33,22 @@ constexpr int K2_RB = 4 * K2_IW;         // rows per workgroup tile (32)
 constexpr int K2_CB = 64 * K2_JR;        // cols per workgroup tile (256)
 constexpr int K2_TC = 2;                 // registers per inner step (IW*TC*2 SGPRs of A values)
 
+}  // namespace
+// tile grid of a launch: counts the wanted tiles (host mirror of tile_of_block)
+int finish_shape(d2g_ctx *ctx, PairShape &sh, unsigned rb) {
+    sh.rb = rb;
+    sh.nrt = (unsigned)div_up<size_t>(sh.i_hi - sh.i_lo, rb);
+    sh.ct0 = (unsigned)(sh.j_lo / 256);
+    sh.nct = (unsigned)(div_up<size_t>(sh.j_hi, 256) - sh.ct0);
+    size_t total = 0;
+    for (unsigned c = 0; c < sh.nct; ++c) total += tiles_in_column(sh, c);
+    D2G_CHECK(ctx, total < (1ull << 31), "pair tile grid too large; shard rows");
+    sh.nvalid_total = (unsigned)total;
+    sh.per_xcd = (unsigned)div_up<size_t>(total, 8);
+    return D2G_OK;
+}
+namespace {
+
 // ---------------------------------------------------------------- transpose [N][S] -> [S][Npad]
 __global__ __launch_bounds__(256) void k2_transpose_kernel(const uint64_t *__restrict__ rows, uint64_t *__restrict__ cols,
                                                            size_t N, size_t S, size_t Npad) {
@@ -54,15 +70,10 @@ __global__ __launch_bounds__(256) void k2_transpose_kernel(const uint64_t *__res
 template <bool GTLT, class Store>
 __global__ __launch_bounds__(K2_THREADS) void k2_direct_kernel(const uint64_t *__restrict__ rows, const uint64_t *__restrict__ cols,
                                                                size_t S, size_t Npad, PairShape sh, Store store) {
-    // XCD-aware logical tile id: workgroup b runs on XCD b%8; give each XCD a contiguous
-    // range of (column-major) tiles so its L2 holds the B columns they share.
-    const unsigned b = blockIdx.x;
-    const unsigned L = (b & 7u) * sh.per_xcd + (b >> 3);
-    if (L >= sh.nblk) return;
-    const unsigned ct = L / sh.nrt, rt = L % sh.nrt;
+    unsigned ct, rt;
+    if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;
     const size_t i0 = sh.i_lo + (size_t)rt * K2_RB;
     const size_t j0 = (size_t)(sh.ct0 + ct) * K2_CB;
-    if (sh.ut && j0 + K2_CB - 1 <= i0) return;            // tile entirely on/below the diagonal
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -115,28 +126,40 @@ __global__ __launch_bounds__(K2_THREADS) void k2_direct_kernel(const uint64_t *_
             }
         }
     }
+    if constexpr (GTLT) {
 #pragma unroll
-    for (int i = 0; i < K2_IW; ++i) {
-        const size_t ii = iw0 + i;
-        if (ii >= sh.i_hi) break;
+        for (int i = 0; i < K2_IW; ++i) {
+            const size_t ii = iw0 + i;
+            if (ii >= sh.i_hi) break;
 #pragma unroll
-        for (int c = 0; c < K2_JR; ++c) {
-            const size_t jj = j0 + lane + 64 * c;
-            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii))
-                store(out_pos(sh, ii, jj), acc[i][c], GTLT ? accg[i][c] : 0u);
+            for (int c = 0; c < K2_JR; ++c) {
+                const size_t jj = j0 + lane + 64 * c;
+                if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii)) store.put2(out_pos(sh, ii, jj), acc[i][c], accg[i][c]);
+            }
+        }
+    } else {
+        uint32_t val[K2_IW][K2_JR];
+#pragma unroll
+        for (int i = 0; i < K2_IW; ++i)
+#pragma unroll
+            for (int c = 0; c < K2_JR; ++c) val[i][c] = store.value(acc[i][c]);
+#pragma unroll
+        for (int i = 0; i < K2_IW; ++i) {
+            const size_t ii = iw0 + i;
+            if (ii >= sh.i_hi) break;
+#pragma unroll
+            for (int c = 0; c < K2_JR; ++c) {
+                const size_t jj = j0 + lane + 64 * c;
+                if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii)) store.put(out_pos(sh, ii, jj), val[i][c]);
+            }
         }
     }
 }
 
 template <bool GTLT, class Store>
 int launch_direct(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
-    sh.nrt = (unsigned)div_up<size_t>(sh.i_hi - sh.i_lo, K2_RB);
-    sh.ct0 = (unsigned)(sh.j_lo / K2_CB);
-    sh.nct = (unsigned)(div_up<size_t>(sh.j_hi, K2_CB) - sh.ct0);
-    const size_t nblk = (size_t)sh.nrt * sh.nct;
-    D2G_CHECK(ctx, nblk < (1ull << 31), "pair tile grid too large; shard rows");
-    sh.nblk = (unsigned)nblk;
-    sh.per_xcd = (unsigned)div_up<size_t>(nblk, 8);
+    if (int rc = finish_shape(ctx, sh, K2_RB)) return rc;
+    if (sh.nvalid_total == 0) return D2G_OK;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
     hipLaunchKernelGGL((k2_direct_kernel<GTLT, Store>), dim3(sh.per_xcd * 8), dim3(K2_THREADS), 0, s,
                        set->d_rows, set->d_cols, set->S, set->Npad, sh, store);

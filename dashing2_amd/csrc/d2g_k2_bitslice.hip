@@ -148,7 +148,7 @@ constexpr unsigned BITOP3_C_OR_A_AND_B = 0xAA | (0xF0 & 0xCC);   // both values 
 // IW = 16 rows per wave (one s_load_dwordx16 per plane), JR = 64-column groups per lane,
 // WC = waves side by side along the columns (WC * JR * 64 = 256), PF = software prefetch of the
 // next plane's operands (register double buffer).
-template <int JR, bool PF, class Store>
+template <int JR, bool PF, class Store, int ABL = 0>
 __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
                                                                  const uint32_t *__restrict__ meta, int ntb, uint32_t S,
                                                                  PairShape sh, Store store) {
@@ -156,10 +156,8 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
     constexpr int WC = BS_CB / (64 * JR);          // waves along columns: 1 (JR=4) or 2 (JR=2)
     constexpr int WR = 4 / WC;                     // waves along rows
     constexpr int RB = WR * IW;                    // rows per workgroup tile
-    const unsigned b = blockIdx.x;
-    const unsigned L = (b & 7u) * sh.per_xcd + (b >> 3);      // XCD-contiguous, column-major tiles
-    if (L >= sh.nblk) return;
-    const unsigned ct = L / sh.nrt, rt = L % sh.nrt;
+    unsigned ct, rt;
+    if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
     const size_t i0 = sh.i_lo + (size_t)rt * RB;
     const size_t jt0 = (size_t)(sh.ct0 + ct) * BS_CB;
     if (sh.ut && jt0 + BS_CB - 1 <= i0) return;
@@ -236,14 +234,21 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
 #pragma unroll
                 for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
                 off_n = (p + 1 < nbits) ? off_n + Nstride : base + uoff;      // after the last id plane: the unique plane
-                sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
+                if (ABL != 1) {
+                    sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
 #pragma unroll
-                for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
+                    for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
+                }
+                if (ABL == 2) {
 #pragma unroll
-                for (int i = 0; i < IW; ++i)
+                    for (int c = 0; c < JR; ++c) z[0][c] ^= sa[0] ^ vb[c];      // ablation: loads only
+                } else {
 #pragma unroll
-                    for (int c = 0; c < JR; ++c)
-                        z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+                    for (int i = 0; i < IW; ++i)
+#pragma unroll
+                        for (int c = 0; c < JR; ++c)
+                            z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+                }
             }
             {
                 const u32x16_u sa = sa_n;
@@ -262,6 +267,14 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
             }
         }
     }
+    // padded registers never mismatch; a sketch equals itself even where its values are
+    // column-unique (the "unique" plane only separates DIFFERENT sketches)
+    uint32_t val[IW][JR];
+#pragma unroll
+    for (int i = 0; i < IW; ++i)
+#pragma unroll
+        for (int c = 0; c < JR; ++c)
+            val[i][c] = store.value((iw0 + i) == (j0 + lane + 64 * c) ? S : S - acc[i][c]);
 #pragma unroll
     for (int i = 0; i < IW; ++i) {
         const size_t ii = iw0 + i;
@@ -269,10 +282,227 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
 #pragma unroll
         for (int c = 0; c < JR; ++c) {
             const size_t jj = j0 + lane + 64 * c;
-            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii))
-                // padded registers never mismatch; a sketch equals itself even where its values are
-                // column-unique (the "unique" plane only separates DIFFERENT sketches)
-                store(out_pos(sh, ii, jj), ii == jj ? S : S - acc[i][c], 0u);
+            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii)) store.put(out_pos(sh, ii, jj), val[i][c]);
+        }
+    }
+}
+
+// Ring-prefetch form: the (id planes..., unique plane) sequence of all 32-register groups is one
+// stream of Q = ntb * (nbits + 1) steps; D steps of operands are kept in flight per wave
+// (D * JR VGPRs + D * 16 SGPRs), which covers the L2 / scalar-cache latency with few waves.
+template <int JR, int D, class Store>
+__global__ __launch_bounds__(BS_THREADS) void k2_bitslice_ring_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
+                                                                      const uint32_t *__restrict__ meta, int ntb, uint32_t S,
+                                                                      PairShape sh, Store store) {
+    constexpr int IW = 16;
+    constexpr int WC = BS_CB / (64 * JR);
+    constexpr int WR = 4 / WC;
+    constexpr int RB = WR * IW;
+    unsigned ct, rt;
+    if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
+    const size_t i0 = sh.i_lo + (size_t)rt * RB;
+    const size_t jt0 = (size_t)(sh.ct0 + ct) * BS_CB;
+    if (sh.ut && jt0 + BS_CB - 1 <= i0) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const size_t iw0 = i0 + (size_t)(wave / WC) * IW;
+    const size_t j0 = jt0 + (size_t)(wave % WC) * (64 * JR);
+    if (iw0 >= sh.i_hi) return;
+    if (sh.ut && j0 + 64 * JR - 1 <= iw0) return;
+
+    const int nbits = live_planes(meta);
+    const uint32_t *prow = planes + iw0;
+    const uint32_t *pcol = planes + j0 + lane;
+    const size_t tbstride = (size_t)(nbits_cap + 1) * Nstride;
+    const size_t uoff = (size_t)nbits_cap * Nstride;
+    const int Q = ntb * (nbits + 1);
+
+    uint32_t acc[IW][JR], z[IW][JR];
+#pragma unroll
+    for (int i = 0; i < IW; ++i)
+#pragma unroll
+        for (int c = 0; c < JR; ++c) { acc[i][c] = 0; z[i][c] = 0; }
+
+    // load stream state: (group, plane-within-group) of the next step to fetch
+    int ltb = 0, lp = 0;
+    auto next_off = [&]() -> size_t {
+        const size_t off = (ltb < ntb) ? (size_t)ltb * tbstride + (lp < nbits ? (size_t)lp * Nstride : uoff) : 0;
+        if (++lp > nbits) { lp = 0; ++ltb; }
+        return off;
+    };
+    u32x16_u sa_r[D];
+    uint32_t vb_r[D][JR];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        const size_t off = next_off();
+        sa_r[u] = *reinterpret_cast<const u32x16_u *>(prow + off);
+#pragma unroll
+        for (int c = 0; c < JR; ++c) vb_r[u][c] = pcol[off + 64 * c];
+    }
+    int p = 0;                                   // plane-within-group of the step being computed
+    for (int q = 0; q < Q;) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            if (q < Q) {
+                const u32x16_u sa = sa_r[u];
+                uint32_t vb[JR];
+#pragma unroll
+                for (int c = 0; c < JR; ++c) vb[c] = vb_r[u][c];
+                const size_t off = next_off();
+                sa_r[u] = *reinterpret_cast<const u32x16_u *>(prow + off);
+#pragma unroll
+                for (int c = 0; c < JR; ++c) vb_r[u][c] = pcol[off + 64 * c];
+                if (p < nbits) {
+#pragma unroll
+                    for (int i = 0; i < IW; ++i)
+#pragma unroll
+                        for (int c = 0; c < JR; ++c)
+                            z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+                    ++p;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < IW; ++i)
+#pragma unroll
+                        for (int c = 0; c < JR; ++c) {
+                            acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_AND_B));
+                            z[i][c] = 0;
+                        }
+                    p = 0;
+                }
+                ++q;
+            }
+        }
+    }
+    // padded registers never mismatch; a sketch equals itself even where its values are
+    // column-unique (the "unique" plane only separates DIFFERENT sketches)
+    uint32_t val[IW][JR];
+#pragma unroll
+    for (int i = 0; i < IW; ++i)
+#pragma unroll
+        for (int c = 0; c < JR; ++c)
+            val[i][c] = store.value((iw0 + i) == (j0 + lane + 64 * c) ? S : S - acc[i][c]);
+#pragma unroll
+    for (int i = 0; i < IW; ++i) {
+        const size_t ii = iw0 + i;
+        if (ii >= sh.i_hi) break;
+#pragma unroll
+        for (int c = 0; c < JR; ++c) {
+            const size_t jj = j0 + lane + 64 * c;
+            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii)) store.put(out_pos(sh, ii, jj), val[i][c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LDS-staged pair kernel
+// Workgroup = 4 waves, tile = 32 rows x 256 columns; wave w owns rows 8w..8w+7 x all 256 columns,
+// lane l owns columns 4l..4l+3 (one ds_read_b128 per plane).  For every 32-register group the
+// workgroup stages the group's (nbits+1) plane rows -- 256 column words + 32 row words each --
+// into LDS with global_load_lds (asynchronous, no VGPR round trip), one group ahead of the
+// compute (double buffer, one barrier per group).  Row words are read back with uniform-address
+// (broadcast) ds_read_b128, so every v_bitop3 operand is a VGPR and no scalar-load latency
+// (out-of-order s_load => lgkmcnt(0)) sits on the critical path.
+constexpr int BL_ROWS = 32;
+constexpr int BL_PLANE_WORDS = 256 + BL_ROWS;          // LDS words per staged plane
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <class Store>
+__global__ __launch_bounds__(BS_THREADS) void k2_bitslice_lds_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
+                                                                     const uint32_t *__restrict__ meta, int ntb, uint32_t S,
+                                                                     PairShape sh, Store store) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];      // 2 x (nbits_cap+1) x BL_PLANE_WORDS
+    unsigned ct, rt;
+    if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
+    const size_t i0 = sh.i_lo + (size_t)rt * BL_ROWS;
+    const size_t jt0 = (size_t)(sh.ct0 + ct) * BS_CB;
+    if (sh.ut && jt0 + BS_CB - 1 <= i0) return;                          // whole tile on/below the diagonal (block-uniform)
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nbits = live_planes(meta);
+    const int nb1 = nbits + 1;
+    const size_t tbstride = (size_t)(nbits_cap + 1) * Nstride;
+    const size_t uoff = (size_t)nbits_cap * Nstride;
+    const int bufwords = (nbits_cap + 1) * BL_PLANE_WORDS;
+
+    // staging: wave w copies column words [64w, 64w+64) of every plane; wave 0 lanes 0..31 also the row words
+    const uint32_t *gcol = planes + jt0 + threadIdx.x;
+    const uint32_t *grow = planes + i0 + lane;
+    auto stage = [&](int tb, int buf) {
+        const size_t base = (size_t)tb * tbstride;
+        uint32_t *dst = lds + buf * bufwords;
+        for (int p = 0; p < nb1; ++p) {
+            const size_t off = base + (p < nbits ? (size_t)p * Nstride : uoff);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)(gcol + off),
+                                             (__attribute__((address_space(3))) uint32_t *)(dst + p * BL_PLANE_WORDS + 64 * wave), 4, 0, 0);
+            if (wave == 0 && lane < BL_ROWS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)(grow + off),
+                                                 (__attribute__((address_space(3))) uint32_t *)(dst + p * BL_PLANE_WORDS + 256), 4, 0, 0);
+        }
+    };
+
+    uint32_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c] = 0;
+
+    stage(0, 0);
+    for (int tb = 0; tb < ntb; ++tb) {
+        const int buf = tb & 1;
+        // the loads of group tb were issued one iteration ago: wait for them, make them visible
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tb + 1 < ntb) stage(tb + 1, buf ^ 1);                        // prefetch the next group (other buffer)
+        const uint32_t *src = lds + buf * bufwords;
+        uint32_t z[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) z[i][c] = 0;
+#pragma unroll 2
+        for (int p = 0; p < nbits; ++p) {
+            const uint32_t *pl = src + p * BL_PLANE_WORDS;
+            const u32x4 cw = *reinterpret_cast<const u32x4 *>(pl + 4 * lane);
+            const u32x4 r0 = *reinterpret_cast<const u32x4 *>(pl + 256 + 8 * wave);
+            const u32x4 r1 = *reinterpret_cast<const u32x4 *>(pl + 256 + 8 * wave + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t rw = i < 4 ? r0[i] : r1[i - 4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) z[i][c] = __builtin_amdgcn_bitop3_b32(rw, cw[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+            }
+        }
+        {
+            const uint32_t *pl = src + nbits * BL_PLANE_WORDS;
+            const u32x4 cw = *reinterpret_cast<const u32x4 *>(pl + 4 * lane);
+            const u32x4 r0 = *reinterpret_cast<const u32x4 *>(pl + 256 + 8 * wave);
+            const u32x4 r1 = *reinterpret_cast<const u32x4 *>(pl + 256 + 8 * wave + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t rw = i < 4 ? r0[i] : r1[i - 4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(rw, cw[c], z[i][c], BITOP3_C_OR_A_AND_B));
+            }
+        }
+        // all waves must be done reading buffer `buf` before it is overwritten two iterations later:
+        // guaranteed by the barrier at the top of the next iteration (loads into `buf` are issued after it)
+    }
+    const size_t iw0 = i0 + 8 * (size_t)wave;
+    uint32_t val[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) val[i][c] = store.value((iw0 + i) == (jt0 + 4 * lane + c) ? S : S - acc[i][c]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const size_t ii = iw0 + i;
+        if (ii >= sh.i_hi) break;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const size_t jj = jt0 + 4 * lane + c;
+            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii)) store.put(out_pos(sh, ii, jj), val[i][c]);
         }
     }
 }
@@ -285,16 +515,12 @@ int bs_variant() {
 
 template <class Store>
 int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
-    const int var = bs_variant();            // 0: JR4  1: JR2  2: JR4+prefetch  3: JR2+prefetch
-    const int JR = (var & 1) ? 2 : 4;
-    const int RB = (var & 1) ? 32 : 64;
-    sh.nrt = (unsigned)div_up<size_t>(sh.i_hi - sh.i_lo, RB);
-    sh.ct0 = (unsigned)(sh.j_lo / BS_CB);
-    sh.nct = (unsigned)(div_up<size_t>(sh.j_hi, BS_CB) - sh.ct0);
-    const size_t nblk = (size_t)sh.nrt * sh.nct;
-    D2G_CHECK(ctx, nblk < (1ull << 31), "pair tile grid too large; shard rows");
-    sh.nblk = (unsigned)nblk;
-    sh.per_xcd = (unsigned)div_up<size_t>(nblk, 8);
+    const int var = bs_variant();            // 0: JR4  1: JR2  2: JR4+prefetch  3: JR2+prefetch  4/5/6: JR2 ring D=2/3/4  7: JR4 ring D=3
+    const bool jr2 = (var == 1 || var == 3 || var == 4 || var == 5 || var == 6 || var == 8 || var == 9 || var == 10);
+    const int JR = jr2 ? 2 : 4;
+    const int RB = jr2 ? 32 : 64;
+    if (int rc = finish_shape(ctx, sh, (unsigned)RB)) return rc;
+    if (sh.nvalid_total == 0) return D2G_OK;
     (void)JR;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
 #define BS_LAUNCH(JRV, PFV) hipLaunchKernelGGL((k2_bitslice_kernel<JRV, PFV, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, \
@@ -303,6 +529,22 @@ int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store st
         case 1: BS_LAUNCH(2, false); break;
         case 2: BS_LAUNCH(4, true); break;
         case 3: BS_LAUNCH(2, true); break;
+#define BS_RING(JRV, DV) hipLaunchKernelGGL((k2_bitslice_ring_kernel<JRV, DV, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, \
+        set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store)
+        case 8: hipLaunchKernelGGL((k2_bitslice_kernel<2, true, Store, 1>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store); break;   // ablation: compute only
+        case 9: hipLaunchKernelGGL((k2_bitslice_kernel<2, true, Store, 2>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store); break;   // ablation: loads only
+        case 10: {
+            const size_t ldsb = 2 * (size_t)(set->nbits_cap + 1) * BL_PLANE_WORDS * sizeof(uint32_t);
+            auto kern = k2_bitslice_lds_kernel<Store>;
+            if (ldsb > 48 * 1024) D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            hipLaunchKernelGGL(kern, dim3(sh.per_xcd * 8), dim3(BS_THREADS), ldsb, s, set->d_planes, set->Nstride, set->nbits_cap,
+                               set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
+        } break;
+        case 4: BS_RING(2, 2); break;
+        case 5: BS_RING(2, 3); break;
+        case 6: BS_RING(2, 4); break;
+        case 7: BS_RING(4, 3); break;
+#undef BS_RING
         default: BS_LAUNCH(4, false); break;
     }
 #undef BS_LAUNCH

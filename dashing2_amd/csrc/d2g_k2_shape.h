@@ -10,11 +10,36 @@ struct PairShape {
     size_t i_lo, i_hi;   // rows of the pair matrix this launch covers
     size_t j_lo, j_hi;   // columns
     int ut;          // 1: only j > i, condensed upper-triangular addressing
-    unsigned nrt, nct;   // tile grid
-    unsigned ct0;        // first column tile (j_lo / K2_CB)
-    unsigned nblk;       // nrt * nct
-    unsigned per_xcd;    // ceil(nblk / 8)
+    unsigned nrt, nct;   // tile grid (row tiles of RB rows, column tiles of 256 columns)
+    unsigned ct0;        // first column tile (j_lo / 256)
+    unsigned rb;         // rows per workgroup tile
+    unsigned nvalid_total;   // tiles that contain at least one wanted pair
+    unsigned per_xcd;        // ceil(nvalid_total / 8)
 };
+
+// number of row tiles of column tile c (0-based within the launch) that hold a pair with j > i:
+// tile (rt, c) is wanted iff i_lo + rt*rb < 256*(ct0+c+1) - 1.  256 % rb == 0.
+__host__ __device__ __forceinline__ unsigned tiles_in_column(const PairShape &sh, unsigned c) {
+    if (!sh.ut) return sh.nrt;
+    const long long x = (long long)(256 / sh.rb) * (long long)(sh.ct0 + c + 1) - (long long)((sh.i_lo + 1) / sh.rb);
+    return x <= 0 ? 0u : (x >= (long long)sh.nrt ? sh.nrt : (unsigned)x);
+}
+
+// Workgroup b -> tile.  Workgroups are dealt to XCDs round-robin by the hardware (b % 8); every XCD
+// gets an equal COUNT of wanted tiles, contiguous in column-major order, so its L2 keeps the
+// column operand its workgroups share and the triangle stays load-balanced across XCDs.
+__device__ __forceinline__ bool tile_of_block(const PairShape &sh, unsigned b, unsigned &ct, unsigned &rt) {
+    unsigned v = (b & 7u) * sh.per_xcd + (b >> 3);
+    if (v >= sh.nvalid_total) return false;
+    unsigned c = 0;
+    for (;; ++c) {                                   // uniform scalar scan over <= nct column tiles
+        const unsigned n = tiles_in_column(sh, c);
+        if (v < n) break;
+        v -= n;
+    }
+    ct = c; rt = v;
+    return true;
+}
 
 __device__ __forceinline__ size_t out_pos(const PairShape &sh, size_t i, size_t j) {
     if (sh.ut) {
@@ -26,10 +51,19 @@ __device__ __forceinline__ size_t out_pos(const PairShape &sh, size_t i, size_t 
     return (i - sh.i_lo) * (sh.j_hi - sh.j_lo) + (j - sh.j_lo);
 }
 
-struct StoreEq  { uint32_t *out; __device__ __forceinline__ void operator()(size_t pos, uint32_t eq, uint32_t) const { out[pos] = eq; } };
-struct StoreLut { float *out; const float *lut; __device__ __forceinline__ void operator()(size_t pos, uint32_t eq, uint32_t) const { out[pos] = lut[eq]; } };
-struct StoreGtLt {
-    uint32_t *gt, *lt; uint32_t S;
-    __device__ __forceinline__ void operator()(size_t pos, uint32_t eq, uint32_t g) const { gt[pos] = g; lt[pos] = S - g - eq; }
+// Store functors: value(eq) is evaluated for all of a lane's outputs first (independent gathers
+// in flight together), put(pos, v) afterwards -- the table and the output never alias.
+struct StoreEq {
+    uint32_t *__restrict__ out;
+    __device__ __forceinline__ uint32_t value(uint32_t eq) const { return eq; }
+    __device__ __forceinline__ void put(size_t pos, uint32_t v) const { out[pos] = v; }
 };
-
+struct StoreLut {
+    float *__restrict__ out; const float *__restrict__ lut;
+    __device__ __forceinline__ uint32_t value(uint32_t eq) const { return __float_as_uint(lut[eq]); }
+    __device__ __forceinline__ void put(size_t pos, uint32_t v) const { out[pos] = __uint_as_float(v); }
+};
+struct StoreGtLt {
+    uint32_t *__restrict__ gt, *__restrict__ lt; uint32_t S;
+    __device__ __forceinline__ void put2(size_t pos, uint32_t eq, uint32_t g) const { gt[pos] = g; lt[pos] = S - g - eq; }
+};
