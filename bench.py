@@ -50,6 +50,25 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel_substr, wide_loads):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_b_pmc.json,
+    produced by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same
+    command).  MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE
+    tallies wide (16 B/lane) coalesced reads at half their bytes -> doubled for such kernels;
+    narrow-load kernels are reported raw (uncalibrated per the guide)."""
+    path = os.path.join(ROOT, "profiles", "r01_b_pmc.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        for k, e in json.load(open(path)).items():
+            if kernel_substr in k and "hbm_write_bytes" in e:
+                rd = e["hbm_read_bytes_x2_wide_load_correction"] if wide_loads else e["hbm_read_bytes_raw"]
+                return rd + e["hbm_write_bytes"]
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(sig_np, cards_np, S, seconds):
     """The oracle's OpenMP all-pairs (reference loop structure) on a bounded row sample."""
     from oracle import oracle as O
@@ -171,7 +190,9 @@ def main():
     alg_bytes = 8 * S * N + 4 * my_pairs          # each sketch read once + one float per pair
     achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic("k2_bitslice_kernel", False) if (cs.algo == D.CMP_BITSLICE and world == 1 and N == 10000 and S == 1024) else None,
+                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of the same workload, profiles/r01_b_pmc.json; dword loads: read side raw/uncalibrated",
                 "kernel": "k2_bitslice_kernel" if cs.algo == D.CMP_BITSLICE else "k2_direct_kernel",
                 "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
                 "prep_ms": prep_ms,
@@ -221,7 +242,9 @@ def main():
                   "unit": "bases/s", "ms_per_step": sdt / reps * 1e3,
                   "config": {"workload": f"{n_g * world} synthetic random genomes x {L} bp, k=31, S={S}, OPH, canonical"},
                   "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": "k1_oph_kernel",
+                               "frac": ach / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic("k1_oph_kernel", True) if (world == 1 and n_g == 1000 and L == 5_000_000) else None,
+                               "kernel": "k1_oph_kernel",
                                "kernel_ms": k1_ms, "algorithmic_bytes": k1_bytes}}
         # sanity: a sketch of random bases has no empty bucket and id % m == bucket
         chk = regs_dev[0].cpu().numpy().view(np.uint64)

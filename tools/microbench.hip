@@ -115,6 +115,90 @@ __global__ void k_wang(uint64_t *out) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = x[0] ^ x[1] ^ x[2] ^ x[3];
 }
 
+
+// ---- candidates for a cheaper exact Wang mix (same function, different instruction selection)
+__device__ __forceinline__ uint64_t lshl_add(uint64_t a, const int sh, uint64_t b) {   // (a << sh) + b, sh in 0..4
+    uint64_t r;
+    switch (sh) {
+        case 1: asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(a), "v"(b)); break;
+        case 2: asm("v_lshl_add_u64 %0, %1, 2, %2" : "=v"(r) : "v"(a), "v"(b)); break;
+        case 3: asm("v_lshl_add_u64 %0, %1, 3, %2" : "=v"(r) : "v"(a), "v"(b)); break;
+        default: asm("v_lshl_add_u64 %0, %1, 4, %2" : "=v"(r) : "v"(a), "v"(b)); break;
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t wang64_v2(uint64_t k) {
+    // k = ~k + (k << 21)  in 32-bit halves
+    {
+        const uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+        const uint32_t slo = lo << 21, shi = __builtin_amdgcn_alignbit(hi, lo, 11);
+        k = (((uint64_t)shi << 32) | slo) + ~k;
+    }
+    k ^= k >> 24;
+    {   // k * 265 = k + 8k + 256k
+        const uint64_t t = lshl_add(k, 3, k);         // 9k
+        const uint64_t a = lshl_add(k, 4, 0);         // 16k
+        k = lshl_add(a, 4, t);                        // 256k + 9k
+    }
+    k ^= k >> 14;
+    {   // k * 21 = k + 4k + 16k
+        const uint64_t t = lshl_add(k, 2, k);         // 5k
+        k = lshl_add(k, 4, t);                        // 16k + 5k
+    }
+    k ^= k >> 28;
+    {   // k += k << 31 in halves
+        const uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+        const uint32_t slo = lo << 31, shi = __builtin_amdgcn_alignbit(hi, lo, 1);
+        k += ((uint64_t)shi << 32) | slo;
+    }
+    return k;
+}
+__global__ void k_wang_v2(uint64_t *out) {
+    uint64_t x[4];
+    for (int i = 0; i < 4; ++i) x[i] = threadIdx.x * 77 + i;
+    for (int it = 0; it < ITER; ++it)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = wang64_v2(x[i]);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x[0] ^ x[1] ^ x[2] ^ x[3];
+}
+__global__ void k_wang_check(uint64_t *out) {      // out[t] = number of mismatches between the two forms
+    uint64_t bad = 0, x = threadIdx.x * 0x9E3779B97F4A7C15ull + blockIdx.x;
+    for (int it = 0; it < 256; ++it) { bad += wang64(x) != wang64_v2(x); x = wang64(x) + it; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = bad;
+}
+__global__ void k_lshl_add_u64(uint64_t *out) {
+    uint64_t z[16], v = threadIdx.x * 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 16; ++i) z[i] = i;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(z[i]) : "v"(v));
+        v = v * 3 + 1;
+    }
+    uint64_t s = 0; for (int i = 0; i < 16; ++i) s ^= z[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_mad_u64_u32(uint64_t *out) {
+    uint64_t z[16]; uint32_t v = threadIdx.x * 2654435761u;
+    for (int i = 0; i < 16; ++i) z[i] = i;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(z[i]) : "v"(v), "v"((uint32_t)z[i]) : "vcc");
+        v = v * 3 + 1;
+    }
+    uint64_t s = 0; for (int i = 0; i < 16; ++i) s ^= z[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_lshrrev_b64(uint64_t *out) {
+    uint64_t z[16], v = threadIdx.x * 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 16; ++i) z[i] = v + i;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(z[i]));
+    }
+    uint64_t s = 0; for (int i = 0; i < 16; ++i) s ^= z[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <class F> float time_kernel(F launch) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     launch(); hipDeviceSynchronize();
@@ -128,7 +212,14 @@ int main() {
     printf("device %s, %d CUs, clock %d kHz\n", p.gcnArchName, cus, p.clockRate);
     void *out; CHECK(hipMalloc(&out, 64 << 20));
     uint64_t h[8] = {1, 2, 3, 4, 5, 6, 7, 8}; void *sc; CHECK(hipMalloc(&sc, 64)); CHECK(hipMemcpy(sc, h, 64, hipMemcpyHostToDevice));
-    for (int wps : {1, 2, 4, 8}) {            // waves per SIMD
+    {
+        k_wang_check<<<64, 256>>>((uint64_t *)out);
+        std::vector<uint64_t> h(64 * 256);
+        CHECK(hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost));
+        uint64_t bad = 0; for (auto x : h) bad += x;
+        printf("wang64_v2 vs wang64: %llu mismatches over %zu values\n", (unsigned long long)bad, h.size() * 256);
+    }
+    for (int wps : {2, 8}) {            // waves per SIMD
         const int blocks = cus * wps, threads = 256;   // 4 waves per block -> wps blocks per CU
         const double winst = (double)blocks * 4 * ITER * 16;   // wave-instructions of the measured op
         auto rep = [&](const char *name, float ms, double ops_per = 1.0) {
@@ -144,6 +235,15 @@ int main() {
         rep("cmp_eq_u64+addc (2)", time_kernel([&] { k_cmp64_addc<<<blocks, threads>>>((uint32_t *)out, (uint64_t *)sc); }), 2.0);
         rep("cmp_eq_u32+addc (2)", time_kernel([&] { k_cmp32_addc<<<blocks, threads>>>((uint32_t *)out, (uint32_t *)sc); }), 2.0);
         rep("cmp_eq_u64+s_bcnt1", time_kernel([&] { k_cmp64_sbcnt<<<blocks, threads>>>((uint32_t *)out, (uint64_t *)sc); }));
+        rep("v_lshl_add_u64", time_kernel([&] { k_lshl_add_u64<<<blocks, threads>>>((uint64_t *)out); }));
+        rep("v_mad_u64_u32", time_kernel([&] { k_mad_u64_u32<<<blocks, threads>>>((uint64_t *)out); }));
+        rep("v_lshrrev_b64", time_kernel([&] { k_lshrrev_b64<<<blocks, threads>>>((uint64_t *)out); }));
+        {
+            const float ms = time_kernel([&] { k_wang_v2<<<blocks, threads>>>((uint64_t *)out); });
+            const double hashes = (double)blocks * 256 * ITER * 4;
+            printf("  wps=%d %-22s %8.3f ms  %.3e wang64/s chip  (%.1f lane-cycles per hash @2.4GHz)\n", wps, "wang64_v2 (lshl_add)", ms,
+                   hashes / (ms * 1e-3), (double)cus * 4 * 32 * 2.4e9 / (hashes / (ms * 1e-3)));
+        }
         {   // wang: 4 chains x ITER hashes per lane
             const float ms = time_kernel([&] { k_wang<<<blocks, threads>>>((uint64_t *)out); });
             const double hashes = (double)blocks * 256 * ITER * 4;
