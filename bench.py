@@ -178,7 +178,7 @@ def main():
     ctx.set_timing(False)
     nk2, k2_ms, _ = ctx.kernel_ms("k2")
     _, prep_ms, _ = ctx.kernel_ms("k2prep")
-    max_distinct, nbits = cs.planes(stream)
+    max_distinct, nbits, mean_nbits = cs.planes(stream)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,12 +198,12 @@ def main():
                 "prep_ms": prep_ms,
                 "note": "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute"}
     if cs.algo == D.CMP_BITSLICE:
-        ops = my_pairs * ((S + 31) // 32) * (nbits + 2)      # id planes + unique plane (v_bitop3) + v_bcnt
+        ops = my_pairs * ((S + 31) // 32) * (mean_nbits + 2)  # id planes + unique plane (v_bitop3) + v_bcnt
     else:
         ops = my_pairs * S * 2
     compute = {"bound": "valu", "unit": "lane-ops/s", "achieved": ops / (k2_ms * 1e-3) if k2_ms > 0 else 0.0,
                "peak": VALU_PEAK_LANEOPS, "frac": (ops / (k2_ms * 1e-3) / VALU_PEAK_LANEOPS) if k2_ms > 0 else 0.0,
-               "bit_planes": nbits, "max_shared_values_per_column_plus1": max_distinct}
+               "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct}
 
     # ---- secondary: K1 sketch construction, packed bases resident in HBM
     sketch = None

@@ -85,7 +85,7 @@ SIGNATURES = {
     "d2g_cmp_set_create_dev": (_int, [_vp, _vp, _sz, _sz, _int, _vp, C.POINTER(_vp)]),
     "d2g_cmp_set_create": (_int, [_vp, _vp, _sz, _sz, _int, C.POINTER(_vp)]),
     "d2g_cmp_set_update_dev": (_int, [_vp, _vp, _vp, _vp]),
-    "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int)]),
+    "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int), C.POINTER(_f32)]),
     "d2g_cmp_set_destroy": (None, [_vp]),
     "d2g_cmp_set_algo": (_int, [_vp]),
     "d2g_cmp_eqcount_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
@@ -422,10 +422,10 @@ class CmpSet:
         self.ctx._check(lib().d2g_cmp_set_update_dev(self.ctx._h, self._h, dev_ptr, stream))
 
     def planes(self, stream=None):
-        """-> (max distinct values per register column, live bit planes); (0, 0) for a DIRECT set"""
-        md, nb = C.c_uint(), _int()
-        self.ctx._check(lib().d2g_cmp_set_planes(self.ctx._h, self._h, stream, C.byref(md), C.byref(nb)))
-        return int(md.value), int(nb.value)
+        """-> (max shared values per column + 1, max id planes of a group, mean id planes); zeros for DIRECT"""
+        md, nb, mean = C.c_uint(), _int(), _f32()
+        self.ctx._check(lib().d2g_cmp_set_planes(self.ctx._h, self._h, stream, C.byref(md), C.byref(nb), C.byref(mean)))
+        return int(md.value), int(nb.value), float(mean.value)
 
     def eqcount_ut_dev(self, out_dev_ptr, r0=0, r1=None, stream=None):
         r1 = self.N if r1 is None else r1

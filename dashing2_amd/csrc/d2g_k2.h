@@ -14,7 +14,7 @@ struct d2g_cmp_set {
     size_t Nstride = 0;           // Npad + 64 (row tiles may read past Npad)
     int nbits_cap = 0;            // plane slots per 32-register group = ceil(log2 N) (>= 1)
     int ntb = 0;                  // ceil(S/32)
-    uint32_t *d_meta = nullptr;   // [0] = max over columns of (#values occurring >= 2 times) + 1 (device side; the kernels
+    uint32_t *d_meta = nullptr;   // [tb] = max over the group's columns of (#values occurring >= 2 times) + 1 (device side; the kernels
                                   //       derive the live plane count from it, no host round trip)
     uint32_t *d_owner = nullptr;  // workspace: [S][T] open-addressing owner table
     uint32_t *d_ids = nullptr;    // workspace: [S][Npad] dense ids

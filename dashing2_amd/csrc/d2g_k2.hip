@@ -242,17 +242,25 @@ int d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_b
     return cmp_set_load(ctx, set, sig_bits_dev, as_stream(stream));
 }
 
-int d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits) {
+int d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits, float *mean_nbits) {
     if (!ctx) return D2G_ERR_INVALID;
     D2G_CHECK(ctx, set && set->ctx == ctx, "cmp_set_planes: set belongs to another context");
     unsigned md = 0; int nb = 0;
     if (set->algo == D2G_CMP_BITSLICE) {
+        std::vector<unsigned> m(set->ntb);
         D2G_HIP(ctx, hipSetDevice(ctx->device));
-        D2G_HIP(ctx, hipMemcpyAsync(&md, set->d_meta, sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream)));
+        D2G_HIP(ctx, hipMemcpyAsync(m.data(), set->d_meta, m.size() * sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream)));
         D2G_HIP(ctx, hipStreamSynchronize(as_stream(stream)));
-        nb = 1;
-        while ((1ull << nb) < md) ++nb;
-    }
+        double sum = 0;
+        for (unsigned x : m) {                       // per 32-register group: ceil(log2(x)) id planes, at least 1
+            md = std::max(md, x);
+            int b = 1;
+            while ((1ull << b) < x) ++b;
+            nb = std::max(nb, b);
+            sum += b;
+        }
+        if (mean_nbits) *mean_nbits = m.empty() ? 0.f : float(sum / m.size());
+    } else if (mean_nbits) *mean_nbits = 0.f;
     if (max_distinct) *max_distinct = md;
     if (nbits) *nbits = nb;
     return D2G_OK;

@@ -37,7 +37,7 @@ constexpr uint32_t BS_UNIQ = 0x80000000u;      // id flag: value occurs once in 
 
 // Singleton folding: a value that occurs exactly once in its register column can never compare
 // equal to anything, so all such values share id 0 and set the "unique" bit instead; only values
-// occurring >= 2 times get dense ids 1..D2.  meta[0] = D2 + 1 (number of id values).
+// occurring >= 2 times get dense ids 1..D2.  meta[t/32] = max over the group's columns of D2 + 1.
 template <bool LDS_TABLE>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
                                                                   uint32_t *owner_all, uint32_t T, int logT,
@@ -98,24 +98,24 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         if (tid == 0) running = r0 + tot;
         __syncthreads();
     }
-    if (tid == 0) atomicMax(max_distinct, running);
+    if (tid == 0) atomicMax(&max_distinct[t >> 5], running);          // per 32-register group
     for (size_t j = tid; j < N; j += BS_RANK_THREADS) ids[j] = own[ids[j]];
 }
 
 // ------------------------------------------------------------------ 2. 32 x nbits bit transpose
 // thread (tb, j): reads the ids of sketch j for 32 consecutive registers, writes nbits words.
-__device__ __forceinline__ int live_planes(const uint32_t *meta) {
-    const uint32_t md = meta[0];                       // max distinct values in any column
+__device__ __forceinline__ int live_planes(const uint32_t *meta, int tb) {
+    const uint32_t md = meta[tb];                      // max over the group's columns of (#shared values + 1)
     return md <= 2 ? 1 : 32 - __clz(md - 1);          // ceil(log2(md)), at least 1
 }
 
 __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t S, size_t N, size_t Npad,
                                                         uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
                                                         const uint32_t *__restrict__ meta) {
-    const int nbits = live_planes(meta);
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tb = blockIdx.y;
     if (j >= Nstride) return;
+    const int nbits = live_planes(meta, (int)tb);
     uint32_t id[32];
 #pragma unroll
     for (int x = 0; x < 32; ++x) {
@@ -148,7 +148,7 @@ constexpr unsigned BITOP3_C_OR_A_AND_B = 0xAA | (0xF0 & 0xCC);   // both values 
 // IW = 16 rows per wave (one s_load_dwordx16 per plane), JR = 64-column groups per lane,
 // WC = waves side by side along the columns (WC * JR * 64 = 256), PF = software prefetch of the
 // next plane's operands (register double buffer).
-template <int JR, bool PF, class Store, int ABL = 0>
+template <int JR, bool PF, class Store>
 __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
                                                                  const uint32_t *__restrict__ meta, int ntb, uint32_t S,
                                                                  PairShape sh, Store store) {
@@ -169,7 +169,6 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
     if (iw0 >= sh.i_hi) return;
     if (sh.ut && j0 + 64 * JR - 1 <= iw0) return;
 
-    const int nbits = live_planes(meta);             // uniform (scalar load)
     uint32_t acc[IW][JR];
 #pragma unroll
     for (int i = 0; i < IW; ++i)
@@ -182,6 +181,7 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
     const size_t uoff = (size_t)nbits_cap * Nstride;          // slot of the "unique" plane within a group
     if (!PF) {
         for (int tb = 0; tb < ntb; ++tb) {
+            const int nbits = live_planes(meta, tb);                 // uniform (scalar load), per 32-register group
             uint32_t z[IW][JR];
 #pragma unroll
             for (int i = 0; i < IW; ++i)
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
 #pragma unroll
         for (int c = 0; c < JR; ++c) vb_n[c] = pcol[64 * c];
         for (int tb = 0; tb < ntb; ++tb) {
+            const int nbits = live_planes(meta, tb);                 // uniform (scalar load), per 32-register group
             uint32_t z[IW][JR];
 #pragma unroll
             for (int i = 0; i < IW; ++i)
@@ -234,21 +235,14 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
 #pragma unroll
                 for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
                 off_n = (p + 1 < nbits) ? off_n + Nstride : base + uoff;      // after the last id plane: the unique plane
-                if (ABL != 1) {
-                    sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
+                sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
 #pragma unroll
-                    for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
-                }
-                if (ABL == 2) {
+                for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
 #pragma unroll
-                    for (int c = 0; c < JR; ++c) z[0][c] ^= sa[0] ^ vb[c];      // ablation: loads only
-                } else {
+                for (int i = 0; i < IW; ++i)
 #pragma unroll
-                    for (int i = 0; i < IW; ++i)
-#pragma unroll
-                        for (int c = 0; c < JR; ++c)
-                            z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
-                }
+                    for (int c = 0; c < JR; ++c)
+                        z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
             }
             {
                 const u32x16_u sa = sa_n;
@@ -287,226 +281,6 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
     }
 }
 
-// Ring-prefetch form: the (id planes..., unique plane) sequence of all 32-register groups is one
-// stream of Q = ntb * (nbits + 1) steps; D steps of operands are kept in flight per wave
-// (D * JR VGPRs + D * 16 SGPRs), which covers the L2 / scalar-cache latency with few waves.
-template <int JR, int D, class Store>
-__global__ __launch_bounds__(BS_THREADS) void k2_bitslice_ring_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
-                                                                      const uint32_t *__restrict__ meta, int ntb, uint32_t S,
-                                                                      PairShape sh, Store store) {
-    constexpr int IW = 16;
-    constexpr int WC = BS_CB / (64 * JR);
-    constexpr int WR = 4 / WC;
-    constexpr int RB = WR * IW;
-    unsigned ct, rt;
-    if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
-    const size_t i0 = sh.i_lo + (size_t)rt * RB;
-    const size_t jt0 = (size_t)(sh.ct0 + ct) * BS_CB;
-    if (sh.ut && jt0 + BS_CB - 1 <= i0) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const size_t iw0 = i0 + (size_t)(wave / WC) * IW;
-    const size_t j0 = jt0 + (size_t)(wave % WC) * (64 * JR);
-    if (iw0 >= sh.i_hi) return;
-    if (sh.ut && j0 + 64 * JR - 1 <= iw0) return;
-
-    const int nbits = live_planes(meta);
-    const uint32_t *prow = planes + iw0;
-    const uint32_t *pcol = planes + j0 + lane;
-    const size_t tbstride = (size_t)(nbits_cap + 1) * Nstride;
-    const size_t uoff = (size_t)nbits_cap * Nstride;
-    const int Q = ntb * (nbits + 1);
-
-    uint32_t acc[IW][JR], z[IW][JR];
-#pragma unroll
-    for (int i = 0; i < IW; ++i)
-#pragma unroll
-        for (int c = 0; c < JR; ++c) { acc[i][c] = 0; z[i][c] = 0; }
-
-    // load stream state: (group, plane-within-group) of the next step to fetch
-    int ltb = 0, lp = 0;
-    auto next_off = [&]() -> size_t {
-        const size_t off = (ltb < ntb) ? (size_t)ltb * tbstride + (lp < nbits ? (size_t)lp * Nstride : uoff) : 0;
-        if (++lp > nbits) { lp = 0; ++ltb; }
-        return off;
-    };
-    u32x16_u sa_r[D];
-    uint32_t vb_r[D][JR];
-#pragma unroll
-    for (int u = 0; u < D; ++u) {
-        const size_t off = next_off();
-        sa_r[u] = *reinterpret_cast<const u32x16_u *>(prow + off);
-#pragma unroll
-        for (int c = 0; c < JR; ++c) vb_r[u][c] = pcol[off + 64 * c];
-    }
-    int p = 0;                                   // plane-within-group of the step being computed
-    for (int q = 0; q < Q;) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            if (q < Q) {
-                const u32x16_u sa = sa_r[u];
-                uint32_t vb[JR];
-#pragma unroll
-                for (int c = 0; c < JR; ++c) vb[c] = vb_r[u][c];
-                const size_t off = next_off();
-                sa_r[u] = *reinterpret_cast<const u32x16_u *>(prow + off);
-#pragma unroll
-                for (int c = 0; c < JR; ++c) vb_r[u][c] = pcol[off + 64 * c];
-                if (p < nbits) {
-#pragma unroll
-                    for (int i = 0; i < IW; ++i)
-#pragma unroll
-                        for (int c = 0; c < JR; ++c)
-                            z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
-                    ++p;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < IW; ++i)
-#pragma unroll
-                        for (int c = 0; c < JR; ++c) {
-                            acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_AND_B));
-                            z[i][c] = 0;
-                        }
-                    p = 0;
-                }
-                ++q;
-            }
-        }
-    }
-    // padded registers never mismatch; a sketch equals itself even where its values are
-    // column-unique (the "unique" plane only separates DIFFERENT sketches)
-    uint32_t val[IW][JR];
-#pragma unroll
-    for (int i = 0; i < IW; ++i)
-#pragma unroll
-        for (int c = 0; c < JR; ++c)
-            val[i][c] = store.value((iw0 + i) == (j0 + lane + 64 * c) ? S : S - acc[i][c]);
-#pragma unroll
-    for (int i = 0; i < IW; ++i) {
-        const size_t ii = iw0 + i;
-        if (ii >= sh.i_hi) break;
-#pragma unroll
-        for (int c = 0; c < JR; ++c) {
-            const size_t jj = j0 + lane + 64 * c;
-            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii)) store.put(out_pos(sh, ii, jj), val[i][c]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------ LDS-staged pair kernel
-// Workgroup = 4 waves, tile = 32 rows x 256 columns; wave w owns rows 8w..8w+7 x all 256 columns,
-// lane l owns columns 4l..4l+3 (one ds_read_b128 per plane).  For every 32-register group the
-// workgroup stages the group's (nbits+1) plane rows -- 256 column words + 32 row words each --
-// into LDS with global_load_lds (asynchronous, no VGPR round trip), one group ahead of the
-// compute (double buffer, one barrier per group).  Row words are read back with uniform-address
-// (broadcast) ds_read_b128, so every v_bitop3 operand is a VGPR and no scalar-load latency
-// (out-of-order s_load => lgkmcnt(0)) sits on the critical path.
-constexpr int BL_ROWS = 32;
-constexpr int BL_PLANE_WORDS = 256 + BL_ROWS;          // LDS words per staged plane
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-template <class Store>
-__global__ __launch_bounds__(BS_THREADS) void k2_bitslice_lds_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
-                                                                     const uint32_t *__restrict__ meta, int ntb, uint32_t S,
-                                                                     PairShape sh, Store store) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];      // 2 x (nbits_cap+1) x BL_PLANE_WORDS
-    unsigned ct, rt;
-    if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
-    const size_t i0 = sh.i_lo + (size_t)rt * BL_ROWS;
-    const size_t jt0 = (size_t)(sh.ct0 + ct) * BS_CB;
-    if (sh.ut && jt0 + BS_CB - 1 <= i0) return;                          // whole tile on/below the diagonal (block-uniform)
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int nbits = live_planes(meta);
-    const int nb1 = nbits + 1;
-    const size_t tbstride = (size_t)(nbits_cap + 1) * Nstride;
-    const size_t uoff = (size_t)nbits_cap * Nstride;
-    const int bufwords = (nbits_cap + 1) * BL_PLANE_WORDS;
-
-    // staging: wave w copies column words [64w, 64w+64) of every plane; wave 0 lanes 0..31 also the row words
-    const uint32_t *gcol = planes + jt0 + threadIdx.x;
-    const uint32_t *grow = planes + i0 + lane;
-    auto stage = [&](int tb, int buf) {
-        const size_t base = (size_t)tb * tbstride;
-        uint32_t *dst = lds + buf * bufwords;
-        for (int p = 0; p < nb1; ++p) {
-            const size_t off = base + (p < nbits ? (size_t)p * Nstride : uoff);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)(gcol + off),
-                                             (__attribute__((address_space(3))) uint32_t *)(dst + p * BL_PLANE_WORDS + 64 * wave), 4, 0, 0);
-            if (wave == 0 && lane < BL_ROWS)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)(grow + off),
-                                                 (__attribute__((address_space(3))) uint32_t *)(dst + p * BL_PLANE_WORDS + 256), 4, 0, 0);
-        }
-    };
-
-    uint32_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[i][c] = 0;
-
-    stage(0, 0);
-    for (int tb = 0; tb < ntb; ++tb) {
-        const int buf = tb & 1;
-        // the loads of group tb were issued one iteration ago: wait for them, make them visible
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tb + 1 < ntb) stage(tb + 1, buf ^ 1);                        // prefetch the next group (other buffer)
-        const uint32_t *src = lds + buf * bufwords;
-        uint32_t z[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) z[i][c] = 0;
-#pragma unroll 2
-        for (int p = 0; p < nbits; ++p) {
-            const uint32_t *pl = src + p * BL_PLANE_WORDS;
-            const u32x4 cw = *reinterpret_cast<const u32x4 *>(pl + 4 * lane);
-            const u32x4 r0 = *reinterpret_cast<const u32x4 *>(pl + 256 + 8 * wave);
-            const u32x4 r1 = *reinterpret_cast<const u32x4 *>(pl + 256 + 8 * wave + 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t rw = i < 4 ? r0[i] : r1[i - 4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) z[i][c] = __builtin_amdgcn_bitop3_b32(rw, cw[c], z[i][c], BITOP3_C_OR_A_XOR_B);
-            }
-        }
-        {
-            const uint32_t *pl = src + nbits * BL_PLANE_WORDS;
-            const u32x4 cw = *reinterpret_cast<const u32x4 *>(pl + 4 * lane);
-            const u32x4 r0 = *reinterpret_cast<const u32x4 *>(pl + 256 + 8 * wave);
-            const u32x4 r1 = *reinterpret_cast<const u32x4 *>(pl + 256 + 8 * wave + 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t rw = i < 4 ? r0[i] : r1[i - 4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(rw, cw[c], z[i][c], BITOP3_C_OR_A_AND_B));
-            }
-        }
-        // all waves must be done reading buffer `buf` before it is overwritten two iterations later:
-        // guaranteed by the barrier at the top of the next iteration (loads into `buf` are issued after it)
-    }
-    const size_t iw0 = i0 + 8 * (size_t)wave;
-    uint32_t val[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) val[i][c] = store.value((iw0 + i) == (jt0 + 4 * lane + c) ? S : S - acc[i][c]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const size_t ii = iw0 + i;
-        if (ii >= sh.i_hi) break;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const size_t jj = jt0 + 4 * lane + c;
-            if (jj < sh.j_hi && jj >= sh.j_lo && (!sh.ut || jj > ii)) store.put(out_pos(sh, ii, jj), val[i][c]);
-        }
-    }
-}
-
 int bs_variant() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("D2G_BS_VARIANT"); v = e ? atoi(e) : 3; }
@@ -515,37 +289,19 @@ int bs_variant() {
 
 template <class Store>
 int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
-    const int var = bs_variant();            // 0: JR4  1: JR2  2: JR4+prefetch  3: JR2+prefetch  4/5/6: JR2 ring D=2/3/4  7: JR4 ring D=3
-    const bool jr2 = (var == 1 || var == 3 || var == 4 || var == 5 || var == 6 || var == 8 || var == 9 || var == 10);
-    const int JR = jr2 ? 2 : 4;
-    const int RB = jr2 ? 32 : 64;
-    if (int rc = finish_shape(ctx, sh, (unsigned)RB)) return rc;
+    // D2G_BS_VARIANT (experiments): 0: 16x256/wave  1: 16x128/wave  2: 0+prefetch  3: 1+prefetch (default, fastest measured)
+    const int var = bs_variant();
+    const bool jr2 = (var == 1 || var == 3);
+    if (int rc = finish_shape(ctx, sh, jr2 ? 32u : 64u)) return rc;
     if (sh.nvalid_total == 0) return D2G_OK;
-    (void)JR;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
 #define BS_LAUNCH(JRV, PFV) hipLaunchKernelGGL((k2_bitslice_kernel<JRV, PFV, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, \
         set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store)
     switch (var) {
+        case 0: BS_LAUNCH(4, false); break;
         case 1: BS_LAUNCH(2, false); break;
         case 2: BS_LAUNCH(4, true); break;
-        case 3: BS_LAUNCH(2, true); break;
-#define BS_RING(JRV, DV) hipLaunchKernelGGL((k2_bitslice_ring_kernel<JRV, DV, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, \
-        set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store)
-        case 8: hipLaunchKernelGGL((k2_bitslice_kernel<2, true, Store, 1>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store); break;   // ablation: compute only
-        case 9: hipLaunchKernelGGL((k2_bitslice_kernel<2, true, Store, 2>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store); break;   // ablation: loads only
-        case 10: {
-            const size_t ldsb = 2 * (size_t)(set->nbits_cap + 1) * BL_PLANE_WORDS * sizeof(uint32_t);
-            auto kern = k2_bitslice_lds_kernel<Store>;
-            if (ldsb > 48 * 1024) D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
-            hipLaunchKernelGGL(kern, dim3(sh.per_xcd * 8), dim3(BS_THREADS), ldsb, s, set->d_planes, set->Nstride, set->nbits_cap,
-                               set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
-        } break;
-        case 4: BS_RING(2, 2); break;
-        case 5: BS_RING(2, 3); break;
-        case 6: BS_RING(2, 4); break;
-        case 7: BS_RING(4, 3); break;
-#undef BS_RING
-        default: BS_LAUNCH(4, false); break;
+        default: BS_LAUNCH(2, true); break;
     }
 #undef BS_LAUNCH
     tm.stop();
@@ -576,7 +332,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     const bool lds_table = (size_t)set->T * sizeof(uint32_t) <= 128 * 1024;
     if ((!lds_table && (e = hipMalloc((void **)&set->d_owner, S * (size_t)set->T * sizeof(uint32_t))) != hipSuccess) ||
         (e = hipMalloc((void **)&set->d_ids, S * Npad * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_meta, 4 * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_meta, (size_t)(set->ntb + 4) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_planes, (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride * sizeof(uint32_t))) != hipSuccess) {
         ctx->last_error = std::string("bitslice alloc: ") + hipGetErrorString(e);
         d2g_bitslice_free(set);
@@ -588,7 +344,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 // ids + planes for the operand currently in set->d_cols.  Fully asynchronous on `s`.
 int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
-    D2G_HIP(ctx, hipMemsetAsync(set->d_meta, 0, 4 * sizeof(uint32_t), s));
+    D2G_HIP(ctx, hipMemsetAsync(set->d_meta, 0, (size_t)(set->ntb + 4) * sizeof(uint32_t), s));
     if (set->d_owner == nullptr) {
         // owner table in LDS (T * 4 bytes <= 128 KiB): ds_cmpst instead of global CAS chains
         const size_t lds = (size_t)set->T * sizeof(uint32_t);

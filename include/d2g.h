@@ -186,9 +186,11 @@ int  d2g_cmp_set_create(d2g_ctx *ctx, const uint64_t *sig_bits_host, size_t N, s
  * buffer (no allocation, no host synchronisation: the whole prepare chain is enqueued on `stream`) */
 int  d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, void *stream);
 /* bit-sliced sets: max over register columns of (#values occurring >= 2 times) + 1 (values that
- * occur once share id 0 + a "unique" plane) and the resulting id-plane count (synchronises
- * `stream`); both 0 for a DIRECT set */
-int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits);
+ * occur once share id 0 + a "unique" plane), the largest id-plane count of any 32-register group
+ * and the mean over groups (each group only walks its own planes).  Synchronises `stream`;
+ * all 0 for a DIRECT set. */
+int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits,
+                        float *mean_nbits);
 void d2g_cmp_set_destroy(d2g_cmp_set *set);
 int  d2g_cmp_set_algo(const d2g_cmp_set *set);      /* the algorithm actually selected */
 /* equality counts (u32) for rows [r0,r1) of the upper triangle */
