@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--no-sketch", action="store_true", help="skip the secondary K1 measurement")
     ap.add_argument("--sketch-genomes", type=int, default=1000)
     ap.add_argument("--sketch-len", type=int, default=5_000_000)
+    ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "broadcast"],
+                    help="N>1: row-sharded sketches + all-to-all/all-gather of the compact operand (default), "
+                         "or rank-0 sketches broadcast whole")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -133,12 +136,17 @@ def main():
     algo = {"auto": D.CMP_AUTO, "direct": D.CMP_DIRECT, "bitslice": D.CMP_BITSLICE}[args.algo]
     S = args.sketchsize
     N = int(round(args.sketches * math.sqrt(world)))
+    if world > 1:
+        N = (N + world - 1) // world * world                 # equal row blocks per rank
     pairs_total = N * (N - 1) // 2
     bounds = D.ut_partition(N, world)
     r0, r1 = bounds[rank], bounds[rank + 1]
     my_pairs = D.ut_count(N, r0, r1)
+    sharded = world > 1 and args.exchange == "alltoall"
 
-    # ---- synthetic pre-built sketches (rank 0), resident in HBM before the timed region
+    # ---- synthetic pre-built sketches, resident in HBM before the timed region.
+    # N == 1 or --exchange broadcast: the whole matrix lives on rank 0.
+    # N > 1 (default): rank r holds rows [r N/W, (r+1) N/W) -- what sharded sketching leaves behind.
     sig_np = cards_np = None
     if rank == 0:
         regs = synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928)
@@ -150,14 +158,29 @@ def main():
     out = torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     if world > 1:
-        dist.broadcast(sig_dev, 0)
-    cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
+        dist.broadcast(sig_dev, 0)                           # untimed distribution of the synthetic input
+    eng = cs = None
+    if sharded:
+        from dashing2_amd import dist as DD
+        n_loc = N // world
+        my_rows = sig_dev[rank * n_loc:(rank + 1) * n_loc].clone()
+        del sig_dev
+        eng = DD.RowShardedAllPairs(ctx, N, S, dev)
+        assert (eng.r0, eng.r1) == (r0, r1)
 
-    def step():
-        if world > 1:
-            dist.broadcast(sig_dev, 0)                      # the path's one exchange (RCCL over xGMI)
-        cs.update_dev(sig_dev.data_ptr(), stream)           # transpose + ids + planes (async)
-        cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), r0, r1, stream)   # pair kernel + fused epilogue
+        def step():
+            # all-to-all (rows -> column slices), prepare S/W columns, all-gather planes, pair kernel
+            eng.step_lut(my_rows, lut, out, stream)
+        step()
+        cs = eng.full
+    else:
+        cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
+
+        def step():
+            if world > 1:
+                dist.broadcast(sig_dev, 0)                      # the path's one exchange (RCCL over xGMI)
+            cs.update_dev(sig_dev.data_ptr(), stream)           # transpose + ids + planes (async)
+            cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), r0, r1, stream)   # pair kernel + fused epilogue
 
     def barrier():
         torch.cuda.synchronize()
@@ -264,12 +287,16 @@ def main():
             "config": {"workload": f"BASELINE config 3 (x sqrt(n_gpus) sketches): {N} pre-built OPH sketches, S={S}, "
                                    f"all-pairs cmp only, {pairs_total} pairs, float32 Jaccard",
                        "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if cs.algo == D.CMP_BITSLICE else "direct",
-                       "step": "RCCL broadcast (n_gpus>1) + prepare + pair kernel w/ fused epilogue; inputs resident in HBM",
+                       "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + pair kernel w/ fused epilogue; row-sharded sketches resident in HBM"
+                                if sharded else "RCCL broadcast (n_gpus>1) + prepare + pair kernel w/ fused epilogue; sketches resident in HBM"),
                        "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count"},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "sketch": sketch,
         }
         print(json.dumps(line))
-    cs.close()
+    if eng is not None:
+        eng.close()
+    else:
+        cs.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

@@ -11,7 +11,7 @@ from .capi import (  # noqa: F401
     SIMILARITY, CONTAINMENT, SYMMETRIC_CONTAINMENT, POISSON_LLR, INTERSECTION, UNION_SIZE,
     CMP_AUTO, CMP_DIRECT, CMP_BITSLICE,
     wang_hash, seed_mask, oph_xor_const, oph_m, oph_finalize, densify, epilogue_lut,
-    epilogue_gtlt, epilogue_neq, host_epilogue_ut, ut_count, ut_partition,
+    epilogue_gtlt, epilogue_neq, host_epilogue_ut, operand_layout, ut_count, ut_partition,
 )
 
 __all__ = [
@@ -19,5 +19,5 @@ __all__ = [
     "SIMILARITY", "CONTAINMENT", "SYMMETRIC_CONTAINMENT", "POISSON_LLR", "INTERSECTION", "UNION_SIZE",
     "CMP_AUTO", "CMP_DIRECT", "CMP_BITSLICE",
     "wang_hash", "seed_mask", "oph_xor_const", "oph_m", "oph_finalize", "densify", "epilogue_lut",
-    "epilogue_gtlt", "epilogue_neq", "host_epilogue_ut", "ut_count", "ut_partition",
+    "epilogue_gtlt", "epilogue_neq", "host_epilogue_ut", "operand_layout", "ut_count", "ut_partition",
 ]

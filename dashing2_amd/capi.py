@@ -86,6 +86,10 @@ SIGNATURES = {
     "d2g_cmp_set_create": (_int, [_vp, _vp, _sz, _sz, _int, C.POINTER(_vp)]),
     "d2g_cmp_set_update_dev": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int), C.POINTER(_f32)]),
+    "d2g_operand_layout": (_int, [_sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "d2g_cmp_set_export_operand_dev": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "d2g_cmp_set_from_planes_dev": (_int, [_vp, _sz, _sz, _vp, _vp, C.POINTER(_vp)]),
+    "d2g_pack_column_slices_dev": (_int, [_vp, _vp, _sz, _sz, _int, _vp, _vp]),
     "d2g_cmp_set_destroy": (None, [_vp]),
     "d2g_cmp_set_algo": (_int, [_vp]),
     "d2g_cmp_eqcount_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
@@ -186,6 +190,15 @@ def epilogue_gtlt(gt, lt, S, lhc, rhc, measure=SIMILARITY, k=31):
 
 def epilogue_neq(neq, S, lhc, rhc, measure=SIMILARITY, k=31):
     return float(lib().d2g_epilogue_neq(neq, S, lhc, rhc, measure, k))
+
+
+def operand_layout(N, S):
+    """-> (u32 words per 32-register group, number of groups) of the bit-sliced operand"""
+    gw, ng = _sz(), _sz()
+    rc = lib().d2g_operand_layout(N, S, C.byref(gw), C.byref(ng))
+    if rc:
+        raise D2GError(rc)
+    return int(gw.value), int(ng.value)
 
 
 def ut_count(N, r0=0, r1=None):
@@ -342,6 +355,14 @@ class Context:
         self._check(lib().d2g_cmp_set_create_dev(self._h, dev_ptr, N, S, algo, stream, C.byref(h)))
         return CmpSet(self, h, N, S)
 
+    def cmp_set_from_planes(self, N, S, planes_dev_ptr, meta_dev_ptr):
+        h = _vp()
+        self._check(lib().d2g_cmp_set_from_planes_dev(self._h, N, S, planes_dev_ptr, meta_dev_ptr, C.byref(h)))
+        return CmpSet(self, h, N, S)
+
+    def pack_column_slices_dev(self, rows_dev_ptr, n, S, W, out_dev_ptr, stream=None):
+        self._check(lib().d2g_pack_column_slices_dev(self._h, rows_dev_ptr, n, S, W, out_dev_ptr, stream))
+
     def cmp_eqcount_ut(self, sig_bits_host, r0=0, r1=None, algo=CMP_AUTO):
         a = np.ascontiguousarray(sig_bits_host)
         assert a.dtype.itemsize == 8 and a.ndim == 2
@@ -417,6 +438,9 @@ class CmpSet:
             self._h = None
 
     __del__ = close
+
+    def export_operand_dev(self, planes_out_ptr, meta_out_ptr, stream=None):
+        self.ctx._check(lib().d2g_cmp_set_export_operand_dev(self.ctx._h, self._h, planes_out_ptr, meta_out_ptr, stream))
 
     def update_dev(self, dev_ptr, stream=None):
         self.ctx._check(lib().d2g_cmp_set_update_dev(self.ctx._h, self._h, dev_ptr, stream))

@@ -19,12 +19,14 @@ struct d2g_cmp_set {
     uint32_t *d_owner = nullptr;  // workspace: [S][T] open-addressing owner table
     uint32_t *d_ids = nullptr;    // workspace: [S][Npad] dense ids
     uint32_t T = 0; int logT = 0;
+    bool borrowed = false;        // planes/meta belong to the caller (d2g_cmp_set_from_planes_dev)
 };
 
 struct PairShape;
 int  finish_shape(d2g_ctx *ctx, PairShape &sh, unsigned rb);   // d2g_k2.hip
 
 // d2g_k2_bitslice part (same shared object)
+void d2g_bitslice_geometry(d2g_cmp_set *set);
 int  d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 void d2g_bitslice_free(d2g_cmp_set *set);

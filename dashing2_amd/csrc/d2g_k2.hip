@@ -237,6 +237,7 @@ int d2g_cmp_set_create_dev(d2g_ctx *ctx, const uint64_t *sig_bits_dev, size_t N,
 int d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, void *stream) {
     if (!ctx) return D2G_ERR_INVALID;
     D2G_CHECK(ctx, set && set->ctx == ctx, "cmp_set_update: set belongs to another context");
+    D2G_CHECK(ctx, !set->borrowed, "cmp_set_update: this set wraps a caller-owned operand");
     D2G_CHECK(ctx, sig_bits_dev != nullptr, "cmp_set_update: null signatures");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     return cmp_set_load(ctx, set, sig_bits_dev, as_stream(stream));
@@ -317,6 +318,7 @@ int d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t 
     if (int rc = check_rows(ctx, set, r0, r1)) return rc;
     if (d2g_ut_count(set->N, r0, r1) == 0) return D2G_OK;
     D2G_CHECK(ctx, gt != nullptr && lt != nullptr, "cmp: null output");
+    D2G_CHECK(ctx, set->d_rows != nullptr, "cmp: (gt,lt) needs the raw patterns; this set wraps a gathered bit-sliced operand");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     // order needs the raw patterns: always the direct kernel (rows/cols are kept for every set)
     return launch_direct<true>(ctx, set, ut_shape(set, r0, r1), StoreGtLt{gt, lt, (uint32_t)set->S}, as_stream(stream));
@@ -343,10 +345,67 @@ int d2g_cmp_gtlt_rect_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_
     D2G_CHECK(ctx, a0 <= a1 && a1 <= set->N && b0 <= b1 && b1 <= set->N, "cmp: rect out of bounds");
     if (a0 == a1 || b0 == b1) return D2G_OK;
     D2G_CHECK(ctx, gt != nullptr && lt != nullptr, "cmp: null output");
+    D2G_CHECK(ctx, set->d_rows != nullptr, "cmp: (gt,lt) needs the raw patterns; this set wraps a gathered bit-sliced operand");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     PairShape sh{};
     sh.N = set->N; sh.i_lo = a0; sh.i_hi = a1; sh.j_lo = b0; sh.j_hi = b1; sh.ut = 0;
     return launch_direct<true>(ctx, set, sh, StoreGtLt{gt, lt, (uint32_t)set->S}, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- sharded prepare (multi-GPU)
+int d2g_operand_layout(size_t N, size_t S, size_t *group_words, size_t *ngroups) {
+    if (!N || !S) return D2G_ERR_INVALID;
+    d2g_cmp_set tmp;
+    tmp.N = N; tmp.S = S; tmp.Npad = div_up<size_t>(N, K2_CB) * K2_CB;
+    d2g_bitslice_geometry(&tmp);
+    if (group_words) *group_words = (size_t)(tmp.nbits_cap + 1) * tmp.Nstride;
+    if (ngroups) *ngroups = (size_t)tmp.ntb;
+    return D2G_OK;
+}
+
+int d2g_cmp_set_export_operand_dev(d2g_ctx *ctx, const d2g_cmp_set *set, uint32_t *planes_out_dev, uint32_t *meta_out_dev, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, set && set->ctx == ctx, "export_operand: set belongs to another context");
+    D2G_CHECK(ctx, set->algo == D2G_CMP_BITSLICE, "export_operand: not a bit-sliced set");
+    D2G_CHECK(ctx, planes_out_dev && meta_out_dev, "export_operand: null output");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t words = (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride;
+    D2G_HIP(ctx, hipMemcpyAsync(planes_out_dev, set->d_planes, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, as_stream(stream)));
+    D2G_HIP(ctx, hipMemcpyAsync(meta_out_dev, set->d_meta, (size_t)set->ntb * sizeof(uint32_t), hipMemcpyDeviceToDevice, as_stream(stream)));
+    return D2G_OK;
+}
+
+int d2g_cmp_set_from_planes_dev(d2g_ctx *ctx, size_t N, size_t S, const uint32_t *planes_dev, const uint32_t *meta_dev, d2g_cmp_set **out) {
+    if (!ctx || !out) return D2G_ERR_INVALID;
+    *out = nullptr;
+    D2G_CHECK(ctx, N >= 1 && S >= 1 && N < (1ull << 30) && S < (1ull << 31), "from_planes: bad shape");
+    D2G_CHECK(ctx, planes_dev && meta_dev, "from_planes: null operand");
+    d2g_cmp_set *set = new (std::nothrow) d2g_cmp_set();
+    if (!set) return D2G_ERR_NOMEM;
+    set->ctx = ctx; set->N = N; set->S = S;
+    set->Npad = div_up<size_t>(N, K2_CB) * K2_CB;
+    d2g_bitslice_geometry(set);
+    set->algo = D2G_CMP_BITSLICE;
+    set->borrowed = true;
+    set->d_planes = const_cast<uint32_t *>(planes_dev);
+    set->d_meta = const_cast<uint32_t *>(meta_dev);
+    *out = set;
+    return D2G_OK;
+}
+
+// rows [n][S] -> W consecutive blocks [n][S/W] (block q = columns [q S/W, (q+1) S/W)): the send
+// layout of the row-slice -> column-slice all-to-all
+int d2g_pack_column_slices_dev(d2g_ctx *ctx, const uint64_t *rows_dev, size_t n, size_t S, int W, uint64_t *out_dev, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, W >= 1 && S % (size_t)W == 0, "pack_column_slices: S must be divisible by the number of ranks");
+    if (!n) return D2G_OK;
+    D2G_CHECK(ctx, rows_dev && out_dev, "pack_column_slices: null buffer");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t Sl = S / W;
+    for (int q = 0; q < W; ++q)
+        D2G_HIP(ctx, hipMemcpy2DAsync(out_dev + (size_t)q * n * Sl, Sl * 8, rows_dev + (size_t)q * Sl, S * 8, Sl * 8, n,
+                                      hipMemcpyDeviceToDevice, as_stream(stream)));
+    return D2G_OK;
 }
 
 // ---------------------------------------------------------------- host-pointer conveniences

@@ -313,21 +313,27 @@ int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store st
 
 void d2g_bitslice_free(d2g_cmp_set *set) {
     if (!set) return;
-    (void)hipFree(set->d_planes); (void)hipFree(set->d_meta); (void)hipFree(set->d_owner); (void)hipFree(set->d_ids);
+    if (!set->borrowed) { (void)hipFree(set->d_planes); (void)hipFree(set->d_meta); }
+    (void)hipFree(set->d_owner); (void)hipFree(set->d_ids);
     set->d_planes = set->d_meta = set->d_owner = set->d_ids = nullptr;
+}
+
+// geometry of the bit-sliced operand: a function of N (and S) only, identical on every rank
+void d2g_bitslice_geometry(d2g_cmp_set *set) {
+    set->nbits_cap = 1;
+    while ((1ull << set->nbits_cap) < set->N) ++set->nbits_cap;
+    set->ntb = (int)div_up<size_t>(set->S, 32);
+    set->Nstride = set->Npad + 64;
 }
 
 // one-time allocation of the bit-sliced operand and its workspace
 int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
     if (N >= (1ull << 30)) { ctx->last_error = "bitslice: N too large"; return D2G_ERR_UNSUPPORTED; }
+    d2g_bitslice_geometry(set);
     // owner table: power of two >= 1.5 N (load <= 2/3), at least 64 slots
     set->T = 64; set->logT = 6;
     while ((uint64_t)set->T * 2 < (uint64_t)N * 3) { set->T <<= 1; ++set->logT; }
-    set->nbits_cap = 1;
-    while ((1ull << set->nbits_cap) < N) ++set->nbits_cap;
-    set->ntb = (int)div_up<size_t>(S, 32);
-    set->Nstride = Npad + 64;
     hipError_t e;
     const bool lds_table = (size_t)set->T * sizeof(uint32_t) <= 128 * 1024;
     if ((!lds_table && (e = hipMalloc((void **)&set->d_owner, S * (size_t)set->T * sizeof(uint32_t))) != hipSuccess) ||

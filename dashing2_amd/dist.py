@@ -143,6 +143,87 @@ def gather_slabs(slab):
     return None
 
 
+
+# --------------------------------------------------------------------------------------------
+# Scalable exchange for row-sharded sketches (what sharded sketching leaves in HBM):
+#   all-to-all (row slices -> column slices), per-rank prepare of S/W columns, all-gather of the
+#   compact bit-sliced operand (<= (ceil(log2 N)+1)/64 of the raw 8-byte registers).
+# --------------------------------------------------------------------------------------------
+def exchange_rows_to_colslices(send, recv):
+    """send: [W][n_loc][S_loc] (block q = my rows, column slice q); recv: [W*n_loc][S_loc] = all rows of
+    my column slice, in global row order (ranks own consecutive row blocks)."""
+    rank, world = rank_world()
+    if world == 1:
+        recv.copy_(send.view(recv.shape))
+    else:
+        _dist().all_to_all_single(recv.view(-1), send.view(-1))
+    return recv
+
+
+def gather_groups(local, full):
+    """all-gather of per-rank operand pieces, rank-major (= register-group order)."""
+    rank, world = rank_world()
+    if world == 1:
+        full.copy_(local.view(full.shape))
+    else:
+        _dist().all_gather_into_tensor(full.view(-1), local.view(-1))
+    return full
+
+
+class RowShardedAllPairs:
+    """All-pairs over an N x S sketch matrix whose rows [rank*n_loc, (rank+1)*n_loc) live on this
+    rank's GPU.  step() runs one whole pass: exchange, sharded prepare, this rank's slab of pairs."""
+
+    def __init__(self, ctx, N, S, device):
+        import torch
+        from . import capi
+        self.ctx = ctx
+        self.rank, self.world = rank_world()
+        W = self.world
+        if N % W or S % (32 * W):
+            raise ValueError(f"row-sharded all-pairs needs N % world == 0 and S % (32*world) == 0 (N={N}, S={S}, world={W})")
+        self.N, self.S, self.n_loc, self.S_loc = N, S, N // W, S // W
+        gw, ng = capi.operand_layout(N, S)
+        gw_l, ng_l = capi.operand_layout(N, self.S_loc)
+        assert gw == gw_l and ng == ng_l * W
+        i64, i32 = torch.int64, torch.int32
+        self.send = torch.empty((W, self.n_loc, self.S_loc), dtype=i64, device=device)
+        self.recv = torch.empty((N, self.S_loc), dtype=i64, device=device)
+        self.planes_loc = torch.empty(ng_l * gw, dtype=i32, device=device)
+        self.meta_loc = torch.empty(ng_l, dtype=i32, device=device)
+        self.planes_all = torch.empty(ng * gw, dtype=i32, device=device)
+        self.meta_all = torch.empty(ng, dtype=i32, device=device)
+        self.local = None
+        self.full = ctx.cmp_set_from_planes(N, S, self.planes_all.data_ptr(), self.meta_all.data_ptr())
+        b = row_bounds(N, W)
+        self.r0, self.r1 = b[self.rank], b[self.rank + 1]
+
+    def prepare(self, rows_t, stream):
+        from . import capi
+        self.ctx.pack_column_slices_dev(rows_t.data_ptr(), self.n_loc, self.S, self.world, self.send.data_ptr(), stream)
+        exchange_rows_to_colslices(self.send, self.recv)
+        if self.local is None:
+            self.local = self.ctx.cmp_set_dev(self.recv.data_ptr(), self.N, self.S_loc, algo=capi.CMP_BITSLICE, stream=stream)
+        else:
+            self.local.update_dev(self.recv.data_ptr(), stream)
+        self.local.export_operand_dev(self.planes_loc.data_ptr(), self.meta_loc.data_ptr(), stream)
+        gather_groups(self.planes_loc, self.planes_all)
+        gather_groups(self.meta_loc, self.meta_all)
+
+    def step_lut(self, rows_t, lut_t, out_t, stream):
+        self.prepare(rows_t, stream)
+        self.full.lut_ut_dev(lut_t.data_ptr(), out_t.data_ptr(), self.r0, self.r1, stream)
+
+    def step_eqcount(self, rows_t, out_t, stream):
+        self.prepare(rows_t, stream)
+        self.full.eqcount_ut_dev(out_t.data_ptr(), self.r0, self.r1, stream)
+
+    def close(self):
+        if self.local is not None:
+            self.local.close()
+        self.full.close()
+
+
 def load_stacked(path):
     """[u64 N][u64 S][f64 card x N][f64 x N*S]  (src/sketch_core.cpp:130-140, cmp_main.cpp:61-94)"""
     raw = np.fromfile(path, np.uint8)

@@ -191,6 +191,20 @@ int  d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_
  * all 0 for a DIRECT set. */
 int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits,
                         float *mean_nbits);
+/* ---- sharded prepare (multi-GPU).  The bit-sliced operand is an array of independent
+ * 32-register groups of `group_words` u32 each (+ one u32 of meta per group) whose geometry depends
+ * on N only, so ranks can each build the groups of their own column slice and all-gather them:
+ *   rows held by rank r --d2g_pack_column_slices_dev--> all-to-all --> column slice [N][S/W]
+ *   --d2g_cmp_set_create_dev(N, S/W, BITSLICE)--> d2g_cmp_set_export_operand_dev --> all-gather
+ *   --d2g_cmp_set_from_planes_dev(N, S, gathered)--> d2g_cmp_*_ut_dev on this rank's row range. */
+int  d2g_operand_layout(size_t N, size_t sketchsize, size_t *group_words, size_t *ngroups);
+int  d2g_cmp_set_export_operand_dev(d2g_ctx *ctx, const d2g_cmp_set *set, uint32_t *planes_out_dev,
+                                    uint32_t *meta_out_dev, void *stream);
+/* wraps a caller-owned (gathered) operand; only equality-count entry points work on it */
+int  d2g_cmp_set_from_planes_dev(d2g_ctx *ctx, size_t N, size_t sketchsize, const uint32_t *planes_dev,
+                                 const uint32_t *meta_dev, d2g_cmp_set **out);
+int  d2g_pack_column_slices_dev(d2g_ctx *ctx, const uint64_t *rows_dev, size_t n, size_t sketchsize, int nslices,
+                                uint64_t *out_dev, void *stream);
 void d2g_cmp_set_destroy(d2g_cmp_set *set);
 int  d2g_cmp_set_algo(const d2g_cmp_set *set);      /* the algorithm actually selected */
 /* equality counts (u32) for rows [r0,r1) of the upper triangle */

@@ -184,3 +184,77 @@ def test_k2_rejects_bad_input(gpu_ctx, d2g):
     with pytest.raises(d2g.D2GError):
         gpu_ctx.cmp_dist_ut(sigs, np.ones(4), measure=17)
     cs.close()
+
+
+@pytest.mark.parametrize("W", [1, 2, 4])
+def test_k2_sharded_prepare_single_gpu(gpu_ctx, d2g, oracle, W):
+    """multi-GPU prepare simulated rank by rank on one GPU: every 'rank' builds the bit-sliced
+    groups of its S/W columns from its column slice; the concatenation (what the all-gather produces)
+    wrapped by d2g_cmp_set_from_planes_dev must give the oracle's counts for every row range."""
+    rng = np.random.default_rng(W)
+    N, S = 260, 256
+    sigs = _planted(rng, N, S, nvals=5)
+    bits = sigs.view(np.uint64)
+    gw, ng = d2g.operand_layout(N, S)
+    S_loc = S // W
+    gw_l, ng_l = d2g.operand_layout(N, S_loc)
+    assert gw_l == gw and ng_l * W == ng
+    planes_all = gpu_ctx.malloc(ng * gw * 4)
+    meta_all = gpu_ctx.malloc(ng * 4)
+    n_loc = N // W
+    # pack + "all-to-all" emulated on the host: rank q receives columns [q*S_loc, (q+1)*S_loc) of all rows
+    rows_dev = gpu_ctx.malloc(n_loc * S * 8)
+    send_dev = gpu_ctx.malloc(n_loc * S * 8)
+    sends = []
+    for r in range(W):
+        gpu_ctx.h2d(rows_dev, np.ascontiguousarray(bits[r * n_loc:(r + 1) * n_loc]))
+        gpu_ctx.pack_column_slices_dev(rows_dev, n_loc, S, W, send_dev)
+        buf = np.empty((W, n_loc, S_loc), np.uint64)
+        gpu_ctx.d2h(buf, send_dev)
+        sends.append(buf)
+    for q in range(W):
+        colslice = np.concatenate([sends[r][q] for r in range(W)], axis=0)          # [N][S_loc]
+        np.testing.assert_array_equal(colslice, bits[:n_loc * W, q * S_loc:(q + 1) * S_loc])
+    if N % W:
+        pytest.skip("N not divisible")
+    for q in range(W):
+        cs = gpu_ctx.cmp_set(np.ascontiguousarray(bits[:, q * S_loc:(q + 1) * S_loc]), algo=d2g.CMP_BITSLICE)
+        cs.export_operand_dev(planes_all + q * ng_l * gw * 4, meta_all + q * ng_l * 4)
+        gpu_ctx.sync()
+        cs.close()
+    full = gpu_ctx.cmp_set_from_planes(N, S, planes_all, meta_all)
+    exp = oracle.eqcounts_ut(sigs)
+    np.testing.assert_array_equal(full.eqcount_ut(), exp)
+    b = d2g.ut_partition(N, 3)
+    np.testing.assert_array_equal(np.concatenate([full.eqcount_ut(b[i], b[i + 1]) for i in range(3)]), exp)
+    with pytest.raises(d2g.D2GError):
+        full.gtlt_ut()                      # a gathered operand has no raw patterns
+    full.close()
+    for p_ in (planes_all, meta_all, rows_dev, send_dev):
+        gpu_ctx.free(p_)
+
+
+def test_row_sharded_allpairs_world1(gpu_ctx, d2g, oracle):
+    """the torch-facing multi-GPU driver (dashing2_amd.dist.RowShardedAllPairs) in its degenerate
+    single-rank form: same library calls and buffers as the N>1 path, no process group."""
+    import torch
+    from dashing2_amd import dist as DD
+    rng = np.random.default_rng(77)
+    N, S = 384, 1024
+    sigs = _planted(rng, N, S, nvals=6)
+    dev = torch.device("cuda", 0)
+    rows = torch.from_numpy(sigs.view(np.int64)).to(dev)
+    eng = DD.RowShardedAllPairs(gpu_ctx, N, S, dev)
+    out = torch.empty(N * (N - 1) // 2, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(2):                                   # second pass reuses every buffer (update path)
+        eng.step_eqcount(rows, out, stream)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy().view(np.uint32), oracle.eqcounts_ut(sigs))
+    lut = torch.from_numpy(d2g.epilogue_lut(S, d2g.POISSON_LLR, 31)).to(dev)
+    fout = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
+    eng.step_lut(rows, lut, fout, stream)
+    torch.cuda.synchronize()
+    exp = oracle.allpairs_ut(sigs, np.ones(N), measure=oracle.POISSON_LLR, k=31, nthreads=4)
+    np.testing.assert_array_equal(fout.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    eng.close()
