@@ -107,6 +107,14 @@ def lib():
     """Load libd2g.so (once).  Raises if the extension has not been built: no fallback."""
     global _lib
     if _lib is None:
+        # torch wheels bundle their own HIP/HSA runtime; two runtimes in one process cannot both own
+        # the GPU.  If torch is going to be used next to libd2g (bench, dist), load it FIRST so that
+        # libd2g's libamdhip64.so.7 dependency resolves to the copy that is already mapped.
+        if os.environ.get("D2G_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not os.path.exists(LIB_PATH):
             raise OSError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(dashing2_amd has no CPU fallback)")
