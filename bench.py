@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "broadcast"],
                     help="N>1: row-sharded sketches + all-to-all/all-gather of the compact operand (default), "
                          "or rank-0 sketches broadcast whole")
+    ap.add_argument("--force-sharded", action="store_true", help="debug: run the N>1 code path at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -142,7 +143,7 @@ def main():
     bounds = D.ut_partition(N, world)
     r0, r1 = bounds[rank], bounds[rank + 1]
     my_pairs = D.ut_count(N, r0, r1)
-    sharded = world > 1 and args.exchange == "alltoall"
+    sharded = (world > 1 and args.exchange == "alltoall") or args.force_sharded
 
     # ---- synthetic pre-built sketches, resident in HBM before the timed region.
     # N == 1 or --exchange broadcast: the whole matrix lives on rank 0.

@@ -187,10 +187,11 @@ int d2g_cmp_set_algo(const d2g_cmp_set *set) { return set ? set->algo : D2G_ERR_
 // (re)load the operand: copy + transpose + (bitslice) ids/planes.  Everything is enqueued on `s`.
 static int cmp_set_load(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, hipStream_t s) {
     const size_t N = set->N, S = set->S;
-    D2G_HIP(ctx, hipMemcpyAsync(set->d_rows, sig_bits_dev, N * S * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    // only the DIRECT kernel reads the row-major operand; bit-sliced sets transpose straight from the caller's buffer
+    if (set->d_rows) D2G_HIP(ctx, hipMemcpyAsync(set->d_rows, sig_bits_dev, N * S * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
     d2g_timer tm(ctx, &ctx->ev_k2prep, s);
     dim3 grid((unsigned)div_up<size_t>(S, 32), (unsigned)div_up<size_t>(set->Npad, 32));
-    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, set->d_rows, set->d_cols, N, S, set->Npad);
+    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, sig_bits_dev, set->d_cols, N, S, set->Npad);
     int rc = D2G_OK;
     if (set->algo == D2G_CMP_BITSLICE) rc = d2g_bitslice_prepare(ctx, set, s);
     tm.stop();
@@ -214,19 +215,25 @@ int d2g_cmp_set_create_dev(d2g_ctx *ctx, const uint64_t *sig_bits_dev, size_t N,
     set->ctx = ctx; set->N = N; set->S = S;
     set->Npad = div_up<size_t>(N, K2_CB) * K2_CB;
     hipError_t e;
-    if ((e = hipMalloc((void **)&set->d_rows, (N + K2_RB) * S * sizeof(uint64_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_cols, set->Npad * S * sizeof(uint64_t))) != hipSuccess) {
+    if ((e = hipMalloc((void **)&set->d_cols, set->Npad * S * sizeof(uint64_t))) != hipSuccess) {
         ctx->last_error = hipGetErrorString(e);
         d2g_cmp_set_destroy(set);
         return D2G_ERR_NOMEM;
     }
-    // slack rows past N are read (never stored) by a partial last row tile
-    (void)hipMemsetAsync(set->d_rows + N * S, 0, (size_t)K2_RB * S * sizeof(uint64_t), s);
     set->algo = D2G_CMP_DIRECT;
     if (algo != D2G_CMP_DIRECT) {
         int rc = d2g_bitslice_alloc(ctx, set);
         if (rc == D2G_OK) set->algo = D2G_CMP_BITSLICE;
         else if (!(rc == D2G_ERR_UNSUPPORTED && algo == D2G_CMP_AUTO)) { d2g_cmp_set_destroy(set); return rc; }
+    }
+    if (set->algo == D2G_CMP_DIRECT) {
+        if ((e = hipMalloc((void **)&set->d_rows, (N + K2_RB) * S * sizeof(uint64_t))) != hipSuccess) {
+            ctx->last_error = hipGetErrorString(e);
+            d2g_cmp_set_destroy(set);
+            return D2G_ERR_NOMEM;
+        }
+        // slack rows past N are read (never stored) by a partial last row tile
+        (void)hipMemsetAsync(set->d_rows + N * S, 0, (size_t)K2_RB * S * sizeof(uint64_t), s);
     }
     int rc = cmp_set_load(ctx, set, sig_bits_dev, s);
     if (rc) { d2g_cmp_set_destroy(set); return rc; }
@@ -318,9 +325,9 @@ int d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t 
     if (int rc = check_rows(ctx, set, r0, r1)) return rc;
     if (d2g_ut_count(set->N, r0, r1) == 0) return D2G_OK;
     D2G_CHECK(ctx, gt != nullptr && lt != nullptr, "cmp: null output");
-    D2G_CHECK(ctx, set->d_rows != nullptr, "cmp: (gt,lt) needs the raw patterns; this set wraps a gathered bit-sliced operand");
+    D2G_CHECK(ctx, set->d_rows != nullptr, "cmp: (gt,lt) needs the raw patterns: create the set with D2G_CMP_DIRECT");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
-    // order needs the raw patterns: always the direct kernel (rows/cols are kept for every set)
+    // order needs the raw patterns: the direct kernel on a DIRECT set
     return launch_direct<true>(ctx, set, ut_shape(set, r0, r1), StoreGtLt{gt, lt, (uint32_t)set->S}, as_stream(stream));
 }
 
@@ -345,7 +352,7 @@ int d2g_cmp_gtlt_rect_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_
     D2G_CHECK(ctx, a0 <= a1 && a1 <= set->N && b0 <= b1 && b1 <= set->N, "cmp: rect out of bounds");
     if (a0 == a1 || b0 == b1) return D2G_OK;
     D2G_CHECK(ctx, gt != nullptr && lt != nullptr, "cmp: null output");
-    D2G_CHECK(ctx, set->d_rows != nullptr, "cmp: (gt,lt) needs the raw patterns; this set wraps a gathered bit-sliced operand");
+    D2G_CHECK(ctx, set->d_rows != nullptr, "cmp: (gt,lt) needs the raw patterns: create the set with D2G_CMP_DIRECT");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     PairShape sh{};
     sh.N = set->N; sh.i_lo = a0; sh.i_hi = a1; sh.j_lo = b0; sh.j_hi = b1; sh.ut = 0;

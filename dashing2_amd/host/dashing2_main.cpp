@@ -112,7 +112,7 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
     // groups of files bounded by input bytes: parsed in parallel on the host, sketched one group per launch
     std::vector<std::pair<size_t, size_t>> groups;                      // [begin,end) into todo
     {
-        const size_t limit = size_t(128) << 20;
+        const size_t limit = size_t(48) << 20;
         size_t b = 0, acc = 0;
         for (size_t t = 0; t < todo.size(); ++t) {
             size_t fs = 0;
@@ -131,7 +131,7 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
     double t_parse = 0, t_gpu = 0, t_fin = 0;
     uint64_t total_bases = 0;
 #ifdef _OPENMP
-    #pragma omp parallel for schedule(dynamic) num_threads(std::min<unsigned>(o.nthreads(), 8))
+    #pragma omp parallel for schedule(dynamic) num_threads(std::min<unsigned>(o.nthreads(), 64))
 #endif
     for (size_t g = 0; g < groups.size(); ++g) {
         const size_t b = groups[g].first, e = groups[g].second, n = e - b;

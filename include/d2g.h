@@ -213,7 +213,8 @@ int  d2g_cmp_eqcount_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, siz
 /* fused table epilogue: out = lut[neq] (lut_dev: S+1 floats, see d2g_epilogue_lut) */
 int  d2g_cmp_lut_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
                         const float *lut_dev, float *out_dev, void *stream);
-/* (#a>b, #a<b) counts per pair (direct algorithm only; needed when S is not a power of two) */
+/* (#a>b, #a<b) counts per pair: needs a set created with D2G_CMP_DIRECT (the raw patterns);
+ * required when S is not a power of two in set space */
 int  d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
                          uint32_t *gt_out_dev, uint32_t *lt_out_dev, void *stream);
 /* rectangular block: rows [a0,a1) x cols [b0,b1) of the full N x N equality-count matrix,

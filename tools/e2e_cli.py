@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the drop-in CLI on synthetic data (GPU box):
+   sketch: G genomes x L bp FASTA on local disk -> stacked sketch file
+   cmp   : N presketched synthetic sketches -> binary / PHYLIP matrix
+usage: e2e_cli.py [--genomes 200] [--len 5000000] [--sketches 10000] [--threads 64] [--workdir /tmp/d2e2e]"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+EXE = os.path.join(ROOT, "dashing2_amd", "bin", "dashing2")
+
+
+def run(args):
+    t0 = time.perf_counter()
+    r = subprocess.run([EXE] + args, capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    if r.returncode:
+        print(r.stderr[-2000:])
+        raise SystemExit(1)
+    info = [l for l in r.stderr.splitlines() if l.startswith("[d2g]")]
+    return dt, info
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genomes", type=int, default=200)
+    ap.add_argument("--len", type=int, default=5_000_000)
+    ap.add_argument("--sketches", type=int, default=10000)
+    ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 1))
+    ap.add_argument("--workdir", default="/tmp/d2e2e")
+    a = ap.parse_args()
+    import dashing2_amd as D
+    from dashing2_amd import synth
+    os.makedirs(a.workdir, exist_ok=True)
+    t0 = time.perf_counter()
+    paths = []
+    for i in range(a.genomes):
+        p = os.path.join(a.workdir, f"g{i:05d}.fa")
+        if not os.path.exists(p):
+            synth.write_fasta(p, f"g{i:05d}", synth.random_genome(i, a.len))
+        paths.append(p)
+    lst = os.path.join(a.workdir, "files.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    print(f"generated {a.genomes} x {a.len} bp FASTA in {time.perf_counter() - t0:.1f}s")
+    out = os.path.join(a.workdir, "stack.bin")
+    for rep in range(2):
+        dt, info = run(["sketch", "-v", "-k", "31", "-S", "1024", "-p", str(a.threads), "-F", lst, "-o", out])
+        bases = a.genomes * a.len
+        print(f"sketch run {rep}: {dt:.2f}s wall -> {bases / dt:.3e} bases/s end-to-end (FASTA on disk -> stacked sketches)")
+        for l in info:
+            print("   ", l)
+    # cmp on synthetic presketched collection
+    N, S = a.sketches, 1024
+    regs = synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928)
+    sigs, cards = D.oph_finalize(regs, S, nthreads=os.cpu_count() or 1)
+    st = os.path.join(a.workdir, "syn.bin")
+    with open(st, "wb") as f:
+        np.array([N, S], np.uint64).tofile(f)
+        cards.tofile(f)
+        sigs.tofile(f)
+    pairs = N * (N - 1) // 2
+    for name, flags in [("binary", ["--binary-output"]), ("phylip", ["--phylip"]), ("binary mash", ["--binary-output", "--distance"]),
+                        ("binary containment (host x87 epilogue)", ["--binary-output", "--containment"])]:
+        o = os.path.join(a.workdir, "dist.out")
+        dt, info = run(["cmp", "-v", "--presketched", "-k", "31", "-p", str(a.threads), "--cmpout", o] + flags + [st])
+        print(f"cmp {name}: {dt:.2f}s wall -> {pairs / dt:.3e} pairs/s end-to-end ({os.path.getsize(o) / 1e6:.0f} MB out)")
+        for l in info:
+            print("   ", l)
+
+
+if __name__ == "__main__":
+    main()
