@@ -16,9 +16,8 @@ struct d2g_cmp_set {
     int ntb = 0;                  // ceil(S/32)
     uint32_t *d_meta = nullptr;   // [tb] = max over the group's columns of (#values occurring >= 2 times) + 1 (device side; the kernels
                                   //       derive the live plane count from it, no host round trip)
-    uint32_t *d_owner = nullptr;  // workspace: [S][T] open-addressing owner table
     uint32_t *d_ids = nullptr;    // workspace: [S][Npad] dense ids
-    uint32_t T = 0; int logT = 0;
+    uint32_t T = 0; int logT = 0; // hash space of the rank kernel (power of two >= 1.5 N)
     bool borrowed = false;        // planes/meta belong to the caller (d2g_cmp_set_from_planes_dev)
 };
 

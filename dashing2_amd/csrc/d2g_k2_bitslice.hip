@@ -34,72 +34,86 @@ constexpr int BS_RANK_THREADS = 1024;
 // storage and no reserved sentinel value is needed.
 constexpr uint32_t BS_DUP = 0x80000000u;       // owner-table flag: the value has been seen again
 constexpr uint32_t BS_UNIQ = 0x80000000u;      // id flag: value occurs once in its column (never equal)
+constexpr int BS_LOG_TLDS_MAX = 15;            // LDS owner table: at most 32768 slots = 128 KiB
+
+__device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
+    // Fibonacci hashing: the top logT bits of the product (partition = top bits, slot = low bits of those)
+    return (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> (64 - logT));
+}
 
 // Singleton folding: a value that occurs exactly once in its register column can never compare
 // equal to anything, so all such values share id 0 and set the "unique" bit instead; only values
 // occurring >= 2 times get dense ids 1..D2.  meta[t/32] = max over the group's columns of D2 + 1.
-template <bool LDS_TABLE>
+//
+// One workgroup per register index t.  The T-slot hash space is walked in P = T / Tl partitions
+// (top hash bits); each pass inserts the values of one partition into a Tl-slot LDS table of
+// *owner sketch indices* (equality is decided against the owner's value: no key storage, no
+// reserved sentinel), compacts the slots whose value was seen again into dense ranks, and
+// writes the ids of that partition.  T >= 1.5 N, so a partition holds <= 2/3 Tl values on average.
+template <bool MULTI>   // MULTI: more than one partition (N > 21845)
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
-                                                                  uint32_t *owner_all, uint32_t T, int logT,
-                                                                  uint32_t *ids_all, uint32_t *max_distinct) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];   // LDS_TABLE: T owner slots
+                                                                  uint32_t T, int logT, uint32_t *ids_all, uint32_t *max_distinct) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t own[];        // Tl owner slots
     const size_t t = blockIdx.x;
     const uint64_t *col = cols + t * Npad;
-    uint32_t *own = LDS_TABLE ? lds_tab : owner_all + t * (size_t)T;
     uint32_t *ids = ids_all + t * Npad;
     const int tid = threadIdx.x;
-    const uint32_t mask = T - 1;
-
-    if (LDS_TABLE) {
-        for (uint32_t h = tid; h < T; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
-        __syncthreads();
-    }
-    for (size_t j = tid; j < N; j += BS_RANK_THREADS) {
-        const uint64_t v = col[j];
-        uint32_t h = (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> (64 - logT));
-        for (;;) {
-            const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, (uint32_t)j);
-            if (cur == BS_EMPTY) break;                                   // first occurrence: we own the slot
-            if (col[cur & ~BS_DUP] == v) {                                // same value seen again
-                if (!(cur & BS_DUP)) atomicOr(&own[h], BS_DUP);
-                break;
-            }
-            h = (h + 1) & mask;
-        }
-        ids[j] = h;
-    }
-    __syncthreads();
-
-    // compaction: slots whose value occurs >= 2 times get ranks 1..D2; singletons get BS_UNIQ
+    const int logTl = logT < BS_LOG_TLDS_MAX ? logT : BS_LOG_TLDS_MAX;
+    const uint32_t Tl = 1u << logTl, mask = Tl - 1, nparts = MULTI ? (T >> logTl) : 1u;
     __shared__ uint32_t wave_tot[BS_RANK_THREADS / 64];
     __shared__ uint32_t running;
     if (tid == 0) running = 1;                                           // id 0 is reserved for singletons
-    __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
-    for (uint32_t base = 0; base < T; base += BS_RANK_THREADS) {
-        const uint32_t h = base + tid;
-        uint32_t cur = BS_EMPTY;
-        if (h < T) cur = LDS_TABLE ? own[h] : __hip_atomic_load(&own[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool occ = cur != BS_EMPTY;
-        const bool dup = occ && (cur & BS_DUP);
-        const unsigned long long bal = __ballot(dup);
-        const uint32_t before = __popcll(bal & ((1ull << lane) - 1));
-        if (lane == 0) wave_tot[wave] = __popcll(bal);
+
+    for (uint32_t part = 0; part < nparts; ++part) {
+        for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
         __syncthreads();
-        uint32_t woff = 0, tot = 0;
-        for (int w = 0; w < BS_RANK_THREADS / 64; ++w) {
-            const uint32_t x = wave_tot[w];
-            if (w < wave) woff += x;
-            tot += x;
+        for (size_t j = tid; j < N; j += BS_RANK_THREADS) {
+            const uint64_t v = col[j];
+            const uint32_t hh = bs_hash(v, logT);
+            if (MULTI && (hh >> logTl) != part) continue;
+            uint32_t h = hh & mask;
+            for (;;) {
+                const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, (uint32_t)j);
+                if (cur == BS_EMPTY) break;                               // first occurrence: we own the slot
+                if (col[cur & ~BS_DUP] == v) {                            // same value seen again
+                    if (!(cur & BS_DUP)) atomicOr(&own[h], BS_DUP);
+                    break;
+                }
+                h = (h + 1) & mask;
+            }
+            ids[j] = h;
         }
-        const uint32_t r0 = running;
-        if (occ) own[h] = dup ? r0 + woff + before : BS_UNIQ;
         __syncthreads();
-        if (tid == 0) running = r0 + tot;
+        // compaction: slots whose value occurs >= 2 times get the next dense ranks; singletons BS_UNIQ
+        for (uint32_t base = 0; base < Tl; base += BS_RANK_THREADS) {
+            const uint32_t h = base + tid;
+            const uint32_t cur = h < Tl ? own[h] : BS_EMPTY;
+            const bool occ = cur != BS_EMPTY;
+            const bool dup = occ && (cur & BS_DUP);
+            const unsigned long long bal = __ballot(dup);
+            const uint32_t before = __popcll(bal & ((1ull << lane) - 1));
+            if (lane == 0) wave_tot[wave] = __popcll(bal);
+            __syncthreads();
+            uint32_t woff = 0, tot = 0;
+            for (int w = 0; w < BS_RANK_THREADS / 64; ++w) {
+                const uint32_t x = wave_tot[w];
+                if (w < wave) woff += x;
+                tot += x;
+            }
+            const uint32_t r0 = running;
+            if (occ) own[h] = dup ? r0 + woff + before : BS_UNIQ;
+            __syncthreads();
+            if (tid == 0) running = r0 + tot;
+            __syncthreads();
+        }
+        for (size_t j = tid; j < N; j += BS_RANK_THREADS) {
+            if (MULTI && (bs_hash(col[j], logT) >> logTl) != part) continue;
+            ids[j] = own[ids[j]];
+        }
         __syncthreads();
     }
-    if (tid == 0) atomicMax(&max_distinct[t >> 5], running);          // per 32-register group
-    for (size_t j = tid; j < N; j += BS_RANK_THREADS) ids[j] = own[ids[j]];
+    if (tid == 0) atomicMax(&max_distinct[t >> 5], running);              // per 32-register group
 }
 
 // ------------------------------------------------------------------ 2. 32 x nbits bit transpose
@@ -314,8 +328,8 @@ int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store st
 void d2g_bitslice_free(d2g_cmp_set *set) {
     if (!set) return;
     if (!set->borrowed) { (void)hipFree(set->d_planes); (void)hipFree(set->d_meta); }
-    (void)hipFree(set->d_owner); (void)hipFree(set->d_ids);
-    set->d_planes = set->d_meta = set->d_owner = set->d_ids = nullptr;
+    (void)hipFree(set->d_ids);
+    set->d_planes = set->d_meta = set->d_ids = nullptr;
 }
 
 // geometry of the bit-sliced operand: a function of N (and S) only, identical on every rank
@@ -331,13 +345,11 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
     if (N >= (1ull << 30)) { ctx->last_error = "bitslice: N too large"; return D2G_ERR_UNSUPPORTED; }
     d2g_bitslice_geometry(set);
-    // owner table: power of two >= 1.5 N (load <= 2/3), at least 64 slots
+    // hash space: power of two >= 1.5 N (load <= 2/3), at least 64 slots; walked in LDS-sized partitions
     set->T = 64; set->logT = 6;
     while ((uint64_t)set->T * 2 < (uint64_t)N * 3) { set->T <<= 1; ++set->logT; }
     hipError_t e;
-    const bool lds_table = (size_t)set->T * sizeof(uint32_t) <= 128 * 1024;
-    if ((!lds_table && (e = hipMalloc((void **)&set->d_owner, S * (size_t)set->T * sizeof(uint32_t))) != hipSuccess) ||
-        (e = hipMalloc((void **)&set->d_ids, S * Npad * sizeof(uint32_t))) != hipSuccess ||
+    if ((e = hipMalloc((void **)&set->d_ids, S * Npad * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_meta, (size_t)(set->ntb + 4) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_planes, (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride * sizeof(uint32_t))) != hipSuccess) {
         ctx->last_error = std::string("bitslice alloc: ") + hipGetErrorString(e);
@@ -351,18 +363,14 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
     D2G_HIP(ctx, hipMemsetAsync(set->d_meta, 0, (size_t)(set->ntb + 4) * sizeof(uint32_t), s));
-    if (set->d_owner == nullptr) {
-        // owner table in LDS (T * 4 bytes <= 128 KiB): ds_cmpst instead of global CAS chains
-        const size_t lds = (size_t)set->T * sizeof(uint32_t);
-        auto kern = bs_rank_kernel<true>;
+    {
+        const int logTl = set->logT < BS_LOG_TLDS_MAX ? set->logT : BS_LOG_TLDS_MAX;
+        const size_t lds = (size_t(1) << logTl) * sizeof(uint32_t);
+        auto kern = set->logT > BS_LOG_TLDS_MAX ? bs_rank_kernel<true> : bs_rank_kernel<false>;
         if (lds > 48 * 1024)
             D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, (uint32_t *)nullptr,
-                           set->T, set->logT, set->d_ids, set->d_meta);
-    } else {
-        D2G_HIP(ctx, hipMemsetAsync(set->d_owner, 0xFF, S * (size_t)set->T * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(bs_rank_kernel<false>, dim3((unsigned)S), dim3(BS_RANK_THREADS), 0, s, set->d_cols, N, Npad,
-                           set->d_owner, set->T, set->logT, set->d_ids, set->d_meta);
+        hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
+                           set->d_ids, set->d_meta);
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, S, N, Npad, set->d_planes, set->Nstride,
