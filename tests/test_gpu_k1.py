@@ -111,3 +111,17 @@ def test_k1_rejects_bad_input(gpu_ctx, d2g):
         gpu_ctx.oph_sketch(packed, rs, rl, go, 33, 1024)            # k > 32 unsupported
     with pytest.raises(d2g.D2GError):
         gpu_ctx.oph_sketch(packed, rs, (rl * 0 + 5).astype(np.uint32), go, 31, 1024)   # run shorter than k
+
+
+def test_k1_huge_sketch_global_registers(gpu_ctx, d2g, oracle):
+    """m * 8 bytes > 128 KiB does not fit the LDS register file: the kernel then min-updates HBM directly."""
+    k, S = 21, 32768
+    fa = synth.fasta_bytes("g", synth.random_genome(5, 400000))
+    sp = d2g.SeqPack(k)
+    sp.add_fastx(fa)
+    regs = gpu_ctx.oph_sketch_seqpack(sp, S)
+    np.testing.assert_array_equal(regs[0], oracle.sketch_buffer(fa, k=k, S=S)[0])
+    # and the largest LDS-resident size
+    S2 = 16384
+    regs2 = gpu_ctx.oph_sketch_seqpack(sp, S2)
+    np.testing.assert_array_equal(regs2[0], oracle.sketch_buffer(fa, k=k, S=S2)[0])

@@ -258,3 +258,19 @@ def test_row_sharded_allpairs_world1(gpu_ctx, d2g, oracle):
     exp = oracle.allpairs_ut(sigs, np.ones(N), measure=oracle.POISSON_LLR, k=31, nthreads=4)
     np.testing.assert_array_equal(fout.cpu().numpy().view(np.uint32), exp.view(np.uint32))
     eng.close()
+
+
+def test_k2_large_n_multi_partition(gpu_ctx, d2g):
+    """N > 21 845 takes the multi-partition rank kernel (hash space walked in LDS-sized pieces).
+    Checked against the independent DIRECT algorithm and the column-count checksum."""
+    N, S = 23_000, 64
+    regs = synth.synthetic_registers(N, S, nclusters=120, seed=3)
+    cs = gpu_ctx.cmp_set(regs, algo=d2g.CMP_BITSLICE)
+    a = cs.eqcount_ut()
+    md, nb, mean = cs.planes()
+    assert 2 <= md <= N and 1 <= nb <= 15
+    cs.close()
+    total, _ = _column_pair_totals(regs)
+    assert int(a.sum(dtype=np.int64)) == total
+    b = gpu_ctx.cmp_eqcount_ut(regs, algo=d2g.CMP_DIRECT)
+    np.testing.assert_array_equal(a, b)
