@@ -45,6 +45,8 @@ SIGNATURES = {
     "d2g_sync": (_int, [_vp, _vp]),
     "d2g_malloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "d2g_free": (_int, [_vp, _vp]),
+    "d2g_malloc_host": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "d2g_free_host": (_int, [_vp, _vp]),
     "d2g_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "d2g_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "d2g_set_timing": (_int, [_vp, _int]),

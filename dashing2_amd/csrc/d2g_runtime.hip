@@ -63,6 +63,18 @@ int d2g_free(d2g_ctx *c, void *dptr) {
     D2G_HIP(c, hipFree(dptr));
     return D2G_OK;
 }
+int d2g_malloc_host(d2g_ctx *c, size_t nbytes, void **hptr) {
+    if (!c || !hptr) return D2G_ERR_INVALID;
+    D2G_HIP(c, hipSetDevice(c->device));
+    D2G_HIP(c, hipHostMalloc(hptr, nbytes ? nbytes : 1, hipHostMallocDefault));
+    return D2G_OK;
+}
+int d2g_free_host(d2g_ctx *c, void *hptr) {
+    if (!c) return D2G_ERR_INVALID;
+    if (!hptr) return D2G_OK;
+    D2G_HIP(c, hipHostFree(hptr));
+    return D2G_OK;
+}
 int d2g_memcpy_h2d(d2g_ctx *c, void *dst, const void *src, size_t n, void *stream) {
     if (!c || (n && (!dst || !src))) return D2G_ERR_INVALID;
     D2G_HIP(c, hipSetDevice(c->device));

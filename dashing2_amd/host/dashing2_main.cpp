@@ -319,6 +319,12 @@ struct DevBuf {
     DevBuf(d2g_ctx *c, size_t n) : ctx(c) { check(c, d2g_malloc(c, n ? n : 4, &p), "d2g_malloc"); }
     ~DevBuf() { d2g_free(ctx, p); }
 };
+struct PinnedBuf {                            // page-locked host staging, reused across row batches
+    d2g_ctx *ctx; void *p = nullptr;
+    PinnedBuf(d2g_ctx *c, size_t n) : ctx(c) { check(c, d2g_malloc_host(c, n ? n : 4, &p), "d2g_malloc_host"); }
+    ~PinnedBuf() { d2g_free_host(ctx, p); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
 
 void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_core.cpp:615-751 (dense outputs)
     const size_t ns = res.names.size(), S = o.sketchsize;
@@ -344,45 +350,34 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     const size_t max_vals = size_t(1) << 27;                        // values per device batch (512 MiB of floats)
     double t_dev = 0, t_emit = 0;
     if (o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP) {            // emitrect.cpp:290-323
+        const size_t total_pairs = ns * (ns - 1) / 2, cap = std::min(std::max<size_t>(total_pairs, 1), max_vals + ns);
+        PinnedBuf hout(ctx, cap * 4), hca(ctx, have_lut ? 4 : cap * 4), hcb(ctx, need_gtlt ? cap * 4 : 4);
+        DevBuf da(ctx, cap * 4), db(ctx, need_gtlt ? cap * 4 : 4);
+        float *out = hout.as<float>();
+        uint32_t *ca = hca.as<uint32_t>(), *cb = hcb.as<uint32_t>();
         for (size_t r0 = 0; r0 < ns;) {
             size_t r1 = r0, cnt = 0;
             while (r1 < ns && (cnt == 0 || cnt + (ns - 1 - r1) <= max_vals)) { cnt += ns - 1 - r1; ++r1; }
-            std::vector<float> out(cnt);
             const double ta = now();
             if (cnt) {
                 if (have_lut) {
-                    DevBuf d(ctx, cnt * 4);
-                    check(ctx, d2g_cmp_lut_ut_dev(ctx, set, r0, r1, (const float *)dlut.p, (float *)d.p, nullptr), "d2g_cmp_lut_ut_dev");
-                    check(ctx, d2g_memcpy_d2h(ctx, out.data(), d.p, cnt * 4, nullptr), "d2h");
+                    check(ctx, d2g_cmp_lut_ut_dev(ctx, set, r0, r1, (const float *)dlut.p, (float *)da.p, nullptr), "d2g_cmp_lut_ut_dev");
+                    check(ctx, d2g_memcpy_d2h(ctx, out, da.p, cnt * 4, nullptr), "d2h");
                 } else {
-                    std::vector<uint32_t> ca(cnt), cb;
-                    DevBuf da(ctx, cnt * 4);
                     if (need_gtlt) {
-                        DevBuf db(ctx, cnt * 4);
-                        cb.resize(cnt);
                         check(ctx, d2g_cmp_gtlt_ut_dev(ctx, set, r0, r1, (uint32_t *)da.p, (uint32_t *)db.p, nullptr), "d2g_cmp_gtlt_ut_dev");
-                        check(ctx, d2g_memcpy_d2h(ctx, cb.data(), db.p, cnt * 4, nullptr), "d2h");
+                        check(ctx, d2g_memcpy_d2h(ctx, cb, db.p, cnt * 4, nullptr), "d2h");
                     } else {
                         check(ctx, d2g_cmp_eqcount_ut_dev(ctx, set, r0, r1, (uint32_t *)da.p, nullptr), "d2g_cmp_eqcount_ut_dev");
                     }
-                    check(ctx, d2g_memcpy_d2h(ctx, ca.data(), da.p, cnt * 4, nullptr), "d2h");
+                    check(ctx, d2g_memcpy_d2h(ctx, ca, da.p, cnt * 4, nullptr), "d2h");
                     // x87 epilogue on the host (cmp_core.cpp:458-517)
-                    std::vector<size_t> off(r1 - r0 + 1, 0);
-                    for (size_t i = r0; i < r1; ++i) off[i - r0 + 1] = off[i - r0] + (ns - 1 - i);
-#ifdef _OPENMP
-                    #pragma omp parallel for schedule(dynamic, 4) num_threads(o.nthreads())
-#endif
-                    for (size_t i = r0; i < r1; ++i)
-                        for (size_t j = i + 1; j < ns; ++j) {
-                            const size_t p = off[i - r0] + (j - i - 1);
-                            out[p] = multiset ? d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k)
-                                   : need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
-                                               : d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], o.measure, o.k);
-                        }
+                    check(ctx, d2g_epilogue_ut(ca, need_gtlt ? cb : nullptr, cards, ns, S, r0, r1, o.measure, o.k, multiset,
+                                               int(o.nthreads()), out), "d2g_epilogue_ut");
                 }
             }
             const double tb = now();
-            em.rows(r0, r1, out.data(), [&](size_t i) { return ns - 1 - i; });
+            em.rows(r0, r1, out, [&](size_t i) { return ns - 1 - i; });
             t_dev += tb - ta; t_emit += now() - tb;
             r0 = r1;
         }
@@ -391,22 +386,22 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
         const size_t c0 = o.ok == PANEL ? nf : 0, c1 = ns, ncol = c1 - c0;
         if (ncol == 0 || nf == 0) { check(ctx, D2G_OK, ""); }
         const size_t rows_per = std::max<size_t>(1, max_vals / std::max<size_t>(ncol, 1));
+        const size_t cap = std::max<size_t>(1, std::min(rows_per, std::max<size_t>(nf, 1)) * ncol);
+        PinnedBuf hout(ctx, cap * 4), hca(ctx, cap * 4), hcb(ctx, need_gtlt ? cap * 4 : 4);
+        DevBuf da(ctx, cap * 4), db(ctx, need_gtlt ? cap * 4 : 4);
+        float *out = hout.as<float>();
+        uint32_t *ca = hca.as<uint32_t>(), *cb = hcb.as<uint32_t>();
         for (size_t r0 = 0; r0 < nf; r0 += rows_per) {
             const size_t r1 = std::min(nf, r0 + rows_per), cnt = (r1 - r0) * ncol;
-            std::vector<float> out(cnt);
-            std::vector<uint32_t> ca(cnt), cb;
             const double ta = now();
             if (cnt) {
-                DevBuf da(ctx, cnt * 4);
                 if (need_gtlt) {
-                    DevBuf db(ctx, cnt * 4);
-                    cb.resize(cnt);
                     check(ctx, d2g_cmp_gtlt_rect_dev(ctx, set, r0, r1, c0, c1, (uint32_t *)da.p, (uint32_t *)db.p, nullptr), "d2g_cmp_gtlt_rect_dev");
-                    check(ctx, d2g_memcpy_d2h(ctx, cb.data(), db.p, cnt * 4, nullptr), "d2h");
+                    check(ctx, d2g_memcpy_d2h(ctx, cb, db.p, cnt * 4, nullptr), "d2h");
                 } else {
                     check(ctx, d2g_cmp_eqcount_rect_dev(ctx, set, r0, r1, c0, c1, (uint32_t *)da.p, nullptr), "d2g_cmp_eqcount_rect_dev");
                 }
-                check(ctx, d2g_memcpy_d2h(ctx, ca.data(), da.p, cnt * 4, nullptr), "d2h");
+                check(ctx, d2g_memcpy_d2h(ctx, ca, da.p, cnt * 4, nullptr), "d2h");
 #ifdef _OPENMP
                 #pragma omp parallel for schedule(dynamic, 4) num_threads(o.nthreads())
 #endif
@@ -420,11 +415,11 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                     }
             }
             const double tb = now();
-            em.rows(r0, r1, out.data(), [&](size_t) { return ncol; });
+            em.rows(r0, r1, out, [&](size_t) { return ncol; });
             t_dev += tb - ta; t_emit += now() - tb;
         }
     }
-    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp: %zu sketches x S=%zu: prepare %.3fs, device+epilogue %.3fs, emit %.3fs (algo %s)\n", ns, S,
+    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp: %zu sketches x S=%zu: upload+prepare+buffers %.3fs, device+D2H+epilogue %.3fs, emit %.3fs (algo %s)\n", ns, S,
                                   0.0 + (now() - t0 - t_dev - t_emit), t_dev, t_emit, d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE ? "bitslice" : "direct");
     d2g_cmp_set_destroy(set);
 }

@@ -67,6 +67,9 @@ int         d2g_ctx_device(const d2g_ctx *ctx);
 int         d2g_sync(d2g_ctx *ctx, void *stream);
 int         d2g_malloc(d2g_ctx *ctx, size_t nbytes, void **dptr);
 int         d2g_free(d2g_ctx *ctx, void *dptr);
+/* page-locked host memory: D2H/H2D at PCIe rate, no per-batch page faults */
+int         d2g_malloc_host(d2g_ctx *ctx, size_t nbytes, void **hptr);
+int         d2g_free_host(d2g_ctx *ctx, void *hptr);
 int         d2g_memcpy_h2d(d2g_ctx *ctx, void *dst_dev, const void *src_host, size_t nbytes, void *stream);
 int         d2g_memcpy_d2h(d2g_ctx *ctx, void *dst_host, const void *src_dev, size_t nbytes, void *stream);
 /* Per-launch HIP-event timing of the dominant kernels.  With timing enabled every launch of
