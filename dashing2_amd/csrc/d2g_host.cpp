@@ -283,7 +283,9 @@ struct d2g_seqpack {
     uint8_t  accum = 0;                // partially filled byte lives in packed.back()
     bool padded = false;
 
-    static constexpr uint32_t MAX_RUN = 1u << 30;
+    // runs longer than this are split into pieces that overlap by k-1 bases in place (run_len is u32);
+    // D2G_MAX_RUN lowers it so that tests can exercise the split
+    uint32_t MAX_RUN = [] { const char *e = std::getenv("D2G_MAX_RUN"); const long v = e ? std::atol(e) : 0; return v >= 64 ? uint32_t(v) : (1u << 30); }();
 
     inline void push_base(unsigned code) {
         const unsigned sh = (nbases & 3) * 2;

@@ -125,3 +125,25 @@ def test_k1_huge_sketch_global_registers(gpu_ctx, d2g, oracle):
     S2 = 16384
     regs2 = gpu_ctx.oph_sketch_seqpack(sp, S2)
     np.testing.assert_array_equal(regs2[0], oracle.sketch_buffer(fa, k=k, S=S2)[0])
+
+
+def test_k1_long_run_split_registers(oracle, tmp_path):
+    """same split exercised end to end on the GPU (fresh process with D2G_MAX_RUN=4096)."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import dashing2_amd as D
+from dashing2_amd import synth
+from oracle import oracle as O
+g = synth.fasta_bytes("g", synth.random_genome(12, 300000))
+sp = D.SeqPack(31); sp.add_fastx(g)
+assert sp.nruns > 50
+ctx = D.Context(0)
+regs = ctx.oph_sketch_seqpack(sp, 1024)
+assert np.array_equal(regs[0], O.sketch_buffer(g, k=31, S=1024)[0])
+print("OK")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, D2G_MAX_RUN="4096"))
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]

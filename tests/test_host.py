@@ -239,3 +239,34 @@ def test_cli_flag_validation_and_errors(tmp_path):
     for flag in (["--prob"], ["--full"], ["-k", "40"], ["--edit-distance"], ["--topk", "3"]):
         r = subprocess.run([exe, "sketch"] + flag + ["x.fa"], capture_output=True, text=True)
         assert r.returncode == 1 and "outside" in r.stderr, flag
+
+
+def test_seqpack_long_run_split(oracle, tmp_path):
+    """runs longer than the u32-safe limit are split into overlapping pieces (k-1 bases shared in place):
+    the k-mer multiset must be unchanged.  D2G_MAX_RUN lowers the limit for the test (fresh process)."""
+    import subprocess, sys, json
+    code = """
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import dashing2_amd as D
+from dashing2_amd import synth
+g = synth.random_genome(11, 5000).tobytes()
+sp = D.SeqPack(21)
+sp.add_sequence(g)
+packed, rs, rl, go = sp.arrays()
+kmers = set()
+tot = 0
+for s0, l in zip(rs.tolist(), rl.tolist()):
+    assert l <= 1000 and l >= 21
+    tot += l - 20
+    for p in range(s0, s0 + l - 20):
+        kmers.add(p)
+print(json.dumps({"nruns": int(rs.size), "sum_kmers": tot, "distinct_starts": len(kmers), "nkmers": sp.nkmers(0)}))
+""" % ROOT
+    env = dict(os.environ, D2G_MAX_RUN="1000")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["nruns"] > 4
+    assert r["nkmers"] == 5000 - 20
+    assert r["sum_kmers"] == 5000 - 20 == r["distinct_starts"]      # every k-mer start covered exactly once
