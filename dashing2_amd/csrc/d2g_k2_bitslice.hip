@@ -160,9 +160,12 @@ constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);   // mismatch acc
 constexpr unsigned BITOP3_C_OR_A_AND_B = 0xAA | (0xF0 & 0xCC);   // both values unique => never equal
 
 // IW = 16 rows per wave (one s_load_dwordx16 per plane), JR = 64-column groups per lane,
-// WC = waves side by side along the columns (WC * JR * 64 = 256), PF = software prefetch of the
-// next plane's operands (register double buffer).
-template <int JR, bool PF, class Store>
+// WC = waves side by side along the columns (WC * JR * 64 = 256).  The operands of the next plane
+// are always in flight (register double buffer).  Per 32-register group: plane 0 initialises
+// z = a ^ b (full-rate v_xor, no zeroing), planes 1.. accumulate with v_bitop3 z |= a ^ b, the
+// unique plane finishes with z | (ua & ub) feeding one accumulating v_bcnt.  Plane operands are
+// addressed as uniform plane pointer (SGPR pair, advanced by SALU) + per-lane 32-bit offset.
+template <int JR, class Store>
 __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap,
                                                                  const uint32_t *__restrict__ meta, int ntb, uint32_t S,
                                                                  PairShape sh, Store store) {
@@ -174,7 +177,6 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
     if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
     const size_t i0 = sh.i_lo + (size_t)rt * RB;
     const size_t jt0 = (size_t)(sh.ct0 + ct) * BS_CB;
-    if (sh.ut && jt0 + BS_CB - 1 <= i0) return;
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -189,92 +191,65 @@ __global__ __launch_bounds__(BS_THREADS) void k2_bitslice_kernel(const uint32_t 
 #pragma unroll
         for (int c = 0; c < JR; ++c) acc[i][c] = 0;
 
-    const uint32_t *prow = planes + iw0;          // uniform: scalar loads
-    const uint32_t *pcol = planes + j0 + lane;    // per lane: coalesced dword loads
+    const uint32_t colb = ((uint32_t)j0 + (uint32_t)lane) * 4u;  // byte offset inside a plane (per lane): saddr + voffset form
+    const uint32_t row = (uint32_t)iw0;                          // element offset of the wave's 16 row words (uniform)
     const size_t tbstride = (size_t)(nbits_cap + 1) * Nstride;
-    const size_t uoff = (size_t)nbits_cap * Nstride;          // slot of the "unique" plane within a group
-    if (!PF) {
-        for (int tb = 0; tb < ntb; ++tb) {
-            const int nbits = live_planes(meta, tb);                 // uniform (scalar load), per 32-register group
-            uint32_t z[IW][JR];
+    const size_t uoff = (size_t)nbits_cap * Nstride;             // slot of the "unique" plane within a group
+
+#define BS_FETCH(PLANE_PTR)                                                            \
+    do {                                                                               \
+        const uint32_t *pl__ = (PLANE_PTR);                                            \
+        sa_n = *reinterpret_cast<const u32x16_u *>(pl__ + row);     /* s_load_dwordx16 */ \
+        _Pragma("unroll") for (int c = 0; c < JR; ++c)                                 \
+            vb_n[c] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(pl__) + colb + 256 * c); \
+    } while (0)
+
+    u32x16_u sa_n;
+    uint32_t vb_n[JR];
+    BS_FETCH(planes);                                            // group 0, plane 0
+    for (int tb = 0; tb < ntb; ++tb) {
+        const int nbits = live_planes(meta, tb);                 // uniform (scalar load), per 32-register group
+        const uint32_t *gbase = planes + (size_t)tb * tbstride;
+        const uint32_t *gnext = (tb + 1 < ntb) ? gbase + tbstride : planes;   // last: harmless reload
+        uint32_t z[IW][JR];
+        {   // plane 0
+            const u32x16_u sa = sa_n;
+            uint32_t vb[JR];
+#pragma unroll
+            for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
+            BS_FETCH(nbits > 1 ? gbase + Nstride : gbase + uoff);
 #pragma unroll
             for (int i = 0; i < IW; ++i)
 #pragma unroll
-                for (int c = 0; c < JR; ++c) z[i][c] = 0;
-            const size_t base = (size_t)tb * tbstride;
-#pragma unroll 2
-            for (int p = 0; p < nbits; ++p) {
-                const size_t off = base + (size_t)p * Nstride;
-                const u32x16_u sa = *reinterpret_cast<const u32x16_u *>(prow + off);   // s_load_dwordx16
-                uint32_t vb[JR];
-#pragma unroll
-                for (int c = 0; c < JR; ++c) vb[c] = pcol[off + 64 * c];
-#pragma unroll
-                for (int i = 0; i < IW; ++i)
-#pragma unroll
-                    for (int c = 0; c < JR; ++c)
-                        z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
-            }
-            {
-                const u32x16_u sa = *reinterpret_cast<const u32x16_u *>(prow + base + uoff);
-                uint32_t vb[JR];
-#pragma unroll
-                for (int c = 0; c < JR; ++c) vb[c] = pcol[base + uoff + 64 * c];
-#pragma unroll
-                for (int i = 0; i < IW; ++i)
-#pragma unroll
-                    for (int c = 0; c < JR; ++c)
-                        acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_AND_B));
-            }
+                for (int c = 0; c < JR; ++c) z[i][c] = sa[i] ^ vb[c];
         }
-    } else {
-        size_t off_n = 0;
-        u32x16_u sa_n = *reinterpret_cast<const u32x16_u *>(prow);
-        uint32_t vb_n[JR];
+#pragma unroll 2
+        for (int p = 1; p < nbits; ++p) {
+            const u32x16_u sa = sa_n;
+            uint32_t vb[JR];
 #pragma unroll
-        for (int c = 0; c < JR; ++c) vb_n[c] = pcol[64 * c];
-        for (int tb = 0; tb < ntb; ++tb) {
-            const int nbits = live_planes(meta, tb);                 // uniform (scalar load), per 32-register group
-            uint32_t z[IW][JR];
+            for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
+            BS_FETCH(p + 1 < nbits ? gbase + (size_t)(p + 1) * Nstride : gbase + uoff);
 #pragma unroll
             for (int i = 0; i < IW; ++i)
 #pragma unroll
-                for (int c = 0; c < JR; ++c) z[i][c] = 0;
-            const size_t base = (size_t)tb * tbstride;
-            const size_t next_base = (tb + 1 < ntb) ? base + tbstride : 0;   // last: harmless reload of plane 0
-#pragma unroll 2
-            for (int p = 0; p < nbits; ++p) {
-                const u32x16_u sa = sa_n;
-                uint32_t vb[JR];
+                for (int c = 0; c < JR; ++c)
+                    z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+        }
+        {   // unique plane, then the group's mismatch count
+            const u32x16_u sa = sa_n;
+            uint32_t vb[JR];
 #pragma unroll
-                for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
-                off_n = (p + 1 < nbits) ? off_n + Nstride : base + uoff;      // after the last id plane: the unique plane
-                sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
+            for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
+            BS_FETCH(gnext);
 #pragma unroll
-                for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
+            for (int i = 0; i < IW; ++i)
 #pragma unroll
-                for (int i = 0; i < IW; ++i)
-#pragma unroll
-                    for (int c = 0; c < JR; ++c)
-                        z[i][c] = __builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_XOR_B);
-            }
-            {
-                const u32x16_u sa = sa_n;
-                uint32_t vb[JR];
-#pragma unroll
-                for (int c = 0; c < JR; ++c) vb[c] = vb_n[c];
-                off_n = next_base;
-                sa_n = *reinterpret_cast<const u32x16_u *>(prow + off_n);
-#pragma unroll
-                for (int c = 0; c < JR; ++c) vb_n[c] = pcol[off_n + 64 * c];
-#pragma unroll
-                for (int i = 0; i < IW; ++i)
-#pragma unroll
-                    for (int c = 0; c < JR; ++c)
-                        acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_AND_B));
-            }
+                for (int c = 0; c < JR; ++c)
+                    acc[i][c] += __builtin_popcount(__builtin_amdgcn_bitop3_b32(sa[i], vb[c], z[i][c], BITOP3_C_OR_A_AND_B));
         }
     }
+#undef BS_FETCH
     // padded registers never mismatch; a sketch equals itself even where its values are
     // column-unique (the "unique" plane only separates DIFFERENT sketches)
     uint32_t val[IW][JR];
@@ -303,21 +278,18 @@ int bs_variant() {
 
 template <class Store>
 int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
-    // D2G_BS_VARIANT (experiments): 0: 16x256/wave  1: 16x128/wave  2: 0+prefetch  3: 1+prefetch (default, fastest measured)
-    const int var = bs_variant();
-    const bool jr2 = (var == 1 || var == 3);
+    // D2G_BS_VARIANT (experiments): 0 = 16x256 per wave, anything else = 16x128 per wave (default, fastest measured)
+    const bool jr2 = bs_variant() != 0;
     if (int rc = finish_shape(ctx, sh, jr2 ? 32u : 64u)) return rc;
     if (sh.nvalid_total == 0) return D2G_OK;
+    D2G_CHECK(ctx, (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride < (1ull << 32), "bit-sliced operand exceeds 2^32 words");
     d2g_timer tm(ctx, &ctx->ev_k2, s);
-#define BS_LAUNCH(JRV, PFV) hipLaunchKernelGGL((k2_bitslice_kernel<JRV, PFV, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, \
-        set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store)
-    switch (var) {
-        case 0: BS_LAUNCH(4, false); break;
-        case 1: BS_LAUNCH(2, false); break;
-        case 2: BS_LAUNCH(4, true); break;
-        default: BS_LAUNCH(2, true); break;
-    }
-#undef BS_LAUNCH
+    if (jr2)
+        hipLaunchKernelGGL((k2_bitslice_kernel<2, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes, set->Nstride,
+                           set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
+    else
+        hipLaunchKernelGGL((k2_bitslice_kernel<4, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes, set->Nstride,
+                           set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
