@@ -65,6 +65,7 @@ SIGNATURES = {
     "d2g_epilogue_lut": (_int, [_sz, _int, _int, _int, _pf32]),
     "d2g_seqpack_create": (_int, [_int, C.POINTER(_vp)]),
     "d2g_seqpack_destroy": (None, [_vp]),
+    "d2g_seqpack_clear": (None, [_vp]),
     "d2g_seqpack_add_path": (_int, [_vp, _cp]),
     "d2g_seqpack_add_fastx": (_int, [_vp, _cp, _sz]),
     "d2g_seqpack_add_sequence": (_int, [_vp, _cp, _sz]),
@@ -83,6 +84,9 @@ SIGNATURES = {
     "d2g_oph_plan_nkmers": (_u64, [_vp]),
     "d2g_oph_plan_nbases": (_u64, [_vp]),
     "d2g_oph_sketch_dev": (_int, [_vp, _vp, _vp, _int, _u64, _sz, _vp, _vp]),
+    "d2g_sketcher_create": (_int, [_vp, C.POINTER(_vp)]),
+    "d2g_sketcher_destroy": (None, [_vp]),
+    "d2g_sketcher_run": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, _vp]),
     "d2g_ut_count": (_sz, [_sz, _sz, _sz]),
     "d2g_cmp_set_create_dev": (_int, [_vp, _vp, _sz, _sz, _int, _vp, C.POINTER(_vp)]),
     "d2g_cmp_set_create": (_int, [_vp, _vp, _sz, _sz, _int, C.POINTER(_vp)]),
@@ -340,6 +344,9 @@ class Context:
         packed, rs, rl, go = sp.arrays()
         return self.oph_sketch(packed, rs, rl, go, sp.k, S, canon, xormask)
 
+    def sketcher(self):
+        return Sketcher(self)
+
     def oph_plan(self, run_start, run_len, genome_run_off, k):
         run_start = np.ascontiguousarray(run_start, np.uint64)
         run_len = np.ascontiguousarray(run_len, np.uint32)
@@ -410,6 +417,32 @@ class Context:
     def d2h(self, arr, dptr, stream=None):
         assert arr.flags["C_CONTIGUOUS"]
         self._check(lib().d2g_memcpy_d2h(self._h, _np_ptr(arr), dptr, arr.nbytes, stream))
+
+
+class Sketcher:
+    """persistent K1 front end (d2g_sketcher): reuses device buffers across calls"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._h = None
+        h = _vp()
+        ctx._check(lib().d2g_sketcher_create(ctx._h, C.byref(h)))
+        self._h = h
+
+    def run(self, sp, S, canon=True, xormask=0):
+        packed, rs, rl, go = sp.arrays()
+        n = go.size - 1
+        regs = np.empty((n, oph_m(S)), np.uint64)
+        self.ctx._check(lib().d2g_sketcher_run(self._h, _np_ptr(packed), packed.size, _np_ptr(rs), _np_ptr(rl), rs.size,
+                                               _np_ptr(go), n, sp.k, int(canon), xormask, S, _np_ptr(regs)))
+        return regs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().d2g_sketcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 class OphPlan:

@@ -14,6 +14,7 @@
 #include <limits>
 #include <random>
 #include <string>
+#include <sys/stat.h>
 #include <vector>
 #include <zlib.h>
 #ifdef _OPENMP
@@ -281,25 +282,18 @@ struct d2g_seqpack {
     uint64_t cur_start = 0, cur_len = 0;
     uint64_t cur_kmers = 0;
     uint8_t  accum = 0;                // partially filled byte lives in packed.back()
-    bool padded = false;
 
     // runs longer than this are split into pieces that overlap by k-1 bases in place (run_len is u32);
     // D2G_MAX_RUN lowers it so that tests can exercise the split
     uint32_t MAX_RUN = [] { const char *e = std::getenv("D2G_MAX_RUN"); const long v = e ? std::atol(e) : 0; return v >= 64 ? uint32_t(v) : (1u << 30); }();
 
-    inline void push_base(unsigned code) {
-        const unsigned sh = (nbases & 3) * 2;
-        if (sh == 0) packed.push_back(uint8_t(code));
-        else packed.back() |= uint8_t(code << sh);
-        ++nbases;
-    }
     // bases of a run shorter than k are useless: rewind the stream over them
+    // (packed.size() may exceed the stream: the logical length is nbases)
     inline void rewind_to(uint64_t nb) {
         nbases = nb;
-        packed.resize((nb + 3) / 4);
-        if (nb & 3) packed.back() &= uint8_t((1u << ((nb & 3) * 2)) - 1);
+        if (nb & 3) packed[nb >> 2] &= uint8_t((1u << ((nb & 3) * 2)) - 1);
     }
-    void close_run() {
+    void close_run_raw() {
         if (cur_len >= uint64_t(k)) {
             // split very long runs; pieces overlap by k-1 bases in place
             uint64_t s = cur_start, left = cur_len;
@@ -315,15 +309,26 @@ struct d2g_seqpack {
         }
         cur_len = 0;
     }
+    void close_run() { close_run_raw(); }
     inline void feed(const char *s, size_t n) {
         static const int8_t *lut = code_lut();
+        // worst case every byte is a base: make room once, then write through a raw pointer
+        const size_t need = (nbases + n + 3) / 4 + 1;
+        if (packed.size() < need) packed.resize(std::max(need, packed.size() + packed.size() / 2));
+        uint8_t *pk = packed.data();
+        uint64_t nb = nbases, clen = cur_len;
         for (size_t i = 0; i < n; ++i) {
             const int c = lut[(unsigned char)s[i]];
-            if (c < 0) { if (cur_len) close_run(); continue; }
-            if (!cur_len) cur_start = nbases;
-            push_base(unsigned(c));
-            ++cur_len;
+            if (c < 0) {
+                if (clen) { nbases = nb; cur_len = clen; close_run_raw(); nb = nbases; clen = 0; pk = packed.data(); }
+                continue;
+            }
+            if (!clen) cur_start = nb;
+            const unsigned sh = (unsigned)(nb & 3) * 2;
+            if (sh == 0) pk[nb >> 2] = uint8_t(c); else pk[nb >> 2] |= uint8_t(c << sh);
+            ++nb; ++clen;
         }
+        nbases = nb; cur_len = clen;
     }
     void end_record() { if (cur_len) close_run(); }
     void end_genome() {
@@ -383,31 +388,50 @@ struct d2g_seqpack {
         }
     }
     void finalize_pad() {
-        if (padded) return;
-        packed.resize((nbases + 3) / 4 + 64, 0);
-        padded = true;
+        // logical stream = ceil(nbases/4) bytes; everything after it must read as zero-initialised pad
+        const size_t nbytes = (nbases + 3) / 4;
+        if (packed.size() < nbytes + 64) packed.resize(nbytes + 64, 0);
+        std::memset(packed.data() + nbytes, 0, 64);
+        padded_bytes = nbytes + 64;
     }
-    void unpad() {
-        if (!padded) return;
-        packed.resize((nbases + 3) / 4);
-        padded = false;
+    void unpad() {}
+    void reserve_bases(uint64_t more) {
+        const size_t need = (nbases + more + 3) / 4 + 65;
+        if (packed.size() < need) packed.resize(need);
     }
+    size_t padded_bytes = 0;
 };
 
-static bool slurp_gz(const char *path, std::vector<char> &out) {
-    gzFile fp = gzopen(path, "rb");
+// whole file into a reusable per-thread buffer; gzip members go through zlib, plain files are read directly
+static bool slurp(const char *path, std::vector<char> &out, size_t &len) {
+    len = 0;
+    std::FILE *fp = std::fopen(path, "rb");
     if (!fp) return false;
-    gzbuffer(fp, 1 << 20);
-    out.clear();
-    size_t len = 0;
+    unsigned char magic[2] = {0, 0};
+    const size_t got = std::fread(magic, 1, 2, fp);
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (!gz) {
+        struct stat st;
+        if (::fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode)) {
+            const size_t sz = size_t(st.st_size);
+            if (out.size() < sz + 1) out.resize(sz + 1);
+            std::rewind(fp);
+            len = std::fread(out.data(), 1, sz, fp);
+            std::fclose(fp);
+            return len == sz;
+        }
+    }
+    std::fclose(fp);
+    gzFile gp = gzopen(path, "rb");
+    if (!gp) return false;
+    gzbuffer(gp, 1 << 20);
     for (;;) {
         if (out.size() - len < (1u << 20)) out.resize(std::max<size_t>(out.size() * 2, 1u << 22));
-        const int n = gzread(fp, out.data() + len, unsigned(std::min<size_t>(out.size() - len, 1u << 30)));
+        const int n = gzread(gp, out.data() + len, unsigned(std::min<size_t>(out.size() - len, 1u << 30)));
         if (n <= 0) break;
         len += size_t(n);
     }
-    gzclose(fp);
-    out.resize(len);
+    gzclose(gp);
     return true;
 }
 
@@ -423,6 +447,12 @@ int d2g_seqpack_create(int k, d2g_seqpack **out) {
     return D2G_OK;
 }
 void d2g_seqpack_destroy(d2g_seqpack *sp) { delete sp; }
+void d2g_seqpack_clear(d2g_seqpack *sp) {          // keep every allocation, forget the content
+    if (!sp) return;
+    sp->nbases = 0; sp->cur_start = sp->cur_len = sp->cur_kmers = 0; sp->padded_bytes = 0;
+    sp->run_start.clear(); sp->run_len.clear(); sp->genome_nkmers.clear();
+    sp->genome_run_off.assign(1, 0);
+}
 
 int d2g_seqpack_add_path(d2g_seqpack *sp, const char *line) {
     if (!sp || !line) return D2G_ERR_INVALID;
@@ -430,15 +460,17 @@ int d2g_seqpack_add_path(d2g_seqpack *sp, const char *line) {
     // d2.h:52-71 for_each_substr: space-separated sub-paths feed one sketch
     std::string s(line);
     size_t b = 0;
-    std::vector<char> buf;
+    static thread_local std::vector<char> buf;        // reused across files: no per-file allocation / zero fill
     int rc = D2G_OK;
     while (b <= s.size()) {
         size_t e = s.find(' ', b);
         if (e == std::string::npos) e = s.size();
         if (e > b) {
             const std::string sub = s.substr(b, e - b);
-            if (!slurp_gz(sub.c_str(), buf)) { rc = D2G_ERR_IO; break; }
-            sp->feed_fastx(buf.data(), buf.size());
+            size_t len = 0;
+            if (!slurp(sub.c_str(), buf, len)) { rc = D2G_ERR_IO; break; }
+            sp->reserve_bases(len);
+            sp->feed_fastx(buf.data(), len);
         }
         b = e + 1;
     }
@@ -461,7 +493,7 @@ int d2g_seqpack_add_sequence(d2g_seqpack *sp, const char *seq, size_t len) {
 }
 size_t d2g_seqpack_ngenomes(const d2g_seqpack *sp) { return sp->genome_run_off.size() - 1; }
 size_t d2g_seqpack_nruns(const d2g_seqpack *sp) { return sp->run_start.size(); }
-size_t d2g_seqpack_packed_bytes(const d2g_seqpack *sp) { const_cast<d2g_seqpack *>(sp)->finalize_pad(); return sp->packed.size(); }
+size_t d2g_seqpack_packed_bytes(const d2g_seqpack *sp) { const_cast<d2g_seqpack *>(sp)->finalize_pad(); return sp->padded_bytes; }
 const uint8_t *d2g_seqpack_packed(const d2g_seqpack *sp) { const_cast<d2g_seqpack *>(sp)->finalize_pad(); return sp->packed.data(); }
 const uint64_t *d2g_seqpack_run_start(const d2g_seqpack *sp) { return sp->run_start.data(); }
 const uint32_t *d2g_seqpack_run_len(const d2g_seqpack *sp) { return sp->run_len.data(); }

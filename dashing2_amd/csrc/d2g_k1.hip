@@ -16,6 +16,7 @@
 //     consecutive lanes read consecutive 16-byte pieces (1 KiB per wave-instruction).
 #include "d2g_internal.h"
 #include <algorithm>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -192,51 +193,104 @@ void d2g_oph_plan_destroy(d2g_oph_plan *p) {
 uint64_t d2g_oph_plan_nkmers(const d2g_oph_plan *p) { return p ? p->nkmers : 0; }
 uint64_t d2g_oph_plan_nbases(const d2g_oph_plan *p) { return p ? p->nbases : 0; }
 
+}  // extern "C"
+
+namespace {
+// host-side launch plan: 64-k-mer chunks per run, <= K1_BLOCK_CHUNKS chunks of one genome per workgroup
+struct PlanHost {
+    std::vector<uint64_t> chunk_off, bc0;
+    std::vector<uint32_t> bg, bn, blo, bhi;
+    uint64_t nkmers = 0, nbases = 0;
+};
+int build_plan_host(d2g_ctx *ctx, const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, PlanHost &p) {
+    D2G_CHECK(ctx, genome_run_off && (nrun == 0 || run_len), "oph plan: null table");
+    if (k < 1 || k > 32) { ctx->last_error = "k must be in [1,32] (exact 2-bit encoding path)"; return D2G_ERR_UNSUPPORTED; }
+    D2G_CHECK(ctx, genome_run_off[n] == nrun, "oph plan: genome_run_off[n] != nrun");
+    D2G_CHECK(ctx, nrun < (1ull << 32), "oph plan: too many runs");
+    p.chunk_off.assign(nrun + 1, 0);
+    for (size_t r = 0; r < nrun; ++r) {
+        D2G_CHECK(ctx, run_len[r] >= (uint32_t)k, "run shorter than k");
+        const uint64_t nk = (uint64_t)run_len[r] - k + 1;
+        p.chunk_off[r + 1] = p.chunk_off[r] + div_up<uint64_t>(nk, K1_CHUNK);
+        p.nkmers += nk;
+        p.nbases += run_len[r];
+    }
+    for (size_t g = 0; g < n; ++g) {
+        const size_t r0 = genome_run_off[g], r1 = genome_run_off[g + 1];
+        D2G_CHECK(ctx, r1 >= r0 && r1 <= nrun, "genome_run_off not monotone");
+        const uint64_t cbeg = p.chunk_off[r0], cend = p.chunk_off[r1];
+        size_t r = r0;
+        for (uint64_t c = cbeg; c < cend; c += K1_BLOCK_CHUNKS) {
+            const uint32_t nc = (uint32_t)std::min<uint64_t>(K1_BLOCK_CHUNKS, cend - c);
+            while (p.chunk_off[r + 1] <= c) ++r;
+            size_t rl = r;
+            while (p.chunk_off[rl + 1] < c + nc) ++rl;
+            p.bg.push_back((uint32_t)g); p.bc0.push_back(c); p.bn.push_back(nc);
+            p.blo.push_back((uint32_t)r); p.bhi.push_back((uint32_t)rl + 1);
+        }
+    }
+    D2G_CHECK(ctx, p.bg.size() < (1ull << 31), "oph plan: too many workgroups; sketch in smaller batches");
+    return D2G_OK;
+}
+
+int launch_k1(d2g_ctx *ctx, K1Args a, size_t nblk, size_t m, hipStream_t s) {
+    const bool pow2 = (m & (m - 1)) == 0;
+    const size_t lds = m * sizeof(uint64_t);
+    const bool use_lds = lds <= 128 * 1024;
+    auto kern = pow2 ? (use_lds ? k1_oph_kernel<true, true> : k1_oph_kernel<true, false>)
+                     : (use_lds ? k1_oph_kernel<false, true> : k1_oph_kernel<false, false>);
+    if (use_lds && lds > 48 * 1024)
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    d2g_timer tm(ctx, &ctx->ev_k1, s);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(K1_THREADS), use_lds ? lds : 0, s, a);
+    tm.stop();
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+template <class T> int grow(d2g_ctx *ctx, T **p, size_t *cap, size_t need) {
+    if (need <= *cap) return D2G_OK;
+    (void)hipFree(*p); *p = nullptr; *cap = 0;
+    const size_t ncap = need + need / 4 + 4096;
+    D2G_HIP(ctx, hipMalloc((void **)p, ncap * sizeof(T)));
+    *cap = ncap;
+    return D2G_OK;
+}
+}  // namespace
+
+// Host ingest feeds K1 in groups of inputs; re-allocating device buffers and uploading eight
+// small tables per group costs ~20 ms, the kernel ~0.1 ms.  The sketcher keeps grow-only device
+// buffers and ships all launch tables in ONE copy from a pinned arena.
+struct d2g_sketcher {
+    d2g_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;
+    uint8_t *d_packed = nullptr; size_t cap_packed = 0;
+    uint64_t *d_regs = nullptr;  size_t cap_regs = 0;      // in u64
+    uint8_t *d_arena = nullptr, *h_arena = nullptr; size_t cap_arena = 0;
+    uint8_t *h_stage = nullptr; size_t cap_stage = 0;      // pinned staging of the packed stream
+};
+
+extern "C" {
+
 int d2g_oph_plan_create(d2g_ctx *ctx, const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
                         const uint64_t *genome_run_off, size_t n, int k, d2g_oph_plan **out) {
     if (!ctx || !out) return D2G_ERR_INVALID;
     *out = nullptr;
-    D2G_CHECK(ctx, genome_run_off && (nrun == 0 || (run_start && run_len)), "d2g_oph_plan_create: null table");
-    if (k < 1 || k > 32) { ctx->last_error = "k must be in [1,32] (exact 2-bit encoding path)"; return D2G_ERR_UNSUPPORTED; }
-    D2G_CHECK(ctx, genome_run_off[n] == nrun, "d2g_oph_plan_create: genome_run_off[n] != nrun");
-    D2G_CHECK(ctx, nrun < (1ull << 32), "d2g_oph_plan_create: too many runs");
+    D2G_CHECK(ctx, nrun == 0 || run_start, "d2g_oph_plan_create: null table");
+    PlanHost ph;
+    if (int rc = build_plan_host(ctx, run_len, nrun, genome_run_off, n, k, ph)) return rc;
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     d2g_oph_plan *p = new (std::nothrow) d2g_oph_plan();
     if (!p) return D2G_ERR_NOMEM;
     p->ctx = ctx; p->k = k; p->n = n; p->nrun = nrun;
-
-    std::vector<uint64_t> chunk_off(nrun + 1, 0);
-    for (size_t r = 0; r < nrun; ++r) {
-        if (run_len[r] < (uint32_t)k) { delete p; ctx->last_error = "run shorter than k"; return D2G_ERR_INVALID; }
-        const uint64_t nk = (uint64_t)run_len[r] - k + 1;
-        chunk_off[r + 1] = chunk_off[r] + div_up<uint64_t>(nk, K1_CHUNK);
-        p->nkmers += nk;
-        p->nbases += run_len[r];
-    }
-    std::vector<uint32_t> bg, bn, blo, bhi;
-    std::vector<uint64_t> bc0;
-    for (size_t g = 0; g < n; ++g) {
-        const size_t r0 = genome_run_off[g], r1 = genome_run_off[g + 1];
-        if (r1 < r0 || r1 > nrun) { delete p; ctx->last_error = "genome_run_off not monotone"; return D2G_ERR_INVALID; }
-        const uint64_t cbeg = chunk_off[r0], cend = chunk_off[r1];
-        size_t r = r0;
-        for (uint64_t c = cbeg; c < cend; c += K1_BLOCK_CHUNKS) {
-            const uint32_t nc = (uint32_t)std::min<uint64_t>(K1_BLOCK_CHUNKS, cend - c);
-            while (chunk_off[r + 1] <= c) ++r;
-            size_t rl = r;
-            while (chunk_off[rl + 1] < c + nc) ++rl;
-            bg.push_back((uint32_t)g); bc0.push_back(c); bn.push_back(nc);
-            blo.push_back((uint32_t)r); bhi.push_back((uint32_t)rl + 1);
-        }
-    }
-    p->nblk = bg.size();
+    p->nkmers = ph.nkmers; p->nbases = ph.nbases; p->nblk = ph.bg.size();
     std::vector<uint64_t> rs(run_start, run_start + nrun);
     std::vector<uint32_t> rl(run_len, run_len + nrun);
     int rc;
     if ((rc = upload(ctx, rs, &p->d_run_start)) || (rc = upload(ctx, rl, &p->d_run_len)) ||
-        (rc = upload(ctx, chunk_off, &p->d_run_chunk_off)) || (rc = upload(ctx, bg, &p->d_blk_genome)) ||
-        (rc = upload(ctx, bc0, &p->d_blk_chunk0)) || (rc = upload(ctx, bn, &p->d_blk_nchunks)) ||
-        (rc = upload(ctx, blo, &p->d_blk_run_lo)) || (rc = upload(ctx, bhi, &p->d_blk_run_hi))) {
+        (rc = upload(ctx, ph.chunk_off, &p->d_run_chunk_off)) || (rc = upload(ctx, ph.bg, &p->d_blk_genome)) ||
+        (rc = upload(ctx, ph.bc0, &p->d_blk_chunk0)) || (rc = upload(ctx, ph.bn, &p->d_blk_nchunks)) ||
+        (rc = upload(ctx, ph.blo, &p->d_blk_run_lo)) || (rc = upload(ctx, ph.bhi, &p->d_blk_run_hi))) {
         d2g_oph_plan_destroy(p);
         return rc;
     }
@@ -265,18 +319,7 @@ int d2g_oph_sketch_dev(d2g_ctx *ctx, const d2g_oph_plan *plan, const uint8_t *pa
     a.blk_run_lo = plan->d_blk_run_lo; a.blk_run_hi = plan->d_blk_run_hi;
     a.regs_out = regs_out_dev; a.xormask = xormask; a.ophxor = d2g_oph_xor_const();
     a.m = (uint32_t)m; a.k = plan->k; a.canon = canon;
-    const bool pow2 = (m & (m - 1)) == 0;
-    const size_t lds = m * sizeof(uint64_t);
-    const bool use_lds = lds <= 128 * 1024;
-    auto kern = pow2 ? (use_lds ? k1_oph_kernel<true, true> : k1_oph_kernel<true, false>)
-                     : (use_lds ? k1_oph_kernel<false, true> : k1_oph_kernel<false, false>);
-    if (use_lds && lds > 48 * 1024)
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    d2g_timer tm(ctx, &ctx->ev_k1, s);
-    hipLaunchKernelGGL(kern, dim3((unsigned)plan->nblk), dim3(K1_THREADS), use_lds ? lds : 0, s, a);
-    tm.stop();
-    D2G_HIP(ctx, hipGetLastError());
-    return D2G_OK;
+    return launch_k1(ctx, a, plan->nblk, m, s);
 }
 
 int d2g_oph_sketch(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
@@ -316,6 +359,112 @@ int d2g_oph_sketch(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes, con
     }
     cleanup();
     return rc;
+}
+
+void d2g_sketcher_destroy(d2g_sketcher *sk) {
+    if (!sk) return;
+    (void)hipSetDevice(sk->ctx->device);
+    (void)hipFree(sk->d_packed); (void)hipFree(sk->d_regs); (void)hipFree(sk->d_arena);
+    if (sk->h_arena) (void)hipHostFree(sk->h_arena);
+    if (sk->h_stage) (void)hipHostFree(sk->h_stage);
+    if (sk->stream) (void)hipStreamDestroy(sk->stream);
+    delete sk;
+}
+
+int d2g_sketcher_create(d2g_ctx *ctx, d2g_sketcher **out) {
+    if (!ctx || !out) return D2G_ERR_INVALID;
+    *out = nullptr;
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    d2g_sketcher *sk = new (std::nothrow) d2g_sketcher();
+    if (!sk) return D2G_ERR_NOMEM;
+    sk->ctx = ctx;
+    hipError_t e = hipStreamCreateWithFlags(&sk->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { ctx->last_error = hipGetErrorString(e); delete sk; return D2G_ERR_HIP; }
+    *out = sk;
+    return D2G_OK;
+}
+
+int d2g_sketcher_run(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
+                     const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
+                     uint64_t xormask, size_t sketchsize, uint64_t *regs_out) {
+    if (!sk) return D2G_ERR_INVALID;
+    d2g_ctx *ctx = sk->ctx;
+    D2G_CHECK(ctx, sketchsize >= 1 && sketchsize < (1ull << 31), "sketchsize out of range");
+    D2G_CHECK(ctx, regs_out != nullptr || n == 0, "null regs_out");
+    D2G_CHECK(ctx, nrun == 0 || (run_start && packed), "null input");
+    PlanHost ph;
+    if (int rc = build_plan_host(ctx, run_len, nrun, genome_run_off, n, k, ph)) return rc;
+    if (nrun) {
+        uint64_t maxend = 0;
+        for (size_t r = 0; r < nrun; ++r) maxend = std::max<uint64_t>(maxend, run_start[r] + run_len[r]);
+        D2G_CHECK(ctx, packed_bytes >= (maxend + 3) / 4 + 64, "packed stream lacks the 64-byte tail pad");
+    }
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t m = d2g_oph_m(sketchsize), nblk = ph.bg.size();
+    if (int rc = grow(ctx, &sk->d_packed, &sk->cap_packed, std::max<size_t>(packed_bytes, 4))) return rc;
+    if (int rc = grow(ctx, &sk->d_regs, &sk->cap_regs, std::max<size_t>(n * m, 1))) return rc;
+    // arena layout (256-byte aligned pieces)
+    auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
+    size_t off = 0;
+    const size_t o_rs = off;  off = al(off + nrun * 8);
+    const size_t o_co = off;  off = al(off + (nrun + 1) * 8);
+    const size_t o_c0 = off;  off = al(off + nblk * 8);
+    const size_t o_rl = off;  off = al(off + nrun * 4);
+    const size_t o_bg = off;  off = al(off + nblk * 4);
+    const size_t o_bn = off;  off = al(off + nblk * 4);
+    const size_t o_lo = off;  off = al(off + nblk * 4);
+    const size_t o_hi = off;  off = al(off + nblk * 4);
+    if (off > sk->cap_arena) {
+        (void)hipFree(sk->d_arena);
+        if (sk->h_arena) (void)hipHostFree(sk->h_arena);
+        sk->d_arena = sk->h_arena = nullptr; sk->cap_arena = 0;
+        const size_t ncap = off + off / 4 + 65536;
+        D2G_HIP(ctx, hipMalloc((void **)&sk->d_arena, ncap));
+        D2G_HIP(ctx, hipHostMalloc((void **)&sk->h_arena, ncap, hipHostMallocDefault));
+        sk->cap_arena = ncap;
+    }
+    uint8_t *h = sk->h_arena;
+    if (nrun) { std::memcpy(h + o_rs, run_start, nrun * 8); std::memcpy(h + o_rl, run_len, nrun * 4); }
+    std::memcpy(h + o_co, ph.chunk_off.data(), (nrun + 1) * 8);
+    if (nblk) {
+        std::memcpy(h + o_c0, ph.bc0.data(), nblk * 8); std::memcpy(h + o_bg, ph.bg.data(), nblk * 4);
+        std::memcpy(h + o_bn, ph.bn.data(), nblk * 4);  std::memcpy(h + o_lo, ph.blo.data(), nblk * 4);
+        std::memcpy(h + o_hi, ph.bhi.data(), nblk * 4);
+    }
+    hipStream_t s = sk->stream;
+    D2G_HIP(ctx, hipMemcpyAsync(sk->d_arena, h, off, hipMemcpyHostToDevice, s));
+    if (packed_bytes) {
+        // pageable source: stage through our own pinned buffer (the runtime would otherwise pin the
+        // caller's pages on the fly, which contends with parser threads on the process' mm locks)
+        if (packed_bytes > sk->cap_stage) {
+            if (sk->h_stage) (void)hipHostFree(sk->h_stage);
+            sk->h_stage = nullptr; sk->cap_stage = 0;
+            const size_t ncap = packed_bytes + packed_bytes / 4 + 65536;
+            D2G_HIP(ctx, hipHostMalloc((void **)&sk->h_stage, ncap, hipHostMallocDefault));
+            sk->cap_stage = ncap;
+        }
+        std::memcpy(sk->h_stage, packed, packed_bytes);
+        D2G_HIP(ctx, hipMemcpyAsync(sk->d_packed, sk->h_stage, packed_bytes, hipMemcpyHostToDevice, s));
+    }
+    D2G_HIP(ctx, hipMemsetAsync(sk->d_regs, 0xFF, std::max<size_t>(n * m, 1) * sizeof(uint64_t), s));   // registers_ = T(-1): oph.h:147,233
+    if (nblk) {
+        K1Args a;
+        a.packed = reinterpret_cast<const uint32_t *>(sk->d_packed);
+        a.run_start = reinterpret_cast<const uint64_t *>(sk->d_arena + o_rs);
+        a.run_len = reinterpret_cast<const uint32_t *>(sk->d_arena + o_rl);
+        a.run_chunk_off = reinterpret_cast<const uint64_t *>(sk->d_arena + o_co);
+        a.blk_genome = reinterpret_cast<const uint32_t *>(sk->d_arena + o_bg);
+        a.blk_chunk0 = reinterpret_cast<const uint64_t *>(sk->d_arena + o_c0);
+        a.blk_nchunks = reinterpret_cast<const uint32_t *>(sk->d_arena + o_bn);
+        a.blk_run_lo = reinterpret_cast<const uint32_t *>(sk->d_arena + o_lo);
+        a.blk_run_hi = reinterpret_cast<const uint32_t *>(sk->d_arena + o_hi);
+        a.regs_out = sk->d_regs; a.xormask = xormask; a.ophxor = d2g_oph_xor_const();
+        a.m = (uint32_t)m; a.k = k; a.canon = canon;
+        if (int rc = launch_k1(ctx, a, nblk, m, s)) return rc;
+    }
+    if (n) D2G_HIP(ctx, hipMemcpyAsync(regs_out, sk->d_regs, n * m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipStreamSynchronize(s));
+    return D2G_OK;
 }
 
 }  // extern "C"

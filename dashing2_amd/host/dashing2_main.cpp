@@ -11,7 +11,12 @@
 #include "d2_options.h"
 #include "fmtfloat.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -94,6 +99,7 @@ void write_cached(const std::string &path, const double *sig, double card, size_
 
 // ------------------------------------------------------------------------------------ sketch
 void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
+    const double t_enter = now();
     const size_t N = o.paths.size(), S = o.sketchsize, m = d2g_oph_m(S);
     if (!N) die("Can't sketch empty path set");
     res.names = o.paths;                                                // fastxsketch.cpp:625
@@ -128,34 +134,69 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
         }
         if (b < todo.size()) groups.emplace_back(b, todo.size());
     }
+    const double t_setup = now();
+    // Host ingest pipeline: parser threads turn groups of files into packed run streams
+    // (d2g_seqpack); ONE device thread (this one) owns the GPU context and feeds K1 through a persistent
+    // d2g_sketcher, finalises (x87) and writes caches.  A bounded queue keeps memory in check.
     double t_parse = 0, t_gpu = 0, t_fin = 0;
     uint64_t total_bases = 0;
-#ifdef _OPENMP
-    #pragma omp parallel for schedule(dynamic) num_threads(std::min<unsigned>(o.nthreads(), 64))
-#endif
-    for (size_t g = 0; g < groups.size(); ++g) {
-        const size_t b = groups[g].first, e = groups[g].second, n = e - b;
-        d2g_seqpack *sp = nullptr;
-        check(ctx, d2g_seqpack_create(o.k, &sp), "d2g_seqpack_create");
-        const double t0 = now();
-        for (size_t t = b; t < e; ++t) {
-            const int rc = d2g_seqpack_add_path(sp, o.paths[todo[t]].c_str());
-            if (rc) die("Failed to open " + o.paths[todo[t]]);
+    d2g_sketcher *sk = nullptr;
+    check(ctx, d2g_sketcher_create(ctx, &sk), "d2g_sketcher_create");
+    struct Ready { size_t g; d2g_seqpack *sp; double tparse; };
+    std::deque<Ready> ready;
+    std::vector<d2g_seqpack *> pool;                                    // recycled packers (allocations kept)
+    std::mutex mu;
+    std::condition_variable cv_ready, cv_space;
+    std::atomic<size_t> next_group{0};
+    std::string parse_error;
+    const size_t nparsers = std::max<size_t>(1, std::min<size_t>({size_t(o.nthreads()), groups.size(), size_t(192)}));
+    const size_t max_ready = 2 * nparsers + 2;
+    std::vector<std::thread> parsers;
+    for (size_t t = 0; t < nparsers; ++t) parsers.emplace_back([&]() {
+        for (;;) {
+            const size_t g = next_group.fetch_add(1);
+            if (g >= groups.size()) break;
+            d2g_seqpack *sp = nullptr;
+            const double t0 = now();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!pool.empty()) { sp = pool.back(); pool.pop_back(); }
+            }
+            int rc = sp ? int(D2G_OK) : d2g_seqpack_create(o.k, &sp);
+            std::string bad;
+            for (size_t x = groups[g].first; rc == D2G_OK && x < groups[g].second; ++x) {
+                rc = d2g_seqpack_add_path(sp, o.paths[todo[x]].c_str());
+                if (rc) bad = o.paths[todo[x]];
+            }
+            if (rc == D2G_OK) (void)d2g_seqpack_packed_bytes(sp);            // pad now, off the device thread
+            std::unique_lock<std::mutex> lk(mu);
+            if (rc) { if (parse_error.empty()) parse_error = "Failed to open " + bad; d2g_seqpack_destroy(sp); sp = nullptr; }
+            cv_space.wait(lk, [&] { return ready.size() < max_ready; });
+            ready.push_back({g, sp, now() - t0});
+            cv_ready.notify_one();
         }
-        const double t1 = now();
-        std::vector<uint64_t> regs(n * m);
-        int rc;
-#ifdef _OPENMP
-        #pragma omp critical(d2g_device)
-#endif
+    });
+    std::vector<uint64_t> regs;
+    std::vector<double> sigs, cards;
+    for (size_t done = 0; done < groups.size(); ++done) {
+        Ready r;
         {
-            rc = d2g_oph_sketch(ctx, d2g_seqpack_packed(sp), d2g_seqpack_packed_bytes(sp), d2g_seqpack_run_start(sp),
-                                d2g_seqpack_run_len(sp), d2g_seqpack_nruns(sp), d2g_seqpack_genome_run_off(sp), n, o.k,
-                                o.canon, xormask, S, regs.data());
+            std::unique_lock<std::mutex> lk(mu);
+            cv_ready.wait(lk, [&] { return !ready.empty(); });
+            r = ready.front();
+            ready.pop_front();
+            cv_space.notify_one();
         }
-        check(ctx, rc, "d2g_oph_sketch");
+        if (!r.sp) continue;                                                // error recorded; drain the queue
+        const size_t b = groups[r.g].first, e = groups[r.g].second, n = e - b;
+        const double t1 = now();
+        regs.resize(n * m);
+        const int rc = d2g_sketcher_run(sk, d2g_seqpack_packed(r.sp), d2g_seqpack_packed_bytes(r.sp), d2g_seqpack_run_start(r.sp),
+                                        d2g_seqpack_run_len(r.sp), d2g_seqpack_nruns(r.sp), d2g_seqpack_genome_run_off(r.sp), n, o.k,
+                                        o.canon, xormask, S, regs.data());
+        check(ctx, rc, "d2g_sketcher_run");
         const double t2 = now();
-        std::vector<double> sigs(n * S), cards(n);
+        sigs.resize(n * S); cards.resize(n);
         check(ctx, d2g_oph_finalize(regs.data(), n, m, S, sigs.data(), cards.data(), 1), "d2g_oph_finalize");
         for (size_t t = b; t < e; ++t) {
             const size_t i = todo[t];
@@ -163,14 +204,19 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
             res.cardinalities[i] = cards[t - b];
             if (o.cache) write_cached(res.destination_files[i], &sigs[(t - b) * S], cards[t - b], S);
         }
-#ifdef _OPENMP
-        #pragma omp critical(d2g_stats)
-#endif
-        { t_parse += t1 - t0; t_gpu += t2 - t1; t_fin += now() - t2; total_bases += d2g_seqpack_nbases(sp); }
-        d2g_seqpack_destroy(sp);
+        t_parse += r.tparse; t_gpu += t2 - t1; t_fin += now() - t2; total_bases += d2g_seqpack_nbases(r.sp);
+        d2g_seqpack_clear(r.sp);
+        { std::lock_guard<std::mutex> lk(mu); pool.push_back(r.sp); }
     }
-    if (o.verbosity) std::fprintf(stderr, "[d2g] sketched %zu inputs (%" PRIu64 " ACGT bases): host parse %.3fs, device (H2D+K1+D2H) %.3fs, finalise %.3fs (thread-seconds)\n",
-                                  todo.size(), total_bases, t_parse, t_gpu, t_fin);
+    for (auto &th : parsers) th.join();
+    for (d2g_seqpack *p : pool) d2g_seqpack_destroy(p);
+    d2g_sketcher_destroy(sk);
+    const double t_pipe = now();
+    if (!parse_error.empty()) die(parse_error);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] sketched %zu inputs (%" PRIu64 " ACGT bases) in %zu groups: host parse %.3fs over %zu threads, "
+                                          "device thread: H2D+K1+D2H %.3fs, x87 finalise+cache %.3fs\n",
+                                  todo.size(), total_bases, groups.size(), t_parse, nparsers, t_gpu, t_fin);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] sketch wall: setup (stat, cache probe) %.3fs, ingest pipeline %.3fs\n", t_setup - t_enter, t_pipe - t_setup);
     // stacked output: [u64 N][u64 S][f64 card x N][f64 x N*S]   (sketch_core.cpp:130-140, fastxsketch.cpp:236-240)
     if (!o.outfile.empty()) {
         if (o.outfile == "-" || o.outfile == "/dev/stdout")
@@ -432,10 +478,12 @@ d2g_ctx *make_ctx(const Options &o) {
 }
 
 int sketch_main(int argc, char **argv) {                          // src/sketch_main.cpp:23-152
+    const double t_start = now();
     Options o;
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
     if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); sketch_usage(); return 1; }
     d2g_ctx *ctx = make_ctx(o);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] options + GPU context: %.3fs\n", now() - t_start);
     Result res;
     sketch_core(res, o, ctx);
     res.nq = o.nq;

@@ -122,6 +122,8 @@ int      d2g_epilogue_lut(size_t sketchsize, int measure, int k, int multiset_sp
 typedef struct d2g_seqpack d2g_seqpack;
 int  d2g_seqpack_create(int k, d2g_seqpack **out);
 void d2g_seqpack_destroy(d2g_seqpack *sp);
+/* forget the content but keep the allocations (pooling packers avoids page-fault storms) */
+void d2g_seqpack_clear(d2g_seqpack *sp);
 /* appends one genome from a file "line" (gz transparently via zlib). */
 int  d2g_seqpack_add_path(d2g_seqpack *sp, const char *path_line);
 /* appends one genome from an in-memory FASTA/FASTQ buffer */
@@ -167,6 +169,16 @@ uint64_t d2g_oph_plan_nbases(const d2g_oph_plan *plan);   /* total bases in the 
 int  d2g_oph_sketch_dev(d2g_ctx *ctx, const d2g_oph_plan *plan, const uint8_t *packed_dev,
                         int canon, uint64_t xormask, size_t sketchsize,
                         uint64_t *regs_out_dev /* [n][m] */, void *stream);
+
+/* persistent form for host ingest pipelines: grow-only device buffers, one pinned-arena upload of
+ * the launch tables per call, own stream.  Same arguments and result as d2g_oph_sketch. */
+typedef struct d2g_sketcher d2g_sketcher;
+int  d2g_sketcher_create(d2g_ctx *ctx, d2g_sketcher **out);
+void d2g_sketcher_destroy(d2g_sketcher *sk);
+int  d2g_sketcher_run(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes,
+                      const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
+                      const uint64_t *genome_run_off, size_t n, int k, int canon, uint64_t xormask,
+                      size_t sketchsize, uint64_t *regs_out /* host [n][m] */);
 
 /* ---- K2: dense all-pairs comparison -------------------------------------------
  * Replaces HOT LOOP B: emit_rectangular's row loops calling compare()

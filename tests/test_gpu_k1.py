@@ -147,3 +147,19 @@ print("OK")
 """ % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, D2G_MAX_RUN="4096"))
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_k1_sketcher_reuse(gpu_ctx, d2g, oracle):
+    """the persistent front end (d2g_sketcher) over groups of different shapes: buffers grow and are
+    reused, results stay bit-exact"""
+    sk = gpu_ctx.sketcher()
+    rng = np.random.default_rng(1)
+    for rnd, (k, S, lens) in enumerate([(31, 1024, [50000, 1200]), (21, 256, [300000, 7, 90000, 4000]), (31, 1024, [100]), (15, 1000, [20000] * 5)]):
+        fas = [synth.fasta_bytes(f"g{rnd}_{i}", synth.random_genome(100 * rnd + i, L)) for i, L in enumerate(lens)]
+        sp = d2g.SeqPack(k)
+        for f in fas:
+            sp.add_fastx(f)
+        regs = sk.run(sp, S)
+        for i, f in enumerate(fas):
+            np.testing.assert_array_equal(regs[i], oracle.sketch_buffer(f, k=k, S=S)[0], err_msg=f"round {rnd} genome {i}")
+    sk.close()
