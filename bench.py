@@ -55,12 +55,12 @@ def parse_args():
 
 
 def pmc_traffic(kernel_substr, wide_loads):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_b_pmc.json,
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_c_pmc.json,
     produced by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same
     command).  MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE
     tallies wide (16 B/lane) coalesced reads at half their bytes -> doubled for such kernels;
     narrow-load kernels are reported raw (uncalibrated per the guide)."""
-    path = os.path.join(ROOT, "profiles", "r01_b_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc.json")
     if not os.path.exists(path):
         return None
     try:
@@ -216,7 +216,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("k2_bitslice_kernel", False) if (cs.algo == D.CMP_BITSLICE and world == 1 and N == 10000 and S == 1024) else None,
-                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of the same workload, profiles/r01_b_pmc.json; dword loads: read side raw/uncalibrated",
+                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of the same workload, profiles/r01_c_pmc.json; dword loads: read side raw/uncalibrated",
                 "kernel": "k2_bitslice_kernel" if cs.algo == D.CMP_BITSLICE else "k2_direct_kernel",
                 "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
                 "prep_ms": prep_ms,
