@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libd2g.so")
+LIB_PATH = os.environ.get("D2G_LIB") or os.path.join(_HERE, "libd2g.so")
 _lib = None
 
 SIMILARITY, CONTAINMENT, SYMMETRIC_CONTAINMENT, POISSON_LLR, INTERSECTION, UNION_SIZE = range(6)
@@ -87,6 +87,10 @@ SIGNATURES = {
     "d2g_sketcher_create": (_int, [_vp, C.POINTER(_vp)]),
     "d2g_sketcher_destroy": (None, [_vp]),
     "d2g_sketcher_run": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, _vp]),
+    "d2g_sketcher_run_bmh": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, C.c_double, _vp, _vp]),
+    "d2g_bmh_sketch": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, C.c_double, _vp, _vp]),
+    "d2g_kmer_count": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, C.c_double, _vp, _vp, _sz, _vp]),
+    "d2g_bmh_from_weighted": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]),
     "d2g_ut_count": (_sz, [_sz, _sz, _sz]),
     "d2g_cmp_set_create_dev": (_int, [_vp, _vp, _sz, _sz, _int, _vp, C.POINTER(_vp)]),
     "d2g_cmp_set_create": (_int, [_vp, _vp, _sz, _sz, _int, C.POINTER(_vp)]),
@@ -347,6 +351,48 @@ class Context:
     def sketcher(self):
         return Sketcher(self)
 
+    # -- K3 (--multiset: exact k-mer counts -> BagMinHash) ---------------------
+    def bmh_sketch_seqpack(self, sp: "SeqPack", S, canon=True, xormask=0, count_threshold=0.0):
+        """-> (sig float64[n][S], total_weight float64[n])"""
+        packed, rs, rl, go = sp.arrays()
+        n = go.size - 1
+        sig = np.empty((n, S), np.float64)
+        tw = np.empty(n, np.float64)
+        self._check(lib().d2g_bmh_sketch(self._h, _np_ptr(packed), packed.size, _np_ptr(rs), _np_ptr(rl), rs.size,
+                                         _np_ptr(go), n, sp.k, int(canon), xormask, S, count_threshold,
+                                         _np_ptr(sig), _np_ptr(tw)))
+        return sig, tw
+
+    def kmer_count_seqpack(self, sp: "SeqPack", canon=True, xormask=0, count_threshold=0.0):
+        """-> list over genomes of (keys uint64[nd], counts uint32[nd]), each sorted by key"""
+        packed, rs, rl, go = sp.arrays()
+        n = go.size - 1
+        cap = int(sum(sp.nkmers(g) for g in range(n)))
+        keys = np.empty(max(cap, 1), np.uint64)
+        counts = np.empty(max(cap, 1), np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        self._check(lib().d2g_kmer_count(self._h, _np_ptr(packed), packed.size, _np_ptr(rs), _np_ptr(rl), rs.size,
+                                         _np_ptr(go), n, sp.k, int(canon), xormask, count_threshold,
+                                         _np_ptr(keys), _np_ptr(counts), cap, _np_ptr(off)))
+        out = []
+        for g in range(n):
+            k_, c_ = keys[int(off[g]):int(off[g + 1])], counts[int(off[g]):int(off[g + 1])]
+            o = np.argsort(k_, kind="stable")
+            out.append((k_[o].copy(), c_[o].copy()))
+        return out
+
+    def bmh_from_weighted(self, ids, weights, set_off, S):
+        """-> (sig float64[nsets][S], total_weight float64[nsets])"""
+        ids = np.ascontiguousarray(ids, np.uint64)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float64)
+        set_off = np.ascontiguousarray(set_off, np.uint64)
+        ns = set_off.size - 1
+        sig = np.empty((ns, S), np.float64)
+        tw = np.empty(ns, np.float64)
+        self._check(lib().d2g_bmh_from_weighted(self._h, _np_ptr(ids), None if w is None else _np_ptr(w), _np_ptr(set_off),
+                                                ns, S, _np_ptr(sig), _np_ptr(tw)))
+        return sig, tw
+
     def oph_plan(self, run_start, run_len, genome_run_off, k):
         run_start = np.ascontiguousarray(run_start, np.uint64)
         run_len = np.ascontiguousarray(run_len, np.uint32)
@@ -436,6 +482,16 @@ class Sketcher:
         self.ctx._check(lib().d2g_sketcher_run(self._h, _np_ptr(packed), packed.size, _np_ptr(rs), _np_ptr(rl), rs.size,
                                                _np_ptr(go), n, sp.k, int(canon), xormask, S, _np_ptr(regs)))
         return regs
+
+    def run_bmh(self, sp, S, canon=True, xormask=0, count_threshold=0.0):
+        packed, rs, rl, go = sp.arrays()
+        n = go.size - 1
+        sig = np.empty((n, S), np.float64)
+        tw = np.empty(n, np.float64)
+        self.ctx._check(lib().d2g_sketcher_run_bmh(self._h, _np_ptr(packed), packed.size, _np_ptr(rs), _np_ptr(rl), rs.size,
+                                                   _np_ptr(go), n, sp.k, int(canon), xormask, S, count_threshold,
+                                                   _np_ptr(sig), _np_ptr(tw)))
+        return sig, tw
 
     def close(self):
         if getattr(self, "_h", None):

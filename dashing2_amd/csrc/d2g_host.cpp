@@ -34,6 +34,7 @@ const char *d2g_strerror(int st) {
         case D2G_ERR_NOMEM: return "out of memory";
         case D2G_ERR_UNSUPPORTED: return "unsupported configuration for the MI355X hot path";
         case D2G_ERR_IO: return "I/O error";
+        case D2G_ERR_INTERNAL: return "internal invariant failed";
         default: return "unknown d2g status";
     }
 }

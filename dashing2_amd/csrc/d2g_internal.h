@@ -16,7 +16,7 @@ struct d2g_ctx {
     int num_cus = 0;
     std::string last_error;
     bool timing = false;
-    d2g_evlog ev_k1, ev_k2, ev_k2prep;
+    d2g_evlog ev_k1, ev_k2, ev_k2prep, ev_k3;
 };
 
 #define D2G_HIP(ctx, call)                                                            \

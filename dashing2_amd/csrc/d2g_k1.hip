@@ -14,7 +14,7 @@
 //     with global_atomic_umin_x2.  min is associative and commutative, so any split is exact.
 //   * packed bases are read straight from HBM/L2: lane l reads the 16..20 bytes of its chunk,
 //     consecutive lanes read consecutive 16-byte pieces (1 KiB per wave-instruction).
-#include "d2g_internal.h"
+#include "d2g_k1.h"
 #include <algorithm>
 #include <cstring>
 #include <new>
@@ -22,54 +22,19 @@
 
 namespace {
 
-constexpr int K1_THREADS = 256;
-constexpr int K1_CHUNK = 64;          // k-mers per lane-chunk
-constexpr int K1_CPT = 4;             // chunks per lane (16 measured 3% slower: fewer, longer workgroups)
-constexpr int K1_BLOCK_CHUNKS = K1_THREADS * K1_CPT;
-
-__device__ __forceinline__ uint64_t wang64(uint64_t k) {
-    k = ~k + (k << 21);
-    k ^= k >> 24;
-    k = k + (k << 3) + (k << 8);
-    k ^= k >> 14;
-    k = k + (k << 2) + (k << 4);
-    k ^= k >> 28;
-    k += k << 31;
-    return k;
-}
-
 struct K1Args {
-    const uint32_t *packed;        // 16 bases per dword, base p at bits [2(p%16), +2)
-    const uint64_t *run_start;
-    const uint32_t *run_len;
-    const uint64_t *run_chunk_off; // [nrun+1] exclusive prefix of chunks per run
-    const uint32_t *blk_genome;
-    const uint64_t *blk_chunk0;
-    const uint32_t *blk_nchunks;
-    const uint32_t *blk_run_lo;
-    const uint32_t *blk_run_hi;
+    KmerArgs km;
     uint64_t *regs_out;            // [n][m], pre-filled with ~0
     uint64_t xormask;
     uint64_t ophxor;
     uint32_t m;
-    int k;
-    int canon;
 };
-
-// funnel shift: low 32 bits of (hi:lo) >> sh, 0 <= sh < 32
-__device__ __forceinline__ uint32_t fsr(uint32_t hi, uint32_t lo, uint32_t sh) {
-    return __builtin_amdgcn_alignbit(hi, lo, sh);
-}
 
 template <bool POW2, bool USE_LDS>
 __global__ __launch_bounds__(K1_THREADS) void k1_oph_kernel(K1Args a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t lreg[];
     const int tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
-    const uint32_t g = a.blk_genome[b];
-    const uint64_t c0 = a.blk_chunk0[b];
-    const uint32_t nc = a.blk_nchunks[b];
-    const uint32_t rlo = a.blk_run_lo[b], rhi = a.blk_run_hi[b];
+    const uint32_t g = a.km.blk_genome[blockIdx.x];
     const uint32_t m = a.m;
     uint64_t *gout = a.regs_out + (size_t)g * m;
 
@@ -77,75 +42,17 @@ __global__ __launch_bounds__(K1_THREADS) void k1_oph_kernel(K1Args a) {
         for (uint32_t i = tid; i < m; i += K1_THREADS) lreg[i] = ~0ull;
         __syncthreads();
     }
-    const int k = a.k;
-    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    const int rcshift = 2 * (k - 1);
-    const bool canon = a.canon != 0;
     const uint64_t xormask = a.xormask, ophxor = a.ophxor;
-
-    for (int it = 0; it < K1_CPT; ++it) {
-        const uint32_t ci_blk = it * K1_THREADS + tid;
-        if (ci_blk >= nc) break;
-        const uint64_t c = c0 + ci_blk;
-        // run containing chunk c (runs of this block only: usually a single candidate)
-        uint32_t lo = rlo, hi = rhi;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (a.run_chunk_off[mid] <= c) lo = mid; else hi = mid;
+    d2g_for_each_kmer(a.km, [&](uint64_t x) {
+        const uint64_t id = wang64(wang64(x ^ xormask) ^ ophxor);
+        // Schismatic<uint32_t>::mod(size_t): argument narrowed to 32 bits (oph.h:184)
+        const uint32_t idx = POW2 ? ((uint32_t)id & (m - 1)) : ((uint32_t)id % m);
+        if (USE_LDS) {
+            if (id < lreg[idx]) atomicMin((unsigned long long *)&lreg[idx], (unsigned long long)id);
+        } else {
+            if (id < gout[idx]) atomicMin((unsigned long long *)&gout[idx], (unsigned long long)id);
         }
-        const uint64_t ci = c - a.run_chunk_off[lo];
-        const uint64_t nk = (uint64_t)a.run_len[lo] - k + 1;
-        const uint64_t p = a.run_start[lo] + ci * K1_CHUNK;       // first k-mer start (base index)
-        const uint64_t left = nk - ci * K1_CHUNK;
-        const int n = left < (uint64_t)K1_CHUNK ? (int)left : K1_CHUNK;
-
-        // warm-up window: bases [p, p+k-1) (<= 31 bases) as one 64-bit value
-        uint64_t fwd = 0, rc = 0;
-        {
-            const uint32_t *w = a.packed + (p >> 4);
-            const uint32_t sh = (uint32_t)(p & 15) * 2;
-            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-            uint64_t X = ((uint64_t)fsr(w2, w1, sh) << 32) | fsr(w1, w0, sh);
-            for (int j = 0; j < k - 1; ++j) {
-                const uint64_t cb = X & 3;
-                X >>= 2;
-                fwd = (fwd << 2) | cb;
-                rc = (rc >> 2) | ((3 - cb) << rcshift);
-            }
-        }
-        // main window: bases [q, q+64), q = p + k - 1, aligned into 4 dwords
-        uint32_t M0, M1, M2, M3;
-        {
-            const uint64_t q = p + (uint64_t)(k - 1);
-            const uint32_t *w = a.packed + (q >> 4);
-            const uint32_t sh = (uint32_t)(q & 15) * 2;
-            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-            M0 = fsr(w1, w0, sh); M1 = fsr(w2, w1, sh); M2 = fsr(w3, w2, sh); M3 = fsr(w4, w3, sh);
-        }
-#pragma unroll 1
-        for (int wi = 0; wi < 4; ++wi) {
-            const uint32_t W = wi == 0 ? M0 : wi == 1 ? M1 : wi == 2 ? M2 : M3;
-            const int ebase = wi * 16;
-            if (ebase >= n) break;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint64_t cb = (W >> (2 * e)) & 3u;
-                fwd = ((fwd << 2) | cb) & kmask;
-                rc = (rc >> 2) | ((3 - cb) << rcshift);
-                if (ebase + e < n) {
-                    const uint64_t x = canon ? (fwd < rc ? fwd : rc) : fwd;
-                    const uint64_t id = wang64(wang64(x ^ xormask) ^ ophxor);
-                    // Schismatic<uint32_t>::mod(size_t): argument narrowed to 32 bits (oph.h:184)
-                    const uint32_t idx = POW2 ? ((uint32_t)id & (m - 1)) : ((uint32_t)id % m);
-                    if (USE_LDS) {
-                        if (id < lreg[idx]) atomicMin((unsigned long long *)&lreg[idx], (unsigned long long)id);
-                    } else {
-                        if (id < gout[idx]) atomicMin((unsigned long long *)&gout[idx], (unsigned long long)id);
-                    }
-                }
-            }
-        }
-    }
+    });
     if (USE_LDS) {
         __syncthreads();
         for (uint32_t i = tid; i < m; i += K1_THREADS) {
@@ -164,21 +71,6 @@ static int upload(d2g_ctx *ctx, const std::vector<T> &h, T **d) {
 
 }  // namespace
 
-struct d2g_oph_plan {
-    d2g_ctx *ctx = nullptr;
-    int k = 0;
-    size_t n = 0, nrun = 0, nblk = 0;
-    uint64_t nkmers = 0, nbases = 0;
-    uint64_t *d_run_start = nullptr;
-    uint32_t *d_run_len = nullptr;
-    uint64_t *d_run_chunk_off = nullptr;
-    uint32_t *d_blk_genome = nullptr;
-    uint64_t *d_blk_chunk0 = nullptr;
-    uint32_t *d_blk_nchunks = nullptr;
-    uint32_t *d_blk_run_lo = nullptr;
-    uint32_t *d_blk_run_hi = nullptr;
-};
-
 extern "C" {
 
 void d2g_oph_plan_destroy(d2g_oph_plan *p) {
@@ -195,14 +87,7 @@ uint64_t d2g_oph_plan_nbases(const d2g_oph_plan *p) { return p ? p->nbases : 0; 
 
 }  // extern "C"
 
-namespace {
-// host-side launch plan: 64-k-mer chunks per run, <= K1_BLOCK_CHUNKS chunks of one genome per workgroup
-struct PlanHost {
-    std::vector<uint64_t> chunk_off, bc0;
-    std::vector<uint32_t> bg, bn, blo, bhi;
-    uint64_t nkmers = 0, nbases = 0;
-};
-int build_plan_host(d2g_ctx *ctx, const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, PlanHost &p) {
+int d2g_build_plan_host(d2g_ctx *ctx, const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, PlanHost &p) {
     D2G_CHECK(ctx, genome_run_off && (nrun == 0 || run_len), "oph plan: null table");
     if (k < 1 || k > 32) { ctx->last_error = "k must be in [1,32] (exact 2-bit encoding path)"; return D2G_ERR_UNSUPPORTED; }
     D2G_CHECK(ctx, genome_run_off[n] == nrun, "oph plan: genome_run_off[n] != nrun");
@@ -233,6 +118,7 @@ int build_plan_host(d2g_ctx *ctx, const uint32_t *run_len, size_t nrun, const ui
     return D2G_OK;
 }
 
+namespace {
 int launch_k1(d2g_ctx *ctx, K1Args a, size_t nblk, size_t m, hipStream_t s) {
     const bool pow2 = (m & (m - 1)) == 0;
     const size_t lds = m * sizeof(uint64_t);
@@ -248,27 +134,7 @@ int launch_k1(d2g_ctx *ctx, K1Args a, size_t nblk, size_t m, hipStream_t s) {
     return D2G_OK;
 }
 
-template <class T> int grow(d2g_ctx *ctx, T **p, size_t *cap, size_t need) {
-    if (need <= *cap) return D2G_OK;
-    (void)hipFree(*p); *p = nullptr; *cap = 0;
-    const size_t ncap = need + need / 4 + 4096;
-    D2G_HIP(ctx, hipMalloc((void **)p, ncap * sizeof(T)));
-    *cap = ncap;
-    return D2G_OK;
-}
 }  // namespace
-
-// Host ingest feeds K1 in groups of inputs; re-allocating device buffers and uploading eight
-// small tables per group costs ~20 ms, the kernel ~0.1 ms.  The sketcher keeps grow-only device
-// buffers and ships all launch tables in ONE copy from a pinned arena.
-struct d2g_sketcher {
-    d2g_ctx *ctx = nullptr;
-    hipStream_t stream = nullptr;
-    uint8_t *d_packed = nullptr; size_t cap_packed = 0;
-    uint64_t *d_regs = nullptr;  size_t cap_regs = 0;      // in u64
-    uint8_t *d_arena = nullptr, *h_arena = nullptr; size_t cap_arena = 0;
-    uint8_t *h_stage = nullptr; size_t cap_stage = 0;      // pinned staging of the packed stream
-};
 
 extern "C" {
 
@@ -278,7 +144,7 @@ int d2g_oph_plan_create(d2g_ctx *ctx, const uint64_t *run_start, const uint32_t 
     *out = nullptr;
     D2G_CHECK(ctx, nrun == 0 || run_start, "d2g_oph_plan_create: null table");
     PlanHost ph;
-    if (int rc = build_plan_host(ctx, run_len, nrun, genome_run_off, n, k, ph)) return rc;
+    if (int rc = d2g_build_plan_host(ctx, run_len, nrun, genome_run_off, n, k, ph)) return rc;
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     d2g_oph_plan *p = new (std::nothrow) d2g_oph_plan();
     if (!p) return D2G_ERR_NOMEM;
@@ -313,12 +179,9 @@ int d2g_oph_sketch_dev(d2g_ctx *ctx, const d2g_oph_plan *plan, const uint8_t *pa
     if (plan->nblk == 0) return D2G_OK;
     D2G_CHECK(ctx, packed_dev != nullptr, "null packed stream");
     K1Args a;
-    a.packed = reinterpret_cast<const uint32_t *>(packed_dev);
-    a.run_start = plan->d_run_start; a.run_len = plan->d_run_len; a.run_chunk_off = plan->d_run_chunk_off;
-    a.blk_genome = plan->d_blk_genome; a.blk_chunk0 = plan->d_blk_chunk0; a.blk_nchunks = plan->d_blk_nchunks;
-    a.blk_run_lo = plan->d_blk_run_lo; a.blk_run_hi = plan->d_blk_run_hi;
+    a.km = d2g_plan_args(plan, packed_dev, canon);
     a.regs_out = regs_out_dev; a.xormask = xormask; a.ophxor = d2g_oph_xor_const();
-    a.m = (uint32_t)m; a.k = plan->k; a.canon = canon;
+    a.m = (uint32_t)m;
     return launch_k1(ctx, a, plan->nblk, m, s);
 }
 
@@ -367,6 +230,7 @@ void d2g_sketcher_destroy(d2g_sketcher *sk) {
     (void)hipFree(sk->d_packed); (void)hipFree(sk->d_regs); (void)hipFree(sk->d_arena);
     if (sk->h_arena) (void)hipHostFree(sk->h_arena);
     if (sk->h_stage) (void)hipHostFree(sk->h_stage);
+    if (sk->k3) d2g_k3_state_destroy(sk->k3);
     if (sk->stream) (void)hipStreamDestroy(sk->stream);
     delete sk;
 }
@@ -391,18 +255,42 @@ int d2g_sketcher_run(d2g_sketcher *sk, const uint8_t *packed, size_t packed_byte
     d2g_ctx *ctx = sk->ctx;
     D2G_CHECK(ctx, sketchsize >= 1 && sketchsize < (1ull << 31), "sketchsize out of range");
     D2G_CHECK(ctx, regs_out != nullptr || n == 0, "null regs_out");
+    K1Args a;
+    size_t nblk = 0;
+    if (int rc = d2g_sketcher_stage(sk, packed, packed_bytes, run_start, run_len, nrun, genome_run_off, n, k, canon,
+                                    &a.km, &nblk, nullptr)) return rc;
+    const size_t m = d2g_oph_m(sketchsize);
+    if (int rc = d2g_grow(ctx, &sk->d_regs, &sk->cap_regs, std::max<size_t>(n * m, 1))) return rc;
+    hipStream_t s = sk->stream;
+    D2G_HIP(ctx, hipMemsetAsync(sk->d_regs, 0xFF, std::max<size_t>(n * m, 1) * sizeof(uint64_t), s));   // registers_ = T(-1): oph.h:147,233
+    if (nblk) {
+        a.regs_out = sk->d_regs; a.xormask = xormask; a.ophxor = d2g_oph_xor_const();
+        a.m = (uint32_t)m;
+        if (int rc = launch_k1(ctx, a, nblk, m, s)) return rc;
+    }
+    if (n) D2G_HIP(ctx, hipMemcpyAsync(regs_out, sk->d_regs, n * m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipStreamSynchronize(s));
+    return D2G_OK;
+}
+
+}  // extern "C"
+
+int d2g_sketcher_stage(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
+                       const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
+                       KmerArgs *out, size_t *nblk_out, PlanHost *ph_out) {
+    d2g_ctx *ctx = sk->ctx;
     D2G_CHECK(ctx, nrun == 0 || (run_start && packed), "null input");
-    PlanHost ph;
-    if (int rc = build_plan_host(ctx, run_len, nrun, genome_run_off, n, k, ph)) return rc;
+    PlanHost ph_local;
+    PlanHost &ph = ph_out ? *ph_out : ph_local;
+    if (int rc = d2g_build_plan_host(ctx, run_len, nrun, genome_run_off, n, k, ph)) return rc;
     if (nrun) {
         uint64_t maxend = 0;
         for (size_t r = 0; r < nrun; ++r) maxend = std::max<uint64_t>(maxend, run_start[r] + run_len[r]);
         D2G_CHECK(ctx, packed_bytes >= (maxend + 3) / 4 + 64, "packed stream lacks the 64-byte tail pad");
     }
     D2G_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t m = d2g_oph_m(sketchsize), nblk = ph.bg.size();
-    if (int rc = grow(ctx, &sk->d_packed, &sk->cap_packed, std::max<size_t>(packed_bytes, 4))) return rc;
-    if (int rc = grow(ctx, &sk->d_regs, &sk->cap_regs, std::max<size_t>(n * m, 1))) return rc;
+    const size_t nblk = ph.bg.size();
+    if (int rc = d2g_grow(ctx, &sk->d_packed, &sk->cap_packed, std::max<size_t>(packed_bytes, 4))) return rc;
     // arena layout (256-byte aligned pieces)
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     size_t off = 0;
@@ -446,25 +334,16 @@ int d2g_sketcher_run(d2g_sketcher *sk, const uint8_t *packed, size_t packed_byte
         std::memcpy(sk->h_stage, packed, packed_bytes);
         D2G_HIP(ctx, hipMemcpyAsync(sk->d_packed, sk->h_stage, packed_bytes, hipMemcpyHostToDevice, s));
     }
-    D2G_HIP(ctx, hipMemsetAsync(sk->d_regs, 0xFF, std::max<size_t>(n * m, 1) * sizeof(uint64_t), s));   // registers_ = T(-1): oph.h:147,233
-    if (nblk) {
-        K1Args a;
-        a.packed = reinterpret_cast<const uint32_t *>(sk->d_packed);
-        a.run_start = reinterpret_cast<const uint64_t *>(sk->d_arena + o_rs);
-        a.run_len = reinterpret_cast<const uint32_t *>(sk->d_arena + o_rl);
-        a.run_chunk_off = reinterpret_cast<const uint64_t *>(sk->d_arena + o_co);
-        a.blk_genome = reinterpret_cast<const uint32_t *>(sk->d_arena + o_bg);
-        a.blk_chunk0 = reinterpret_cast<const uint64_t *>(sk->d_arena + o_c0);
-        a.blk_nchunks = reinterpret_cast<const uint32_t *>(sk->d_arena + o_bn);
-        a.blk_run_lo = reinterpret_cast<const uint32_t *>(sk->d_arena + o_lo);
-        a.blk_run_hi = reinterpret_cast<const uint32_t *>(sk->d_arena + o_hi);
-        a.regs_out = sk->d_regs; a.xormask = xormask; a.ophxor = d2g_oph_xor_const();
-        a.m = (uint32_t)m; a.k = k; a.canon = canon;
-        if (int rc = launch_k1(ctx, a, nblk, m, s)) return rc;
-    }
-    if (n) D2G_HIP(ctx, hipMemcpyAsync(regs_out, sk->d_regs, n * m * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    D2G_HIP(ctx, hipStreamSynchronize(s));
+    out->packed = reinterpret_cast<const uint32_t *>(sk->d_packed);
+    out->run_start = reinterpret_cast<const uint64_t *>(sk->d_arena + o_rs);
+    out->run_len = reinterpret_cast<const uint32_t *>(sk->d_arena + o_rl);
+    out->run_chunk_off = reinterpret_cast<const uint64_t *>(sk->d_arena + o_co);
+    out->blk_genome = reinterpret_cast<const uint32_t *>(sk->d_arena + o_bg);
+    out->blk_chunk0 = reinterpret_cast<const uint64_t *>(sk->d_arena + o_c0);
+    out->blk_nchunks = reinterpret_cast<const uint32_t *>(sk->d_arena + o_bn);
+    out->blk_run_lo = reinterpret_cast<const uint32_t *>(sk->d_arena + o_lo);
+    out->blk_run_hi = reinterpret_cast<const uint32_t *>(sk->d_arena + o_hi);
+    out->k = k; out->canon = canon;
+    *nblk_out = nblk;
     return D2G_OK;
 }
-
-}  // extern "C"

@@ -1,0 +1,870 @@
+// d2g_k3_bmh.hip -- K3: the --multiset sketch path on gfx950.
+//
+//   R11  exact k-mer counting      reference src/counter.h:68-77 (Counter::add(uint64_t)), finalize 118-138,
+//                                  driver src/fastxsketch.cpp:425-445
+//   R12  BagMinHash                sketch::BagMinHash2<double> (ABSENT dnbaker/sketch bmh.h; parity unpinned);
+//                                  restated from Ertl, KDD 2018 under the "BMH-D2G" spec of DESIGN.md
+//
+// The reference counts with one robin-hood hash map per thread and feeds (kmer, count) to the
+// sketch one at a time.  Here:
+//   1. k3_hist / k3_scan / k3_scatter  : every masked k-mer key = Wang(kmer ^ XORMASK) of a genome is
+//      multi-split by its top bits into <= 4096 buckets of ~1-2 K keys (LDS-aggregated histogram,
+//      one global reservation per (workgroup, bucket)); k-mers are re-generated from the packed
+//      bases in each pass instead of being stored (generation is ~100 VALU slots, a store+load is 16 B).
+//   2. k3_bmh_seed / k3_bmh_main       : one workgroup per bucket counts it exactly in a 4096-slot LDS
+//      open-addressing table (ds_cmpst_b64 claim + ds_add), then every occupied slot IS one
+//      (key, count) element and its owner lane runs the BagMinHash Poisson-process tree for it,
+//      depth-first with a private stack, against a certified upper bound of the genome's current
+//      maximum register.  Registers live in HBM/L2 as the bit patterns of non-negative doubles and
+//      are lowered with global_atomic_umin_x2 behind a read filter.
+//      min is order-free and pruning by ANY valid bound only drops points that cannot win, so the
+//      result is bit-identical to the time-ordered sequential algorithm (oracle/d2_bmh_oracle.c).
+//      The first non-empty bucket of each genome is processed alone first ("seed") with iterative
+//      deepening on a guessed bound so that every later workgroup starts from a finite bound.
+#include "d2g_k1.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int K3_THREADS = 256;
+constexpr int K3_MAXBBITS = 12;
+constexpr int K3_MAXB = 1 << K3_MAXBBITS;   // buckets per genome (LDS histogram)
+constexpr int K3_TAB = 4096;                // LDS count-table slots
+constexpr int K3_ROUND_KEYS = 2048;         // keys one table round is sized for (load <= 0.5 + duplicates)
+constexpr int K3_TARGET = 1024;             // mean keys per bucket aimed for
+constexpr uint64_t K3_EMPTY = ~0ull;
+constexpr uint64_t BMH_LEVEL_MAX = 0x4340000000000000ull;     // bit pattern of 2^53
+constexpr uint64_t BMH_INF = 0x7FF0000000000000ull;
+constexpr int BMH_STACK = 72;
+constexpr uint32_t K3_HLDS_MAX = 8192;      // registers kept in LDS by the seed workgroup
+
+struct K3Args {
+    KmerArgs km;
+    uint64_t xormask;
+    const uint32_t *g_bbits;   // [n]   log2(#buckets) of genome g
+    const uint32_t *g_boff;    // [n+1] first global bucket of genome g
+    uint32_t *bucket_cnt;      // [TB]
+    uint64_t *bucket_off;      // [TB+1] exclusive prefix of bucket_cnt
+    uint64_t *cursor;          // [TB]   scatter cursors (copy of bucket_off)
+    uint64_t *keys;            // [total k-mers] bucketed keys
+    uint32_t TB;
+};
+
+__device__ __forceinline__ uint32_t bucket_of(uint64_t key, uint32_t bb) { return bb ? (uint32_t)(key >> (64 - bb)) : 0u; }
+
+__global__ __launch_bounds__(K1_THREADS) void k3_hist_kernel(K3Args a) {
+    __shared__ uint32_t hist[K3_MAXB];
+    const int tid = threadIdx.x;
+    const uint32_t g = a.km.blk_genome[blockIdx.x];
+    const uint32_t bb = a.g_bbits[g], B = 1u << bb, boff = a.g_boff[g];
+    for (uint32_t i = tid; i < B; i += K1_THREADS) hist[i] = 0;
+    __syncthreads();
+    const uint64_t xormask = a.xormask;
+    d2g_for_each_kmer(a.km, [&](uint64_t x) {
+        const uint64_t key = wang64(x ^ xormask);              // maskfn: src/enums.h:136-140
+        atomicAdd(&hist[bucket_of(key, bb)], 1u);
+    });
+    __syncthreads();
+    for (uint32_t i = tid; i < B; i += K1_THREADS)
+        if (hist[i]) atomicAdd(&a.bucket_cnt[boff + i], hist[i]);
+}
+
+// exclusive prefix of bucket_cnt (single workgroup; TB <= a few million)
+__global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
+    __shared__ uint64_t part[1024];
+    const uint32_t tid = threadIdx.x, TB = a.TB;
+    const uint32_t per = (TB + 1023) / 1024;
+    const uint32_t lo = min(TB, tid * per), hi = min(TB, lo + per);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += a.bucket_cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const uint64_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t i = lo; i < hi; ++i) {
+        a.bucket_off[i] = run; a.cursor[i] = run;
+        run += a.bucket_cnt[i];
+    }
+    if (tid == 1023) a.bucket_off[TB] = part[1023];
+}
+
+__global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
+    __shared__ uint32_t cnt[K3_MAXB];
+    __shared__ uint64_t base[K3_MAXB];
+    const int tid = threadIdx.x;
+    const uint32_t g = a.km.blk_genome[blockIdx.x];
+    const uint32_t bb = a.g_bbits[g], B = 1u << bb, boff = a.g_boff[g];
+    for (uint32_t i = tid; i < B; i += K1_THREADS) cnt[i] = 0;
+    __syncthreads();
+    const uint64_t xormask = a.xormask;
+    d2g_for_each_kmer(a.km, [&](uint64_t x) { atomicAdd(&cnt[bucket_of(wang64(x ^ xormask), bb)], 1u); });
+    __syncthreads();
+    for (uint32_t i = tid; i < B; i += K1_THREADS) {
+        const uint32_t c = cnt[i];
+        base[i] = c ? atomicAdd((unsigned long long *)&a.cursor[boff + i], (unsigned long long)c) : 0;
+        cnt[i] = 0;
+    }
+    __syncthreads();
+    d2g_for_each_kmer(a.km, [&](uint64_t x) {
+        const uint64_t key = wang64(x ^ xormask);
+        const uint32_t b = bucket_of(key, bb);
+        const uint32_t r = atomicAdd(&cnt[b], 1u);
+        a.keys[base[b] + r] = key;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact counting of one bucket round into the LDS table
+// ---------------------------------------------------------------------------------------------
+struct CountTab {
+    uint64_t *key;          // [K3_TAB]
+    uint32_t *cnt;          // [K3_TAB]
+    uint32_t *ones;         // count of the key == K3_EMPTY (cannot live in the table)
+};
+
+__device__ __forceinline__ uint32_t tab_hash(uint64_t key) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 52); }
+
+// keys of round r of R (R a power of two: low key bits select the round); returns false on overflow
+__device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, uint32_t R, uint32_t r) {
+    const int tid = threadIdx.x;
+    for (int s = tid; s < K3_TAB; s += K3_THREADS) { t.key[s] = K3_EMPTY; t.cnt[s] = 0; }
+    if (tid == 0) *t.ones = 0;
+    __syncthreads();
+    bool ok = true;
+    for (uint64_t i = tid; i < n; i += K3_THREADS) {
+        const uint64_t key = kb[i];
+        if (R > 1 && ((uint32_t)key & (R - 1)) != r) continue;
+        if (key == K3_EMPTY) { atomicAdd(t.ones, 1u); continue; }
+        uint32_t s = tab_hash(key);
+        int probes = 0;
+        for (;;) {
+            const uint64_t cur = t.key[s];
+            if (cur == key) break;
+            if (cur == K3_EMPTY) {
+                const uint64_t prev = atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)K3_EMPTY, (unsigned long long)key);
+                if (prev == K3_EMPTY || prev == key) break;
+            }
+            s = (s + 1) & (K3_TAB - 1);
+            if (++probes >= K3_TAB) { ok = false; break; }
+        }
+        if (!ok) break;
+        atomicAdd(&t.cnt[s], 1u);
+    }
+    return !__syncthreads_or(!ok);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BMH-D2G process machinery (spec: DESIGN.md; sequential twin: oracle/d2_bmh_oracle.c)
+// ---------------------------------------------------------------------------------------------
+struct Proc {
+    uint64_t p, q;       // weight-level range [V(p), V(q)), double bit patterns
+    double x;            // time of the current point
+    uint64_t rng;        // wyhash64_stateless state (in-tree twin: reference src/ssi.h:26-36)
+    uint32_t i;          // register of the current point
+    uint32_t pad;
+};
+
+__device__ __forceinline__ double V(uint64_t l) { return __longlong_as_double((long long)l); }
+__device__ __forceinline__ uint64_t dbits(double d) { return (uint64_t)__double_as_longlong(d); }
+
+__device__ __forceinline__ uint64_t wy_next(uint64_t &s) {
+    s += 0x60bee2bee120fc15ull;
+    const uint64_t a = s ^ 0xe7037ed1a0b428dbull;
+    return (a * s) ^ __umul64hi(a, s);
+}
+
+// natural log on [2^-53, 1] in plain IEEE double ops (no FMA contraction: -ffp-contract=off), the
+// same operation sequence as d2o_dlog
+__device__ __forceinline__ double dlog(double u) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const uint64_t b = dbits(u);
+    int e = (int)(b >> 52) - 1023;
+    double m = V((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double R = z * (Lg1 + z * (Lg2 + z * (Lg3 + z * (Lg4 + z * (Lg5 + z * (Lg6 + z * Lg7))))));
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// advance to the process's next point; false = certainly later than `bound` (drop the process).
+// Early-out: -log(u) >= 1 - u, so (1-u)/width > bound already proves x > bound without the log
+// and the division (the 1e-9 margin dwarfs every rounding involved).
+__device__ __forceinline__ bool proc_next(Proc &P, uint32_t m, double bound) {
+    const double width = V(P.q) - V(P.p);
+    const uint64_t r1 = wy_next(P.rng);
+    const double uu = (double)((r1 >> 11) + 1) * 0x1p-53;            // (0, 1]
+    if ((1.0 - uu) > bound * width * 1.000000001) return false;
+    const double E = -dlog(uu);
+    P.x = P.x + E / width;
+    const uint64_t r2 = wy_next(P.rng);
+    P.i = (uint32_t)__umul64hi(r2, (uint64_t)m);
+    return P.x <= bound;
+}
+
+__device__ __forceinline__ void reg_min(uint64_t *h, uint32_t i, double x) {
+    const uint64_t xb = dbits(x);
+    if (xb < h[i]) atomicMin((unsigned long long *)&h[i], (unsigned long long)xb);
+}
+
+// locate P's current point: narrow P to the half that holds it, level by level; the other half
+// becomes a fresh process starting at P.x.  Pushes what may still matter.
+__device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk, int &sp) {
+    bool counted = false, relevant = true;
+    for (;;) {
+        if (!counted && V(P.q) <= w) { reg_min(h, P.i, P.x); counted = true; }
+        if (P.q - P.p <= 1) break;
+        const uint64_t r = P.p + ((P.q - P.p) >> 1);
+        const uint64_t rb = wy_next(P.rng);
+        const double ub = (double)(rb >> 11) * 0x1p-53;              // [0, 1)
+        const double vp = V(P.p), vq = V(P.q), vr = V(r);
+        const bool left = ub * (vq - vp) < (vr - vp);
+        Proc S;
+        S.x = P.x; S.i = 0; S.pad = 0;
+        S.rng = d ^ (r * 0x9E3779B97F4A7C15ull) ^ 0xD6E8FEB86659FD93ull;
+        if (left) { S.p = r; S.q = P.q; P.q = r; }
+        else      { S.p = P.p; S.q = r; P.p = r; }
+        if (V(S.p) < w) {
+            if (proc_next(S, m, bound)) stk[sp++] = S;
+        }
+        if (!(V(P.p) < w)) { relevant = false; break; }
+    }
+    if (relevant) {
+        if (proc_next(P, m, bound)) stk[sp++] = P;
+    }
+}
+
+// one lane's walk over its elements.  Elements are the occupied table slots s = tid, tid+256, ...
+// (plus the all-ones key as pseudo-slot K3_TAB for lane 0).
+struct Lane {
+    int slot;            // next table slot to look at
+    int sp;              // stack depth
+    uint64_t d;          // current element
+    double w;
+};
+
+__device__ __forceinline__ bool lane_fetch(Lane &L, const CountTab &t, double thr, double &tw) {
+    while (L.slot <= K3_TAB) {
+        const int s = L.slot;
+        L.slot += K3_THREADS;
+        uint32_t c; uint64_t key;
+        if (s < K3_TAB) { c = t.cnt[s]; key = t.key[s]; }
+        else { c = *t.ones; key = K3_EMPTY; }                       // s == K3_TAB: only lane 0 gets here
+        if (c && (double)c > thr) {                                  // counter.h:123: pair.second > threshold
+            L.d = key; L.w = (double)c;
+            tw += L.w;
+            return true;
+        }
+    }
+    return false;
+}
+
+// one unit of work; false when the lane has nothing left
+__device__ __forceinline__ bool lane_step(Lane &L, const CountTab &t, double thr, uint32_t m, double bound, uint64_t *h,
+                                          Proc *stk, double &tw, bool count_tw) {
+    if (L.sp == 0) {
+        double dummy = 0.;
+        if (!lane_fetch(L, t, thr, count_tw ? tw : dummy)) return false;
+        Proc P;
+        P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = L.d; P.i = 0; P.pad = 0;
+        if (proc_next(P, m, bound)) stk[L.sp++] = P;
+        return true;
+    }
+    const Proc P = stk[--L.sp];
+    if (P.x <= bound) bmh_locate(P, L.d, L.w, m, bound, h, stk, L.sp);
+    return true;
+}
+
+__device__ uint64_t block_hmax(const uint64_t *h, uint32_t m, uint64_t *red) {
+    const int tid = threadIdx.x;
+    uint64_t v = 0;
+    for (uint32_t i = tid; i < m; i += K3_THREADS) { const uint64_t x = h[i]; v = x > v ? x : v; }
+    for (int o = 32; o; o >>= 1) { const uint64_t x = __shfl_xor(v, o); v = x > v ? x : v; }
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    v = red[0];
+    for (int k = 1; k < K3_THREADS / 64; ++k) v = red[k] > v ? red[k] : v;
+    return v;
+}
+
+__device__ double block_sum(double v, double *red) {
+    const int tid = threadIdx.x;
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+    for (int k = 1; k < K3_THREADS / 64; ++k) s += red[k];
+    return s;
+}
+
+struct BmhArgs {
+    const uint64_t *keys;
+    const uint64_t *bucket_off;
+    const uint32_t *g_boff;
+    uint32_t n;              // genomes
+    uint32_t TB;
+    uint32_t m;
+    double thr;
+    uint64_t *h;             // [n][m] register bit patterns, +inf initially
+    uint64_t *hbound;        // [n] certified upper bound of max(h[g]) (bit pattern), +inf initially
+    double *tw;              // [n] total weight
+    uint32_t *seed_bucket;   // [n] unit the seed workgroup processed: bucket (or ~0: no element) ...
+    uint32_t *seed_round;    // [n] ... and round
+    int *status;
+    // optional R11 output (k3_count_kernel): distinct (key,count) written in place of the bucket
+    uint64_t *out_keys; uint32_t *out_counts; uint32_t *bucket_nd;
+};
+
+struct SharedK3 {
+    uint64_t key[K3_TAB];
+    uint32_t cnt[K3_TAB];
+    uint64_t red[8];
+    uint32_t ones;
+    uint32_t misc;
+};
+
+__device__ __forceinline__ uint32_t genome_of_bucket(const uint32_t *g_boff, uint32_t n, uint32_t tb) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_boff[mid] <= tb) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// seed: the first (bucket, round) unit of genome g that holds an element passing the count
+// threshold is processed alone, with iterative deepening on a guessed bound; it leaves a finite
+// certified bound behind (or no element at all exists and nobody needs one)
+__global__ __launch_bounds__(K3_THREADS) void k3_bmh_seed_kernel(BmhArgs a) {
+    __shared__ SharedK3 sh;
+    extern __shared__ __attribute__((aligned(16))) uint64_t hlds[];
+    const int tid = threadIdx.x;
+    const uint32_t g = blockIdx.x, m = a.m;
+    const uint32_t b0 = a.g_boff[g], b1 = a.g_boff[g + 1];
+    uint64_t *hg = a.h + (size_t)g * m;
+    const bool use_lds = m <= K3_HLDS_MAX;
+    uint64_t *h = use_lds ? hlds : hg;
+    for (uint32_t i = tid; i < m; i += K3_THREADS) { h[i] = BMH_INF; if (use_lds) hg[i] = BMH_INF; }
+    __syncthreads();
+    const CountTab t{sh.key, sh.cnt, &sh.ones};
+    Proc stk[BMH_STACK];
+    double tw = 0.;
+    uint32_t seed_tb = ~0u, seed_r = 0;
+    for (uint32_t tb = b0; tb < b1 && seed_tb == ~0u; ++tb) {
+        const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
+        if (nk == 0) continue;
+        const uint64_t *kb = a.keys + o0;
+        uint32_t R = 1;
+        while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
+        for (uint32_t r = 0; r < R; ++r) {
+            if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
+            // weight of this unit's elements -> first guess of the bound: registers fill at rate W/m each
+            double wsum = 0.;
+            for (int s = tid; s < K3_TAB; s += K3_THREADS) { const uint32_t c = sh.cnt[s]; if (c && (double)c > a.thr) wsum += (double)c; }
+            if (tid == 0 && sh.ones && (double)sh.ones > a.thr) wsum += (double)sh.ones;
+            wsum = block_sum(wsum, reinterpret_cast<double *>(sh.red));
+            if (!(wsum > 0.)) continue;
+            seed_tb = tb; seed_r = r; tw = wsum;
+            double beta = 2.0 * (double)m * ((double)__logf((float)m) + 1.0) / wsum;
+            for (;;) {
+                Lane L{tid, 0, 0, 0.};
+                double unused = 0.;
+                uint64_t hm = block_hmax(h, m, sh.red);
+                for (;;) {
+                    const double live = V(hm);
+                    const double bound = live < beta ? live : beta;
+                    const bool more = lane_step(L, t, a.thr, m, bound, h, stk, unused, false);
+                    if (!__syncthreads_or(more)) break;
+                    hm = block_hmax(h, m, sh.red);
+                }
+                hm = block_hmax(h, m, sh.red);
+                if (V(hm) <= beta) break;          // every dropped point was later than the final maximum: exact
+                beta *= 16.0;
+            }
+            break;
+        }
+    }
+    const uint64_t hm = block_hmax(h, m, sh.red);
+    if (use_lds) for (uint32_t i = tid; i < m; i += K3_THREADS) hg[i] = h[i];
+    if (tid == 0) { a.hbound[g] = hm; a.tw[g] = tw; a.seed_bucket[g] = seed_tb; a.seed_round[g] = seed_r; }
+}
+
+// all other units: bound = the genome's certified bound at workgroup start
+__global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
+    __shared__ SharedK3 sh;
+    const int tid = threadIdx.x;
+    const uint32_t tb = blockIdx.x, m = a.m;
+    const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
+    if (nk == 0) return;
+    const uint32_t g = genome_of_bucket(a.g_boff, a.n, tb);
+    const uint32_t seed_tb = a.seed_bucket[g], seed_r = a.seed_round[g];
+    if (seed_tb == ~0u) return;                      // no element of this genome passes the threshold
+    uint64_t *h = a.h + (size_t)g * m;
+    const CountTab t{sh.key, sh.cnt, &sh.ones};
+    const uint64_t *kb = a.keys + o0;
+    uint32_t R = 1;
+    while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
+    Proc stk[BMH_STACK];
+    double tw = 0.;
+    for (uint32_t r = 0; r < R; ++r) {
+        if (tb == seed_tb && r == seed_r) continue;
+        if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
+        const double bound = V(__hip_atomic_load(&a.hbound[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        Lane L{tid, 0, 0, 0.};
+        while (lane_step(L, t, a.thr, m, bound, h, stk, tw, true)) {}
+        __syncthreads();
+    }
+    tw = block_sum(tw, reinterpret_cast<double *>(sh.red));
+    if (tid == 0 && tw != 0.) atomicAdd(&a.tw[g], tw);
+    // tighten the genome's bound for workgroups that start later
+    __threadfence();
+    const uint64_t hm = block_hmax(h, m, sh.red);
+    if (tid == 0) atomicMin((unsigned long long *)&a.hbound[g], (unsigned long long)hm);
+}
+
+// R11 alone: distinct (key, count) of every bucket, compacted to the front of the bucket's region
+__global__ __launch_bounds__(K3_THREADS) void k3_count_kernel(BmhArgs a) {
+    __shared__ SharedK3 sh;
+    const int tid = threadIdx.x;
+    const uint32_t tb = blockIdx.x;
+    const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
+    if (tid == 0) sh.misc = 0;
+    if (nk == 0) { if (tid == 0) a.bucket_nd[tb] = 0; return; }
+    const CountTab t{sh.key, sh.cnt, &sh.ones};
+    const uint64_t *kb = a.keys + o0;
+    uint32_t R = 1;
+    while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
+    for (uint32_t r = 0; r < R; ++r) {
+        if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
+        for (int s = tid; s < K3_TAB; s += K3_THREADS) {
+            const uint32_t c = sh.cnt[s];
+            if (c && (double)c > a.thr) {
+                const uint32_t j = atomicAdd(&sh.misc, 1u);
+                a.out_keys[o0 + j] = sh.key[s]; a.out_counts[o0 + j] = c;
+            }
+        }
+        if (tid == 0 && sh.ones && (double)sh.ones > a.thr) {
+            const uint32_t j = atomicAdd(&sh.misc, 1u);
+            a.out_keys[o0 + j] = K3_EMPTY; a.out_counts[o0 + j] = sh.ones;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) a.bucket_nd[tb] = sh.misc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// explicit weighted sets (wsketch.cpp:54-73 minwise_det / 17-51 rowwise CSR): elements come
+// from (id, weight) arrays instead of the count table
+// ---------------------------------------------------------------------------------------------
+struct WsArgs {
+    const uint64_t *ids;
+    const double *w;             // nullptr => 1.0
+    const uint64_t *set_off;     // [nsets+1]
+    const uint32_t *blk_set;     // main kernel: set of workgroup
+    const uint64_t *blk_lo;      //              first element
+    const uint32_t *blk_cnt;     //              element count
+    uint32_t m;
+    uint32_t seed_elems;         // elements [0, seed_elems) of each set are the seed
+    uint64_t *h; uint64_t *hbound; double *tw;
+    int *status;
+};
+
+__device__ __forceinline__ bool ws_fetch(const WsArgs &a, uint64_t idx, uint64_t &d, double &w, int *status) {
+    d = a.ids[idx];
+    w = a.w ? a.w[idx] : 1.0;
+    if (!(w > 0.)) return false;                                   // BagMinHash2::update ignores w <= 0
+    if (!(w <= 0x1p53)) { atomicExch(status, 2); return false; }   // outside the level set (also NaN)
+    return true;
+}
+
+template <bool SEED>
+__global__ __launch_bounds__(K3_THREADS) void k3_bmh_sets_kernel(WsArgs a) {
+    __shared__ uint64_t red[8];
+    extern __shared__ __attribute__((aligned(16))) uint64_t hlds[];
+    const int tid = threadIdx.x;
+    const uint32_t m = a.m;
+    uint32_t set; uint64_t lo; uint64_t cnt;
+    if (SEED) {
+        set = blockIdx.x;
+        lo = a.set_off[set];
+        cnt = a.set_off[set + 1] - lo;
+        if (cnt > a.seed_elems) cnt = a.seed_elems;
+    } else {
+        set = a.blk_set[blockIdx.x]; lo = a.blk_lo[blockIdx.x]; cnt = a.blk_cnt[blockIdx.x];
+    }
+    uint64_t *hg = a.h + (size_t)set * m;
+    Proc stk[BMH_STACK];
+    double tw = 0.;
+    if (SEED) {
+        const bool use_lds = m <= K3_HLDS_MAX;
+        uint64_t *h = use_lds ? hlds : hg;
+        for (uint32_t i = tid; i < m; i += K3_THREADS) { h[i] = BMH_INF; if (use_lds) hg[i] = BMH_INF; }
+        // first window of seed_elems elements that carries weight (window 0 belongs to this workgroup
+        // alone; later windows are also walked by a main workgroup, which then owns their total weight)
+        const uint64_t len = a.set_off[set + 1] - lo;
+        double wsum = 0.;
+        uint64_t w0 = 0;
+        for (; w0 < len; w0 += a.seed_elems) {
+            cnt = len - w0 < a.seed_elems ? len - w0 : a.seed_elems;
+            double ws = 0.;
+            for (uint64_t e = tid; e < cnt; e += K3_THREADS) { uint64_t d; double w; if (ws_fetch(a, lo + w0 + e, d, w, a.status)) ws += w; }
+            wsum = block_sum(ws, reinterpret_cast<double *>(red));
+            if (wsum > 0.) break;
+        }
+        if (!(wsum > 0.)) { if (tid == 0) { a.hbound[set] = BMH_INF; a.tw[set] = 0.; } return; }
+        lo += w0;
+        double beta = 2.0 * (double)m * ((double)__logf((float)m) + 1.0) / wsum;
+        for (;;) {
+            uint64_t e = tid; int sp = 0; uint64_t d = 0; double w = 0.;
+            uint64_t hm = block_hmax(h, m, red);
+            for (;;) {
+                const double live = V(hm);
+                const double bound = live < beta ? live : beta;
+                bool more = true;
+                if (sp == 0) {
+                    bool got = false;
+                    while (e < cnt && !got) { got = ws_fetch(a, lo + e, d, w, a.status); e += K3_THREADS; }
+                    if (got) {
+                        Proc P; P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = d; P.i = 0; P.pad = 0;
+                        if (proc_next(P, m, bound)) stk[sp++] = P;
+                    } else more = false;
+                } else {
+                    const Proc P = stk[--sp];
+                    if (P.x <= bound) bmh_locate(P, d, w, m, bound, h, stk, sp);
+                }
+                if (!__syncthreads_or(more)) break;
+                hm = block_hmax(h, m, red);
+            }
+            hm = block_hmax(h, m, red);
+            if (V(hm) <= beta) break;
+            beta *= 16.0;
+        }
+        const uint64_t hm = block_hmax(h, m, red);
+        if (use_lds) for (uint32_t i = tid; i < m; i += K3_THREADS) hg[i] = h[i];
+        if (tid == 0) { a.hbound[set] = hm; a.tw[set] = w0 == 0 ? wsum : 0.; }
+    } else {
+        const double bound = V(__hip_atomic_load(&a.hbound[set], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        for (uint64_t e = tid; e < cnt; e += K3_THREADS) {
+            uint64_t d; double w;
+            if (!ws_fetch(a, lo + e, d, w, a.status)) continue;
+            tw += w;
+            int sp = 0;
+            Proc P; P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = d; P.i = 0; P.pad = 0;
+            if (proc_next(P, m, bound)) stk[sp++] = P;
+            while (sp) { const Proc Q = stk[--sp]; if (Q.x <= bound) bmh_locate(Q, d, w, m, bound, hg, stk, sp); }
+        }
+        tw = block_sum(tw, reinterpret_cast<double *>(red));
+        if (tid == 0 && tw != 0.) atomicAdd(&a.tw[set], tw);
+        __threadfence();
+        const uint64_t hm = block_hmax(hg, m, red);
+        if (tid == 0) atomicMin((unsigned long long *)&a.hbound[set], (unsigned long long)hm);
+    }
+}
+
+uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x) ++b; return b; }
+
+}  // namespace
+
+// grow-only work buffers of the --multiset path (owned by a sketcher or by a one-shot call)
+struct d2g_k3_state {
+    d2g_ctx *ctx = nullptr;
+    uint32_t *d_gtab = nullptr; size_t cap_gtab = 0;        // g_bbits [n] + g_boff [n+1]
+    uint32_t *d_bucket_cnt = nullptr; size_t cap_bcnt = 0;
+    uint64_t *d_bucket_off = nullptr; size_t cap_boff = 0;
+    uint64_t *d_cursor = nullptr; size_t cap_cursor = 0;
+    uint64_t *d_keys = nullptr; size_t cap_keys = 0;
+    uint64_t *d_h = nullptr; size_t cap_h = 0;
+    uint64_t *d_hbound = nullptr; size_t cap_hbound = 0;
+    double *d_tw = nullptr; size_t cap_tw = 0;
+    uint32_t *d_seed = nullptr; size_t cap_seed = 0;
+    int *d_status = nullptr;
+    uint32_t *d_out_counts = nullptr; size_t cap_oc = 0;
+    uint32_t *d_bucket_nd = nullptr; size_t cap_nd = 0;
+    uint64_t *d_out_keys = nullptr; size_t cap_ok = 0;
+};
+
+void d2g_k3_state_destroy(d2g_k3_state *st) {
+    if (!st) return;
+    (void)hipFree(st->d_gtab); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor);
+    (void)hipFree(st->d_keys); (void)hipFree(st->d_h); (void)hipFree(st->d_hbound); (void)hipFree(st->d_tw);
+    (void)hipFree(st->d_seed); (void)hipFree(st->d_status); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
+    (void)hipFree(st->d_out_keys);
+    delete st;
+}
+
+namespace {
+
+struct K3Host {
+    std::vector<uint32_t> gtab;        // bbits[n] then boff[n+1]
+    std::vector<uint64_t> gk;          // k-mers per genome
+    uint64_t total = 0;
+    uint32_t TB = 0;
+};
+
+int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_off, size_t n, int k, K3Host &kh) {
+    kh.gtab.assign(2 * n + 1, 0);
+    kh.gk.assign(n, 0);
+    uint64_t tb = 0;
+    for (size_t g = 0; g < n; ++g) {
+        uint64_t nk = 0;
+        for (uint64_t r = genome_run_off[g]; r < genome_run_off[g + 1]; ++r) nk += (uint64_t)run_len[r] - k + 1;
+        D2G_CHECK(ctx, nk < (1ull << 32), "--multiset: more than 2^32 k-mers in one input");
+        kh.gk[g] = nk; kh.total += nk;
+        const uint32_t bb = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((nk + K3_TARGET - 1) / K3_TARGET));
+        kh.gtab[g] = bb;
+        kh.gtab[n + g] = (uint32_t)tb;
+        tb += 1ull << bb;
+        D2G_CHECK(ctx, tb < (1ull << 31), "--multiset: too many buckets in one batch; use smaller batches");
+    }
+    kh.gtab[2 * n] = (uint32_t)tb;
+    kh.TB = (uint32_t)tb;
+    return D2G_OK;
+}
+
+// count (R11) + sketch (R12) of one staged batch; results stay on the device in st->d_h / st->d_tw
+int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, size_t nblk, const K3Host &kh, size_t n,
+           uint64_t xormask, size_t m, double thr, bool count_only) {
+    const uint32_t TB = kh.TB;
+    if (int rc = d2g_grow(ctx, &st->d_gtab, &st->cap_gtab, 2 * n + 1)) return rc;
+    if (int rc = d2g_grow(ctx, &st->d_bucket_cnt, &st->cap_bcnt, (size_t)TB + 1)) return rc;
+    if (int rc = d2g_grow(ctx, &st->d_bucket_off, &st->cap_boff, (size_t)TB + 1)) return rc;
+    if (int rc = d2g_grow(ctx, &st->d_cursor, &st->cap_cursor, (size_t)TB + 1)) return rc;
+    if (int rc = d2g_grow(ctx, &st->d_keys, &st->cap_keys, std::max<uint64_t>(kh.total, 1))) return rc;
+    if (!st->d_status) D2G_HIP(ctx, hipMalloc((void **)&st->d_status, sizeof(int)));
+    D2G_HIP(ctx, hipMemcpyAsync(st->d_gtab, kh.gtab.data(), (2 * n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    D2G_HIP(ctx, hipMemsetAsync(st->d_bucket_cnt, 0, ((size_t)TB + 1) * sizeof(uint32_t), s));
+    D2G_HIP(ctx, hipMemsetAsync(st->d_status, 0, sizeof(int), s));
+    K3Args a;
+    a.km = km; a.xormask = xormask;
+    a.g_bbits = st->d_gtab; a.g_boff = st->d_gtab + n;
+    a.bucket_cnt = st->d_bucket_cnt; a.bucket_off = st->d_bucket_off; a.cursor = st->d_cursor; a.keys = st->d_keys;
+    a.TB = TB;
+    d2g_timer tm(ctx, &ctx->ev_k3, s);
+    if (nblk) hipLaunchKernelGGL(k3_hist_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k3_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    if (nblk) hipLaunchKernelGGL(k3_scatter_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
+    BmhArgs b;
+    std::memset(&b, 0, sizeof(b));
+    b.keys = st->d_keys; b.bucket_off = st->d_bucket_off; b.g_boff = st->d_gtab + n;
+    b.n = (uint32_t)n; b.TB = TB; b.m = (uint32_t)m; b.thr = thr; b.status = st->d_status;
+    if (count_only) {
+        if (int rc = d2g_grow(ctx, &st->d_out_keys, &st->cap_ok, std::max<uint64_t>(kh.total, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_out_counts, &st->cap_oc, std::max<uint64_t>(kh.total, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_bucket_nd, &st->cap_nd, (size_t)TB + 1)) return rc;
+        b.out_keys = st->d_out_keys; b.out_counts = st->d_out_counts; b.bucket_nd = st->d_bucket_nd;
+        if (TB) hipLaunchKernelGGL(k3_count_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
+    } else {
+        if (int rc = d2g_grow(ctx, &st->d_h, &st->cap_h, std::max<size_t>(n * m, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_hbound, &st->cap_hbound, std::max<size_t>(n, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_tw, &st->cap_tw, std::max<size_t>(n, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_seed, &st->cap_seed, 2 * std::max<size_t>(n, 1))) return rc;
+        b.h = st->d_h; b.hbound = st->d_hbound; b.tw = st->d_tw; b.seed_bucket = st->d_seed; b.seed_round = st->d_seed + n;
+        const size_t hl = m <= K3_HLDS_MAX ? m * sizeof(uint64_t) : 0;
+        if (hl + sizeof(SharedK3) > 48 * 1024)
+            D2G_HIP(ctx, hipFuncSetAttribute((const void *)k3_bmh_seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
+        if (n) hipLaunchKernelGGL(k3_bmh_seed_kernel, dim3((unsigned)n), dim3(K3_THREADS), hl, s, b);
+        if (TB) hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
+    }
+    tm.stop();
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+int k3_check_status(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s) {
+    int status = 0;
+    D2G_HIP(ctx, hipMemcpyAsync(&status, st->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipStreamSynchronize(s));
+    if (status == 1) { ctx->last_error = "internal: k-mer count table overflow"; return D2G_ERR_INTERNAL; }
+    if (status == 2) { ctx->last_error = "BagMinHash weight outside (0, 2^53]"; return D2G_ERR_INVALID; }
+    return D2G_OK;
+}
+
+d2g_k3_state *k3_state_of(d2g_sketcher *sk) {
+    if (!sk->k3) { sk->k3 = new (std::nothrow) d2g_k3_state(); if (sk->k3) sk->k3->ctx = sk->ctx; }
+    return sk->k3;
+}
+
+}  // namespace
+
+extern "C" {
+
+int d2g_sketcher_run_bmh(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
+                         const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
+                         uint64_t xormask, size_t sketchsize, double count_threshold, double *sig_out,
+                         double *total_weight_out) {
+    if (!sk) return D2G_ERR_INVALID;
+    d2g_ctx *ctx = sk->ctx;
+    D2G_CHECK(ctx, sketchsize >= 1 && sketchsize < (1ull << 24), "sketchsize out of range");
+    D2G_CHECK(ctx, (sig_out && total_weight_out) || n == 0, "null output");
+    D2G_CHECK(ctx, count_threshold == count_threshold, "count_threshold is NaN");
+    d2g_k3_state *st = k3_state_of(sk);
+    if (!st) return D2G_ERR_NOMEM;
+    KmerArgs km;
+    size_t nblk = 0;
+    if (int rc = d2g_sketcher_stage(sk, packed, packed_bytes, run_start, run_len, nrun, genome_run_off, n, k, canon, &km,
+                                    &nblk, nullptr)) return rc;
+    K3Host kh;
+    if (int rc = k3_layout(ctx, run_len, genome_run_off, n, k, kh)) return rc;
+    if (n == 0) return D2G_OK;
+    hipStream_t s = sk->stream;
+    if (int rc = k3_run(ctx, st, s, km, nblk, kh, n, xormask, sketchsize, count_threshold, false)) return rc;
+    D2G_HIP(ctx, hipMemcpyAsync(sig_out, st->d_h, n * sketchsize * sizeof(double), hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipMemcpyAsync(total_weight_out, st->d_tw, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    return k3_check_status(ctx, st, s);
+}
+
+int d2g_bmh_sketch(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
+                   const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
+                   uint64_t xormask, size_t sketchsize, double count_threshold, double *sig_out, double *total_weight_out) {
+    if (!ctx) return D2G_ERR_INVALID;
+    d2g_sketcher *sk = nullptr;
+    if (int rc = d2g_sketcher_create(ctx, &sk)) return rc;
+    const int rc = d2g_sketcher_run_bmh(sk, packed, packed_bytes, run_start, run_len, nrun, genome_run_off, n, k, canon,
+                                        xormask, sketchsize, count_threshold, sig_out, total_weight_out);
+    d2g_sketcher_destroy(sk);
+    return rc;
+}
+
+int d2g_kmer_count(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
+                   const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
+                   uint64_t xormask, double count_threshold, uint64_t *keys_out, uint32_t *counts_out, size_t cap,
+                   uint64_t *genome_off_out) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, genome_off_out != nullptr, "null genome_off_out");
+    D2G_CHECK(ctx, cap == 0 || (keys_out && counts_out), "null output");
+    d2g_sketcher *sk = nullptr;
+    if (int rc = d2g_sketcher_create(ctx, &sk)) return rc;
+    int rc = D2G_OK;
+    do {
+        d2g_k3_state *st = k3_state_of(sk);
+        if (!st) { rc = D2G_ERR_NOMEM; break; }
+        KmerArgs km;
+        size_t nblk = 0;
+        if ((rc = d2g_sketcher_stage(sk, packed, packed_bytes, run_start, run_len, nrun, genome_run_off, n, k, canon, &km,
+                                     &nblk, nullptr))) break;
+        K3Host kh;
+        if ((rc = k3_layout(ctx, run_len, genome_run_off, n, k, kh))) break;
+        for (size_t g = 0; g <= n; ++g) genome_off_out[g] = 0;
+        if (n == 0) break;
+        hipStream_t s = sk->stream;
+        if ((rc = k3_run(ctx, st, s, km, nblk, kh, n, xormask, 1, count_threshold, true))) break;
+        if ((rc = k3_check_status(ctx, st, s))) break;
+        // compact the per-bucket prefixes on the host (utility entry point, not the sketch path)
+        std::vector<uint32_t> nd(kh.TB);
+        std::vector<uint64_t> boff((size_t)kh.TB + 1);
+        hipError_t e;
+        if ((e = hipMemcpy(nd.data(), st->d_bucket_nd, kh.TB * sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess ||
+            (e = hipMemcpy(boff.data(), st->d_bucket_off, ((size_t)kh.TB + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess) {
+            ctx->last_error = hipGetErrorString(e); rc = D2G_ERR_HIP; break;
+        }
+        std::vector<uint64_t> hk(std::max<uint64_t>(kh.total, 1));
+        std::vector<uint32_t> hc(std::max<uint64_t>(kh.total, 1));
+        if (kh.total &&
+            ((e = hipMemcpy(hk.data(), st->d_out_keys, kh.total * sizeof(uint64_t), hipMemcpyDeviceToHost)) != hipSuccess ||
+             (e = hipMemcpy(hc.data(), st->d_out_counts, kh.total * sizeof(uint32_t), hipMemcpyDeviceToHost)) != hipSuccess)) {
+            ctx->last_error = hipGetErrorString(e); rc = D2G_ERR_HIP; break;
+        }
+        size_t w = 0;
+        for (size_t g = 0; g < n && rc == D2G_OK; ++g) {
+            genome_off_out[g] = w;
+            for (uint32_t tb = kh.gtab[n + g]; tb < kh.gtab[n + g + 1]; ++tb) {
+                if (w + nd[tb] > cap) { ctx->last_error = "d2g_kmer_count: output capacity too small"; rc = D2G_ERR_INVALID; break; }
+                std::memcpy(keys_out + w, hk.data() + boff[tb], nd[tb] * sizeof(uint64_t));
+                std::memcpy(counts_out + w, hc.data() + boff[tb], nd[tb] * sizeof(uint32_t));
+                w += nd[tb];
+            }
+        }
+        genome_off_out[n] = w;
+    } while (0);
+    d2g_sketcher_destroy(sk);
+    return rc;
+}
+
+int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weights, const uint64_t *set_off, size_t nsets,
+                          size_t sketchsize, double *sig_out, double *total_weight_out) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, set_off != nullptr && (nsets == 0 || (sig_out && total_weight_out)), "null argument");
+    D2G_CHECK(ctx, sketchsize >= 1 && sketchsize < (1ull << 24), "sketchsize out of range");
+    D2G_CHECK(ctx, nsets < (1ull << 31), "too many sets");
+    if (nsets == 0) return D2G_OK;
+    const uint64_t total = set_off[nsets];
+    D2G_CHECK(ctx, total == 0 || ids != nullptr, "null ids");
+    for (size_t i = 0; i < nsets; ++i) D2G_CHECK(ctx, set_off[i] <= set_off[i + 1], "set_off not monotone");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t seed_elems = 1024, chunk = 2048;
+    std::vector<uint32_t> bset, bcnt;
+    std::vector<uint64_t> blo;
+    for (size_t i = 0; i < nsets; ++i) {
+        const uint64_t lo = set_off[i], hi = set_off[i + 1];
+        for (uint64_t e = lo + std::min<uint64_t>(seed_elems, hi - lo); e < hi; e += chunk) {
+            bset.push_back((uint32_t)i); blo.push_back(e); bcnt.push_back((uint32_t)std::min<uint64_t>(chunk, hi - e));
+        }
+    }
+    D2G_CHECK(ctx, bset.size() < (1ull << 31), "too many workgroups");
+    const size_t m = sketchsize, nb = bset.size();
+    uint64_t *d_ids = nullptr, *d_off = nullptr, *d_blo = nullptr, *d_h = nullptr, *d_hb = nullptr;
+    double *d_w = nullptr, *d_tw = nullptr;
+    uint32_t *d_bset = nullptr, *d_bcnt = nullptr;
+    int *d_status = nullptr;
+    int rc = D2G_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_ids); (void)hipFree(d_off); (void)hipFree(d_blo); (void)hipFree(d_h); (void)hipFree(d_hb);
+        (void)hipFree(d_w); (void)hipFree(d_tw); (void)hipFree(d_bset); (void)hipFree(d_bcnt); (void)hipFree(d_status);
+    };
+#define K3_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->last_error = hipGetErrorString(e_); cleanup(); return D2G_ERR_HIP; } } while (0)
+    K3_TRY(hipMalloc((void **)&d_ids, std::max<uint64_t>(total, 1) * 8));
+    K3_TRY(hipMalloc((void **)&d_off, (nsets + 1) * 8));
+    K3_TRY(hipMalloc((void **)&d_blo, std::max<size_t>(nb, 1) * 8));
+    K3_TRY(hipMalloc((void **)&d_bset, std::max<size_t>(nb, 1) * 4));
+    K3_TRY(hipMalloc((void **)&d_bcnt, std::max<size_t>(nb, 1) * 4));
+    K3_TRY(hipMalloc((void **)&d_h, nsets * m * 8));
+    K3_TRY(hipMalloc((void **)&d_hb, nsets * 8));
+    K3_TRY(hipMalloc((void **)&d_tw, nsets * 8));
+    K3_TRY(hipMalloc((void **)&d_status, sizeof(int)));
+    if (weights) { K3_TRY(hipMalloc((void **)&d_w, std::max<uint64_t>(total, 1) * 8)); K3_TRY(hipMemcpy(d_w, weights, total * 8, hipMemcpyHostToDevice)); }
+    if (total) K3_TRY(hipMemcpy(d_ids, ids, total * 8, hipMemcpyHostToDevice));
+    K3_TRY(hipMemcpy(d_off, set_off, (nsets + 1) * 8, hipMemcpyHostToDevice));
+    if (nb) {
+        K3_TRY(hipMemcpy(d_blo, blo.data(), nb * 8, hipMemcpyHostToDevice));
+        K3_TRY(hipMemcpy(d_bset, bset.data(), nb * 4, hipMemcpyHostToDevice));
+        K3_TRY(hipMemcpy(d_bcnt, bcnt.data(), nb * 4, hipMemcpyHostToDevice));
+    }
+    K3_TRY(hipMemset(d_status, 0, sizeof(int)));
+    WsArgs a;
+    a.ids = d_ids; a.w = d_w; a.set_off = d_off; a.blk_set = d_bset; a.blk_lo = d_blo; a.blk_cnt = d_bcnt;
+    a.m = (uint32_t)m; a.seed_elems = seed_elems; a.h = d_h; a.hbound = d_hb; a.tw = d_tw; a.status = d_status;
+    const size_t hl = m <= K3_HLDS_MAX ? m * sizeof(uint64_t) : 0;
+    if (hl > 48 * 1024)
+        K3_TRY(hipFuncSetAttribute((const void *)k3_bmh_sets_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
+    {
+        d2g_timer tm(ctx, &ctx->ev_k3, nullptr);
+        hipLaunchKernelGGL(k3_bmh_sets_kernel<true>, dim3((unsigned)nsets), dim3(K3_THREADS), hl, nullptr, a);
+        if (nb) hipLaunchKernelGGL(k3_bmh_sets_kernel<false>, dim3((unsigned)nb), dim3(K3_THREADS), 0, nullptr, a);
+        tm.stop();
+    }
+    K3_TRY(hipGetLastError());
+    int status = 0;
+    K3_TRY(hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost));
+    K3_TRY(hipMemcpy(sig_out, d_h, nsets * m * 8, hipMemcpyDeviceToHost));
+    K3_TRY(hipMemcpy(total_weight_out, d_tw, nsets * 8, hipMemcpyDeviceToHost));
+#undef K3_TRY
+    cleanup();
+    if (status == 2) { ctx->last_error = "BagMinHash weight outside (0, 2^53]"; rc = D2G_ERR_INVALID; }
+    return rc;
+}
+
+}  // extern "C"

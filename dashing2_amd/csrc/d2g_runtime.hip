@@ -33,7 +33,7 @@ int d2g_ctx_create(int device, d2g_ctx **out) {
 void d2g_ctx_destroy(d2g_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (d2g_evlog *e : {&c->ev_k1, &c->ev_k2, &c->ev_k2prep}) {
+    for (d2g_evlog *e : {&c->ev_k1, &c->ev_k2, &c->ev_k2prep, &c->ev_k3}) {
         for (hipEvent_t x : e->a) (void)hipEventDestroy(x);
         for (hipEvent_t x : e->b) (void)hipEventDestroy(x);
     }
@@ -102,6 +102,7 @@ int d2g_kernel_ms(d2g_ctx *c, const char *which, int reset, int *count, float *a
     if (!std::strcmp(which, "k1")) e = &c->ev_k1;
     else if (!std::strcmp(which, "k2")) e = &c->ev_k2;
     else if (!std::strcmp(which, "k2prep")) e = &c->ev_k2prep;
+    else if (!std::strcmp(which, "k3")) e = &c->ev_k3;
     D2G_CHECK(c, e != nullptr, "d2g_kernel_ms: unknown kernel name");
     D2G_HIP(c, hipSetDevice(c->device));
     double sum = 0;

@@ -40,7 +40,8 @@ enum d2g_status {
     D2G_ERR_HIP = -3,          /* HIP runtime error; see d2g_last_error */
     D2G_ERR_NOMEM = -4,
     D2G_ERR_UNSUPPORTED = -5,  /* outside the hot-path scope (e.g. k > 32) */
-    D2G_ERR_IO = -6
+    D2G_ERR_IO = -6,
+    D2G_ERR_INTERNAL = -7      /* an internal invariant failed (reported, never silent) */
 };
 
 /* measures: order of enum Measure, reference src/cmp_main.h:8-17 */
@@ -179,6 +180,46 @@ int  d2g_sketcher_run(d2g_sketcher *sk, const uint8_t *packed, size_t packed_byt
                       const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
                       const uint64_t *genome_run_off, size_t n, int k, int canon, uint64_t xormask,
                       size_t sketchsize, uint64_t *regs_out /* host [n][m] */);
+
+/* ---- K3: --multiset sketches: exact k-mer counts (R11) -> BagMinHash (R12) ------
+ * Replaces, per input, the reference chain
+ *   Counter::add(maskfn(kmer))          src/counter.h:68-77 ; src/fastxsketch.cpp:386,430
+ *   Counter::finalize(bmh, threshold)   src/counter.h:118-138 (update(key, count) for count > threshold)
+ *   BagMinHash2<double>::update/data/total_weight   (ABSENT dnbaker/sketch bmh.h; src/d2.h:247,
+ *                                                    src/fastxsketch.cpp:443-445,477-487)
+ * Inputs are the packed run stream of K1.  Outputs per genome: S doubles (the register minima)
+ * and the total weight (= number of counted k-mers with count > threshold), which the reference
+ * stores as the cardinality.  BagMinHash arithmetic follows the published algorithm under the
+ * "BMH-D2G" spec in DESIGN.md: PARITY UNPINNED against a real dashing2 binary (its source is
+ * absent), bit-exact against oracle/d2_bmh_oracle.c.  An input without k-mers yields +inf registers.
+ */
+int d2g_bmh_sketch(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes,
+                   const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
+                   const uint64_t *genome_run_off, size_t n,
+                   int k, int canon, uint64_t xormask, size_t sketchsize, double count_threshold,
+                   double *sig_out /* host [n][S] */, double *total_weight_out /* host [n] */);
+/* persistent form (same buffers/stream as d2g_sketcher_run) */
+int d2g_sketcher_run_bmh(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes,
+                         const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
+                         const uint64_t *genome_run_off, size_t n, int k, int canon, uint64_t xormask,
+                         size_t sketchsize, double count_threshold,
+                         double *sig_out /* host [n][S] */, double *total_weight_out /* host [n] */);
+/* R11 alone (Counter::finalize(vector&, vector&, threshold), src/counter.h:78-117, minus the
+ * sort): the distinct masked k-mers of genome g with count > threshold and their counts land in
+ * keys_out/counts_out[genome_off_out[g] .. genome_off_out[g+1]) in unspecified order.
+ * cap = capacity of the two output arrays (the total k-mer count always suffices). */
+int d2g_kmer_count(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes,
+                   const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
+                   const uint64_t *genome_run_off, size_t n, int k, int canon, uint64_t xormask,
+                   double count_threshold, uint64_t *keys_out, uint32_t *counts_out, size_t cap,
+                   uint64_t *genome_off_out /* [n+1] */);
+/* BagMinHash of explicit weighted sets (reference src/wsketch.cpp:54-73 minwise_det and 17-51
+ * minhash_rowwise_csr: h.update(id, weight) per element): set i = elements
+ * [set_off[i], set_off[i+1]); weights == NULL means 1.0; weights <= 0 are ignored (as
+ * BagMinHash2::update does), weights above 2^53 or NaN are rejected. */
+int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weights,
+                          const uint64_t *set_off /* [nsets+1] */, size_t nsets, size_t sketchsize,
+                          double *sig_out /* host [nsets][S] */, double *total_weight_out /* host [nsets] */);
 
 /* ---- K2: dense all-pairs comparison -------------------------------------------
  * Replaces HOT LOOP B: emit_rectangular's row loops calling compare()

@@ -295,7 +295,7 @@ int d2o_sketch_buffer(const char *buf, size_t len, int k, int canon, uint64_t xo
     return rc;
 }
 
-static char *slurp(const char *path, size_t *len_out) {
+char *d2o_slurp(const char *path, size_t *len_out) {
     gzFile fp = gzopen(path, "rb");
     if (!fp) return NULL;
     size_t cap = 1 << 20, len = 0;
@@ -321,7 +321,7 @@ int d2o_sketch_file(const char *path, int k, int canon, uint64_t xormask, size_t
     int rc = 0;
     for (char *save = NULL, *tok = strtok_r(line, " ", &save); tok; tok = strtok_r(NULL, " ", &save)) {
         size_t len = 0;
-        char *buf = slurp(tok, &len);
+        char *buf = d2o_slurp(tok, &len);
         if (!buf) { rc = -2; break; }
         d2o_encode_fastx_buffer(buf, len, k, canon, upd_cb, &u);
         free(buf);

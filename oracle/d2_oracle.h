@@ -124,6 +124,63 @@ void d2o_eqcounts_ut(const double *sigs, size_t N, size_t S, uint32_t *neq_out);
 /* cmp_main.cpp:370-388 default_batchsize */
 size_t d2o_default_batchsize(size_t batch_size, size_t S, unsigned nthreads);
 
+
+/* ---- --multiset path: exact k-mer counting (R11) + BagMinHash (R12) -------------------------
+ * R11 restates counter.h:68-77 (Counter::add(uint64_t), exact int32 counts of maskfn'd k-mers)
+ * and counter.h:118-138 (finalize: update(key, count) for every entry with count > threshold);
+ * driver fastxsketch.cpp:425-445.
+ *
+ * R12: sketch::BagMinHash2<double> lives in the ABSENT dnbaker/sketch submodule (bmh.h; SHA
+ * unknown), and no reference test or golden vector touches it: PARITY UNPINNED.  What is restated
+ * here is the PUBLISHED algorithm -- O. Ertl, "BagMinHash - Minwise Hashing Algorithm for Weighted
+ * Sets", KDD 2018 (arXiv:1802.03914), final algorithm: per element a Poisson process over
+ * [0, V_L] x time that is recursively split over the binary tree of weight levels, points kept in
+ * time order, processing stopped once a process is later than the current maximum register -- with
+ * every free choice (level set, RNG, seeding, log) fixed by the "BMH-D2G" spec in DESIGN.md so that
+ * the HIP path can be bit-exact against this file.  Register values therefore differ from a real
+ * dashing2 binary; the estimator properties (P[h_i(A)==h_i(B)] = weighted Jaccard; consistency in
+ * the weight) are what the tests pin.  This file explores processes in time order with a heap
+ * (as published); the HIP kernels use a different order (depth-first with a stale bound), and the
+ * result must not depend on it.
+ */
+/* deterministic natural log for u in [2^-53, 1]: fdlibm-style argument reduction + degree-7
+ * polynomial in plain IEEE double ops (no FMA, no libm) so CPU and GPU agree bit for bit */
+double d2o_dlog(double u);
+/* one RNG step of the process generator (== d2o_wyhash64_stateless) is reused */
+#define D2O_BMH_LEVEL_MAX 0x4340000000000000ull      /* bit pattern of 2^53: weights in (0, 2^53] */
+
+typedef struct d2o_bmh d2o_bmh;
+d2o_bmh *d2o_bmh_create(size_t sketchsize);
+void     d2o_bmh_destroy(d2o_bmh *b);
+void     d2o_bmh_reset(d2o_bmh *b);
+/* BagMinHash2::update(id, w); w <= 0 is ignored (as the reference's callers assume); returns
+ * the number of process steps taken (diagnostic) */
+uint64_t d2o_bmh_update(d2o_bmh *b, uint64_t id, double w);
+double   d2o_bmh_total_weight(const d2o_bmh *b);
+void     d2o_bmh_data(const d2o_bmh *b, double *sig /* [sketchsize] */);
+/* wsketch.cpp:54-73 minwise_det: ids[i] with weight w[i] (NULL => 1) */
+int d2o_bmh_from_weighted(const uint64_t *ids, const double *w, size_t n, size_t sketchsize,
+                          double *sig_out, double *total_weight_out);
+
+/* R11: sorted distinct maskfn'd k-mers and their counts for one FASTA/FASTQ buffer.
+ * *keys_out / *counts_out are malloc'd (caller frees with d2o_free). */
+int d2o_kmer_count_buffer(const char *buf, size_t len, int k, int canon, uint64_t xormask,
+                          uint64_t **keys_out, uint32_t **counts_out, size_t *ndistinct_out,
+                          uint64_t *nkmers_out);
+void d2o_free(void *p);
+/* R11+R12: fastxsketch.cpp:425-445,477-487 for one input buffer / one path line / many paths */
+int d2o_bmh_sketch_buffer(const char *buf, size_t len, int k, int canon, uint64_t xormask,
+                          size_t sketchsize, double count_threshold, double *sig_out,
+                          double *total_weight_out, uint64_t *nkmers_out);
+int d2o_bmh_sketch_file(const char *path, int k, int canon, uint64_t xormask, size_t sketchsize,
+                        double count_threshold, double *sig_out, double *total_weight_out,
+                        uint64_t *nkmers_out);
+int d2o_bmh_sketch_files(const char *const *paths, size_t n, int k, int canon, uint64_t xormask,
+                         size_t sketchsize, double count_threshold, double *sig_out /* [n][S] */,
+                         double *total_weight_out /* [n] */, uint64_t *nkmers_out /* [n] or NULL */);
+/* file reader shared with d2o_sketch_file (gz/plain); caller frees with d2o_free */
+char *d2o_slurp(const char *path, size_t *len_out);
+
 #ifdef __cplusplus
 }
 #endif

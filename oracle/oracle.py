@@ -66,6 +66,20 @@ def load(path=None):
         "d2o_allpairs_ut_rows": (None, [pdbl, pdbl, sz, sz, i32, i32, sz, sz, pf32, i32, sz]),
         "d2o_eqcounts_ut": (None, [pdbl, sz, sz, pu32]),
         "d2o_default_batchsize": (sz, [sz, sz, C.c_uint]),
+        "d2o_dlog": (dbl, [dbl]),
+        "d2o_bmh_create": (C.c_void_p, [sz]),
+        "d2o_bmh_destroy": (None, [C.c_void_p]),
+        "d2o_bmh_reset": (None, [C.c_void_p]),
+        "d2o_bmh_update": (u64, [C.c_void_p, u64, dbl]),
+        "d2o_bmh_total_weight": (dbl, [C.c_void_p]),
+        "d2o_bmh_data": (None, [C.c_void_p, pdbl]),
+        "d2o_bmh_from_weighted": (i32, [pu64, pdbl, sz, sz, pdbl, pdbl]),
+        "d2o_kmer_count_buffer": (i32, [C.c_char_p, sz, i32, i32, u64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(sz), pu64]),
+        "d2o_free": (None, [C.c_void_p]),
+        "d2o_bmh_sketch_buffer": (i32, [C.c_char_p, sz, i32, i32, u64, sz, dbl, pdbl, pdbl, pu64]),
+        "d2o_bmh_sketch_file": (i32, [C.c_char_p, i32, i32, u64, sz, dbl, pdbl, pdbl, pu64]),
+        "d2o_bmh_sketch_files": (i32, [C.POINTER(C.c_char_p), sz, i32, i32, u64, sz, dbl, pdbl, pdbl, pu64]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
@@ -186,3 +200,58 @@ def eqcounts_ut(sigs):
     out = np.empty(N * (N - 1) // 2, np.uint32)
     load().d2o_eqcounts_ut(_p(sigs, C.c_double), N, S, _p(out, C.c_uint32))
     return out
+
+
+# ---- --multiset path (R11 exact k-mer counts, R12 BagMinHash; see d2_bmh_oracle.c) ----------
+
+def dlog(u):
+    return float(load().d2o_dlog(float(u)))
+
+
+def bmh_from_weighted(ids, weights, S):
+    """-> (sig float64[S], total_weight)"""
+    ids = np.ascontiguousarray(ids, np.uint64)
+    w = None if weights is None else np.ascontiguousarray(weights, np.float64)
+    sig = np.empty(S, np.float64)
+    tw = C.c_double()
+    rc = load().d2o_bmh_from_weighted(_p(ids, C.c_uint64), None if w is None else _p(w, C.c_double), ids.size, S,
+                                      _p(sig, C.c_double), C.byref(tw))
+    assert rc == 0
+    return sig, tw.value
+
+
+def kmer_count_buffer(buf, k, canon=True, xormask=0):
+    """-> (keys uint64[nd] sorted, counts uint32[nd], nkmers)"""
+    keys, counts, nd, nk = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_uint64()
+    rc = load().d2o_kmer_count_buffer(buf, len(buf), k, int(canon), xormask, C.byref(keys), C.byref(counts),
+                                      C.byref(nd), C.byref(nk))
+    assert rc == 0
+    n = nd.value
+    ko = np.ctypeslib.as_array(C.cast(keys, C.POINTER(C.c_uint64)), (max(n, 1),))[:n].copy()
+    co = np.ctypeslib.as_array(C.cast(counts, C.POINTER(C.c_uint32)), (max(n, 1),))[:n].copy()
+    load().d2o_free(keys)
+    load().d2o_free(counts)
+    return ko, co, nk.value
+
+
+def bmh_sketch_buffer(buf, k, S, canon=True, xormask=0, count_threshold=0.0):
+    """-> (sig float64[S], total_weight, nkmers)"""
+    sig = np.empty(S, np.float64)
+    tw, nk = C.c_double(), C.c_uint64()
+    rc = load().d2o_bmh_sketch_buffer(buf, len(buf), k, int(canon), xormask, S, count_threshold,
+                                      _p(sig, C.c_double), C.byref(tw), C.byref(nk))
+    assert rc == 0
+    return sig, tw.value, nk.value
+
+
+def bmh_sketch_files(paths, k, S, canon=True, xormask=0, count_threshold=0.0):
+    """-> (sigs float64[n][S], total_weights float64[n], nkmers uint64[n])"""
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+    sigs = np.empty((n, S), np.float64)
+    tw = np.empty(n, np.float64)
+    nk = np.empty(n, np.uint64)
+    rc = load().d2o_bmh_sketch_files(arr, n, k, int(canon), xormask, S, count_threshold, _p(sigs, C.c_double),
+                                     _p(tw, C.c_double), _p(nk, C.c_uint64))
+    assert rc == 0, rc
+    return sigs, tw, nk

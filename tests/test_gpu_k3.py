@@ -1,0 +1,126 @@
+"""GPU parity tests for K3, the --multiset sketch path: exact k-mer counting (R11) and BagMinHash
+(R12) through the C ABI versus the oracle.  Counts are integers and must match exactly; the
+BagMinHash registers are doubles produced by the same IEEE operation sequence on both sides
+(own log, no FMA contraction) and must match BIT FOR BIT even though the GPU explores the Poisson
+process tree depth-first against a stale bound while the oracle uses a time-ordered heap."""
+import numpy as np
+import pytest
+
+from dashing2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _genomes(rng):
+    base = synth.random_genome(11, 60000)
+    rep = np.tile(synth.random_genome(12, 500), 40)                     # 40 tandem copies: counts up to 40
+    low = np.frombuffer(b"ACGT" * 3000, np.uint8)                       # 4 distinct k-mers, huge counts
+    polya = np.frombuffer(b"A" * 5000, np.uint8)                        # ONE distinct k-mer
+    return [
+        synth.fasta_bytes("g0", base),
+        synth.fasta_bytes("g1", synth.mutate(base, 0.02, 5)) + synth.fasta_bytes("g1b", rep),
+        synth.fasta_bytes("rep", rep),
+        synth.fasta_bytes("low", low),
+        synth.fasta_bytes("polyA", polya),
+        b">tiny\nACGTTGCA\n",
+        b"",
+        synth.fasta_bytes("big", synth.random_genome(13, 400000)),       # several buckets, > 1 workgroup of chunks
+        synth.fasta_bytes("n", synth.random_genome(14, 3000)) + b">x\nNNNNACGTNNNN\n",
+    ]
+
+
+@pytest.mark.parametrize("k,canon,xormask,thr", [(21, True, 0, 0.0), (31, True, 0, 0.0), (11, False, 0x1234, 0.0),
+                                                  (7, True, 0, 2.0), (32, True, 0, 0.0)])
+def test_kmer_counts_exact(gpu_ctx, d2g, oracle, k, canon, xormask, thr):
+    rng = np.random.default_rng(k)
+    genomes = _genomes(rng)
+    sp = d2g.SeqPack(k)
+    for g in genomes:
+        sp.add_fastx(g)
+    got = gpu_ctx.kmer_count_seqpack(sp, canon=canon, xormask=xormask, count_threshold=thr)
+    assert len(got) == len(genomes)
+    for gi, g in enumerate(genomes):
+        ek, ec, enk = oracle.kmer_count_buffer(g, k, canon=canon, xormask=xormask)
+        keep = ec.astype(np.float64) > thr
+        assert sp.nkmers(gi) == enk
+        np.testing.assert_array_equal(got[gi][0], ek[keep], err_msg=f"genome {gi} keys")
+        np.testing.assert_array_equal(got[gi][1], ec[keep], err_msg=f"genome {gi} counts")
+
+
+@pytest.mark.parametrize("k,S,canon,thr", [(21, 2048, True, 0.0),       # BASELINE config 5 shape
+                                           (31, 1024, True, 0.0),
+                                           (15, 100, False, 0.0),       # non power-of-two register count
+                                           (9, 64, True, 1.0)])         # count threshold
+def test_bmh_sketch_bit_exact(gpu_ctx, d2g, oracle, k, S, canon, thr):
+    rng = np.random.default_rng(S)
+    genomes = _genomes(rng)
+    sp = d2g.SeqPack(k)
+    for g in genomes:
+        sp.add_fastx(g)
+    sig, tw = gpu_ctx.bmh_sketch_seqpack(sp, S, canon=canon, count_threshold=thr)
+    assert sig.shape == (len(genomes), S)
+    for gi, g in enumerate(genomes):
+        esig, etw, enk = oracle.bmh_sketch_buffer(g, k, S, canon=canon, count_threshold=thr)
+        assert tw[gi] == etw, f"genome {gi} total weight"
+        np.testing.assert_array_equal(sig[gi].view(np.uint64), esig.view(np.uint64), err_msg=f"genome {gi}")
+    # the persistent sketcher gives the same answer and can be reused
+    sk = gpu_ctx.sketcher()
+    for _ in range(2):
+        sig2, tw2 = sk.run_bmh(sp, S, canon=canon, count_threshold=thr)
+        np.testing.assert_array_equal(sig2.view(np.uint64), sig.view(np.uint64))
+        np.testing.assert_array_equal(tw2, tw)
+    sk.close()
+
+
+def test_bmh_weighted_jaccard_property(gpu_ctx, d2g):
+    """size-independent property at BASELINE config-5 scale (one 5 Mbp genome, k=21, S=2048):
+    P[register equal] = weighted Jaccard of the k-mer count vectors"""
+    base = synth.random_genome(21, 5_000_000)
+    mut = synth.mutate(base, 0.01, 22)
+    sp = d2g.SeqPack(21)
+    sp.add_fastx(synth.fasta_bytes("a", base))
+    sp.add_fastx(synth.fasta_bytes("b", mut))
+    sp.add_fastx(synth.fasta_bytes("a2", base) + synth.fasta_bytes("a3", base))     # every count doubled
+    S = 2048
+    sig, tw = gpu_ctx.bmh_sketch_seqpack(sp, S)
+    assert np.isfinite(sig).all() and (sig > 0).all()
+    nk = 5_000_000 - 20
+    assert tw[0] == nk and tw[1] == nk and tw[2] == 2 * nk
+    # expected Jaccard of k-mer sets under 1% substitutions: each k-mer survives with (0.99)^21
+    p = 0.99 ** 21
+    j_ab = p / (2 - p)
+    est = (sig[0] == sig[1]).mean()
+    assert abs(est - j_ab) < 5 * np.sqrt(j_ab * (1 - j_ab) / S), (est, j_ab)
+    # doubling every weight: weighted Jaccard = 1/2
+    est2 = (sig[0] == sig[2]).mean()
+    assert abs(est2 - 0.5) < 5 * np.sqrt(0.25 / S), est2
+    # consistency in the weight: more weight can only lower a register
+    assert (sig[2] <= sig[0]).all()
+
+
+def test_bmh_from_weighted_matches_oracle(gpu_ctx, d2g, oracle):
+    rng = np.random.default_rng(5)
+    sets = []
+    for n in (0, 1, 7, 1024, 1025, 5000, 20000):
+        ids = rng.integers(0, 2 ** 63, n).astype(np.uint64) if n != 5000 else np.arange(n, dtype=np.uint64)
+        w = rng.random(n) * 10 ** rng.integers(-3, 6, n).astype(np.float64)
+        if n > 10:
+            w[::7] = 0.0
+            w[3] = -1.0
+        sets.append((ids, w))
+    ids = np.concatenate([s[0] for s in sets])
+    w = np.concatenate([s[1] for s in sets])
+    off = np.cumsum([0] + [len(s[0]) for s in sets]).astype(np.uint64)
+    for S in (64, 1000):
+        sig, tw = gpu_ctx.bmh_from_weighted(ids, w, off, S)
+        for i, (si, wi) in enumerate(sets):
+            esig, etw = oracle.bmh_from_weighted(si, wi, S)
+            np.testing.assert_array_equal(sig[i].view(np.uint64), esig.view(np.uint64), err_msg=f"set {i} S={S}")
+            assert abs(tw[i] - etw) <= 1e-9 * max(1.0, etw)      # double sums in a different order
+    # unit weights
+    sig, tw = gpu_ctx.bmh_from_weighted(sets[5][0], None, np.array([0, 5000], np.uint64), 256)
+    esig, etw = oracle.bmh_from_weighted(sets[5][0], None, 256)
+    np.testing.assert_array_equal(sig[0].view(np.uint64), esig.view(np.uint64))
+    assert tw[0] == etw == 5000.0
+    with pytest.raises(d2g.D2GError):
+        gpu_ctx.bmh_from_weighted(np.array([1], np.uint64), np.array([2.0 ** 60]), np.array([0, 1], np.uint64), 16)
