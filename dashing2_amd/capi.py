@@ -88,6 +88,7 @@ SIGNATURES = {
     "d2g_sketcher_destroy": (None, [_vp]),
     "d2g_sketcher_run": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, _vp]),
     "d2g_sketcher_run_bmh": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, C.c_double, _vp, _vp]),
+    "d2g_bmh_sketch_dev": (_int, [_vp, _vp, _vp, _int, _u64, _sz, C.c_double, _vp, _vp, _vp]),
     "d2g_bmh_sketch": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, C.c_double, _vp, _vp]),
     "d2g_kmer_count": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, C.c_double, _vp, _vp, _sz, _vp]),
     "d2g_bmh_from_weighted": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]),
@@ -362,6 +363,11 @@ class Context:
                                          _np_ptr(go), n, sp.k, int(canon), xormask, S, count_threshold,
                                          _np_ptr(sig), _np_ptr(tw)))
         return sig, tw
+
+    def bmh_sketch_dev(self, plan, packed_dev_ptr, S, sig_dev_ptr, tw_dev_ptr, canon=True, xormask=0, count_threshold=0.0,
+                       stream=None):
+        self._check(lib().d2g_bmh_sketch_dev(self._h, plan._h, packed_dev_ptr, int(canon), xormask, S, count_threshold,
+                                             sig_dev_ptr, tw_dev_ptr, stream))
 
     def kmer_count_seqpack(self, sp: "SeqPack", canon=True, xormask=0, count_threshold=0.0):
         """-> list over genomes of (keys uint64[nd], counts uint32[nd]), each sorted by key"""

@@ -17,7 +17,9 @@ struct d2g_ctx {
     std::string last_error;
     bool timing = false;
     d2g_evlog ev_k1, ev_k2, ev_k2prep, ev_k3;
+    struct d2g_k3_state *k3 = nullptr;      // work buffers of d2g_bmh_sketch_dev (d2g_k3_bmh.hip)
 };
+void d2g_k3_state_destroy(struct d2g_k3_state *st);
 
 #define D2G_HIP(ctx, call)                                                            \
     do {                                                                              \

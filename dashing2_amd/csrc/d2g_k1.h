@@ -18,6 +18,8 @@ struct d2g_oph_plan {
     int k = 0;
     size_t n = 0, nrun = 0, nblk = 0;
     uint64_t nkmers = 0, nbases = 0;
+    std::vector<uint32_t> h_run_len;           // host copies kept for K3's bucket layout
+    std::vector<uint64_t> h_genome_run_off;
     uint64_t *d_run_start = nullptr;
     uint32_t *d_run_len = nullptr;
     uint64_t *d_run_chunk_off = nullptr;
@@ -68,4 +70,3 @@ struct d2g_sketcher {
 int d2g_sketcher_stage(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
                        const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
                        KmerArgs *out, size_t *nblk, PlanHost *ph_out);
-void d2g_k3_state_destroy(d2g_k3_state *st);

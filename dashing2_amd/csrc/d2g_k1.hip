@@ -149,6 +149,8 @@ int d2g_oph_plan_create(d2g_ctx *ctx, const uint64_t *run_start, const uint32_t 
     d2g_oph_plan *p = new (std::nothrow) d2g_oph_plan();
     if (!p) return D2G_ERR_NOMEM;
     p->ctx = ctx; p->k = k; p->n = n; p->nrun = nrun;
+    p->h_run_len.assign(run_len, run_len + nrun);
+    p->h_genome_run_off.assign(genome_run_off, genome_run_off + n + 1);
     p->nkmers = ph.nkmers; p->nbases = ph.nbases; p->nblk = ph.bg.size();
     std::vector<uint64_t> rs(run_start, run_start + nrun);
     std::vector<uint32_t> rl(run_len, run_len + nrun);

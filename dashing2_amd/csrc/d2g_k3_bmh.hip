@@ -24,6 +24,8 @@
 #include "d2g_k1.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -33,13 +35,16 @@ namespace {
 constexpr int K3_THREADS = 256;
 constexpr int K3_MAXBBITS = 12;
 constexpr int K3_MAXB = 1 << K3_MAXBBITS;   // buckets per genome (LDS histogram)
-constexpr int K3_TAB = 4096;                // LDS count-table slots
-constexpr int K3_ROUND_KEYS = 2048;         // keys one table round is sized for (load <= 0.5 + duplicates)
+constexpr int K3_TAB = 2048;                // LDS count-table slots (24.6 KB with the counts: 6 workgroups per CU)
+constexpr int K3_ROUND_KEYS = 1400;         // keys one table round is sized for (load <= 0.69)
 constexpr int K3_TARGET = 1024;             // mean keys per bucket aimed for
 constexpr uint64_t K3_EMPTY = ~0ull;
 constexpr uint64_t BMH_LEVEL_MAX = 0x4340000000000000ull;     // bit pattern of 2^53
 constexpr uint64_t BMH_INF = 0x7FF0000000000000ull;
-constexpr int BMH_STACK = 72;
+#ifndef BMH_STACK_N
+#define BMH_STACK_N 72
+#endif
+constexpr int BMH_STACK = BMH_STACK_N;
 constexpr uint32_t K3_HLDS_MAX = 8192;      // registers kept in LDS by the seed workgroup
 
 struct K3Args {
@@ -131,7 +136,8 @@ struct CountTab {
     uint32_t *ones;         // count of the key == K3_EMPTY (cannot live in the table)
 };
 
-__device__ __forceinline__ uint32_t tab_hash(uint64_t key) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 52); }
+__device__ __forceinline__ uint32_t tab_hash(uint64_t key) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53); }
+static_assert(K3_TAB == 1 << 11, "tab_hash takes the top 11 bits");
 
 // keys of round r of R (R a power of two: low key bits select the round); returns false on overflow
 __device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, uint32_t R, uint32_t r) {
@@ -205,11 +211,18 @@ __device__ __forceinline__ double dlog(double u) {
 // advance to the process's next point; false = certainly later than `bound` (drop the process).
 // Early-out: -log(u) >= 1 - u, so (1-u)/width > bound already proves x > bound without the log
 // and the division (the 1e-9 margin dwarfs every rounding involved).
+#ifdef K3_STATS
+__device__ unsigned long long k3_stats[8];
+#define K3_STAT(i) atomicAdd(&k3_stats[i], 1ull)
+#else
+#define K3_STAT(i)
+#endif
 __device__ __forceinline__ bool proc_next(Proc &P, uint32_t m, double bound) {
     const double width = V(P.q) - V(P.p);
     const uint64_t r1 = wy_next(P.rng);
     const double uu = (double)((r1 >> 11) + 1) * 0x1p-53;            // (0, 1]
-    if ((1.0 - uu) > bound * width * 1.000000001) return false;
+    if ((1.0 - uu) > bound * width * 1.000000001) { K3_STAT(1); return false; }
+    K3_STAT(2);
     const double E = -dlog(uu);
     P.x = P.x + E / width;
     const uint64_t r2 = wy_next(P.rng);
@@ -229,6 +242,7 @@ __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double boun
     for (;;) {
         if (!counted && V(P.q) <= w) { reg_min(h, P.i, P.x); counted = true; }
         if (P.q - P.p <= 1) break;
+        K3_STAT(0);
         const uint64_t r = P.p + ((P.q - P.p) >> 1);
         const uint64_t rb = wy_next(P.rng);
         const double ub = (double)(rb >> 11) * 0x1p-53;              // [0, 1)
@@ -240,7 +254,7 @@ __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double boun
         if (left) { S.p = r; S.q = P.q; P.q = r; }
         else      { S.p = P.p; S.q = r; P.p = r; }
         if (V(S.p) < w) {
-            if (proc_next(S, m, bound)) stk[sp++] = S;
+            if (proc_next(S, m, bound)) { K3_STAT(3); stk[sp++] = S; }
         }
         if (!(V(P.p) < w)) { relevant = false; break; }
     }
@@ -249,45 +263,48 @@ __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double boun
     }
 }
 
-// one lane's walk over its elements.  Elements are the occupied table slots s = tid, tid+256, ...
-// (plus the all-ones key as pseudo-slot K3_TAB for lane 0).
-struct Lane {
-    int slot;            // next table slot to look at
-    int sp;              // stack depth
-    uint64_t d;          // current element
-    double w;
-};
-
-__device__ __forceinline__ bool lane_fetch(Lane &L, const CountTab &t, double thr, double &tw) {
-    while (L.slot <= K3_TAB) {
-        const int s = L.slot;
-        L.slot += K3_THREADS;
-        uint32_t c; uint64_t key;
-        if (s < K3_TAB) { c = t.cnt[s]; key = t.key[s]; }
-        else { c = *t.ones; key = K3_EMPTY; }                       // s == K3_TAB: only lane 0 gets here
-        if (c && (double)c > thr) {                                  // counter.h:123: pair.second > threshold
-            L.d = key; L.w = (double)c;
-            tw += L.w;
-            return true;
-        }
+// After count_round: squeeze the occupied slots that pass the count threshold to the front of the
+// table arrays (the all-ones key, which cannot live in the table, is appended), so that the walk
+// below runs over a dense element list with every lane busy.  Returns the number of elements.
+__device__ uint32_t compact_elements(const CountTab &t, uint32_t *nelem, double thr) {
+    constexpr int PER = K3_TAB / K3_THREADS;
+    const int tid = threadIdx.x;
+    uint64_t k[PER];
+    uint32_t c[PER];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int s = tid + j * K3_THREADS;
+        const uint32_t cc = t.cnt[s];
+        k[j] = t.key[s];
+        c[j] = (cc && (double)cc > thr) ? cc : 0u;                   // counter.h:123: pair.second > threshold
+        mine += c[j] != 0;
     }
-    return false;
+    const uint32_t ones = *t.ones;
+    const bool extra = tid == 0 && ones && (double)ones > thr;
+    mine += extra;
+    if (tid == 0) *nelem = 0;
+    __syncthreads();
+    uint32_t pos = mine ? atomicAdd(nelem, mine) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (c[j]) { t.key[pos] = k[j]; t.cnt[pos] = c[j]; ++pos; }
+    if (extra) { t.key[pos] = K3_EMPTY; t.cnt[pos] = ones; }
+    __syncthreads();
+    return *nelem;
 }
 
-// one unit of work; false when the lane has nothing left
-__device__ __forceinline__ bool lane_step(Lane &L, const CountTab &t, double thr, uint32_t m, double bound, uint64_t *h,
-                                          Proc *stk, double &tw, bool count_tw) {
-    if (L.sp == 0) {
-        double dummy = 0.;
-        if (!lane_fetch(L, t, thr, count_tw ? tw : dummy)) return false;
-        Proc P;
-        P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = L.d; P.i = 0; P.pad = 0;
-        if (proc_next(P, m, bound)) stk[L.sp++] = P;
-        return true;
+// walk every process of element (d, w) that can still matter under `bound`
+__device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk) {
+    int sp = 0;
+    Proc P;
+    P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = d; P.i = 0; P.pad = 0;
+    if (proc_next(P, m, bound)) bmh_locate(P, d, w, m, bound, h, stk, sp);
+    while (sp) {
+        const Proc Q = stk[--sp];
+        if (Q.x <= bound) bmh_locate(Q, d, w, m, bound, h, stk, sp);
     }
-    const Proc P = stk[--L.sp];
-    if (P.x <= bound) bmh_locate(P, L.d, L.w, m, bound, h, stk, L.sp);
-    return true;
 }
 
 __device__ uint64_t block_hmax(const uint64_t *h, uint32_t m, uint64_t *red) {
@@ -325,19 +342,27 @@ struct BmhArgs {
     uint64_t *h;             // [n][m] register bit patterns, +inf initially
     uint64_t *hbound;        // [n] certified upper bound of max(h[g]) (bit pattern), +inf initially
     double *tw;              // [n] total weight
+    double *tw_bucket;       // [TB] per-bucket partial of the main pass (zeroed by the host)
     uint32_t *seed_bucket;   // [n] unit the seed workgroup processed: bucket (or ~0: no element) ...
     uint32_t *seed_round;    // [n] ... and round
+    uint64_t *guess;         // [n] uncertified part of the bound the main pass ran with (bit pattern)
+    uint32_t *redo;          // [n] 1 = the guess was too small: the main pass must be repeated under a certified bound
+    uint32_t *nredo;         // [1]
+    int redo_mode;
+    double guess_scale;      // 1.0; D2G_K3_GUESS_SCALE overrides it (tests force the verify/redo path with a tiny value)
     int *status;
     // optional R11 output (k3_count_kernel): distinct (key,count) written in place of the bucket
     uint64_t *out_keys; uint32_t *out_counts; uint32_t *bucket_nd;
 };
 
 struct SharedK3 {
-    uint64_t key[K3_TAB];
-    uint32_t cnt[K3_TAB];
+    uint64_t key[K3_TAB + 1];      // +1: the all-ones key joins the compacted element list
+    uint32_t cnt[K3_TAB + 2];
     uint64_t red[8];
     uint32_t ones;
     uint32_t misc;
+    uint32_t nelem;
+    uint32_t pad;
 };
 
 __device__ __forceinline__ uint32_t genome_of_bucket(const uint32_t *g_boff, uint32_t n, uint32_t tb) {
@@ -364,6 +389,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_seed_kernel(BmhArgs a) {
     Proc stk[BMH_STACK];
     double tw = 0.;
     uint32_t seed_tb = ~0u, seed_r = 0;
+    double wguess = V(BMH_INF);
     for (uint32_t tb = b0; tb < b1 && seed_tb == ~0u; ++tb) {
         const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
         if (nk == 0) continue;
@@ -373,21 +399,39 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_seed_kernel(BmhArgs a) {
         for (uint32_t r = 0; r < R; ++r) {
             if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
             // weight of this unit's elements -> first guess of the bound: registers fill at rate W/m each
+            const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
             double wsum = 0.;
-            for (int s = tid; s < K3_TAB; s += K3_THREADS) { const uint32_t c = sh.cnt[s]; if (c && (double)c > a.thr) wsum += (double)c; }
-            if (tid == 0 && sh.ones && (double)sh.ones > a.thr) wsum += (double)sh.ones;
+            for (uint32_t e = tid; e < ne; e += K3_THREADS) wsum += (double)sh.cnt[e];
             wsum = block_sum(wsum, reinterpret_cast<double *>(sh.red));
             if (!(wsum > 0.)) continue;
             seed_tb = tb; seed_r = r; tw = wsum;
+            // the genome's final maximum register is the max of m exponentials of rate W/m: mean
+            // (m/W)(ln m + 0.58), sd 1.28 m/W.  W is estimated from this unit (a hash-uniform sample
+            // of the keys); the main pass prunes against 1.25 x (mean + 6 sd) and is verified afterwards
+            // (k3_bmh_verify_kernel), so a wrong estimate costs a second pass, never exactness.
+            {
+                const double frac = ((double)nk / (double)R) / (double)(a.bucket_off[b1] - a.bucket_off[b0]);
+                const double west = wsum / frac;
+                wguess = a.guess_scale * 1.25 * (double)m * ((double)__logf((float)m) + 0.58 + 8.0) / west;
+            }
             double beta = 2.0 * (double)m * ((double)__logf((float)m) + 1.0) / wsum;
             for (;;) {
-                Lane L{tid, 0, 0, 0.};
-                double unused = 0.;
+                uint32_t e = tid; int sp = 0; uint64_t d = 0; double w = 0.;
                 uint64_t hm = block_hmax(h, m, sh.red);
-                for (;;) {
+                for (;;) {                          // one process step per lane, then refresh the live bound
                     const double live = V(hm);
                     const double bound = live < beta ? live : beta;
-                    const bool more = lane_step(L, t, a.thr, m, bound, h, stk, unused, false);
+                    bool more = true;
+                    if (sp == 0) {
+                        if (e < ne) {
+                            d = sh.key[e]; w = (double)sh.cnt[e]; e += K3_THREADS;
+                            Proc P; P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = d; P.i = 0; P.pad = 0;
+                            if (proc_next(P, m, bound)) stk[sp++] = P;
+                        } else more = false;
+                    } else {
+                        const Proc P = stk[--sp];
+                        if (P.x <= bound) bmh_locate(P, d, w, m, bound, h, stk, sp);
+                    }
                     if (!__syncthreads_or(more)) break;
                     hm = block_hmax(h, m, sh.red);
                 }
@@ -400,7 +444,11 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_seed_kernel(BmhArgs a) {
     }
     const uint64_t hm = block_hmax(h, m, sh.red);
     if (use_lds) for (uint32_t i = tid; i < m; i += K3_THREADS) hg[i] = h[i];
-    if (tid == 0) { a.hbound[g] = hm; a.tw[g] = tw; a.seed_bucket[g] = seed_tb; a.seed_round[g] = seed_r; }
+    if (tid == 0) {
+        const uint64_t gb = dbits(wguess);
+        a.hbound[g] = hm < gb ? hm : gb; a.guess[g] = gb; a.redo[g] = 0;
+        a.tw[g] = tw; a.seed_bucket[g] = seed_tb; a.seed_round[g] = seed_r;
+    }
 }
 
 // all other units: bound = the genome's certified bound at workgroup start
@@ -413,6 +461,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
     const uint32_t g = genome_of_bucket(a.g_boff, a.n, tb);
     const uint32_t seed_tb = a.seed_bucket[g], seed_r = a.seed_round[g];
     if (seed_tb == ~0u) return;                      // no element of this genome passes the threshold
+    if (a.redo_mode && !a.redo[g]) return;
     uint64_t *h = a.h + (size_t)g * m;
     const CountTab t{sh.key, sh.cnt, &sh.ones};
     const uint64_t *kb = a.keys + o0;
@@ -424,16 +473,40 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
         if (tb == seed_tb && r == seed_r) continue;
         if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
         const double bound = V(__hip_atomic_load(&a.hbound[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        Lane L{tid, 0, 0, 0.};
-        while (lane_step(L, t, a.thr, m, bound, h, stk, tw, true)) {}
+        const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
+        for (uint32_t e = tid; e < ne; e += K3_THREADS) {
+            const uint64_t d = sh.key[e];
+            const double w = (double)sh.cnt[e];
+            tw += w;
+#ifndef K3_SKIP_WALK
+            walk_element(d, w, m, bound, h, stk);
+#endif
+        }
         __syncthreads();
     }
+    // per-bucket total weight (integers: exact in any order); summed per genome by the verify kernel.
+    // No per-workgroup tightening of hbound here: thousands of same-address atomics per genome
+    // serialise in L2 (measured 25 ms per 4e5 workgroups) and the guessed bound is already within
+    // ~2x of the final maximum.
     tw = block_sum(tw, reinterpret_cast<double *>(sh.red));
-    if (tid == 0 && tw != 0.) atomicAdd(&a.tw[g], tw);
-    // tighten the genome's bound for workgroups that start later
-    __threadfence();
-    const uint64_t hm = block_hmax(h, m, sh.red);
-    if (tid == 0) atomicMin((unsigned long long *)&a.hbound[g], (unsigned long long)hm);
+    if (tid == 0 && !a.redo_mode) a.tw_bucket[tb] = tw;
+}
+
+// after the main pass: was every bound that pruned a point at least the final maximum register?
+__global__ __launch_bounds__(K3_THREADS) void k3_bmh_verify_kernel(BmhArgs a) {
+    __shared__ uint64_t red[8];
+    const uint32_t g = blockIdx.x;
+    const uint64_t hm = block_hmax(a.h + (size_t)g * a.m, a.m, red);
+    double tw = 0.;
+    for (uint32_t tb = a.g_boff[g] + threadIdx.x; tb < a.g_boff[g + 1]; tb += K3_THREADS) tw += a.tw_bucket[tb];
+    tw = block_sum(tw, reinterpret_cast<double *>(red));
+    if (threadIdx.x == 0) {
+        a.tw[g] += tw;                                     // seed unit's weight + every other unit's
+        a.hbound[g] = hm;                                  // certified from here on
+        const bool bad = a.seed_bucket[g] != ~0u && hm > a.guess[g];
+        a.redo[g] = bad;
+        if (bad) atomicAdd(a.nredo, 1u);
+    }
 }
 
 // R11 alone: distinct (key, count) of every bucket, compacted to the front of the bucket's region
@@ -450,17 +523,11 @@ __global__ __launch_bounds__(K3_THREADS) void k3_count_kernel(BmhArgs a) {
     while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
     for (uint32_t r = 0; r < R; ++r) {
         if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
-        for (int s = tid; s < K3_TAB; s += K3_THREADS) {
-            const uint32_t c = sh.cnt[s];
-            if (c && (double)c > a.thr) {
-                const uint32_t j = atomicAdd(&sh.misc, 1u);
-                a.out_keys[o0 + j] = sh.key[s]; a.out_counts[o0 + j] = c;
-            }
-        }
-        if (tid == 0 && sh.ones && (double)sh.ones > a.thr) {
-            const uint32_t j = atomicAdd(&sh.misc, 1u);
-            a.out_keys[o0 + j] = K3_EMPTY; a.out_counts[o0 + j] = sh.ones;
-        }
+        const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
+        const uint32_t j0 = sh.misc;
+        for (uint32_t e = tid; e < ne; e += K3_THREADS) { a.out_keys[o0 + j0 + e] = sh.key[e]; a.out_counts[o0 + j0 + e] = sh.cnt[e]; }
+        __syncthreads();
+        if (tid == 0) sh.misc = j0 + ne;
         __syncthreads();
     }
     if (tid == 0) a.bucket_nd[tb] = sh.misc;
@@ -591,7 +658,11 @@ struct d2g_k3_state {
     uint64_t *d_hbound = nullptr; size_t cap_hbound = 0;
     double *d_tw = nullptr; size_t cap_tw = 0;
     uint32_t *d_seed = nullptr; size_t cap_seed = 0;
-    int *d_status = nullptr;
+    int *d_status = nullptr;               // [0] status, [1] nredo
+    uint64_t *d_guess = nullptr; size_t cap_guess = 0;
+    double *d_tw_bucket = nullptr; size_t cap_twb = 0;
+    int last_nredo = 0;
+    uint32_t *d_redo = nullptr; size_t cap_redo = 0;
     uint32_t *d_out_counts = nullptr; size_t cap_oc = 0;
     uint32_t *d_bucket_nd = nullptr; size_t cap_nd = 0;
     uint64_t *d_out_keys = nullptr; size_t cap_ok = 0;
@@ -601,7 +672,7 @@ void d2g_k3_state_destroy(d2g_k3_state *st) {
     if (!st) return;
     (void)hipFree(st->d_gtab); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor);
     (void)hipFree(st->d_keys); (void)hipFree(st->d_h); (void)hipFree(st->d_hbound); (void)hipFree(st->d_tw);
-    (void)hipFree(st->d_seed); (void)hipFree(st->d_status); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
+    (void)hipFree(st->d_seed); (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
     (void)hipFree(st->d_out_keys);
     delete st;
 }
@@ -644,10 +715,10 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
     if (int rc = d2g_grow(ctx, &st->d_bucket_off, &st->cap_boff, (size_t)TB + 1)) return rc;
     if (int rc = d2g_grow(ctx, &st->d_cursor, &st->cap_cursor, (size_t)TB + 1)) return rc;
     if (int rc = d2g_grow(ctx, &st->d_keys, &st->cap_keys, std::max<uint64_t>(kh.total, 1))) return rc;
-    if (!st->d_status) D2G_HIP(ctx, hipMalloc((void **)&st->d_status, sizeof(int)));
+    if (!st->d_status) D2G_HIP(ctx, hipMalloc((void **)&st->d_status, 2 * sizeof(int)));
     D2G_HIP(ctx, hipMemcpyAsync(st->d_gtab, kh.gtab.data(), (2 * n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     D2G_HIP(ctx, hipMemsetAsync(st->d_bucket_cnt, 0, ((size_t)TB + 1) * sizeof(uint32_t), s));
-    D2G_HIP(ctx, hipMemsetAsync(st->d_status, 0, sizeof(int), s));
+    D2G_HIP(ctx, hipMemsetAsync(st->d_status, 0, 2 * sizeof(int), s));
     K3Args a;
     a.km = km; a.xormask = xormask;
     a.g_bbits = st->d_gtab; a.g_boff = st->d_gtab + n;
@@ -672,12 +743,31 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         if (int rc = d2g_grow(ctx, &st->d_hbound, &st->cap_hbound, std::max<size_t>(n, 1))) return rc;
         if (int rc = d2g_grow(ctx, &st->d_tw, &st->cap_tw, std::max<size_t>(n, 1))) return rc;
         if (int rc = d2g_grow(ctx, &st->d_seed, &st->cap_seed, 2 * std::max<size_t>(n, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_guess, &st->cap_guess, std::max<size_t>(n, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_redo, &st->cap_redo, std::max<size_t>(n, 1))) return rc;
         b.h = st->d_h; b.hbound = st->d_hbound; b.tw = st->d_tw; b.seed_bucket = st->d_seed; b.seed_round = st->d_seed + n;
+        if (int rc = d2g_grow(ctx, &st->d_tw_bucket, &st->cap_twb, (size_t)TB + 1)) return rc;
+        D2G_HIP(ctx, hipMemsetAsync(st->d_tw_bucket, 0, ((size_t)TB + 1) * sizeof(double), s));
+        b.tw_bucket = st->d_tw_bucket;
+        b.guess_scale = 1.0;
+        if (const char *e = std::getenv("D2G_K3_GUESS_SCALE")) { const double v = std::atof(e); if (v > 0.) b.guess_scale = v; }
+        b.guess = st->d_guess; b.redo = st->d_redo; b.nredo = reinterpret_cast<uint32_t *>(st->d_status + 1);
         const size_t hl = m <= K3_HLDS_MAX ? m * sizeof(uint64_t) : 0;
         if (hl + sizeof(SharedK3) > 48 * 1024)
             D2G_HIP(ctx, hipFuncSetAttribute((const void *)k3_bmh_seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
         if (n) hipLaunchKernelGGL(k3_bmh_seed_kernel, dim3((unsigned)n), dim3(K3_THREADS), hl, s, b);
         if (TB) hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
+        if (n) hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, b);
+        // a guess that proved too small: repeat those genomes' main pass under the (now finite and
+        // near-final) certified bound.  Registers only go down, so the repeat is idempotent.
+        int nredo = 0;
+        D2G_HIP(ctx, hipMemcpyAsync(&nredo, st->d_status + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        D2G_HIP(ctx, hipStreamSynchronize(s));
+        if (nredo) {
+            b.redo_mode = 1;
+            hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
+        }
+        st->last_nredo = nredo;
     }
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
@@ -685,6 +775,11 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
 }
 
 int k3_check_status(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s) {
+#ifdef K3_STATS
+    { unsigned long long h[8]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(k3_stats), sizeof(h));
+      std::fprintf(stderr, "K3_STATS levels=%llu next_early=%llu next_full=%llu push=%llu elems=%llu locate=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+      std::memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(k3_stats), h, sizeof(h)); }
+#endif
     int status = 0;
     D2G_HIP(ctx, hipMemcpyAsync(&status, st->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     D2G_HIP(ctx, hipStreamSynchronize(s));
@@ -724,6 +819,30 @@ int d2g_sketcher_run_bmh(d2g_sketcher *sk, const uint8_t *packed, size_t packed_
     if (int rc = k3_run(ctx, st, s, km, nblk, kh, n, xormask, sketchsize, count_threshold, false)) return rc;
     D2G_HIP(ctx, hipMemcpyAsync(sig_out, st->d_h, n * sketchsize * sizeof(double), hipMemcpyDeviceToHost, s));
     D2G_HIP(ctx, hipMemcpyAsync(total_weight_out, st->d_tw, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    return k3_check_status(ctx, st, s);
+}
+
+int d2g_bmh_sketch_dev(d2g_ctx *ctx, const d2g_oph_plan *plan, const uint8_t *packed_dev, int canon, uint64_t xormask,
+                       size_t sketchsize, double count_threshold, double *sig_out_dev, double *total_weight_out_dev,
+                       void *stream) {
+    if (!ctx || !plan) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, plan->ctx == ctx, "plan belongs to another context");
+    D2G_CHECK(ctx, sketchsize >= 1 && sketchsize < (1ull << 24), "sketchsize out of range");
+    D2G_CHECK(ctx, (sig_out_dev && total_weight_out_dev) || plan->n == 0, "null output");
+    D2G_CHECK(ctx, count_threshold == count_threshold, "count_threshold is NaN");
+    D2G_CHECK(ctx, ((uintptr_t)packed_dev & 3) == 0, "packed stream must be 4-byte aligned");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->k3) { ctx->k3 = new (std::nothrow) d2g_k3_state(); if (!ctx->k3) return D2G_ERR_NOMEM; ctx->k3->ctx = ctx; }
+    d2g_k3_state *st = ctx->k3;
+    const size_t n = plan->n;
+    K3Host kh;
+    if (int rc = k3_layout(ctx, plan->h_run_len.data(), plan->h_genome_run_off.data(), n, plan->k, kh)) return rc;
+    if (n == 0) return D2G_OK;
+    hipStream_t s = as_stream(stream);
+    if (int rc = k3_run(ctx, st, s, d2g_plan_args(plan, packed_dev, canon), plan->nblk, kh, n, xormask, sketchsize,
+                        count_threshold, false)) return rc;
+    D2G_HIP(ctx, hipMemcpyAsync(sig_out_dev, st->d_h, n * sketchsize * sizeof(double), hipMemcpyDeviceToDevice, s));
+    D2G_HIP(ctx, hipMemcpyAsync(total_weight_out_dev, st->d_tw, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     return k3_check_status(ctx, st, s);
 }
 

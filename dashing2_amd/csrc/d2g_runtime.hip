@@ -37,6 +37,7 @@ void d2g_ctx_destroy(d2g_ctx *c) {
         for (hipEvent_t x : e->a) (void)hipEventDestroy(x);
         for (hipEvent_t x : e->b) (void)hipEventDestroy(x);
     }
+    if (c->k3) d2g_k3_state_destroy(c->k3);
     delete c;
 }
 

@@ -198,6 +198,11 @@ int d2g_bmh_sketch(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes,
                    const uint64_t *genome_run_off, size_t n,
                    int k, int canon, uint64_t xormask, size_t sketchsize, double count_threshold,
                    double *sig_out /* host [n][S] */, double *total_weight_out /* host [n] */);
+/* device-resident form (plan and packed stream as for d2g_oph_sketch_dev); synchronises `stream`
+ * before returning (the status word of the kernels is checked) */
+int d2g_bmh_sketch_dev(d2g_ctx *ctx, const d2g_oph_plan *plan, const uint8_t *packed_dev,
+                       int canon, uint64_t xormask, size_t sketchsize, double count_threshold,
+                       double *sig_out_dev /* [n][S] */, double *total_weight_out_dev /* [n] */, void *stream);
 /* persistent form (same buffers/stream as d2g_sketcher_run) */
 int d2g_sketcher_run_bmh(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes,
                          const uint64_t *run_start, const uint32_t *run_len, size_t nrun,

@@ -1,6 +1,6 @@
 """Time K1 (d2g_oph_sketch_dev) on synthetic packed bases: python tools/k1_time.py [ngenomes] [len] [k] [S]"""
 import sys, numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dashing2_amd as d2
 ng = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 L = int(float(sys.argv[2])) if len(sys.argv) > 2 else 5_000_000
