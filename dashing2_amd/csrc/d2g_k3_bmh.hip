@@ -39,7 +39,6 @@ constexpr int K3_TAB = 2048;                // LDS count-table slots (24.6 KB wi
 constexpr int K3_ROUND_KEYS = 1400;         // keys one table round is sized for (load <= 0.69)
 constexpr int K3_TARGET = 1024;             // mean keys per bucket aimed for
 constexpr uint64_t K3_EMPTY = ~0ull;
-constexpr uint64_t BMH_LEVEL_MAX = 0x4340000000000000ull;     // bit pattern of 2^53
 constexpr uint64_t BMH_INF = 0x7FF0000000000000ull;
 #ifndef BMH_STACK_N
 #define BMH_STACK_N 72
@@ -212,10 +211,18 @@ __device__ __forceinline__ double dlog(double u) {
 // Early-out: -log(u) >= 1 - u, so (1-u)/width > bound already proves x > bound without the log
 // and the division (the 1e-9 margin dwarfs every rounding involved).
 #ifdef K3_STATS
-__device__ unsigned long long k3_stats[8];
+__device__ unsigned long long k3_stats[16];
+#ifdef K3_TIMING_ONLY
+#define K3_STAT(i)
+#else
 #define K3_STAT(i) atomicAdd(&k3_stats[i], 1ull)
+#endif
+#define K3_T0() long long t0_ = wall_clock64()
+#define K3_T(i) do { if (threadIdx.x == 0) { const long long t1_ = wall_clock64(); atomicAdd(&k3_stats[i], (unsigned long long)(t1_ - t0_)); t0_ = t1_; } } while (0)
 #else
 #define K3_STAT(i)
+#define K3_T0()
+#define K3_T(i)
 #endif
 __device__ __forceinline__ bool proc_next(Proc &P, uint32_t m, double bound) {
     const double width = V(P.q) - V(P.p);
@@ -237,8 +244,22 @@ __device__ __forceinline__ void reg_min(uint64_t *h, uint32_t i, double x) {
 
 // locate P's current point: narrow P to the half that holds it, level by level; the other half
 // becomes a fresh process starting at P.x.  Pushes what may still matter.
+// The expensive half of proc_next (log + division) is NOT done inside the level loop: a sibling
+// that survives the cheap early-out is parked on the stack with its uniform in .x, and all parked
+// processes are finished after the loop, where the lanes of a wave are converged again (inside
+// the loop each lane would hit the expensive branch at a different level and the wave would pay
+// for it once per level).  Same arithmetic in a different order: identical results.
 __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk, int &sp) {
+    const int sp0 = sp;
     bool counted = false, relevant = true;
+    auto park = [&](Proc &S) {
+        const double width = V(S.q) - V(S.p);
+        const uint64_t r1 = wy_next(S.rng);
+        const double uu = (double)((r1 >> 11) + 1) * 0x1p-53;        // (0, 1]
+        if ((1.0 - uu) > bound * width * 1.000000001) { K3_STAT(1); return; }   // see proc_next
+        S.x = uu;
+        stk[sp++] = S;
+    };
     for (;;) {
         if (!counted && V(P.q) <= w) { reg_min(h, P.i, P.x); counted = true; }
         if (P.q - P.p <= 1) break;
@@ -249,18 +270,25 @@ __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double boun
         const double vp = V(P.p), vq = V(P.q), vr = V(r);
         const bool left = ub * (vq - vp) < (vr - vp);
         Proc S;
-        S.x = P.x; S.i = 0; S.pad = 0;
+        S.x = 0.; S.i = 0; S.pad = 0;
         S.rng = d ^ (r * 0x9E3779B97F4A7C15ull) ^ 0xD6E8FEB86659FD93ull;
         if (left) { S.p = r; S.q = P.q; P.q = r; }
         else      { S.p = P.p; S.q = r; P.p = r; }
-        if (V(S.p) < w) {
-            if (proc_next(S, m, bound)) { K3_STAT(3); stk[sp++] = S; }
-        }
+        if (V(S.p) < w) park(S);
         if (!(V(P.p) < w)) { relevant = false; break; }
     }
-    if (relevant) {
-        if (proc_next(P, m, bound)) stk[sp++] = P;
+    if (relevant) park(P);                                           // single-level strip: its next point
+    int out = sp0;
+    for (int j = sp0; j < sp; ++j) {
+        Proc S = stk[j];
+        K3_STAT(2);
+        const double E = -dlog(S.x);
+        S.x = P.x + E / (V(S.q) - V(S.p));
+        const uint64_t r2 = wy_next(S.rng);
+        S.i = (uint32_t)__umul64hi(r2, (uint64_t)m);
+        if (S.x <= bound) { K3_STAT(3); stk[out++] = S; }
     }
+    sp = out;
 }
 
 // After count_round: squeeze the occupied slots that pass the count threshold to the front of the
@@ -295,17 +323,45 @@ __device__ uint32_t compact_elements(const CountTab &t, uint32_t *nelem, double 
     return *nelem;
 }
 
-// walk every process of element (d, w) that can still matter under `bound`
-__device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk) {
-    int sp = 0;
+// BMH-D2G top level: 65 fixed strips of [0, 2^53) -- 16 unit strips, then octaves -- each an
+// independent Poisson process from time 0 (see oracle/d2_bmh_oracle.c).  A k-mer seen once costs
+// one seed, one generator step and one compare.
+constexpr int BMH_NTOP = 65;
+__device__ __forceinline__ double top_edge(int t) {
+    return t <= 16 ? (double)t : V((uint64_t)(1023 + t - 12) << 52);           // 2^(t-12)
+}
+__device__ __forceinline__ Proc top_proc(uint64_t d, int t) {
     Proc P;
-    P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = d; P.i = 0; P.pad = 0;
-    if (proc_next(P, m, bound)) bmh_locate(P, d, w, m, bound, h, stk, sp);
+    P.p = dbits(top_edge(t)); P.q = dbits(top_edge(t + 1)); P.x = 0.; P.i = 0; P.pad = 0;
+    P.rng = d ^ ((uint64_t)(t + 1) * 0xA0761D6478BD642Full) ^ 0x8EBC6AF09C88C6E3ull;
+    return P;
+}
+
+// everything below a process whose current point is at or before `bound`
+__device__ __forceinline__ void walk_process(const Proc &P0, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk) {
+    int sp = 0;
+    bmh_locate(P0, d, w, m, bound, h, stk, sp);
     while (sp) {
         const Proc Q = stk[--sp];
         if (Q.x <= bound) bmh_locate(Q, d, w, m, bound, h, stk, sp);
     }
 }
+
+// walk every process of element (d, w) that can still matter under `bound`
+__device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk) {
+    for (int t = 0; t < BMH_NTOP && top_edge(t) < w; ++t) {
+        Proc P = top_proc(d, t);
+        if (proc_next(P, m, bound)) walk_process(P, d, w, m, bound, h, stk);
+    }
+}
+
+// The main pass splits the walk in two.  Phase 1 (every element, every lane): the first point of
+// each relevant top strip; 99% die in the early-out of proc_next.  A survivor needs the ~60-level
+// descent of bmh_locate, which one lane would run alone while 63 wait -- so survivors are queued in
+// LDS and phase 2 drains the queue with one survivor per lane once enough have accumulated.
+struct QEntry { Proc P; uint64_t d; double w; };
+constexpr int K3_QCAP = 256;
+constexpr int K3_QDRAIN = 160;          // drain when at least this many are waiting
 
 __device__ uint64_t block_hmax(const uint64_t *h, uint32_t m, uint64_t *red) {
     const int tid = threadIdx.x;
@@ -416,18 +472,21 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_seed_kernel(BmhArgs a) {
             }
             double beta = 2.0 * (double)m * ((double)__logf((float)m) + 1.0) / wsum;
             for (;;) {
-                uint32_t e = tid; int sp = 0; uint64_t d = 0; double w = 0.;
+                uint32_t e = tid; int sp = 0, t = BMH_NTOP; uint64_t d = 0; double w = 0.;
                 uint64_t hm = block_hmax(h, m, sh.red);
                 for (;;) {                          // one process step per lane, then refresh the live bound
                     const double live = V(hm);
                     const double bound = live < beta ? live : beta;
                     bool more = true;
-                    if (sp == 0) {
-                        if (e < ne) {
-                            d = sh.key[e]; w = (double)sh.cnt[e]; e += K3_THREADS;
-                            Proc P; P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = d; P.i = 0; P.pad = 0;
+                    if (sp == 0) {                  // next top strip of the current element, else the next element
+                        if (!(t < BMH_NTOP && top_edge(t) < w)) {
+                            if (e < ne) { d = sh.key[e]; w = (double)sh.cnt[e]; e += K3_THREADS; t = 0; }
+                            else more = false;
+                        }
+                        if (more) {
+                            Proc P = top_proc(d, t++);
                             if (proc_next(P, m, bound)) stk[sp++] = P;
-                        } else more = false;
+                        }
                     } else {
                         const Proc P = stk[--sp];
                         if (P.x <= bound) bmh_locate(P, d, w, m, bound, h, stk, sp);
@@ -454,42 +513,69 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_seed_kernel(BmhArgs a) {
 // all other units: bound = the genome's certified bound at workgroup start
 __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
     __shared__ SharedK3 sh;
+    __shared__ QEntry queue[K3_QCAP];
+    __shared__ uint32_t qn;
     const int tid = threadIdx.x;
-    const uint32_t tb = blockIdx.x, m = a.m;
-    const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
-    if (nk == 0) return;
-    const uint32_t g = genome_of_bucket(a.g_boff, a.n, tb);
-    const uint32_t seed_tb = a.seed_bucket[g], seed_r = a.seed_round[g];
-    if (seed_tb == ~0u) return;                      // no element of this genome passes the threshold
-    if (a.redo_mode && !a.redo[g]) return;
-    uint64_t *h = a.h + (size_t)g * m;
+    const uint32_t m = a.m;
     const CountTab t{sh.key, sh.cnt, &sh.ones};
-    const uint64_t *kb = a.keys + o0;
-    uint32_t R = 1;
-    while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
     Proc stk[BMH_STACK];
-    double tw = 0.;
-    for (uint32_t r = 0; r < R; ++r) {
-        if (tb == seed_tb && r == seed_r) continue;
-        if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
-        const double bound = V(__hip_atomic_load(&a.hbound[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
-        for (uint32_t e = tid; e < ne; e += K3_THREADS) {
-            const uint64_t d = sh.key[e];
-            const double w = (double)sh.cnt[e];
-            tw += w;
-#ifndef K3_SKIP_WALK
-            walk_element(d, w, m, bound, h, stk);
-#endif
+    if (tid == 0) qn = 0;
+    __syncthreads();
+    // phase 2: one queued survivor per lane (P.pad carries the genome)
+    auto drain = [&]() {
+        const uint32_t n = qn < (uint32_t)K3_QCAP ? qn : (uint32_t)K3_QCAP;
+        for (uint32_t i = tid; i < n; i += K3_THREADS) {
+            const QEntry q = queue[i];
+            const uint32_t g = q.P.pad;
+            const double bound = V(__hip_atomic_load(&a.hbound[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (q.P.x <= bound) walk_process(q.P, q.d, q.w, m, bound, a.h + (size_t)g * m, stk);
         }
         __syncthreads();
+        if (tid == 0) qn = 0;
+        __syncthreads();
+    };
+    // persistent workgroups: the queue has to live across buckets
+    for (uint32_t tb = blockIdx.x; tb < a.TB; tb += gridDim.x) {
+        const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
+        if (nk == 0) continue;
+        const uint32_t g = genome_of_bucket(a.g_boff, a.n, tb);
+        const uint32_t seed_tb = a.seed_bucket[g], seed_r = a.seed_round[g];
+        if (seed_tb == ~0u) continue;                    // no element of this genome passes the threshold
+        if (a.redo_mode && !a.redo[g]) continue;
+        uint64_t *h = a.h + (size_t)g * m;
+        const uint64_t *kb = a.keys + o0;
+        uint32_t R = 1;
+        while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
+        double tw = 0.;
+        for (uint32_t r = 0; r < R; ++r) {
+            if (tb == seed_tb && r == seed_r) continue;
+            if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
+            const double bound = V(__hip_atomic_load(&a.hbound[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
+            for (uint32_t e = tid; e < ne; e += K3_THREADS) {
+                const uint64_t d = sh.key[e];
+                const double w = (double)sh.cnt[e];
+                tw += w;
+                for (int tt = 0; tt < BMH_NTOP && top_edge(tt) < w; ++tt) {
+                    Proc P = top_proc(d, tt);
+                    if (!proc_next(P, m, bound)) continue;
+                    const uint32_t slot = atomicAdd(&qn, 1u);
+                    if (slot < (uint32_t)K3_QCAP) { P.pad = g; queue[slot].P = P; queue[slot].d = d; queue[slot].w = w; }
+                    else walk_process(P, d, w, m, bound, h, stk);          // queue full: do it now
+                }
+            }
+            __syncthreads();
+            if (qn >= (uint32_t)K3_QDRAIN) drain();
+        }
+        // per-bucket total weight (integers: exact in any order); summed per genome by the verify
+        // kernel.  No per-workgroup tightening of hbound here: thousands of same-address atomics per
+        // genome serialise in L2 (measured 25 ms per 4e5 workgroups) and the guessed bound is already
+        // within ~2x of the final maximum.
+        tw = block_sum(tw, reinterpret_cast<double *>(sh.red));
+        if (tid == 0 && !a.redo_mode) a.tw_bucket[tb] = tw;
     }
-    // per-bucket total weight (integers: exact in any order); summed per genome by the verify kernel.
-    // No per-workgroup tightening of hbound here: thousands of same-address atomics per genome
-    // serialise in L2 (measured 25 ms per 4e5 workgroups) and the guessed bound is already within
-    // ~2x of the final maximum.
-    tw = block_sum(tw, reinterpret_cast<double *>(sh.red));
-    if (tid == 0 && !a.redo_mode) a.tw_bucket[tb] = tw;
+    __syncthreads();
+    drain();
 }
 
 // after the main pass: was every bound that pruned a point at least the final maximum register?
@@ -596,19 +682,22 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_sets_kernel(WsArgs a) {
         lo += w0;
         double beta = 2.0 * (double)m * ((double)__logf((float)m) + 1.0) / wsum;
         for (;;) {
-            uint64_t e = tid; int sp = 0; uint64_t d = 0; double w = 0.;
+            uint64_t e = tid; int sp = 0, t = BMH_NTOP; uint64_t d = 0; double w = 0.;
             uint64_t hm = block_hmax(h, m, red);
             for (;;) {
                 const double live = V(hm);
                 const double bound = live < beta ? live : beta;
                 bool more = true;
                 if (sp == 0) {
-                    bool got = false;
-                    while (e < cnt && !got) { got = ws_fetch(a, lo + e, d, w, a.status); e += K3_THREADS; }
-                    if (got) {
-                        Proc P; P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = d; P.i = 0; P.pad = 0;
+                    if (!(t < BMH_NTOP && top_edge(t) < w)) {
+                        bool got = false;
+                        while (e < cnt && !got) { got = ws_fetch(a, lo + e, d, w, a.status); e += K3_THREADS; }
+                        if (got) t = 0; else more = false;
+                    }
+                    if (more) {
+                        Proc P = top_proc(d, t++);
                         if (proc_next(P, m, bound)) stk[sp++] = P;
-                    } else more = false;
+                    }
                 } else {
                     const Proc P = stk[--sp];
                     if (P.x <= bound) bmh_locate(P, d, w, m, bound, h, stk, sp);
@@ -629,10 +718,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_sets_kernel(WsArgs a) {
             uint64_t d; double w;
             if (!ws_fetch(a, lo + e, d, w, a.status)) continue;
             tw += w;
-            int sp = 0;
-            Proc P; P.p = 0; P.q = BMH_LEVEL_MAX; P.x = 0.; P.rng = d; P.i = 0; P.pad = 0;
-            if (proc_next(P, m, bound)) stk[sp++] = P;
-            while (sp) { const Proc Q = stk[--sp]; if (Q.x <= bound) bmh_locate(Q, d, w, m, bound, hg, stk, sp); }
+            walk_element(d, w, m, bound, hg, stk);
         }
         tw = block_sum(tw, reinterpret_cast<double *>(red));
         if (tid == 0 && tw != 0.) atomicAdd(&a.tw[set], tw);
@@ -756,7 +842,8 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         if (hl + sizeof(SharedK3) > 48 * 1024)
             D2G_HIP(ctx, hipFuncSetAttribute((const void *)k3_bmh_seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
         if (n) hipLaunchKernelGGL(k3_bmh_seed_kernel, dim3((unsigned)n), dim3(K3_THREADS), hl, s, b);
-        if (TB) hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
+        const unsigned main_grid = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * 8);
+        if (TB) hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
         if (n) hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, b);
         // a guess that proved too small: repeat those genomes' main pass under the (now finite and
         // near-final) certified bound.  Registers only go down, so the repeat is idempotent.
@@ -765,7 +852,7 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         D2G_HIP(ctx, hipStreamSynchronize(s));
         if (nredo) {
             b.redo_mode = 1;
-            hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
+            hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
         }
         st->last_nredo = nredo;
     }
@@ -776,8 +863,8 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
 
 int k3_check_status(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s) {
 #ifdef K3_STATS
-    { unsigned long long h[8]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(k3_stats), sizeof(h));
-      std::fprintf(stderr, "K3_STATS levels=%llu next_early=%llu next_full=%llu push=%llu elems=%llu locate=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+    { unsigned long long h[16]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(k3_stats), sizeof(h));
+      std::fprintf(stderr, "K3_STATS levels=%llu next_early=%llu next_full=%llu push=%llu elems=%llu locate=%llu | ticks(100MHz) meta=%llu count=%llu compact=%llu walk=%llu sync=%llu tail=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13]);
       std::memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(k3_stats), h, sizeof(h)); }
 #endif
     int status = 0;

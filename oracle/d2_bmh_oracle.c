@@ -139,14 +139,28 @@ void d2o_bmh_reset(d2o_bmh *b) {
 double d2o_bmh_total_weight(const d2o_bmh *b) { return b->total_weight; }
 void d2o_bmh_data(const d2o_bmh *b, double *sig) { memcpy(sig, b->tree + b->leaves, b->m * sizeof(double)); }
 
+/* BMH-D2G top level: [0, 2^53) is cut into 65 fixed strips -- 16 unit strips [t, t+1) for the
+ * small integer weights k-mer counts mostly are, then the octaves [2^j, 2^(j+1)) up to 2^53 -- and
+ * each strip is an independent Poisson process from time 0 with its own generator (a Poisson
+ * process over a union of disjoint strips IS the superposition of independent ones, so no root
+ * point is needed).  Inside a strip the published lazy bisection applies, over double bit patterns. */
+#define D2O_BMH_NTOP 65
+static inline double top_edge(int t) { return t <= 16 ? (double)t : ldexp(1.0, t - 12); }
+
 uint64_t d2o_bmh_update(d2o_bmh *b, uint64_t id, double w) {
     if (!(w > 0.) || !(w <= 0x1p53)) return 0;
     b->total_weight += w;
     uint64_t steps = 0;
     b->nheap = 0;
-    proc_t P = { 0, D2O_BMH_LEVEL_MAX, 0., id, 0 };
-    proc_next(&P, b->m);
-    for (;;) {
+    for (int t = 0; t < D2O_BMH_NTOP && top_edge(t) < w; ++t) {
+        proc_t P = { d2u(top_edge(t)), d2u(top_edge(t + 1)), 0.,
+                     id ^ ((uint64_t)(t + 1) * 0xA0761D6478BD642Full) ^ 0x8EBC6AF09C88C6E3ull, 0 };
+        proc_next(&P, b->m);
+        ++steps;
+        if (P.x <= hmax(b)) heap_push(b, &P);
+    }
+    while (b->nheap) {
+        proc_t P = heap_pop(b);
         if (P.x > hmax(b)) break;                  /* time-ordered: everything pending is later still */
         /* locate the point (P.x, P.i): narrow P to the half that holds it, down to one level */
         int counted = 0, relevant = 1;
@@ -173,8 +187,6 @@ uint64_t d2o_bmh_update(d2o_bmh *b, uint64_t id, double w) {
             proc_next(&P, b->m);
             if (P.x <= hmax(b)) heap_push(b, &P);
         }
-        if (!b->nheap) break;
-        P = heap_pop(b);
     }
     return steps;
 }

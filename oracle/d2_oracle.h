@@ -147,7 +147,7 @@ size_t d2o_default_batchsize(size_t batch_size, size_t S, unsigned nthreads);
  * polynomial in plain IEEE double ops (no FMA, no libm) so CPU and GPU agree bit for bit */
 double d2o_dlog(double u);
 /* one RNG step of the process generator (== d2o_wyhash64_stateless) is reused */
-#define D2O_BMH_LEVEL_MAX 0x4340000000000000ull      /* bit pattern of 2^53: weights in (0, 2^53] */
+#define D2O_BMH_WEIGHT_MAX 0x1p53                  /* weights in (0, 2^53] */
 
 typedef struct d2o_bmh d2o_bmh;
 d2o_bmh *d2o_bmh_create(size_t sketchsize);

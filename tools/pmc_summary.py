@@ -22,7 +22,7 @@ def main():
     res = {}
     for k, cs in agg.items():
         short = k.split("(")[0].split("::")[-1].split("<")[0].strip()
-        if not any(x in k for x in ("k1_oph", "k2_", "bs_rank", "bs_planes")):
+        if not any(x in k for x in ("k1_oph", "k2_", "bs_rank", "bs_planes", "k3_")):
             continue
         e = {c: sum(v) / len(v) for c, v in cs.items()}
         e["dispatches"] = max(len(v) for v in cs.values())
