@@ -74,6 +74,7 @@ std::string Options::to_string() const {    // src/d2.cpp:10-43 (fields that exi
     pos += std::snprintf(buf + pos, sizeof buf - pos, ";%s", "parsebyfile");
     pos += std::snprintf(buf + pos, sizeof buf - pos, ";trimchr");
     pos += std::snprintf(buf + pos, sizeof buf - pos, ";sketchsize:%zu", sketchsize);
+    if (count_threshold > 0) pos += std::snprintf(buf + pos, sizeof buf - pos, ";%u", count_threshold);
     pos += std::snprintf(buf + pos, sizeof buf - pos, ";sketchtype:%s",
                          kmer_result == ONE_PERM ? "onepermsetsketch"
                          : (sspace == SPACE_SET ? "fullsetsketch" : sspace == SPACE_MULTISET ? "bagminhash" : "probminhash"));
@@ -107,6 +108,7 @@ int parse_options(int argc, char **argv, Options &o) {
         {"verbose", no_argument, 0, 'v'}, {"presketched", no_argument, 0, OPT_PRESKETCHED},
         {"multiset", no_argument, 0, OPT_MULTISET}, {"bagminhash", no_argument, 0, OPT_MULTISET}, {"bmh", no_argument, 0, OPT_MULTISET},
         {"BMH", no_argument, 0, OPT_MULTISET},
+        {"count-threshold", required_argument, 0, 'm'}, {"threshold", required_argument, 0, 'm'},
         {0, 0, 0, 0}};
     // every other valid reference flag is recognised but outside the hot-path scope
     std::vector<struct option> all(longopts, longopts + sizeof(longopts) / sizeof(longopts[0]) - 1);
@@ -152,10 +154,8 @@ int parse_options(int argc, char **argv, Options &o) {
             case OPT_SEED: o.seedseed = std::strtoull(optarg, 0, 10); break;
             case OPT_BATCH: o.batch_size = std::strtoull(optarg, 0, 10); break;
             case OPT_PRESKETCHED: o.presketched = true; break;
-            case OPT_MULTISET: case 'B':
-                std::fprintf(stderr, "dashing2 (MI355X): --multiset/BagMinHash sketching is outside this build's hot-path scope "
-                                     "(its arithmetic lives in the absent sketch/bmh.h); comparing presketched .bmh files works.\n");
-                return 1 + 1;
+            case OPT_MULTISET: case 'B': o.sspace = SPACE_MULTISET; break;         // options.h:111
+            case 'm': o.count_threshold = unsigned(std::atoi(optarg)); break;      // options.h:352
             case OPT_HELP: case 'h': case '?': o.is_cmp ? cmp_usage() : sketch_usage(); return 1 + 1;
             case OPT_UNSUPPORTED:
                 std::fprintf(stderr, "dashing2 (MI355X): option --%s is outside the hot-path scope of this build "
@@ -184,6 +184,12 @@ int parse_options(int argc, char **argv, Options &o) {
         for (std::string l; std::getline(ifs, l);) o.paths.push_back(l);
     }
     o.nq = o.paths.size() - nref;
+    if (o.sspace != SPACE_SET && o.kmer_result == ONE_PERM) o.kmer_result = FULL_SETSKETCH;   // sketch_main.cpp:124-127
+    if (o.sspace == SPACE_SET && o.count_threshold > 0) {
+        std::fprintf(stderr, "dashing2 (MI355X): -m/--count-threshold with set sketches (OPH min-count filtering, oph.h:186-205) "
+                             "is outside this build's hot-path scope; it is supported with --multiset.\n");
+        return 1 + 1;
+    }
     if (o.k > 32) {
         std::fprintf(stderr, "dashing2 (MI355X): k = %d > 32 uses the reference's rolling-hash encoder "
                              "(fastxsketch.cpp:420), which is outside this build's hot-path scope.\n", o.k);

@@ -22,6 +22,7 @@ struct Options {
     size_t sketchsize = 1024;
     uint64_t seedseed = 0;
     size_t batch_size = 0;
+    unsigned count_threshold = 0;         // -m/--threshold/--count-threshold (d2.h:103); --multiset only in this build
     std::string ffile, qfile, outfile, cmpout, outprefix;
     OutputKind ok = SYMMETRIC_ALL_PAIRS;
     OutputFormat of = HUMAN_READABLE;

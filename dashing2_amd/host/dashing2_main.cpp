@@ -64,7 +64,7 @@ std::string trim_folder(const std::string &s) {          // src/enums.cpp:22-26
 }
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// src/fastxmerge.cpp:70-120 for SPACE_SET / ONE_PERM, DNA, unspaced
+// src/fastxmerge.cpp:70-120 for DNA, unspaced, w <= k: OPH set sketches and exact-counting multiset sketches
 std::string makedest(const Options &o, const std::string &path) {
     std::string ret = path.substr(0, path.find_first_of(' '));
     if (!o.outprefix.empty()) ret = o.outprefix + '/' + trim_folder(path);
@@ -72,9 +72,11 @@ std::string makedest(const Options &o, const std::string &path) {
     if (o.canon) ret += ".rc_canon";
     ret += ".sketchsize" + std::to_string(o.sketchsize);
     ret += ".k" + std::to_string(o.k);
-    ret += ".SetSpace";                                   // to_string(SPACE_SET), src/enums.cpp:40-46
+    if (o.count_threshold > 0) ret += ".ct_threshold" + std::to_string(int(o.count_threshold));   // fastxmerge.cpp:91-95
+    if (o.sspace != SPACE_SET) ret += ".ExactCounting";   // to_string(ct()), src/enums.cpp:47; fastxmerge.cpp:96-100
+    ret += o.sspace == SPACE_SET ? ".SetSpace" : ".MultisetSpace";   // to_string(sspace), src/enums.cpp:40-46
     ret += ".DNA";                                        // bns::to_string(rht_) (absent bonsai; expected "DNA")
-    ret += ".opss";                                       // to_suffix, src/enums.cpp:28-38
+    ret += o.sspace == SPACE_SET ? ".opss" : ".bmh";      // to_suffix, src/enums.cpp:28-38
     return ret;
 }
 
@@ -190,14 +192,24 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
         if (!r.sp) continue;                                                // error recorded; drain the queue
         const size_t b = groups[r.g].first, e = groups[r.g].second, n = e - b;
         const double t1 = now();
-        regs.resize(n * m);
-        const int rc = d2g_sketcher_run(sk, d2g_seqpack_packed(r.sp), d2g_seqpack_packed_bytes(r.sp), d2g_seqpack_run_start(r.sp),
-                                        d2g_seqpack_run_len(r.sp), d2g_seqpack_nruns(r.sp), d2g_seqpack_genome_run_off(r.sp), n, o.k,
-                                        o.canon, xormask, S, regs.data());
-        check(ctx, rc, "d2g_sketcher_run");
-        const double t2 = now();
         sigs.resize(n * S); cards.resize(n);
-        check(ctx, d2g_oph_finalize(regs.data(), n, m, S, sigs.data(), cards.data(), 1), "d2g_oph_finalize");
+        double t2;
+        if (o.sspace == SPACE_MULTISET) {
+            // fastxsketch.cpp:425-445: Counter -> BagMinHash; cardinality = total weight, signature = data()[0..S)
+            const int rc = d2g_sketcher_run_bmh(sk, d2g_seqpack_packed(r.sp), d2g_seqpack_packed_bytes(r.sp), d2g_seqpack_run_start(r.sp),
+                                                d2g_seqpack_run_len(r.sp), d2g_seqpack_nruns(r.sp), d2g_seqpack_genome_run_off(r.sp), n,
+                                                o.k, o.canon, xormask, S, double(o.count_threshold), sigs.data(), cards.data());
+            check(ctx, rc, "d2g_sketcher_run_bmh");
+            t2 = now();
+        } else {
+            regs.resize(n * m);
+            const int rc = d2g_sketcher_run(sk, d2g_seqpack_packed(r.sp), d2g_seqpack_packed_bytes(r.sp), d2g_seqpack_run_start(r.sp),
+                                            d2g_seqpack_run_len(r.sp), d2g_seqpack_nruns(r.sp), d2g_seqpack_genome_run_off(r.sp), n, o.k,
+                                            o.canon, xormask, S, regs.data());
+            check(ctx, rc, "d2g_sketcher_run");
+            t2 = now();
+            check(ctx, d2g_oph_finalize(regs.data(), n, m, S, sigs.data(), cards.data(), 1), "d2g_oph_finalize");
+        }
         for (size_t t = b; t < e; ++t) {
             const size_t i = todo[t];
             std::memcpy(&res.signatures[i * S], &sigs[(t - b) * S], S * sizeof(double));   // fastxsketch.cpp:610

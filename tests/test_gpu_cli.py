@@ -180,3 +180,48 @@ def test_dist_tool_single_rank(oracle, genomes, tmp_path):
                        capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(b1, "rb").read() == open(b2, "rb").read()
+
+
+def test_cli_multiset_sketch_and_cmp(oracle, genomes, tmp_path):
+    """BASELINE config 5 shape at test size: `dashing2 sketch --multiset` (exact k-mer counts ->
+    BagMinHash on the GPU) then all-pairs: stacked file, names, .bmh cache files and the distance
+    matrix must be byte-identical to the oracle pipeline (src/fastxsketch.cpp:425-445 ;
+    src/cmp_core.cpp:495-517 for the multiset-space compare)."""
+    from oracle import textfmt
+    k, S = 21, 256
+    out = tmp_path / "ms.bin"
+    phy = tmp_path / "ms.phylip"
+    r = _run(["sketch", "--multiset", "-k", str(k), "-S", str(S), "-p", "4", "-o", str(out), "--cmpout", str(phy), "--phylip",
+              "--cache", "--outprefix", str(tmp_path)] + genomes)
+    esigs, ecards, _ = oracle.bmh_sketch_files(genomes, k, S)
+    N = len(genomes)
+    raw = np.fromfile(out, np.uint8)
+    exp = np.concatenate([np.array([N, S], np.uint64).view(np.uint8), ecards.view(np.uint8), esigs.reshape(-1).view(np.uint8)])
+    assert raw.tobytes() == exp.tobytes()
+    # F-a cache naming for multiset sketches (fastxmerge.cpp:70-120, enums.cpp:28-47)
+    for i, g in enumerate(genomes):
+        dest = tmp_path / (os.path.basename(g) + f".rc_canon.sketchsize{S}.k{k}.ExactCounting.MultisetSpace.DNA.bmh")
+        blob = np.fromfile(dest, np.float64)
+        assert blob[0] == ecards[i]
+        np.testing.assert_array_equal(blob[1:].view(np.uint64), esigs[i].view(np.uint64))
+    # multiset-space compare: from the equality count and the total weights
+    neq = oracle.eqcounts_ut(esigs)
+    iu = np.triu_indices(N, 1)
+    exp_d = np.array([oracle.compare_from_neq(int(c), S, ecards[i], ecards[j], oracle.SIMILARITY, k)
+                      for c, i, j in zip(neq, iu[0], iu[1])], np.float32)
+    assert open(phy).read() == textfmt.render_symmetric(genomes, exp_d, phylip=True)
+    assert exp_d.max() > 0.5
+    # cmp --presketched picks the space up from the cache suffix; count threshold changes names and sketches
+    b = tmp_path / "d.bin"
+    caches = [str(tmp_path / (os.path.basename(g) + f".rc_canon.sketchsize{S}.k{k}.ExactCounting.MultisetSpace.DNA.bmh")) for g in genomes]
+    _run(["cmp", "--presketched", "-k", str(k), "--binary-output", "--cmpout", str(b)] + caches)
+    np.testing.assert_array_equal(np.fromfile(b, np.float32).view(np.uint32), exp_d.view(np.uint32))
+    out2 = tmp_path / "ms2.bin"
+    _run(["sketch", "--multiset", "-m", "1", "-k", "7", "-S", "64", "-o", str(out2)] + genomes[:3])
+    esigs2, ecards2, _ = oracle.bmh_sketch_files(genomes[:3], 7, 64, count_threshold=1.0)
+    raw2 = np.fromfile(out2, np.uint8)
+    exp2 = np.concatenate([np.array([3, 64], np.uint64).view(np.uint8), ecards2.view(np.uint8), esigs2.reshape(-1).view(np.uint8)])
+    assert raw2.tobytes() == exp2.tobytes()
+    # OPH min-count filtering stays out of scope
+    r = subprocess.run([EXE, "sketch", "-m", "2", "-k", "21"] + genomes[:2], capture_output=True)
+    assert r.returncode != 0 and b"outside this build" in r.stderr
