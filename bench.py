@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--no-sketch", action="store_true", help="skip the secondary K1 measurement")
     ap.add_argument("--sketch-genomes", type=int, default=1000)
     ap.add_argument("--sketch-len", type=int, default=5_000_000)
+    ap.add_argument("--no-multiset", action="store_true", help="skip the secondary K3 (--multiset / BagMinHash) measurement")
+    ap.add_argument("--multiset-genomes", type=int, default=1000)
+    ap.add_argument("--multiset-batch", type=int, default=250, help="genomes per d2g_bmh_sketch_dev call (8 B of key per k-mer live in HBM)")
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "broadcast"],
                     help="N>1: row-sharded sketches + all-to-all/all-gather of the compact operand (default), "
                          "or rank-0 sketches broadcast whole")
@@ -275,6 +278,57 @@ def main():
         assert ((chk & np.uint64(m - 1)) == np.arange(m, dtype=np.uint64)).all()
         del packed, regs_dev
 
+    # ---- secondary: K3 --multiset sketch construction (BASELINE config 5: k=21, S=2048, exact k-mer
+    # counts -> BagMinHash), packed bases resident in HBM
+    multiset = None
+    if not args.no_multiset:
+        n_g, L, k3, S3 = args.multiset_genomes, args.sketch_len, 21, 2048
+        n_g = max(1, n_g // world * world) // world          # inputs are sharded one-per-rank, no collectives
+        nb = max(1, min(args.multiset_batch, n_g))
+        n_g = n_g // nb * nb if n_g >= nb else n_g
+        Lb = ((L + 3) // 4 + 63) // 64 * 64
+        packed = torch.randint(0, 256, (n_g * Lb + 64,), dtype=torch.uint8, device=dev)
+        plan = ctx.oph_plan(np.arange(nb, dtype=np.uint64) * np.uint64(Lb * 4), np.full(nb, L, np.uint32),
+                            np.arange(nb + 1, dtype=np.uint64), k3)
+        sig3 = torch.empty((n_g, S3), dtype=torch.float64, device=dev)
+        tw3 = torch.empty((n_g,), dtype=torch.float64, device=dev)
+
+        def k3_pass():
+            for b0 in range(0, n_g, nb):
+                ctx.bmh_sketch_dev(plan, packed.data_ptr() + b0 * Lb, S3, sig3[b0:].data_ptr(), tw3[b0:].data_ptr(), stream=stream)
+
+        k3_pass()
+        barrier()
+        ctx.set_timing(True)
+        ctx.kernel_ms("k3")
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            k3_pass()
+        barrier()
+        mdt = time.perf_counter() - t0
+        ctx.set_timing(False)
+        ncalls, k3_ms, _ = ctx.kernel_ms("k3")
+        if world > 1:
+            t = torch.tensor([mdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mdt = float(t.item())
+        k3_bytes = nb * ((L + 3) // 4 + 8 * S3 + 8)
+        ach = k3_bytes / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
+        assert bool(torch.isfinite(sig3).all()) and bool((tw3 == float(L - k3 + 1)).all())
+        multiset = {"metric": "multiset sketch input bases/s (K3: exact k-mer counts + BagMinHash, packed bases resident in HBM)",
+                    "value": n_g * L * world / (mdt / reps), "unit": "bases/s", "ms_per_step": mdt / reps * 1e3,
+                    "config": {"workload": f"BASELINE config 5: {n_g * world} synthetic random genomes x {L} bp, k={k3}, S={S3}, "
+                                           f"--multiset (BagMinHash), canonical, {nb} genomes per call"},
+                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "k3 chain (hist, scan, scatter, bmh_seed, bmh_main, verify)",
+                                 "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
+                                 "note": "per call of %d genomes; the chain also writes and re-reads 8 B of key per k-mer "
+                                         "(bucketed multi-split), which the compulsory-byte figure does not count" % nb},
+                    "parity": "bit-exact vs oracle/d2_bmh_oracle.c (published BagMinHash under the BMH-D2G spec; the "
+                              "reference's sketch/bmh.h is absent: parity unpinned against a real dashing2 binary)"}
+        del packed, sig3, tw3
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sig_np, cards_np, S, args.cpu_seconds)
@@ -291,7 +345,7 @@ def main():
                        "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + pair kernel w/ fused epilogue; row-sharded sketches resident in HBM"
                                 if sharded else "RCCL broadcast (n_gpus>1) + prepare + pair kernel w/ fused epilogue; sketches resident in HBM"),
                        "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count"},
-            "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "sketch": sketch,
+            "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "sketch": sketch, "multiset_sketch": multiset,
         }
         print(json.dumps(line))
     if eng is not None:
