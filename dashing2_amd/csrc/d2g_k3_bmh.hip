@@ -51,6 +51,7 @@ struct K3Args {
     uint64_t xormask;
     const uint32_t *g_bbits;   // [n]   log2(#buckets) of genome g
     const uint32_t *g_boff;    // [n+1] first global bucket of genome g
+    const uint64_t *g_koff;    // [n+1] first key of genome g in `keys` (host prefix of the k-mer counts)
     uint32_t *bucket_cnt;      // [TB]
     uint64_t *bucket_off;      // [TB+1] exclusive prefix of bucket_cnt
     uint64_t *cursor;          // [TB]   scatter cursors (copy of bucket_off)
@@ -77,28 +78,28 @@ __global__ __launch_bounds__(K1_THREADS) void k3_hist_kernel(K3Args a) {
         if (hist[i]) atomicAdd(&a.bucket_cnt[boff + i], hist[i]);
 }
 
-// exclusive prefix of bucket_cnt (single workgroup; TB <= a few million)
-__global__ __launch_bounds__(1024) void k3_scan_kernel(K3Args a) {
-    __shared__ uint64_t part[1024];
-    const uint32_t tid = threadIdx.x, TB = a.TB;
-    const uint32_t per = (TB + 1023) / 1024;
-    const uint32_t lo = min(TB, tid * per), hi = min(TB, lo + per);
-    uint64_t s = 0;
-    for (uint32_t i = lo; i < hi; ++i) s += a.bucket_cnt[i];
-    part[tid] = s;
+// exclusive prefix of bucket_cnt: one workgroup per genome scans its <= 4096 buckets (coalesced, 16 per
+// lane); the genome's first key offset comes from the host, which knows every genome's k-mer count
+__global__ __launch_bounds__(K3_THREADS) void k3_scan_kernel(K3Args a) {
+    __shared__ uint32_t wsum[K3_THREADS / 64];
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    const uint32_t b0 = a.g_boff[g], B = a.g_boff[g + 1] - b0;
+    const uint32_t per = (B + K3_THREADS - 1) / K3_THREADS;             // <= 16
+    const uint32_t lo = min(B, tid * per), hi = min(B, lo + per);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += a.bucket_cnt[b0 + i];
+    uint32_t incl = s;                                                  // inclusive scan across the wave, then the 4 waves
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((tid & 63) >= (uint32_t)o) incl += v; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        const uint64_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint64_t run = tid ? part[tid - 1] : 0;
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
+    uint64_t run = a.g_koff[g] + wbase + (incl - s);
     for (uint32_t i = lo; i < hi; ++i) {
-        a.bucket_off[i] = run; a.cursor[i] = run;
-        run += a.bucket_cnt[i];
+        a.bucket_off[b0 + i] = run; a.cursor[b0 + i] = run;
+        run += a.bucket_cnt[b0 + i];
     }
-    if (tid == 1023) a.bucket_off[TB] = part[1023];
+    if (g == gridDim.x - 1 && tid == K3_THREADS - 1) a.bucket_off[a.TB] = a.g_koff[g + 1];
 }
 
 __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
@@ -126,6 +127,20 @@ __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
     });
 }
 
+#ifdef K3_STATS
+__device__ unsigned long long k3_stats[16];
+#ifdef K3_TIMING_ONLY
+#define K3_STAT(i)
+#else
+#define K3_STAT(i) atomicAdd(&k3_stats[i], 1ull)
+#endif
+#define K3_T0() long long t0_ = wall_clock64()
+#define K3_T(i) do { if (threadIdx.x == 0) { const long long t1_ = wall_clock64(); atomicAdd(&k3_stats[i], (unsigned long long)(t1_ - t0_)); t0_ = t1_; } } while (0)
+#else
+#define K3_STAT(i)
+#define K3_T0()
+#define K3_T(i)
+#endif
 // ---------------------------------------------------------------------------------------------
 // exact counting of one bucket round into the LDS table
 // ---------------------------------------------------------------------------------------------
@@ -141,30 +156,48 @@ static_assert(K3_TAB == 1 << 11, "tab_hash takes the top 11 bits");
 // keys of round r of R (R a power of two: low key bits select the round); returns false on overflow
 __device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, uint32_t R, uint32_t r) {
     const int tid = threadIdx.x;
+    K3_T0();
     for (int s = tid; s < K3_TAB; s += K3_THREADS) { t.key[s] = K3_EMPTY; t.cnt[s] = 0; }
     if (tid == 0) *t.ones = 0;
     __syncthreads();
+    K3_T(1);
     bool ok = true;
-    for (uint64_t i = tid; i < n; i += K3_THREADS) {
-        const uint64_t key = kb[i];
-        if (R > 1 && ((uint32_t)key & (R - 1)) != r) continue;
-        if (key == K3_EMPTY) { atomicAdd(t.ones, 1u); continue; }
-        uint32_t s = tab_hash(key);
-        int probes = 0;
-        for (;;) {
-            const uint64_t cur = t.key[s];
-            if (cur == key) break;
-            if (cur == K3_EMPTY) {
-                const uint64_t prev = atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)K3_EMPTY, (unsigned long long)key);
-                if (prev == K3_EMPTY || prev == key) break;
-            }
-            s = (s + 1) & (K3_TAB - 1);
-            if (++probes >= K3_TAB) { ok = false; break; }
+    // keys are fetched K3_KPF per lane at a time BEFORE the probe chains: with the load inside the
+    // probing loop every key exposed a full HBM/L2 round trip (measured 25 us per 1220-key bucket)
+    constexpr int K3_KPF = 6;
+    for (uint64_t base = 0; base < n && ok; base += (uint64_t)K3_KPF * K3_THREADS) {
+        uint64_t kreg[K3_KPF];
+#pragma unroll
+        for (int j = 0; j < K3_KPF; ++j) {
+            const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
+            kreg[j] = i < n ? kb[i] : 0;
         }
-        if (!ok) break;
-        atomicAdd(&t.cnt[s], 1u);
+#pragma unroll
+        for (int j = 0; j < K3_KPF; ++j) {
+            const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
+            const uint64_t key = kreg[j];
+            if (i >= n || !ok) continue;
+            if (R > 1 && ((uint32_t)key & (R - 1)) != r) continue;
+            if (key == K3_EMPTY) { atomicAdd(t.ones, 1u); continue; }
+            uint32_t s = tab_hash(key);
+            int probes = 0;
+            for (;;) {
+                const uint64_t cur = t.key[s];
+                if (cur == key) break;
+                if (cur == K3_EMPTY) {
+                    const uint64_t prev = atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)K3_EMPTY, (unsigned long long)key);
+                    if (prev == K3_EMPTY || prev == key) break;
+                }
+                s = (s + 1) & (K3_TAB - 1);
+                if (++probes >= K3_TAB) { ok = false; break; }
+            }
+            if (ok) atomicAdd(&t.cnt[s], 1u);
+        }
     }
-    return !__syncthreads_or(!ok);
+    K3_T(2);
+    const bool res = !__syncthreads_or(!ok);
+    K3_T(3);
+    return res;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -210,20 +243,6 @@ __device__ __forceinline__ double dlog(double u) {
 // advance to the process's next point; false = certainly later than `bound` (drop the process).
 // Early-out: -log(u) >= 1 - u, so (1-u)/width > bound already proves x > bound without the log
 // and the division (the 1e-9 margin dwarfs every rounding involved).
-#ifdef K3_STATS
-__device__ unsigned long long k3_stats[16];
-#ifdef K3_TIMING_ONLY
-#define K3_STAT(i)
-#else
-#define K3_STAT(i) atomicAdd(&k3_stats[i], 1ull)
-#endif
-#define K3_T0() long long t0_ = wall_clock64()
-#define K3_T(i) do { if (threadIdx.x == 0) { const long long t1_ = wall_clock64(); atomicAdd(&k3_stats[i], (unsigned long long)(t1_ - t0_)); t0_ = t1_; } } while (0)
-#else
-#define K3_STAT(i)
-#define K3_T0()
-#define K3_T(i)
-#endif
 __device__ __forceinline__ bool proc_next(Proc &P, uint32_t m, double bound) {
     const double width = V(P.q) - V(P.p);
     const uint64_t r1 = wy_next(P.rng);
@@ -359,7 +378,8 @@ __device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, d
 // each relevant top strip; 99% die in the early-out of proc_next.  A survivor needs the ~60-level
 // descent of bmh_locate, which one lane would run alone while 63 wait -- so survivors are queued in
 // LDS and phase 2 drains the queue with one survivor per lane once enough have accumulated.
-struct QEntry { Proc P; uint64_t d; double w; };
+struct QEntry { uint64_t d; double w; uint32_t t, g; };     // strip t of element (d, w) of genome g: the survivor's
+                                                             // process is regenerated in phase 2 (24 B instead of 56)
 constexpr int K3_QCAP = 256;
 constexpr int K3_QDRAIN = 160;          // drain when at least this many are waiting
 
@@ -405,6 +425,7 @@ struct BmhArgs {
     uint32_t *redo;          // [n] 1 = the guess was too small: the main pass must be repeated under a certified bound
     uint32_t *nredo;         // [1]
     int redo_mode;
+    uint32_t round_keys;     // K3_ROUND_KEYS; D2G_K3_ROUND_KEYS lowers it (tests force multi-round buckets on small inputs)
     double guess_scale;      // 1.0; D2G_K3_GUESS_SCALE overrides it (tests force the verify/redo path with a tiny value)
     int *status;
     // optional R11 output (k3_count_kernel): distinct (key,count) written in place of the bucket
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_seed_kernel(BmhArgs a) {
         if (nk == 0) continue;
         const uint64_t *kb = a.keys + o0;
         uint32_t R = 1;
-        while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
+        while ((uint64_t)R * a.round_keys < nk) R <<= 1;
         for (uint32_t r = 0; r < R; ++r) {
             if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
             // weight of this unit's elements -> first guess of the bound: registers fill at rate W/m each
@@ -521,37 +542,54 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
     Proc stk[BMH_STACK];
     if (tid == 0) qn = 0;
     __syncthreads();
-    // phase 2: one queued survivor per lane (P.pad carries the genome)
+    // phase 2: one queued survivor per lane
     auto drain = [&]() {
         const uint32_t n = qn < (uint32_t)K3_QCAP ? qn : (uint32_t)K3_QCAP;
         for (uint32_t i = tid; i < n; i += K3_THREADS) {
             const QEntry q = queue[i];
-            const uint32_t g = q.P.pad;
-            const double bound = V(__hip_atomic_load(&a.hbound[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (q.P.x <= bound) walk_process(q.P, q.d, q.w, m, bound, a.h + (size_t)g * m, stk);
+            const double bound = V(__hip_atomic_load(&a.hbound[q.g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            Proc P = top_proc(q.d, (int)q.t);
+            if (proc_next(P, m, bound)) walk_process(P, q.d, q.w, m, bound, a.h + (size_t)q.g * m, stk);
         }
         __syncthreads();
         if (tid == 0) qn = 0;
         __syncthreads();
     };
     // persistent workgroups: the queue has to live across buckets
-    for (uint32_t tb = blockIdx.x; tb < a.TB; tb += gridDim.x) {
-        const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
-        if (nk == 0) continue;
-        const uint32_t g = genome_of_bucket(a.g_boff, a.n, tb);
-        const uint32_t seed_tb = a.seed_bucket[g], seed_r = a.seed_round[g];
-        if (seed_tb == ~0u) continue;                    // no element of this genome passes the threshold
-        if (a.redo_mode && !a.redo[g]) continue;
+    K3_T0();
+    // each workgroup owns a contiguous range of buckets: the genome (and with it seed unit, bound,
+    // registers) changes rarely and is tracked incrementally -- a binary search plus four dependent
+    // scalar loads per bucket cost 16 us of exposed latency per bucket
+    const uint32_t per = (a.TB + gridDim.x - 1) / gridDim.x;
+    const uint32_t tb_lo = blockIdx.x * per, tb_hi = tb_lo + per < a.TB ? tb_lo + per : a.TB;
+    if (tb_lo >= tb_hi) return;
+    uint32_t g = genome_of_bucket(a.g_boff, a.n, tb_lo), g_end = a.g_boff[g + 1];
+    uint32_t seed_tb = a.seed_bucket[g], seed_r = a.seed_round[g];
+    bool skip_g = seed_tb == ~0u || (a.redo_mode && !a.redo[g]);
+    uint64_t o_next = a.bucket_off[tb_lo];
+    for (uint32_t tb = tb_lo; tb < tb_hi; ++tb) {
+        const uint64_t o0 = o_next;
+        o_next = a.bucket_off[tb + 1];
+        const uint64_t nk = o_next - o0;
+        while (tb >= g_end) {
+            ++g; g_end = a.g_boff[g + 1];
+            seed_tb = a.seed_bucket[g]; seed_r = a.seed_round[g];
+            skip_g = seed_tb == ~0u || (a.redo_mode && !a.redo[g]);     // no element passes the threshold / nothing to redo
+        }
+        if (nk == 0 || skip_g) continue;
         uint64_t *h = a.h + (size_t)g * m;
         const uint64_t *kb = a.keys + o0;
         uint32_t R = 1;
-        while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
+        while ((uint64_t)R * a.round_keys < nk) R <<= 1;
         double tw = 0.;
+        K3_T(8);
         for (uint32_t r = 0; r < R; ++r) {
             if (tb == seed_tb && r == seed_r) continue;
             if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
+            K3_T(9);
             const double bound = V(__hip_atomic_load(&a.hbound[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
+            K3_T(10);
             for (uint32_t e = tid; e < ne; e += K3_THREADS) {
                 const uint64_t d = sh.key[e];
                 const double w = (double)sh.cnt[e];
@@ -560,12 +598,15 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
                     Proc P = top_proc(d, tt);
                     if (!proc_next(P, m, bound)) continue;
                     const uint32_t slot = atomicAdd(&qn, 1u);
-                    if (slot < (uint32_t)K3_QCAP) { P.pad = g; queue[slot].P = P; queue[slot].d = d; queue[slot].w = w; }
+                    if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
                     else walk_process(P, d, w, m, bound, h, stk);          // queue full: do it now
                 }
             }
+            K3_T(11);
             __syncthreads();
+            K3_T(12);
             if (qn >= (uint32_t)K3_QDRAIN) drain();
+            K3_T(13);
         }
         // per-bucket total weight (integers: exact in any order); summed per genome by the verify
         // kernel.  No per-workgroup tightening of hbound here: thousands of same-address atomics per
@@ -573,6 +614,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
         // within ~2x of the final maximum.
         tw = block_sum(tw, reinterpret_cast<double *>(sh.red));
         if (tid == 0 && !a.redo_mode) a.tw_bucket[tb] = tw;
+        K3_T(14);
     }
     __syncthreads();
     drain();
@@ -606,7 +648,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_count_kernel(BmhArgs a) {
     const CountTab t{sh.key, sh.cnt, &sh.ones};
     const uint64_t *kb = a.keys + o0;
     uint32_t R = 1;
-    while ((uint64_t)R * K3_ROUND_KEYS < nk) R <<= 1;
+    while ((uint64_t)R * a.round_keys < nk) R <<= 1;
     for (uint32_t r = 0; r < R; ++r) {
         if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
         const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
@@ -736,6 +778,7 @@ uint32_t ceil_log2(uint64_t x) { uint32_t b = 0; while ((1ull << b) < x) ++b; re
 struct d2g_k3_state {
     d2g_ctx *ctx = nullptr;
     uint32_t *d_gtab = nullptr; size_t cap_gtab = 0;        // g_bbits [n] + g_boff [n+1]
+    uint64_t *d_koff = nullptr; size_t cap_koff = 0;        // [n+1]
     uint32_t *d_bucket_cnt = nullptr; size_t cap_bcnt = 0;
     uint64_t *d_bucket_off = nullptr; size_t cap_boff = 0;
     uint64_t *d_cursor = nullptr; size_t cap_cursor = 0;
@@ -756,7 +799,7 @@ struct d2g_k3_state {
 
 void d2g_k3_state_destroy(d2g_k3_state *st) {
     if (!st) return;
-    (void)hipFree(st->d_gtab); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor);
+    (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor);
     (void)hipFree(st->d_keys); (void)hipFree(st->d_h); (void)hipFree(st->d_hbound); (void)hipFree(st->d_tw);
     (void)hipFree(st->d_seed); (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
     (void)hipFree(st->d_out_keys);
@@ -768,6 +811,7 @@ namespace {
 struct K3Host {
     std::vector<uint32_t> gtab;        // bbits[n] then boff[n+1]
     std::vector<uint64_t> gk;          // k-mers per genome
+    std::vector<uint64_t> koff;        // [n+1] exclusive prefix of gk
     uint64_t total = 0;
     uint32_t TB = 0;
 };
@@ -789,6 +833,8 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     }
     kh.gtab[2 * n] = (uint32_t)tb;
     kh.TB = (uint32_t)tb;
+    kh.koff.assign(n + 1, 0);
+    for (size_t g = 0; g < n; ++g) kh.koff[g + 1] = kh.koff[g] + kh.gk[g];
     return D2G_OK;
 }
 
@@ -802,22 +848,26 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
     if (int rc = d2g_grow(ctx, &st->d_cursor, &st->cap_cursor, (size_t)TB + 1)) return rc;
     if (int rc = d2g_grow(ctx, &st->d_keys, &st->cap_keys, std::max<uint64_t>(kh.total, 1))) return rc;
     if (!st->d_status) D2G_HIP(ctx, hipMalloc((void **)&st->d_status, 2 * sizeof(int)));
+    if (int rc = d2g_grow(ctx, &st->d_koff, &st->cap_koff, n + 1)) return rc;
     D2G_HIP(ctx, hipMemcpyAsync(st->d_gtab, kh.gtab.data(), (2 * n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    D2G_HIP(ctx, hipMemcpyAsync(st->d_koff, kh.koff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     D2G_HIP(ctx, hipMemsetAsync(st->d_bucket_cnt, 0, ((size_t)TB + 1) * sizeof(uint32_t), s));
     D2G_HIP(ctx, hipMemsetAsync(st->d_status, 0, 2 * sizeof(int), s));
     K3Args a;
     a.km = km; a.xormask = xormask;
-    a.g_bbits = st->d_gtab; a.g_boff = st->d_gtab + n;
+    a.g_bbits = st->d_gtab; a.g_boff = st->d_gtab + n; a.g_koff = st->d_koff;
     a.bucket_cnt = st->d_bucket_cnt; a.bucket_off = st->d_bucket_off; a.cursor = st->d_cursor; a.keys = st->d_keys;
     a.TB = TB;
     d2g_timer tm(ctx, &ctx->ev_k3, s);
     if (nblk) hipLaunchKernelGGL(k3_hist_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k3_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k3_scan_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, a);
     if (nblk) hipLaunchKernelGGL(k3_scatter_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
     BmhArgs b;
     std::memset(&b, 0, sizeof(b));
     b.keys = st->d_keys; b.bucket_off = st->d_bucket_off; b.g_boff = st->d_gtab + n;
     b.n = (uint32_t)n; b.TB = TB; b.m = (uint32_t)m; b.thr = thr; b.status = st->d_status;
+    b.round_keys = K3_ROUND_KEYS;
+    if (const char *e = std::getenv("D2G_K3_ROUND_KEYS")) { const int v = std::atoi(e); if (v >= 1 && v <= K3_ROUND_KEYS) b.round_keys = (uint32_t)v; }
     if (count_only) {
         if (int rc = d2g_grow(ctx, &st->d_out_keys, &st->cap_ok, std::max<uint64_t>(kh.total, 1))) return rc;
         if (int rc = d2g_grow(ctx, &st->d_out_counts, &st->cap_oc, std::max<uint64_t>(kh.total, 1))) return rc;
@@ -864,7 +914,8 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
 int k3_check_status(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s) {
 #ifdef K3_STATS
     { unsigned long long h[16]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(k3_stats), sizeof(h));
-      std::fprintf(stderr, "K3_STATS levels=%llu next_early=%llu next_full=%llu push=%llu elems=%llu locate=%llu | ticks(100MHz) meta=%llu count=%llu compact=%llu walk=%llu sync=%llu tail=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13]);
+      std::fprintf(stderr, "K3_STATS levels=%llu next_early=%llu next_full=%llu push=%llu elems=%llu locate=%llu | ticks(100MHz) meta=%llu count=%llu compact=%llu phase1=%llu sync=%llu drain=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13]);
+      std::fprintf(stderr, "K3_STATS drain=%llu tail=%llu | count: clear=%llu insert=%llu sync=%llu\n", h[13], h[14], h[1], h[2], h[3]);
       std::memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(k3_stats), h, sizeof(h)); }
 #endif
     int status = 0;

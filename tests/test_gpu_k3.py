@@ -124,3 +124,56 @@ def test_bmh_from_weighted_matches_oracle(gpu_ctx, d2g, oracle):
     assert tw[0] == etw == 5000.0
     with pytest.raises(d2g.D2GError):
         gpu_ctx.bmh_from_weighted(np.array([1], np.uint64), np.array([2.0 ** 60]), np.array([0, 1], np.uint64), 16)
+
+
+def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
+    """fresh processes with the two test hooks: D2G_K3_ROUND_KEYS=64 makes every bucket need several
+    table rounds (the path genomes above ~5.7 Mbp take), D2G_K3_GUESS_SCALE=1e-3 makes the guessed
+    pruning bound fail its verification so the main pass is repeated under the certified bound.
+    Counts and BagMinHash registers must not change."""
+    import os, subprocess, sys, json
+    g = synth.fasta_bytes("a", synth.random_genome(31, 150000)) + synth.fasta_bytes("r", np.tile(synth.random_genome(32, 300), 30))
+    fa = tmp_path / "x.fa"
+    fa.write_bytes(g)
+    esig, etw, _ = oracle.bmh_sketch_buffer(g, 17, 128)
+    ek, ec, _ = oracle.kmer_count_buffer(g, 17)
+    code = (
+        "import sys, json, numpy as np; sys.path.insert(0, %r); import dashing2_amd as D\n"
+        "ctx = D.Context(0); sp = D.SeqPack(17); sp.add_path(%r)\n"
+        "sig, tw = ctx.bmh_sketch_seqpack(sp, 128); kc = ctx.kmer_count_seqpack(sp)\n"
+        "print(json.dumps([sig.view(np.uint64).tolist(), tw.tolist(), kc[0][0].tolist(), kc[0][1].tolist()]))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(fa))
+    for env in ({"D2G_K3_ROUND_KEYS": "64"}, {"D2G_K3_GUESS_SCALE": "0.001"}, {"D2G_K3_ROUND_KEYS": "100", "D2G_K3_GUESS_SCALE": "0.01"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, env={**os.environ, **env}, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        sig, tw, keys, counts = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        assert tw[0] == etw, env
+        np.testing.assert_array_equal(np.array(sig[0], np.uint64), esig.view(np.uint64), err_msg=str(env))
+        np.testing.assert_array_equal(np.array(keys, np.uint64), ek, err_msg=str(env))
+        np.testing.assert_array_equal(np.array(counts, np.uint32), ec, err_msg=str(env))
+
+
+def test_k3_many_small_and_one_large_input(gpu_ctx, d2g, oracle):
+    """batch shapes: 300 read-sized inputs (one bucket each, many workgroup-less genomes) next to a
+    12 Mbp genome (4096 buckets of ~2900 keys: 4 table rounds each)"""
+    rng = np.random.default_rng(9)
+    sp = d2g.SeqPack(21)
+    small = [synth.fasta_bytes(f"s{i}", synth.random_genome(1000 + i, int(rng.integers(30, 3000)))) for i in range(300)]
+    for f in small:
+        sp.add_fastx(f)
+    big = synth.random_genome(77, 12_000_000)
+    sp.add_fastx(synth.fasta_bytes("big", big))
+    sp.add_fastx(synth.fasta_bytes("big2", big) + synth.fasta_bytes("big3", big[:6_000_000]))
+    S = 512
+    sig, tw = gpu_ctx.bmh_sketch_seqpack(sp, S)
+    for i in (0, 17, 150, 299):
+        esig, etw, _ = oracle.bmh_sketch_buffer(small[i], 21, S)
+        assert tw[i] == etw
+        np.testing.assert_array_equal(sig[i].view(np.uint64), esig.view(np.uint64), err_msg=f"small {i}")
+    nk = 12_000_000 - 20
+    assert tw[300] == nk and tw[301] == nk + 6_000_000 - 20
+    assert np.isfinite(sig[300:]).all()
+    # big2 = big + the first half again: weighted Jaccard = |big| / (|big| + |half|) = 2/3
+    est = (sig[300] == sig[301]).mean()
+    assert abs(est - 2 / 3) < 5 * np.sqrt((2 / 9) / S), est
+    assert (sig[301] <= sig[300]).all()
