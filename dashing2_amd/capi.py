@@ -91,6 +91,11 @@ SIGNATURES = {
     "d2g_bmh_sketch_dev": (_int, [_vp, _vp, _vp, _int, _u64, _sz, C.c_double, _vp, _vp, _vp]),
     "d2g_bmh_sketch": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _sz, C.c_double, _vp, _vp]),
     "d2g_kmer_count": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, C.c_double, _vp, _vp, _sz, _vp]),
+    "d2g_kmer_distinct": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _vp]),
+    "d2g_sketcher_run_distinct": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _vp]),
+    "d2g_seqpack_add_path_by_record": (_int, [_vp, C.c_char_p]),
+    "d2g_seqpack_add_fastx_by_record": (_int, [_vp, C.c_char_p, _sz]),
+    "d2g_seqpack_name": (C.c_char_p, [_vp, _sz]),
     "d2g_bmh_from_weighted": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]),
     "d2g_ut_count": (_sz, [_sz, _sz, _sz]),
     "d2g_cmp_set_create_dev": (_int, [_vp, _vp, _sz, _sz, _int, _vp, C.POINTER(_vp)]),
@@ -257,6 +262,19 @@ class SeqPack:
         if rc:
             raise D2GError(rc, str(path))
 
+    def add_path_by_record(self, path):
+        rc = lib().d2g_seqpack_add_path_by_record(self._h, os.fsencode(path))
+        if rc:
+            raise D2GError(rc, str(path))
+
+    def add_fastx_by_record(self, buf):
+        rc = lib().d2g_seqpack_add_fastx_by_record(self._h, buf, len(buf))
+        if rc:
+            raise D2GError(rc, "add_fastx_by_record")
+
+    def name(self, g):
+        return lib().d2g_seqpack_name(self._h, g).decode()
+
     def add_fastx(self, data: bytes):
         rc = lib().d2g_seqpack_add_fastx(self._h, data, len(data))
         if rc:
@@ -385,6 +403,15 @@ class Context:
             k_, c_ = keys[int(off[g]):int(off[g + 1])], counts[int(off[g]):int(off[g + 1])]
             o = np.argsort(k_, kind="stable")
             out.append((k_[o].copy(), c_[o].copy()))
+        return out
+
+    def kmer_distinct_seqpack(self, sp: "SeqPack", canon=True, xormask=0):
+        """-> uint64[n]: exact number of distinct masked k-mers per genome"""
+        packed, rs, rl, go = sp.arrays()
+        n = go.size - 1
+        out = np.zeros(n, np.uint64)
+        self._check(lib().d2g_kmer_distinct(self._h, _np_ptr(packed), packed.size, _np_ptr(rs), _np_ptr(rl), rs.size,
+                                            _np_ptr(go), n, sp.k, int(canon), xormask, _np_ptr(out)))
         return out
 
     def bmh_from_weighted(self, ids, weights, set_off, S):

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
 #include <limits>
 #include <random>
@@ -279,6 +280,8 @@ struct d2g_seqpack {
     std::vector<uint32_t> run_len;
     std::vector<uint64_t> genome_run_off{0};
     std::vector<uint64_t> genome_nkmers;
+    bool by_record = false;            // --parse-by-seq: every FASTX record is its own genome ...
+    std::vector<std::string> names;    // ... named by its header up to the first whitespace (kseq name)
     // open run state
     uint64_t cur_start = 0, cur_len = 0;
     uint64_t cur_kmers = 0;
@@ -357,6 +360,11 @@ struct d2g_seqpack {
         };
         while (pos < len && buf[pos] != '>' && buf[pos] != '@') skip_line();
         while (pos < len) {
+            if (by_record) {                               // fastxsketchbyseq.cpp:243-244: names_ = kseq name
+                size_t e = pos + 1;
+                while (e < len && !std::isspace((unsigned char)buf[e])) ++e;
+                names.emplace_back(buf + pos + 1, e - pos - 1);
+            }
             skip_line();                                   // header
             size_t seqlen = 0;
             int c = -1;
@@ -372,7 +380,7 @@ struct d2g_seqpack {
                 pos = nl ? e + 1 : len;
                 c = -1;
             }
-            end_record();
+            if (by_record) end_genome(); else end_record();
             if (pos < len && c == '+') {
                 skip_line();
                 size_t ql = 0;
@@ -451,7 +459,7 @@ void d2g_seqpack_destroy(d2g_seqpack *sp) { delete sp; }
 void d2g_seqpack_clear(d2g_seqpack *sp) {          // keep every allocation, forget the content
     if (!sp) return;
     sp->nbases = 0; sp->cur_start = sp->cur_len = sp->cur_kmers = 0; sp->padded_bytes = 0;
-    sp->run_start.clear(); sp->run_len.clear(); sp->genome_nkmers.clear();
+    sp->run_start.clear(); sp->run_len.clear(); sp->genome_nkmers.clear(); sp->names.clear();
     sp->genome_run_off.assign(1, 0);
 }
 
@@ -478,6 +486,37 @@ int d2g_seqpack_add_path(d2g_seqpack *sp, const char *line) {
     sp->end_genome();
     return rc;
 }
+// --parse-by-seq: one genome per record of the (space-separated) files of `line`
+int d2g_seqpack_add_path_by_record(d2g_seqpack *sp, const char *line) {
+    if (!sp || !line) return D2G_ERR_INVALID;
+    std::string s(line);
+    size_t b = 0;
+    static thread_local std::vector<char> buf;
+    int rc = D2G_OK;
+    sp->by_record = true;
+    while (b <= s.size()) {
+        size_t e = s.find(' ', b);
+        if (e == std::string::npos) e = s.size();
+        if (e > b) {
+            const std::string sub = s.substr(b, e - b);
+            size_t len = 0;
+            if (!slurp(sub.c_str(), buf, len)) { rc = D2G_ERR_IO; break; }
+            sp->reserve_bases(len);
+            sp->feed_fastx(buf.data(), len);
+        }
+        b = e + 1;
+    }
+    sp->by_record = false;
+    return rc;
+}
+int d2g_seqpack_add_fastx_by_record(d2g_seqpack *sp, const char *buf, size_t len) {
+    if (!sp || (!buf && len)) return D2G_ERR_INVALID;
+    sp->by_record = true;
+    sp->feed_fastx(buf, len);
+    sp->by_record = false;
+    return D2G_OK;
+}
+const char *d2g_seqpack_name(const d2g_seqpack *sp, size_t g) { return sp && g < sp->names.size() ? sp->names[g].c_str() : ""; }
 int d2g_seqpack_add_fastx(d2g_seqpack *sp, const char *buf, size_t len) {
     if (!sp || (!buf && len)) return D2G_ERR_INVALID;
     sp->unpad();

@@ -653,7 +653,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_count_kernel(BmhArgs a) {
         if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
         const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
         const uint32_t j0 = sh.misc;
-        for (uint32_t e = tid; e < ne; e += K3_THREADS) { a.out_keys[o0 + j0 + e] = sh.key[e]; a.out_counts[o0 + j0 + e] = sh.cnt[e]; }
+        if (a.out_keys)
+            for (uint32_t e = tid; e < ne; e += K3_THREADS) { a.out_keys[o0 + j0 + e] = sh.key[e]; a.out_counts[o0 + j0 + e] = sh.cnt[e]; }
         __syncthreads();
         if (tid == 0) sh.misc = j0 + ne;
         __syncthreads();
@@ -840,7 +841,7 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
 
 // count (R11) + sketch (R12) of one staged batch; results stay on the device in st->d_h / st->d_tw
 int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, size_t nblk, const K3Host &kh, size_t n,
-           uint64_t xormask, size_t m, double thr, bool count_only) {
+           uint64_t xormask, size_t m, double thr, bool count_only, bool distinct_only = false) {
     const uint32_t TB = kh.TB;
     if (int rc = d2g_grow(ctx, &st->d_gtab, &st->cap_gtab, 2 * n + 1)) return rc;
     if (int rc = d2g_grow(ctx, &st->d_bucket_cnt, &st->cap_bcnt, (size_t)TB + 1)) return rc;
@@ -869,10 +870,13 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
     b.round_keys = K3_ROUND_KEYS;
     if (const char *e = std::getenv("D2G_K3_ROUND_KEYS")) { const int v = std::atoi(e); if (v >= 1 && v <= K3_ROUND_KEYS) b.round_keys = (uint32_t)v; }
     if (count_only) {
-        if (int rc = d2g_grow(ctx, &st->d_out_keys, &st->cap_ok, std::max<uint64_t>(kh.total, 1))) return rc;
-        if (int rc = d2g_grow(ctx, &st->d_out_counts, &st->cap_oc, std::max<uint64_t>(kh.total, 1))) return rc;
+        if (!distinct_only) {
+            if (int rc = d2g_grow(ctx, &st->d_out_keys, &st->cap_ok, std::max<uint64_t>(kh.total, 1))) return rc;
+            if (int rc = d2g_grow(ctx, &st->d_out_counts, &st->cap_oc, std::max<uint64_t>(kh.total, 1))) return rc;
+            b.out_keys = st->d_out_keys; b.out_counts = st->d_out_counts;
+        }
         if (int rc = d2g_grow(ctx, &st->d_bucket_nd, &st->cap_nd, (size_t)TB + 1)) return rc;
-        b.out_keys = st->d_out_keys; b.out_counts = st->d_out_counts; b.bucket_nd = st->d_bucket_nd;
+        b.bucket_nd = st->d_bucket_nd;
         if (TB) hipLaunchKernelGGL(k3_count_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
     } else {
         if (int rc = d2g_grow(ctx, &st->d_h, &st->cap_h, std::max<size_t>(n * m, 1))) return rc;
@@ -992,6 +996,47 @@ int d2g_bmh_sketch(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes, con
     if (int rc = d2g_sketcher_create(ctx, &sk)) return rc;
     const int rc = d2g_sketcher_run_bmh(sk, packed, packed_bytes, run_start, run_len, nrun, genome_run_off, n, k, canon,
                                         xormask, sketchsize, count_threshold, sig_out, total_weight_out);
+    d2g_sketcher_destroy(sk);
+    return rc;
+}
+
+int d2g_sketcher_run_distinct(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
+                              const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
+                              uint64_t xormask, uint64_t *ndistinct_out) {
+    if (!sk) return D2G_ERR_INVALID;
+    d2g_ctx *ctx = sk->ctx;
+    D2G_CHECK(ctx, ndistinct_out != nullptr || n == 0, "null output");
+    d2g_k3_state *st = k3_state_of(sk);
+    if (!st) return D2G_ERR_NOMEM;
+    KmerArgs km;
+    size_t nblk = 0;
+    if (int rc = d2g_sketcher_stage(sk, packed, packed_bytes, run_start, run_len, nrun, genome_run_off, n, k, canon, &km,
+                                    &nblk, nullptr)) return rc;
+    K3Host kh;
+    if (int rc = k3_layout(ctx, run_len, genome_run_off, n, k, kh)) return rc;
+    if (n == 0) return D2G_OK;
+    hipStream_t s = sk->stream;
+    if (int rc = k3_run(ctx, st, s, km, nblk, kh, n, xormask, 1, 0.0, true, true)) return rc;
+    if (int rc = k3_check_status(ctx, st, s)) return rc;
+    std::vector<uint32_t> nd(kh.TB);
+    D2G_HIP(ctx, hipMemcpyAsync(nd.data(), st->d_bucket_nd, kh.TB * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipStreamSynchronize(s));
+    for (size_t g = 0; g < n; ++g) {
+        uint64_t t = 0;
+        for (uint32_t tb = kh.gtab[n + g]; tb < kh.gtab[n + g + 1]; ++tb) t += nd[tb];
+        ndistinct_out[g] = t;
+    }
+    return D2G_OK;
+}
+
+int d2g_kmer_distinct(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
+                      const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
+                      uint64_t xormask, uint64_t *ndistinct_out) {
+    if (!ctx) return D2G_ERR_INVALID;
+    d2g_sketcher *sk = nullptr;
+    if (int rc = d2g_sketcher_create(ctx, &sk)) return rc;
+    const int rc = d2g_sketcher_run_distinct(sk, packed, packed_bytes, run_start, run_len, nrun, genome_run_off, n, k, canon,
+                                             xormask, ndistinct_out);
     d2g_sketcher_destroy(sk);
     return rc;
 }

@@ -29,7 +29,7 @@ static const char *const VALID_LONG[] = {
 
 enum {
     OPT_CMPOUT = 1000, OPT_OUTPREF, OPT_BINARY, OPT_PHYLIP, OPT_ASYM, OPT_ISZ, OPT_USZ, OPT_MASH, OPT_SYMCONTAIN,
-    OPT_CONTAIN, OPT_SEED, OPT_HELP, OPT_BATCH, OPT_PRESKETCHED, OPT_MULTISET, OPT_UNSUPPORTED
+    OPT_CONTAIN, OPT_SEED, OPT_HELP, OPT_BATCH, OPT_PRESKETCHED, OPT_MULTISET, OPT_PARSEBYSEQ, OPT_UNSUPPORTED
 };
 
 void sketch_usage() {
@@ -71,7 +71,7 @@ std::string Options::to_string() const {    // src/d2.cpp:10-43 (fields that exi
     char buf[4096];
     int pos = std::snprintf(buf, sizeof buf, "Dashing2Options;k:%d", k);
     if (w > 0) pos += std::snprintf(buf + pos, sizeof buf - pos, ";w:%d", w);
-    pos += std::snprintf(buf + pos, sizeof buf - pos, ";%s", "parsebyfile");
+    pos += std::snprintf(buf + pos, sizeof buf - pos, ";%s", parse_by_seq ? "parsebyseq" : "parsebyfile");
     pos += std::snprintf(buf + pos, sizeof buf - pos, ";trimchr");
     pos += std::snprintf(buf + pos, sizeof buf - pos, ";sketchsize:%zu", sketchsize);
     if (count_threshold > 0) pos += std::snprintf(buf + pos, sizeof buf - pos, ";%u", count_threshold);
@@ -109,6 +109,7 @@ int parse_options(int argc, char **argv, Options &o) {
         {"multiset", no_argument, 0, OPT_MULTISET}, {"bagminhash", no_argument, 0, OPT_MULTISET}, {"bmh", no_argument, 0, OPT_MULTISET},
         {"BMH", no_argument, 0, OPT_MULTISET},
         {"count-threshold", required_argument, 0, 'm'}, {"threshold", required_argument, 0, 'm'},
+        {"parse-by-seq", no_argument, 0, OPT_PARSEBYSEQ},
         {0, 0, 0, 0}};
     // every other valid reference flag is recognised but outside the hot-path scope
     std::vector<struct option> all(longopts, longopts + sizeof(longopts) / sizeof(longopts[0]) - 1);
@@ -156,6 +157,7 @@ int parse_options(int argc, char **argv, Options &o) {
             case OPT_PRESKETCHED: o.presketched = true; break;
             case OPT_MULTISET: case 'B': o.sspace = SPACE_MULTISET; break;         // options.h:111
             case 'm': o.count_threshold = unsigned(std::atoi(optarg)); break;      // options.h:352
+            case OPT_PARSEBYSEQ: o.parse_by_seq = true; break;                     // options.h:378
             case OPT_HELP: case 'h': case '?': o.is_cmp ? cmp_usage() : sketch_usage(); return 1 + 1;
             case OPT_UNSUPPORTED:
                 std::fprintf(stderr, "dashing2 (MI355X): option --%s is outside the hot-path scope of this build "

@@ -19,6 +19,7 @@ struct Options {
     bool is_cmp = false;
     int k = -1, w = -1, nt = -1;
     bool canon = true, cache = false, presketched = false;
+    bool parse_by_seq = false;            // --parse-by-seq (options.h:378): one sketch per FASTX record of ONE input file
     size_t sketchsize = 1024;
     uint64_t seedseed = 0;
     size_t batch_size = 0;

@@ -100,6 +100,31 @@ void write_cached(const std::string &path, const double *sig, double card, size_
 }
 
 // ------------------------------------------------------------------------------------ sketch
+// stacked output: [u64 N][u64 S][f64 card x N][f64 x N*S]   (sketch_core.cpp:130-140, fastxsketch.cpp:236-240)
+void write_stacked(const Result &res, const Options &o) {
+    const size_t N = res.names.size(), S = o.sketchsize;
+    if (!o.outfile.empty()) {
+        if (o.outfile == "-" || o.outfile == "/dev/stdout")
+            die("Not yet supported: writing stacked sketches to file streams. This may change.");     // sketch_core.cpp:141-144
+        std::FILE *fp = std::fopen(o.outfile.c_str(), "wb");
+        if (!fp) die("Failed to open file " + o.outfile + " for in-place modification");
+        const uint64_t hdr[2] = {uint64_t(N), uint64_t(S)};
+        if (std::fwrite(hdr, 8, 2, fp) != 2 || std::fwrite(res.cardinalities.data(), 8, N, fp) != N ||
+            std::fwrite(res.signatures.data(), 8, N * S, fp) != N * S) die("Failed to write " + o.outfile);
+        std::fclose(fp);
+        // <out>.names.txt (sketch_core.cpp:146-161, enums.h:160 "%0.24g")
+        const std::string nf = o.outfile + ".names.txt";
+        if (!(fp = std::fopen(nf.c_str(), "wb"))) die("Failed to open outfile at " + nf);
+        std::fputs("#Name\tCardinality\n", fp);
+        for (size_t i = 0; i < N; ++i) {
+            std::fwrite(res.names[i].data(), 1, res.names[i].size(), fp);
+            std::fprintf(fp, "\t%0.24g", res.cardinalities[i]);
+            std::fputc('\n', fp);
+        }
+        std::fclose(fp);
+    }
+}
+
 void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
     const double t_enter = now();
     const size_t N = o.paths.size(), S = o.sketchsize, m = d2g_oph_m(S);
@@ -229,27 +254,81 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
                                           "device thread: H2D+K1+D2H %.3fs, x87 finalise+cache %.3fs\n",
                                   todo.size(), total_bases, groups.size(), t_parse, nparsers, t_gpu, t_fin);
     if (o.verbosity) std::fprintf(stderr, "[d2g] sketch wall: setup (stat, cache probe) %.3fs, ingest pipeline %.3fs\n", t_setup - t_enter, t_pipe - t_setup);
-    // stacked output: [u64 N][u64 S][f64 card x N][f64 x N*S]   (sketch_core.cpp:130-140, fastxsketch.cpp:236-240)
-    if (!o.outfile.empty()) {
-        if (o.outfile == "-" || o.outfile == "/dev/stdout")
-            die("Not yet supported: writing stacked sketches to file streams. This may change.");     // sketch_core.cpp:141-144
-        std::FILE *fp = std::fopen(o.outfile.c_str(), "wb");
-        if (!fp) die("Failed to open file " + o.outfile + " for in-place modification");
-        const uint64_t hdr[2] = {uint64_t(N), uint64_t(S)};
-        if (std::fwrite(hdr, 8, 2, fp) != 2 || std::fwrite(res.cardinalities.data(), 8, N, fp) != N ||
-            std::fwrite(res.signatures.data(), 8, N * S, fp) != N * S) die("Failed to write " + o.outfile);
-        std::fclose(fp);
-        // <out>.names.txt (sketch_core.cpp:146-161, enums.h:160 "%0.24g")
-        const std::string nf = o.outfile + ".names.txt";
-        if (!(fp = std::fopen(nf.c_str(), "wb"))) die("Failed to open outfile at " + nf);
-        std::fputs("#Name\tCardinality\n", fp);
-        for (size_t i = 0; i < N; ++i) {
-            std::fwrite(res.names[i].data(), 1, res.names[i].size(), fp);
-            std::fprintf(fp, "\t%0.24g", res.cardinalities[i]);
-            std::fputc('\n', fp);
+    write_stacked(res, o);
+}
+
+// --parse-by-seq (sketch_core.cpp:23-29 -> fastxsketchbyseq.cpp:102-268,270-531): one sketch per record of
+// ONE input file; OPH set sketches (cardinality = exact distinct k-mer count when the estimate is below
+// 10 S, lines 415-430) or multiset sketches; names are the record names.
+void sketch_core_byseq(Result &res, const Options &o, d2g_ctx *ctx) {
+    if (o.paths.size() != 1)
+        die("parse-by-seq currently only handles one file at a time. To process multiple files, simply concatenate them into one file, and run dashing2 on that.");
+    const size_t S = o.sketchsize, m = d2g_oph_m(S);
+    const uint64_t xormask = d2g_seed_mask(o.seedseed);
+    d2g_seqpack *sp = nullptr;
+    check(ctx, d2g_seqpack_create(o.k, &sp), "d2g_seqpack_create");
+    if (d2g_seqpack_add_path_by_record(sp, o.paths[0].c_str()) != D2G_OK) die("Failed to read from " + o.paths[0]);
+    const size_t N = d2g_seqpack_ngenomes(sp);
+    res.names.resize(N);
+    for (size_t i = 0; i < N; ++i) res.names[i] = d2g_seqpack_name(sp, i);
+    res.destination_files.assign(N, std::string());
+    res.cardinalities.assign(N, 0.);
+    res.signatures.assign(N * S, 0.);
+    const size_t total_bytes = d2g_seqpack_packed_bytes(sp);
+    const uint8_t *packed = d2g_seqpack_packed(sp);
+    const uint64_t *run_start = d2g_seqpack_run_start(sp), *goff = d2g_seqpack_genome_run_off(sp);
+    const uint32_t *run_len = d2g_seqpack_run_len(sp);
+    d2g_sketcher *sk = nullptr;
+    check(ctx, d2g_sketcher_create(ctx, &sk), "d2g_sketcher_create");
+    std::vector<uint64_t> regs, rs_rel, goff_rel, ndist;
+    std::vector<double> sigs, cards;
+    const size_t max_rec = std::max<size_t>(1, (size_t(64) << 20) / m);            // <= 512 MiB of registers per launch
+    for (size_t g0 = 0; g0 < N;) {
+        // batch [g0, g1): bounded by records and by packed bytes (the slice is re-based so that only it is uploaded)
+        size_t g1 = g0;
+        const uint64_t r0 = goff[g0];
+        const uint64_t base0 = r0 < goff[N] ? (run_start[r0] & ~uint64_t(15)) : 0;
+        while (g1 < N && g1 - g0 < max_rec) {
+            const uint64_t r1 = goff[g1 + 1];
+            const uint64_t endb = r1 > r0 ? run_start[r1 - 1] + run_len[r1 - 1] : base0;
+            if (g1 > g0 && endb - base0 > (uint64_t(192) << 20)) break;            // ~48 MB of packed bases
+            ++g1;
         }
-        std::fclose(fp);
+        const size_t n = g1 - g0, r1 = goff[g1], nrun = r1 - r0;
+        rs_rel.resize(nrun); goff_rel.resize(n + 1);
+        for (size_t r = 0; r < nrun; ++r) rs_rel[r] = run_start[r0 + r] - base0;
+        for (size_t g = 0; g <= n; ++g) goff_rel[g] = goff[g0 + g] - r0;
+        const uint8_t *pk = packed + base0 / 4;
+        const uint64_t endb = nrun ? run_start[r1 - 1] + run_len[r1 - 1] : base0;
+        const size_t pk_bytes = std::min<size_t>(total_bytes - base0 / 4, (endb - base0 + 3) / 4 + 64);   // slice + its 64 readable pad bytes
+        sigs.resize(n * S); cards.resize(n);
+        if (o.sspace == SPACE_MULTISET) {
+            check(ctx, d2g_sketcher_run_bmh(sk, pk, pk_bytes, rs_rel.data(), run_len + r0, nrun, goff_rel.data(), n, o.k, o.canon,
+                                            xormask, S, double(o.count_threshold), sigs.data(), cards.data()), "d2g_sketcher_run_bmh");
+        } else {
+            regs.resize(n * m);
+            check(ctx, d2g_sketcher_run(sk, pk, pk_bytes, rs_rel.data(), run_len + r0, nrun, goff_rel.data(), n, o.k, o.canon,
+                                        xormask, S, regs.data()), "d2g_sketcher_run");
+            check(ctx, d2g_oph_finalize(regs.data(), n, m, S, sigs.data(), cards.data(), int(o.nthreads())), "d2g_oph_finalize");
+            bool need = false;
+            for (size_t i = 0; i < n; ++i) {
+                if (std::isnan(cards[i])) cards[i] = 0.;                              // fastxsketchbyseq.cpp:410-414
+                need |= cards[i] < 10. * double(S);
+            }
+            if (need) {                                                               // lines 415-430: exact distinct count
+                ndist.resize(n);
+                check(ctx, d2g_sketcher_run_distinct(sk, pk, pk_bytes, rs_rel.data(), run_len + r0, nrun, goff_rel.data(), n, o.k,
+                                                     o.canon, xormask, ndist.data()), "d2g_sketcher_run_distinct");
+                for (size_t i = 0; i < n; ++i) if (cards[i] < 10. * double(S)) cards[i] = double(ndist[i]);
+            }
+        }
+        std::memcpy(&res.signatures[g0 * S], sigs.data(), n * S * sizeof(double));
+        std::memcpy(&res.cardinalities[g0], cards.data(), n * sizeof(double));
+        g0 = g1;
     }
+    d2g_sketcher_destroy(sk);
+    d2g_seqpack_destroy(sp);
+    write_stacked(res, o);
 }
 
 // ------------------------------------------------------------------------------------ cmp: load
@@ -497,7 +576,7 @@ int sketch_main(int argc, char **argv) {                          // src/sketch_
     d2g_ctx *ctx = make_ctx(o);
     if (o.verbosity) std::fprintf(stderr, "[d2g] options + GPU context: %.3fs\n", now() - t_start);
     Result res;
-    sketch_core(res, o, ctx);
+    if (o.parse_by_seq) sketch_core_byseq(res, o, ctx); else sketch_core(res, o, ctx);
     res.nq = o.nq;
     if (!o.cmpout.empty()) cmp_core(o, res, ctx);                  // sketch_main.cpp:144-148
     d2g_ctx_destroy(ctx);
@@ -524,7 +603,7 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
         load_results(o, res);
     } else {
         if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); cmp_usage(); return 1; }
-        sketch_core(res, o, ctx);
+        if (o.parse_by_seq) sketch_core_byseq(res, o, ctx); else sketch_core(res, o, ctx);
         res.nq = o.nq;
     }
     cmp_core(o, res, ctx);

@@ -131,6 +131,12 @@ int  d2g_seqpack_add_path(d2g_seqpack *sp, const char *path_line);
 int  d2g_seqpack_add_fastx(d2g_seqpack *sp, const char *buf, size_t len);
 /* appends one genome consisting of a single raw sequence (no header) */
 int  d2g_seqpack_add_sequence(d2g_seqpack *sp, const char *seq, size_t len);
+/* --parse-by-seq (reference src/fastxsketchbyseq.cpp:233-252): every FASTA/FASTQ record of the file(s)
+ * becomes its own genome, named by its header up to the first whitespace (kseq's name); records
+ * without a k-mer still get an (empty) genome so that indices line up with the reference's names_. */
+int             d2g_seqpack_add_path_by_record(d2g_seqpack *sp, const char *path_line);
+int             d2g_seqpack_add_fastx_by_record(d2g_seqpack *sp, const char *buf, size_t len);
+const char     *d2g_seqpack_name(const d2g_seqpack *sp, size_t genome);   /* packs filled by *_by_record only */
 size_t          d2g_seqpack_ngenomes(const d2g_seqpack *sp);
 size_t          d2g_seqpack_nruns(const d2g_seqpack *sp);
 size_t          d2g_seqpack_packed_bytes(const d2g_seqpack *sp);   /* including the 64-byte pad */
@@ -218,6 +224,17 @@ int d2g_kmer_count(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes,
                    const uint64_t *genome_run_off, size_t n, int k, int canon, uint64_t xormask,
                    double count_threshold, uint64_t *keys_out, uint32_t *counts_out, size_t cap,
                    uint64_t *genome_off_out /* [n+1] */);
+/* number of DISTINCT masked k-mers per genome (exact): the cardinality the reference substitutes for
+ * small --parse-by-seq sketches (src/fastxsketchbyseq.cpp:415-430, `ids.size()`); same bucketed LDS
+ * counting as d2g_kmer_count without materialising the keys on the host. */
+int d2g_kmer_distinct(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes,
+                      const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
+                      const uint64_t *genome_run_off, size_t n, int k, int canon, uint64_t xormask,
+                      uint64_t *ndistinct_out /* host [n] */);
+int d2g_sketcher_run_distinct(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes,
+                              const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
+                              const uint64_t *genome_run_off, size_t n, int k, int canon, uint64_t xormask,
+                              uint64_t *ndistinct_out /* host [n] */);
 /* BagMinHash of explicit weighted sets (reference src/wsketch.cpp:54-73 minwise_det and 17-51
  * minhash_rowwise_csr: h.update(id, weight) per element): set i = elements
  * [set_off[i], set_off[i+1]); weights == NULL means 1.0; weights <= 0 are ignored (as

@@ -310,3 +310,73 @@ int d2o_bmh_sketch_files(const char *const *paths, size_t n, int k, int canon, u
     }
     return rc;
 }
+
+/* ------------------------------------------------------------------ */
+/* --parse-by-seq: one sketch per record                                */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int k, canon, multiset; uint64_t xormask; size_t S; double thr;
+    size_t n, cap; double *sigs, *cards; char *names; size_t names_len, names_cap;
+} byseq_t;
+
+static void byseq_cb(const char *name, size_t name_len, const char *seq, size_t seq_len, void *ud) {
+    byseq_t *b = (byseq_t *)ud;
+    if (b->n == b->cap) {
+        b->cap = b->cap ? b->cap * 2 : 64;
+        b->sigs = (double *)realloc(b->sigs, b->cap * b->S * sizeof(double));
+        b->cards = (double *)realloc(b->cards, b->cap * sizeof(double));
+    }
+    if (b->names_len + name_len + 2 > b->names_cap) {
+        b->names_cap = (b->names_len + name_len + 2) * 2;
+        b->names = (char *)realloc(b->names, b->names_cap);
+    }
+    memcpy(b->names + b->names_len, name, name_len);                  /* fastxsketchbyseq.cpp:243-244 */
+    b->names_len += name_len;
+    b->names[b->names_len++] = '\n';
+    double *sig = b->sigs + b->n * b->S;
+    kvec_t kv = { NULL, 0, 0, b->xormask };
+    d2o_encode_seq(seq, seq_len, b->k, b->canon, kvec_cb, &kv);        /* masked k-mers of this record */
+    if (b->multiset) {                                                  /* lines 443-451 */
+        double tw = 0.;
+        bmh_from_kvec(&kv, b->S, b->thr, sig, &tw, NULL);
+        b->cards[b->n] = tw;
+    } else {                                                            /* lines 366-442, OPH */
+        d2o_oph s;
+        d2o_oph_init(&s, b->S);
+        for (size_t i = 0; i < kv.n; ++i) d2o_oph_update(&s, kv.v[i]);
+        double card = d2o_oph_getcard(&s);
+        double *tmp = (double *)malloc(s.m * sizeof(double));
+        d2o_oph_data(&s, tmp);
+        memcpy(sig, tmp, b->S * sizeof(double));
+        free(tmp);
+        d2o_oph_free(&s);
+        if (card != card) card = 0.;                                    /* 410-414 */
+        if (card < 10. * (double)b->S) {                                /* 415-430: exact distinct count */
+            if (!kv.v) kv.v = (uint64_t *)malloc(8);
+            uint64_t *keys; uint32_t *counts; size_t nd;
+            kvec_finish(&kv, &keys, &counts, &nd);
+            card = (double)nd;
+            free(counts);
+            kv.v = keys;
+        }
+        b->cards[b->n] = card;
+        free(kv.v);
+    }
+    ++b->n;
+}
+
+int d2o_sketch_buffer_byseq(const char *buf, size_t len, int k, int canon, uint64_t xormask, size_t sketchsize,
+                            int multiset, double count_threshold, size_t *nrec_out, double **sigs_out,
+                            double **cards_out, char **names_out) {
+    byseq_t b;
+    memset(&b, 0, sizeof(b));
+    b.k = k; b.canon = canon; b.multiset = multiset; b.xormask = xormask; b.S = sketchsize; b.thr = count_threshold;
+    d2o_walk_fastx_records(buf, len, byseq_cb, &b);
+    if (!b.names) b.names = (char *)calloc(1, 1);
+    else b.names[b.names_len] = 0;
+    *nrec_out = b.n;
+    *sigs_out = b.sigs ? b.sigs : (double *)malloc(8);
+    *cards_out = b.cards ? b.cards : (double *)malloc(8);
+    *names_out = b.names;
+    return 0;
+}

@@ -7,6 +7,7 @@
 #define _GNU_SOURCE
 #include "d2_oracle.h"
 #include <float.h>
+#include <ctype.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -210,8 +211,8 @@ size_t d2o_encode_seq(const char *seq, size_t len, int k, int canon, d2o_kmer_cb
 /* kseq.h semantics (klib, absent): records start at '>' or '@'; the sequence is every
  * following line (newline and trailing '\r' stripped) until a line starting with
  * '>', '@' or '+'; after '+', quality lines are consumed until qual.l >= seq.l. */
-size_t d2o_encode_fastx_buffer(const char *buf, size_t len, int k, int canon, d2o_kmer_cb cb, void *ud) {
-    size_t pos = 0, total = 0;
+size_t d2o_walk_fastx_records(const char *buf, size_t len, d2o_record_cb rcb, void *ud) {
+    size_t pos = 0, nrec = 0;
     char *seq = NULL; size_t cap = 0;
     /* jump to first header */
     while (pos < len && buf[pos] != '>' && buf[pos] != '@') {
@@ -219,9 +220,13 @@ size_t d2o_encode_fastx_buffer(const char *buf, size_t len, int k, int canon, d2
         pos = nl ? (size_t)(nl - buf) + 1 : len;
     }
     while (pos < len) {
-        /* header line */
+        /* header line: name = up to the first whitespace (kseq name/comment split) */
         const char *nl = memchr(buf + pos, '\n', len - pos);
-        pos = nl ? (size_t)(nl - buf) + 1 : len;
+        const size_t hend = nl ? (size_t)(nl - buf) : len;
+        const char *name = buf + pos + 1;
+        size_t name_len = 0;
+        while (pos + 1 + name_len < hend && !isspace((unsigned char)name[name_len])) ++name_len;
+        pos = nl ? hend + 1 : len;
         size_t sl = 0;
         int c = -1;
         while (pos < len) {
@@ -238,7 +243,8 @@ size_t d2o_encode_fastx_buffer(const char *buf, size_t len, int k, int canon, d2
             pos = nl ? e + 1 : len;
             c = -1;
         }
-        total += d2o_encode_seq(seq, sl, k, canon, cb, ud);
+        rcb(name, name_len, seq, sl, ud);
+        ++nrec;
         if (pos < len && c == '+') {
             nl = memchr(buf + pos, '\n', len - pos);       /* rest of '+' line */
             pos = nl ? (size_t)(nl - buf) + 1 : len;
@@ -259,7 +265,19 @@ size_t d2o_encode_fastx_buffer(const char *buf, size_t len, int k, int canon, d2
         }
     }
     free(seq);
-    return total;
+    return nrec;
+}
+
+typedef struct { int k, canon; d2o_kmer_cb cb; void *ud; size_t total; } enc_rec_ctx;
+static void enc_rec_cb(const char *name, size_t name_len, const char *seq, size_t seq_len, void *ud) {
+    enc_rec_ctx *e = (enc_rec_ctx *)ud;
+    (void)name; (void)name_len;
+    e->total += d2o_encode_seq(seq, seq_len, e->k, e->canon, e->cb, e->ud);
+}
+size_t d2o_encode_fastx_buffer(const char *buf, size_t len, int k, int canon, d2o_kmer_cb cb, void *ud) {
+    enc_rec_ctx e = { k, canon, cb, ud, 0 };
+    d2o_walk_fastx_records(buf, len, enc_rec_cb, &e);
+    return e.total;
 }
 
 typedef struct { d2o_oph *s; uint64_t xormask; } upd_ctx;

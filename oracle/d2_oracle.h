@@ -78,6 +78,10 @@ typedef void (*d2o_kmer_cb)(uint64_t kmer, void *ud);
 /* Emits every valid k-mer (canonical if canon) of one sequence record. Returns #emitted. */
 size_t d2o_encode_seq(const char *seq, size_t len, int k, int canon, d2o_kmer_cb cb, void *ud);
 /* Parse a FASTA/FASTQ buffer (kseq semantics) and emit k-mers record by record. */
+/* the kseq-style record walk itself: cb(name, name_len, seq, seq_len) per record; name = header up to
+ * the first whitespace.  Returns the number of records. */
+typedef void (*d2o_record_cb)(const char *name, size_t name_len, const char *seq, size_t seq_len, void *ud);
+size_t d2o_walk_fastx_records(const char *buf, size_t len, d2o_record_cb cb, void *ud);
 size_t d2o_encode_fastx_buffer(const char *buf, size_t len, int k, int canon, d2o_kmer_cb cb, void *ud);
 
 /* ---- sketch one "file" (fastxsketch.cpp:302-424,554-610; OPH branch) ---- */
@@ -178,6 +182,14 @@ int d2o_bmh_sketch_file(const char *path, int k, int canon, uint64_t xormask, si
 int d2o_bmh_sketch_files(const char *const *paths, size_t n, int k, int canon, uint64_t xormask,
                          size_t sketchsize, double count_threshold, double *sig_out /* [n][S] */,
                          double *total_weight_out /* [n] */, uint64_t *nkmers_out /* [n] or NULL */);
+/* --parse-by-seq (fastxsketchbyseq.cpp:102-268 driver, 270-531 resize_fill): ONE sketch per record.
+ * set space / OPH without count threshold (lines 366-442): sig = data(), card = getcard(), NaN -> 0,
+ * and when card < 10*S the cardinality is replaced by the EXACT number of distinct masked k-mers
+ * (lines 415-430).  multiset != 0: Counter -> BagMinHash per record (443-451), card = total weight.
+ * Outputs are malloc'd (d2o_free): sigs [nrec][S], cards [nrec], names '\n'-joined (names_, 243-244). */
+int d2o_sketch_buffer_byseq(const char *buf, size_t len, int k, int canon, uint64_t xormask, size_t sketchsize,
+                            int multiset, double count_threshold, size_t *nrec_out, double **sigs_out,
+                            double **cards_out, char **names_out);
 /* file reader shared with d2o_sketch_file (gz/plain); caller frees with d2o_free */
 char *d2o_slurp(const char *path, size_t *len_out);
 

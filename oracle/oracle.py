@@ -77,6 +77,8 @@ def load(path=None):
         "d2o_kmer_count_buffer": (i32, [C.c_char_p, sz, i32, i32, u64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(sz), pu64]),
         "d2o_free": (None, [C.c_void_p]),
+        "d2o_sketch_buffer_byseq": (i32, [C.c_char_p, sz, i32, i32, u64, sz, i32, dbl, C.POINTER(sz), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
         "d2o_bmh_sketch_buffer": (i32, [C.c_char_p, sz, i32, i32, u64, sz, dbl, pdbl, pdbl, pu64]),
         "d2o_bmh_sketch_file": (i32, [C.c_char_p, i32, i32, u64, sz, dbl, pdbl, pdbl, pu64]),
         "d2o_bmh_sketch_files": (i32, [C.POINTER(C.c_char_p), sz, i32, i32, u64, sz, dbl, pdbl, pdbl, pu64]),
@@ -255,3 +257,18 @@ def bmh_sketch_files(paths, k, S, canon=True, xormask=0, count_threshold=0.0):
                                      _p(tw, C.c_double), _p(nk, C.c_uint64))
     assert rc == 0, rc
     return sigs, tw, nk
+
+
+def sketch_buffer_byseq(buf, k, S, canon=True, xormask=0, multiset=False, count_threshold=0.0):
+    """--parse-by-seq: -> (names list[str], sigs float64[n][S], cards float64[n])"""
+    n, sigs, cards, names = C.c_size_t(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    rc = load().d2o_sketch_buffer_byseq(buf, len(buf), k, int(canon), xormask, S, int(multiset), count_threshold,
+                                        C.byref(n), C.byref(sigs), C.byref(cards), C.byref(names))
+    assert rc == 0
+    nn = n.value
+    so = np.ctypeslib.as_array(C.cast(sigs, C.POINTER(C.c_double)), (max(nn * S, 1),))[:nn * S].reshape(nn, S).copy()
+    co = np.ctypeslib.as_array(C.cast(cards, C.POINTER(C.c_double)), (max(nn, 1),))[:nn].copy()
+    nm = C.string_at(names).decode().split("\n")[:nn] if nn else []
+    for p in (sigs, cards, names):
+        load().d2o_free(p)
+    return nm, so, co

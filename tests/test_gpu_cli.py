@@ -225,3 +225,58 @@ def test_cli_multiset_sketch_and_cmp(oracle, genomes, tmp_path):
     # OPH min-count filtering stays out of scope
     r = subprocess.run([EXE, "sketch", "-m", "2", "-k", "21"] + genomes[:2], capture_output=True)
     assert r.returncode != 0 and b"outside this build" in r.stderr
+
+
+def test_cli_parse_by_seq(oracle, tmp_path):
+    """--parse-by-seq (src/fastxsketchbyseq.cpp): one sketch per record of one file, names = record
+    names, cardinality = exact distinct k-mer count below 10 S; OPH and multiset; stacked file,
+    names file and PHYLIP byte-identical to the oracle pipeline."""
+    from oracle import textfmt
+    rng = np.random.default_rng(3)
+    base = synth.random_genome(50, 30000)
+    recs = [synth.fasta_bytes("base some comment", base), synth.fasta_bytes("mut1\tx", synth.mutate(base, 0.01, 1)),
+            b">empty\n\n", b">short\nACGTACG\n", synth.fasta_bytes("mut5", synth.mutate(base, 0.05, 2)),
+            synth.fasta_bytes("big", synth.random_genome(51, 300000)),      # estimate above 10 S: keeps getcard()
+            b"@fq1\nACGTTGCAAGCTAGCTAGCTAGGATCGATCGATTTAGC\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n"]
+    for i in range(40):
+        recs.append(synth.fasta_bytes(f"read{i}", synth.random_genome(600 + i, int(rng.integers(20, 400)))))
+    fa = tmp_path / "multi.fa"
+    fa.write_bytes(b"".join(recs))
+    buf = fa.read_bytes()
+    for extra, multiset, k, S in ([], False, 21, 256), (["--multiset"], True, 15, 128):
+        out = tmp_path / ("bs%d.bin" % multiset)
+        phy = tmp_path / ("bs%d.phy" % multiset)
+        _run(["sketch", "--parse-by-seq", "-k", str(k), "-S", str(S), "-p", "4", "-o", str(out), "--cmpout", str(phy), "--phylip"]
+             + extra + [str(fa)])
+        names, esigs, ecards = oracle.sketch_buffer_byseq(buf, k, S, multiset=multiset)
+        N = len(names)
+        assert N == len(recs) and names[0] == "base" and names[1] == "mut1" and names[6] == "fq1"
+        raw = np.fromfile(out, np.uint8)
+        exp = np.concatenate([np.array([N, S], np.uint64).view(np.uint8), ecards.view(np.uint8), esigs.reshape(-1).view(np.uint8)])
+        assert raw.tobytes() == exp.tobytes()
+        lines = open(str(out) + ".names.txt").read().splitlines()
+        assert [l.split("\t")[0] for l in lines[1:]] == names
+        if not multiset:
+            assert ecards[2] == 0 and ecards[3] == 0 and ecards[6] == 18.0          # exact distinct counts (38 - 21 + 1 = 18 k-mers)
+            assert (ecards[7:] == np.floor(ecards[7:])).all() and ecards[5] != float(int(ecards[5]))   # estimate kept above 10 S
+            dens = _densified(oracle, esigs)
+            dist = oracle.allpairs_ut(dens, ecards, measure=oracle.SIMILARITY, k=k, nthreads=2)
+        else:
+            neq = oracle.eqcounts_ut(esigs)
+            iu = np.triu_indices(N, 1)
+            dist = np.array([oracle.compare_from_neq(int(c), S, ecards[i], ecards[j], oracle.SIMILARITY, k)
+                             for c, i, j in zip(neq, iu[0], iu[1])], np.float32)
+        assert open(phy).read() == textfmt.render_symmetric(names, dist, phylip=True)
+    r = subprocess.run([EXE, "sketch", "--parse-by-seq", str(fa), str(fa)], capture_output=True)
+    assert r.returncode != 0 and b"only handles one file at a time" in r.stderr
+
+
+def test_kmer_distinct_matches_oracle(gpu_ctx, d2g, oracle):
+    g = [synth.fasta_bytes("a", synth.random_genome(3, 50000)), b">x\nACGTACGTACGTACGT\n", b"",
+         synth.fasta_bytes("r", np.tile(synth.random_genome(4, 100), 50))]
+    sp = d2g.SeqPack(11)
+    for f in g:
+        sp.add_fastx(f)
+    got = gpu_ctx.kmer_distinct_seqpack(sp)
+    exp = [oracle.kmer_count_buffer(f, 11)[0].size for f in g]
+    assert got.tolist() == exp

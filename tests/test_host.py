@@ -270,3 +270,18 @@ print(json.dumps({"nruns": int(rs.size), "sum_kmers": tot, "distinct_starts": le
     assert r["nruns"] > 4
     assert r["nkmers"] == 5000 - 20
     assert r["sum_kmers"] == 5000 - 20 == r["distinct_starts"]      # every k-mer start covered exactly once
+
+
+def test_seqpack_by_record_matches_oracle_walk(d2g, oracle):
+    """--parse-by-seq packing: one genome per FASTX record, kseq names, k-mer counts per record equal
+    to the oracle's record walk (fastxsketchbyseq.cpp:233-252)."""
+    buf = (b">r1 desc\nACGTACGTTTGACCA\nACGGT\n>r2\nNNNN\n>r3\tx\nACGTACGTTTGACCAACGGT\r\n@q\nACGTAGCATCGACTAGCTA\n+\n"
+           b"IIIIIIIIIIIIIIIIIII\n>last")
+    sp = d2g.SeqPack(5)
+    sp.add_fastx_by_record(buf)
+    names, sigs, cards = oracle.sketch_buffer_byseq(buf, 5, 8)
+    assert [sp.name(i) for i in range(sp.ngenomes)] == names == ["r1", "r2", "r3", "q", "last"]
+    assert [sp.nkmers(i) for i in range(sp.ngenomes)] == [16, 0, 16, 15, 0]
+    assert cards.tolist() == [14.0, 0.0, 14.0, 14.0, 0.0]          # below 10 S: exact distinct canonical 5-mers
+    _, _, mcards = oracle.sketch_buffer_byseq(buf, 5, 8, multiset=True)
+    assert mcards.tolist() == [16.0, 0.0, 16.0, 15.0, 0.0]         # multiset: total weight = k-mer count
