@@ -321,7 +321,7 @@ def main():
                     "config": {"workload": f"BASELINE config 5: {n_g * world} synthetic random genomes x {L} bp, k={k3}, S={S3}, "
                                            f"--multiset (BagMinHash), canonical, {nb} genomes per call"},
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k3 chain (hist, scan, scatter, bmh_seed, bmh_main, verify)",
+                                 "traffic": None, "kernel": "k3 chain (hist, scan, scatter, bmh_main, verify)",
                                  "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
                                  "note": "per call of %d genomes; the chain also writes and re-reads 8 B of key per k-mer "
                                          "(bucketed multi-split), which the compulsory-byte figure does not count" % nb},

@@ -11,16 +11,17 @@
 //      multi-split by its top bits into <= 4096 buckets of ~1-2 K keys (LDS-aggregated histogram,
 //      one global reservation per (workgroup, bucket)); k-mers are re-generated from the packed
 //      bases in each pass instead of being stored (generation is ~100 VALU slots, a store+load is 16 B).
-//   2. k3_bmh_seed / k3_bmh_main       : one workgroup per bucket counts it exactly in a 4096-slot LDS
-//      open-addressing table (ds_cmpst_b64 claim + ds_add), then every occupied slot IS one
-//      (key, count) element and its owner lane runs the BagMinHash Poisson-process tree for it,
-//      depth-first with a private stack, against a certified upper bound of the genome's current
-//      maximum register.  Registers live in HBM/L2 as the bit patterns of non-negative doubles and
-//      are lowered with global_atomic_umin_x2 behind a read filter.
-//      min is order-free and pruning by ANY valid bound only drops points that cannot win, so the
-//      result is bit-identical to the time-ordered sequential algorithm (oracle/d2_bmh_oracle.c).
-//      The first non-empty bucket of each genome is processed alone first ("seed") with iterative
-//      deepening on a guessed bound so that every later workgroup starts from a finite bound.
+//   2. k3_bmh_main / k3_bmh_verify     : persistent workgroups walk the buckets; each bucket is counted
+//      exactly in a 2048-slot LDS open-addressing table (ds_cmpst_b64 claim + ds_add), then every occupied
+//      slot IS one (key, count) element and the BagMinHash Poisson-process tree is walked for it,
+//      depth-first with a private stack, pruned against a bound of the genome's final maximum register.
+//      Registers live in HBM/L2 as the bit patterns of non-negative doubles and are lowered with
+//      global_atomic_umin_x2 behind a read filter.
+//      min is order-free and pruning by ANY bound >= the final maximum only drops points that cannot win,
+//      so the result is bit-identical to the time-ordered sequential algorithm (oracle/d2_bmh_oracle.c).
+//      The bound is GUESSED from the genome's total weight (max of m exponentials of rate W/m) and
+//      VERIFIED afterwards (max(h) <= guess); a genome that fails is walked again under a 16x larger
+//      guess (idempotent: registers only go down).
 #include "d2g_k1.h"
 #include <algorithm>
 #include <cmath>
@@ -40,11 +41,7 @@ constexpr int K3_ROUND_KEYS = 1400;         // keys one table round is sized for
 constexpr int K3_TARGET = 1024;             // mean keys per bucket aimed for
 constexpr uint64_t K3_EMPTY = ~0ull;
 constexpr uint64_t BMH_INF = 0x7FF0000000000000ull;
-#ifndef BMH_STACK_N
-#define BMH_STACK_N 72
-#endif
-constexpr int BMH_STACK = BMH_STACK_N;
-constexpr uint32_t K3_HLDS_MAX = 8192;      // registers kept in LDS by the seed workgroup
+constexpr int BMH_STACK = 72;
 
 struct K3Args {
     KmerArgs km;
@@ -127,20 +124,6 @@ __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
     });
 }
 
-#ifdef K3_STATS
-__device__ unsigned long long k3_stats[16];
-#ifdef K3_TIMING_ONLY
-#define K3_STAT(i)
-#else
-#define K3_STAT(i) atomicAdd(&k3_stats[i], 1ull)
-#endif
-#define K3_T0() long long t0_ = wall_clock64()
-#define K3_T(i) do { if (threadIdx.x == 0) { const long long t1_ = wall_clock64(); atomicAdd(&k3_stats[i], (unsigned long long)(t1_ - t0_)); t0_ = t1_; } } while (0)
-#else
-#define K3_STAT(i)
-#define K3_T0()
-#define K3_T(i)
-#endif
 // ---------------------------------------------------------------------------------------------
 // exact counting of one bucket round into the LDS table
 // ---------------------------------------------------------------------------------------------
@@ -156,11 +139,9 @@ static_assert(K3_TAB == 1 << 11, "tab_hash takes the top 11 bits");
 // keys of round r of R (R a power of two: low key bits select the round); returns false on overflow
 __device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, uint32_t R, uint32_t r) {
     const int tid = threadIdx.x;
-    K3_T0();
     for (int s = tid; s < K3_TAB; s += K3_THREADS) { t.key[s] = K3_EMPTY; t.cnt[s] = 0; }
     if (tid == 0) *t.ones = 0;
     __syncthreads();
-    K3_T(1);
     bool ok = true;
     // keys are fetched K3_KPF per lane at a time BEFORE the probe chains: with the load inside the
     // probing loop every key exposed a full HBM/L2 round trip (measured 25 us per 1220-key bucket)
@@ -194,9 +175,7 @@ __device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, u
             if (ok) atomicAdd(&t.cnt[s], 1u);
         }
     }
-    K3_T(2);
     const bool res = !__syncthreads_or(!ok);
-    K3_T(3);
     return res;
 }
 
@@ -247,9 +226,8 @@ __device__ __forceinline__ bool proc_next(Proc &P, uint32_t m, double bound) {
     const double width = V(P.q) - V(P.p);
     const uint64_t r1 = wy_next(P.rng);
     const double uu = (double)((r1 >> 11) + 1) * 0x1p-53;            // (0, 1]
-    if ((1.0 - uu) > bound * width * 1.000000001) { K3_STAT(1); return false; }
-    K3_STAT(2);
-    const double E = -dlog(uu);
+    if ((1.0 - uu) > bound * width * 1.000000001) { return false; }
+        const double E = -dlog(uu);
     P.x = P.x + E / width;
     const uint64_t r2 = wy_next(P.rng);
     P.i = (uint32_t)__umul64hi(r2, (uint64_t)m);
@@ -275,15 +253,14 @@ __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double boun
         const double width = V(S.q) - V(S.p);
         const uint64_t r1 = wy_next(S.rng);
         const double uu = (double)((r1 >> 11) + 1) * 0x1p-53;        // (0, 1]
-        if ((1.0 - uu) > bound * width * 1.000000001) { K3_STAT(1); return; }   // see proc_next
+        if ((1.0 - uu) > bound * width * 1.000000001) return;   // see proc_next
         S.x = uu;
         stk[sp++] = S;
     };
     for (;;) {
         if (!counted && V(P.q) <= w) { reg_min(h, P.i, P.x); counted = true; }
         if (P.q - P.p <= 1) break;
-        K3_STAT(0);
-        const uint64_t r = P.p + ((P.q - P.p) >> 1);
+                const uint64_t r = P.p + ((P.q - P.p) >> 1);
         const uint64_t rb = wy_next(P.rng);
         const double ub = (double)(rb >> 11) * 0x1p-53;              // [0, 1)
         const double vp = V(P.p), vq = V(P.q), vr = V(r);
@@ -300,12 +277,11 @@ __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double boun
     int out = sp0;
     for (int j = sp0; j < sp; ++j) {
         Proc S = stk[j];
-        K3_STAT(2);
-        const double E = -dlog(S.x);
+                const double E = -dlog(S.x);
         S.x = P.x + E / (V(S.q) - V(S.p));
         const uint64_t r2 = wy_next(S.rng);
         S.i = (uint32_t)__umul64hi(r2, (uint64_t)m);
-        if (S.x <= bound) { K3_STAT(3); stk[out++] = S; }
+        if (S.x <= bound) { stk[out++] = S; }
     }
     sp = out;
 }
@@ -416,17 +392,13 @@ struct BmhArgs {
     uint32_t m;
     double thr;
     uint64_t *h;             // [n][m] register bit patterns, +inf initially
-    uint64_t *hbound;        // [n] certified upper bound of max(h[g]) (bit pattern), +inf initially
+    uint64_t *guess;         // [n] pruning bound of the current pass (bit pattern of a double)
     double *tw;              // [n] total weight
-    double *tw_bucket;       // [TB] per-bucket partial of the main pass (zeroed by the host)
-    uint32_t *seed_bucket;   // [n] unit the seed workgroup processed: bucket (or ~0: no element) ...
-    uint32_t *seed_round;    // [n] ... and round
-    uint64_t *guess;         // [n] uncertified part of the bound the main pass ran with (bit pattern)
-    uint32_t *redo;          // [n] 1 = the guess was too small: the main pass must be repeated under a certified bound
+    double *tw_bucket;       // [TB] per-bucket partial of the first pass (zeroed by the host)
+    uint32_t *redo;          // [n] 1 = the guess proved too small: walk this genome again
     uint32_t *nredo;         // [1]
-    int redo_mode;
+    int redo_mode;           // 0 = first pass (every genome, weights are summed); 1 = only genomes with redo[g]
     uint32_t round_keys;     // K3_ROUND_KEYS; D2G_K3_ROUND_KEYS lowers it (tests force multi-round buckets on small inputs)
-    double guess_scale;      // 1.0; D2G_K3_GUESS_SCALE overrides it (tests force the verify/redo path with a tiny value)
     int *status;
     // optional R11 output (k3_count_kernel): distinct (key,count) written in place of the bucket
     uint64_t *out_keys; uint32_t *out_counts; uint32_t *bucket_nd;
@@ -448,90 +420,17 @@ __device__ __forceinline__ uint32_t genome_of_bucket(const uint32_t *g_boff, uin
     return lo;
 }
 
-// seed: the first (bucket, round) unit of genome g that holds an element passing the count
-// threshold is processed alone, with iterative deepening on a guessed bound; it leaves a finite
-// certified bound behind (or no element at all exists and nobody needs one)
-__global__ __launch_bounds__(K3_THREADS) void k3_bmh_seed_kernel(BmhArgs a) {
-    __shared__ SharedK3 sh;
-    extern __shared__ __attribute__((aligned(16))) uint64_t hlds[];
-    const int tid = threadIdx.x;
-    const uint32_t g = blockIdx.x, m = a.m;
-    const uint32_t b0 = a.g_boff[g], b1 = a.g_boff[g + 1];
-    uint64_t *hg = a.h + (size_t)g * m;
-    const bool use_lds = m <= K3_HLDS_MAX;
-    uint64_t *h = use_lds ? hlds : hg;
-    for (uint32_t i = tid; i < m; i += K3_THREADS) { h[i] = BMH_INF; if (use_lds) hg[i] = BMH_INF; }
-    __syncthreads();
-    const CountTab t{sh.key, sh.cnt, &sh.ones};
-    Proc stk[BMH_STACK];
-    double tw = 0.;
-    uint32_t seed_tb = ~0u, seed_r = 0;
-    double wguess = V(BMH_INF);
-    for (uint32_t tb = b0; tb < b1 && seed_tb == ~0u; ++tb) {
-        const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
-        if (nk == 0) continue;
-        const uint64_t *kb = a.keys + o0;
-        uint32_t R = 1;
-        while ((uint64_t)R * a.round_keys < nk) R <<= 1;
-        for (uint32_t r = 0; r < R; ++r) {
-            if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
-            // weight of this unit's elements -> first guess of the bound: registers fill at rate W/m each
-            const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
-            double wsum = 0.;
-            for (uint32_t e = tid; e < ne; e += K3_THREADS) wsum += (double)sh.cnt[e];
-            wsum = block_sum(wsum, reinterpret_cast<double *>(sh.red));
-            if (!(wsum > 0.)) continue;
-            seed_tb = tb; seed_r = r; tw = wsum;
-            // the genome's final maximum register is the max of m exponentials of rate W/m: mean
-            // (m/W)(ln m + 0.58), sd 1.28 m/W.  W is estimated from this unit (a hash-uniform sample
-            // of the keys); the main pass prunes against 1.25 x (mean + 6 sd) and is verified afterwards
-            // (k3_bmh_verify_kernel), so a wrong estimate costs a second pass, never exactness.
-            {
-                const double frac = ((double)nk / (double)R) / (double)(a.bucket_off[b1] - a.bucket_off[b0]);
-                const double west = wsum / frac;
-                wguess = a.guess_scale * 1.25 * (double)m * ((double)__logf((float)m) + 0.58 + 8.0) / west;
-            }
-            double beta = 2.0 * (double)m * ((double)__logf((float)m) + 1.0) / wsum;
-            for (;;) {
-                uint32_t e = tid; int sp = 0, t = BMH_NTOP; uint64_t d = 0; double w = 0.;
-                uint64_t hm = block_hmax(h, m, sh.red);
-                for (;;) {                          // one process step per lane, then refresh the live bound
-                    const double live = V(hm);
-                    const double bound = live < beta ? live : beta;
-                    bool more = true;
-                    if (sp == 0) {                  // next top strip of the current element, else the next element
-                        if (!(t < BMH_NTOP && top_edge(t) < w)) {
-                            if (e < ne) { d = sh.key[e]; w = (double)sh.cnt[e]; e += K3_THREADS; t = 0; }
-                            else more = false;
-                        }
-                        if (more) {
-                            Proc P = top_proc(d, t++);
-                            if (proc_next(P, m, bound)) stk[sp++] = P;
-                        }
-                    } else {
-                        const Proc P = stk[--sp];
-                        if (P.x <= bound) bmh_locate(P, d, w, m, bound, h, stk, sp);
-                    }
-                    if (!__syncthreads_or(more)) break;
-                    hm = block_hmax(h, m, sh.red);
-                }
-                hm = block_hmax(h, m, sh.red);
-                if (V(hm) <= beta) break;          // every dropped point was later than the final maximum: exact
-                beta *= 16.0;
-            }
-            break;
-        }
-    }
-    const uint64_t hm = block_hmax(h, m, sh.red);
-    if (use_lds) for (uint32_t i = tid; i < m; i += K3_THREADS) hg[i] = h[i];
-    if (tid == 0) {
-        const uint64_t gb = dbits(wguess);
-        a.hbound[g] = hm < gb ? hm : gb; a.guess[g] = gb; a.redo[g] = 0;
-        a.tw[g] = tw; a.seed_bucket[g] = seed_tb; a.seed_round[g] = seed_r;
-    }
+// registers to +inf, weights to zero
+__global__ __launch_bounds__(K3_THREADS) void k3_bmh_init_kernel(uint64_t *h, size_t nh, double *tw, uint32_t *redo, size_t n) {
+    const size_t i = (size_t)blockIdx.x * K3_THREADS + threadIdx.x;
+    if (i < nh) h[i] = BMH_INF;
+    if (i < n) { tw[i] = 0.; redo[i] = 0; }
 }
 
-// all other units: bound = the genome's certified bound at workgroup start
+// the pruning bound for total weight W: the final maximum register is the max of m exponentials of
+// rate W/m -- mean (m/W)(ln m + 0.58), sd 1.28 m/W; 1.25 x (mean + 6 sd) fails about once in 4000 genomes
+__host__ __device__ inline double bmh_guess(double W, double m, double lnm) { return 1.25 * (m / W) * (lnm + 0.58 + 8.0); }
+
 __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
     __shared__ SharedK3 sh;
     __shared__ QEntry queue[K3_QCAP];
@@ -547,7 +446,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
         const uint32_t n = qn < (uint32_t)K3_QCAP ? qn : (uint32_t)K3_QCAP;
         for (uint32_t i = tid; i < n; i += K3_THREADS) {
             const QEntry q = queue[i];
-            const double bound = V(__hip_atomic_load(&a.hbound[q.g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const double bound = V(a.guess[q.g]);
             Proc P = top_proc(q.d, (int)q.t);
             if (proc_next(P, m, bound)) walk_process(P, q.d, q.w, m, bound, a.h + (size_t)q.g * m, stk);
         }
@@ -556,16 +455,15 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
         __syncthreads();
     };
     // persistent workgroups: the queue has to live across buckets
-    K3_T0();
-    // each workgroup owns a contiguous range of buckets: the genome (and with it seed unit, bound,
+    // each workgroup owns a contiguous range of buckets: the genome (and with it bound and
     // registers) changes rarely and is tracked incrementally -- a binary search plus four dependent
     // scalar loads per bucket cost 16 us of exposed latency per bucket
     const uint32_t per = (a.TB + gridDim.x - 1) / gridDim.x;
     const uint32_t tb_lo = blockIdx.x * per, tb_hi = tb_lo + per < a.TB ? tb_lo + per : a.TB;
     if (tb_lo >= tb_hi) return;
     uint32_t g = genome_of_bucket(a.g_boff, a.n, tb_lo), g_end = a.g_boff[g + 1];
-    uint32_t seed_tb = a.seed_bucket[g], seed_r = a.seed_round[g];
-    bool skip_g = seed_tb == ~0u || (a.redo_mode && !a.redo[g]);
+    bool skip_g = a.redo_mode && !a.redo[g];
+    double bound = V(a.guess[g]);
     uint64_t o_next = a.bucket_off[tb_lo];
     for (uint32_t tb = tb_lo; tb < tb_hi; ++tb) {
         const uint64_t o0 = o_next;
@@ -573,8 +471,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
         const uint64_t nk = o_next - o0;
         while (tb >= g_end) {
             ++g; g_end = a.g_boff[g + 1];
-            seed_tb = a.seed_bucket[g]; seed_r = a.seed_round[g];
-            skip_g = seed_tb == ~0u || (a.redo_mode && !a.redo[g]);     // no element passes the threshold / nothing to redo
+            skip_g = a.redo_mode && !a.redo[g];                          // second passes: only genomes whose guess failed
+            bound = V(a.guess[g]);
         }
         if (nk == 0 || skip_g) continue;
         uint64_t *h = a.h + (size_t)g * m;
@@ -582,14 +480,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
         uint32_t R = 1;
         while ((uint64_t)R * a.round_keys < nk) R <<= 1;
         double tw = 0.;
-        K3_T(8);
         for (uint32_t r = 0; r < R; ++r) {
-            if (tb == seed_tb && r == seed_r) continue;
             if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
-            K3_T(9);
-            const double bound = V(__hip_atomic_load(&a.hbound[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
-            K3_T(10);
             for (uint32_t e = tid; e < ne; e += K3_THREADS) {
                 const uint64_t d = sh.key[e];
                 const double w = (double)sh.cnt[e];
@@ -602,38 +495,42 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
                     else walk_process(P, d, w, m, bound, h, stk);          // queue full: do it now
                 }
             }
-            K3_T(11);
             __syncthreads();
-            K3_T(12);
             if (qn >= (uint32_t)K3_QDRAIN) drain();
-            K3_T(13);
         }
         // per-bucket total weight (integers: exact in any order); summed per genome by the verify
-        // kernel.  No per-workgroup tightening of hbound here: thousands of same-address atomics per
-        // genome serialise in L2 (measured 25 ms per 4e5 workgroups) and the guessed bound is already
-        // within ~2x of the final maximum.
+        // kernel.  The bound is never tightened per workgroup: thousands of same-address atomics per
+        // genome serialise in L2 (measured 25 ms per 4e5 workgroups) and the guess is already within
+        // ~2x of the final maximum.
         tw = block_sum(tw, reinterpret_cast<double *>(sh.red));
         if (tid == 0 && !a.redo_mode) a.tw_bucket[tb] = tw;
-        K3_T(14);
     }
     __syncthreads();
     drain();
 }
 
-// after the main pass: was every bound that pruned a point at least the final maximum register?
+// after a pass: was the bound that pruned points at least the final maximum register?  The first
+// pass also sums the genome's total weight, from which a failed guess is recomputed.
 __global__ __launch_bounds__(K3_THREADS) void k3_bmh_verify_kernel(BmhArgs a) {
     __shared__ uint64_t red[8];
     const uint32_t g = blockIdx.x;
+    if (a.redo_mode && !a.redo[g]) return;
     const uint64_t hm = block_hmax(a.h + (size_t)g * a.m, a.m, red);
     double tw = 0.;
-    for (uint32_t tb = a.g_boff[g] + threadIdx.x; tb < a.g_boff[g + 1]; tb += K3_THREADS) tw += a.tw_bucket[tb];
-    tw = block_sum(tw, reinterpret_cast<double *>(red));
+    if (!a.redo_mode) {
+        for (uint32_t tb = a.g_boff[g] + threadIdx.x; tb < a.g_boff[g + 1]; tb += K3_THREADS) tw += a.tw_bucket[tb];
+        tw = block_sum(tw, reinterpret_cast<double *>(red));
+    }
     if (threadIdx.x == 0) {
-        a.tw[g] += tw;                                     // seed unit's weight + every other unit's
-        a.hbound[g] = hm;                                  // certified from here on
-        const bool bad = a.seed_bucket[g] != ~0u && hm > a.guess[g];
+        if (!a.redo_mode) a.tw[g] = tw; else tw = a.tw[g];
+        const double guess = V(a.guess[g]);
+        const bool bad = tw > 0. && !(V(hm) <= guess);               // no element at all: registers stay +inf, nothing to redo
         a.redo[g] = bad;
-        if (bad) atomicAdd(a.nredo, 1u);
+        if (bad) {
+            const double better = bmh_guess(tw, (double)a.m, (double)__logf((float)a.m));
+            a.guess[g] = dbits(better > 16. * guess ? better : 16. * guess);
+            atomicAdd(a.nredo, 1u);
+        }
     }
 }
 
@@ -669,13 +566,14 @@ __global__ __launch_bounds__(K3_THREADS) void k3_count_kernel(BmhArgs a) {
 struct WsArgs {
     const uint64_t *ids;
     const double *w;             // nullptr => 1.0
-    const uint64_t *set_off;     // [nsets+1]
-    const uint32_t *blk_set;     // main kernel: set of workgroup
-    const uint64_t *blk_lo;      //              first element
-    const uint32_t *blk_cnt;     //              element count
+    const uint32_t *blk_set;     // set of workgroup
+    const uint64_t *blk_lo;      // first element
+    const uint32_t *blk_cnt;     // element count
     uint32_t m;
-    uint32_t seed_elems;         // elements [0, seed_elems) of each set are the seed
-    uint64_t *h; uint64_t *hbound; double *tw;
+    uint64_t *h;                 // [nsets][m]
+    const uint64_t *guess;       // [nsets] pruning bound of this pass
+    const uint32_t *redo;        // [nsets] (redo_mode) sets to walk again
+    int redo_mode;
     int *status;
 };
 
@@ -687,87 +585,31 @@ __device__ __forceinline__ bool ws_fetch(const WsArgs &a, uint64_t idx, uint64_t
     return true;
 }
 
-template <bool SEED>
 __global__ __launch_bounds__(K3_THREADS) void k3_bmh_sets_kernel(WsArgs a) {
-    __shared__ uint64_t red[8];
-    extern __shared__ __attribute__((aligned(16))) uint64_t hlds[];
-    const int tid = threadIdx.x;
-    const uint32_t m = a.m;
-    uint32_t set; uint64_t lo; uint64_t cnt;
-    if (SEED) {
-        set = blockIdx.x;
-        lo = a.set_off[set];
-        cnt = a.set_off[set + 1] - lo;
-        if (cnt > a.seed_elems) cnt = a.seed_elems;
-    } else {
-        set = a.blk_set[blockIdx.x]; lo = a.blk_lo[blockIdx.x]; cnt = a.blk_cnt[blockIdx.x];
-    }
-    uint64_t *hg = a.h + (size_t)set * m;
+    const uint32_t set = a.blk_set[blockIdx.x];
+    if (a.redo_mode && !a.redo[set]) return;
+    const uint64_t lo = a.blk_lo[blockIdx.x], cnt = a.blk_cnt[blockIdx.x];
+    const double bound = V(a.guess[set]);
+    uint64_t *hg = a.h + (size_t)set * a.m;
     Proc stk[BMH_STACK];
-    double tw = 0.;
-    if (SEED) {
-        const bool use_lds = m <= K3_HLDS_MAX;
-        uint64_t *h = use_lds ? hlds : hg;
-        for (uint32_t i = tid; i < m; i += K3_THREADS) { h[i] = BMH_INF; if (use_lds) hg[i] = BMH_INF; }
-        // first window of seed_elems elements that carries weight (window 0 belongs to this workgroup
-        // alone; later windows are also walked by a main workgroup, which then owns their total weight)
-        const uint64_t len = a.set_off[set + 1] - lo;
-        double wsum = 0.;
-        uint64_t w0 = 0;
-        for (; w0 < len; w0 += a.seed_elems) {
-            cnt = len - w0 < a.seed_elems ? len - w0 : a.seed_elems;
-            double ws = 0.;
-            for (uint64_t e = tid; e < cnt; e += K3_THREADS) { uint64_t d; double w; if (ws_fetch(a, lo + w0 + e, d, w, a.status)) ws += w; }
-            wsum = block_sum(ws, reinterpret_cast<double *>(red));
-            if (wsum > 0.) break;
-        }
-        if (!(wsum > 0.)) { if (tid == 0) { a.hbound[set] = BMH_INF; a.tw[set] = 0.; } return; }
-        lo += w0;
-        double beta = 2.0 * (double)m * ((double)__logf((float)m) + 1.0) / wsum;
-        for (;;) {
-            uint64_t e = tid; int sp = 0, t = BMH_NTOP; uint64_t d = 0; double w = 0.;
-            uint64_t hm = block_hmax(h, m, red);
-            for (;;) {
-                const double live = V(hm);
-                const double bound = live < beta ? live : beta;
-                bool more = true;
-                if (sp == 0) {
-                    if (!(t < BMH_NTOP && top_edge(t) < w)) {
-                        bool got = false;
-                        while (e < cnt && !got) { got = ws_fetch(a, lo + e, d, w, a.status); e += K3_THREADS; }
-                        if (got) t = 0; else more = false;
-                    }
-                    if (more) {
-                        Proc P = top_proc(d, t++);
-                        if (proc_next(P, m, bound)) stk[sp++] = P;
-                    }
-                } else {
-                    const Proc P = stk[--sp];
-                    if (P.x <= bound) bmh_locate(P, d, w, m, bound, h, stk, sp);
-                }
-                if (!__syncthreads_or(more)) break;
-                hm = block_hmax(h, m, red);
-            }
-            hm = block_hmax(h, m, red);
-            if (V(hm) <= beta) break;
-            beta *= 16.0;
-        }
-        const uint64_t hm = block_hmax(h, m, red);
-        if (use_lds) for (uint32_t i = tid; i < m; i += K3_THREADS) hg[i] = h[i];
-        if (tid == 0) { a.hbound[set] = hm; a.tw[set] = w0 == 0 ? wsum : 0.; }
-    } else {
-        const double bound = V(__hip_atomic_load(&a.hbound[set], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        for (uint64_t e = tid; e < cnt; e += K3_THREADS) {
-            uint64_t d; double w;
-            if (!ws_fetch(a, lo + e, d, w, a.status)) continue;
-            tw += w;
-            walk_element(d, w, m, bound, hg, stk);
-        }
-        tw = block_sum(tw, reinterpret_cast<double *>(red));
-        if (tid == 0 && tw != 0.) atomicAdd(&a.tw[set], tw);
-        __threadfence();
-        const uint64_t hm = block_hmax(hg, m, red);
-        if (tid == 0) atomicMin((unsigned long long *)&a.hbound[set], (unsigned long long)hm);
+    for (uint64_t e = threadIdx.x; e < cnt; e += K3_THREADS) {
+        uint64_t d; double w;
+        if (ws_fetch(a, lo + e, d, w, a.status)) walk_element(d, w, a.m, bound, hg, stk);
+    }
+}
+
+// per set: max(h) <= guess ?  else raise the guess and flag the set
+__global__ __launch_bounds__(K3_THREADS) void k3_sets_verify_kernel(const uint64_t *h, uint32_t m, uint64_t *guess, uint32_t *redo,
+                                                                   const double *tw, uint32_t *nredo, int redo_mode) {
+    __shared__ uint64_t red[8];
+    const uint32_t set = blockIdx.x;
+    if (redo_mode && !redo[set]) return;
+    const uint64_t hm = block_hmax(h + (size_t)set * m, m, red);
+    if (threadIdx.x == 0) {
+        const double g = V(guess[set]);
+        const bool bad = tw[set] > 0. && !(V(hm) <= g);
+        redo[set] = bad;
+        if (bad) { guess[set] = dbits(16. * g); atomicAdd(nredo, 1u); }
     }
 }
 
@@ -785,9 +627,7 @@ struct d2g_k3_state {
     uint64_t *d_cursor = nullptr; size_t cap_cursor = 0;
     uint64_t *d_keys = nullptr; size_t cap_keys = 0;
     uint64_t *d_h = nullptr; size_t cap_h = 0;
-    uint64_t *d_hbound = nullptr; size_t cap_hbound = 0;
     double *d_tw = nullptr; size_t cap_tw = 0;
-    uint32_t *d_seed = nullptr; size_t cap_seed = 0;
     int *d_status = nullptr;               // [0] status, [1] nredo
     uint64_t *d_guess = nullptr; size_t cap_guess = 0;
     double *d_tw_bucket = nullptr; size_t cap_twb = 0;
@@ -801,8 +641,8 @@ struct d2g_k3_state {
 void d2g_k3_state_destroy(d2g_k3_state *st) {
     if (!st) return;
     (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor);
-    (void)hipFree(st->d_keys); (void)hipFree(st->d_h); (void)hipFree(st->d_hbound); (void)hipFree(st->d_tw);
-    (void)hipFree(st->d_seed); (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
+    (void)hipFree(st->d_keys); (void)hipFree(st->d_h); (void)hipFree(st->d_tw);
+    (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
     (void)hipFree(st->d_out_keys);
     delete st;
 }
@@ -880,35 +720,42 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         if (TB) hipLaunchKernelGGL(k3_count_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
     } else {
         if (int rc = d2g_grow(ctx, &st->d_h, &st->cap_h, std::max<size_t>(n * m, 1))) return rc;
-        if (int rc = d2g_grow(ctx, &st->d_hbound, &st->cap_hbound, std::max<size_t>(n, 1))) return rc;
         if (int rc = d2g_grow(ctx, &st->d_tw, &st->cap_tw, std::max<size_t>(n, 1))) return rc;
-        if (int rc = d2g_grow(ctx, &st->d_seed, &st->cap_seed, 2 * std::max<size_t>(n, 1))) return rc;
         if (int rc = d2g_grow(ctx, &st->d_guess, &st->cap_guess, std::max<size_t>(n, 1))) return rc;
         if (int rc = d2g_grow(ctx, &st->d_redo, &st->cap_redo, std::max<size_t>(n, 1))) return rc;
-        b.h = st->d_h; b.hbound = st->d_hbound; b.tw = st->d_tw; b.seed_bucket = st->d_seed; b.seed_round = st->d_seed + n;
         if (int rc = d2g_grow(ctx, &st->d_tw_bucket, &st->cap_twb, (size_t)TB + 1)) return rc;
         D2G_HIP(ctx, hipMemsetAsync(st->d_tw_bucket, 0, ((size_t)TB + 1) * sizeof(double), s));
-        b.tw_bucket = st->d_tw_bucket;
-        b.guess_scale = 1.0;
-        if (const char *e = std::getenv("D2G_K3_GUESS_SCALE")) { const double v = std::atof(e); if (v > 0.) b.guess_scale = v; }
-        b.guess = st->d_guess; b.redo = st->d_redo; b.nredo = reinterpret_cast<uint32_t *>(st->d_status + 1);
-        const size_t hl = m <= K3_HLDS_MAX ? m * sizeof(uint64_t) : 0;
-        if (hl + sizeof(SharedK3) > 48 * 1024)
-            D2G_HIP(ctx, hipFuncSetAttribute((const void *)k3_bmh_seed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
-        if (n) hipLaunchKernelGGL(k3_bmh_seed_kernel, dim3((unsigned)n), dim3(K3_THREADS), hl, s, b);
-        const unsigned main_grid = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * 8);
-        if (TB) hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
-        if (n) hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, b);
-        // a guess that proved too small: repeat those genomes' main pass under the (now finite and
-        // near-final) certified bound.  Registers only go down, so the repeat is idempotent.
-        int nredo = 0;
-        D2G_HIP(ctx, hipMemcpyAsync(&nredo, st->d_status + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        D2G_HIP(ctx, hipStreamSynchronize(s));
-        if (nredo) {
-            b.redo_mode = 1;
-            hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+        // first guess: with no count threshold the total weight IS the k-mer count; with one it is an
+        // upper bound (a too small guess only costs a second pass, which then knows the exact weight)
+        double scale = 1.0;
+        if (const char *e = std::getenv("D2G_K3_GUESS_SCALE")) { const double v = std::atof(e); if (v > 0.) scale = v; }   // tests force the redo path
+        std::vector<uint64_t> guess(n);
+        const double lnm = std::log((double)m);
+        for (size_t g = 0; g < n; ++g) {
+            const double gv = scale * bmh_guess((double)std::max<uint64_t>(kh.gk[g], 1), (double)m, lnm);
+            std::memcpy(&guess[g], &gv, 8);
         }
-        st->last_nredo = nredo;
+        D2G_HIP(ctx, hipMemcpyAsync(st->d_guess, guess.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        b.h = st->d_h; b.tw = st->d_tw; b.tw_bucket = st->d_tw_bucket; b.guess = st->d_guess; b.redo = st->d_redo;
+        b.nredo = reinterpret_cast<uint32_t *>(st->d_status + 1);
+        const size_t ninit = std::max<size_t>(n * m, n);
+        hipLaunchKernelGGL(k3_bmh_init_kernel, dim3((unsigned)div_up<size_t>(ninit, K3_THREADS)), dim3(K3_THREADS), 0, s,
+                           st->d_h, n * m, st->d_tw, st->d_redo, n);
+        const unsigned main_grid = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * 8);
+        st->last_nredo = 0;
+        for (int pass = 0;; ++pass) {
+            b.redo_mode = pass > 0;
+            if (TB) hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+            hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, b);
+            int st2[2] = {0, 0};                                  // [0] kernel status, [1] genomes whose guess failed
+            D2G_HIP(ctx, hipMemcpyAsync(st2, st->d_status, sizeof(st2), hipMemcpyDeviceToHost, s));
+            D2G_HIP(ctx, hipStreamSynchronize(s));
+            const int nredo = st2[1];
+            if (st2[0] || !nredo) break;
+            st->last_nredo += nredo;
+            D2G_CHECK(ctx, pass < 40, "internal: BagMinHash bound did not converge");
+            D2G_HIP(ctx, hipMemsetAsync(st->d_status + 1, 0, sizeof(int), s));
+        }
     }
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
@@ -916,12 +763,6 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
 }
 
 int k3_check_status(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s) {
-#ifdef K3_STATS
-    { unsigned long long h[16]; (void)hipStreamSynchronize(s); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(k3_stats), sizeof(h));
-      std::fprintf(stderr, "K3_STATS levels=%llu next_early=%llu next_full=%llu push=%llu elems=%llu locate=%llu | ticks(100MHz) meta=%llu count=%llu compact=%llu phase1=%llu sync=%llu drain=%llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[8], h[9], h[10], h[11], h[12], h[13]);
-      std::fprintf(stderr, "K3_STATS drain=%llu tail=%llu | count: clear=%llu insert=%llu sync=%llu\n", h[13], h[14], h[1], h[2], h[3]);
-      std::memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(k3_stats), h, sizeof(h)); }
-#endif
     int status = 0;
     D2G_HIP(ctx, hipMemcpyAsync(&status, st->d_status, sizeof(int), hipMemcpyDeviceToHost, s));
     D2G_HIP(ctx, hipStreamSynchronize(s));
@@ -1107,62 +948,89 @@ int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weigh
     D2G_CHECK(ctx, total == 0 || ids != nullptr, "null ids");
     for (size_t i = 0; i < nsets; ++i) D2G_CHECK(ctx, set_off[i] <= set_off[i + 1], "set_off not monotone");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t seed_elems = 1024, chunk = 2048;
+    const size_t m = sketchsize;
+    // total weights on the host (the caller's arrays are host arrays): the result, and the first guess of the bound
+    const uint32_t chunk = 2048;
     std::vector<uint32_t> bset, bcnt;
-    std::vector<uint64_t> blo;
+    std::vector<uint64_t> blo, guess(nsets);
+    std::vector<double> tw(nsets, 0.);
+    const double lnm = std::log((double)m);
+    double scale = 1.0;
+    if (const char *e = std::getenv("D2G_K3_GUESS_SCALE")) { const double v = std::atof(e); if (v > 0.) scale = v; }
     for (size_t i = 0; i < nsets; ++i) {
         const uint64_t lo = set_off[i], hi = set_off[i + 1];
-        for (uint64_t e = lo + std::min<uint64_t>(seed_elems, hi - lo); e < hi; e += chunk) {
+        double t = 0.;
+        for (uint64_t e = lo; e < hi; ++e) {
+            const double w = weights ? weights[e] : 1.0;
+            if (w > 0.) {
+                if (!(w <= 0x1p53)) { ctx->last_error = "BagMinHash weight outside (0, 2^53]"; return D2G_ERR_INVALID; }
+                t += w;
+            } else if (w != w) { ctx->last_error = "BagMinHash weight is NaN"; return D2G_ERR_INVALID; }
+        }
+        tw[i] = t;
+        const double gv = t > 0. ? scale * bmh_guess(t, (double)m, lnm) : 0.;
+        std::memcpy(&guess[i], &gv, 8);
+        for (uint64_t e = lo; e < hi; e += chunk) {
             bset.push_back((uint32_t)i); blo.push_back(e); bcnt.push_back((uint32_t)std::min<uint64_t>(chunk, hi - e));
         }
     }
     D2G_CHECK(ctx, bset.size() < (1ull << 31), "too many workgroups");
-    const size_t m = sketchsize, nb = bset.size();
-    uint64_t *d_ids = nullptr, *d_off = nullptr, *d_blo = nullptr, *d_h = nullptr, *d_hb = nullptr;
+    const size_t nb = bset.size();
+    uint64_t *d_ids = nullptr, *d_blo = nullptr, *d_h = nullptr, *d_guess = nullptr;
     double *d_w = nullptr, *d_tw = nullptr;
-    uint32_t *d_bset = nullptr, *d_bcnt = nullptr;
+    uint32_t *d_bset = nullptr, *d_bcnt = nullptr, *d_redo = nullptr;
     int *d_status = nullptr;
     int rc = D2G_OK;
     auto cleanup = [&]() {
-        (void)hipFree(d_ids); (void)hipFree(d_off); (void)hipFree(d_blo); (void)hipFree(d_h); (void)hipFree(d_hb);
+        (void)hipFree(d_ids); (void)hipFree(d_blo); (void)hipFree(d_h); (void)hipFree(d_guess); (void)hipFree(d_redo);
         (void)hipFree(d_w); (void)hipFree(d_tw); (void)hipFree(d_bset); (void)hipFree(d_bcnt); (void)hipFree(d_status);
     };
 #define K3_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->last_error = hipGetErrorString(e_); cleanup(); return D2G_ERR_HIP; } } while (0)
     K3_TRY(hipMalloc((void **)&d_ids, std::max<uint64_t>(total, 1) * 8));
-    K3_TRY(hipMalloc((void **)&d_off, (nsets + 1) * 8));
     K3_TRY(hipMalloc((void **)&d_blo, std::max<size_t>(nb, 1) * 8));
     K3_TRY(hipMalloc((void **)&d_bset, std::max<size_t>(nb, 1) * 4));
     K3_TRY(hipMalloc((void **)&d_bcnt, std::max<size_t>(nb, 1) * 4));
     K3_TRY(hipMalloc((void **)&d_h, nsets * m * 8));
-    K3_TRY(hipMalloc((void **)&d_hb, nsets * 8));
+    K3_TRY(hipMalloc((void **)&d_guess, nsets * 8));
+    K3_TRY(hipMalloc((void **)&d_redo, nsets * 4));
     K3_TRY(hipMalloc((void **)&d_tw, nsets * 8));
-    K3_TRY(hipMalloc((void **)&d_status, sizeof(int)));
+    K3_TRY(hipMalloc((void **)&d_status, 2 * sizeof(int)));
     if (weights) { K3_TRY(hipMalloc((void **)&d_w, std::max<uint64_t>(total, 1) * 8)); K3_TRY(hipMemcpy(d_w, weights, total * 8, hipMemcpyHostToDevice)); }
     if (total) K3_TRY(hipMemcpy(d_ids, ids, total * 8, hipMemcpyHostToDevice));
-    K3_TRY(hipMemcpy(d_off, set_off, (nsets + 1) * 8, hipMemcpyHostToDevice));
+    K3_TRY(hipMemcpy(d_guess, guess.data(), nsets * 8, hipMemcpyHostToDevice));
     if (nb) {
         K3_TRY(hipMemcpy(d_blo, blo.data(), nb * 8, hipMemcpyHostToDevice));
         K3_TRY(hipMemcpy(d_bset, bset.data(), nb * 4, hipMemcpyHostToDevice));
         K3_TRY(hipMemcpy(d_bcnt, bcnt.data(), nb * 4, hipMemcpyHostToDevice));
     }
-    K3_TRY(hipMemset(d_status, 0, sizeof(int)));
+    K3_TRY(hipMemset(d_status, 0, 2 * sizeof(int)));
     WsArgs a;
-    a.ids = d_ids; a.w = d_w; a.set_off = d_off; a.blk_set = d_bset; a.blk_lo = d_blo; a.blk_cnt = d_bcnt;
-    a.m = (uint32_t)m; a.seed_elems = seed_elems; a.h = d_h; a.hbound = d_hb; a.tw = d_tw; a.status = d_status;
-    const size_t hl = m <= K3_HLDS_MAX ? m * sizeof(uint64_t) : 0;
-    if (hl > 48 * 1024)
-        K3_TRY(hipFuncSetAttribute((const void *)k3_bmh_sets_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl));
+    a.ids = d_ids; a.w = d_w; a.blk_set = d_bset; a.blk_lo = d_blo; a.blk_cnt = d_bcnt;
+    a.m = (uint32_t)m; a.h = d_h; a.guess = d_guess; a.redo = d_redo; a.redo_mode = 0; a.status = d_status;
     {
         d2g_timer tm(ctx, &ctx->ev_k3, nullptr);
-        hipLaunchKernelGGL(k3_bmh_sets_kernel<true>, dim3((unsigned)nsets), dim3(K3_THREADS), hl, nullptr, a);
-        if (nb) hipLaunchKernelGGL(k3_bmh_sets_kernel<false>, dim3((unsigned)nb), dim3(K3_THREADS), 0, nullptr, a);
+        const size_t ninit = std::max<size_t>(nsets * m, nsets);
+        hipLaunchKernelGGL(k3_bmh_init_kernel, dim3((unsigned)div_up<size_t>(ninit, K3_THREADS)), dim3(K3_THREADS), 0, nullptr,
+                           d_h, nsets * m, d_tw, d_redo, nsets);
+        K3_TRY(hipMemcpy(d_tw, tw.data(), nsets * 8, hipMemcpyHostToDevice));
+        for (int pass = 0;; ++pass) {
+            a.redo_mode = pass > 0;
+            if (nb) hipLaunchKernelGGL(k3_bmh_sets_kernel, dim3((unsigned)nb), dim3(K3_THREADS), 0, nullptr, a);
+            hipLaunchKernelGGL(k3_sets_verify_kernel, dim3((unsigned)nsets), dim3(K3_THREADS), 0, nullptr, d_h, (uint32_t)m, d_guess, d_redo,
+                               d_tw, reinterpret_cast<uint32_t *>(d_status + 1), a.redo_mode);
+            int st2[2] = {0, 0};
+            K3_TRY(hipMemcpy(st2, d_status, sizeof(st2), hipMemcpyDeviceToHost));
+            if (st2[0] || !st2[1]) break;
+            if (pass >= 40) { ctx->last_error = "internal: BagMinHash bound did not converge"; cleanup(); return D2G_ERR_INTERNAL; }
+            K3_TRY(hipMemset(d_status + 1, 0, sizeof(int)));
+        }
         tm.stop();
     }
     K3_TRY(hipGetLastError());
     int status = 0;
     K3_TRY(hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost));
     K3_TRY(hipMemcpy(sig_out, d_h, nsets * m * 8, hipMemcpyDeviceToHost));
-    K3_TRY(hipMemcpy(total_weight_out, d_tw, nsets * 8, hipMemcpyDeviceToHost));
+    std::memcpy(total_weight_out, tw.data(), nsets * sizeof(double));
 #undef K3_TRY
     cleanup();
     if (status == 2) { ctx->last_error = "BagMinHash weight outside (0, 2^53]"; rc = D2G_ERR_INVALID; }

@@ -55,6 +55,11 @@ def main():
         print(f"sketch run {rep}: {dt:.2f}s wall -> {bases / dt:.3e} bases/s end-to-end (FASTA on disk -> stacked sketches)")
         for l in info:
             print("   ", l)
+    for rep in range(2):
+        dt, info = run(["sketch", "--multiset", "-v", "-k", "21", "-S", "2048", "-p", str(a.threads), "-F", lst, "-o", out + ".bmh"])
+        print(f"sketch --multiset run {rep}: {dt:.2f}s wall -> {bases / dt:.3e} bases/s end-to-end (FASTA on disk -> stacked BagMinHash sketches)")
+        for l in info:
+            print("   ", l)
     # cmp on synthetic presketched collection
     N, S = a.sketches, 1024
     regs = synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928)
