@@ -118,6 +118,35 @@ def cpu_baseline(sig_np, cards_np, S, seconds):
                       f"{'-march=native' if so else '-march=x86-64-v3'}; cpu='{model}'"}
 
 
+def cpu_baseline_multiset(L, k, S):
+    """The oracle's --multiset restatement (sort + run-length Counter, time-ordered BagMinHash) on all
+    host cores: one thread per input, like the reference's OpenMP loop over files (fastxsketch.cpp:302)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    from dashing2_amd import synth
+    so = "/tmp/libd2oracle_native.so"
+    lib = O.load(so) if os.path.exists(so) else O.load()
+    import ctypes as C
+    ncores = os.cpu_count() or 1
+    Ls = min(L, 2_000_000)
+    buf = synth.fasta_bytes("g", synth.random_genome(7, Ls))
+
+    def one(_):
+        sig = np.empty(S, np.float64)
+        tw, nk = C.c_double(), C.c_uint64()
+        lib.d2o_bmh_sketch_buffer(buf, len(buf), k, 1, 0, S, 0.0, sig.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tw), C.byref(nk))
+        return tw.value
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(ncores) as ex:
+        tws = list(ex.map(one, range(ncores)))
+    dt = time.perf_counter() - t0
+    assert all(t == Ls - k + 1 for t in tws)
+    return {"value": ncores * Ls / dt, "unit": "bases/s", "cores": ncores, "kind": "port",
+            "sample": f"{ncores} inputs of {Ls} bp sketched concurrently (one thread each) in {dt:.2f}s; oracle restatement of "
+                      f"Counter + BagMinHash (BMH-D2G spec), k={k}, S={S}"}
+
+
 def main():
     args = parse_args()
     import torch
@@ -327,6 +356,8 @@ def main():
                                          "(bucketed multi-split), which the compulsory-byte figure does not count" % nb},
                     "parity": "bit-exact vs oracle/d2_bmh_oracle.c (published BagMinHash under the BMH-D2G spec; the "
                               "reference's sketch/bmh.h is absent: parity unpinned against a real dashing2 binary)"}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            multiset["cpu_baseline"] = cpu_baseline_multiset(L, k3, S3)
         del packed, sig3, tw3
 
     cpu = None
