@@ -246,7 +246,7 @@ __device__ __forceinline__ void reg_min(uint64_t *h, uint32_t i, double x) {
 // processes are finished after the loop, where the lanes of a wave are converged again (inside
 // the loop each lane would hit the expensive branch at a different level and the wave would pay
 // for it once per level).  Same arithmetic in a different order: identical results.
-__device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk, int &sp) {
+__device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk, int &sp, int *status) {
     const int sp0 = sp;
     bool counted = false, relevant = true;
     auto park = [&](Proc &S) {
@@ -255,6 +255,7 @@ __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double boun
         const double uu = (double)((r1 >> 11) + 1) * 0x1p-53;        // (0, 1]
         if ((1.0 - uu) > bound * width * 1.000000001) return;   // see proc_next
         S.x = uu;
+        if (sp >= BMH_STACK) { atomicExch(status, 3); return; }        // cannot happen (<= one sibling per tree level); never silent
         stk[sp++] = S;
     };
     for (;;) {
@@ -333,20 +334,21 @@ __device__ __forceinline__ Proc top_proc(uint64_t d, int t) {
 }
 
 // everything below a process whose current point is at or before `bound`
-__device__ __forceinline__ void walk_process(const Proc &P0, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk) {
+__device__ __forceinline__ void walk_process(const Proc &P0, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk,
+                                             int *status) {
     int sp = 0;
-    bmh_locate(P0, d, w, m, bound, h, stk, sp);
+    bmh_locate(P0, d, w, m, bound, h, stk, sp, status);
     while (sp) {
         const Proc Q = stk[--sp];
-        if (Q.x <= bound) bmh_locate(Q, d, w, m, bound, h, stk, sp);
+        if (Q.x <= bound) bmh_locate(Q, d, w, m, bound, h, stk, sp, status);
     }
 }
 
 // walk every process of element (d, w) that can still matter under `bound`
-__device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk) {
+__device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk, int *status) {
     for (int t = 0; t < BMH_NTOP && top_edge(t) < w; ++t) {
         Proc P = top_proc(d, t);
-        if (proc_next(P, m, bound)) walk_process(P, d, w, m, bound, h, stk);
+        if (proc_next(P, m, bound)) walk_process(P, d, w, m, bound, h, stk, status);
     }
 }
 
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
             const QEntry q = queue[i];
             const double bound = V(a.guess[q.g]);
             Proc P = top_proc(q.d, (int)q.t);
-            if (proc_next(P, m, bound)) walk_process(P, q.d, q.w, m, bound, a.h + (size_t)q.g * m, stk);
+            if (proc_next(P, m, bound)) walk_process(P, q.d, q.w, m, bound, a.h + (size_t)q.g * m, stk, a.status);
         }
         __syncthreads();
         if (tid == 0) qn = 0;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
                     if (!proc_next(P, m, bound)) continue;
                     const uint32_t slot = atomicAdd(&qn, 1u);
                     if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
-                    else walk_process(P, d, w, m, bound, h, stk);          // queue full: do it now
+                    else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
                 }
             }
             __syncthreads();
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_sets_kernel(WsArgs a) {
     Proc stk[BMH_STACK];
     for (uint64_t e = threadIdx.x; e < cnt; e += K3_THREADS) {
         uint64_t d; double w;
-        if (ws_fetch(a, lo + e, d, w, a.status)) walk_element(d, w, a.m, bound, hg, stk);
+        if (ws_fetch(a, lo + e, d, w, a.status)) walk_element(d, w, a.m, bound, hg, stk, a.status);
     }
 }
 
@@ -768,6 +770,7 @@ int k3_check_status(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s) {
     D2G_HIP(ctx, hipStreamSynchronize(s));
     if (status == 1) { ctx->last_error = "internal: k-mer count table overflow"; return D2G_ERR_INTERNAL; }
     if (status == 2) { ctx->last_error = "BagMinHash weight outside (0, 2^53]"; return D2G_ERR_INVALID; }
+    if (status == 3) { ctx->last_error = "internal: BagMinHash process stack overflow"; return D2G_ERR_INTERNAL; }
     return D2G_OK;
 }
 
@@ -1034,6 +1037,7 @@ int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weigh
 #undef K3_TRY
     cleanup();
     if (status == 2) { ctx->last_error = "BagMinHash weight outside (0, 2^53]"; rc = D2G_ERR_INVALID; }
+    if (status == 3) { ctx->last_error = "internal: BagMinHash process stack overflow"; rc = D2G_ERR_INTERNAL; }
     return rc;
 }
 
