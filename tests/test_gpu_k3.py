@@ -177,3 +177,29 @@ def test_k3_many_small_and_one_large_input(gpu_ctx, d2g, oracle):
     est = (sig[300] == sig[301]).mean()
     assert abs(est - 2 / 3) < 5 * np.sqrt((2 / 9) / S), est
     assert (sig[301] <= sig[300]).all()
+
+
+def test_bmh_golden_known_answers(gpu_ctx, d2g):
+    """GPU vs the frozen BMH-D2G known answers (no oracle in the loop): tests/golden/bmh_kat.npz"""
+    import os, sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_bmh_golden as G
+    kat = np.load(os.path.join(GOLDEN, "bmh_kat.npz"))
+    ids, w, seq_ids, fasta = G.inputs()
+    for S in (64, 1000):
+        sig, tw = gpu_ctx.bmh_from_weighted(np.concatenate([ids, seq_ids]), np.concatenate([w, np.ones(seq_ids.size)]),
+                                            np.array([0, ids.size, ids.size + seq_ids.size], np.uint64), S)
+        np.testing.assert_array_equal(sig[0].view(np.uint64), kat[f"weighted_S{S}"].view(np.uint64))
+        np.testing.assert_array_equal(sig[1].view(np.uint64), kat[f"unit_S{S}"].view(np.uint64))
+        assert tw[0] == float(kat[f"weighted_tw_S{S}"]) and tw[1] == float(seq_ids.size)
+    sp = d2g.SeqPack(21)
+    sp.add_fastx(fasta)
+    sig, tw = gpu_ctx.bmh_sketch_seqpack(sp, 256)
+    np.testing.assert_array_equal(sig[0].view(np.uint64), kat["fasta_k21_S256"].view(np.uint64))
+    assert tw[0] == float(kat["fasta_tw"]) and sp.nkmers(0) == int(kat["fasta_nk"])
+    sp = d2g.SeqPack(11)
+    sp.add_fastx(fasta)
+    sig, tw = gpu_ctx.bmh_sketch_seqpack(sp, 128, canon=False, count_threshold=1.0)
+    np.testing.assert_array_equal(sig[0].view(np.uint64), kat["fasta_k11_S128_thr1"].view(np.uint64))
+    assert tw[0] == float(kat["fasta_tw_thr1"])

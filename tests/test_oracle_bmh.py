@@ -104,3 +104,25 @@ def test_bmh_sketch_buffer_is_counts_then_update(oracle):
         sig, tw, nk2 = oracle.bmh_sketch_buffer(buf, 13, 200, count_threshold=thr)
         assert nk2 == nk and tw == etw == counts[keep].sum()
         np.testing.assert_array_equal(sig.view(np.uint64), esig.view(np.uint64))
+
+
+def test_bmh_spec_known_answers(oracle):
+    """the frozen BMH-D2G known answers (tests/golden/make_bmh_golden.py): any change of the spec shows here"""
+    import os, sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_bmh_golden as G
+    kat = np.load(os.path.join(GOLDEN, "bmh_kat.npz"))
+    ids, w, seq_ids, fasta = G.inputs()
+    for S in (64, 1000):
+        sig, tw = oracle.bmh_from_weighted(ids, w, S)
+        np.testing.assert_array_equal(sig.view(np.uint64), kat[f"weighted_S{S}"].view(np.uint64))
+        assert tw == float(kat[f"weighted_tw_S{S}"])
+        np.testing.assert_array_equal(oracle.bmh_from_weighted(seq_ids, None, S)[0].view(np.uint64), kat[f"unit_S{S}"].view(np.uint64))
+    sig, tw, nk = oracle.bmh_sketch_buffer(fasta, 21, 256)
+    np.testing.assert_array_equal(sig.view(np.uint64), kat["fasta_k21_S256"].view(np.uint64))
+    assert tw == float(kat["fasta_tw"]) and nk == int(kat["fasta_nk"])
+    sig, tw, _ = oracle.bmh_sketch_buffer(fasta, 11, 128, canon=False, count_threshold=1.0)
+    np.testing.assert_array_equal(sig.view(np.uint64), kat["fasta_k11_S128_thr1"].view(np.uint64))
+    assert tw == float(kat["fasta_tw_thr1"])
+    np.testing.assert_array_equal(np.array([oracle.dlog(u) for u in kat["dlog_u"]]).view(np.uint64), kat["dlog"].view(np.uint64))
