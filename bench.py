@@ -118,6 +118,16 @@ def cpu_baseline(sig_np, cards_np, S, seconds):
                       f"{'-march=native' if so else '-march=x86-64-v3'}; cpu='{model}'"}
 
 
+def k3_pmc_traffic():
+    """HBM bytes per K3 call (250 genomes x 5 Mbp) from the committed PMC passes, or None"""
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_k3_pmc.json")
+    try:
+        d = json.load(open(p))
+        return float(sum(v.get("fetch_bytes_raw", 0.0) + v.get("write_bytes", 0.0) for k, v in d.items() if k.startswith("k3_")))
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline_multiset(L, k, S):
     """The oracle's --multiset restatement (sort + run-length Counter, time-ordered BagMinHash) on all
     host cores: one thread per input, like the reference's OpenMP loop over files (fastxsketch.cpp:302)."""
@@ -350,7 +360,9 @@ def main():
                     "config": {"workload": f"BASELINE config 5: {n_g * world} synthetic random genomes x {L} bp, k={k3}, S={S3}, "
                                            f"--multiset (BagMinHash), canonical, {nb} genomes per call"},
                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k3 chain (hist, scan, scatter, bmh_main, verify)",
+                                 "traffic": k3_pmc_traffic() if (world == 1 and nb == 250 and L == 5_000_000) else None,
+                                 "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE, same shape, profiles/r01_d_k3_pmc.json",
+                                 "kernel": "k3 chain (hist, scan, scatter, bmh_main, verify)",
                                  "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
                                  "note": "per call of %d genomes; the chain also writes and re-reads 8 B of key per k-mer "
                                          "(bucketed multi-split), which the compulsory-byte figure does not count" % nb},
