@@ -34,11 +34,13 @@ enum {
 
 void sketch_usage() {
     std::fprintf(stderr, "dashing2 sketch <opts> [fastas... (optional)]\n"
-                         "MI355X build: One-Permutation SetSketch of k-mers (k <= 32), optional all-pairs comparison.\n"
+                         "MI355X build: One-Permutation SetSketch (default) or --multiset BagMinHash of k-mers (k <= 32),\n"
+                         "optional all-pairs comparison.\n"
                          "  -k/--kmer-length k   -S/--sketchsize S   -L/--sketch-size-l2 l   -p/--threads n\n"
                          "  -F/--ffile paths.txt -Q/--qfile queries.txt  -o/--outfile stacked.bin\n"
                          "  --cmpout/--distout/--cmp-outfile out   --phylip   --binary-output   --asymmetric-all-pairs\n"
                          "  --no-canon/-C  --seed s  --cache/-W  --outprefix dir  --oph/-Z\n"
+                         "  --multiset/--bagminhash/-B [-m/--count-threshold c]   --parse-by-seq (one sketch per record of ONE file)\n"
                          "  --distance/--mash-distance --containment --symmetric-containment --intersection --union-size\n"
                          "  --batch-size n  -v\n");
 }
