@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign on a GPU box: product (C ABI) vs oracle on random parameters.
+usage: fuzz_parity.py [seconds=120] [seed=1]   -- prints one line per failure and a summary"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dashing2_amd as D                       # noqa: E402
+from dashing2_amd import synth                # noqa: E402
+from oracle import oracle as O                # noqa: E402
+
+
+def rand_fasta(rng, maxlen):
+    recs = []
+    for r in range(int(rng.integers(1, 6))):
+        L = int(rng.integers(0, maxlen))
+        g = synth.random_genome(int(rng.integers(0, 1 << 30)), max(L, 1))[:L].copy()
+        if L > 50 and rng.random() < 0.5:
+            for _ in range(int(rng.integers(1, 5))):
+                a = int(rng.integers(0, L - 1))
+                g[a:a + int(rng.integers(1, 60))] = ord("N")
+        if L > 200 and rng.random() < 0.4:                         # repeats: counts > 1
+            seg = g[:int(rng.integers(20, 200))]
+            g = np.concatenate([g, np.tile(seg, int(rng.integers(2, 30)))])
+        if rng.random() < 0.3:
+            g = np.frombuffer(bytes(g).lower(), np.uint8)
+        hdr = ">" if rng.random() < 0.8 else "@"
+        if hdr == ">":
+            recs.append(synth.fasta_bytes(f"r{r} c", g, width=int(rng.integers(10, 100))))
+        else:
+            recs.append(b"@q%d\n" % r + bytes(g) + b"\n+\n" + b"I" * len(g) + b"\n")
+    return b"".join(recs)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    ctx = D.Context(0)
+    t0 = time.time()
+    n = {"k1": 0, "k2": 0, "k3": 0, "byseq": 0}
+    fails = 0
+    while time.time() - t0 < budget:
+        which = rng.choice(["k1", "k2", "k3", "byseq"])
+        try:
+            if which == "k1":
+                k = int(rng.integers(1, 33)); S = int(rng.choice([8, 63, 64, 100, 1000, 1024, 4096])); canon = bool(rng.integers(0, 2))
+                xm = int(rng.choice([0, 0x724526e320f9967d, int(rng.integers(1, 1 << 62))]))
+                fa = [rand_fasta(rng, int(rng.choice([300, 5000, 120000]))) for _ in range(int(rng.integers(1, 5)))]
+                sp = D.SeqPack(k)
+                for f in fa:
+                    sp.add_fastx(f)
+                regs = ctx.oph_sketch_seqpack(sp, S, canon=canon, xormask=xm)
+                sig, card = D.oph_finalize(regs, S)
+                for i, f in enumerate(fa):
+                    er, es, ec, _ = O.sketch_buffer(f, k=k, canon=canon, xormask=xm, S=S)
+                    assert np.array_equal(regs[i], er) and np.array_equal(sig[i].view(np.uint64), es.view(np.uint64)) and card[i] == ec
+            elif which == "k2":
+                N = int(rng.integers(2, 700)); S = int(rng.choice([32, 64, 100, 128, 1000, 1024])); meas = int(rng.integers(0, 6))
+                regs = synth.synthetic_registers(N, S, nclusters=int(rng.integers(1, 12)), seed=int(rng.integers(0, 1 << 30)))
+                sig, card = D.oph_finalize(regs, S)
+                multiset = bool(rng.integers(0, 2))
+                got = ctx.cmp_dist_ut(sig.view(np.uint64), card, measure=meas, k=int(rng.integers(1, 33)) if False else 31,
+                                      multiset_space=multiset, algo=int(rng.choice([D.CMP_AUTO, D.CMP_DIRECT, D.CMP_BITSLICE])))
+                if multiset:
+                    neq = O.eqcounts_ut(sig)
+                    iu = np.triu_indices(N, 1)
+                    exp = np.array([O.compare_from_neq(int(c), S, card[i], card[j], meas, 31) for c, i, j in zip(neq, iu[0], iu[1])], np.float32)
+                else:
+                    exp = O.allpairs_ut(sig, card, measure=meas, k=31, nthreads=4)
+                assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+            elif which == "k3":
+                k = int(rng.integers(3, 33)); S = int(rng.choice([16, 100, 256, 2048])); canon = bool(rng.integers(0, 2))
+                thr = float(rng.choice([0, 0, 1, 3]))
+                fa = [rand_fasta(rng, int(rng.choice([300, 5000, 80000]))) for _ in range(int(rng.integers(1, 5)))]
+                sp = D.SeqPack(k)
+                for f in fa:
+                    sp.add_fastx(f)
+                sig, tw = ctx.bmh_sketch_seqpack(sp, S, canon=canon, count_threshold=thr)
+                kc = ctx.kmer_count_seqpack(sp, canon=canon, count_threshold=thr)
+                for i, f in enumerate(fa):
+                    es, et, _ = O.bmh_sketch_buffer(f, k, S, canon=canon, count_threshold=thr)
+                    ek, ec, _ = O.kmer_count_buffer(f, k, canon=canon)
+                    keep = ec.astype(np.float64) > thr
+                    assert tw[i] == et and np.array_equal(sig[i].view(np.uint64), es.view(np.uint64))
+                    assert np.array_equal(kc[i][0], ek[keep]) and np.array_equal(kc[i][1], ec[keep])
+            else:
+                k = int(rng.integers(3, 33)); S = int(rng.choice([16, 64, 256]))
+                f = b"".join(rand_fasta(rng, 2000) for _ in range(int(rng.integers(1, 8))))
+                sp = D.SeqPack(k)
+                sp.add_fastx_by_record(f)
+                names, es, ec = O.sketch_buffer_byseq(f, k, S)
+                assert [sp.name(i) for i in range(sp.ngenomes)] == names
+                regs = ctx.oph_sketch_seqpack(sp, S)
+                sig, card = D.oph_finalize(regs, S)
+                nd = ctx.kmer_distinct_seqpack(sp)
+                card = np.where(np.isnan(card), 0.0, card)
+                card = np.where(card < 10.0 * S, nd.astype(np.float64), card)
+                assert np.array_equal(sig.view(np.uint64), es.view(np.uint64)) and np.array_equal(card, ec)
+            n[which] += 1
+        except AssertionError:
+            fails += 1
+            print(f"FAIL {which} (case #{sum(n.values()) + fails}, seed {seed})", flush=True)
+    print(f"fuzz: {n} cases passed, {fails} failed in {time.time() - t0:.0f}s")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
