@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 #include <vector>
 #include <zlib.h>
+#include <immintrin.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -272,6 +273,40 @@ int d2g_ut_partition(size_t N, int nparts, size_t *bounds) {
 // ---------------------------------------------------------------------------
 // FASTX ingest -> packed run stream
 // ---------------------------------------------------------------------------
+// 32 ASCII bases -> 64 bits (2 bits/base, base i at bits [2i, 2i+2)); false if any byte is not ACGTacgt.
+// code = ((c >> 1) & 3) ^ ((c >> 2) & 1): A 0, C 1, G 2, T 3.
+__attribute__((target("avx2"))) static inline bool pack32_avx2(const char *s, uint64_t *out) {
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(s));
+    const __m256i u = _mm256_and_si256(v, _mm256_set1_epi8((char)0xDF));
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, _mm256_set1_epi8('A')), _mm256_cmpeq_epi8(u, _mm256_set1_epi8('C'))),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(u, _mm256_set1_epi8('G')), _mm256_cmpeq_epi8(u, _mm256_set1_epi8('T'))));
+    if ((uint32_t)_mm256_movemask_epi8(ok) != 0xFFFFFFFFu) return false;
+    const __m256i c1 = _mm256_and_si256(_mm256_srli_epi16(u, 1), _mm256_set1_epi8(3));
+    const __m256i c2 = _mm256_and_si256(_mm256_srli_epi16(u, 2), _mm256_set1_epi8(1));
+    const __m256i code = _mm256_xor_si256(c1, c2);
+    const __m256i p16 = _mm256_maddubs_epi16(code, _mm256_set1_epi16(0x0401));       // c0 + 4 c1 per 16-bit lane
+    const __m256i p32 = _mm256_madd_epi16(p16, _mm256_set1_epi32(0x00100001));        // 4 bases per 32-bit lane (one byte)
+    const __m256i sh = _mm256_shuffle_epi8(p32, _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                                                  0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+    const uint32_t lo = (uint32_t)_mm256_extract_epi32(sh, 0), hi = (uint32_t)_mm256_extract_epi32(sh, 4);
+    *out = (uint64_t)lo | ((uint64_t)hi << 32);
+    return true;
+}
+
+// 16-base variant (the tail of an 80-column line): 32 bits out
+__attribute__((target("avx2"))) static inline bool pack16_avx2(const char *s, uint32_t *out) {
+    const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(s));
+    const __m128i u = _mm_and_si128(v, _mm_set1_epi8((char)0xDF));
+    const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(u, _mm_set1_epi8('A')), _mm_cmpeq_epi8(u, _mm_set1_epi8('C'))),
+                                    _mm_or_si128(_mm_cmpeq_epi8(u, _mm_set1_epi8('G')), _mm_cmpeq_epi8(u, _mm_set1_epi8('T'))));
+    if (_mm_movemask_epi8(ok) != 0xFFFF) return false;
+    const __m128i code = _mm_xor_si128(_mm_and_si128(_mm_srli_epi16(u, 1), _mm_set1_epi8(3)), _mm_and_si128(_mm_srli_epi16(u, 2), _mm_set1_epi8(1)));
+    const __m128i p32 = _mm_madd_epi16(_mm_maddubs_epi16(code, _mm_set1_epi16(0x0401)), _mm_set1_epi32(0x00100001));
+    const __m128i sh = _mm_shuffle_epi8(p32, _mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+    *out = (uint32_t)_mm_cvtsi128_si32(sh);
+    return true;
+}
+
 struct d2g_seqpack {
     int k;
     std::vector<uint8_t> packed;       // 4 bases / byte
@@ -321,7 +356,41 @@ struct d2g_seqpack {
         if (packed.size() < need) packed.resize(std::max(need, packed.size() + packed.size() / 2));
         uint8_t *pk = packed.data();
         uint64_t nb = nbases, clen = cur_len;
-        for (size_t i = 0; i < n; ++i) {
+        size_t i = 0;
+        static const bool have_avx2 = __builtin_cpu_supports("avx2");
+        if (have_avx2) {
+            // 32 bases at a time while the bytes are all ACGT (the common case inside a sequence line);
+            // anything else drops to the scalar loop below for the rest of this call
+            uint64_t w;
+            while (i + 32 <= n && pack32_avx2(s + i, &w)) {
+                if (!clen) cur_start = nb;
+                const unsigned sh = (unsigned)(nb & 3) * 2;
+                uint8_t *dst = pk + (nb >> 2);
+                if (sh == 0) {
+                    std::memcpy(dst, &w, 8);
+                } else {
+                    const uint64_t lowpart = (w << sh) | dst[0];        // dst[0] holds the stream's last (4 - sh/2 ... ) bases in its low sh bits
+                    std::memcpy(dst, &lowpart, 8);
+                    dst[8] = uint8_t(w >> (64 - sh));
+                }
+                nb += 32; clen += 32; i += 32;
+            }
+            uint32_t w32;
+            if (i + 16 <= n && n - i < 32 && pack16_avx2(s + i, &w32)) {
+                if (!clen) cur_start = nb;
+                const unsigned sh = (unsigned)(nb & 3) * 2;
+                uint8_t *dst = pk + (nb >> 2);
+                if (sh == 0) {
+                    std::memcpy(dst, &w32, 4);
+                } else {
+                    const uint32_t lowpart = (w32 << sh) | dst[0];
+                    std::memcpy(dst, &lowpart, 4);
+                    dst[4] = uint8_t(w32 >> (32 - sh));
+                }
+                nb += 16; clen += 16; i += 16;
+            }
+        }
+        for (; i < n; ++i) {
             const int c = lut[(unsigned char)s[i]];
             if (c < 0) {
                 if (clen) { nbases = nb; cur_len = clen; close_run_raw(); nb = nbases; clen = 0; pk = packed.data(); }
