@@ -65,6 +65,78 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
     if (tid == 0) running = 1;                                           // id 0 is reserved for singletons
     const int lane = tid & 63, wave = tid >> 6;
 
+    // the compaction of one table pass: slots whose value occurs >= 2 times get the next dense ranks,
+    // singletons BS_UNIQ
+    auto compact = [&]() {
+        // one block-wide prefix over per-thread counts (a thread owns slots tid, tid + 1024, ...): three
+        // barriers per pass instead of three per 1024 slots; any bijection onto 1..#dups is a valid ranking
+        uint32_t cnt = 0;
+        for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) {
+            const uint32_t cur = own[h];
+            cnt += (cur != BS_EMPTY) && (cur & BS_DUP);
+        }
+        uint32_t incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+        for (int w = 0; w < BS_RANK_THREADS / 64; ++w) {
+            const uint32_t x = wave_tot[w];
+            if (w < wave) woff += x;
+            tot += x;
+        }
+        uint32_t r = running + woff + (incl - cnt);
+        for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) {
+            const uint32_t cur = own[h];
+            if (cur != BS_EMPTY) own[h] = (cur & BS_DUP) ? r++ : BS_UNIQ;
+        }
+        __syncthreads();
+        if (tid == 0) running += tot;
+        __syncthreads();
+    };
+    auto insert = [&](uint64_t v, uint32_t j, uint32_t h) {
+        for (;;) {
+            const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, j);
+            if (cur == BS_EMPTY) break;                                   // first occurrence: we own the slot
+            if (col[cur & ~BS_DUP] == v) {                                // same value seen again
+                if (!(cur & BS_DUP)) atomicOr(&own[h], BS_DUP);
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+        return h;
+    };
+
+    constexpr int PF = 12;      // values a thread keeps in registers (fast path: N <= 12288, one partition)
+    if (!MULTI && N <= (size_t)PF * BS_RANK_THREADS) {
+        // every value is fetched BEFORE the probe chains (a load inside the chain exposed a full
+        // HBM/L2 round trip per value: 76 us for the 1024 columns of config 3) and its slot stays in
+        // a register until the ids are written
+        uint64_t v[PF];
+        uint32_t hs[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const size_t j = (size_t)i * BS_RANK_THREADS + tid;
+            v[i] = j < N ? col[j] : 0;
+        }
+        for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const size_t j = (size_t)i * BS_RANK_THREADS + tid;
+            hs[i] = j < N ? insert(v[i], (uint32_t)j, bs_hash(v[i], logT) & mask) : 0u;
+        }
+        __syncthreads();
+        compact();
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const size_t j = (size_t)i * BS_RANK_THREADS + tid;
+            if (j < N) ids[j] = own[hs[i]];
+        }
+        if (tid == 0) atomicMax(&max_distinct[t >> 5], running);
+        return;
+    }
+
     for (uint32_t part = 0; part < nparts; ++part) {
         for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
         __syncthreads();
@@ -72,41 +144,10 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
             const uint64_t v = col[j];
             const uint32_t hh = bs_hash(v, logT);
             if (MULTI && (hh >> logTl) != part) continue;
-            uint32_t h = hh & mask;
-            for (;;) {
-                const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, (uint32_t)j);
-                if (cur == BS_EMPTY) break;                               // first occurrence: we own the slot
-                if (col[cur & ~BS_DUP] == v) {                            // same value seen again
-                    if (!(cur & BS_DUP)) atomicOr(&own[h], BS_DUP);
-                    break;
-                }
-                h = (h + 1) & mask;
-            }
-            ids[j] = h;
+            ids[j] = insert(v, (uint32_t)j, hh & mask);
         }
         __syncthreads();
-        // compaction: slots whose value occurs >= 2 times get the next dense ranks; singletons BS_UNIQ
-        for (uint32_t base = 0; base < Tl; base += BS_RANK_THREADS) {
-            const uint32_t h = base + tid;
-            const uint32_t cur = h < Tl ? own[h] : BS_EMPTY;
-            const bool occ = cur != BS_EMPTY;
-            const bool dup = occ && (cur & BS_DUP);
-            const unsigned long long bal = __ballot(dup);
-            const uint32_t before = __popcll(bal & ((1ull << lane) - 1));
-            if (lane == 0) wave_tot[wave] = __popcll(bal);
-            __syncthreads();
-            uint32_t woff = 0, tot = 0;
-            for (int w = 0; w < BS_RANK_THREADS / 64; ++w) {
-                const uint32_t x = wave_tot[w];
-                if (w < wave) woff += x;
-                tot += x;
-            }
-            const uint32_t r0 = running;
-            if (occ) own[h] = dup ? r0 + woff + before : BS_UNIQ;
-            __syncthreads();
-            if (tid == 0) running = r0 + tot;
-            __syncthreads();
-        }
+        compact();
         for (size_t j = tid; j < N; j += BS_RANK_THREADS) {
             if (MULTI && (bs_hash(col[j], logT) >> logTl) != part) continue;
             ids[j] = own[ids[j]];
