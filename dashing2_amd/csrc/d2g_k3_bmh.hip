@@ -157,22 +157,23 @@ __device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, u
         for (int j = 0; j < K3_KPF; ++j) {
             const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
             const uint64_t key = kreg[j];
-            if (i >= n || !ok) continue;
-            if (R > 1 && ((uint32_t)key & (R - 1)) != r) continue;
-            if (key == K3_EMPTY) { atomicAdd(t.ones, 1u); continue; }
+            const bool mine = i < n && (R == 1 || ((uint32_t)key & (R - 1)) == r);
+            if (mine && key == K3_EMPTY) atomicAdd(t.ones, 1u);
+            if (!mine || key == K3_EMPTY) continue;
+            // one exit test per probe (structured-control-flow bookkeeping is SALU work: the first
+            // version of this loop issued 30 scalar instructions per probe)
             uint32_t s = tab_hash(key);
             int probes = 0;
+            bool placed;
             for (;;) {
-                const uint64_t cur = t.key[s];
-                if (cur == key) break;
-                if (cur == K3_EMPTY) {
-                    const uint64_t prev = atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)K3_EMPTY, (unsigned long long)key);
-                    if (prev == K3_EMPTY || prev == key) break;
-                }
+                uint64_t cur = t.key[s];
+                if (cur == K3_EMPTY)
+                    cur = atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)K3_EMPTY, (unsigned long long)key) == K3_EMPTY ? key : t.key[s];
+                placed = cur == key;
+                if (placed | (++probes >= K3_TAB)) break;
                 s = (s + 1) & (K3_TAB - 1);
-                if (++probes >= K3_TAB) { ok = false; break; }
             }
-            if (ok) atomicAdd(&t.cnt[s], 1u);
+            if (placed) atomicAdd(&t.cnt[s], 1u); else ok = false;
         }
     }
     const bool res = !__syncthreads_or(!ok);
@@ -326,6 +327,14 @@ constexpr int BMH_NTOP = 65;
 __device__ __forceinline__ double top_edge(int t) {
     return t <= 16 ? (double)t : V((uint64_t)(1023 + t - 12) << 52);           // 2^(t-12)
 }
+// number of strips whose lower edge is below w (0 < w <= 2^53): strips 0..top_count(w)-1 are the relevant ones
+__device__ __forceinline__ int top_count(double w) {
+    if (w <= 16.0) { const int c = (int)w; return c + ((double)c < w); }              // ceil(w)
+    const uint64_t b = dbits(w);
+    const int e = (int)(b >> 52) - 1023;                                                // floor(log2 w) >= 4
+    const int c = 12 + e + ((b & 0x000FFFFFFFFFFFFFull) != 0);                          // edges 2^(t-12) < w  <=>  t < 12 + log2 w
+    return c < BMH_NTOP ? c : BMH_NTOP;
+}
 __device__ __forceinline__ Proc top_proc(uint64_t d, int t) {
     Proc P;
     P.p = dbits(top_edge(t)); P.q = dbits(top_edge(t + 1)); P.x = 0.; P.i = 0; P.pad = 0;
@@ -346,7 +355,8 @@ __device__ __forceinline__ void walk_process(const Proc &P0, uint64_t d, double 
 
 // walk every process of element (d, w) that can still matter under `bound`
 __device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk, int *status) {
-    for (int t = 0; t < BMH_NTOP && top_edge(t) < w; ++t) {
+    const int nt = top_count(w);
+    for (int t = 0; t < nt; ++t) {
         Proc P = top_proc(d, t);
         if (proc_next(P, m, bound)) walk_process(P, d, w, m, bound, h, stk, status);
     }
@@ -489,7 +499,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
                 const uint64_t d = sh.key[e];
                 const double w = (double)sh.cnt[e];
                 tw += w;
-                for (int tt = 0; tt < BMH_NTOP && top_edge(tt) < w; ++tt) {
+                const int nt = top_count(w);
+                for (int tt = 0; tt < nt; ++tt) {
                     Proc P = top_proc(d, tt);
                     if (!proc_next(P, m, bound)) continue;
                     const uint32_t slot = atomicAdd(&qn, 1u);
