@@ -9,6 +9,9 @@ so there is no reduction.  Each rank writes its slab at its own offset of the bi
 
 Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
              -m dashing2_amd.dist --presketched stack.bin --cmpout dist.bin [--distance] [-k 31]
+         ... -m dashing2_amd.dist sketch -F files.txt -o stack.bin [-k 31 -S 1024 --multiset ...]
+SKETCH shards by input (rank r takes files r, r+world, ...; each rank runs the CLI on its own GPU;
+no collective, one barrier) and rank 0 interleaves the shards back into input order.
 
 PyTorch is plumbing only (process group, device tensors); the computation is libd2g's.
 `compute=` lets the CPU tests substitute the checker for the device call; the product default is
@@ -224,6 +227,85 @@ class RowShardedAllPairs:
         self.full.close()
 
 
+def _default_cli_run(args, device):
+    """run the drop-in CLI on one GPU (D2G_DEVICE selects it); raises on failure"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "dashing2")
+    env = dict(os.environ, D2G_DEVICE=str(device))
+    r = subprocess.run([exe] + list(args), env=env, capture_output=True)
+    if r.returncode:
+        raise RuntimeError("dashing2 %s failed on device %s: %s" % (" ".join(args[:1]), device, r.stderr.decode()[-2000:]))
+
+
+def sketch_sharded(paths, out, cli_args=(), run=None, device=None):
+    """SKETCH across ranks (inputs sharded one-per-GPU, no collectives): rank r sketches
+    paths[r::world] with the CLI on its GPU into `out`.shard<r>; after a barrier rank 0 interleaves the
+    shards back into input order and writes the stacked file + names (F-b / F-c layouts,
+    src/sketch_core.cpp:130-161).  `run(args, device)` is the per-rank CLI call (tests substitute it)."""
+    rank, world = rank_world()
+    run = run or _default_cli_run
+    device = int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+    mine = list(range(rank, len(paths), world))
+    shard = f"{out}.shard{rank}"
+    lst = shard + ".files.txt"
+    with open(lst, "w") as f:
+        f.write("".join(paths[i] + "\n" for i in mine))
+    if mine:
+        run(["sketch", *cli_args, "-F", lst, "-o", shard], device)
+    if world > 1:
+        _dist().barrier()
+    if rank != 0:
+        return None
+    N = len(paths)
+    S = cards = sigs = None
+    for r in range(world):
+        idx = list(range(r, N, world))
+        if not idx:
+            continue
+        n_r, S_r, c_r, s_r = load_stacked(f"{out}.shard{r}")
+        if n_r != len(idx):
+            raise RuntimeError(f"shard {r} holds {n_r} sketches, expected {len(idx)}")
+        if S is None:
+            S, cards, sigs = S_r, np.empty(N, np.float64), np.empty((N, S_r), np.float64)
+        cards[idx] = c_r
+        sigs[idx] = s_r
+    with open(out, "wb") as f:
+        np.array([N, S or 0], np.uint64).tofile(f)
+        if N:
+            cards.tofile(f)
+            sigs.tofile(f)
+    with open(out + ".names.txt", "w") as f:
+        f.write("#Name\tCardinality\n")
+        for i in range(N):
+            f.write("%s\t%0.24g\n" % (paths[i], cards[i]))
+    for r in range(world):
+        for suffix in ("", ".names.txt", ".files.txt"):
+            try:
+                os.remove(f"{out}.shard{r}{suffix}")
+            except OSError:
+                pass
+    return N, S, cards, sigs
+
+
+def sketch_main(argv):
+    """python -m dashing2_amd.dist sketch -F files.txt -o stacked.bin [any `dashing2 sketch` flags]"""
+    ap = argparse.ArgumentParser(prog="dashing2_amd.dist sketch")
+    ap.add_argument("-F", "--ffile", required=True)
+    ap.add_argument("-o", "--outfile", required=True)
+    args, passthrough = ap.parse_known_args(argv)
+    dist = _dist()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)     # a barrier is all this path needs
+    paths = [l.rstrip("\n") for l in open(args.ffile) if l.strip()]
+    sketch_sharded(paths, args.outfile, passthrough)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def load_stacked(path):
     """[u64 N][u64 S][f64 card x N][f64 x N*S]  (src/sketch_core.cpp:130-140, cmp_main.cpp:61-94)"""
     raw = np.fromfile(path, np.uint8)
@@ -234,6 +316,9 @@ def load_stacked(path):
 
 
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    if argv and argv[0] == "sketch":
+        return sketch_main(argv[1:])
     import torch
     from . import capi
     ap = argparse.ArgumentParser(prog="dashing2_amd.dist")

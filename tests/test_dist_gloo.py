@@ -105,3 +105,62 @@ def test_row_sharded_exchange_gloo(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_worker_v2, args=(world, _free_port(), str(tmp_path), 5, 64), nprocs=world, join=True)
     assert os.path.exists(tmp_path / "ok2.npy")
+
+
+def _sketch_worker(rank, world, port, tmp, npaths):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from dashing2_amd import dist as D
+    from dashing2_amd import synth
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, S = 15, 64
+    paths = [os.path.join(tmp, f"g{i}.fa") for i in range(npaths)]
+    if rank == 0:
+        for i, p in enumerate(paths):
+            synth.write_fasta(p, f"g{i}", synth.random_genome(100 + i, 2000 + 300 * i))
+    dist.barrier()
+
+    def fake_cli(args, device):              # stands in for the GPU CLI: the oracle writes the shard's stacked file
+        assert args[0] == "sketch" and "-F" in args and "-o" in args
+        lst, out = args[args.index("-F") + 1], args[args.index("-o") + 1]
+        mine = [l.strip() for l in open(lst) if l.strip()]
+        sigs, cards = O.sketch_files(mine, k=k, canon=True, xormask=0, S=S, nthreads=1)
+        with open(out, "wb") as f:
+            np.array([len(mine), S], np.uint64).tofile(f)
+            cards.tofile(f)
+            sigs.tofile(f)
+
+    out = os.path.join(tmp, "stack.bin")
+    res = D.sketch_sharded(paths, out, ["-k", str(k), "-S", str(S)], run=fake_cli, device=rank)
+    if rank == 0:
+        N, S2, cards, sigs = res
+        esigs, ecards = O.sketch_files(paths, k=k, canon=True, xormask=0, S=S, nthreads=2)
+        assert N == npaths and S2 == S
+        np.testing.assert_array_equal(sigs.view(np.uint64), esigs.view(np.uint64))
+        np.testing.assert_array_equal(cards, ecards)
+        n2, s2, c2, g2 = D.load_stacked(out)
+        assert (n2, s2) == (npaths, S) and np.array_equal(g2.view(np.uint64), esigs.view(np.uint64)) and np.array_equal(c2, ecards)
+        lines = open(out + ".names.txt").read().splitlines()
+        assert lines[0] == "#Name\tCardinality" and [l.split("\t")[0] for l in lines[1:]] == paths
+        assert all(l.split("\t")[1] == "%0.24g" % c for l, c in zip(lines[1:], ecards))
+        assert not any(f.startswith("stack.bin.shard") for f in os.listdir(tmp))
+        np.save(os.path.join(tmp, "ok.npy"), np.array([1]))
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,npaths", [(2, 7), (3, 2)])
+def test_sketch_sharded_gloo(tmp_path, world, npaths):
+    """SKETCH across ranks: files r, r+world, ... per rank, one barrier, rank 0 interleaves the shards
+    back into input order (world 3 with 2 inputs leaves one rank without work)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_sketch_worker, args=(world, port, str(tmp_path), npaths), nprocs=world, join=True)
+    assert os.path.exists(tmp_path / "ok.npy")

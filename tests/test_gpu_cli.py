@@ -280,3 +280,17 @@ def test_kmer_distinct_matches_oracle(gpu_ctx, d2g, oracle):
     got = gpu_ctx.kmer_distinct_seqpack(sp)
     exp = [oracle.kmer_count_buffer(f, 11)[0].size for f in g]
     assert got.tolist() == exp
+
+
+def test_dist_sketch_tool_single_rank(genomes, tmp_path):
+    """python -m dashing2_amd.dist sketch (world 1): same stacked file and names as the CLI itself"""
+    import sys
+    lst = tmp_path / "files.txt"
+    lst.write_text("\n".join(genomes) + "\n")
+    a, b = tmp_path / "a.bin", tmp_path / "b.bin"
+    _run(["sketch", "-k", "21", "-S", "128", "-F", str(lst), "-o", str(a)])
+    r = subprocess.run([sys.executable, "-m", "dashing2_amd.dist", "sketch", "-F", str(lst), "-o", str(b), "-k", "21", "-S", "128"],
+                       capture_output=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert a.read_bytes() == b.read_bytes()
+    assert open(str(a) + ".names.txt").read() == open(str(b) + ".names.txt").read()
