@@ -100,27 +100,29 @@ __global__ __launch_bounds__(K3_THREADS) void k3_scan_kernel(K3Args a) {
 }
 
 __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
-    __shared__ uint32_t cnt[K3_MAXB];
-    __shared__ uint64_t base[K3_MAXB];
+    // ONE 16 KB LDS array: first the workgroup's count per bucket, then (after one 64-bit reservation
+    // per bucket) the next write position relative to the genome's first key -- a genome holds < 2^32
+    // k-mers -- so that a key's slot is a single LDS atomic.  (Separate count and 64-bit base arrays
+    // cost 48 KB and left room for 3 workgroups per CU.)
+    __shared__ uint32_t pos[K3_MAXB];
     const int tid = threadIdx.x;
     const uint32_t g = a.km.blk_genome[blockIdx.x];
     const uint32_t bb = a.g_bbits[g], B = 1u << bb, boff = a.g_boff[g];
-    for (uint32_t i = tid; i < B; i += K1_THREADS) cnt[i] = 0;
+    const uint64_t koff = a.g_koff[g];
+    for (uint32_t i = tid; i < B; i += K1_THREADS) pos[i] = 0;
     __syncthreads();
     const uint64_t xormask = a.xormask;
-    d2g_for_each_kmer(a.km, [&](uint64_t x) { atomicAdd(&cnt[bucket_of(wang64(x ^ xormask), bb)], 1u); });
+    d2g_for_each_kmer(a.km, [&](uint64_t x) { atomicAdd(&pos[bucket_of(wang64(x ^ xormask), bb)], 1u); });
     __syncthreads();
     for (uint32_t i = tid; i < B; i += K1_THREADS) {
-        const uint32_t c = cnt[i];
-        base[i] = c ? atomicAdd((unsigned long long *)&a.cursor[boff + i], (unsigned long long)c) : 0;
-        cnt[i] = 0;
+        const uint32_t c = pos[i];
+        if (c) pos[i] = (uint32_t)(atomicAdd((unsigned long long *)&a.cursor[boff + i], (unsigned long long)c) - koff);
     }
     __syncthreads();
+    uint64_t *keys = a.keys + koff;
     d2g_for_each_kmer(a.km, [&](uint64_t x) {
         const uint64_t key = wang64(x ^ xormask);
-        const uint32_t b = bucket_of(key, bb);
-        const uint32_t r = atomicAdd(&cnt[b], 1u);
-        a.keys[base[b] + r] = key;
+        keys[atomicAdd(&pos[bucket_of(key, bb)], 1u)] = key;
     });
 }
 
