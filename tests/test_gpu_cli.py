@@ -294,3 +294,35 @@ def test_dist_sketch_tool_single_rank(genomes, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert a.read_bytes() == b.read_bytes()
     assert open(str(a) + ".names.txt").read() == open(str(b) + ".names.txt").read()
+
+
+def test_cli_multiset_shapes_and_measures(oracle, genomes, tmp_path):
+    """multiset space through the other dense shapes and every measure: asymmetric all-pairs (square)
+    and -Q panel, binary outputs, expected from the oracle's multiset-space compare
+    (src/cmp_core.cpp:495-517) pair by pair."""
+    k, S = 17, 128
+    esigs, ecards, _ = oracle.bmh_sketch_files(genomes, k, S)
+    N = len(genomes)
+
+    def cmp_ms(i, j, meas):
+        neq = int((esigs[i] == esigs[j]).sum())
+        return oracle.compare_from_neq(neq, S, ecards[i], ecards[j], meas, k)
+
+    st = tmp_path / "ms.bin"
+    _run(["sketch", "--multiset", "-k", str(k), "-S", str(S), "-o", str(st)] + genomes)
+    for flags, meas in [([], oracle.SIMILARITY), (["--distance"], oracle.POISSON_LLR), (["--intersection"], oracle.INTERSECTION),
+                        (["--containment"], oracle.CONTAINMENT), (["--symmetric-containment"], oracle.SYMMETRIC_CONTAINMENT),
+                        (["--union-size"], oracle.UNION_SIZE)]:
+        b = tmp_path / "sq.bin"
+        _run(["cmp", "--multiset", "--presketched", "-k", str(k), "--binary-output", "--square", "--cmpout", str(b)] + flags + [str(st)])
+        exp = np.array([[cmp_ms(i, j, meas) for j in range(N)] for i in range(N)], np.float32)
+        np.testing.assert_array_equal(np.fromfile(b, np.float32).view(np.uint32), exp.reshape(-1).view(np.uint32), err_msg=str(flags))
+    # panel straight from FASTA: rows = references, columns = queries
+    refs, qs = genomes[:3], genomes[3:]
+    ff, qf = tmp_path / "r.txt", tmp_path / "q.txt"
+    ff.write_text("\n".join(refs) + "\n")
+    qf.write_text("\n".join(qs) + "\n")
+    b = tmp_path / "panel.bin"
+    _run(["sketch", "--multiset", "-k", str(k), "-S", str(S), "-F", str(ff), "-Q", str(qf), "--binary-output", "--containment", "--cmpout", str(b)])
+    exp = np.array([[cmp_ms(i, len(refs) + j, oracle.CONTAINMENT) for j in range(len(qs))] for i in range(len(refs))], np.float32)
+    np.testing.assert_array_equal(np.fromfile(b, np.float32).view(np.uint32), exp.reshape(-1).view(np.uint32))
