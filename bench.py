@@ -271,9 +271,25 @@ def main():
                "peak": VALU_PEAK_LANEOPS, "frac": (ops / (k2_ms * 1e-3) / VALU_PEAK_LANEOPS) if k2_ms > 0 else 0.0,
                "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct}
 
+    def guarded(fn):
+        """A secondary leg does LOCAL work only and returns (seconds, build(seconds_max) -> dict).  One
+        collective afterwards carries the failure flag and the max time, so an exception on any rank
+        becomes {"error": ...} on all of them instead of hanging the others or losing the primary line."""
+        err, secs, build = None, 0.0, None
+        try:
+            secs, build = fn()
+        except Exception as e:                                   # noqa: BLE001 - reported, not swallowed
+            err = f"{type(e).__name__}: {e}"
+        if world > 1:
+            t = torch.tensor([1.0 if err else 0.0, secs], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if t[0].item() > 0 and err is None:
+                err = "failed on another rank"
+            secs = float(t[1].item())
+        return {"error": err} if err else build(secs)
+
     # ---- secondary: K1 sketch construction, packed bases resident in HBM
-    sketch = None
-    if not args.no_sketch:
+    def sketch_leg():
         n_g, L, k = args.sketch_genomes, args.sketch_len, 31
         n_g = max(1, n_g // world * world) // world          # genomes are sharded one-per-rank, no collectives
         Lb = (L + 3) // 4
@@ -286,41 +302,40 @@ def main():
         regs_dev = torch.empty((n_g, m), dtype=torch.int64, device=dev)
         for _ in range(2):
             ctx.oph_sketch_dev(plan, packed.data_ptr(), S, regs_dev.data_ptr(), stream=stream)
-        barrier()
+        torch.cuda.synchronize()
         ctx.set_timing(True)
         ctx.kernel_ms("k1")
         reps = 5
         t0 = time.perf_counter()
         for _ in range(reps):
             ctx.oph_sketch_dev(plan, packed.data_ptr(), S, regs_dev.data_ptr(), stream=stream)
-        barrier()
+        torch.cuda.synchronize()
         sdt = time.perf_counter() - t0
         ctx.set_timing(False)
         _, k1_ms, _ = ctx.kernel_ms("k1")
-        if world > 1:
-            t = torch.tensor([sdt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sdt = float(t.item())
-        bases = n_g * L
-        k1_bytes = n_g * (Lb + 8 * m)
-        ach = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        sketch = {"metric": "sketch input bases/s (K1, packed bases resident in HBM)", "value": bases * world / (sdt / reps),
-                  "unit": "bases/s", "ms_per_step": sdt / reps * 1e3,
-                  "config": {"workload": f"{n_g * world} synthetic random genomes x {L} bp, k=31, S={S}, OPH, canonical"},
-                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic("k1_oph_kernel", True) if (world == 1 and n_g == 1000 and L == 5_000_000) else None,
-                               "kernel": "k1_oph_kernel",
-                               "kernel_ms": k1_ms, "algorithmic_bytes": k1_bytes}}
         # sanity: a sketch of random bases has no empty bucket and id % m == bucket
         chk = regs_dev[0].cpu().numpy().view(np.uint64)
         assert ((chk & np.uint64(m - 1)) == np.arange(m, dtype=np.uint64)).all()
-        del packed, regs_dev
+        bases = n_g * L
+        k1_bytes = n_g * (Lb + 8 * m)
+        ach = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+
+        def build(sdt):
+            return {"metric": "sketch input bases/s (K1, packed bases resident in HBM)", "value": bases * world / (sdt / reps),
+                    "unit": "bases/s", "ms_per_step": sdt / reps * 1e3,
+                    "config": {"workload": f"{n_g * world} synthetic random genomes x {L} bp, k=31, S={S}, OPH, canonical"},
+                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": ach / HBM_PEAK_GBS,
+                                 "traffic": pmc_traffic("k1_oph_kernel", True) if (world == 1 and n_g == 1000 and L == 5_000_000) else None,
+                                 "kernel": "k1_oph_kernel",
+                                 "kernel_ms": k1_ms, "algorithmic_bytes": k1_bytes}}
+        return sdt, build
+
+    sketch = None if args.no_sketch else guarded(sketch_leg)
 
     # ---- secondary: K3 --multiset sketch construction (BASELINE config 5: k=21, S=2048, exact k-mer
     # counts -> BagMinHash), packed bases resident in HBM
-    multiset = None
-    if not args.no_multiset:
+    def multiset_leg():
         n_g, L, k3, S3 = args.multiset_genomes, args.sketch_len, 21, 2048
         n_g = max(1, n_g // world * world) // world          # inputs are sharded one-per-rank, no collectives
         nb = max(1, min(args.multiset_batch, n_g))
@@ -337,40 +352,42 @@ def main():
                 ctx.bmh_sketch_dev(plan, packed.data_ptr() + b0 * Lb, S3, sig3[b0:].data_ptr(), tw3[b0:].data_ptr(), stream=stream)
 
         k3_pass()
-        barrier()
+        torch.cuda.synchronize()
         ctx.set_timing(True)
         ctx.kernel_ms("k3")
         reps = 2
         t0 = time.perf_counter()
         for _ in range(reps):
             k3_pass()
-        barrier()
+        torch.cuda.synchronize()
         mdt = time.perf_counter() - t0
         ctx.set_timing(False)
         ncalls, k3_ms, _ = ctx.kernel_ms("k3")
-        if world > 1:
-            t = torch.tensor([mdt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            mdt = float(t.item())
         k3_bytes = nb * ((L + 3) // 4 + 8 * S3 + 8)
         ach = k3_bytes / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
         assert bool(torch.isfinite(sig3).all()) and bool((tw3 == float(L - k3 + 1)).all())
-        multiset = {"metric": "multiset sketch input bases/s (K3: exact k-mer counts + BagMinHash, packed bases resident in HBM)",
-                    "value": n_g * L * world / (mdt / reps), "unit": "bases/s", "ms_per_step": mdt / reps * 1e3,
-                    "config": {"workload": f"BASELINE config 5: {n_g * world} synthetic random genomes x {L} bp, k={k3}, S={S3}, "
-                                           f"--multiset (BagMinHash), canonical, {nb} genomes per call"},
-                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": k3_pmc_traffic() if (world == 1 and nb == 250 and L == 5_000_000) else None,
-                                 "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE, same shape, profiles/r01_d_k3_pmc.json",
-                                 "kernel": "k3 chain (hist, scan, scatter, bmh_main, verify)",
-                                 "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
-                                 "note": "per call of %d genomes; the chain also writes and re-reads 8 B of key per k-mer "
-                                         "(bucketed multi-split), which the compulsory-byte figure does not count" % nb},
-                    "parity": "bit-exact vs oracle/d2_bmh_oracle.c (published BagMinHash under the BMH-D2G spec; the "
-                              "reference's sketch/bmh.h is absent: parity unpinned against a real dashing2 binary)"}
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            multiset["cpu_baseline"] = cpu_baseline_multiset(L, k3, S3)
-        del packed, sig3, tw3
+        cpu_ms = cpu_baseline_multiset(L, k3, S3) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+
+        def build(mdt):
+            out = {"metric": "multiset sketch input bases/s (K3: exact k-mer counts + BagMinHash, packed bases resident in HBM)",
+                   "value": n_g * L * world / (mdt / reps), "unit": "bases/s", "ms_per_step": mdt / reps * 1e3,
+                   "config": {"workload": f"BASELINE config 5: {n_g * world} synthetic random genomes x {L} bp, k={k3}, S={S3}, "
+                                          f"--multiset (BagMinHash), canonical, {nb} genomes per call"},
+                   "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                "traffic": k3_pmc_traffic() if (world == 1 and nb == 250 and L == 5_000_000) else None,
+                                "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE, same shape, profiles/r01_d_k3_pmc.json",
+                                "kernel": "k3 chain (hist, scan, scatter, bmh_main, verify)",
+                                "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
+                                "note": "per call of %d genomes; the chain also writes and re-reads 8 B of key per k-mer "
+                                        "(bucketed multi-split), which the compulsory-byte figure does not count" % nb},
+                   "parity": "bit-exact vs oracle/d2_bmh_oracle.c (published BagMinHash under the BMH-D2G spec; the "
+                             "reference's sketch/bmh.h is absent: parity unpinned against a real dashing2 binary)"}
+            if cpu_ms is not None:
+                out["cpu_baseline"] = cpu_ms
+            return out
+        return mdt, build
+
+    multiset = None if args.no_multiset else guarded(multiset_leg)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
