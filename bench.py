@@ -203,18 +203,37 @@ def main():
     if world > 1:
         dist.broadcast(sig_dev, 0)                           # untimed distribution of the synthetic input
     eng = cs = None
+    exchange_fallback = None
     if sharded:
+        # first (untimed) pass under a guard: if the row-sharded exchange fails on any rank (every rank
+        # learns it through one flag all-reduce) the run falls back to the whole-matrix broadcast
+        # instead of losing the measurement
         from dashing2_amd import dist as DD
         n_loc = N // world
         my_rows = sig_dev[rank * n_loc:(rank + 1) * n_loc].clone()
+        err = None
+        try:
+            eng = DD.RowShardedAllPairs(ctx, N, S, dev)
+            assert (eng.r0, eng.r1) == (r0, r1)
+            eng.step_lut(my_rows, lut, out, stream)
+            torch.cuda.synchronize()
+        except Exception as e:                                   # noqa: BLE001 - reported in the JSON line
+            err = f"{type(e).__name__}: {e}"
+        if world > 1:
+            flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.item() > 0 and err is None:
+                err = "row-sharded exchange failed on another rank"
+        if err:
+            exchange_fallback = err
+            sharded = False
+            eng = None
+    if sharded:
         del sig_dev
-        eng = DD.RowShardedAllPairs(ctx, N, S, dev)
-        assert (eng.r0, eng.r1) == (r0, r1)
 
         def step():
             # all-to-all (rows -> column slices), prepare S/W columns, all-gather planes, pair kernel
             eng.step_lut(my_rows, lut, out, stream)
-        step()
         cs = eng.full
     else:
         cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
@@ -404,7 +423,8 @@ def main():
                        "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if cs.algo == D.CMP_BITSLICE else "direct",
                        "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + pair kernel w/ fused epilogue; row-sharded sketches resident in HBM"
                                 if sharded else "RCCL broadcast (n_gpus>1) + prepare + pair kernel w/ fused epilogue; sketches resident in HBM"),
-                       "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count"},
+                       "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count",
+                       **({"exchange_fallback": exchange_fallback} if exchange_fallback else {})},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "sketch": sketch, "multiset_sketch": multiset,
         }
         print(json.dumps(line))
