@@ -285,3 +285,24 @@ def test_seqpack_by_record_matches_oracle_walk(d2g, oracle):
     assert cards.tolist() == [14.0, 0.0, 14.0, 14.0, 0.0]          # below 10 S: exact distinct canonical 5-mers
     _, _, mcards = oracle.sketch_buffer_byseq(buf, 5, 8, multiset=True)
     assert mcards.tolist() == [16.0, 0.0, 16.0, 15.0, 0.0]         # multiset: total weight = k-mer count
+
+
+def test_public_header_is_plain_c_and_links(tmp_path):
+    """include/d2g.h is the drop-in boundary: it must compile as C11 and as C++17, and a C program must
+    link against libd2g.so through it (host-only entry points; no GPU needed)."""
+    import subprocess
+    from conftest import ROOT
+    src = tmp_path / "t.c"
+    src.write_text('#include "d2g.h"\n#include <stdio.h>\n'
+                   'int main(void) { double sig[4]; double card; unsigned long long regs[4] = {1ull << 60, 3ull << 61, ~0ull, 0};\n'
+                   '  if (d2g_oph_finalize((const uint64_t *)regs, 1, 4, 4, sig, &card, 1) != D2G_OK) return 2;\n'
+                   '  printf("%llu %d %s\\n", (unsigned long long)d2g_wang_hash(133348), d2g_version(), d2g_strerror(D2G_ERR_INTERNAL));\n'
+                   '  return sig[2] == 0.0 && sig[3] == 0.0 && sig[0] > 0.0 ? 0 : 3; }\n')
+    inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "dashing2_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c11", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-ld2g", f"-Wl,-rpath,{libdir}"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    assert r.stdout.split()[2:] == ["internal", "invariant", "failed"]
