@@ -171,6 +171,17 @@ int launch_direct(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store stor
 }  // namespace
 
 // =====================================================================================
+namespace {
+__global__ __launch_bounds__(256) void k2_pack_slices_kernel(const uint64_t *__restrict__ rows, size_t n, size_t S, size_t Sl,
+                                                             uint64_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // element of the row-major input
+    if (i >= n * S) return;
+    const size_t r = i / S, c = i - r * S, q = c / Sl;
+    out[(q * n + r) * Sl + (c - q * Sl)] = rows[i];                    // reads and writes both coalesced (Sl >= 32)
+}
+}  // namespace
+
+
 extern "C" {
 
 void d2g_cmp_set_destroy(d2g_cmp_set *set) {
@@ -401,17 +412,17 @@ int d2g_cmp_set_from_planes_dev(d2g_ctx *ctx, size_t N, size_t S, const uint32_t
 }
 
 // rows [n][S] -> W consecutive blocks [n][S/W] (block q = columns [q S/W, (q+1) S/W)): the send
-// layout of the row-slice -> column-slice all-to-all
+// layout of the row-slice -> column-slice all-to-all.  One launch (W strided 2-D copies cost W launch
+// latencies on the critical path of every multi-GPU step).
 int d2g_pack_column_slices_dev(d2g_ctx *ctx, const uint64_t *rows_dev, size_t n, size_t S, int W, uint64_t *out_dev, void *stream) {
     if (!ctx) return D2G_ERR_INVALID;
     D2G_CHECK(ctx, W >= 1 && S % (size_t)W == 0, "pack_column_slices: S must be divisible by the number of ranks");
     if (!n) return D2G_OK;
     D2G_CHECK(ctx, rows_dev && out_dev, "pack_column_slices: null buffer");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t Sl = S / W;
-    for (int q = 0; q < W; ++q)
-        D2G_HIP(ctx, hipMemcpy2DAsync(out_dev + (size_t)q * n * Sl, Sl * 8, rows_dev + (size_t)q * Sl, S * 8, Sl * 8, n,
-                                      hipMemcpyDeviceToDevice, as_stream(stream)));
+    hipLaunchKernelGGL(k2_pack_slices_kernel, dim3((unsigned)div_up<size_t>(n * S, 256)), dim3(256), 0, as_stream(stream),
+                       rows_dev, n, S, S / W, out_dev);
+    D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
 
