@@ -186,13 +186,13 @@ def test_k2_rejects_bad_input(gpu_ctx, d2g):
     cs.close()
 
 
-@pytest.mark.parametrize("W", [1, 2, 4])
+@pytest.mark.parametrize("W", [1, 2, 4, 8])
 def test_k2_sharded_prepare_single_gpu(gpu_ctx, d2g, oracle, W):
     """multi-GPU prepare simulated rank by rank on one GPU: every 'rank' builds the bit-sliced
     groups of its S/W columns from its column slice; the concatenation (what the all-gather produces)
     wrapped by d2g_cmp_set_from_planes_dev must give the oracle's counts for every row range."""
     rng = np.random.default_rng(W)
-    N, S = 260, 256
+    N, S = (264 if W == 8 else 260), 256
     sigs = _planted(rng, N, S, nvals=5)
     bits = sigs.view(np.uint64)
     gw, ng = d2g.operand_layout(N, S)
@@ -274,3 +274,33 @@ def test_k2_large_n_multi_partition(gpu_ctx, d2g):
     assert int(a.sum(dtype=np.int64)) == total
     b = gpu_ctx.cmp_eqcount_ut(regs, algo=d2g.CMP_DIRECT)
     np.testing.assert_array_equal(a, b)
+
+
+def test_k2_sharded_prepare_8gpu_bench_shape(gpu_ctx, d2g):
+    """the operand the 8-GPU bench step assembles (N = 28288 = 10000*sqrt(8) rounded to 8, S = 1024:
+    each rank prepares 128 columns with the two-partition rank kernel, 15+1 plane slots per group),
+    simulated rank by rank on one GPU, must count exactly like the unsharded operand."""
+    from dashing2_amd import synth
+    N, S, W = 28288, 1024, 8
+    regs = synth.synthetic_registers(N, S, nclusters=N // 150, seed=8)
+    bits = d2g.oph_finalize(regs, S, nthreads=16)[0].view(np.uint64)
+    gw, ng = d2g.operand_layout(N, S)
+    S_loc = S // W
+    gw_l, ng_l = d2g.operand_layout(N, S_loc)
+    assert gw_l == gw and ng_l * W == ng
+    planes_all = gpu_ctx.malloc(ng * gw * 4)
+    meta_all = gpu_ctx.malloc(ng * 4)
+    for q in range(W):
+        cs = gpu_ctx.cmp_set(np.ascontiguousarray(bits[:, q * S_loc:(q + 1) * S_loc]), algo=d2g.CMP_BITSLICE)
+        cs.export_operand_dev(planes_all + q * ng_l * gw * 4, meta_all + q * ng_l * 4)
+        gpu_ctx.sync()
+        cs.close()
+    full = gpu_ctx.cmp_set_from_planes(N, S, planes_all, meta_all)
+    ref = gpu_ctx.cmp_set(bits, algo=d2g.CMP_BITSLICE)
+    b = d2g.ut_partition(N, W)
+    for r0, r1 in ((0, 1500), (b[3], b[3] + 1200), (N - 4000, N)):
+        np.testing.assert_array_equal(full.eqcount_ut(r0, r1), ref.eqcount_ut(r0, r1))
+    full.close()
+    ref.close()
+    gpu_ctx.free(planes_all)
+    gpu_ctx.free(meta_all)
