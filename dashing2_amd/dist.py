@@ -221,10 +221,59 @@ class RowShardedAllPairs:
         self.prepare(rows_t, stream)
         self.full.eqcount_ut_dev(out_t.data_ptr(), self.r0, self.r1, stream)
 
+    # ---- software-pipelined form: exchange + prepare of batch i+1 overlap the pair kernel of batch i
+    def _pipe_init(self):
+        import torch
+        dev = self.planes_all.device
+        self._xs = torch.cuda.Stream(device=dev)                   # exchange / prepare stream
+        self._pl = [self.planes_all, torch.empty_like(self.planes_all)]
+        self._mt = [self.meta_all, torch.empty_like(self.meta_all)]
+        self._full = [self.full, self.ctx.cmp_set_from_planes(self.N, self.S, self._pl[1].data_ptr(), self._mt[1].data_ptr())]
+        self._x_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._p_done = [None, None]
+        self._n = 0
+
+    def enqueue_lut(self, rows_t, lut_t, out_t):
+        """One step, pipelined over two operand buffers: the all-to-all, the sharded prepare and the
+        all-gather of step i run on their own stream while the pair kernel of step i-1 is still busy on
+        the caller's current stream.  Results land in out_t in step order; torch.cuda.synchronize()
+        (or any later work on the current stream) observes them."""
+        import torch
+        from . import capi
+        if not hasattr(self, "_xs"):
+            self._pipe_init()
+        main = torch.cuda.current_stream()
+        i = self._n & 1
+        xs = self._xs
+        if self._n == 0:
+            xs.wait_stream(main)                                    # inputs produced on the main stream
+        if self._p_done[i] is not None:
+            xs.wait_event(self._p_done[i])                          # buffer i is free once pair(i-2) is done
+        with torch.cuda.stream(xs):
+            st = xs.cuda_stream
+            self.ctx.pack_column_slices_dev(rows_t.data_ptr(), self.n_loc, self.S, self.world, self.send.data_ptr(), st)
+            exchange_rows_to_colslices(self.send, self.recv)
+            if self.local is None:
+                self.local = self.ctx.cmp_set_dev(self.recv.data_ptr(), self.N, self.S_loc, algo=capi.CMP_BITSLICE, stream=st)
+            else:
+                self.local.update_dev(self.recv.data_ptr(), st)
+            self.local.export_operand_dev(self.planes_loc.data_ptr(), self.meta_loc.data_ptr(), st)
+            gather_groups(self.planes_loc, self._pl[i])
+            gather_groups(self.meta_loc, self._mt[i])
+            self._x_done[i].record(xs)
+        main.wait_event(self._x_done[i])
+        self._full[i].lut_ut_dev(lut_t.data_ptr(), out_t.data_ptr(), self.r0, self.r1, main.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._p_done[i] = ev
+        self._n += 1
+
     def close(self):
         if self.local is not None:
             self.local.close()
         self.full.close()
+        if hasattr(self, "_full"):
+            self._full[1].close()
 
 
 def _default_cli_run(args, device):
