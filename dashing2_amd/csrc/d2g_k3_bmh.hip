@@ -39,6 +39,7 @@ constexpr int K3_MAXB = 1 << K3_MAXBBITS;   // buckets per genome (LDS histogram
 constexpr int K3_TAB = 2048;                // LDS count-table slots (24.6 KB with the counts: 6 workgroups per CU)
 constexpr int K3_ROUND_KEYS = 1400;         // keys one table round is sized for (load <= 0.69)
 constexpr int K3_TARGET = 1024;             // mean keys per bucket aimed for
+constexpr uint64_t K3_SPLIT_MIN = 4 * 1400; // mean bucket size above which a genome's buckets are split once more
 constexpr uint64_t K3_EMPTY = ~0ull;
 constexpr uint64_t BMH_INF = 0x7FF0000000000000ull;
 constexpr int BMH_STACK = 72;
@@ -139,7 +140,8 @@ __device__ __forceinline__ uint32_t tab_hash(uint64_t key) { return (uint32_t)((
 static_assert(K3_TAB == 1 << 11, "tab_hash takes the top 11 bits");
 
 // keys of round r of R (R a power of two: low key bits select the round); returns false on overflow
-__device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, uint32_t R, uint32_t r) {
+// keys of round r of R (R a power of two: key bits [shift, shift + log2 R) select the round)
+__device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, uint32_t R, uint32_t r, uint32_t shift) {
     const int tid = threadIdx.x;
     for (int s = tid; s < K3_TAB; s += K3_THREADS) { t.key[s] = K3_EMPTY; t.cnt[s] = 0; }
     if (tid == 0) *t.ones = 0;
@@ -159,7 +161,7 @@ __device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, u
         for (int j = 0; j < K3_KPF; ++j) {
             const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
             const uint64_t key = kreg[j];
-            const bool mine = i < n && (R == 1 || ((uint32_t)key & (R - 1)) == r);
+            const bool mine = i < n && (R == 1 || ((uint32_t)(key >> shift) & (R - 1)) == r);
             if (mine && key == K3_EMPTY) atomicAdd(t.ones, 1u);
             if (!mine || key == K3_EMPTY) continue;
             // one exit test per probe (structured-control-flow bookkeeping is SALU work: the first
@@ -414,6 +416,13 @@ struct BmhArgs {
     int redo_mode;           // 0 = first pass (every genome, weights are summed); 1 = only genomes with redo[g]
     uint32_t round_keys;     // K3_ROUND_KEYS; D2G_K3_ROUND_KEYS lowers it (tests force multi-round buckets on small inputs)
     int *status;
+    // big inputs: buckets of a genome with g_split[g] = s > 0 were split once more into 2^s sub-ranges by
+    // their low key bits (k3_split_kernel): sub-range j of bucket tb = skeys[sub_off[i] .. sub_off[i+1]),
+    // i = g_sub[g] + ((tb - g_boff[g]) << s) + j
+    const uint32_t *g_split;  // [n] or nullptr
+    const uint64_t *g_sub;    // [n+1]
+    uint64_t *sub_off;        // [nsub + 1]
+    uint64_t *skeys;          // [total k-mers]
     // optional R11 output (k3_count_kernel): distinct (key,count) written in place of the bucket
     uint64_t *out_keys; uint32_t *out_counts; uint32_t *bucket_nd;
 };
@@ -432,6 +441,60 @@ __device__ __forceinline__ uint32_t genome_of_bucket(const uint32_t *g_boff, uin
     uint32_t lo = 0, hi = n;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (g_boff[mid] <= tb) lo = mid; else hi = mid; }
     return lo;
+}
+
+// Buckets of big inputs hold far more keys than one table round takes (a 1 Gbp genome: 2.4e5 keys per
+// bucket = 256 rounds, each of which would re-read the whole bucket).  This pass splits such a bucket
+// ONCE by its low key bits into 2^s contiguous sub-ranges of ~1000 keys, so that every later round reads
+// only its own keys.  One workgroup per bucket at a time; the bucket (<= a few MB) stays in L2 between
+// the counting and the scattering read.
+__global__ __launch_bounds__(K3_THREADS) void k3_split_kernel(BmhArgs a) {
+    __shared__ uint32_t pos[K3_MAXB];
+    __shared__ uint32_t wsum[K3_THREADS / 64];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t tb = blockIdx.x; tb < a.TB; tb += gridDim.x) {
+        const uint32_t g = genome_of_bucket(a.g_boff, a.n, tb);
+        const uint32_t sb = a.g_split[g];
+        if (sb == 0) continue;
+        const uint32_t R = 1u << sb;
+        const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
+        const uint64_t *kb = a.keys + o0;
+        const uint64_t base = a.g_sub[g] + ((uint64_t)(tb - a.g_boff[g]) << sb);
+        for (uint32_t i = tid; i < R; i += K3_THREADS) pos[i] = 0;
+        __syncthreads();
+        constexpr int PF = 8;
+        for (uint64_t b0 = 0; b0 < nk; b0 += (uint64_t)PF * K3_THREADS) {
+            uint64_t kk[PF];
+#pragma unroll
+            for (int j = 0; j < PF; ++j) { const uint64_t i = b0 + (uint64_t)j * K3_THREADS + tid; kk[j] = i < nk ? kb[i] : 0; }
+#pragma unroll
+            for (int j = 0; j < PF; ++j) if (b0 + (uint64_t)j * K3_THREADS + tid < nk) atomicAdd(&pos[(uint32_t)kk[j] & (R - 1)], 1u);
+        }
+        __syncthreads();
+        // exclusive prefix of pos[0..R): each thread owns R / 256 consecutive counters (R <= 4096)
+        const uint32_t per = (R + K3_THREADS - 1) / K3_THREADS, lo = min(R, tid * per), hi = min(R, lo + per);
+        uint32_t sum = 0;
+        for (uint32_t i = lo; i < hi; ++i) sum += pos[i];
+        uint32_t incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((tid & 63) >= (uint32_t)o) incl += v; }
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < (tid >> 6); ++w) run += wsum[w];
+        for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = pos[i]; pos[i] = run; a.sub_off[base + i] = o0 + run; run += c; }
+        if (tid == 0) a.sub_off[base + R] = o0 + nk;            // = the next bucket's first entry (same value), or the genome's end
+        __syncthreads();
+        uint64_t *dst = a.skeys + o0;
+        for (uint64_t b0 = 0; b0 < nk; b0 += (uint64_t)PF * K3_THREADS) {
+            uint64_t kk[PF];
+#pragma unroll
+            for (int j = 0; j < PF; ++j) { const uint64_t i = b0 + (uint64_t)j * K3_THREADS + tid; kk[j] = i < nk ? kb[i] : 0; }
+#pragma unroll
+            for (int j = 0; j < PF; ++j)
+                if (b0 + (uint64_t)j * K3_THREADS + tid < nk) dst[atomicAdd(&pos[(uint32_t)kk[j] & (R - 1)], 1u)] = kk[j];
+        }
+        __syncthreads();
+    }
 }
 
 // registers to +inf, weights to zero
@@ -478,6 +541,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
     uint32_t g = genome_of_bucket(a.g_boff, a.n, tb_lo), g_end = a.g_boff[g + 1];
     bool skip_g = a.redo_mode && !a.redo[g];
     double bound = V(a.guess[g]);
+    uint32_t sbits = a.g_split ? a.g_split[g] : 0u;
     uint64_t o_next = a.bucket_off[tb_lo];
     for (uint32_t tb = tb_lo; tb < tb_hi; ++tb) {
         const uint64_t o0 = o_next;
@@ -487,32 +551,50 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
             ++g; g_end = a.g_boff[g + 1];
             skip_g = a.redo_mode && !a.redo[g];                          // second passes: only genomes whose guess failed
             bound = V(a.guess[g]);
+            sbits = a.g_split ? a.g_split[g] : 0u;
         }
         if (nk == 0 || skip_g) continue;
         uint64_t *h = a.h + (size_t)g * m;
-        const uint64_t *kb = a.keys + o0;
-        uint32_t R = 1;
-        while ((uint64_t)R * a.round_keys < nk) R <<= 1;
         double tw = 0.;
-        for (uint32_t r = 0; r < R; ++r) {
-            if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
-            const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
-            for (uint32_t e = tid; e < ne; e += K3_THREADS) {
-                const uint64_t d = sh.key[e];
-                const double w = (double)sh.cnt[e];
-                tw += w;
-                const int nt = top_count(w);
-                for (int tt = 0; tt < nt; ++tt) {
-                    Proc P = top_proc(d, tt);
-                    if (!proc_next(P, m, bound)) continue;
-                    const uint32_t slot = atomicAdd(&qn, 1u);
-                    if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
-                    else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
+        // one range of keys: as many table rounds as its size asks for; each round's elements go through phase 1
+        auto process = [&](const uint64_t *kb, uint64_t rn, uint32_t shift) -> bool {
+            uint32_t R = 1;
+            while ((uint64_t)R * a.round_keys < rn) R <<= 1;
+            for (uint32_t r = 0; r < R; ++r) {
+                if (!count_round(t, kb, rn, R, r, shift)) return false;
+                const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
+                for (uint32_t e = tid; e < ne; e += K3_THREADS) {
+                    const uint64_t d = sh.key[e];
+                    const double w = (double)sh.cnt[e];
+                    tw += w;
+                    const int nt = top_count(w);
+                    for (int tt = 0; tt < nt; ++tt) {
+                        Proc P = top_proc(d, tt);
+                        if (!proc_next(P, m, bound)) continue;
+                        const uint32_t slot = atomicAdd(&qn, 1u);
+                        if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
+                        else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
+                    }
                 }
+                __syncthreads();
+                if (qn >= (uint32_t)K3_QDRAIN) drain();
             }
-            __syncthreads();
-            if (qn >= (uint32_t)K3_QDRAIN) drain();
+            return true;
+        };
+        bool fine;
+        if (sbits == 0) {
+            fine = process(a.keys + o0, nk, 0);
+        } else {                                             // big inputs: the bucket's pre-split sub-ranges, one after the other
+            fine = true;
+            const uint64_t sub0 = a.g_sub[g] + ((uint64_t)(tb - a.g_boff[g]) << sbits);
+            uint64_t lo = a.sub_off[sub0];
+            for (uint32_t rg = 0; rg < (1u << sbits) && fine; ++rg) {
+                const uint64_t hi = a.sub_off[sub0 + rg + 1];
+                if (hi > lo) fine = process(a.skeys + lo, hi - lo, sbits);
+                lo = hi;
+            }
         }
+        if (!fine) { if (tid == 0) atomicExch(a.status, 1); return; }
         // per-bucket total weight (integers: exact in any order); summed per genome by the verify
         // kernel.  The bound is never tightened per workgroup: thousands of same-address atomics per
         // genome serialise in L2 (measured 25 ms per 4e5 workgroups) and the guess is already within
@@ -558,18 +640,27 @@ __global__ __launch_bounds__(K3_THREADS) void k3_count_kernel(BmhArgs a) {
     if (tid == 0) sh.misc = 0;
     if (nk == 0) { if (tid == 0) a.bucket_nd[tb] = 0; return; }
     const CountTab t{sh.key, sh.cnt, &sh.ones};
-    const uint64_t *kb = a.keys + o0;
-    uint32_t R = 1;
-    while ((uint64_t)R * a.round_keys < nk) R <<= 1;
-    for (uint32_t r = 0; r < R; ++r) {
-        if (!count_round(t, kb, nk, R, r)) { if (tid == 0) atomicExch(a.status, 1); return; }
-        const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
-        const uint32_t j0 = sh.misc;
-        if (a.out_keys)
-            for (uint32_t e = tid; e < ne; e += K3_THREADS) { a.out_keys[o0 + j0 + e] = sh.key[e]; a.out_counts[o0 + j0 + e] = sh.cnt[e]; }
-        __syncthreads();
-        if (tid == 0) sh.misc = j0 + ne;
-        __syncthreads();
+    const uint32_t g = a.g_split ? genome_of_bucket(a.g_boff, a.n, tb) : 0u;
+    const uint32_t sbits = a.g_split ? a.g_split[g] : 0u;
+    const uint32_t nranges = 1u << sbits;
+    const uint64_t sub0 = sbits ? a.g_sub[g] + ((uint64_t)(tb - a.g_boff[g]) << sbits) : 0;
+    for (uint32_t rg = 0; rg < nranges; ++rg) {
+        const uint64_t lo = sbits ? a.sub_off[sub0 + rg] : o0;
+        const uint64_t rn = sbits ? a.sub_off[sub0 + rg + 1] - lo : nk;
+        if (rn == 0) continue;
+        const uint64_t *kb = (sbits ? a.skeys : a.keys) + lo;
+        uint32_t R = 1;
+        while ((uint64_t)R * a.round_keys < rn) R <<= 1;
+        for (uint32_t r = 0; r < R; ++r) {
+            if (!count_round(t, kb, rn, R, r, sbits)) { if (tid == 0) atomicExch(a.status, 1); return; }
+            const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
+            const uint32_t j0 = sh.misc;
+            if (a.out_keys)
+                for (uint32_t e = tid; e < ne; e += K3_THREADS) { a.out_keys[o0 + j0 + e] = sh.key[e]; a.out_counts[o0 + j0 + e] = sh.cnt[e]; }
+            __syncthreads();
+            if (tid == 0) sh.misc = j0 + ne;
+            __syncthreads();
+        }
     }
     if (tid == 0) a.bucket_nd[tb] = sh.misc;
 }
@@ -641,6 +732,10 @@ struct d2g_k3_state {
     uint64_t *d_bucket_off = nullptr; size_t cap_boff = 0;
     uint64_t *d_cursor = nullptr; size_t cap_cursor = 0;
     uint64_t *d_keys = nullptr; size_t cap_keys = 0;
+    uint64_t *d_skeys = nullptr; size_t cap_skeys = 0;      // big inputs: keys regrouped by sub-range
+    uint64_t *d_sub_off = nullptr; size_t cap_sub_off = 0;
+    uint32_t *d_gsplit = nullptr; size_t cap_gsplit = 0;
+    uint64_t *d_gsub = nullptr; size_t cap_gsub = 0;
     uint64_t *d_h = nullptr; size_t cap_h = 0;
     double *d_tw = nullptr; size_t cap_tw = 0;
     int *d_status = nullptr;               // [0] status, [1] nredo
@@ -656,7 +751,7 @@ struct d2g_k3_state {
 void d2g_k3_state_destroy(d2g_k3_state *st) {
     if (!st) return;
     (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor);
-    (void)hipFree(st->d_keys); (void)hipFree(st->d_h); (void)hipFree(st->d_tw);
+    (void)hipFree(st->d_keys); (void)hipFree(st->d_skeys); (void)hipFree(st->d_sub_off); (void)hipFree(st->d_gsplit); (void)hipFree(st->d_gsub); (void)hipFree(st->d_h); (void)hipFree(st->d_tw);
     (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
     (void)hipFree(st->d_out_keys);
     delete st;
@@ -668,6 +763,9 @@ struct K3Host {
     std::vector<uint32_t> gtab;        // bbits[n] then boff[n+1]
     std::vector<uint64_t> gk;          // k-mers per genome
     std::vector<uint64_t> koff;        // [n+1] exclusive prefix of gk
+    std::vector<uint32_t> gsplit;      // [n] log2(sub-ranges per bucket) of big genomes, 0 otherwise
+    std::vector<uint64_t> gsub;        // [n+1] first sub-range of genome g
+    bool any_split = false;
     uint64_t total = 0;
     uint32_t TB = 0;
 };
@@ -691,6 +789,20 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     kh.TB = (uint32_t)tb;
     kh.koff.assign(n + 1, 0);
     for (size_t g = 0; g < n; ++g) kh.koff[g + 1] = kh.koff[g] + kh.gk[g];
+    // big inputs: buckets averaging more than K3_SPLIT_MIN keys are split once more (k3_split_kernel)
+    // into sub-ranges of ~K3_TARGET keys; D2G_K3_SPLIT_MIN lowers the limit so that tests reach the path
+    uint64_t split_min = K3_SPLIT_MIN;
+    if (const char *e = std::getenv("D2G_K3_SPLIT_MIN")) { const long v = std::atol(e); if (v >= 1) split_min = (uint64_t)v; }
+    kh.gsplit.assign(n, 0);
+    kh.gsub.assign(n + 1, 0);
+    for (size_t g = 0; g < n; ++g) {
+        const uint64_t B = 1ull << kh.gtab[g], mean = kh.gk[g] / B;
+        if (mean > split_min) {
+            kh.gsplit[g] = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((mean + K3_TARGET - 1) / K3_TARGET));
+            kh.any_split = true;
+        }
+        kh.gsub[g + 1] = kh.gsub[g] + (kh.gsplit[g] ? (B << kh.gsplit[g]) : 0);
+    }
     return D2G_OK;
 }
 
@@ -722,6 +834,18 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
     std::memset(&b, 0, sizeof(b));
     b.keys = st->d_keys; b.bucket_off = st->d_bucket_off; b.g_boff = st->d_gtab + n;
     b.n = (uint32_t)n; b.TB = TB; b.m = (uint32_t)m; b.thr = thr; b.status = st->d_status;
+    if (kh.any_split) {
+        const uint64_t nsub = kh.gsub[n];
+        if (int rc = d2g_grow(ctx, &st->d_skeys, &st->cap_skeys, std::max<uint64_t>(kh.total, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_sub_off, &st->cap_sub_off, nsub + 1)) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_gsplit, &st->cap_gsplit, n)) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_gsub, &st->cap_gsub, n + 1)) return rc;
+        D2G_HIP(ctx, hipMemcpyAsync(st->d_gsplit, kh.gsplit.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        D2G_HIP(ctx, hipMemcpyAsync(st->d_gsub, kh.gsub.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        b.g_split = st->d_gsplit; b.g_sub = st->d_gsub; b.sub_off = st->d_sub_off; b.skeys = st->d_skeys;
+        const unsigned gs = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * 8);
+        hipLaunchKernelGGL(k3_split_kernel, dim3(gs), dim3(K3_THREADS), 0, s, b);
+    }
     b.round_keys = K3_ROUND_KEYS;
     if (const char *e = std::getenv("D2G_K3_ROUND_KEYS")) { const int v = std::atoi(e); if (v >= 1 && v <= K3_ROUND_KEYS) b.round_keys = (uint32_t)v; }
     if (count_only) {

@@ -127,10 +127,11 @@ def test_bmh_from_weighted_matches_oracle(gpu_ctx, d2g, oracle):
 
 
 def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
-    """fresh processes with the two test hooks: D2G_K3_ROUND_KEYS=64 makes every bucket need several
+    """fresh processes with the test hooks: D2G_K3_ROUND_KEYS=64 makes every bucket need several
     table rounds (the path genomes above ~5.7 Mbp take), D2G_K3_GUESS_SCALE=1e-3 makes the guessed
-    pruning bound fail its verification so the main pass is repeated under the certified bound.
-    Counts and BagMinHash registers must not change."""
+    pruning bound fail its verification so the main pass is repeated under a larger bound,
+    D2G_K3_SPLIT_MIN lowers the bucket size above which buckets are split once more by their low key
+    bits (the path inputs above ~23 Mbp take).  Counts and BagMinHash registers must not change."""
     import os, subprocess, sys, json
     g = synth.fasta_bytes("a", synth.random_genome(31, 150000)) + synth.fasta_bytes("r", np.tile(synth.random_genome(32, 300), 30))
     fa = tmp_path / "x.fa"
@@ -143,7 +144,9 @@ def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
         "sig, tw = ctx.bmh_sketch_seqpack(sp, 128); kc = ctx.kmer_count_seqpack(sp)\n"
         "print(json.dumps([sig.view(np.uint64).tolist(), tw.tolist(), kc[0][0].tolist(), kc[0][1].tolist()]))\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(fa))
-    for env in ({"D2G_K3_ROUND_KEYS": "64"}, {"D2G_K3_GUESS_SCALE": "0.001"}, {"D2G_K3_ROUND_KEYS": "100", "D2G_K3_GUESS_SCALE": "0.01"}):
+    for env in ({"D2G_K3_ROUND_KEYS": "64"}, {"D2G_K3_GUESS_SCALE": "0.001"}, {"D2G_K3_ROUND_KEYS": "100", "D2G_K3_GUESS_SCALE": "0.01"},
+                {"D2G_K3_SPLIT_MIN": "100"},                                   # big-input path: buckets pre-split by low key bits
+                {"D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"}):       # ... and sub-ranges that still need rounds
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, env={**os.environ, **env}, timeout=300)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         sig, tw, keys, counts = json.loads(r.stdout.decode().strip().splitlines()[-1])
