@@ -3,25 +3,33 @@
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
-Primary metric (BASELINE.json): all-pairs sketch comparison throughput, **pairs/s**, on
-BASELINE config 3 at N=1: 10 000 pre-built OPH sketches, S = 1024 (49 995 000 pairs), float32
+Primary metric (BASELINE.json): all-pairs sketch comparison throughput, **pairs/s**.
+N = 1: BASELINE config 3 -- 10 000 pre-built OPH sketches, S = 1024 (49 995 000 pairs), float32
 Jaccard output.  One step = one whole pass of the path over sketches already resident in HBM:
 prepare (transpose, per-column dense ids, bit planes) + the pair kernel with its fused epilogue.
-Secondary metric in the same JSON line: sketch construction **bases/s** (K1) on BASELINE config 2's
-shape (1 000 x 5 Mbp, k=31, S=1024) with the packed bases resident in HBM.
 
-N > 1 (weak scaling, constant pairs per GPU): N_sketches = round(10000 * sqrt(N)); rank 0 owns the
-sketches, each step broadcasts them over RCCL, every rank prepares the operand and computes its
-pair-balanced row range of the upper triangle.  No other collective on the data path.
+N > 1 (default --scaling strong): BASELINE config 4 -- 50 000 sketches, S = 1024 (1 249 975 000 pairs),
+the SAME total work at every N > 1; rank r holds rows [r N/W, (r+1) N/W) (what sharded sketching leaves
+in HBM), one all-to-all + one all-gather of the compact bit-plane operand per step, every rank computes
+its pair-balanced row range of the upper triangle.  `--scaling weak` keeps pairs per GPU constant
+instead (N_sketches = 10000 * sqrt(N)).  The N = 1 line also carries `config4_1gpu`: config 4 on one GPU,
+the base a strong-scaling curve should be read against.
+
+Secondary objects in the same JSON line (N = 1 measures all of them; N > 1 shards them by input):
+  compute.matrices  the pair kernel on three matrices: unrelated sketches (1 id plane), the stated one,
+                    and an adversarial one where every value occurs exactly twice per column
+  sketch            K1 bases/s on BASELINE config 2's shape (1 000 x 5 Mbp, k=31, S=1024): synthetic
+                    genomes -> FASTA bytes -> d2g_seqpack (the product's ingest) -> HBM; kernel-only and
+                    parse-inclusive rates, and the oracle timed on the host cores beside it
+  multiset_sketch   K3 bases/s on BASELINE config 5's shape (k=21, S=2048, --multiset)
 
 PyTorch is plumbing only (device memory, streams, torch.distributed); all computation goes through
-the C ABI of libd2g.so.  The oracle is used ONLY for the cpu_baseline leg.
+the C ABI of libd2g.so.  The oracle is used ONLY for the cpu_baseline legs.
 """
 import argparse
 import json
 import math
 import os
-import subprocess
 import sys
 import time
 
@@ -32,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py
 
 
 def parse_args():
@@ -40,8 +49,13 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--algo", default="auto", choices=["auto", "direct", "bitslice"])
-    ap.add_argument("--sketches", type=int, default=10000, help="sketches at 1 GPU (config 3: 10000)")
+    ap.add_argument("--sketches", type=int, default=0, help="sketches (default: 10000 = config 3 at 1 GPU and for "
+                    "--scaling weak; 50000 = config 4 for N > 1 --scaling strong)")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="N > 1: strong (default) = BASELINE config 4, fixed 50000 sketches; weak = 10000*sqrt(N) sketches")
     ap.add_argument("--sketchsize", type=int, default=1024)
+    ap.add_argument("--no-config4", action="store_true", help="N = 1: skip the secondary config-4 (50000 sketches) run")
+    ap.add_argument("--no-matrices", action="store_true", help="N = 1: skip the plane-count sensitivity runs")
     ap.add_argument("--no-sketch", action="store_true", help="skip the secondary K1 measurement")
     ap.add_argument("--sketch-genomes", type=int, default=1000)
     ap.add_argument("--sketch-len", type=int, default=5_000_000)
@@ -60,34 +74,53 @@ def parse_args():
     return ap.parse_args()
 
 
-def pmc_traffic(kernel_substr, wide_loads):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01_c_pmc.json,
-    produced by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs of this same
-    command).  MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE
-    tallies wide (16 B/lane) coalesced reads at half their bytes -> doubled for such kernels;
-    narrow-load kernels are reported raw (uncalibrated per the guide)."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc.json")
-    if not os.path.exists(path):
-        return None
+def pmc_entry(kernel_substr):
+    """the committed rocprofv3 --pmc summary of this same command (separate FETCH_SIZE / WRITE_SIZE passes,
+    tools/pmc_round.sh + tools/pmc_summary.py), or None"""
     try:
-        for k, e in json.load(open(path)).items():
+        for k, e in json.load(open(PMC_FILE)).items():
             if kernel_substr in k and "hbm_write_bytes" in e:
-                rd = e["hbm_read_bytes_x2_wide_load_correction"] if wide_loads else e["hbm_read_bytes_raw"]
-                return rd + e["hbm_write_bytes"]
-    except Exception:
+                return e
+    except (OSError, ValueError):
         return None
     return None
 
 
-def cpu_baseline(sig_np, cards_np, S, seconds):
-    """The oracle's OpenMP all-pairs (reference loop structure) on a bounded row sample."""
+def pmc_traffic(kernel_substr, wide_loads):
+    """HBM bytes per launch.  MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE
+    tallies wide (16 B/lane) coalesced reads at half their bytes -> doubled for such kernels; narrow-load
+    kernels are reported raw (uncalibrated per the guide)."""
+    e = pmc_entry(kernel_substr)
+    if e is None:
+        return None
+    rd = e["hbm_read_bytes_x2_wide_load_correction"] if wide_loads else e["hbm_read_bytes_raw"]
+    return rd + e["hbm_write_bytes"]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
+
+
+def oracle_lib():
+    """native build of the checker for the box's host CPU (falls back to the portable x86-64-v3 build)"""
     from oracle import oracle as O
     so = None
-    try:   # native build for the box's host CPU; falls back to the portable x86-64-v3 build
+    try:
         so = O.build(march="native", out="/tmp/libd2oracle_native.so")
     except Exception:
         so = None
-    lib = O.load(so) if so else O.load()
+    return (O.load(so) if so else O.load()), ("-march=native" if so else "-march=x86-64-v3")
+
+
+def cpu_baseline(sig_np, cards_np, S, seconds):
+    """The oracle's OpenMP all-pairs (reference loop structure) on a bounded row sample."""
+    lib, march = oracle_lib()
     import ctypes as C
     ncores = os.cpu_count() or 1
     N = sig_np.shape[0]
@@ -107,42 +140,108 @@ def cpu_baseline(sig_np, cards_np, S, seconds):
     rows = int(min(N, max(2 * ncores, seconds * rate / max(N - 1, 1))))
     rows = max(ncores, rows // ncores * ncores)
     n, dt = run(0, min(rows, N))
-    model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
     return {"value": n / dt, "unit": "pairs/s", "cores": ncores, "kind": "port",
             "sample": f"rows [0,{min(rows, N)}) of the same {N}x{S} matrix = {n} pairs in {dt:.2f}s; "
-                      f"oracle OpenMP restatement of emit_rectangular+compare, batch={bs}, "
-                      f"{'-march=native' if so else '-march=x86-64-v3'}; cpu='{model}'"}
+                      f"oracle OpenMP restatement of emit_rectangular+compare, batch={bs}, {march}; cpu='{cpu_model()}'"}
 
 
-def k3_pmc_traffic():
-    """HBM bytes per K3 call (250 genomes x 5 Mbp) from the committed PMC passes, or None"""
-    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_k3_pmc.json")
+def cpu_baseline_sketch(fastas, L, k, S, seconds):
+    """K1's CPU leg.  (a) a slice of config 2: the oracle's restatement of the reference's per-file loop
+    (fastxsketch.cpp:302: one OpenMP thread per input file) over in-memory FASTA buffers, all host cores,
+    repeated until `seconds`/2 have passed; (b) BASELINE config 1 end to end: 32 x 1 Mbp FASTA files on disk
+    -> sketch (k=31, S=1024) -> all-pairs --cmpout, the oracle beside the product's CLI."""
+    from concurrent.futures import ThreadPoolExecutor
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from dashing2_amd import synth
+    lib, march = oracle_lib()
+    ncores = os.cpu_count() or 1
+    m = S + (S & 1)
+
+    def one(buf):
+        regs = np.empty(m, np.uint64)
+        sig = np.empty(S, np.float64)
+        card, nk = C.c_double(), C.c_uint64()
+        lib.d2o_sketch_buffer(buf, len(buf), k, 1, 0, S, regs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                              sig.ctypes.data_as(C.POINTER(C.c_double)), C.byref(card), C.byref(nk))
+        return nk.value
+
+    done, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(ncores) as ex:
+        while True:
+            nks = list(ex.map(one, fastas))
+            done += len(fastas)
+            dt = time.perf_counter() - t0
+            if dt >= seconds * 0.5 or done >= 64 * len(fastas):
+                break
+    assert all(x == L - k + 1 for x in nks)
+    out = {"value": done * L / dt, "unit": "bases/s", "cores": ncores, "kind": "port",
+           "sample": f"{done} sketches of in-memory {L} bp FASTA inputs ({len(fastas)} distinct genomes of config 2, one thread per input "
+                     f"as fastxsketch.cpp:302) in {dt:.2f}s; oracle restatement of Encoder::for_each + maskfn + OPSetSketch::update + "
+                     f"getcard/data, k={k}, S={S}, {march}; cpu='{cpu_model()}'"}
+    # ---- config 1 end to end
     try:
-        d = json.load(open(p))
-        return float(sum(v.get("fetch_bytes_raw", 0.0) + v.get("write_bytes", 0.0) for k, v in d.items() if k.startswith("k3_")))
-    except (OSError, ValueError):
-        return None
+        with tempfile.TemporaryDirectory(prefix="d2g_c1_") as td:
+            paths = []
+            for i in range(32):
+                p = os.path.join(td, "g%05d.fa" % i)
+                synth.write_fasta(p, "g%05d" % i, synth.random_genome(1000 + i, 1_000_000))
+                paths.append(p)
+            arr = (C.c_char_p * 32)(*[p.encode() for p in paths])
+            sigs = np.empty((32, 1024), np.float64)
+            cards = np.empty(32, np.float64)
+            dist = np.empty(32 * 31 // 2, np.float32)
+            nt = min(ncores, 32)
+            PD = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                lib.d2o_sketch_files(arr, 32, 31, 1, 0, 1024, PD(sigs), PD(cards), nt)
+                for i in range(32):
+                    lib.d2o_densify(PD(sigs[i]), 1024)
+                lib.d2o_allpairs_ut(PD(sigs), PD(cards), 32, 1024, 0, 31, dist.ctypes.data_as(C.POINTER(C.c_float)), nt, 0)
+                dt1 = time.perf_counter() - t0
+                best = dt1 if best is None else min(best, dt1)
+            c1 = {"workload": "BASELINE config 1: 32 synthetic 1 Mbp FASTA files on disk, k=31, S=1024, sketch + all-pairs (--cmpout)",
+                  "cpu_s": best, "cpu_threads": nt, "cpu_bases_per_s": 32e6 / best,
+                  "cpu_note": "oracle d2o_sketch_files (file-parallel, fastxsketch.cpp:302) + densify + d2o_allpairs_ut; best of 3"}
+            out["config1"] = c1
+            exe = os.path.join(ROOT, "dashing2_amd", "bin", "dashing2")
+            if os.path.exists(exe):
+                lst = os.path.join(td, "files.txt")
+                with open(lst, "w") as f:
+                    f.write("".join(p + "\n" for p in paths))
+                bestg = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([exe, "sketch", "-k", "31", "-S", "1024", "-F", lst, "--cmpout", os.path.join(td, "d.bin"),
+                                        "--binary-output", "-o", os.path.join(td, "s.bin"), "-p", str(nt)],
+                                       capture_output=True)
+                    dtg = time.perf_counter() - t0
+                    if r.returncode:
+                        raise RuntimeError(r.stderr.decode()[-300:])
+                    bestg = dtg if bestg is None else min(bestg, dtg)
+                got = np.fromfile(os.path.join(td, "d.bin"), np.float32)
+                same = got.size == dist.size and np.array_equal(got.view(np.uint32), dist.view(np.uint32))
+                c1["gpu_cli_s"] = bestg
+                c1["gpu_cli_note"] = ("`dashing2 sketch --cmpout` process wall time (start-up, GPU context, parse, K1, K2, output); "
+                                      "best of 3; distances %s the oracle's" % ("bit-identical to" if same else "DIFFER from"))
+    except Exception as e:                                       # noqa: BLE001 - reported in the line
+        out.setdefault("config1", {})["error"] = f"{type(e).__name__}: {e}"[:400]
+    return out
 
 
 def cpu_baseline_multiset(L, k, S):
     """The oracle's --multiset restatement (sort + run-length Counter, time-ordered BagMinHash) on all
     host cores: one thread per input, like the reference's OpenMP loop over files (fastxsketch.cpp:302)."""
     from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
     from dashing2_amd import synth
-    so = "/tmp/libd2oracle_native.so"
-    lib = O.load(so) if os.path.exists(so) else O.load()
+    lib, march = oracle_lib()
     import ctypes as C
     ncores = os.cpu_count() or 1
     Ls = min(L, 2_000_000)
-    buf = synth.fasta_bytes("g", synth.random_genome(7, Ls))
+    buf = synth.fasta_bytes_fast("g", synth.random_genome(7, Ls))
 
     def one(_):
         sig = np.empty(S, np.float64)
@@ -157,7 +256,43 @@ def cpu_baseline_multiset(L, k, S):
     assert all(t == Ls - k + 1 for t in tws)
     return {"value": ncores * Ls / dt, "unit": "bases/s", "cores": ncores, "kind": "port",
             "sample": f"{ncores} inputs of {Ls} bp sketched concurrently (one thread each) in {dt:.2f}s; oracle restatement of "
-                      f"Counter + BagMinHash (BMH-D2G spec), k={k}, S={S}"}
+                      f"Counter + BagMinHash (BMH-D2G spec), k={k}, S={S}, {march}"}
+
+
+def pack_genomes(D, synth, first, count, L, k, keep=0, nthreads=None):
+    """`count` synthetic genomes (indices first..) -> FASTA bytes -> d2g_seqpack (the product's ingest), on
+    all host cores; returns one merged packed run stream + the first `keep` FASTA buffers."""
+    from concurrent.futures import ThreadPoolExecutor
+    nthreads = nthreads or min(os.cpu_count() or 1, 64)
+    chunks = [list(range(first + c, min(first + count, first + c + 8))) for c in range(0, count, 8)]
+
+    def work(idx):
+        sp = D.SeqPack(k)
+        kept = []
+        for i in idx:
+            fa = synth.fasta_bytes_fast("g%05d" % i, synth.random_genome(i, L))
+            sp.add_fastx(fa)
+            if i - first < keep:
+                kept.append(fa)
+        packed, run_start, run_len, goff = sp.arrays()
+        res = (packed[:(sp.nbases + 3) // 4], run_start, run_len, goff, kept)
+        sp.close()
+        return res
+
+    with ThreadPoolExecutor(nthreads) as ex:
+        parts = list(ex.map(work, chunks))
+    packed, rs, rl, go, kept = [], [], [], [np.zeros(1, np.uint64)], []
+    byte_off, run_off = 0, 0
+    for p, s, l, g, kp in parts:
+        packed.append(p)
+        rs.append(s + np.uint64(byte_off * 4))
+        rl.append(l)
+        go.append(g[1:] + np.uint64(run_off))
+        byte_off += p.size
+        run_off += s.size
+        kept += kp
+    packed.append(np.zeros(64, np.uint8))
+    return np.concatenate(packed), np.concatenate(rs), np.concatenate(rl), np.concatenate(go), kept
 
 
 def main():
@@ -181,7 +316,16 @@ def main():
     ctx = D.Context(local_rank)
     algo = {"auto": D.CMP_AUTO, "direct": D.CMP_DIRECT, "bitslice": D.CMP_BITSLICE}[args.algo]
     S = args.sketchsize
-    N = int(round(args.sketches * math.sqrt(world)))
+    scaling = args.scaling or "strong"
+    if world == 1:
+        N = args.sketches or 10000
+        workload = "BASELINE config 3" if (N, S) == (10000, 1024) else "custom"
+    elif scaling == "strong":
+        N = args.sketches or 50000
+        workload = "BASELINE config 4" if (N, S) == (50000, 1024) else "custom"
+    else:
+        N = int(round((args.sketches or 10000) * math.sqrt(world)))
+        workload = "BASELINE config 3 x sqrt(n_gpus) sketches (constant pairs per GPU)"
     if world > 1:
         N = (N + world - 1) // world * world                 # equal row blocks per rank
     pairs_total = N * (N - 1) // 2
@@ -189,20 +333,24 @@ def main():
     r0, r1 = bounds[rank], bounds[rank + 1]
     my_pairs = D.ut_count(N, r0, r1)
     sharded = (world > 1 and args.exchange == "alltoall") or args.force_sharded
+    stream = torch.cuda.current_stream().cuda_stream
+    ncores = os.cpu_count() or 1
+
+    def make_sketches(n, seed=20260928):
+        regs = synth.synthetic_registers(n, S, nclusters=max(8, n // 150), seed=seed)
+        return D.oph_finalize(regs, S, nthreads=ncores)
 
     # ---- synthetic pre-built sketches, resident in HBM before the timed region.
     # N == 1 or --exchange broadcast: the whole matrix lives on rank 0.
     # N > 1 (default): rank r holds rows [r N/W, (r+1) N/W) -- what sharded sketching leaves behind.
     sig_np = cards_np = None
     if rank == 0:
-        regs = synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928)
-        sig_np, cards_np = D.oph_finalize(regs, S, nthreads=os.cpu_count() or 1)
+        sig_np, cards_np = make_sketches(N)
         sig_dev = torch.from_numpy(sig_np.view(np.int64)).to(dev)
     else:
         sig_dev = torch.empty((N, S), dtype=torch.int64, device=dev)
     lut = torch.from_numpy(D.epilogue_lut(S, D.SIMILARITY, 31)).to(dev)
     out = torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
     if world > 1:
         dist.broadcast(sig_dev, 0)                           # untimed distribution of the synthetic input
     eng = cs = None
@@ -289,6 +437,7 @@ def main():
             pipeline_check = "MISMATCH: re-measured without the overlap"
             pipelined = False
             dt = timed_run()
+        del got
     nk2, k2_ms, _ = ctx.kernel_ms("k2")
     _, prep_ms, _ = ctx.kernel_ms("k2prep")
     max_distinct, nbits, mean_nbits = cs.planes(stream)
@@ -298,25 +447,92 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = pairs_total / (dt / args.steps)
+    algo_used = cs.algo
+    ops_extra = getattr(D, "BITSLICE_OPS_PER_GROUP_EXTRA", 2)   # VALU ops per pair and 32-register group beyond the id planes
 
     # ---- roofline of the dominant kernel (the pair kernel), rank 0's launch
     alg_bytes = 8 * S * N + 4 * my_pairs          # each sketch read once + one float per pair
     achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
+    kname = "k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2_direct_kernel"
+    pmc_ok = (algo_used == D.CMP_BITSLICE and world == 1 and N == 10000 and S == 1024)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k2_bitslice_kernel", False) if (cs.algo == D.CMP_BITSLICE and world == 1 and N == 10000 and S == 1024) else None,
-                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of the same workload, profiles/r01_c_pmc.json; dword loads: read side raw/uncalibrated",
-                "kernel": "k2_bitslice_kernel" if cs.algo == D.CMP_BITSLICE else "k2_direct_kernel",
-                "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
+                "traffic": pmc_traffic(kname, False) if pmc_ok else None,
+                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of this command, profiles/r02_pmc.json "
+                                "(round 2 kernels); dword loads: read side raw/uncalibrated",
+                "kernel": kname, "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
                 "prep_ms": prep_ms,
                 "note": "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute"}
-    if cs.algo == D.CMP_BITSLICE:
-        ops = my_pairs * ((S + 31) // 32) * (mean_nbits + 2)  # id planes + unique plane (v_bitop3) + v_bcnt
-    else:
-        ops = my_pairs * S * 2
-    compute = {"bound": "valu", "unit": "lane-ops/s", "achieved": ops / (k2_ms * 1e-3) if k2_ms > 0 else 0.0,
-               "peak": VALU_PEAK_LANEOPS, "frac": (ops / (k2_ms * 1e-3) / VALU_PEAK_LANEOPS) if k2_ms > 0 else 0.0,
+
+    def valu(pairs, mean_planes, ms):
+        if algo_used == D.CMP_BITSLICE:
+            ops = pairs * ((S + 31) // 32) * (mean_planes + ops_extra)
+        else:
+            ops = pairs * S * 2
+        a = ops / (ms * 1e-3) if ms > 0 else 0.0
+        return a, a / VALU_PEAK_LANEOPS
+
+    va, vf = valu(my_pairs, mean_nbits, k2_ms)
+    compute = {"bound": "valu", "unit": "lane-ops/s", "achieved": va, "peak": VALU_PEAK_LANEOPS, "frac": vf,
                "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct}
+
+    def measure_matrix(bits_np, n, steps=5):
+        """prepare + pair kernel of an n x S matrix on this GPU, whole triangle; returns a small dict"""
+        t_dev = torch.from_numpy(bits_np.view(np.int64)).to(dev)
+        o = torch.empty(n * (n - 1) // 2, dtype=torch.float32, device=dev)
+        c = ctx.cmp_set_dev(t_dev.data_ptr(), n, S, algo=algo, stream=stream)
+        for _ in range(2):
+            c.update_dev(t_dev.data_ptr(), stream)
+            c.lut_ut_dev(lut.data_ptr(), o.data_ptr(), 0, n, stream)
+        torch.cuda.synchronize()
+        ctx.set_timing(True)
+        ctx.kernel_ms("k2"), ctx.kernel_ms("k2prep")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c.update_dev(t_dev.data_ptr(), stream)
+            c.lut_ut_dev(lut.data_ptr(), o.data_ptr(), 0, n, stream)
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t0) / steps
+        ctx.set_timing(False)
+        _, kms, _ = ctx.kernel_ms("k2")
+        _, pms, _ = ctx.kernel_ms("k2prep")
+        md, nb, mean = c.planes(stream)
+        c.close()
+        npairs = n * (n - 1) // 2
+        ab = 8 * S * n + 4 * npairs
+        return {"sketches": n, "pairs_per_s": npairs / d, "ms_per_step": d * 1e3, "kernel_ms": kms, "prep_ms": pms,
+                "bit_planes_max": nb, "bit_planes_mean": mean, "max_shared_values_per_column_plus1": md,
+                "hbm_frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else 0.0,
+                "valu_frac": valu(npairs, mean, kms)[1]}
+
+    config4 = None
+    if world == 1 and not args.force_sharded:
+        del out
+        torch.cuda.empty_cache()
+        if not args.no_matrices:
+            # the plane count -- and with it the pair kernel's time -- depends on how many values a register
+            # column shares among sketches: report the two extremes beside the stated matrix
+            mats = {}
+            try:
+                mats["stated (clustered collection, %d clusters)" % max(8, N // 150)] = {
+                    "sketches": N, "pairs_per_s": value, "ms_per_step": ms_per_step, "kernel_ms": k2_ms, "prep_ms": prep_ms,
+                    "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct,
+                    "hbm_frac": achieved / HBM_PEAK_GBS, "valu_frac": vf}
+                mats["unrelated (no value shared by two sketches)"] = measure_matrix(synth.unrelated_registers(N, S), N)
+                mats["adversarial (every value occurs exactly twice in its column)"] = measure_matrix(synth.paired_registers(N, S), N)
+            except Exception as e:                               # noqa: BLE001 - reported in the line
+                mats["error"] = f"{type(e).__name__}: {e}"
+            compute["matrices"] = mats
+        if not args.no_config4 and S == 1024:
+            try:
+                s4, _ = make_sketches(50000, seed=20260929)
+                r = measure_matrix(s4.view(np.uint64), 50000, steps=3)
+                del s4
+                r["workload"] = "BASELINE config 4 on ONE GPU: 50000 pre-built OPH sketches, S=1024, 1249975000 pairs, float32 Jaccard"
+                config4 = r
+            except Exception as e:                               # noqa: BLE001
+                config4 = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
 
     def guarded(fn):
         """A secondary leg does LOCAL work only and returns (seconds, build(seconds_max) -> dict).  One
@@ -335,15 +551,17 @@ def main():
             secs = float(t[1].item())
         return {"error": err} if err else build(secs)
 
-    # ---- secondary: K1 sketch construction, packed bases resident in HBM
+    # ---- secondary: K1 sketch construction (config 2's shape).  Inputs: synthetic genomes rendered as FASTA
+    # and ingested by the product's own parser/packer (d2g_seqpack); the packed run stream is resident in
+    # HBM when the timed region starts.
     def sketch_leg():
-        n_g, L, k = args.sketch_genomes, args.sketch_len, 31
-        n_g = max(1, n_g // world * world) // world          # genomes are sharded one-per-rank, no collectives
-        Lb = (L + 3) // 4
-        packed = torch.randint(0, 256, (n_g * Lb + 64,), dtype=torch.uint8, device=dev)   # uniform random 2-bit bases
-        run_start = (np.arange(n_g, dtype=np.uint64) * np.uint64(Lb * 4))
-        run_len = np.full(n_g, L, np.uint32)
-        goff = np.arange(n_g + 1, dtype=np.uint64)
+        n_all, L, k = args.sketch_genomes, args.sketch_len, 31
+        n_g = max(1, n_all // world * world) // world        # genomes are sharded one-per-rank, no collectives
+        keep = min(n_g, max(16, min(2 * ncores, 256)))
+        t0 = time.perf_counter()
+        packed_np, run_start, run_len, goff, fastas = pack_genomes(D, synth, rank * n_g, n_g, L, k, keep=keep)
+        gen_s = time.perf_counter() - t0
+        packed = torch.from_numpy(packed_np).to(dev)
         plan = ctx.oph_plan(run_start, run_len, goff, k)
         m = D.oph_m(S)
         regs_dev = torch.empty((n_g, m), dtype=torch.int64, device=dev)
@@ -360,22 +578,66 @@ def main():
         sdt = time.perf_counter() - t0
         ctx.set_timing(False)
         _, k1_ms, _ = ctx.kernel_ms("k1")
-        # sanity: a sketch of random bases has no empty bucket and id % m == bucket
-        chk = regs_dev[0].cpu().numpy().view(np.uint64)
-        assert ((chk & np.uint64(m - 1)) == np.arange(m, dtype=np.uint64)).all()
-        bases = n_g * L
-        k1_bytes = n_g * (Lb + 8 * m)
+        # sanity: a sketch of random bases has no empty bucket and id % m == bucket, and genomes differ
+        chk = regs_dev[:2].cpu().numpy().view(np.uint64)
+        assert ((chk[0] & np.uint64(m - 1)) == np.arange(m, dtype=np.uint64)).all()
+        assert n_g < 2 or (chk[0] != chk[1]).any()
+        bases = int(plan.nbases)
+        assert bases == n_g * L
+        k1_bytes = n_g * ((L + 3) // 4 + 8 * m)
         ach = k1_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
 
+        # parse-inclusive: FASTA bytes in host memory -> parser threads -> packed runs -> H2D -> K1 -> registers
+        # on the host (the library's persistent sketcher, one device thread), over the kept sample
+        from concurrent.futures import ThreadPoolExecutor
+        nthr = max(1, min(ncores, 64, len(fastas)))
+        per = (len(fastas) + nthr - 1) // nthr
+        sk = ctx.sketcher()
+        pools = [D.SeqPack(k) for _ in range(nthr)]
+
+        def parse_job(t):
+            sp = pools[t]
+            sp.clear()
+            for fa in fastas[t * per:(t + 1) * per]:
+                sp.add_fastx(fa)
+            return sp
+
+        def ingest_once():
+            with ThreadPoolExecutor(nthr) as ex:
+                for sp in ex.map(parse_job, range(nthr)):
+                    if sp.ngenomes:
+                        sk.run(sp, S)
+
+        ingest_once()
+        t0 = time.perf_counter()
+        ingest_once()
+        idt = time.perf_counter() - t0
+        for sp in pools:
+            sp.close()
+        sk.close()
+        ingest_rate = len(fastas) * L / idt
+        cpu = cpu_baseline_sketch(fastas[:min(len(fastas), 2 * ncores)], L, k, S, args.cpu_seconds) \
+            if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+        pe = pmc_entry("k1_oph_kernel") if (world == 1 and n_g == 1000 and L == 5_000_000) else None
+
         def build(sdt):
-            return {"metric": "sketch input bases/s (K1, packed bases resident in HBM)", "value": bases * world / (sdt / reps),
-                    "unit": "bases/s", "ms_per_step": sdt / reps * 1e3,
-                    "config": {"workload": f"{n_g * world} synthetic random genomes x {L} bp, k=31, S={S}, OPH, canonical"},
-                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": pmc_traffic("k1_oph_kernel", True) if (world == 1 and n_g == 1000 and L == 5_000_000) else None,
-                                 "kernel": "k1_oph_kernel",
-                                 "kernel_ms": k1_ms, "algorithmic_bytes": k1_bytes}}
+            o = {"metric": "sketch input bases/s (K1 kernel, packed bases resident in HBM)", "value": bases * world / (sdt / reps),
+                 "unit": "bases/s", "ms_per_step": sdt / reps * 1e3,
+                 "config": {"workload": f"BASELINE config 2 shape: {n_g * world} synthetic random genomes x {L} bp, k=31, S={S}, OPH, canonical",
+                            "input": "splitmix64 genomes rendered as 80-column FASTA and ingested through d2g_seqpack (the product's parser + "
+                                     f"2-bit packer; {gen_s:.1f}s, untimed)"},
+                 "parse_inclusive": {"value": ingest_rate * world, "unit": "bases/s",
+                                     "sample": f"{len(fastas)} in-memory FASTA inputs -> {nthr} parser threads (d2g_seqpack) -> pinned staging -> H2D -> K1 -> "
+                                               f"D2H of the registers (d2g_sketcher_run) in {idt:.3f}s; host-bound"},
+                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": ach / HBM_PEAK_GBS,
+                              "traffic": (pe["hbm_read_bytes_x2_wide_load_correction"] + pe["hbm_write_bytes"]) if pe else None,
+                              "kernel": "k1_oph_kernel",
+                              "kernel_ms": k1_ms, "algorithmic_bytes": k1_bytes,
+                              "note": "VALU-bound by the two mandated 64-bit Wang mixes per k-mer (~125 issue slots per base), not by HBM"}}
+            if cpu is not None:
+                o["cpu_baseline"] = cpu
+            return o
         return sdt, build
 
     sketch = None if args.no_sketch else guarded(sketch_leg)
@@ -414,6 +676,14 @@ def main():
         ach = k3_bytes / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
         assert bool(torch.isfinite(sig3).all()) and bool((tw3 == float(L - k3 + 1)).all())
         cpu_ms = cpu_baseline_multiset(L, k3, S3) if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+        traffic = None
+        if world == 1 and nb == 250 and L == 5_000_000:
+            try:
+                d = json.load(open(PMC_FILE))
+                tr = [v["hbm_read_bytes_raw"] + v["hbm_write_bytes"] for kk, v in d.items() if kk.startswith("k3_") and "hbm_write_bytes" in v]
+                traffic = float(sum(tr)) if tr else None
+            except (OSError, ValueError, KeyError):
+                traffic = None
 
         def build(mdt):
             out = {"metric": "multiset sketch input bases/s (K3: exact k-mer counts + BagMinHash, packed bases resident in HBM)",
@@ -421,12 +691,12 @@ def main():
                    "config": {"workload": f"BASELINE config 5: {n_g * world} synthetic random genomes x {L} bp, k={k3}, S={S3}, "
                                           f"--multiset (BagMinHash), canonical, {nb} genomes per call"},
                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                "traffic": k3_pmc_traffic() if (world == 1 and nb == 250 and L == 5_000_000) else None,
-                                "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE, same shape, profiles/r01_d_k3_pmc.json",
+                                "traffic": traffic,
+                                "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE per call, same shape, profiles/r02_pmc.json",
                                 "kernel": "k3 chain (hist, scan, scatter, bmh_main, verify)",
                                 "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
-                                "note": "per call of %d genomes; the chain also writes and re-reads 8 B of key per k-mer "
-                                        "(bucketed multi-split), which the compulsory-byte figure does not count" % nb},
+                                "note": "per call of %d genomes; the chain also writes and re-reads the bucketed k-mer keys, "
+                                        "which the compulsory-byte figure does not count" % nb},
                    "parity": "bit-exact vs oracle/d2_bmh_oracle.c (published BagMinHash under the BMH-D2G spec; the "
                              "reference's sketch/bmh.h is absent: parity unpinned against a real dashing2 binary)"}
             if cpu_ms is not None:
@@ -444,17 +714,17 @@ def main():
         line = {
             "metric": "all-pairs sketch comparison throughput (pairs/s)", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "higher_is_better": True, "scaling": "weak" if (world > 1 and scaling == "weak") else "strong", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3 (x sqrt(n_gpus) sketches): {N} pre-built OPH sketches, S={S}, "
-                                   f"all-pairs cmp only, {pairs_total} pairs, float32 Jaccard",
-                       "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if cs.algo == D.CMP_BITSLICE else "direct",
+            "config": {"workload": f"{workload}: {N} pre-built OPH sketches, S={S}, all-pairs cmp only, {pairs_total} pairs, float32 Jaccard",
+                       "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if algo_used == D.CMP_BITSLICE else "direct",
                        "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + pair kernel w/ fused epilogue; row-sharded sketches resident in HBM"
                                 if sharded else "RCCL broadcast (n_gpus>1) + prepare + pair kernel w/ fused epilogue; sketches resident in HBM"),
                        "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count",
                        **({"exchange_fallback": exchange_fallback} if exchange_fallback else {}),
                        **({"pipelined_exchange": pipeline_check} if pipeline_check else {})},
-            "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "sketch": sketch, "multiset_sketch": multiset,
+            "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "config4_1gpu": config4,
+            "sketch": sketch, "multiset_sketch": multiset,
         }
         print(json.dumps(line))
     if eng is not None:

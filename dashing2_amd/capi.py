@@ -257,6 +257,10 @@ class SeqPack:
 
     __del__ = close
 
+    def clear(self):
+        """forget the content, keep the allocations"""
+        lib().d2g_seqpack_clear(self._h)
+
     def add_path(self, path):
         rc = lib().d2g_seqpack_add_path(self._h, os.fsencode(path))
         if rc:

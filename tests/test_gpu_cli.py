@@ -326,3 +326,32 @@ def test_cli_multiset_shapes_and_measures(oracle, genomes, tmp_path):
     _run(["sketch", "--multiset", "-k", str(k), "-S", str(S), "-F", str(ff), "-Q", str(qf), "--binary-output", "--containment", "--cmpout", str(b)])
     exp = np.array([[cmp_ms(i, len(refs) + j, oracle.CONTAINMENT) for j in range(len(qs))] for i in range(len(refs))], np.float32)
     np.testing.assert_array_equal(np.fromfile(b, np.float32).view(np.uint32), exp.reshape(-1).view(np.uint32))
+
+
+def test_cli_config1_shape(oracle, tmp_path):
+    """BASELINE config 1's shape through the drop-in CLI: `dashing2 sketch --cmpout` on 32 synthetic 1 Mbp
+    FASTA files, k = 31, S = 1024 (OPH default).  Stacked sketches, names and the PHYLIP / binary matrices
+    must equal what the oracle produces from the same files."""
+    from oracle import textfmt
+    paths = []
+    base = synth.random_genome(500, 1_000_000)
+    for i in range(32):
+        # 24 independent genomes + a family of 8 mutated copies, so that the matrix is not all zeros
+        g = synth.random_genome(1000 + i, 1_000_000) if i < 24 else synth.mutate(base, 0.002 * (i - 23), seed=i)
+        p = tmp_path / ("g%05d.fa" % i)
+        synth.write_fasta(p, "g%05d" % i, g)
+        paths.append(str(p))
+    lst = tmp_path / "files.txt"
+    lst.write_text("".join(p + "\n" for p in paths))
+    out, phy, binm = tmp_path / "s.bin", tmp_path / "d.phylip", tmp_path / "d.bin"
+    _run(["sketch", "-k", "31", "-S", "1024", "-p", "8", "-F", str(lst), "-o", str(out), "--cmpout", str(phy), "--phylip"])
+    esigs, ecards = oracle.sketch_files(paths, k=31, S=1024, nthreads=8)
+    raw = np.fromfile(out, np.uint8)
+    exp = np.concatenate([np.array([32, 1024], np.uint64).view(np.uint8), ecards.view(np.uint8), esigs.reshape(-1).view(np.uint8)])
+    assert raw.tobytes() == exp.tobytes()
+    dist = oracle.allpairs_ut(_densified(oracle, esigs), ecards, measure=oracle.SIMILARITY, k=31, nthreads=8)
+    assert open(phy).read() == textfmt.render_symmetric(paths, dist, phylip=True)
+    assert (dist > 0.3).sum() >= 20 and (dist == 0).sum() > 300
+    _run(["cmp", "--presketched", "-k", "31", "--binary-output", "--distance", "--cmpout", str(binm), str(out)])
+    mash = oracle.allpairs_ut(_densified(oracle, esigs), ecards, measure=oracle.POISSON_LLR, k=31, nthreads=8)
+    assert np.fromfile(binm, np.float32).tobytes() == mash.tobytes()

@@ -329,3 +329,53 @@ def test_row_sharded_pipelined_steps_keep_order(gpu_ctx, d2g, oracle):
         exp = oracle.allpairs_ut(x, np.ones(N), measure=oracle.SIMILARITY, k=31, nthreads=4)
         np.testing.assert_array_equal(g.cpu().numpy().view(np.uint32), exp.view(np.uint32))
     eng.close()
+
+
+def test_k2_config4_size_vs_oracle(gpu_ctx, d2g, oracle):
+    """BASELINE config 4's size on ONE GPU (N = 50 000, S = 1024: 410 MB operand, 1 249 975 000 pairs, 5 GB
+    of output).  The whole triangle is checked through size-independent properties (checksum of checksums
+    from per-column value counts; every per-row sum) and sampled row ranges are compared value for value
+    with the ORACLE (equality counts through its float32 SIMILARITY = neq/1024, exact for S = 2^10):
+    the first rows, the seam between two of the 8 row shards, the middle, and the last rows."""
+    import torch
+    N, S = 50_000, 1024
+    regs = synth.synthetic_registers(N, S, nclusters=N // 150, seed=20260929)
+    ncpu = os.cpu_count() or 1
+    sigs, cards = d2g.oph_finalize(regs, S, nthreads=ncpu)
+    del regs
+    bits = sigs.view(np.uint64)
+    dev = torch.device("cuda", 0)
+    t_dev = torch.from_numpy(bits.view(np.int64)).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_BITSLICE, stream=stream)
+    npairs = N * (N - 1) // 2
+    out = torch.empty(npairs, dtype=torch.int32, device=dev)
+    cs.eqcount_ut_dev(out.data_ptr(), 0, N, stream)
+    torch.cuda.synchronize()
+    md, nb, mean = cs.planes(stream)
+    assert 2 <= md and nb <= 16
+    # checksum of checksums + per-row sums, reduced on the device (plumbing only: sums of the kernel's output)
+    total, rowsum = _column_pair_totals(bits)
+    assert int(out.sum(dtype=torch.int64).item()) == total
+    assert int(out.max().item()) <= S
+    off = np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
+    neq = out.cpu().numpy().view(np.uint32)
+    del out
+    got_row = np.zeros(N, np.int64)
+    cs_all = np.concatenate([[0], np.cumsum(neq, dtype=np.int64)])
+    got_row[:N - 1] = cs_all[off[1:N]] - cs_all[off[:N - 1]]          # pairs (i, j>i)
+    del cs_all
+    for i in range(N - 1):                                            # the same pairs seen from j
+        got_row[i + 1:] += neq[off[i]:off[i + 1]]
+    np.testing.assert_array_equal(got_row, rowsum)
+    # oracle on sampled row ranges (incl. the seam of the 8-way row partition)
+    b = d2g.ut_partition(N, 8)
+    lut = d2g.epilogue_lut(S, d2g.SIMILARITY, 31)
+    for r0, r1 in ((0, 48), (b[4] - 24, b[4] + 24), (N // 2, N // 2 + 32), (N - 600, N)):
+        exp = oracle.allpairs_ut(sigs, cards, measure=oracle.SIMILARITY, k=31, nthreads=ncpu, rows=(r0, r1))
+        seg = neq[off[r0]:off[r1]]
+        np.testing.assert_array_equal(lut[seg].view(np.uint32), exp.view(np.uint32))
+        np.testing.assert_array_equal(cs.eqcount_ut(r0, r1), seg)    # a shard's launch == the whole-triangle launch
+        got = cs.lut_ut(lut, r0, r1)                                  # fused float epilogue, bit-exact
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+    cs.close()
