@@ -388,7 +388,7 @@ def main():
             # pipelined: the exchange + prepare of the next step overlap this step's pair kernel (two
             # operand buffers, own stream) -- every step still does all of its work inside the timed region
             if pipelined:
-                eng.enqueue_lut(my_rows, lut, out)
+                eng.enqueue_lut(my_rows, lut, out, ready=False)    # my_rows was complete before the timed region
             else:
                 eng.step_lut(my_rows, lut, out, stream)
         cs = eng.full

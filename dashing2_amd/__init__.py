@@ -9,7 +9,7 @@ re-implements any part of the path and it fails loudly when the shared object is
 from .capi import (  # noqa: F401
     D2GError, Context, CmpSet, SeqPack, lib, build, LIB_PATH,
     SIMILARITY, CONTAINMENT, SYMMETRIC_CONTAINMENT, POISSON_LLR, INTERSECTION, UNION_SIZE,
-    CMP_AUTO, CMP_DIRECT, CMP_BITSLICE,
+    CMP_AUTO, CMP_DIRECT, CMP_BITSLICE, BITSLICE_OPS_PER_GROUP_EXTRA,
     wang_hash, seed_mask, oph_xor_const, oph_m, oph_finalize, densify, epilogue_lut,
     epilogue_gtlt, epilogue_neq, host_epilogue_ut, operand_layout, ut_count, ut_partition,
 )
@@ -17,7 +17,7 @@ from .capi import (  # noqa: F401
 __all__ = [
     "D2GError", "Context", "CmpSet", "SeqPack", "lib", "build", "LIB_PATH",
     "SIMILARITY", "CONTAINMENT", "SYMMETRIC_CONTAINMENT", "POISSON_LLR", "INTERSECTION", "UNION_SIZE",
-    "CMP_AUTO", "CMP_DIRECT", "CMP_BITSLICE",
+    "CMP_AUTO", "CMP_DIRECT", "CMP_BITSLICE", "BITSLICE_OPS_PER_GROUP_EXTRA",
     "wang_hash", "seed_mask", "oph_xor_const", "oph_m", "oph_finalize", "densify", "epilogue_lut",
     "epilogue_gtlt", "epilogue_neq", "host_epilogue_ut", "operand_layout", "ut_count", "ut_partition",
 ]

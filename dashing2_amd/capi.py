@@ -13,6 +13,8 @@ _lib = None
 
 SIMILARITY, CONTAINMENT, SYMMETRIC_CONTAINMENT, POISSON_LLR, INTERSECTION, UNION_SIZE = range(6)
 CMP_AUTO, CMP_DIRECT, CMP_BITSLICE = 0, 1, 2
+# bit-sliced pair kernel: VALU operations per pair and 32-register group = (id planes of the group) + this (one v_bcnt)
+BITSLICE_OPS_PER_GROUP_EXTRA = 1
 
 
 class D2GError(RuntimeError):
@@ -102,6 +104,7 @@ SIGNATURES = {
     "d2g_cmp_set_create": (_int, [_vp, _vp, _sz, _sz, _int, C.POINTER(_vp)]),
     "d2g_cmp_set_update_dev": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int), C.POINTER(_f32)]),
+    "d2g_cmp_set_status": (_int, [_vp, _vp, _vp]),
     "d2g_operand_layout": (_int, [_sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     "d2g_cmp_set_export_operand_dev": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "d2g_cmp_set_from_planes_dev": (_int, [_vp, _sz, _sz, _vp, _vp, C.POINTER(_vp)]),
@@ -580,6 +583,10 @@ class CmpSet:
 
     def update_dev(self, dev_ptr, stream=None):
         self.ctx._check(lib().d2g_cmp_set_update_dev(self.ctx._h, self._h, dev_ptr, stream))
+
+    def status(self, stream=None):
+        """synchronises; raises D2GError(D2G_ERR_INTERNAL) if the asynchronous prepare overflowed"""
+        self.ctx._check(lib().d2g_cmp_set_status(self.ctx._h, self._h, stream))
 
     def planes(self, stream=None):
         """-> (max shared values per column + 1, max id planes of a group, mean id planes); zeros for DIRECT"""

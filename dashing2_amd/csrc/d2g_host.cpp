@@ -18,6 +18,8 @@
 #include <sys/stat.h>
 #include <vector>
 #include <zlib.h>
+#include <unistd.h>
+#include <fcntl.h>
 #include <immintrin.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -483,34 +485,61 @@ struct d2g_seqpack {
 // whole file into a reusable per-thread buffer; gzip members go through zlib, plain files are read directly
 static bool slurp(const char *path, std::vector<char> &out, size_t &len) {
     len = 0;
-    std::FILE *fp = std::fopen(path, "rb");
-    if (!fp) return false;
+    const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
     unsigned char magic[2] = {0, 0};
-    const size_t got = std::fread(magic, 1, 2, fp);
-    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
-    if (!gz) {
-        struct stat st;
-        if (::fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode)) {
-            const size_t sz = size_t(st.st_size);
-            if (out.size() < sz + 1) out.resize(sz + 1);
-            std::rewind(fp);
-            len = std::fread(out.data(), 1, sz, fp);
-            std::fclose(fp);
-            return len == sz;
-        }
+    size_t got = 0;
+    while (got < 2) {                                         // raw reads: stdio would buffer past the magic
+        const ssize_t n = ::read(fd, magic + got, 2 - got);
+        if (n <= 0) break;
+        got += size_t(n);
     }
-    std::fclose(fp);
-    gzFile gp = gzopen(path, "rb");
-    if (!gp) return false;
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    struct stat st;
+    const bool regular = ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+    if (!gz && regular) {
+        const size_t sz = size_t(st.st_size);
+        if (out.size() < sz + 1) out.resize(sz + 1);
+        size_t off = 0;
+        while (off < sz) {
+            const ssize_t n = ::pread(fd, out.data() + off, sz - off, off_t(off));
+            if (n <= 0) break;
+            off += size_t(n);
+        }
+        ::close(fd);
+        len = off;
+        return off == sz;
+    }
+    // gzip member, or a non-regular plain input (FIFO, process substitution): through zlib on the descriptor
+    // that is ALREADY open -- reopening by name would lose the bytes read above.  zlib must see a gzip stream
+    // from its first byte: rewind when the file is seekable; a compressed pipe cannot be re-fed, so refuse it.
+    const bool seekable = ::lseek(fd, 0, SEEK_SET) == 0;
+    if (!seekable && gz) { ::close(fd); return false; }
+    gzFile gp = gzdopen(fd, "rb");
+    if (!gp) { ::close(fd); return false; }
     gzbuffer(gp, 1 << 20);
+    if (!seekable) {                                          // plain pipe: the bytes already consumed come first
+        if (out.size() < (1u << 22)) out.resize(1u << 22);
+        std::memcpy(out.data(), magic, got);
+        len = got;
+    }
+    bool ok = true;
     for (;;) {
         if (out.size() - len < (1u << 20)) out.resize(std::max<size_t>(out.size() * 2, 1u << 22));
         const int n = gzread(gp, out.data() + len, unsigned(std::min<size_t>(out.size() - len, 1u << 30)));
-        if (n <= 0) break;
+        if (n < 0) { ok = false; break; }
+        if (n == 0) break;
         len += size_t(n);
     }
-    gzclose(gp);
-    return true;
+    if (ok) {
+        // a truncated or corrupt member must not be sketched from its readable prefix: gzread
+        // returns 0 at a premature end of file too; gzerror / gzeof / gzclose tell the cases apart
+        int errnum = Z_OK;
+        (void)gzerror(gp, &errnum);
+        if ((errnum != Z_OK && errnum != Z_STREAM_END) || !gzeof(gp)) ok = false;
+    }
+    if (gzclose(gp) != Z_OK) ok = false;                      // Z_BUF_ERROR: input ended inside a deflate stream
+    return ok;
 }
 
 extern "C" {

@@ -271,10 +271,11 @@ int d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsig
         D2G_HIP(ctx, hipMemcpyAsync(m.data(), set->d_meta, m.size() * sizeof(unsigned), hipMemcpyDeviceToHost, as_stream(stream)));
         D2G_HIP(ctx, hipStreamSynchronize(as_stream(stream)));
         double sum = 0;
-        for (unsigned x : m) {                       // per 32-register group: ceil(log2(x)) id planes, at least 1
+        if (int rc = d2g_bitslice_status(ctx, set, as_stream(stream))) return rc;
+        for (unsigned x : m) {                       // per 32-register group: smallest b with 2^b > x (= D2 + 1), at least 1
             md = std::max(md, x);
             int b = 1;
-            while ((1ull << b) < x) ++b;
+            while ((1ull << b) <= x) ++b;
             nb = std::max(nb, b);
             sum += b;
         }
@@ -295,8 +296,24 @@ int d2g_cmp_set_create(d2g_ctx *ctx, const uint64_t *sig_bits_host, size_t N, si
     if (e != hipSuccess) { (void)hipFree(tmp); ctx->last_error = hipGetErrorString(e); return D2G_ERR_HIP; }
     int rc = d2g_cmp_set_create_dev(ctx, tmp, N, S, algo, nullptr, out);
     (void)hipStreamSynchronize(nullptr);
+    if (rc == D2G_OK && (*out)->algo == D2G_CMP_BITSLICE && d2g_bitslice_status(ctx, *out, nullptr) != D2G_OK) {
+        // the rank kernel's partitioned LDS table overflowed (adversarial column): AUTO falls back to the
+        // direct algorithm, an explicit BITSLICE request fails loudly
+        d2g_cmp_set_destroy(*out);
+        *out = nullptr;
+        rc = algo == D2G_CMP_AUTO ? d2g_cmp_set_create_dev(ctx, tmp, N, S, D2G_CMP_DIRECT, nullptr, out) : (int)D2G_ERR_INTERNAL;
+        (void)hipStreamSynchronize(nullptr);
+    }
     (void)hipFree(tmp);
     return rc;
+}
+
+int d2g_cmp_set_status(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, set && set->ctx == ctx, "cmp_set_status: set belongs to another context");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    if (set->algo != D2G_CMP_BITSLICE) { D2G_HIP(ctx, hipStreamSynchronize(as_stream(stream))); return D2G_OK; }
+    return d2g_bitslice_status(ctx, set, as_stream(stream));
 }
 
 static int check_rows(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1) {
@@ -407,6 +424,8 @@ int d2g_cmp_set_from_planes_dev(d2g_ctx *ctx, size_t N, size_t S, const uint32_t
     set->borrowed = true;
     set->d_planes = const_cast<uint32_t *>(planes_dev);
     set->d_meta = const_cast<uint32_t *>(meta_dev);
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = d2g_bitslice_alloc_cplanes(ctx, set)) { delete set; return rc; }   // column coding, derived before every launch
     *out = set;
     return D2G_OK;
 }

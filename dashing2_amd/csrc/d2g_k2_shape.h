@@ -51,17 +51,34 @@ __device__ __forceinline__ size_t out_pos(const PairShape &sh, size_t i, size_t 
     return (i - sh.i_lo) * (sh.j_hi - sh.j_lo) + (j - sh.j_lo);
 }
 
+// wave-uniform part of out_pos: out_pos(sh, i, j) == out_row_base(sh, i) + j (mod 2^64) for every wanted pair
+__device__ __forceinline__ size_t out_row_base(const PairShape &sh, size_t i) {
+    if (sh.ut) {
+        const size_t d = i - sh.i_lo;
+        const size_t tri_i = i * (i - 1) / 2 * (i != 0), tri_0 = sh.i_lo ? sh.i_lo * (sh.i_lo - 1) / 2 : 0;
+        return d * (sh.N - 1) - (tri_i - tri_0) - i - 1;
+    }
+    return (i - sh.i_lo) * (sh.j_hi - sh.j_lo) - sh.j_lo;
+}
+
 // Store functors: value(eq) is evaluated for all of a lane's outputs first (independent gathers
 // in flight together), put(pos, v) afterwards -- the table and the output never alias.
 struct StoreEq {
     uint32_t *__restrict__ out;
     __device__ __forceinline__ uint32_t value(uint32_t eq) const { return eq; }
     __device__ __forceinline__ void put(size_t pos, uint32_t v) const { out[pos] = v; }
+    // interior-tile form: value from the mismatch count, store at (uniform row base) + (32-bit lane column)
+    __device__ __forceinline__ uint32_t value_from_mismatches(uint32_t S, uint32_t mm) const { return S - mm; }
+    __device__ __forceinline__ void put_row(size_t row_base, uint32_t j, uint32_t v) const { (out + row_base)[j] = v; }
 };
 struct StoreLut {
     float *__restrict__ out; const float *__restrict__ lut;
     __device__ __forceinline__ uint32_t value(uint32_t eq) const { return __float_as_uint(lut[eq]); }
     __device__ __forceinline__ void put(size_t pos, uint32_t v) const { out[pos] = __uint_as_float(v); }
+    __device__ __forceinline__ uint32_t value_from_mismatches(uint32_t S, uint32_t mm) const {
+        return __float_as_uint(lut[S - mm]);
+    }
+    __device__ __forceinline__ void put_row(size_t row_base, uint32_t j, uint32_t v) const { (out + row_base)[j] = __uint_as_float(v); }
 };
 struct StoreGtLt {
     uint32_t *__restrict__ gt, *__restrict__ lt; uint32_t S;

@@ -233,11 +233,15 @@ class RowShardedAllPairs:
         self._p_done = [None, None]
         self._n = 0
 
-    def enqueue_lut(self, rows_t, lut_t, out_t):
+    def enqueue_lut(self, rows_t, lut_t, out_t, ready=None):
         """One step, pipelined over two operand buffers: the all-to-all, the sharded prepare and the
         all-gather of step i run on their own stream while the pair kernel of step i-1 is still busy on
         the caller's current stream.  Results land in out_t in step order; torch.cuda.synchronize()
-        (or any later work on the current stream) observes them."""
+        (or any later work on the current stream) observes them.
+
+        ready: when rows_t becomes valid.  None (default) = after everything queued so far on the current
+        stream (safe for inputs produced there right before the call); a torch.cuda.Event = after that
+        event; False = the input is already complete (e.g. synchronised earlier), no dependency."""
         import torch
         from . import capi
         if not hasattr(self, "_xs"):
@@ -245,8 +249,17 @@ class RowShardedAllPairs:
         main = torch.cuda.current_stream()
         i = self._n & 1
         xs = self._xs
-        if self._n == 0:
-            xs.wait_stream(main)                                    # inputs produced on the main stream
+        # rows_t may have been produced on the caller's stream just before this call (in a
+        # sketch-then-compare loop every step's input is), so by default the exchange stream waits for
+        # everything the main stream has queued so far.  That includes the previous step's pair kernel:
+        # the default is safe but serialises exchange(i) behind pair(i-1).  A caller that knows when its
+        # input is complete passes that event (or False) and keeps the overlap.
+        if ready is None:
+            ev_in = torch.cuda.Event()
+            ev_in.record(main)
+            xs.wait_event(ev_in)
+        elif ready is not False:
+            xs.wait_event(ready)
         if self._p_done[i] is not None:
             xs.wait_event(self._p_done[i])                          # buffer i is free once pair(i-2) is done
         with torch.cuda.stream(xs):

@@ -263,10 +263,18 @@ int  d2g_cmp_set_create(d2g_ctx *ctx, const uint64_t *sig_bits_host, size_t N, s
 /* re-load an existing set with a new N x S matrix of the same shape, reusing every device
  * buffer (no allocation, no host synchronisation: the whole prepare chain is enqueued on `stream`) */
 int  d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, void *stream);
+/* The `_dev` prepare chain is asynchronous and cannot report a data-dependent failure when it is
+ * enqueued.  The one such failure: a register column that puts more distinct values into one hash
+ * partition of the bit-sliced prepare than its LDS table holds (N > 21 845 and an adversarial or
+ * extremely skewed column; impossible for hashed registers).  d2g_cmp_set_status synchronises `stream`
+ * and returns D2G_ERR_INTERNAL in that case (results computed from the set are then invalid; re-create
+ * it with D2G_CMP_DIRECT).  The host-pointer entry points (d2g_cmp_set_create, d2g_cmp_eqcount_ut,
+ * d2g_cmp_dist_ut) check it themselves and fall back to the direct algorithm under D2G_CMP_AUTO. */
+int  d2g_cmp_set_status(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream);
 /* bit-sliced sets: max over register columns of (#values occurring >= 2 times) + 1 (values that
- * occur once share id 0 + a "unique" plane), the largest id-plane count of any 32-register group
- * and the mean over groups (each group only walks its own planes).  Synchronises `stream`;
- * all 0 for a DIRECT set. */
+ * occur once are coded 0 in the row operand and all-ones in the column operand), the largest id-plane
+ * count of any 32-register group and the mean over groups (each group only walks its own planes).
+ * Synchronises `stream` and returns d2g_cmp_set_status's error, if any; all 0 for a DIRECT set. */
 int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits,
                         float *mean_nbits);
 /* ---- sharded prepare (multi-GPU).  The bit-sliced operand is an array of independent
@@ -278,7 +286,8 @@ int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsi
 int  d2g_operand_layout(size_t N, size_t sketchsize, size_t *group_words, size_t *ngroups);
 int  d2g_cmp_set_export_operand_dev(d2g_ctx *ctx, const d2g_cmp_set *set, uint32_t *planes_out_dev,
                                     uint32_t *meta_out_dev, void *stream);
-/* wraps a caller-owned (gathered) operand; only equality-count entry points work on it */
+/* wraps a caller-owned (gathered) operand; only equality-count entry points work on it.  The operand may be
+ * re-gathered into the same buffers between launches (its column coding is re-derived before every launch). */
 int  d2g_cmp_set_from_planes_dev(d2g_ctx *ctx, size_t N, size_t sketchsize, const uint32_t *planes_dev,
                                  const uint32_t *meta_dev, d2g_cmp_set **out);
 int  d2g_pack_column_slices_dev(d2g_ctx *ctx, const uint64_t *rows_dev, size_t n, size_t sketchsize, int nslices,

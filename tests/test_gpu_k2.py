@@ -379,3 +379,34 @@ def test_k2_config4_size_vs_oracle(gpu_ctx, d2g, oracle):
         got = cs.lut_ut(lut, r0, r1)                                  # fused float epilogue, bit-exact
         np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
     cs.close()
+
+
+def test_row_sharded_pipelined_input_produced_on_main_stream(gpu_ctx, d2g, oracle):
+    """every step's rows are PRODUCED on the caller's stream immediately before enqueue_lut (a long chain of
+    device copies ending in the real input, into a buffer that held the previous step's input): the exchange
+    stream must wait for the producer (it only did so on the first step)."""
+    import torch
+    from dashing2_amd import dist as DD
+    rng = np.random.default_rng(5)
+    N, S = 512, 1024
+    dev = torch.device("cuda", 0)
+    eng = DD.RowShardedAllPairs(gpu_ctx, N, S, dev)
+    lut = torch.from_numpy(d2g.epilogue_lut(S, d2g.SIMILARITY, 31)).to(dev)
+    out = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
+    inputs = [_planted(rng, N, S, nvals=3 + i) for i in range(5)]
+    staged = [torch.from_numpy(x.view(np.int64)).to(dev) for x in inputs]
+    big = torch.zeros(64 << 20, dtype=torch.int64, device=dev)           # 512 MB: a slow producer
+    rows = torch.zeros((N, S), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    got = []
+    for st in staged:
+        big.add_(1)                                      # main stream: delay, then the real input lands in `rows`
+        big.mul_(3)
+        rows.copy_(st)
+        eng.enqueue_lut(rows, lut, out)
+        got.append(out.clone())
+    torch.cuda.synchronize()
+    for x, g in zip(inputs, got):
+        exp = oracle.allpairs_ut(x, np.ones(N), measure=oracle.SIMILARITY, k=31, nthreads=4)
+        np.testing.assert_array_equal(g.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    eng.close()

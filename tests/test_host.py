@@ -184,6 +184,43 @@ def test_seqpack_gz_and_multipath(d2g, oracle, tmp_path):
         sp.add_path(str(tmp_path / "missing.fa"))
 
 
+def test_seqpack_truncated_gz_and_fifo(d2g, tmp_path):
+    """a truncated / corrupt .gz must fail (D2G_ERR_IO), never be sketched from its readable prefix; a plain
+    FIFO (process substitution) must deliver all of its bytes."""
+    import gzip
+    import threading
+    from dashing2_amd import synth
+    fa = synth.fasta_bytes("x", synth.random_genome(3, 200_000))
+    good = tmp_path / "g.fa.gz"
+    with gzip.open(good, "wb") as f:
+        f.write(fa)
+    raw = good.read_bytes()
+    sp = d2g.SeqPack(21)
+    sp.add_path(str(good))
+    assert sp.nkmers(0) == 200_000 - 20
+    for name, data in (("trunc.fa.gz", raw[:len(raw) // 2]), ("tail.fa.gz", raw[:-6]),
+                       ("corrupt.fa.gz", raw[:len(raw) // 2] + bytes(64) + raw[len(raw) // 2 + 64:])):
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(d2g.D2GError):
+            sp.add_path(str(p))
+    fifo = tmp_path / "pipe.fa"
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(fa)
+    t = threading.Thread(target=feed)
+    t.start()
+    sp2 = d2g.SeqPack(21)
+    sp2.add_path(str(fifo))
+    t.join()
+    assert sp2.nkmers(0) == 200_000 - 20
+    a, b = sp.arrays(), sp2.arrays()
+    n = (200_000 + 3) // 4
+    assert np.array_equal(a[0][:n], b[0][:n])
+
+
 def test_format_fixture_roundtrip():
     """tests/golden/stacked_*.bin parsed by the reference's python/parse.py (frozen) has the layout
     [u64 N][u64 S][f64 card x N][f64 x N*S]  (sketch_core.cpp:130-140, cmp_main.cpp:61-94)."""
