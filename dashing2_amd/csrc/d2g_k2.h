@@ -10,9 +10,10 @@ struct d2g_cmp_set {
     uint64_t *d_rows = nullptr;   // [N][S]     row-major 64-bit patterns
     uint64_t *d_cols = nullptr;   // [S][Npad]  register-major (transposed), zero padded
     // bit-sliced operand (algo == D2G_CMP_BITSLICE); all buffers are allocated once per set
-    uint32_t *d_planes = nullptr; // ROW operand [ntb][nbits_cap+1][Nstride]: bit x of word = bit b of id[32*tb+x][j], unique values
-                                  // coded 0; last slot = the "unique" plane (this is also the exchanged form of the operand)
-    uint32_t *d_cplanes = nullptr;// COLUMN operand [ntb][nbits_cap][Nstride]: the same ids with unique values coded all-ones
+    uint32_t *d_planes = nullptr; // exchanged form [ntb][nbits_cap+1][Nstride]: bit x of word = bit b of id[32*tb+x][j], unique values
+                                  // coded 0; last slot = the "unique" plane (fixed geometry: groups are independent)
+    uint32_t *d_stream = nullptr; // what the pair kernel walks: [live planes of all groups][2][Nstride] -- row-coded words, then the
+                                  // same plane with unique values coded all-ones (column coding); + one block of slack
     size_t Nstride = 0;           // Npad + 64 (row tiles may read past Npad)
     int nbits_cap = 0;            // id-plane slots per 32-register group: smallest c with 2^c >= N/2 + 2
     int ntb = 0;                  // ceil(S/32)
@@ -31,7 +32,7 @@ void d2g_bitslice_geometry(d2g_cmp_set *set);
 int  d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 void d2g_bitslice_free(d2g_cmp_set *set);
-int  d2g_bitslice_alloc_cplanes(d2g_ctx *ctx, d2g_cmp_set *set);
+int  d2g_bitslice_alloc_stream(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_status(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s);   // synchronises; D2G_ERR_INTERNAL on overflow
 // exactly one of (eq_out) or (lut,fout) is non-null
 int  d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out,

@@ -425,7 +425,7 @@ int d2g_cmp_set_from_planes_dev(d2g_ctx *ctx, size_t N, size_t S, const uint32_t
     set->d_planes = const_cast<uint32_t *>(planes_dev);
     set->d_meta = const_cast<uint32_t *>(meta_dev);
     D2G_HIP(ctx, hipSetDevice(ctx->device));
-    if (int rc = d2g_bitslice_alloc_cplanes(ctx, set)) { delete set; return rc; }   // column coding, derived before every launch
+    if (int rc = d2g_bitslice_alloc_stream(ctx, set)) { delete set; return rc; }   // plane stream, derived before every launch
     *out = set;
     return D2G_OK;
 }

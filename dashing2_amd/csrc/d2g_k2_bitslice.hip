@@ -171,8 +171,21 @@ __device__ __forceinline__ int live_planes(const uint32_t *meta, int tb) {
     return md <= 1 ? 1 : 32 - __clz(md);              // smallest nb with 2^nb >= D2 + 2: ranks 1..D2, 0 and 2^nb-1 all distinct
 }
 
+// first slot of group tb in the compact plane stream = sum of the live plane counts of the groups before it
+__device__ __forceinline__ size_t stream_slot(const uint32_t *meta, int tb) {
+    size_t q = 0;
+    for (int t = 0; t < tb; ++t) q += (size_t)live_planes(meta, t);     // uniform scalar loop, ntb = S/32 is small
+    return q;
+}
+
+// Writes both forms of the operand:
+//   planes  [ntb][nbits_cap+1][Nstride]  fixed geometry (a function of N only): row-coded id planes + the unique plane in the
+//                                        last slot -- the form ranks exchange (independent per group);
+//   stream  [sum_tb nbits_tb][2][Nstride] what the pair kernel walks: only the LIVE planes, in group order, each as the
+//                                        row-coded words followed by the column-coded words, so that the kernel's operand
+//                                        pointer simply advances by one block per plane (no per-plane address selection).
 __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t S, size_t N, size_t Npad,
-                                                        uint32_t *__restrict__ planes, uint32_t *__restrict__ cplanes,
+                                                        uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
                                                         size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tb = blockIdx.y;
@@ -184,33 +197,38 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
         const size_t t = tb * 32 + x;
         id[x] = (t < S && j < N) ? ids[t * Npad + j] : 0u;     // padded registers/sketches: id 0 in both codings
     }
-    uint32_t u = 0;                                    // the "unique" plane lives in slot nbits_cap of the row operand
+    uint32_t u = 0;                                    // the "unique" plane
 #pragma unroll
     for (int x = 0; x < 32; ++x) u |= (id[x] >> 31) << x;
     uint32_t *dst = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
-    uint32_t *cdst = cplanes + tb * (size_t)nbits_cap * Nstride + j;
+    uint32_t *sdst = stream + stream_slot(meta, (int)tb) * 2 * Nstride + j;
     for (int b = 0; b < nbits; ++b) {
         uint32_t w = 0;
 #pragma unroll
         for (int x = 0; x < 32; ++x) w |= ((id[x] >> b) & 1u) << x;
         dst[(size_t)b * Nstride] = w;                  // row coding: unique = 0 (BS_UNIQ ids have zero low bits)
-        cdst[(size_t)b * Nstride] = w | u;             // column coding: unique = all ones
+        sdst[(size_t)(2 * b) * Nstride] = w;
+        sdst[(size_t)(2 * b + 1) * Nstride] = w | u;   // column coding: unique = all ones
     }
     dst[(size_t)nbits_cap * Nstride] = u;
 }
 
-// column coding of an operand that arrived as (row-coded id planes + unique plane): the gathered operand of
-// the multi-GPU path (d2g_cmp_set_from_planes_dev)
-__global__ __launch_bounds__(256) void bs_derive_kernel(const uint32_t *__restrict__ planes, uint32_t *__restrict__ cplanes,
+// plane stream of an operand that arrived in the exchanged form (the gathered operand of the multi-GPU path,
+// d2g_cmp_set_from_planes_dev)
+__global__ __launch_bounds__(256) void bs_derive_kernel(const uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
                                                         size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tb = blockIdx.y;
     if (j >= Nstride) return;
     const int nbits = live_planes(meta, (int)tb);
     const uint32_t *src = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
-    uint32_t *cdst = cplanes + tb * (size_t)nbits_cap * Nstride + j;
+    uint32_t *sdst = stream + stream_slot(meta, (int)tb) * 2 * Nstride + j;
     const uint32_t u = src[(size_t)nbits_cap * Nstride];
-    for (int b = 0; b < nbits; ++b) cdst[(size_t)b * Nstride] = src[(size_t)b * Nstride] | u;
+    for (int b = 0; b < nbits; ++b) {
+        const uint32_t w = src[(size_t)b * Nstride];
+        sdst[(size_t)(2 * b) * Nstride] = w;
+        sdst[(size_t)(2 * b + 1) * Nstride] = w | u;
+    }
 }
 
 // ------------------------------------------------------------------ 3. the pair kernel
@@ -225,16 +243,28 @@ constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);   // mismatch acc
 // IW = 16 rows per wave (one s_load_dwordx16 per plane), JR = 64-column groups per lane,
 // WC = waves side by side along the columns (WC * JR * 64 = 256).  Per 32-register group: plane 0
 // initialises z = r ^ c (no zeroing), planes 1.. accumulate with v_bitop3 z |= r ^ c, and one accumulating
-// v_bcnt finishes the group: nbits + 1 VALU operations per pair and group.  Plane operands are addressed
-// as uniform plane pointer (SGPR pair, advanced by SALU) + per-lane 32-bit offset.
+// v_bcnt finishes the group: nbits + 1 VALU operations per pair and group.
 //
-// The operands of plane p+1 -- or of the next group's plane 0 -- are requested before plane p is
-// computed and land in the other of two explicitly alternating register sets (see bs_group).
+// The kernel is bound by instruction ISSUE, all kinds counted: at 4, 5 or 6 waves per SIMD it takes the same
+// time, and it got 13 % faster when the per-plane address arithmetic was (experimentally) constant-folded
+// away -- scalar instructions are not free riders next to the vector ones.  Hence the plane STREAM: the
+// live planes of all groups lie back to back (row words, then column words), the wave keeps ONE uniform
+// pointer that advances by one block per plane, row words are an s_load_dwordx16 at the pointer and column
+// words a global_load_dword at pointer + per-lane offset (saddr + voffset form: no vector address math).
+// The operands of the next plane are requested before the current one is computed and land in the other
+// of two explicitly alternating register sets.
 //
 // Epilogue: interior tiles (every pair of the wave's 16 x 64*JR block is wanted and off the diagonal --
 // all but the ones on the triangle's edge) take a branch-free path: the row's output base is a scalar,
 // the lane adds its column, so an output costs one table gather and one store.
+#ifndef D2G_BS_WPE
+#define D2G_BS_WPE 7
+#endif
+#ifndef D2G_BS_JR
+#define D2G_BS_JR 2
+#endif
 constexpr int BS_IW = 16;
+constexpr int BS_JR = D2G_BS_JR;              // 64-column groups per lane: a wave owns 16 x (64*JR) pairs
 
 template <int JR>
 struct BsOperands {                         // the prefetched operands of one plane
@@ -242,13 +272,27 @@ struct BsOperands {                         // the prefetched operands of one pl
     uint32_t vb[JR];                        // this lane's column words
 };
 
+// Scalar loads return out of order, so the only wait there is for them is lgkmcnt(0): it must come BEFORE
+// the next s_load is issued -- left to the compiler it lands at the first use of the current operands,
+// after the prefetch was issued, and the prefetch is then waited for on the spot.
 template <int JR>
-__device__ __forceinline__ BsOperands<JR> bs_fetch(const uint32_t *rp, const uint32_t *cp, uint32_t row, uint32_t colb) {
+__device__ __forceinline__ BsOperands<JR> bs_fetch(const uint32_t *&ptr, uint32_t coff, size_t step) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): the operands about to be used have arrived
+    __builtin_amdgcn_sched_barrier(0);
     BsOperands<JR> o;
-    o.sa = *reinterpret_cast<const u32x16_u *>(rp + row);                       // s_load_dwordx16
+    // constant address space: the operand is never written while this kernel runs, and a uniform address in
+    // that space is always a scalar load (s_load_dwordx16), whatever the optimiser can or cannot prove
+    typedef const u32x16_u __attribute__((address_space(4))) *row_words_ptr;
+    o.sa = *(row_words_ptr)(uintptr_t)ptr;
+    // the per-lane offset is laundered so that loop strength reduction cannot turn (uniform pointer + lane
+    // offset) into a per-lane 64-bit running address: that costs a vector add per plane and four more VGPRs;
+    // as written the loads select the saddr + voffset form
+    uint32_t co = coff;
+    asm volatile("" : "+v"(co));
 #pragma unroll
     for (int c = 0; c < JR; ++c)
-        o.vb[c] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(cp) + colb + 256 * c);
+        o.vb[c] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ptr) + co + 256 * c);
+    ptr += step;
     return o;
 }
 
@@ -262,36 +306,26 @@ __device__ __forceinline__ void bs_plane(const BsOperands<JR> &o, uint32_t (&z)[
 }
 
 // one 32-register group with `nbits` id planes.  `a` holds plane 0 of this group on entry and plane 0 of the
-// next group (rnext/cnext) on exit.  Two operand sets alternate (a, b): the fetch of plane p+1 is issued
-// before plane p is computed; a copy (8 s_mov_b64 + JR v_mov) happens at most once per GROUP, when the plane
-// count is odd -- a rolled loop with one "next" set copied it once per PLANE.
+// next group on exit (the stream has one block of slack after its last plane).  A copy between the two
+// operand sets (8 s_mov_b64 + JR v_mov) happens at most once per GROUP, when the plane count is odd.
 template <int JR>
-__device__ __forceinline__ void bs_group(int nbits, const uint32_t *rbase, const uint32_t *cbase, const uint32_t *rnext,
-                                         const uint32_t *cnext, size_t Nstride, uint32_t row, uint32_t colb, BsOperands<JR> &a,
+__device__ __forceinline__ void bs_group(int nbits, const uint32_t *&ptr, uint32_t coff, size_t step, BsOperands<JR> &a,
                                          uint32_t (&acc)[BS_IW][JR]) {
     uint32_t z[BS_IW][JR];
-    BsOperands<JR> b;
-    // Scalar loads return out of order, so the only wait there is for them is lgkmcnt(0): it must come
-    // BEFORE the next s_load is issued -- left to the compiler it lands at the first use of the current
-    // operands, after the prefetch was issued, and the prefetch is then waited for on the spot.
-    auto fetch = [&](int p) {                        // plane p of this group, or plane 0 of the next group
-        const bool more = p < nbits;
-        const uint32_t *rp = more ? rbase + (size_t)p * Nstride : rnext, *cp = more ? cbase + (size_t)p * Nstride : cnext;
-        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the operands about to be used have arrived
-        __builtin_amdgcn_sched_barrier(0);
-        return bs_fetch<JR>(rp, cp, row, colb);
-    };
-    b = fetch(1);
+    BsOperands<JR> b = bs_fetch<JR>(ptr, coff, step);
     bs_plane<JR, true>(a, z);                        // plane 0
-    int p = 1;
-    for (;;) {
-        if (p >= nbits) { a = b; break; }            // b holds the next group's plane 0
-        a = fetch(p + 1);
-        bs_plane<JR, false>(b, z);                   // plane p (odd)
-        if (++p >= nbits) break;                     // a holds the next group's plane 0
-        b = fetch(p + 1);
-        bs_plane<JR, false>(a, z);                   // plane p (even)
-        ++p;
+    const int rest = nbits - 1;                      // planes 1 .. nbits-1, two per iteration (a counted loop: z stays in place)
+    for (int k = rest >> 1; k > 0; --k) {
+        a = bs_fetch<JR>(ptr, coff, step);
+        bs_plane<JR, false>(b, z);                   // odd plane
+        b = bs_fetch<JR>(ptr, coff, step);
+        bs_plane<JR, false>(a, z);                   // even plane
+    }
+    if (rest & 1) {
+        a = bs_fetch<JR>(ptr, coff, step);           // the next group's plane 0
+        bs_plane<JR, false>(b, z);
+    } else {
+        a = b;                                       // b holds the next group's plane 0
     }
 #pragma unroll
     for (int i = 0; i < BS_IW; ++i)
@@ -300,9 +334,8 @@ __device__ __forceinline__ void bs_group(int nbits, const uint32_t *rbase, const
 }
 
 template <int JR, class Store>
-__global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void k2_bitslice_kernel(
-    const uint32_t *__restrict__ planes, const uint32_t *__restrict__ cplanes, size_t Nstride, int nbits_cap,
-    const uint32_t *__restrict__ meta, int ntb, uint32_t S, PairShape sh, Store store) {
+__global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_kernel(
+    const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb, uint32_t S, PairShape sh, Store store) {
     constexpr int IW = BS_IW;
     constexpr int WC = BS_CB / (64 * JR);          // waves along columns: 2 (JR=2)
     constexpr int WR = 4 / WC;                     // waves along rows
@@ -325,20 +358,18 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(6)))
 #pragma unroll
         for (int c = 0; c < JR; ++c) acc[i][c] = 0;
 
-    const uint32_t colb = ((uint32_t)j0 + (uint32_t)lane) * 4u;  // byte offset inside a plane (per lane): saddr + voffset form
-    const uint32_t row = (uint32_t)iw0;                          // element offset of the wave's 16 row words (uniform)
-    const size_t rstride = (size_t)(nbits_cap + 1) * Nstride;    // row operand: nbits_cap id planes + the unique plane per group
-    const size_t cstride = (size_t)nbits_cap * Nstride;          // column operand: nbits_cap id planes per group
+    // one uniform pointer: the wave's 16 row words of the current plane; its column words sit at a fixed
+    // per-lane byte offset from it (Nstride >= Npad + 64 > iw0, so the offset is positive and < 2^32)
+    const uint32_t *ptr = stream + iw0;
+    const uint32_t coff = (uint32_t)(Nstride - iw0 + j0 + (size_t)lane) * 4u;
+    const size_t step = 2 * Nstride;                             // words per plane block (row words + column words)
 
-    BsOperands<JR> nx = bs_fetch<JR>(planes, cplanes, row, colb);             // group 0, plane 0
+    BsOperands<JR> nx = bs_fetch<JR>(ptr, coff, step);           // group 0, plane 0
     int nbits_nx = live_planes(meta, 0);
     for (int tb = 0; tb < ntb; ++tb) {
         const int nbits = nbits_nx;                              // uniform, per 32-register group
-        const bool last = tb + 1 >= ntb;                         // last group: harmless reload of group 0
-        nbits_nx = live_planes(meta, last ? 0 : tb + 1);         // scalar load, one group ahead
-        const uint32_t *rbase = planes + (size_t)tb * rstride, *cbase = cplanes + (size_t)tb * cstride;
-        const uint32_t *rnext = last ? planes : rbase + rstride, *cnext = last ? cplanes : cbase + cstride;
-        bs_group<JR>(nbits, rbase, cbase, rnext, cnext, Nstride, row, colb, nx, acc);
+        nbits_nx = live_planes(meta, tb + 1 < ntb ? tb + 1 : 0); // scalar load, one group ahead
+        bs_group<JR>(nbits, ptr, coff, step, nx, acc);
     }
 
     // interior: all 16 rows and all 64*JR columns of this wave are wanted pairs off the diagonal
@@ -385,20 +416,19 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(6)))
 int refresh_borrowed(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s) {
     if (!set->borrowed) return D2G_OK;
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(bs_derive_kernel, grid, dim3(256), 0, s, set->d_planes, set->d_cplanes, set->Nstride, set->nbits_cap, set->d_meta);
+    hipLaunchKernelGGL(bs_derive_kernel, grid, dim3(256), 0, s, set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
 
 template <class Store>
 int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
-    if (int rc = finish_shape(ctx, sh, 32u)) return rc;          // workgroup tile = 32 rows x 256 columns (4 waves of 16 x 128)
+    if (int rc = finish_shape(ctx, sh, BS_JR == 2 ? 32u : 64u)) return rc;   // workgroup tile = (16 * JR) rows x 256 columns (4 waves of 16 x 64*JR)
     if (sh.nvalid_total == 0) return D2G_OK;
-    D2G_CHECK(ctx, (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride < (1ull << 32), "bit-sliced operand exceeds 2^32 words");
     if (int rc = refresh_borrowed(ctx, set, s)) return rc;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
-    hipLaunchKernelGGL((k2_bitslice_kernel<2, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_planes, set->d_cplanes,
-                       set->Nstride, set->nbits_cap, set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
+    hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
+                       set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -409,9 +439,9 @@ int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store st
 void d2g_bitslice_free(d2g_cmp_set *set) {
     if (!set) return;
     if (!set->borrowed) { (void)hipFree(set->d_planes); (void)hipFree(set->d_meta); }
-    (void)hipFree(set->d_cplanes);
+    (void)hipFree(set->d_stream);
     (void)hipFree(set->d_ids);
-    set->d_planes = set->d_cplanes = set->d_meta = set->d_ids = nullptr;
+    set->d_planes = set->d_stream = set->d_meta = set->d_ids = nullptr;
 }
 
 // geometry of the bit-sliced operand: a function of N (and S) only, identical on every rank.
@@ -424,8 +454,10 @@ void d2g_bitslice_geometry(d2g_cmp_set *set) {
     set->Nstride = set->Npad + 64;
 }
 
-int d2g_bitslice_alloc_cplanes(d2g_ctx *ctx, d2g_cmp_set *set) {
-    hipError_t e = hipMalloc((void **)&set->d_cplanes, (size_t)set->ntb * set->nbits_cap * set->Nstride * sizeof(uint32_t));
+// the plane stream: at most nbits_cap live planes per group, two codings each, + one block of slack (the
+// kernel's prefetch runs one plane past the end)
+int d2g_bitslice_alloc_stream(d2g_ctx *ctx, d2g_cmp_set *set) {
+    hipError_t e = hipMalloc((void **)&set->d_stream, ((size_t)set->ntb * set->nbits_cap + 1) * 2 * set->Nstride * sizeof(uint32_t));
     if (e != hipSuccess) {
         ctx->last_error = std::string("bitslice alloc: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
@@ -449,7 +481,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         d2g_bitslice_free(set);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
-    if (int rc = d2g_bitslice_alloc_cplanes(ctx, set)) { d2g_bitslice_free(set); return rc; }
+    if (int rc = d2g_bitslice_alloc_stream(ctx, set)) { d2g_bitslice_free(set); return rc; }
     return D2G_OK;
 }
 
@@ -469,7 +501,7 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
                            set->d_ids, set->d_meta, set->d_meta + set->ntb);
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, S, N, Npad, set->d_planes, set->d_cplanes, set->Nstride,
+    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, S, N, Npad, set->d_planes, set->d_stream, set->Nstride,
                        set->nbits_cap, set->d_meta);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
