@@ -99,6 +99,7 @@ SIGNATURES = {
     "d2g_seqpack_add_fastx_by_record": (_int, [_vp, C.c_char_p, _sz]),
     "d2g_seqpack_name": (C.c_char_p, [_vp, _sz]),
     "d2g_bmh_from_weighted": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]),
+    "d2g_bmh_from_weighted_ids": (_int, [_vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "d2g_ut_count": (_sz, [_sz, _sz, _sz]),
     "d2g_cmp_set_create_dev": (_int, [_vp, _vp, _sz, _sz, _int, _vp, C.POINTER(_vp)]),
     "d2g_cmp_set_create": (_int, [_vp, _vp, _sz, _sz, _int, C.POINTER(_vp)]),
@@ -432,6 +433,19 @@ class Context:
         self._check(lib().d2g_bmh_from_weighted(self._h, _np_ptr(ids), None if w is None else _np_ptr(w), _np_ptr(set_off),
                                                 ns, S, _np_ptr(sig), _np_ptr(tw)))
         return sig, tw
+
+    def bmh_from_weighted_ids(self, ids, weights, set_off, S):
+        """-> (sig, total_weight, owner uint64[nsets][S]): owner = position within its set of the element that set the register"""
+        ids = np.ascontiguousarray(ids, np.uint64)
+        w = None if weights is None else np.ascontiguousarray(weights, np.float64)
+        set_off = np.ascontiguousarray(set_off, np.uint64)
+        ns = set_off.size - 1
+        sig = np.empty((ns, S), np.float64)
+        tw = np.empty(ns, np.float64)
+        own = np.empty((ns, S), np.uint64)
+        self._check(lib().d2g_bmh_from_weighted_ids(self._h, _np_ptr(ids), None if w is None else _np_ptr(w), _np_ptr(set_off),
+                                                    ns, S, _np_ptr(sig), _np_ptr(tw), _np_ptr(own)))
+        return sig, tw, own
 
     def oph_plan(self, run_start, run_len, genome_run_off, k):
         run_start = np.ascontiguousarray(run_start, np.uint64)

@@ -243,6 +243,16 @@ __device__ __forceinline__ void reg_min(uint64_t *h, uint32_t i, double x) {
     const uint64_t xb = dbits(x);
     if (xb < h[i]) atomicMin((unsigned long long *)&h[i], (unsigned long long)xb);
 }
+// second pass over FINAL registers: which element set each register (BagMinHash2::ids(), reference
+// src/wsketch.cpp:66-67).  Ties (two elements with the same point) go to the smaller position.
+struct ArgSink {
+    const uint64_t *h;   // final registers of the set
+    uint64_t *arg;       // [m] position of the element that owns the register, pre-set to ~0
+    uint64_t pos;        // position of the element being walked
+};
+__device__ __forceinline__ void reg_min(const ArgSink &s, uint32_t i, double x) {
+    if (dbits(x) == s.h[i]) atomicMin((unsigned long long *)&s.arg[i], (unsigned long long)s.pos);
+}
 
 // locate P's current point: narrow P to the half that holds it, level by level; the other half
 // becomes a fresh process starting at P.x.  Pushes what may still matter.
@@ -251,7 +261,8 @@ __device__ __forceinline__ void reg_min(uint64_t *h, uint32_t i, double x) {
 // processes are finished after the loop, where the lanes of a wave are converged again (inside
 // the loop each lane would hit the expensive branch at a different level and the wave would pay
 // for it once per level).  Same arithmetic in a different order: identical results.
-__device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk, int &sp, int *status) {
+template <class H>
+__device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double bound, H h, Proc *stk, int &sp, int *status) {
     const int sp0 = sp;
     bool counted = false, relevant = true;
     auto park = [&](Proc &S) {
@@ -347,7 +358,8 @@ __device__ __forceinline__ Proc top_proc(uint64_t d, int t) {
 }
 
 // everything below a process whose current point is at or before `bound`
-__device__ __forceinline__ void walk_process(const Proc &P0, uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk,
+template <class H>
+__device__ __forceinline__ void walk_process(const Proc &P0, uint64_t d, double w, uint32_t m, double bound, H h, Proc *stk,
                                              int *status) {
     int sp = 0;
     bmh_locate(P0, d, w, m, bound, h, stk, sp, status);
@@ -358,7 +370,8 @@ __device__ __forceinline__ void walk_process(const Proc &P0, uint64_t d, double 
 }
 
 // walk every process of element (d, w) that can still matter under `bound`
-__device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, double bound, uint64_t *h, Proc *stk, int *status) {
+template <class H>
+__device__ __forceinline__ void walk_element(uint64_t d, double w, uint32_t m, double bound, H h, Proc *stk, int *status) {
     const int nt = top_count(w);
     for (int t = 0; t < nt; ++t) {
         Proc P = top_proc(d, t);
@@ -681,6 +694,8 @@ struct WsArgs {
     const uint32_t *redo;        // [nsets] (redo_mode) sets to walk again
     int redo_mode;
     int *status;
+    uint64_t *arg;               // argmin pass: [nsets][m] owner positions, pre-set to ~0
+    const uint64_t *set_lo;      // argmin pass: [nsets] first element of each set
 };
 
 __device__ __forceinline__ bool ws_fetch(const WsArgs &a, uint64_t idx, uint64_t &d, double &w, int *status) {
@@ -701,6 +716,20 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_sets_kernel(WsArgs a) {
     for (uint64_t e = threadIdx.x; e < cnt; e += K3_THREADS) {
         uint64_t d; double w;
         if (ws_fetch(a, lo + e, d, w, a.status)) walk_element(d, w, a.m, bound, hg, stk, a.status);
+    }
+}
+
+// after the registers are final: one more walk under the verified bound records, per register, the position
+// (within its set) of the element whose point it holds
+__global__ __launch_bounds__(K3_THREADS) void k3_bmh_sets_argmin_kernel(WsArgs a) {
+    const uint32_t set = a.blk_set[blockIdx.x];
+    const uint64_t lo = a.blk_lo[blockIdx.x], cnt = a.blk_cnt[blockIdx.x];
+    const double bound = V(a.guess[set]);
+    Proc stk[BMH_STACK];
+    for (uint64_t e = threadIdx.x; e < cnt; e += K3_THREADS) {
+        uint64_t d; double w;
+        if (ws_fetch(a, lo + e, d, w, a.status))
+            walk_element(d, w, a.m, bound, ArgSink{a.h + (size_t)set * a.m, a.arg + (size_t)set * a.m, lo + e - a.set_lo[set]}, stk, a.status);
     }
 }
 
@@ -1079,6 +1108,11 @@ int d2g_kmer_count(d2g_ctx *ctx, const uint8_t *packed, size_t packed_bytes, con
 
 int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weights, const uint64_t *set_off, size_t nsets,
                           size_t sketchsize, double *sig_out, double *total_weight_out) {
+    return d2g_bmh_from_weighted_ids(ctx, ids, weights, set_off, nsets, sketchsize, sig_out, total_weight_out, nullptr);
+}
+
+int d2g_bmh_from_weighted_ids(d2g_ctx *ctx, const uint64_t *ids, const double *weights, const uint64_t *set_off, size_t nsets,
+                              size_t sketchsize, double *sig_out, double *total_weight_out, uint64_t *owner_out) {
     if (!ctx) return D2G_ERR_INVALID;
     D2G_CHECK(ctx, set_off != nullptr && (nsets == 0 || (sig_out && total_weight_out)), "null argument");
     D2G_CHECK(ctx, sketchsize >= 1 && sketchsize < (1ull << 24), "sketchsize out of range");
@@ -1116,7 +1150,7 @@ int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weigh
     }
     D2G_CHECK(ctx, bset.size() < (1ull << 31), "too many workgroups");
     const size_t nb = bset.size();
-    uint64_t *d_ids = nullptr, *d_blo = nullptr, *d_h = nullptr, *d_guess = nullptr;
+    uint64_t *d_ids = nullptr, *d_blo = nullptr, *d_h = nullptr, *d_guess = nullptr, *d_arg = nullptr, *d_setlo = nullptr;
     double *d_w = nullptr, *d_tw = nullptr;
     uint32_t *d_bset = nullptr, *d_bcnt = nullptr, *d_redo = nullptr;
     int *d_status = nullptr;
@@ -1124,6 +1158,7 @@ int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weigh
     auto cleanup = [&]() {
         (void)hipFree(d_ids); (void)hipFree(d_blo); (void)hipFree(d_h); (void)hipFree(d_guess); (void)hipFree(d_redo);
         (void)hipFree(d_w); (void)hipFree(d_tw); (void)hipFree(d_bset); (void)hipFree(d_bcnt); (void)hipFree(d_status);
+        (void)hipFree(d_arg); (void)hipFree(d_setlo);
     };
 #define K3_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->last_error = hipGetErrorString(e_); cleanup(); return D2G_ERR_HIP; } } while (0)
     K3_TRY(hipMalloc((void **)&d_ids, std::max<uint64_t>(total, 1) * 8));
@@ -1147,6 +1182,7 @@ int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weigh
     WsArgs a;
     a.ids = d_ids; a.w = d_w; a.blk_set = d_bset; a.blk_lo = d_blo; a.blk_cnt = d_bcnt;
     a.m = (uint32_t)m; a.h = d_h; a.guess = d_guess; a.redo = d_redo; a.redo_mode = 0; a.status = d_status;
+    a.arg = nullptr; a.set_lo = nullptr;
     {
         d2g_timer tm(ctx, &ctx->ev_k3, nullptr);
         const size_t ninit = std::max<size_t>(nsets * m, nsets);
@@ -1164,12 +1200,21 @@ int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weigh
             if (pass >= 40) { ctx->last_error = "internal: BagMinHash bound did not converge"; cleanup(); return D2G_ERR_INTERNAL; }
             K3_TRY(hipMemset(d_status + 1, 0, sizeof(int)));
         }
+        if (owner_out) {
+            K3_TRY(hipMalloc((void **)&d_arg, nsets * m * 8));
+            K3_TRY(hipMalloc((void **)&d_setlo, nsets * 8));
+            K3_TRY(hipMemset(d_arg, 0xFF, nsets * m * 8));
+            K3_TRY(hipMemcpy(d_setlo, set_off, nsets * 8, hipMemcpyHostToDevice));
+            a.arg = d_arg; a.set_lo = d_setlo;
+            if (nb) hipLaunchKernelGGL(k3_bmh_sets_argmin_kernel, dim3((unsigned)nb), dim3(K3_THREADS), 0, nullptr, a);
+        }
         tm.stop();
     }
     K3_TRY(hipGetLastError());
     int status = 0;
     K3_TRY(hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost));
     K3_TRY(hipMemcpy(sig_out, d_h, nsets * m * 8, hipMemcpyDeviceToHost));
+    if (owner_out) K3_TRY(hipMemcpy(owner_out, d_arg, nsets * m * 8, hipMemcpyDeviceToHost));
     std::memcpy(total_weight_out, tw.data(), nsets * sizeof(double));
 #undef K3_TRY
     cleanup();

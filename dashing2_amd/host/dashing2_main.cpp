@@ -76,7 +76,10 @@ std::string makedest(const Options &o, const std::string &path) {
     if (o.sspace != SPACE_SET) ret += ".ExactCounting";   // to_string(ct()), src/enums.cpp:47; fastxmerge.cpp:96-100
     ret += o.sspace == SPACE_SET ? ".SetSpace" : ".MultisetSpace";   // to_string(sspace), src/enums.cpp:40-46
     ret += ".DNA";                                        // bns::to_string(rht_) (absent bonsai; expected "DNA")
-    ret += o.sspace == SPACE_SET ? ".opss" : ".bmh";      // to_suffix, src/enums.cpp:28-38
+    // to_suffix, src/enums.cpp:28-38, gives ".bmh" for BagMinHash.  Multiset sketches of this build follow the repository's
+    // BMH-D2G spec (the reference's sketch/bmh.h is absent): same layout, incomparable register values.  They get their own
+    // suffix so that a --cache directory shared with a stock dashing2 can never mix the two silently.
+    ret += o.sspace == SPACE_SET ? ".opss" : ".d2gbmh";
     return ret;
 }
 
@@ -594,7 +597,18 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
         const std::string &p0 = o.paths.empty() ? std::string() : o.paths.front();
         const auto dot = p0.find_last_of('.');
         const std::string suf = dot == std::string::npos ? std::string() : p0.substr(dot);
-        if (suf == ".bmh") { o.sspace = SPACE_MULTISET; o.kmer_result = FULL_SETSKETCH; }
+        if (suf == ".bmh" || suf == ".d2gbmh") {
+            // stock BagMinHash sketches compare fine among themselves (equality counting does not care how registers were
+            // drawn); what must never happen is one matrix over both kinds
+            o.sspace = SPACE_MULTISET; o.kmer_result = FULL_SETSKETCH;
+            for (const auto &p : o.paths) {
+                const auto d2 = p.find_last_of('.');
+                const std::string s2 = d2 == std::string::npos ? std::string() : p.substr(d2);
+                if ((s2 == ".bmh" || s2 == ".d2gbmh") && s2 != suf)
+                    die("cannot compare stock dashing2 BagMinHash sketches (.bmh) with this build's BMH-D2G sketches (.d2gbmh): "
+                        "their registers are drawn differently (see README)");
+            }
+        }
         else if (suf == ".pmh") { o.sspace = SPACE_PSET; o.kmer_result = FULL_SETSKETCH; }
         else if (suf == ".ss") { o.sspace = SPACE_SET; o.kmer_result = FULL_SETSKETCH; }
         else if (suf == ".opss") { o.sspace = SPACE_SET; o.kmer_result = ONE_PERM; }
@@ -616,11 +630,14 @@ int main_usage() {                                                // src/d2.cpp:
     std::fprintf(stderr, "Usage can be seen in those subcommands. (e.g., `dashing2 sketch -h`)\n\n");
     std::fprintf(stderr, "\tsketch: converts FastX into k-mer sets/sketches; also contains functionality from cmp, for one-step sketch and comparisons\n");
     std::fprintf(stderr, "\tcmp: compares previously sketched/decomposed k-mer sets and emits results. alias: dist\n\n");
-    std::fprintf(stderr, "This MI355X build implements the sketch and cmp hot paths only (wsketch/contain/printmin are out of scope).\n");
+    std::fprintf(stderr, "\twsketch: Takes a tuple of [1-3] input binary files [(u32 or u64), (float or double), (u32 or u64)] and performs weighted minhash sketching.\n");
+    std::fprintf(stderr, "This MI355X build implements the sketch and cmp hot paths and wsketch's BagMinHash selections (contain/printmin are out of scope).\n");
     return 1;
 }
 
 }  // namespace
+
+namespace d2h { int wsketch_main(int argc, char **argv); }        // wsketch_main.cpp
 
 int main(int argc, char **argv) {                                 // src/d2.cpp:133-151
     char cwd[4096];
@@ -630,7 +647,8 @@ int main(int argc, char **argv) {                                 // src/d2.cpp:
     if (argc > 1) {
         if (std::strcmp(argv[1], "sketch") == 0) return sketch_main(argc - 1, argv + 1);
         if (std::strcmp(argv[1], "cmp") == 0 || std::strcmp(argv[1], "dist") == 0) return cmp_main(argc - 1, argv + 1);
-        if (std::strcmp(argv[1], "wsketch") == 0 || std::strcmp(argv[1], "contain") == 0 || std::strcmp(argv[1], "printmin") == 0) {
+        if (std::strcmp(argv[1], "wsketch") == 0) return d2h::wsketch_main(argc - 1, argv + 1);
+        if (std::strcmp(argv[1], "contain") == 0 || std::strcmp(argv[1], "printmin") == 0) {
             std::fprintf(stderr, "dashing2 (MI355X): subcommand %s is outside the hot-path scope of this build.\n", argv[1]);
             return 1;
         }

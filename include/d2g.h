@@ -242,6 +242,13 @@ int d2g_sketcher_run_distinct(d2g_sketcher *sk, const uint8_t *packed, size_t pa
 int d2g_bmh_from_weighted(d2g_ctx *ctx, const uint64_t *ids, const double *weights,
                           const uint64_t *set_off /* [nsets+1] */, size_t nsets, size_t sketchsize,
                           double *sig_out /* host [nsets][S] */, double *total_weight_out /* host [nsets] */);
+/* the same + BagMinHash2::ids() (reference src/wsketch.cpp:36-37,66-67): owner_out[i][r] = position, within
+ * set i, of the element whose point register r holds (the smaller position on an exact tie); ~0 for a
+ * register no element reached (empty set).  owner_out may be NULL. */
+int d2g_bmh_from_weighted_ids(d2g_ctx *ctx, const uint64_t *ids, const double *weights,
+                              const uint64_t *set_off /* [nsets+1] */, size_t nsets, size_t sketchsize,
+                              double *sig_out /* host [nsets][S] */, double *total_weight_out /* host [nsets] */,
+                              uint64_t *owner_out /* host [nsets][S] or NULL */);
 
 /* ---- K2: dense all-pairs comparison -------------------------------------------
  * Replaces HOT LOOP B: emit_rectangular's row loops calling compare()

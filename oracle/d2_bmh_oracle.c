@@ -55,6 +55,8 @@ struct d2o_bmh {
     double *tree;        /* max-tree: tree[leaves + i] = h_i, tree[n] = max(tree[2n], tree[2n+1]) */
     double total_weight;
     proc_t *heap; size_t nheap, capheap;
+    uint64_t *owner;     /* BagMinHash2::ids(): the update() call (its `tag`) that set each register; ~0 = untouched */
+    uint64_t cur_tag;    /* tag of the update in progress */
 };
 
 static inline double V(uint64_t l) { return u2d(l); }
@@ -103,8 +105,9 @@ static proc_t heap_pop(d2o_bmh *b) {
 static inline double hmax(const d2o_bmh *b) { return b->tree[1]; }
 static void reg_update(d2o_bmh *b, uint32_t i, double x) {
     size_t n = b->leaves + i;
-    if (!(x < b->tree[n])) return;
+    if (!(x < b->tree[n])) return;              /* strict: on an exact tie the earlier update keeps the register */
     b->tree[n] = x;
+    b->owner[i] = b->cur_tag;
     for (n >>= 1; n >= 1; n >>= 1) {
         const double a = b->tree[2 * n], c = b->tree[2 * n + 1];
         const double mx = a > c ? a : c;
@@ -120,12 +123,13 @@ d2o_bmh *d2o_bmh_create(size_t sketchsize) {
     b->leaves = 1;
     while (b->leaves < sketchsize) b->leaves <<= 1;
     b->tree = (double *)malloc(2 * b->leaves * sizeof(double));
+    b->owner = (uint64_t *)malloc(sketchsize * sizeof(uint64_t));
     d2o_bmh_reset(b);
     return b;
 }
 void d2o_bmh_destroy(d2o_bmh *b) {
     if (!b) return;
-    free(b->tree); free(b->heap); free(b);
+    free(b->tree); free(b->heap); free(b->owner); free(b);
 }
 void d2o_bmh_reset(d2o_bmh *b) {
     for (size_t i = 0; i < b->leaves; ++i) b->tree[b->leaves + i] = i < b->m ? INFINITY : 0.0;
@@ -135,6 +139,8 @@ void d2o_bmh_reset(d2o_bmh *b) {
     }
     b->total_weight = 0.;
     b->nheap = 0;
+    memset(b->owner, 0xFF, b->m * sizeof(uint64_t));
+    b->cur_tag = 0;
 }
 double d2o_bmh_total_weight(const d2o_bmh *b) { return b->total_weight; }
 void d2o_bmh_data(const d2o_bmh *b, double *sig) { memcpy(sig, b->tree + b->leaves, b->m * sizeof(double)); }
@@ -193,9 +199,17 @@ uint64_t d2o_bmh_update(d2o_bmh *b, uint64_t id, double w) {
 
 int d2o_bmh_from_weighted(const uint64_t *ids, const double *w, size_t n, size_t sketchsize,
                           double *sig_out, double *total_weight_out) {
+    return d2o_bmh_from_weighted_ids(ids, w, n, sketchsize, sig_out, total_weight_out, NULL);
+}
+
+/* + BagMinHash2::ids() as wsketch.cpp:66-67 uses it: owner_out[r] = position i of the element whose point
+ * register r holds (elements are fed in position order, so a strict `<` keeps the smaller position on a tie) */
+int d2o_bmh_from_weighted_ids(const uint64_t *ids, const double *w, size_t n, size_t sketchsize,
+                              double *sig_out, double *total_weight_out, uint64_t *owner_out) {
     d2o_bmh *b = d2o_bmh_create(sketchsize);
     if (!b) return -1;
-    for (size_t i = 0; i < n; ++i) d2o_bmh_update(b, ids[i], w ? w[i] : 1.0);
+    for (size_t i = 0; i < n; ++i) { b->cur_tag = i; d2o_bmh_update(b, ids[i], w ? w[i] : 1.0); }
+    if (owner_out) memcpy(owner_out, b->owner, sketchsize * sizeof(uint64_t));
     if (sig_out) d2o_bmh_data(b, sig_out);
     if (total_weight_out) *total_weight_out = d2o_bmh_total_weight(b);
     d2o_bmh_destroy(b);

@@ -165,6 +165,9 @@ void     d2o_bmh_data(const d2o_bmh *b, double *sig /* [sketchsize] */);
 /* wsketch.cpp:54-73 minwise_det: ids[i] with weight w[i] (NULL => 1) */
 int d2o_bmh_from_weighted(const uint64_t *ids, const double *w, size_t n, size_t sketchsize,
                           double *sig_out, double *total_weight_out);
+/* + BagMinHash2::ids() (wsketch.cpp:36-37,66-67): position of the element that owns each register, ~0 if none */
+int d2o_bmh_from_weighted_ids(const uint64_t *ids, const double *w, size_t n, size_t sketchsize,
+                              double *sig_out, double *total_weight_out, uint64_t *owner_out);
 
 /* R11: sorted distinct maskfn'd k-mers and their counts for one FASTA/FASTQ buffer.
  * *keys_out / *counts_out are malloc'd (caller frees with d2o_free). */

@@ -74,6 +74,7 @@ def load(path=None):
         "d2o_bmh_total_weight": (dbl, [C.c_void_p]),
         "d2o_bmh_data": (None, [C.c_void_p, pdbl]),
         "d2o_bmh_from_weighted": (i32, [pu64, pdbl, sz, sz, pdbl, pdbl]),
+        "d2o_bmh_from_weighted_ids": (i32, [pu64, pdbl, sz, sz, pdbl, pdbl, pu64]),
         "d2o_kmer_count_buffer": (i32, [C.c_char_p, sz, i32, i32, u64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(sz), pu64]),
         "d2o_free": (None, [C.c_void_p]),
@@ -220,6 +221,19 @@ def bmh_from_weighted(ids, weights, S):
                                       _p(sig, C.c_double), C.byref(tw))
     assert rc == 0
     return sig, tw.value
+
+
+def bmh_from_weighted_ids(ids, weights, S):
+    """-> (sig float64[S], total_weight, owner uint64[S])"""
+    ids = np.ascontiguousarray(ids, np.uint64)
+    w = None if weights is None else np.ascontiguousarray(weights, np.float64)
+    sig = np.empty(S, np.float64)
+    own = np.empty(S, np.uint64)
+    tw = C.c_double()
+    rc = load().d2o_bmh_from_weighted_ids(_p(ids, C.c_uint64), None if w is None else _p(w, C.c_double), ids.size, S,
+                                          _p(sig, C.c_double), C.byref(tw), _p(own, C.c_uint64))
+    assert rc == 0
+    return sig, tw.value, own
 
 
 def kmer_count_buffer(buf, k, canon=True, xormask=0):

@@ -184,7 +184,7 @@ def test_dist_tool_single_rank(oracle, genomes, tmp_path):
 
 def test_cli_multiset_sketch_and_cmp(oracle, genomes, tmp_path):
     """BASELINE config 5 shape at test size: `dashing2 sketch --multiset` (exact k-mer counts ->
-    BagMinHash on the GPU) then all-pairs: stacked file, names, .bmh cache files and the distance
+    BagMinHash on the GPU) then all-pairs: stacked file, names, .d2gbmh cache files and the distance
     matrix must be byte-identical to the oracle pipeline (src/fastxsketch.cpp:425-445 ;
     src/cmp_core.cpp:495-517 for the multiset-space compare)."""
     from oracle import textfmt
@@ -200,7 +200,7 @@ def test_cli_multiset_sketch_and_cmp(oracle, genomes, tmp_path):
     assert raw.tobytes() == exp.tobytes()
     # F-a cache naming for multiset sketches (fastxmerge.cpp:70-120, enums.cpp:28-47)
     for i, g in enumerate(genomes):
-        dest = tmp_path / (os.path.basename(g) + f".rc_canon.sketchsize{S}.k{k}.ExactCounting.MultisetSpace.DNA.bmh")
+        dest = tmp_path / (os.path.basename(g) + f".rc_canon.sketchsize{S}.k{k}.ExactCounting.MultisetSpace.DNA.d2gbmh")
         blob = np.fromfile(dest, np.float64)
         assert blob[0] == ecards[i]
         np.testing.assert_array_equal(blob[1:].view(np.uint64), esigs[i].view(np.uint64))
@@ -213,7 +213,7 @@ def test_cli_multiset_sketch_and_cmp(oracle, genomes, tmp_path):
     assert exp_d.max() > 0.5
     # cmp --presketched picks the space up from the cache suffix; count threshold changes names and sketches
     b = tmp_path / "d.bin"
-    caches = [str(tmp_path / (os.path.basename(g) + f".rc_canon.sketchsize{S}.k{k}.ExactCounting.MultisetSpace.DNA.bmh")) for g in genomes]
+    caches = [str(tmp_path / (os.path.basename(g) + f".rc_canon.sketchsize{S}.k{k}.ExactCounting.MultisetSpace.DNA.d2gbmh")) for g in genomes]
     _run(["cmp", "--presketched", "-k", str(k), "--binary-output", "--cmpout", str(b)] + caches)
     np.testing.assert_array_equal(np.fromfile(b, np.float32).view(np.uint32), exp_d.view(np.uint32))
     out2 = tmp_path / "ms2.bin"
@@ -225,6 +225,106 @@ def test_cli_multiset_sketch_and_cmp(oracle, genomes, tmp_path):
     # OPH min-count filtering stays out of scope
     r = subprocess.run([EXE, "sketch", "-m", "2", "-k", "21"] + genomes[:2], capture_output=True)
     assert r.returncode != 0 and b"outside this build" in r.stderr
+    # interop guard: a stock dashing2 `.bmh` cache has the same layout but registers drawn by a
+    # different BagMinHash; one matrix over both kinds is refused, `.bmh` among themselves is fine, and --cache never
+    # picks a `.bmh` file up as its own
+    import shutil
+    stock = [c[:-len(".d2gbmh")] + ".bmh" for c in caches]
+    for c, sname in zip(caches, stock):
+        shutil.copy(c, sname)
+    r = subprocess.run([EXE, "cmp", "--presketched", "-k", str(k), "--binary-output", "--cmpout", str(b), caches[0], stock[1]], capture_output=True)
+    assert r.returncode != 0 and b"cannot compare stock dashing2 BagMinHash" in r.stderr
+    _run(["cmp", "--presketched", "-k", str(k), "--binary-output", "--cmpout", str(b)] + stock)
+    np.testing.assert_array_equal(np.fromfile(b, np.float32).view(np.uint32), exp_d.view(np.uint32))
+    for c in caches:
+        os.remove(c)
+    with open(stock[0], "r+b") as f:                  # a poisoned stock cache: must not be read by sketch --cache
+        f.seek(8)
+        f.write(np.full(S, 123.0).tobytes())
+    out3 = tmp_path / "ms3.bin"
+    _run(["sketch", "--multiset", "-k", str(k), "-S", str(S), "-o", str(out3), "--cache", "--outprefix", str(tmp_path)] + genomes)
+    assert np.fromfile(out3, np.uint8).tobytes() == exp.tobytes()
+    assert all(os.path.exists(c) for c in caches)
+
+
+def test_cli_wsketch(oracle, tmp_path):
+    """`dashing2 wsketch` (src/wsketch.cpp:264-377): binary id / weight / indptr inputs, the reference's output
+    files.  Registers, total weights and the sampled ids must equal the oracle's (BMH-D2G spec); the flag
+    combinations that select ProbMinHash / FullSetSketch in the reference are refused."""
+    rng = np.random.default_rng(12)
+    S = 64
+    n = 5000
+    ids = rng.choice(1 << 40, n, replace=False).astype(np.uint64)
+    w = np.round(rng.gamma(2.0, 3.0, n)) + 1.0
+    w[::97] = 0.0                                            # ignored by update()
+    (tmp_path / "ids.u64").write_bytes(ids.tobytes())
+    (tmp_path / "w.f64").write_bytes(w.tobytes())
+    (tmp_path / "w.f32").write_bytes(w.astype(np.float32).tobytes())
+    (tmp_path / "ids.u32").write_bytes((ids & np.uint64(0xFFFFFFFF)).astype(np.uint32).tobytes())
+    pos = np.arange(n, dtype=np.uint64)                      # update(i, w[i]): the sketch sees positions (wsketch.cpp:57-61)
+    esig, etw, eown = oracle.bmh_from_weighted_ids(pos, w, S)
+    # ---- two inputs (BagMinHash is the code's default here: wsketch.cpp:80-84)
+    pref = str(tmp_path / "o1")
+    r = _run(["wsketch", "-S", str(S), "-o", pref, str(tmp_path / "ids.u64"), str(tmp_path / "w.f64")])
+    blob = np.fromfile(pref + ".sampled.hashes.f64", np.float64)
+    assert blob[0] == etw
+    np.testing.assert_array_equal(blob[1:].view(np.uint64), esig.view(np.uint64))
+    np.testing.assert_array_equal(np.fromfile(pref + ".sampled.ids.u64", np.uint64), ids[eown])
+    np.testing.assert_array_equal(np.fromfile(pref + ".sampled.indices.u64", np.uint64), esig.view(np.uint64))
+    tail = chr((ord(";") + ord("d") + ord(";") + ord("L")) & 0xFF)
+    exp_msg = "Total weight: %f;%s;%s%s\n" % (etw, tmp_path / "ids.u64", tmp_path / "w.f64", tail)
+    assert open(pref + ".sampled.tw.txt", encoding="latin-1").read() == exp_msg
+    assert exp_msg.encode("latin-1") in r.stderr
+    # float32 weights + 32-bit ids, default out prefix = the id path
+    _run(["wsketch", "-S", str(S), "-f", "-u", str(tmp_path / "ids.u32"), str(tmp_path / "w.f32")])
+    blob = np.fromfile(str(tmp_path / "ids.u32") + ".sampled.hashes.f64", np.float64)
+    np.testing.assert_array_equal(blob[1:].view(np.uint64), esig.view(np.uint64))      # the integer weights survive float32
+    np.testing.assert_array_equal(np.fromfile(str(tmp_path / "ids.u32") + ".sampled.ids.u64", np.uint64), (ids & np.uint64(0xFFFFFFFF))[eown])
+    # one input: unit weights
+    pref = str(tmp_path / "o2")
+    _run(["wsketch", "-S", str(S), "-o", pref, str(tmp_path / "ids.u64")])
+    esig1, etw1, _ = oracle.bmh_from_weighted_ids(pos, None, S)
+    blob = np.fromfile(pref + ".sampled.hashes.f64", np.float64)
+    assert blob[0] == etw1 == n
+    np.testing.assert_array_equal(blob[1:].view(np.uint64), esig1.view(np.uint64))
+    # ---- three inputs (CSR; BagMinHash needs -B here: wsketch.cpp:148-150)
+    indptr = np.array([0, 700, 700, 2500, 5000], np.uint64)  # one empty row
+    (tmp_path / "ip.u64").write_bytes(indptr.tobytes())
+    (tmp_path / "ip.u32").write_bytes(indptr.astype(np.uint32).tobytes())
+    for ipf, flags in (("ip.u64", []), ("ip.u32", ["-P"])):
+        pref = str(tmp_path / ("csr" + ipf))
+        _run(["wsketch", "-B", "-S", str(S), "-o", pref] + flags + [str(tmp_path / "ids.u64"), str(tmp_path / "w.f64"), str(tmp_path / ipf)])
+        regs = np.fromfile(pref + f".sampled.regs.stacked.4.{S}.f64", np.uint8)
+        assert regs[:16].view(np.uint64).tolist() == [4, S]
+        tws = regs[16:16 + 32].view(np.float64)
+        sig = regs[48:].view(np.float64).reshape(4, S)
+        samp = np.fromfile(pref + f".sampled.indices.stacked.4.{S}.i64", np.uint64).reshape(4, S)
+        info = open(pref + ".sampled.info.txt").read().split()
+        for i in range(4):
+            lo, hi = int(indptr[i]), int(indptr[i + 1])
+            es, et, eo = oracle.bmh_from_weighted_ids(np.arange(hi - lo, dtype=np.uint64), w[lo:hi], S)
+            assert tws[i] == et and float(info[i]) == et
+            np.testing.assert_array_equal(sig[i].view(np.uint64), es.view(np.uint64))
+            if hi > lo:
+                np.testing.assert_array_equal(samp[i], ids[lo:hi][eo])
+            else:
+                assert np.isinf(sig[i]).all() and (samp[i] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+        # the stacked register file is a valid `cmp --presketched` input
+        b = tmp_path / "csr.bin"
+        _run(["cmp", "--presketched", "--multiset", "--binary-output", "--cmpout", str(b), pref + f".sampled.regs.stacked.4.{S}.f64"])
+        assert np.fromfile(b, np.float32).size == 6
+    # unit weights through '-'
+    pref = str(tmp_path / "csr_unit")
+    _run(["wsketch", "-B", "-S", str(S), "-o", pref, str(tmp_path / "ids.u64"), "-", str(tmp_path / "ip.u64")])
+    regs = np.fromfile(pref + f".sampled.regs.stacked.4.{S}.f64", np.uint8)
+    assert regs[16:48].view(np.float64).tolist() == [700.0, 0.0, 1800.0, 2500.0]
+    # out-of-scope selections say so
+    for args in (["-B", str(tmp_path / "ids.u64")], ["-q", str(tmp_path / "ids.u64")],
+                 [str(tmp_path / "ids.u64"), str(tmp_path / "w.f64"), str(tmp_path / "ip.u64")]):
+        r = subprocess.run([EXE, "wsketch", "-S", "32"] + args, capture_output=True)
+        assert r.returncode == 1 and b"outside this" in r.stderr
+    r = subprocess.run([EXE, "wsketch"], capture_output=True)
+    assert r.returncode == 1 and b"Required: between one and three positional arguments" in r.stderr
 
 
 def test_cli_parse_by_seq(oracle, tmp_path):

@@ -206,3 +206,29 @@ def test_bmh_golden_known_answers(gpu_ctx, d2g):
     sig, tw = gpu_ctx.bmh_sketch_seqpack(sp, 128, canon=False, count_threshold=1.0)
     np.testing.assert_array_equal(sig[0].view(np.uint64), kat["fasta_k11_S128_thr1"].view(np.uint64))
     assert tw[0] == float(kat["fasta_tw_thr1"])
+
+
+def test_bmh_from_weighted_owner_ids(gpu_ctx, oracle):
+    """BagMinHash2::ids() for explicit weighted sets (wsketch.cpp:36-37,66-67): the position of the element that
+    owns each register, several sets per call incl. an empty one and one with duplicate ids (exact ties go to
+    the smaller position), must equal the oracle's; registers and weights are unchanged by the extra pass."""
+    rng = np.random.default_rng(8)
+    S = 128
+    sizes = [3000, 0, 1, 777, 4100]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+    ids = rng.integers(0, 1 << 50, int(off[-1]), dtype=np.uint64)
+    ids[off[3] + 5:off[3] + 300] = ids[off[3] + 4]            # set 3: 296 copies of one id -> identical points, ties
+    w = np.round(rng.gamma(1.5, 4.0, ids.size)) + 1.0
+    w[off[3] + 5:off[3] + 300] = w[off[3] + 4]
+    w[::53] = 0.0
+    sig, tw, own = gpu_ctx.bmh_from_weighted_ids(ids, w, off, S)
+    sig0, tw0 = gpu_ctx.bmh_from_weighted(ids, w, off, S)
+    np.testing.assert_array_equal(sig.view(np.uint64), sig0.view(np.uint64))
+    np.testing.assert_array_equal(tw, tw0)
+    for i in range(len(sizes)):
+        lo, hi = int(off[i]), int(off[i + 1])
+        es, et, eo = oracle.bmh_from_weighted_ids(ids[lo:hi], w[lo:hi], S)
+        assert tw[i] == et
+        np.testing.assert_array_equal(sig[i].view(np.uint64), es.view(np.uint64))
+        np.testing.assert_array_equal(own[i], eo)
+    assert (own[1] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
