@@ -353,45 +353,89 @@ def main():
     out = torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
     if world > 1:
         dist.broadcast(sig_dev, 0)                           # untimed distribution of the synthetic input
-    eng = cs = None
+    eng = cs = comm = None
     pipelined = not args.no_pipeline
     exchange_fallback = None
+    engine_kind = None
     if sharded:
-        # first (untimed) pass under a guard: if the row-sharded exchange fails on any rank (every rank
-        # learns it through one flag all-reduce) the run falls back to the whole-matrix broadcast
-        # instead of losing the measurement
-        from dashing2_amd import dist as DD
-        n_loc = N // world
-        my_rows = sig_dev[rank * n_loc:(rank + 1) * n_loc].clone()
+        # The N > 1 data path: the row-sharded engine behind the C ABI (d2g_comm_* / d2g_allpairs_*: RCCL linked by
+        # libd2g itself; torch.distributed only carries the 128-byte unique id, the barrier and the timing reductions).
+        # First (untimed) pass under a guard: a failure on any rank (every rank learns it through one flag all-reduce)
+        # falls back to the torch.distributed form of the same exchange, then to the whole-matrix broadcast, instead of
+        # losing the measurement.
+        def all_failed(err):
+            if world > 1:
+                flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() > 0 and err is None:
+                    err = "failed on another rank"
+            return err
+
         err = None
         try:
-            eng = DD.RowShardedAllPairs(ctx, N, S, dev)
-            assert (eng.r0, eng.r1) == (r0, r1)
-            eng.step_lut(my_rows, lut, out, stream)
+            uid = [D.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            comm = D.Comm.create(ctx, rank, world, uid[0])
+            import ctypes
+            ctypes.CDLL(None).fflush(None)       # RCCL prints a version banner through C stdio: out now, not after the JSON line
+            eng = D.AllPairs(ctx, comm, N, S)
+            assert eng.rows_computed == (r0, r1)
+            lo, hi = eng.rows_held
+            my_rows = sig_dev[lo:hi].clone()
+            eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
             torch.cuda.synchronize()
         except Exception as e:                                   # noqa: BLE001 - reported in the JSON line
-            err = f"{type(e).__name__}: {e}"
-        if world > 1:
-            flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if flag.item() > 0 and err is None:
-                err = "row-sharded exchange failed on another rank"
-        if err:
+            err = f"C-ABI engine: {type(e).__name__}: {e}"
+        err = all_failed(err)
+        if err is None:
+            engine_kind = "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv groups)"
+
+            def step():
+                # all-to-all (rows -> column slices), prepare S/W columns, all-gather planes, pair kernel; pipelined: the
+                # exchange + prepare of the next step overlap this step's pair kernel (two operand buffers, own stream)
+                # -- every step still does all of its work inside the timed region
+                if pipelined:
+                    eng.enqueue_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream, input_ready=True)
+                else:
+                    eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
+
+            def plain_step():
+                eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
+            cs = eng.operand()
+        else:
             exchange_fallback = err
-            sharded = False
             eng = None
+            err2 = None
+            try:
+                from dashing2_amd import dist as DD
+                n_loc = N // world
+                my_rows = sig_dev[rank * n_loc:(rank + 1) * n_loc].clone()
+                teng = DD.RowShardedAllPairs(ctx, N, S, dev)
+                assert (teng.r0, teng.r1) == (r0, r1)
+                teng.step_lut(my_rows, lut, out, stream)
+                torch.cuda.synchronize()
+            except Exception as e:                               # noqa: BLE001
+                err2 = f"torch engine: {type(e).__name__}: {e}"
+            err2 = all_failed(err2)
+            if err2 is None:
+                engine_kind = "torch.distributed (dashing2_amd.dist.RowShardedAllPairs)"
+                eng = teng
+
+                def step():
+                    if pipelined:
+                        teng.enqueue_lut(my_rows, lut, out, ready=False)    # my_rows was complete before the timed region
+                    else:
+                        teng.step_lut(my_rows, lut, out, stream)
+
+                def plain_step():
+                    teng.step_lut(my_rows, lut, out, stream)
+                cs = teng.full
+            else:
+                exchange_fallback += " | " + err2
+                sharded = False
     if sharded:
         del sig_dev
-
-        def step():
-            # all-to-all (rows -> column slices), prepare S/W columns, all-gather planes, pair kernel;
-            # pipelined: the exchange + prepare of the next step overlap this step's pair kernel (two
-            # operand buffers, own stream) -- every step still does all of its work inside the timed region
-            if pipelined:
-                eng.enqueue_lut(my_rows, lut, out, ready=False)    # my_rows was complete before the timed region
-            else:
-                eng.step_lut(my_rows, lut, out, stream)
-        cs = eng.full
     else:
         cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
 
@@ -427,7 +471,7 @@ def main():
         # the pipelined steps must have produced exactly what one plain step produces; if they did not,
         # the measurement is repeated unpipelined so that the reported number is never from a wrong run
         got = out.clone()
-        eng.step_lut(my_rows, lut, out, stream)
+        plain_step()
         torch.cuda.synchronize()
         same = torch.tensor([1.0 if torch.equal(got, out) else 0.0], dtype=torch.float64, device=dev)
         if world > 1:
@@ -721,14 +765,19 @@ def main():
                        "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + pair kernel w/ fused epilogue; row-sharded sketches resident in HBM"
                                 if sharded else "RCCL broadcast (n_gpus>1) + prepare + pair kernel w/ fused epilogue; sketches resident in HBM"),
                        "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count",
+                       **({"exchange_engine": engine_kind} if engine_kind else {}),
                        **({"exchange_fallback": exchange_fallback} if exchange_fallback else {}),
                        **({"pipelined_exchange": pipeline_check} if pipeline_check else {})},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "config4_1gpu": config4,
             "sketch": sketch, "multiset_sketch": multiset,
         }
-        print(json.dumps(line))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
     if eng is not None:
         eng.close()
+        if comm is not None:
+            comm.close()
     else:
         cs.close()
     ctx.close()

@@ -7,7 +7,8 @@ by the tests, ``bench.py`` and the multi-GPU launcher (``dashing2_amd.dist``); i
 re-implements any part of the path and it fails loudly when the shared object is missing.
 """
 from .capi import (  # noqa: F401
-    D2GError, Context, CmpSet, SeqPack, lib, build, LIB_PATH,
+    D2GError, Context, CmpSet, SeqPack, Comm, AllPairs, lib, build, LIB_PATH,
+    comm_unique_id, allpairs_step_all, allpairs_prepare_all, bcast_sigs,
     SIMILARITY, CONTAINMENT, SYMMETRIC_CONTAINMENT, POISSON_LLR, INTERSECTION, UNION_SIZE,
     CMP_AUTO, CMP_DIRECT, CMP_BITSLICE, BITSLICE_OPS_PER_GROUP_EXTRA,
     wang_hash, seed_mask, oph_xor_const, oph_m, oph_finalize, densify, epilogue_lut,
@@ -15,7 +16,8 @@ from .capi import (  # noqa: F401
 )
 
 __all__ = [
-    "D2GError", "Context", "CmpSet", "SeqPack", "lib", "build", "LIB_PATH",
+    "D2GError", "Context", "CmpSet", "SeqPack", "Comm", "AllPairs", "lib", "build", "LIB_PATH",
+    "comm_unique_id", "allpairs_step_all", "allpairs_prepare_all", "bcast_sigs",
     "SIMILARITY", "CONTAINMENT", "SYMMETRIC_CONTAINMENT", "POISSON_LLR", "INTERSECTION", "UNION_SIZE",
     "CMP_AUTO", "CMP_DIRECT", "CMP_BITSLICE", "BITSLICE_OPS_PER_GROUP_EXTRA",
     "wang_hash", "seed_mask", "oph_xor_const", "oph_m", "oph_finalize", "densify", "epilogue_lut",

@@ -106,6 +106,25 @@ SIGNATURES = {
     "d2g_cmp_set_update_dev": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int), C.POINTER(_f32)]),
     "d2g_cmp_set_status": (_int, [_vp, _vp, _vp]),
+    "d2g_comm_unique_id": (_int, [_vp]),
+    "d2g_comm_create": (_int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
+    "d2g_comm_create_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_vp)]),
+    "d2g_comm_destroy": (None, [_vp]),
+    "d2g_comm_rank": (_int, [_vp]),
+    "d2g_comm_world": (_int, [_vp]),
+    "d2g_comm_is_rccl": (_int, [_vp]),
+    "d2g_bcast_sigs": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int, _vp, _sz, _sz, C.POINTER(_vp)]),
+    "d2g_allpairs_create": (_int, [_vp, _vp, _sz, _sz, C.POINTER(_vp)]),
+    "d2g_allpairs_destroy": (None, [_vp]),
+    "d2g_allpairs_rows_held": (_int, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    "d2g_allpairs_rows_computed": (_int, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    "d2g_allpairs_prepare_dev": (_int, [_vp, _vp, _vp]),
+    "d2g_allpairs_prepare_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "d2g_allpairs_operand": (_vp, [_vp]),
+    "d2g_allpairs_step_lut_dev": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "d2g_allpairs_step_eqcount_dev": (_int, [_vp, _vp, _vp, _vp]),
+    "d2g_allpairs_step_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "d2g_allpairs_enqueue_lut_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _int]),
     "d2g_operand_layout": (_int, [_sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     "d2g_cmp_set_export_operand_dev": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "d2g_cmp_set_from_planes_dev": (_int, [_vp, _sz, _sz, _vp, _vp, C.POINTER(_vp)]),
@@ -578,16 +597,17 @@ class OphPlan:
 class CmpSet:
     """Device-resident prepared signature matrix (d2g_cmp_set)."""
 
-    def __init__(self, ctx, h, N, S):
-        self.ctx, self._h, self.N, self.S = ctx, h, N, S
+    def __init__(self, ctx, h, N, S, owned=True):
+        self.ctx, self._h, self.N, self.S, self._owned = ctx, h, N, S, owned
 
     @property
     def algo(self):
         return int(lib().d2g_cmp_set_algo(self._h))
 
     def close(self):
-        if self._h:
-            lib().d2g_cmp_set_destroy(self._h)
+        if getattr(self, "_h", None):
+            if self._owned:
+                lib().d2g_cmp_set_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -693,3 +713,118 @@ class CmpSet:
             self.ctx.free(dl)
             self.ctx.free(d)
         return out
+
+
+# ---------------------------------------------------------------- multi-GPU (RCCL communicator + row-sharded engine)
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128 opaque bytes (ncclGetUniqueId) rank 0 hands to every rank"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().d2g_comm_unique_id(buf)
+    if rc:
+        raise D2GError(rc, "d2g_comm_unique_id (RCCL not loadable?)")
+    return buf.raw
+
+
+class Comm:
+    def __init__(self, ctx, h):
+        self.ctx, self._h = ctx, h
+
+    @classmethod
+    def create(cls, ctx, rank=0, world=1, unique_id=None):
+        h = _vp()
+        ctx._check(lib().d2g_comm_create(ctx._h, unique_id, rank, world, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def create_all(cls, ctxs):
+        """one process, one communicator per context: RCCL clique over distinct devices, loopback transport otherwise"""
+        n = len(ctxs)
+        arr = (_vp * n)(*[c._h for c in ctxs])
+        out = (_vp * n)()
+        ctxs[0]._check(lib().d2g_comm_create_all(arr, n, out))
+        return [cls(c, _vp(out[i])) for i, c in enumerate(ctxs)]
+
+    rank = property(lambda self: int(lib().d2g_comm_rank(self._h)))
+    world = property(lambda self: int(lib().d2g_comm_world(self._h)))
+    is_rccl = property(lambda self: bool(lib().d2g_comm_is_rccl(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().d2g_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+class AllPairs:
+    """one rank of the row-sharded all-pairs engine (d2g_allpairs)"""
+
+    def __init__(self, ctx, comm, N, S):
+        self.ctx, self.comm, self.N, self.S = ctx, comm, N, S
+        self._h = None
+        h = _vp()
+        ctx._check(lib().d2g_allpairs_create(ctx._h, comm._h, N, S, C.byref(h)))
+        self._h = h
+        a, b = _sz(), _sz()
+        lib().d2g_allpairs_rows_held(h, C.byref(a), C.byref(b))
+        self.rows_held = (a.value, b.value)
+        lib().d2g_allpairs_rows_computed(h, C.byref(a), C.byref(b))
+        self.rows_computed = (a.value, b.value)
+        self.r0, self.r1 = self.rows_computed
+
+    def prepare_dev(self, rows_ptr, stream=None):
+        self.ctx._check(lib().d2g_allpairs_prepare_dev(self._h, rows_ptr, stream))
+
+    def operand(self):
+        """the gathered operand as a (non-owning) CmpSet"""
+        return CmpSet(self.ctx, _vp(lib().d2g_allpairs_operand(self._h)), self.N, self.S, owned=False)
+
+    def step_lut_dev(self, rows_ptr, lut_ptr, out_ptr, stream=None):
+        self.ctx._check(lib().d2g_allpairs_step_lut_dev(self._h, rows_ptr, lut_ptr, out_ptr, stream))
+
+    def step_eqcount_dev(self, rows_ptr, out_ptr, stream=None):
+        self.ctx._check(lib().d2g_allpairs_step_eqcount_dev(self._h, rows_ptr, out_ptr, stream))
+
+    def enqueue_lut_dev(self, rows_ptr, lut_ptr, out_ptr, stream=None, input_ready=False):
+        self.ctx._check(lib().d2g_allpairs_enqueue_lut_dev(self._h, rows_ptr, lut_ptr, out_ptr, stream, int(input_ready)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().d2g_allpairs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def allpairs_step_all(engs, rows_ptrs, lut_ptrs, out_ptrs, streams=None):
+    """single-process multi-rank step: every collective phase is issued for all ranks inside one group"""
+    n = len(engs)
+    E = (_vp * n)(*[e._h for e in engs])
+    R = (_vp * n)(*rows_ptrs)
+    L = (_vp * n)(*lut_ptrs) if lut_ptrs is not None else None
+    O = (_vp * n)(*out_ptrs)
+    St = (_vp * n)(*(streams or [None] * n))
+    engs[0].ctx._check(lib().d2g_allpairs_step_all(E, n, R, L, O, St))
+
+
+def allpairs_prepare_all(engs, rows_ptrs, streams=None):
+    n = len(engs)
+    E = (_vp * n)(*[e._h for e in engs])
+    R = (_vp * n)(*rows_ptrs)
+    St = (_vp * n)(*(streams or [None] * n))
+    engs[0].ctx._check(lib().d2g_allpairs_prepare_all(E, n, R, St))
+
+
+def bcast_sigs(ctxs, comms, sig_bits_host):
+    """-> list of device pointers (one per context) holding the whole matrix (d2g_bcast_sigs)"""
+    a = np.ascontiguousarray(sig_bits_host, np.uint64)
+    N, S = a.shape
+    n = len(ctxs)
+    Cx = (_vp * n)(*[c._h for c in ctxs])
+    Cm = (_vp * n)(*[c._h for c in comms])
+    out = (_vp * n)()
+    ctxs[0]._check(lib().d2g_bcast_sigs(Cx, Cm, n, _np_ptr(a), N, S, out))
+    return [int(out[i]) for i in range(n)]

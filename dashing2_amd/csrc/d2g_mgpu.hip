@@ -1,0 +1,563 @@
+// d2g_mgpu.hip -- multi-GPU half of K2 behind the C ABI: an RCCL communicator wrapper and the row-sharded
+// all-pairs engine (reference seam src/cmp_core.cpp:746-751 -> emit_rectangular).
+//
+// The path shards (independent units after one exchange, no reduction): rank r HOLDS rows
+// [row_lo[r], row_lo[r+1]) of the N x S signature matrix -- the state file-sharded sketching leaves in HBM --
+// and COMPUTES a pair-balanced row range of the upper triangle (d2g_ut_partition).  One step is
+//   A   pack      my rows -> W blocks, block q = my rows x the register columns rank q prepares       (local kernel)
+//   X1  exchange  block q -> rank q  ("all-to-all-v": RCCL send/recv pairs in one group)             (collective)
+//   B   prepare   the bit-sliced operand of my column slice (N x S_q), exported in the exchange form (local kernels)
+//   X2  exchange  my groups -> everyone ("all-gather-v")                                             (collective)
+//   C   compare   the pair kernel over my row range of the gathered operand                          (local kernel)
+// Column slices are whole 32-register groups (the operand's independent unit), rows and groups are split as
+// evenly as integers allow: no divisibility requirement on N or S.  xGMI is a full point-to-point mesh, so
+// direct send/recv pairs use all links at once; nothing here is a ring.
+//
+// RCCL is resolved at first use with dlopen (the copy already in the process, e.g. PyTorch's, else
+// librccl.so.1): libd2g.so itself has no link-time dependency on the 0.5 GB library and the single-GPU CLI
+// never pays for loading it.  Contexts that share ONE device (tests on a 1-GPU box) cannot form an RCCL clique;
+// d2g_comm_create_all gives them a loopback transport (device-to-device copies ordered by events) that runs
+// exactly the same send/recv lists.
+#include "d2g_internal.h"
+#include "d2g_k2.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- RCCL, late-bound
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // a copy already loaded
+        if (!r.lib) for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!r.lib) { r.err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "not found"); return; }
+        auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("RCCL lacks ") + n; return p; };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &r;
+}
+
+}  // namespace
+struct d2g_comm;
+namespace {
+
+// ------------------------------------------------------------------------------------------- loopback transport
+struct LocalOp { int from, to; const void *src; void *dst; size_t bytes; hipStream_t s; bool is_send; };
+struct LocalGroup {
+    std::vector<::d2g_comm *> members;
+    std::vector<LocalOp> pending;
+    int depth = 0;
+};
+
+}  // namespace
+
+struct d2g_comm {
+    d2g_ctx *ctx = nullptr;
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;                 // RCCL transport (distinct devices)
+    std::shared_ptr<LocalGroup> lg;            // loopback transport (one process, any devices)
+};
+
+namespace {
+
+#define D2G_NCCL(ctx, call)                                                                     \
+    do {                                                                                        \
+        ncclResult_t r__ = (call);                                                              \
+        if (r__ != ncclSuccess) {                                                               \
+            (ctx)->last_error = std::string(#call) + ": " + rccl()->GetErrorString(r__);        \
+            return D2G_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+// group_begin / send / recv / group_end: the one interface the engine speaks
+int comm_group_begin(d2g_comm *c) {
+    if (c->lg) { ++c->lg->depth; return D2G_OK; }
+    if (c->world == 1) return D2G_OK;
+    D2G_NCCL(c->ctx, rccl()->GroupStart());
+    return D2G_OK;
+}
+int comm_send(d2g_comm *c, int peer, const void *src, size_t bytes, hipStream_t s) {
+    if (!bytes) return D2G_OK;
+    if (c->lg) { c->lg->pending.push_back({c->rank, peer, src, nullptr, bytes, s, true}); return D2G_OK; }
+    D2G_CHECK(c->ctx, c->world > 1 && peer != c->rank, "comm_send: self transfers are local copies");
+    D2G_NCCL(c->ctx, rccl()->Send(src, bytes, ncclUint8, peer, c->nccl, s));
+    return D2G_OK;
+}
+int comm_recv(d2g_comm *c, int peer, void *dst, size_t bytes, hipStream_t s) {
+    if (!bytes) return D2G_OK;
+    if (c->lg) { c->lg->pending.push_back({peer, c->rank, nullptr, dst, bytes, s, false}); return D2G_OK; }
+    D2G_CHECK(c->ctx, c->world > 1 && peer != c->rank, "comm_recv: self transfers are local copies");
+    D2G_NCCL(c->ctx, rccl()->Recv(dst, bytes, ncclUint8, peer, c->nccl, s));
+    return D2G_OK;
+}
+// loopback: match every send with the recv of the same (from, to) pair, in order, and run it as a copy on
+// the RECEIVER's stream, fenced against both ranks' streams
+int local_flush(d2g_comm *c) {
+    LocalGroup &g = *c->lg;
+    std::vector<LocalOp> ops;
+    ops.swap(g.pending);
+    std::vector<char> used(ops.size(), 0);
+    for (size_t i = 0; i < ops.size(); ++i) {
+        if (!ops[i].is_send) continue;
+        size_t j = 0;
+        for (; j < ops.size(); ++j)
+            if (!used[j] && !ops[j].is_send && ops[j].from == ops[i].from && ops[j].to == ops[i].to) break;
+        D2G_CHECK(c->ctx, j < ops.size() && ops[j].bytes == ops[i].bytes, "loopback transport: unmatched send/recv");
+        used[j] = 1;
+        d2g_ctx *sc = g.members[ops[i].from]->ctx, *rc = g.members[ops[i].to]->ctx;
+        hipEvent_t ready = nullptr, done = nullptr;
+        D2G_HIP(c->ctx, hipSetDevice(sc->device));
+        D2G_HIP(c->ctx, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        D2G_HIP(c->ctx, hipEventRecord(ready, ops[i].s));                   // sender's data is complete
+        D2G_HIP(c->ctx, hipSetDevice(rc->device));
+        D2G_HIP(c->ctx, hipStreamWaitEvent(ops[j].s, ready, 0));
+        D2G_HIP(c->ctx, hipMemcpyAsync(ops[j].dst, ops[i].src, ops[i].bytes, hipMemcpyDeviceToDevice, ops[j].s));
+        D2G_HIP(c->ctx, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        D2G_HIP(c->ctx, hipEventRecord(done, ops[j].s));
+        D2G_HIP(c->ctx, hipSetDevice(sc->device));
+        D2G_HIP(c->ctx, hipStreamWaitEvent(ops[i].s, done, 0));             // the sender may reuse its buffer afterwards
+        (void)hipEventDestroy(ready);
+        (void)hipEventDestroy(done);
+    }
+    for (size_t j = 0; j < ops.size(); ++j)
+        D2G_CHECK(c->ctx, ops[j].is_send || used[j], "loopback transport: recv without a matching send");
+    return D2G_OK;
+}
+int comm_group_end(d2g_comm *c) {
+    if (c->lg) {
+        if (--c->lg->depth > 0) return D2G_OK;
+        return local_flush(c);
+    }
+    if (c->world == 1) return D2G_OK;
+    D2G_NCCL(c->ctx, rccl()->GroupEnd());
+    return D2G_OK;
+}
+
+// ------------------------------------------------------------------------------------------- pack kernel
+// rows [n][S] -> W consecutive blocks, block q = [n][cols_q] with cols_q = [colstart[q], colstart[q+1]):
+// the send layout of the row-slice -> column-slice exchange, one launch.
+__global__ __launch_bounds__(256) void mg_pack_kernel(const uint64_t *__restrict__ rows, size_t n, size_t S, int W,
+                                                      const uint32_t *__restrict__ colstart, uint64_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * S) return;
+    const size_t r = i / S;
+    const uint32_t c = (uint32_t)(i - r * S);
+    int q = 0;
+    while (q + 1 < W && colstart[q + 1] <= c) ++q;                     // W is small; uniform-ish scalar walk
+    const uint32_t c0 = colstart[q], wq = colstart[q + 1] - c0;
+    out[(size_t)n * c0 + r * wq + (c - c0)] = rows[i];
+}
+
+template <class T> std::vector<T> even_split(T total, int parts) {     // [parts+1] bounds, sizes differ by at most one
+    std::vector<T> b(parts + 1);
+    for (int p = 0; p <= parts; ++p) b[p] = (T)((unsigned __int128)total * p / parts);
+    return b;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- the engine
+struct d2g_allpairs {
+    d2g_ctx *ctx = nullptr;
+    d2g_comm *comm = nullptr;
+    size_t N = 0, S = 0;
+    int W = 1, rank = 0;
+    std::vector<size_t> row_lo;          // [W+1] rows each rank holds
+    std::vector<size_t> grp_lo;          // [W+1] 32-register groups each rank prepares
+    std::vector<uint32_t> colstart;      // [W+1] first register column of each rank's slice (last = S)
+    size_t r0 = 0, r1 = 0;               // rows of the triangle this rank computes
+    size_t gw = 0, ng = 0;               // words per exchanged group, number of groups
+    uint32_t *d_colstart = nullptr;
+    uint64_t *d_send = nullptr, *d_recv = nullptr;
+    d2g_cmp_set *local = nullptr;        // my column slice (N x S_me), bit-sliced
+    // two operand buffers: the pipelined form prepares buffer i+1 while the pair kernel reads buffer i
+    uint32_t *d_planes[2] = {nullptr, nullptr}, *d_meta[2] = {nullptr, nullptr};
+    d2g_cmp_set *full[2] = {nullptr, nullptr};
+    hipStream_t xs = nullptr;            // exchange/prepare stream of the pipelined form
+    hipEvent_t x_done[2] = {nullptr, nullptr}, p_done[2] = {nullptr, nullptr}, in_ready = nullptr;
+    bool p_valid[2] = {false, false};
+    unsigned long long nsteps = 0;
+    int last = 0;                        // buffer of the most recent prepare
+    size_t n_me() const { return row_lo[rank + 1] - row_lo[rank]; }
+    size_t s_me() const { return colstart[rank + 1] - colstart[rank]; }
+    size_t g_me() const { return grp_lo[rank + 1] - grp_lo[rank]; }
+};
+
+namespace {
+
+int eng_alloc_buffer(d2g_allpairs *e, int b) {
+    d2g_ctx *ctx = e->ctx;
+    if (e->full[b]) return D2G_OK;
+    D2G_HIP(ctx, hipMalloc((void **)&e->d_planes[b], std::max<size_t>(e->ng * e->gw, 1) * 4));
+    D2G_HIP(ctx, hipMalloc((void **)&e->d_meta[b], std::max<size_t>(e->ng, 1) * 4));
+    return d2g_cmp_set_from_planes_dev(ctx, e->N, e->S, e->d_planes[b], e->d_meta[b], &e->full[b]);
+}
+
+// phases of one step on buffer b, all enqueued on stream s
+int phase_pack(d2g_allpairs *e, const uint64_t *rows_dev, hipStream_t s) {
+    const size_t n = e->n_me();
+    if (!n) return D2G_OK;
+    D2G_CHECK(e->ctx, rows_dev != nullptr, "allpairs: null row block");
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    hipLaunchKernelGGL(mg_pack_kernel, dim3((unsigned)div_up<size_t>(n * e->S, 256)), dim3(256), 0, s, rows_dev, n, e->S, e->W,
+                       e->d_colstart, e->d_send);
+    D2G_HIP(e->ctx, hipGetLastError());
+    return D2G_OK;
+}
+int phase_x1(d2g_allpairs *e, hipStream_t s) {                         // inside a comm group
+    const size_t n = e->n_me(), sm = e->s_me();
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    for (int q = 0; q < e->W; ++q) {
+        const size_t wq = e->colstart[q + 1] - e->colstart[q];
+        const uint64_t *src = e->d_send + n * e->colstart[q];          // block q of my rows
+        uint64_t *dst = e->d_recv + e->row_lo[q] * sm;                  // rows of rank q, my columns
+        const size_t nq = e->row_lo[q + 1] - e->row_lo[q];
+        if (q == e->rank) {
+            if (n * wq) D2G_HIP(e->ctx, hipMemcpyAsync(dst, src, n * wq * 8, hipMemcpyDeviceToDevice, s));
+            continue;
+        }
+        if (int rc = comm_send(e->comm, q, src, n * wq * 8, s)) return rc;
+        if (int rc = comm_recv(e->comm, q, dst, nq * sm * 8, s)) return rc;
+    }
+    return D2G_OK;
+}
+int phase_prepare(d2g_allpairs *e, int b, hipStream_t s) {
+    if (!e->s_me()) return D2G_OK;                                     // more ranks than register groups: nothing to prepare here
+    int rc;
+    if (!e->local) rc = d2g_cmp_set_create_dev(e->ctx, e->d_recv, e->N, e->s_me(), D2G_CMP_BITSLICE, s, &e->local);
+    else rc = d2g_cmp_set_update_dev(e->ctx, e->local, e->d_recv, s);
+    if (rc) return rc;
+    // my groups go straight to their place in the gathered operand
+    return d2g_cmp_set_export_operand_dev(e->ctx, e->local, e->d_planes[b] + e->grp_lo[e->rank] * e->gw, e->d_meta[b] + e->grp_lo[e->rank], s);
+}
+int phase_x2(d2g_allpairs *e, int b, hipStream_t s) {                  // inside a comm group
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    const size_t gm = e->g_me();
+    for (int q = 0; q < e->W; ++q) {
+        if (q == e->rank) continue;
+        const size_t gq = e->grp_lo[q + 1] - e->grp_lo[q];
+        if (int rc = comm_send(e->comm, q, e->d_planes[b] + e->grp_lo[e->rank] * e->gw, gm * e->gw * 4, s)) return rc;
+        if (int rc = comm_send(e->comm, q, e->d_meta[b] + e->grp_lo[e->rank], gm * 4, s)) return rc;
+        if (int rc = comm_recv(e->comm, q, e->d_planes[b] + e->grp_lo[q] * e->gw, gq * e->gw * 4, s)) return rc;
+        if (int rc = comm_recv(e->comm, q, e->d_meta[b] + e->grp_lo[q], gq * 4, s)) return rc;
+    }
+    return D2G_OK;
+}
+
+// exchange + sharded prepare for n ranks driven by this thread (n = 1: one process per GPU)
+int prepare_many(d2g_allpairs **es, int n, const uint64_t *const *rows, const int *bufs, hipStream_t const *ss) {
+    int rc;
+    for (int i = 0; i < n; ++i) if ((rc = eng_alloc_buffer(es[i], bufs[i]))) return rc;
+    for (int i = 0; i < n; ++i) if ((rc = phase_pack(es[i], rows[i], ss[i]))) return rc;
+    if ((rc = comm_group_begin(es[0]->comm))) return rc;
+    for (int i = 0; i < n; ++i) if ((rc = phase_x1(es[i], ss[i]))) { (void)comm_group_end(es[0]->comm); return rc; }
+    if ((rc = comm_group_end(es[0]->comm))) return rc;
+    for (int i = 0; i < n; ++i) if ((rc = phase_prepare(es[i], bufs[i], ss[i]))) return rc;
+    if ((rc = comm_group_begin(es[0]->comm))) return rc;
+    for (int i = 0; i < n; ++i) if ((rc = phase_x2(es[i], bufs[i], ss[i]))) { (void)comm_group_end(es[0]->comm); return rc; }
+    if ((rc = comm_group_end(es[0]->comm))) return rc;
+    for (int i = 0; i < n; ++i) es[i]->last = bufs[i];
+    return D2G_OK;
+}
+
+int check_group(d2g_allpairs **es, int n) {
+    if (!es || n < 1 || !es[0]) return D2G_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        if (!es[i]) return D2G_ERR_INVALID;
+        D2G_CHECK(es[i]->ctx, es[i]->N == es[0]->N && es[i]->S == es[0]->S && es[i]->W == es[0]->W, "allpairs: engines of different shapes");
+    }
+    return D2G_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------- communicator
+int d2g_comm_unique_id(void *id_out) {
+    if (!id_out) return D2G_ERR_INVALID;
+    Rccl *r = rccl();
+    if (!r->err.empty()) return D2G_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (r->GetUniqueId(&id) != ncclSuccess) return D2G_ERR_HIP;
+    static_assert(sizeof(ncclUniqueId) == D2G_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    std::memcpy(id_out, &id, sizeof id);
+    return D2G_OK;
+}
+
+int d2g_comm_create(d2g_ctx *ctx, const void *id, int rank, int world, d2g_comm **out) {
+    if (!ctx || !out) return D2G_ERR_INVALID;
+    *out = nullptr;
+    D2G_CHECK(ctx, world >= 1 && rank >= 0 && rank < world, "comm: bad rank/world");
+    d2g_comm *c = new (std::nothrow) d2g_comm();
+    if (!c) return D2G_ERR_NOMEM;
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    if (world > 1 || id) {                       // a single rank with an id still forms a real (one-member) RCCL communicator
+        Rccl *r = rccl();
+        if (!r->err.empty()) { ctx->last_error = r->err; delete c; return D2G_ERR_UNSUPPORTED; }
+        if (!id) { ctx->last_error = "comm: null unique id"; delete c; return D2G_ERR_INVALID; }
+        ncclUniqueId uid;
+        std::memcpy(&uid, id, sizeof uid);
+        if (hipSetDevice(ctx->device) != hipSuccess) { delete c; return D2G_ERR_HIP; }
+        const ncclResult_t rc = r->CommInitRank(&c->nccl, world, uid, rank);
+        if (rc != ncclSuccess) { ctx->last_error = std::string("ncclCommInitRank: ") + r->GetErrorString(rc); delete c; return D2G_ERR_HIP; }
+    }
+    *out = c;
+    return D2G_OK;
+}
+
+int d2g_comm_create_all(d2g_ctx **ctxs, int nctx, d2g_comm **comms_out) {
+    if (!ctxs || !comms_out || nctx < 1) return D2G_ERR_INVALID;
+    for (int i = 0; i < nctx; ++i) { if (!ctxs[i]) return D2G_ERR_INVALID; comms_out[i] = nullptr; }
+    bool distinct = true;
+    for (int i = 0; i < nctx; ++i)
+        for (int j = 0; j < i; ++j) distinct &= ctxs[i]->device != ctxs[j]->device;
+    std::vector<d2g_comm *> cs(nctx);
+    for (int i = 0; i < nctx; ++i) {
+        cs[i] = new (std::nothrow) d2g_comm();
+        if (!cs[i]) { for (int j = 0; j < i; ++j) delete cs[j]; return D2G_ERR_NOMEM; }
+        cs[i]->ctx = ctxs[i]; cs[i]->rank = i; cs[i]->world = nctx;
+    }
+    const char *force = std::getenv("D2G_COMM_LOOPBACK");
+    if (nctx > 1 && distinct && !(force && force[0] == '1')) {          // one RCCL clique over the devices of this process
+        Rccl *r = rccl();
+        std::vector<ncclComm_t> nc(nctx);
+        std::vector<int> devs(nctx);
+        for (int i = 0; i < nctx; ++i) devs[i] = ctxs[i]->device;
+        const ncclResult_t rc = r->err.empty() ? r->CommInitAll(nc.data(), nctx, devs.data()) : ncclSystemError;
+        if (rc == ncclSuccess) {
+            for (int i = 0; i < nctx; ++i) { cs[i]->nccl = nc[i]; comms_out[i] = cs[i]; }
+            return D2G_OK;
+        }
+        ctxs[0]->last_error = r->err.empty() ? std::string("ncclCommInitAll: ") + r->GetErrorString(rc) : r->err;
+        for (auto *c : cs) delete c;
+        return D2G_ERR_HIP;
+    }
+    if (nctx > 1) {                                                      // shared device(s): loopback transport
+        auto lg = std::make_shared<LocalGroup>();
+        lg->members.assign(cs.begin(), cs.end());
+        for (auto *c : cs) c->lg = lg;
+    }
+    for (int i = 0; i < nctx; ++i) comms_out[i] = cs[i];
+    return D2G_OK;
+}
+
+void d2g_comm_destroy(d2g_comm *c) {
+    if (!c) return;
+    if (c->nccl) { (void)hipSetDevice(c->ctx->device); (void)rccl()->CommDestroy(c->nccl); }
+    delete c;
+}
+int d2g_comm_rank(const d2g_comm *c) { return c ? c->rank : -1; }
+int d2g_comm_world(const d2g_comm *c) { return c ? c->world : -1; }
+int d2g_comm_is_rccl(const d2g_comm *c) { return c && c->nccl != nullptr; }
+
+// the whole matrix from the host to every GPU of this process -- one H2D to ctxs[0], then ONE
+// RCCL broadcast over xGMI (loopback: plain copies).  sig_dev_out[i] is allocated on ctxs[i] (d2g_free).
+int d2g_bcast_sigs(d2g_ctx **ctxs, d2g_comm **comms, int nctx, const uint64_t *host_sig, size_t N, size_t S, uint64_t **sig_dev_out) {
+    if (!ctxs || !comms || nctx < 1 || !sig_dev_out || !ctxs[0]) return D2G_ERR_INVALID;
+    d2g_ctx *c0 = ctxs[0];
+    D2G_CHECK(c0, host_sig != nullptr && N >= 1 && S >= 1, "bcast_sigs: empty matrix");
+    const size_t bytes = N * S * 8;
+    for (int i = 0; i < nctx; ++i) sig_dev_out[i] = nullptr;
+    for (int i = 0; i < nctx; ++i) {
+        D2G_CHECK(c0, ctxs[i] && comms[i] && comms[i]->ctx == ctxs[i] && comms[i]->world == nctx && comms[i]->rank == i, "bcast_sigs: comm/ctx mismatch");
+        D2G_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
+        D2G_HIP(ctxs[i], hipMalloc((void **)&sig_dev_out[i], bytes));
+    }
+    D2G_HIP(c0, hipSetDevice(c0->device));
+    D2G_HIP(c0, hipMemcpyAsync(sig_dev_out[0], host_sig, bytes, hipMemcpyHostToDevice, nullptr));
+    if (nctx > 1) {
+        if (comms[0]->nccl) {
+            D2G_NCCL(c0, rccl()->GroupStart());
+            for (int i = 0; i < nctx; ++i) {
+                (void)hipSetDevice(ctxs[i]->device);
+                const ncclResult_t rc = rccl()->Broadcast(sig_dev_out[0], sig_dev_out[i], bytes, ncclUint8, 0, comms[i]->nccl, nullptr);
+                if (rc != ncclSuccess) { (void)rccl()->GroupEnd(); c0->last_error = std::string("ncclBroadcast: ") + rccl()->GetErrorString(rc); return D2G_ERR_HIP; }
+            }
+            D2G_NCCL(c0, rccl()->GroupEnd());
+        } else {
+            if (int rc = comm_group_begin(comms[0])) return rc;
+            for (int i = 1; i < nctx; ++i) {
+                if (int rc = comm_send(comms[0], i, sig_dev_out[0], bytes, nullptr)) return rc;
+                if (int rc = comm_recv(comms[i], 0, sig_dev_out[i], bytes, nullptr)) return rc;
+            }
+            if (int rc = comm_group_end(comms[0])) return rc;
+        }
+    }
+    for (int i = 0; i < nctx; ++i) {
+        D2G_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
+        D2G_HIP(ctxs[i], hipStreamSynchronize(nullptr));
+    }
+    return D2G_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- engine
+int d2g_allpairs_create(d2g_ctx *ctx, d2g_comm *comm, size_t N, size_t S, d2g_allpairs **out) {
+    if (!ctx || !comm || !out) return D2G_ERR_INVALID;
+    *out = nullptr;
+    D2G_CHECK(ctx, comm->ctx == ctx, "allpairs: the communicator belongs to another context");
+    D2G_CHECK(ctx, N >= 1 && S >= 1 && N < (1ull << 30) && S < (1ull << 31), "allpairs: bad shape");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    d2g_allpairs *e = new (std::nothrow) d2g_allpairs();
+    if (!e) return D2G_ERR_NOMEM;
+    e->ctx = ctx; e->comm = comm; e->N = N; e->S = S; e->W = comm->world; e->rank = comm->rank;
+    e->row_lo = even_split<size_t>(N, e->W);
+    if (int rc = d2g_operand_layout(N, S, &e->gw, &e->ng)) { delete e; return rc; }
+    e->grp_lo = even_split<size_t>(e->ng, e->W);
+    e->colstart.resize(e->W + 1);
+    for (int q = 0; q <= e->W; ++q) e->colstart[q] = (uint32_t)std::min<size_t>(S, e->grp_lo[q] * 32);
+    std::vector<size_t> ob(e->W + 1);
+    d2g_ut_partition(N, e->W, ob.data());
+    e->r0 = ob[e->rank]; e->r1 = ob[e->rank + 1];
+    hipError_t he;
+    if ((he = hipMalloc((void **)&e->d_colstart, (e->W + 1) * 4)) != hipSuccess ||
+        (he = hipMemcpy(e->d_colstart, e->colstart.data(), (e->W + 1) * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (he = hipMalloc((void **)&e->d_send, std::max<size_t>(e->n_me() * S, 1) * 8)) != hipSuccess ||
+        (he = hipMalloc((void **)&e->d_recv, std::max<size_t>(N * e->s_me(), 1) * 8)) != hipSuccess) {
+        ctx->last_error = std::string("allpairs alloc: ") + hipGetErrorString(he);
+        d2g_allpairs_destroy(e);
+        return he == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
+    }
+    if (int rc = eng_alloc_buffer(e, 0)) { d2g_allpairs_destroy(e); return rc; }
+    *out = e;
+    return D2G_OK;
+}
+
+void d2g_allpairs_destroy(d2g_allpairs *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (int b = 0; b < 2; ++b) {
+        d2g_cmp_set_destroy(e->full[b]);
+        (void)hipFree(e->d_planes[b]); (void)hipFree(e->d_meta[b]);
+        if (e->x_done[b]) (void)hipEventDestroy(e->x_done[b]);
+        if (e->p_done[b]) (void)hipEventDestroy(e->p_done[b]);
+    }
+    if (e->in_ready) (void)hipEventDestroy(e->in_ready);
+    d2g_cmp_set_destroy(e->local);
+    (void)hipFree(e->d_colstart); (void)hipFree(e->d_send); (void)hipFree(e->d_recv);
+    if (e->xs) (void)hipStreamDestroy(e->xs);
+    delete e;
+}
+
+int d2g_allpairs_rows_held(const d2g_allpairs *e, size_t *lo, size_t *hi) {
+    if (!e) return D2G_ERR_INVALID;
+    if (lo) *lo = e->row_lo[e->rank];
+    if (hi) *hi = e->row_lo[e->rank + 1];
+    return D2G_OK;
+}
+int d2g_allpairs_rows_computed(const d2g_allpairs *e, size_t *r0, size_t *r1) {
+    if (!e) return D2G_ERR_INVALID;
+    if (r0) *r0 = e->r0;
+    if (r1) *r1 = e->r1;
+    return D2G_OK;
+}
+const d2g_cmp_set *d2g_allpairs_operand(const d2g_allpairs *e) { return e ? e->full[e->last] : nullptr; }
+
+int d2g_allpairs_prepare_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, void *const *streams) {
+    if (int rc = check_group(engs, n)) return rc;
+    std::vector<int> bufs(n, 0);
+    std::vector<hipStream_t> ss(n);
+    for (int i = 0; i < n; ++i) ss[i] = as_stream(streams ? streams[i] : nullptr);
+    return prepare_many(engs, n, rows_dev, bufs.data(), ss.data());
+}
+int d2g_allpairs_prepare_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, void *stream) {
+    return d2g_allpairs_prepare_all(&e, 1, &my_rows_dev, &stream);
+}
+
+// one whole step per engine: exchange + sharded prepare + this rank's slab of pairs (rows_computed)
+int d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, const float *const *lut_dev,
+                          void *const *out_dev, void *const *streams) {
+    if (int rc = d2g_allpairs_prepare_all(engs, n, rows_dev, streams)) return rc;
+    for (int i = 0; i < n; ++i) {
+        d2g_allpairs *e = engs[i];
+        void *s = streams ? streams[i] : nullptr;
+        int rc = (lut_dev && lut_dev[i]) ? d2g_cmp_lut_ut_dev(e->ctx, e->full[e->last], e->r0, e->r1, lut_dev[i], (float *)out_dev[i], s)
+                                         : d2g_cmp_eqcount_ut_dev(e->ctx, e->full[e->last], e->r0, e->r1, (uint32_t *)out_dev[i], s);
+        if (rc) return rc;
+    }
+    return D2G_OK;
+}
+int d2g_allpairs_step_lut_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, const float *lut_dev, float *out_dev, void *stream) {
+    void *o = out_dev;
+    return d2g_allpairs_step_all(&e, 1, &my_rows_dev, &lut_dev, &o, &stream);
+}
+int d2g_allpairs_step_eqcount_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, uint32_t *out_dev, void *stream) {
+    void *o = out_dev;
+    return d2g_allpairs_step_all(&e, 1, &my_rows_dev, nullptr, &o, &stream);
+}
+
+// Software-pipelined step (one rank per calling thread): the exchange + prepare of this call run on the
+// engine's own stream over the operand buffer the PREVIOUS call is not using, so they overlap the previous
+// call's pair kernel, which is still busy on `stream`.  Results land in out_dev in call order on `stream`.
+// input_ready: 0 = my_rows_dev may have been produced by work queued on `stream` just before this call (the
+// exchange waits for everything queued there so far -- safe, but it then also waits for the previous pair
+// kernel); 1 = the input is already complete (synchronised earlier): no dependency, full overlap.
+int d2g_allpairs_enqueue_lut_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, const float *lut_dev, float *out_dev, void *stream,
+                                 int input_ready) {
+    if (!e) return D2G_ERR_INVALID;
+    d2g_ctx *ctx = e->ctx;
+    D2G_CHECK(ctx, lut_dev && out_dev, "allpairs: null lut/output");
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t main = as_stream(stream);
+    if (!e->xs) {
+        D2G_HIP(ctx, hipStreamCreateWithFlags(&e->xs, hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            D2G_HIP(ctx, hipEventCreateWithFlags(&e->x_done[b], hipEventDisableTiming));
+            D2G_HIP(ctx, hipEventCreateWithFlags(&e->p_done[b], hipEventDisableTiming));
+        }
+        D2G_HIP(ctx, hipEventCreateWithFlags(&e->in_ready, hipEventDisableTiming));
+    }
+    const int b = (int)(e->nsteps & 1);
+    if (!input_ready) {
+        D2G_HIP(ctx, hipEventRecord(e->in_ready, main));
+        D2G_HIP(ctx, hipStreamWaitEvent(e->xs, e->in_ready, 0));
+    }
+    if (e->p_valid[b]) D2G_HIP(ctx, hipStreamWaitEvent(e->xs, e->p_done[b], 0));      // buffer b is free once pair(step - 2) is done
+    // send/recv/local are shared by consecutive steps: the exchange stream runs them in order, and the operand
+    // buffer is the only thing the pair kernel on `main` still reads
+    hipStream_t xs = e->xs;
+    if (int rc = prepare_many(&e, 1, &my_rows_dev, &b, &xs)) return rc;
+    D2G_HIP(ctx, hipEventRecord(e->x_done[b], e->xs));
+    D2G_HIP(ctx, hipStreamWaitEvent(main, e->x_done[b], 0));
+    if (int rc = d2g_cmp_lut_ut_dev(ctx, e->full[b], e->r0, e->r1, lut_dev, out_dev, stream)) return rc;
+    D2G_HIP(ctx, hipEventRecord(e->p_done[b], main));
+    e->p_valid[b] = true;
+    ++e->nsteps;
+    return D2G_OK;
+}
+
+}  // extern "C"

@@ -25,6 +25,7 @@
 #include <fstream>
 #include <limits>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -466,6 +467,109 @@ struct PinnedBuf {                            // page-locked host staging, reuse
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
+// D2G_DEVICES = "all" | "0,1,2": the GPUs `cmp` may spread a symmetric all-pairs job over (default: the one device
+// D2G_DEVICE names).  A list that repeats a device is allowed (loopback transport: used by the tests on one GPU).
+std::vector<int> cmp_devices(const Options &o) {
+    std::vector<int> d;
+    const char *e = std::getenv("D2G_DEVICES");
+    if (!e || !*e) return {o.device};
+    if (std::strcmp(e, "all") == 0) { for (int i = 0; i < d2g_device_count(); ++i) d.push_back(i); }
+    else for (const char *p = e; *p;) { char *q; const long v = std::strtol(p, &q, 10); if (q == p) break; d.push_back(int(v)); p = *q == ',' ? q + 1 : q; }
+    if (d.empty()) d.push_back(o.device);
+    return d;
+}
+
+// Symmetric all-pairs over several GPUs from ONE process (the reference's seam is the single call
+// emit_rectangular(opts, result), src/cmp_core.cpp:746-751).  Every GPU gets a contiguous block of rows of the
+// signature matrix; one exchange (d2g_allpairs_prepare_all: all-to-all of column slices, sharded prepare, all-gather
+// of the bit planes over RCCL/xGMI) leaves the whole operand on every GPU; row batches of the condensed triangle are
+// then dealt to the GPUs round-robin, computed concurrently and emitted in row order.
+void cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs, bool have_lut, const std::vector<float> &lut,
+                    bool multiset) {
+    const size_t ns = res.names.size(), S = o.sketchsize;
+    const int W = int(devs.size());
+    const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.signatures.data());
+    const double *cards = res.cardinalities.data();
+    const double t0 = now();
+    std::vector<d2g_ctx *> ctxs(W, nullptr);
+    for (int r = 0; r < W; ++r) {
+        const int rc = d2g_ctx_create(devs[r], &ctxs[r]);
+        if (rc != D2G_OK) die(std::string("D2G_DEVICES: d2g_ctx_create(") + std::to_string(devs[r]) + "): " + d2g_strerror(rc));
+    }
+    std::vector<d2g_comm *> comms(W, nullptr);
+    check(ctxs[0], d2g_comm_create_all(ctxs.data(), W, comms.data()), "d2g_comm_create_all");
+    std::vector<d2g_allpairs *> engs(W, nullptr);
+    std::vector<const uint64_t *> rows(W, nullptr);
+    std::vector<void *> rowbuf(W, nullptr);
+    for (int r = 0; r < W; ++r) {
+        check(ctxs[r], d2g_allpairs_create(ctxs[r], comms[r], ns, S, &engs[r]), "d2g_allpairs_create");
+        size_t lo = 0, hi = 0;
+        d2g_allpairs_rows_held(engs[r], &lo, &hi);
+        check(ctxs[r], d2g_malloc(ctxs[r], std::max<size_t>((hi - lo) * S, 1) * 8, &rowbuf[r]), "d2g_malloc");
+        if (hi > lo) check(ctxs[r], d2g_memcpy_h2d(ctxs[r], rowbuf[r], bits + lo * S, (hi - lo) * S * 8, nullptr), "h2d rows");
+        rows[r] = static_cast<const uint64_t *>(rowbuf[r]);
+    }
+    check(ctxs[0], d2g_allpairs_prepare_all(engs.data(), W, rows.data(), nullptr), "d2g_allpairs_prepare_all");
+    for (int r = 0; r < W; ++r) {
+        check(ctxs[r], d2g_cmp_set_status(ctxs[r], d2g_allpairs_operand(engs[r]), nullptr), "prepare");
+        check(ctxs[r], d2g_free(ctxs[r], rowbuf[r]), "d2g_free");
+    }
+    const double t_prep = now() - t0;
+    Emitter em(o, res);
+    em.header();
+    const size_t max_vals = size_t(1) << 27;
+    const size_t total_pairs = ns * (ns - 1) / 2, cap = std::min(std::max<size_t>(total_pairs, 1), max_vals + ns);
+    std::vector<std::unique_ptr<DevBuf>> da(W), dlut(W);
+    std::vector<std::unique_ptr<PinnedBuf>> hout(W), hca(W);
+    for (int r = 0; r < W; ++r) {
+        da[r].reset(new DevBuf(ctxs[r], cap * 4));
+        dlut[r].reset(new DevBuf(ctxs[r], (S + 1) * sizeof(float)));
+        hout[r].reset(new PinnedBuf(ctxs[r], cap * 4));
+        hca[r].reset(new PinnedBuf(ctxs[r], have_lut ? 4 : cap * 4));
+        if (have_lut) check(ctxs[r], d2g_memcpy_h2d(ctxs[r], dlut[r]->p, lut.data(), (S + 1) * sizeof(float), nullptr), "h2d lut");
+    }
+    double t_dev = 0, t_emit = 0;
+    struct Batch { size_t r0, r1, cnt; };
+    for (size_t next = 0; next < ns;) {
+        // one round: up to W consecutive row batches, one per GPU, launched back to back (asynchronous)
+        std::vector<Batch> round;
+        const double ta = now();
+        for (int r = 0; r < W && next < ns; ++r) {
+            size_t r1 = next, cnt = 0;
+            while (r1 < ns && (cnt == 0 || cnt + (ns - 1 - r1) <= max_vals)) { cnt += ns - 1 - r1; ++r1; }
+            round.push_back({next, r1, cnt});
+            if (cnt) {
+                const d2g_cmp_set *set = d2g_allpairs_operand(engs[r]);
+                if (have_lut) check(ctxs[r], d2g_cmp_lut_ut_dev(ctxs[r], set, next, r1, (const float *)dlut[r]->p, (float *)da[r]->p, nullptr), "d2g_cmp_lut_ut_dev");
+                else check(ctxs[r], d2g_cmp_eqcount_ut_dev(ctxs[r], set, next, r1, (uint32_t *)da[r]->p, nullptr), "d2g_cmp_eqcount_ut_dev");
+            }
+            next = r1;
+        }
+        t_dev += now() - ta;
+        for (size_t b = 0; b < round.size(); ++b) {                 // drain in row order
+            const Batch &bt = round[b];
+            const double tb = now();
+            float *out = hout[b]->as<float>();
+            if (bt.cnt) {
+                if (have_lut) check(ctxs[b], d2g_memcpy_d2h(ctxs[b], out, da[b]->p, bt.cnt * 4, nullptr), "d2h");
+                else {
+                    uint32_t *ca = hca[b]->as<uint32_t>();
+                    check(ctxs[b], d2g_memcpy_d2h(ctxs[b], ca, da[b]->p, bt.cnt * 4, nullptr), "d2h");
+                    check(ctxs[b], d2g_epilogue_ut(ca, nullptr, cards, ns, S, bt.r0, bt.r1, o.measure, o.k, multiset, int(o.nthreads()), out),
+                          "d2g_epilogue_ut");
+                }
+            }
+            const double tc = now();
+            em.rows(bt.r0, bt.r1, out, [&](size_t i) { return ns - 1 - i; });
+            t_dev += tc - tb; t_emit += now() - tc;
+        }
+    }
+    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp on %d GPUs (%s): %zu sketches x S=%zu: upload+exchange+prepare %.3fs, device+D2H+epilogue %.3fs, emit %.3fs\n",
+                                  W, d2g_comm_is_rccl(comms[0]) ? "RCCL" : "loopback", ns, S, t_prep, t_dev, t_emit);
+    da.clear(); dlut.clear(); hout.clear(); hca.clear();
+    for (int r = 0; r < W; ++r) { d2g_allpairs_destroy(engs[r]); d2g_comm_destroy(comms[r]); d2g_ctx_destroy(ctxs[r]); }
+}
+
 void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_core.cpp:615-751 (dense outputs)
     const size_t ns = res.names.size(), S = o.sketchsize;
     if (res.signatures.size() != ns * S) die("Empty signatures; trying to compare but don't have any");
@@ -480,6 +584,15 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     std::vector<float> lut(S + 1);
     const bool have_lut = d2g_epilogue_lut(S, o.measure, o.k, multiset, lut.data()) == D2G_OK;
     const bool need_gtlt = !multiset && (S & (S - 1)) != 0;
+    {
+        const std::vector<int> devs = cmp_devices(o);
+        if (devs.size() > 1 && (o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP) && !need_gtlt && ns >= 2) {
+            cmp_core_multi(o, res, devs, have_lut, lut, multiset);
+            return;
+        }
+        if (devs.size() > 1 && o.verbosity)
+            std::fprintf(stderr, "[d2g] D2G_DEVICES ignored: only symmetric all-pairs with equality counts spreads over GPUs\n");
+    }
     d2g_cmp_set *set = nullptr;
     const double t0 = now();
     check(ctx, d2g_cmp_set_create(ctx, bits, ns, S, need_gtlt ? int(D2G_CMP_DIRECT) : int(D2G_CMP_AUTO), &set), "d2g_cmp_set_create");

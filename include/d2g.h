@@ -329,6 +329,57 @@ int  d2g_cmp_dist_ut(d2g_ctx *ctx, const uint64_t *sig_bits, const double *cards
                      size_t sketchsize, size_t r0, size_t r1, int measure, int k, int multiset_space,
                      int algo, int nthreads, float *out);
 
+/* ---- multi-GPU: RCCL communicator + row-sharded all-pairs engine ------------------------------------
+ * Replaces nothing in the reference (it has no multi-process code); it is how the all-pairs seam
+ * (cmp_core -> emit_rectangular, src/cmp_core.cpp:746-751) spreads over the GPUs of a node: rows of the upper
+ * triangle are independent units, one exchange of the compact bit-plane operand, no reduction.
+ * One d2g_ctx + one d2g_comm + one d2g_allpairs per GPU.  Two deployments share all of it:
+ *   - one process (or host thread) per GPU: rank 0 calls d2g_comm_unique_id, the 128 bytes reach the other
+ *     ranks by any means (file, socket, MPI, a torch.distributed store), every rank calls d2g_comm_create;
+ *   - one process driving several GPUs (the `dashing2 cmp` CLI): d2g_comm_create_all + the `_all` entry
+ *     points, which issue each collective phase for all ranks inside one RCCL group.
+ * RCCL is loaded at first use (dlopen); contexts that share a device get a loopback transport instead
+ * (device copies ordered by events) so that the whole path can be exercised on one GPU. */
+typedef struct d2g_comm d2g_comm;
+#define D2G_COMM_ID_BYTES 128
+int  d2g_comm_unique_id(void *id_out /* D2G_COMM_ID_BYTES */);                       /* ncclGetUniqueId */
+int  d2g_comm_create(d2g_ctx *ctx, const void *id, int rank, int world, d2g_comm **out);   /* ncclCommInitRank (collective) */
+int  d2g_comm_create_all(d2g_ctx **ctxs, int nctx, d2g_comm **comms_out /* [nctx] */);     /* ncclCommInitAll, or loopback */
+void d2g_comm_destroy(d2g_comm *comm);
+int  d2g_comm_rank(const d2g_comm *comm);
+int  d2g_comm_world(const d2g_comm *comm);
+int  d2g_comm_is_rccl(const d2g_comm *comm);                                          /* 0: loopback / single rank without id */
+/* the host matrix to every GPU of this process -- one H2D to ctxs[0], then one RCCL
+ * broadcast over xGMI.  sig_dev_out[i] is allocated on ctxs[i] (release with d2g_free).  Synchronises. */
+int  d2g_bcast_sigs(d2g_ctx **ctxs, d2g_comm **comms, int nctx, const uint64_t *host_sig, size_t N, size_t sketchsize,
+                    uint64_t **sig_dev_out /* [nctx] */);
+
+typedef struct d2g_allpairs d2g_allpairs;
+/* rank `d2g_comm_rank(comm)` of an all-pairs job over an N x S matrix.  No divisibility requirement on N or S. */
+int  d2g_allpairs_create(d2g_ctx *ctx, d2g_comm *comm, size_t N, size_t sketchsize, d2g_allpairs **out);
+void d2g_allpairs_destroy(d2g_allpairs *eng);
+/* rows [lo, hi) of the matrix this rank must HOLD as its input block (contiguous, sizes differ by <= 1) */
+int  d2g_allpairs_rows_held(const d2g_allpairs *eng, size_t *lo, size_t *hi);
+/* rows [r0, r1) of the upper triangle this rank COMPUTES (pair-balanced, d2g_ut_partition) */
+int  d2g_allpairs_rows_computed(const d2g_allpairs *eng, size_t *r0, size_t *r1);
+/* exchange + sharded prepare: afterwards d2g_allpairs_operand() is the whole N x S bit-sliced operand on this
+ * rank's GPU, usable with d2g_cmp_eqcount_ut_dev / d2g_cmp_lut_ut_dev / d2g_cmp_eqcount_rect_dev on ANY rows
+ * (the CLI deals row batches to the GPUs round-robin).  Collective; enqueues on `stream`, no synchronisation. */
+int  d2g_allpairs_prepare_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev /* [hi-lo][S] */, void *stream);
+int  d2g_allpairs_prepare_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, void *const *streams);
+const d2g_cmp_set *d2g_allpairs_operand(const d2g_allpairs *eng);
+/* one whole step: prepare + this rank's slab (rows_computed) of the condensed triangle; out has
+ * d2g_ut_count(N, r0, r1) entries.  lut_dev == NULL (or lut_dev[i] == NULL): u32 equality counts. */
+int  d2g_allpairs_step_lut_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev, const float *lut_dev, float *out_dev, void *stream);
+int  d2g_allpairs_step_eqcount_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev, uint32_t *out_dev, void *stream);
+int  d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, const float *const *lut_dev,
+                           void *const *out_dev, void *const *streams);
+/* software-pipelined step for a stream of matrices: the exchange + prepare of this call overlap the pair kernel
+ * of the previous call (own stream, two operand buffers); results land in out_dev in call order on `stream`.
+ * input_ready != 0: my_rows_dev is already complete (no dependency on work queued on `stream`). */
+int  d2g_allpairs_enqueue_lut_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev, const float *lut_dev, float *out_dev,
+                                  void *stream, int input_ready);
+
 /* ---- multi-GPU row partition (host arithmetic; emitrect.cpp:290-323 row order) ----
  * Splits rows [0,N) into `nparts` contiguous ranges with (near-)equal pair counts.
  * bounds_out has nparts+1 entries. */

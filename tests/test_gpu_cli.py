@@ -455,3 +455,33 @@ def test_cli_config1_shape(oracle, tmp_path):
     _run(["cmp", "--presketched", "-k", "31", "--binary-output", "--distance", "--cmpout", str(binm), str(out)])
     mash = oracle.allpairs_ut(_densified(oracle, esigs), ecards, measure=oracle.POISSON_LLR, k=31, nthreads=8)
     assert np.fromfile(binm, np.float32).tobytes() == mash.tobytes()
+
+
+def test_cli_cmp_multi_gpu_loopback(oracle, genomes, tmp_path):
+    """`dashing2 cmp` spread over several GPUs from one process (D2G_DEVICES): on this 1-GPU box the
+    device list repeats device 0, which selects the loopback transport under the same row-sharded exchange.
+    Outputs must be byte-identical to the single-GPU run for table-epilogue and host-epilogue measures, text and
+    binary, set and multiset space."""
+    k, S = 31, 512
+    out = tmp_path / "s.bin"
+    _run(["sketch", "-k", str(k), "-S", str(S), "-o", str(out)] + genomes)
+    for flags in ([], ["--distance"], ["--containment"], ["--union-size"]):
+        ref = tmp_path / "ref.bin"
+        _run(["cmp", "--presketched", "-k", str(k), "--binary-output", "--cmpout", str(ref)] + flags + [str(out)])
+        for devs in ("0,0", "0,0,0,0,0"):
+            got = tmp_path / "got.bin"
+            r = subprocess.run([EXE, "cmp", "--presketched", "-k", str(k), "--binary-output", "--cmpout", str(got), "-v"] + flags + [str(out)],
+                               capture_output=True, env=dict(os.environ, D2G_DEVICES=devs))
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            assert b"GPUs (loopback)" in r.stderr
+            assert got.read_bytes() == ref.read_bytes(), (flags, devs)
+    reft = _run(["cmp", "--presketched", "-k", str(k), "--phylip", str(out)]).stdout
+    r = subprocess.run([EXE, "cmp", "--presketched", "-k", str(k), "--phylip", str(out)], capture_output=True, env=dict(os.environ, D2G_DEVICES="0,0,0"))
+    assert r.returncode == 0 and r.stdout == reft
+    # multiset space (count_eq branch of compare())
+    ms = tmp_path / "ms.bin"
+    _run(["sketch", "--multiset", "-k", "21", "-S", "256", "-o", str(ms)] + genomes)
+    ref = _run(["cmp", "--presketched", "--multiset", "-k", "21", "--intersection", str(ms)]).stdout
+    r = subprocess.run([EXE, "cmp", "--presketched", "--multiset", "-k", "21", "--intersection", str(ms)], capture_output=True,
+                       env=dict(os.environ, D2G_DEVICES="0,0"))
+    assert r.returncode == 0 and r.stdout == ref
