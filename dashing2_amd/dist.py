@@ -7,9 +7,12 @@ exchange), every rank prepares the operand on its GPU and computes its slab; sla
 so there is no reduction.  Each rank writes its slab at its own offset of the binary matrix
 (F-d layout, src/emitrect.cpp:373-397) or the slabs are gathered to rank 0 for text output.
 
-Launch:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-             -m dashing2_amd.dist --presketched stack.bin --cmpout dist.bin [--distance] [-k 31]
-         ... -m dashing2_amd.dist sketch -F files.txt -o stack.bin [-k 31 -S 1024 --multiset ...]
+Launch:  python -m dashing2_amd.dist cmp --presketched stack.bin --cmpout dist.bin [--distance] [-k 31]
+             (one process: the C++ CLI drives every visible GPU through libd2g's RCCL communicator)
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+             -m dashing2_amd.dist sketch -F files.txt -o stack.bin [-k 31 -S 1024 --multiset ...]
+The torch.distributed classes below (sharded_allpairs, RowShardedAllPairs) are the same exchange written against
+torch collectives: bench.py's fallback when the C-ABI engine cannot be used, and what the gloo CPU tests exercise.
 SKETCH shards by input (rank r takes files r, r+world, ...; each rank runs the CLI on its own GPU;
 no collective, one barrier) and rank 0 interleaves the shards back into input order.
 
@@ -312,10 +315,20 @@ def sketch_sharded(paths, out, cli_args=(), run=None, device=None):
     lst = shard + ".files.txt"
     with open(lst, "w") as f:
         f.write("".join(paths[i] + "\n" for i in mine))
+    err = None
     if mine:
-        run(["sketch", *cli_args, "-F", lst, "-o", shard], device)
+        try:
+            run(["sketch", *cli_args, "-F", lst, "-o", shard], device)
+        except Exception as e:                                   # noqa: BLE001 - re-raised on every rank below
+            err = f"rank {rank}: {type(e).__name__}: {e}"
     if world > 1:
-        _dist().barrier()
+        # one collective carries the failure to every rank: a rank that raised before the barrier used to leave the
+        # others waiting for the process-group timeout
+        errs = [None] * world
+        _dist().all_gather_object(errs, err)
+        err = next((e for e in errs if e), None)
+    if err:
+        raise RuntimeError("sharded sketching failed: " + err)
     if rank != 0:
         return None
     N = len(paths)
@@ -378,46 +391,22 @@ def load_stacked(path):
 
 
 def main(argv=None):
+    """python -m dashing2_amd.dist sketch ...   -> file-sharded sketching, one rank per GPU (above)
+    python -m dashing2_amd.dist [cmp] ...     -> `dashing2 cmp ...` spread over every visible GPU.
+
+    The multi-GPU comparison itself lives behind the C ABI (d2g_comm_* / d2g_allpairs_*, RCCL linked by libd2g) and
+    is driven from ONE process by the drop-in CLI (D2G_DEVICES); this entry point only launches it, with every flag
+    of `dashing2 cmp` (measures, --multiset, text or binary output ...) passed through unchanged."""
     argv = sys.argv[1:] if argv is None else list(argv)
     if argv and argv[0] == "sketch":
         return sketch_main(argv[1:])
-    import torch
-    from . import capi
-    ap = argparse.ArgumentParser(prog="dashing2_amd.dist")
-    ap.add_argument("--presketched", required=True, help="stacked sketch file written by `dashing2 sketch -o`")
-    ap.add_argument("--cmpout", required=True, help="binary float32 condensed matrix (reference --binary-output layout)")
-    ap.add_argument("-k", "--kmer-length", type=int, default=32)
-    for flag, m in (("--distance", capi.POISSON_LLR), ("--mash-distance", capi.POISSON_LLR), ("--containment", capi.CONTAINMENT),
-                    ("--symmetric-containment", capi.SYMMETRIC_CONTAINMENT), ("--intersection", capi.INTERSECTION),
-                    ("--union-size", capi.UNION_SIZE)):
-        ap.add_argument(flag, dest="measure", action="store_const", const=m)
-    ap.set_defaults(measure=capi.SIMILARITY)
-    args = ap.parse_args(argv)
-    dist = _dist()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    ctx = capi.Context(local)
-    hdr = torch.zeros(2, dtype=torch.int64, device="cuda")
-    sigs = cards = None
-    if rank == 0:
-        N, S, cards, sigs = load_stacked(args.presketched)
-        sigs, _ = capi.densify(sigs, nthreads=os.cpu_count() or 1)     # cmp_core.cpp:686-718
-        hdr[0], hdr[1] = N, S
-    if world > 1:
-        dist.broadcast(hdr, 0)
-    N, S = int(hdr[0]), int(hdr[1])
-    r0, r1, slab = sharded_allpairs(sigs.view(np.uint64) if rank == 0 else None, cards, N, S,
-                                    gpu_compute(ctx, args.measure, args.kmer_length), device="cuda")
-    write_slab(args.cmpout, N, r0, slab)
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
-    return 0
+    if argv and argv[0] in ("cmp", "dist"):
+        argv = argv[1:]
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "dashing2")
+    env = dict(os.environ)
+    env.setdefault("D2G_DEVICES", "all")
+    import subprocess
+    return subprocess.call([exe, "cmp"] + argv, env=env)
 
 
 if __name__ == "__main__":

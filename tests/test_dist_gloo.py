@@ -164,3 +164,42 @@ def test_sketch_sharded_gloo(tmp_path, world, npaths):
     port = _free_port()
     mp.spawn(_sketch_worker, args=(world, port, str(tmp_path), npaths), nprocs=world, join=True)
     assert os.path.exists(tmp_path / "ok.npy")
+
+
+def _sketch_fail_worker(rank, world, port, tmp):
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    from dashing2_amd import dist as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    paths = [os.path.join(tmp, f"g{i}.fa") for i in range(4)]
+
+    def failing_cli(args, device):
+        if device == 1:
+            raise RuntimeError("simulated CLI failure")
+        out = args[args.index("-o") + 1]
+        mine = [l for l in open(args[args.index("-F") + 1]) if l.strip()]
+        with open(out, "wb") as f:
+            np.array([len(mine), 4], np.uint64).tofile(f)
+            np.zeros(len(mine) * 5).tofile(f)
+
+    t0 = time.time()
+    try:
+        D.sketch_sharded(paths, os.path.join(tmp, "stack.bin"), [], run=failing_cli, device=rank)
+        raised = False
+    except RuntimeError as e:
+        raised = "simulated CLI failure" in str(e)
+    assert raised and time.time() - t0 < 60                   # every rank learns of the failure, none waits for a timeout
+    np.save(os.path.join(tmp, f"fail{rank}.npy"), np.array([1]))
+    dist.destroy_process_group()
+
+
+def test_sketch_sharded_failure_reaches_every_rank(tmp_path):
+    """a rank whose CLI call raises used to skip the barrier and leave the others hanging"""
+    import torch.multiprocessing as mp
+    mp.spawn(_sketch_fail_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "fail0.npy") and os.path.exists(tmp_path / "fail1.npy")
