@@ -31,6 +31,10 @@
 #include <new>
 #include <vector>
 
+#ifndef D2G_K3_EXP
+#define D2G_K3_EXP 0          // timing experiments (tools/build_variant.sh): 1 = scatter without stores, 2 = 4-byte stores (no main pass); 3 = main without the BagMinHash walk, 4 = main counting only
+#endif
+
 namespace {
 
 constexpr int K3_THREADS = 256;
@@ -40,7 +44,6 @@ constexpr int K3_TAB = 2048;                // LDS count-table slots (24.6 KB wi
 constexpr int K3_ROUND_KEYS = 1400;         // keys one table round is sized for (load <= 0.69)
 constexpr int K3_TARGET = 1024;             // mean keys per bucket aimed for
 constexpr uint64_t K3_SPLIT_MIN = 4 * 1400; // mean bucket size above which a genome's buckets are split once more
-constexpr uint64_t K3_EMPTY = ~0ull;
 constexpr uint64_t BMH_INF = 0x7FF0000000000000ull;
 constexpr int BMH_STACK = 72;
 
@@ -123,35 +126,227 @@ __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
     uint64_t *keys = a.keys + koff;
     d2g_for_each_kmer(a.km, [&](uint64_t x) {
         const uint64_t key = wang64(x ^ xormask);
-        keys[atomicAdd(&pos[bucket_of(key, bb)], 1u)] = key;
+        const uint32_t slot = atomicAdd(&pos[bucket_of(key, bb)], 1u);
+        if (D2G_K3_EXP == 1) { if (slot == 0xFFFFFFFFu) keys[slot] = key; }                      // timing experiment: no stores
+        else if (D2G_K3_EXP == 2) reinterpret_cast<uint32_t *>(keys)[slot] = (uint32_t)key;      // timing experiment: 4-byte stores
+        else keys[slot] = key;
     });
+}
+
+// ---------------------------------------------------------------------------------------------
+// COMPACT path (k <= 21): the multi-split stores 4 bytes per k-mer and writes them coalesced.
+//
+// Counting only needs a key that identifies the k-mer, so the split works on the 2k-bit k-mer x itself (the
+// masked key Wang(x ^ XORMASK) is a bijection of it and is computed once per DISTINCT k-mer in the main pass).
+// x = hi:lo with lo = 32 bits, hi = 2k - 32 <= 10 bits.  With m = lo * 0x9E3779B1 and t = the top bb bits of m,
+//     bucket = t ^ (hi << (bb - hb))                           (bb >= hb bucket bits per genome)
+// hi is recovered from (bucket, lo), so a bucket stores lo only; and within a bucket lo identifies the k-mer.
+// Lower bits of m select sub-ranges and table rounds.
+//
+// The generic scatter issues one 8-byte store per k-mer to 4096 write fronts: 1.25e9 scattered stores take 11.5 ms
+// whatever their width (measured: 13.6 ms with 4-byte stores, 2.9 ms with none) and reach HBM as 38 GB for 10 GB
+// of keys.  Here a workgroup sorts each tile of 16 384 k-mers by bucket in LDS first (<= 1024 buckets: runs of
+// ~16 keys = 64 B) and then flushes the tile with consecutive lanes writing consecutive words.  The per-tile
+// bucket counts come from the histogram pass (u16 per tile and bucket), the scan turns them into per-tile write
+// offsets: no atomics on global memory, two enumerations of the k-mers in total.
+// ---------------------------------------------------------------------------------------------
+constexpr int K3C_MAXBBITS = 10;
+constexpr int K3C_MAXB = 1 << K3C_MAXBBITS;
+constexpr int K3C_TILE = K1_THREADS * K1_CHUNK;       // k-mers of one pass of a workgroup
+constexpr int K3C_TARGET = 4096;                      // mean k-mers per bucket aimed for (3-4 table rounds)
+constexpr uint32_t K3C_MUL = 0x9E3779B1u;
+static_assert(K3C_TILE <= 65535 + 1, "per-tile bucket counts are stored as u16 (a count of 65536 cannot occur: see k3c_hist)");
+
+__device__ __forceinline__ uint32_t k3c_mix(uint32_t lo) { return lo * K3C_MUL; }
+__device__ __forceinline__ uint32_t k3c_bucket(uint64_t x, uint32_t bb, uint32_t hb) {
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t t = bb ? k3c_mix(lo) >> (32 - bb) : 0u;
+    return t ^ (hi << (bb - hb));
+}
+// the k-mer of stored word lo in bucket b (local index) of a genome with bb bucket bits
+__device__ __forceinline__ uint64_t k3c_kmer(uint32_t lo, uint32_t b, uint32_t bb, uint32_t hb) {
+    const uint32_t t = bb ? k3c_mix(lo) >> (32 - bb) : 0u;
+    const uint32_t hi = hb ? (b ^ t) >> (bb - hb) : 0u;
+    return ((uint64_t)hi << 32) | lo;
+}
+
+struct K3cArgs {
+    KmerArgs km;
+    const uint32_t *g_bbits;   // [n]
+    const uint32_t *g_boff;    // [n+1] first global bucket of genome g
+    const uint64_t *g_koff;    // [n+1] first k-mer slot of genome g
+    const uint32_t *g_blk;     // [n+1] first workgroup (launch-plan block) of genome g
+    uint16_t *tile_cnt;        // [ntiles][K3C_MAXB] k-mers of tile (block * K1_CPT + it) per bucket
+    uint32_t *tile_off;        // [ntiles][K3C_MAXB] write offset of that tile in the bucket, relative to the genome's first slot
+    uint32_t *bucket_cnt;      // [TB]
+    uint64_t *bucket_off;      // [TB+1]
+    uint32_t *keys32;          // [total k-mers]
+    uint32_t hb;               // hi bits = max(0, 2k - 32)
+    uint32_t TB;
+};
+
+__global__ __launch_bounds__(K1_THREADS) void k3c_hist_kernel(K3cArgs a) {
+    __shared__ uint32_t cnt[K3C_MAXB];
+    const int tid = threadIdx.x;
+    const uint32_t g = a.km.blk_genome[blockIdx.x];
+    const uint32_t bb = a.g_bbits[g], B = 1u << bb, hb = a.hb;
+    for (int it = 0; it < K1_CPT; ++it) {
+        for (uint32_t i = tid; i < B; i += K1_THREADS) cnt[i] = 0;
+        __syncthreads();
+        d2g_for_each_kmer_its(a.km, it, it + 1, [&](uint64_t x) { atomicAdd(&cnt[k3c_bucket(x, bb, hb)], 1u); });
+        __syncthreads();
+        // a tile holds at most 16384 k-mers: the counts fit u16
+        uint16_t *dst = a.tile_cnt + ((size_t)blockIdx.x * K1_CPT + it) * K3C_MAXB;
+        for (uint32_t i = tid; i < B; i += K1_THREADS) dst[i] = (uint16_t)cnt[i];
+        __syncthreads();
+    }
+}
+
+// one workgroup per genome: bucket totals over the genome's tiles -> exclusive prefix over buckets -> bucket offsets,
+// then per tile and bucket the offset at which that tile writes
+__global__ __launch_bounds__(K3_THREADS) void k3c_scan_kernel(K3cArgs a) {
+    __shared__ uint32_t wsum[K3_THREADS / 64];
+    constexpr int PER = K3C_MAXB / K3_THREADS;                       // 4 consecutive buckets per thread
+    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    const uint32_t bb = a.g_bbits[g], B = 1u << bb, b0 = a.g_boff[g];
+    const size_t t0 = (size_t)a.g_blk[g] * K1_CPT, t1 = (size_t)a.g_blk[g + 1] * K1_CPT;
+    uint32_t tot[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) tot[j] = 0;
+    for (size_t t = t0; t < t1; ++t) {
+        const uint16_t *c = a.tile_cnt + t * K3C_MAXB + tid * PER;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (tid * PER + j < B) tot[j] += c[j];
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) s += tot[j];
+    uint32_t incl = s;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((tid & 63) >= (uint32_t)o) incl += v; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - s;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) run += wsum[w];
+    uint32_t base[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        base[j] = run;
+        if (tid * PER + j < B) { a.bucket_off[b0 + tid * PER + j] = a.g_koff[g] + run; a.bucket_cnt[b0 + tid * PER + j] = tot[j]; }
+        run += tot[j];
+    }
+    if (g == gridDim.x - 1 && tid == K3_THREADS - 1) a.bucket_off[a.TB] = a.g_koff[g + 1];
+    for (size_t t = t0; t < t1; ++t) {
+        const uint16_t *c = a.tile_cnt + t * K3C_MAXB + tid * PER;
+        uint32_t *o = a.tile_off + t * K3C_MAXB + tid * PER;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) if (tid * PER + j < B) { o[j] = base[j]; base[j] += c[j]; }
+    }
+}
+
+// LDS: the tile's 16384 stored words sorted by bucket, the tile-local first slot of each bucket, and a cursor
+struct K3cScatterLds {
+    uint32_t stage[K3C_TILE];
+    uint32_t lbase[K3C_MAXB + 1];
+    uint32_t lcur[K3C_MAXB];
+    uint32_t wsum[K1_THREADS / 64];
+};
+
+__global__ __launch_bounds__(K1_THREADS) void k3c_scatter_kernel(K3cArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char k3c_lds_raw[];
+    K3cScatterLds &L = *reinterpret_cast<K3cScatterLds *>(k3c_lds_raw);
+    constexpr int PER = K3C_MAXB / K1_THREADS;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t g = a.km.blk_genome[blockIdx.x];
+    const uint32_t bb = a.g_bbits[g], B = 1u << bb, hb = a.hb;
+    uint32_t *out = a.keys32 + a.g_koff[g];
+    for (int it = 0; it < K1_CPT; ++it) {
+        const size_t tile = (size_t)blockIdx.x * K1_CPT + it;
+        // tile-local exclusive prefix of the bucket counts
+        const uint16_t *c = a.tile_cnt + tile * K3C_MAXB + tid * PER;
+        uint32_t cnt[PER], s = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { cnt[j] = (tid * PER + j < B) ? c[j] : 0u; s += cnt[j]; }
+        uint32_t incl = s;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((tid & 63) >= (uint32_t)o) incl += v; }
+        if ((tid & 63) == 63) L.wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t run = incl - s, total = 0;
+        for (uint32_t w = 0; w < K1_THREADS / 64; ++w) { if (w < (tid >> 6)) run += L.wsum[w]; total += L.wsum[w]; }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { L.lbase[tid * PER + j] = run; L.lcur[tid * PER + j] = run; run += cnt[j]; }
+        if (tid == K1_THREADS - 1) L.lbase[K3C_MAXB] = run;
+        __syncthreads();
+        if (total == 0) continue;                                    // uniform: every thread computed the same total
+        d2g_for_each_kmer_its(a.km, it, it + 1, [&](uint64_t x) {
+            L.stage[atomicAdd(&L.lcur[k3c_bucket(x, bb, hb)], 1u)] = (uint32_t)x;
+        });
+        __syncthreads();
+        // flush: runs average 16 words, so a quarter wave (16 lanes) copies one bucket's run at a time -- a wave
+        // store covers four runs of ~64 B; no per-element search for the bucket
+        if (D2G_K3_EXP == 6) { __syncthreads(); continue; }          // timing experiment: no flush
+        const uint32_t *toff = a.tile_off + tile * K3C_MAXB;
+        const uint32_t q = tid >> 4, l16 = tid & 15;                 // 16 quarter-waves per workgroup
+        for (uint32_t b = q; b < B; b += K1_THREADS / 16) {
+            const uint32_t r0 = L.lbase[b], r1 = L.lbase[b + 1];
+            if (r0 == r1) continue;
+            uint32_t *dst = out + toff[b];
+            for (uint32_t i = r0 + l16; i < r1; i += 16) dst[i - r0] = L.stage[i];
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // exact counting of one bucket round into the LDS table
 // ---------------------------------------------------------------------------------------------
+// key type of the main-side code: the 64-bit masked key (generic path) or the 32-bit stored word (compact path)
+template <bool C32> struct K3Key;
+template <> struct K3Key<false> {
+    typedef uint64_t T;
+    static constexpr uint64_t EMPTY = ~0ull;
+    static __device__ __forceinline__ uint32_t slot(uint64_t key) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53); }
+    // R rounds: key bits [shift, shift + log2 R) (the bits below `shift` chose the sub-range)
+    static __device__ __forceinline__ uint32_t round_of(uint64_t key, uint32_t R, uint32_t shift, uint32_t) { return (uint32_t)(key >> shift) & (R - 1); }
+    static __device__ __forceinline__ uint32_t sub_of(uint64_t key, uint32_t R, uint32_t) { return (uint32_t)key & (R - 1); }
+};
+template <> struct K3Key<true> {
+    typedef uint32_t T;
+    static constexpr uint32_t EMPTY = ~0u;
+    static __device__ __forceinline__ uint32_t slot(uint32_t lo) { return (lo * 0x85EBCA6Bu) >> 21; }
+    // bits of m = lo * K3C_MUL from the top: bb bucket bits, then `shift` sub-range bits, then log2 R round bits
+    static __device__ __forceinline__ uint32_t round_of(uint32_t lo, uint32_t R, uint32_t shift, uint32_t bb) {
+        const uint32_t v = (k3c_mix(lo) << bb) << shift;            // bb + shift + log2 R <= 32 (checked on the host)
+        return R > 1 ? v >> (__clz(R) + 1) : 0u;                     // 32 - log2 R = clz(R) + 1
+    }
+    static __device__ __forceinline__ uint32_t sub_of(uint32_t lo, uint32_t R, uint32_t bb) {
+        return R > 1 ? (k3c_mix(lo) << bb) >> (__clz(R) + 1) : 0u;
+    }
+};
+static_assert(K3_TAB == 1 << 11, "the slot hashes take the top 11 bits");
+
+template <bool C32>
 struct CountTab {
-    uint64_t *key;          // [K3_TAB]
-    uint32_t *cnt;          // [K3_TAB]
-    uint32_t *ones;         // count of the key == K3_EMPTY (cannot live in the table)
+    typename K3Key<C32>::T *key;   // [K3_TAB]
+    uint32_t *cnt;                 // [K3_TAB]
+    uint32_t *ones;                // count of the key == EMPTY (cannot live in the table)
 };
 
-__device__ __forceinline__ uint32_t tab_hash(uint64_t key) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53); }
-static_assert(K3_TAB == 1 << 11, "tab_hash takes the top 11 bits");
-
-// keys of round r of R (R a power of two: low key bits select the round); returns false on overflow
-// keys of round r of R (R a power of two: key bits [shift, shift + log2 R) select the round)
-__device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, uint32_t R, uint32_t r, uint32_t shift) {
+// keys of round r of R (R a power of two) of one key range; returns false on overflow
+template <bool C32>
+__device__ bool count_round(const CountTab<C32> &t, const typename K3Key<C32>::T *kb, uint64_t n, uint32_t R, uint32_t r, uint32_t shift,
+                            uint32_t bb) {
+    typedef typename K3Key<C32>::T KT;
+    constexpr KT EMPTY = K3Key<C32>::EMPTY;
     const int tid = threadIdx.x;
-    for (int s = tid; s < K3_TAB; s += K3_THREADS) { t.key[s] = K3_EMPTY; t.cnt[s] = 0; }
+    for (int s = tid; s < K3_TAB; s += K3_THREADS) { t.key[s] = EMPTY; t.cnt[s] = 0; }
     if (tid == 0) *t.ones = 0;
     __syncthreads();
     bool ok = true;
     // keys are fetched K3_KPF per lane at a time BEFORE the probe chains: with the load inside the
     // probing loop every key exposed a full HBM/L2 round trip (measured 25 us per 1220-key bucket)
-    constexpr int K3_KPF = 6;
+    constexpr int K3_KPF = C32 ? 8 : 6;
     for (uint64_t base = 0; base < n && ok; base += (uint64_t)K3_KPF * K3_THREADS) {
-        uint64_t kreg[K3_KPF];
+        KT kreg[K3_KPF];
 #pragma unroll
         for (int j = 0; j < K3_KPF; ++j) {
             const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
@@ -160,19 +355,21 @@ __device__ bool count_round(const CountTab &t, const uint64_t *kb, uint64_t n, u
 #pragma unroll
         for (int j = 0; j < K3_KPF; ++j) {
             const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
-            const uint64_t key = kreg[j];
-            const bool mine = i < n && (R == 1 || ((uint32_t)(key >> shift) & (R - 1)) == r);
-            if (mine && key == K3_EMPTY) atomicAdd(t.ones, 1u);
-            if (!mine || key == K3_EMPTY) continue;
+            const KT key = kreg[j];
+            const bool mine = i < n && (R == 1 || K3Key<C32>::round_of(key, R, shift, bb) == r);
+            if (mine && key == EMPTY) atomicAdd(t.ones, 1u);
+            if (!mine || key == EMPTY) continue;
             // one exit test per probe (structured-control-flow bookkeeping is SALU work: the first
             // version of this loop issued 30 scalar instructions per probe)
-            uint32_t s = tab_hash(key);
+            uint32_t s = K3Key<C32>::slot(key);
             int probes = 0;
             bool placed;
             for (;;) {
-                uint64_t cur = t.key[s];
-                if (cur == K3_EMPTY)
-                    cur = atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)K3_EMPTY, (unsigned long long)key) == K3_EMPTY ? key : t.key[s];
+                KT cur = t.key[s];
+                if (cur == EMPTY) {
+                    if constexpr (C32) cur = atomicCAS(&t.key[s], EMPTY, key) == EMPTY ? key : t.key[s];
+                    else cur = atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)EMPTY, (unsigned long long)key) == EMPTY ? key : t.key[s];
+                }
                 placed = cur == key;
                 if (placed | (++probes >= K3_TAB)) break;
                 s = (s + 1) & (K3_TAB - 1);
@@ -306,10 +503,11 @@ __device__ void bmh_locate(Proc P, uint64_t d, double w, uint32_t m, double boun
 // After count_round: squeeze the occupied slots that pass the count threshold to the front of the
 // table arrays (the all-ones key, which cannot live in the table, is appended), so that the walk
 // below runs over a dense element list with every lane busy.  Returns the number of elements.
-__device__ uint32_t compact_elements(const CountTab &t, uint32_t *nelem, double thr) {
+template <bool C32>
+__device__ uint32_t compact_elements(const CountTab<C32> &t, uint32_t *nelem, double thr) {
     constexpr int PER = K3_TAB / K3_THREADS;
     const int tid = threadIdx.x;
-    uint64_t k[PER];
+    typename K3Key<C32>::T k[PER];
     uint32_t c[PER];
     uint32_t mine = 0;
 #pragma unroll
@@ -330,7 +528,7 @@ __device__ uint32_t compact_elements(const CountTab &t, uint32_t *nelem, double 
 #pragma unroll
     for (int j = 0; j < PER; ++j)
         if (c[j]) { t.key[pos] = k[j]; t.cnt[pos] = c[j]; ++pos; }
-    if (extra) { t.key[pos] = K3_EMPTY; t.cnt[pos] = ones; }
+    if (extra) { t.key[pos] = K3Key<C32>::EMPTY; t.cnt[pos] = ones; }
     __syncthreads();
     return *nelem;
 }
@@ -413,7 +611,11 @@ __device__ double block_sum(double v, double *red) {
 }
 
 struct BmhArgs {
-    const uint64_t *keys;
+    const uint64_t *keys;        // generic path: bucketed 64-bit masked keys
+    const uint32_t *keys32;      // compact path: bucketed 32-bit stored words (k3c_*)
+    const uint32_t *g_bbits;     // compact path: [n] bucket bits of genome g
+    uint32_t hb;                 // compact path: hi bits = max(0, 2k - 32)
+    uint64_t xormask;            // compact path: the masked key Wang(x ^ xormask) is formed per distinct k-mer here
     const uint64_t *bucket_off;
     const uint32_t *g_boff;
     uint32_t n;              // genomes
@@ -436,12 +638,14 @@ struct BmhArgs {
     const uint64_t *g_sub;    // [n+1]
     uint64_t *sub_off;        // [nsub + 1]
     uint64_t *skeys;          // [total k-mers]
+    uint32_t *skeys32;        // compact path
     // optional R11 output (k3_count_kernel): distinct (key,count) written in place of the bucket
     uint64_t *out_keys; uint32_t *out_counts; uint32_t *bucket_nd;
 };
 
+template <bool C32>
 struct SharedK3 {
-    uint64_t key[K3_TAB + 1];      // +1: the all-ones key joins the compacted element list
+    typename K3Key<C32>::T key[K3_TAB + 1 + C32];      // +1: the all-ones key joins the compacted element list (+1: alignment)
     uint32_t cnt[K3_TAB + 2];
     uint64_t red[8];
     uint32_t ones;
@@ -461,7 +665,9 @@ __device__ __forceinline__ uint32_t genome_of_bucket(const uint32_t *g_boff, uin
 // ONCE by its low key bits into 2^s contiguous sub-ranges of ~1000 keys, so that every later round reads
 // only its own keys.  One workgroup per bucket at a time; the bucket (<= a few MB) stays in L2 between
 // the counting and the scattering read.
+template <bool C32>
 __global__ __launch_bounds__(K3_THREADS) void k3_split_kernel(BmhArgs a) {
+    typedef typename K3Key<C32>::T KT;
     __shared__ uint32_t pos[K3_MAXB];
     __shared__ uint32_t wsum[K3_THREADS / 64];
     const uint32_t tid = threadIdx.x;
@@ -471,17 +677,18 @@ __global__ __launch_bounds__(K3_THREADS) void k3_split_kernel(BmhArgs a) {
         if (sb == 0) continue;
         const uint32_t R = 1u << sb;
         const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
-        const uint64_t *kb = a.keys + o0;
+        const KT *kb = (C32 ? (const KT *)a.keys32 : (const KT *)a.keys) + o0;
+        const uint32_t bb = C32 ? a.g_bbits[g] : 0u;
         const uint64_t base = a.g_sub[g] + ((uint64_t)(tb - a.g_boff[g]) << sb);
         for (uint32_t i = tid; i < R; i += K3_THREADS) pos[i] = 0;
         __syncthreads();
         constexpr int PF = 8;
         for (uint64_t b0 = 0; b0 < nk; b0 += (uint64_t)PF * K3_THREADS) {
-            uint64_t kk[PF];
+            KT kk[PF];
 #pragma unroll
             for (int j = 0; j < PF; ++j) { const uint64_t i = b0 + (uint64_t)j * K3_THREADS + tid; kk[j] = i < nk ? kb[i] : 0; }
 #pragma unroll
-            for (int j = 0; j < PF; ++j) if (b0 + (uint64_t)j * K3_THREADS + tid < nk) atomicAdd(&pos[(uint32_t)kk[j] & (R - 1)], 1u);
+            for (int j = 0; j < PF; ++j) if (b0 + (uint64_t)j * K3_THREADS + tid < nk) atomicAdd(&pos[K3Key<C32>::sub_of(kk[j], R, bb)], 1u);
         }
         __syncthreads();
         // exclusive prefix of pos[0..R): each thread owns R / 256 consecutive counters (R <= 4096)
@@ -497,14 +704,14 @@ __global__ __launch_bounds__(K3_THREADS) void k3_split_kernel(BmhArgs a) {
         for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = pos[i]; pos[i] = run; a.sub_off[base + i] = o0 + run; run += c; }
         if (tid == 0) a.sub_off[base + R] = o0 + nk;            // = the next bucket's first entry (same value), or the genome's end
         __syncthreads();
-        uint64_t *dst = a.skeys + o0;
+        KT *dst = (C32 ? (KT *)a.skeys32 : (KT *)a.skeys) + o0;
         for (uint64_t b0 = 0; b0 < nk; b0 += (uint64_t)PF * K3_THREADS) {
-            uint64_t kk[PF];
+            KT kk[PF];
 #pragma unroll
             for (int j = 0; j < PF; ++j) { const uint64_t i = b0 + (uint64_t)j * K3_THREADS + tid; kk[j] = i < nk ? kb[i] : 0; }
 #pragma unroll
             for (int j = 0; j < PF; ++j)
-                if (b0 + (uint64_t)j * K3_THREADS + tid < nk) dst[atomicAdd(&pos[(uint32_t)kk[j] & (R - 1)], 1u)] = kk[j];
+                if (b0 + (uint64_t)j * K3_THREADS + tid < nk) dst[atomicAdd(&pos[K3Key<C32>::sub_of(kk[j], R, bb)], 1u)] = kk[j];
         }
         __syncthreads();
     }
@@ -521,13 +728,15 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_init_kernel(uint64_t *h, si
 // rate W/m -- mean (m/W)(ln m + 0.58), sd 1.28 m/W; 1.25 x (mean + 6 sd) fails about once in 4000 genomes
 __host__ __device__ inline double bmh_guess(double W, double m, double lnm) { return 1.25 * (m / W) * (lnm + 0.58 + 8.0); }
 
+template <bool C32>
 __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
-    __shared__ SharedK3 sh;
+    typedef typename K3Key<C32>::T KT;
+    __shared__ SharedK3<C32> sh;
     __shared__ QEntry queue[K3_QCAP];
     __shared__ uint32_t qn;
     const int tid = threadIdx.x;
     const uint32_t m = a.m;
-    const CountTab t{sh.key, sh.cnt, &sh.ones};
+    const CountTab<C32> t{sh.key, sh.cnt, &sh.ones};
     Proc stk[BMH_STACK];
     if (tid == 0) qn = 0;
     __syncthreads();
@@ -555,6 +764,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
     bool skip_g = a.redo_mode && !a.redo[g];
     double bound = V(a.guess[g]);
     uint32_t sbits = a.g_split ? a.g_split[g] : 0u;
+    uint32_t bb = C32 ? a.g_bbits[g] : 0u, g_b0 = a.g_boff[g];
     uint64_t o_next = a.bucket_off[tb_lo];
     for (uint32_t tb = tb_lo; tb < tb_hi; ++tb) {
         const uint64_t o0 = o_next;
@@ -565,25 +775,33 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
             skip_g = a.redo_mode && !a.redo[g];                          // second passes: only genomes whose guess failed
             bound = V(a.guess[g]);
             sbits = a.g_split ? a.g_split[g] : 0u;
+            bb = C32 ? a.g_bbits[g] : 0u; g_b0 = a.g_boff[g];
         }
         if (nk == 0 || skip_g) continue;
         uint64_t *h = a.h + (size_t)g * m;
         double tw = 0.;
         // one range of keys: as many table rounds as its size asks for; each round's elements go through phase 1
-        auto process = [&](const uint64_t *kb, uint64_t rn, uint32_t shift) -> bool {
+        auto process = [&](const KT *kb, uint64_t rn, uint32_t shift) -> bool {
             uint32_t R = 1;
             while ((uint64_t)R * a.round_keys < rn) R <<= 1;
             for (uint32_t r = 0; r < R; ++r) {
-                if (!count_round(t, kb, rn, R, r, shift)) return false;
-                const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
+                if (!count_round<C32>(t, kb, rn, R, r, shift, bb)) return false;
+                if (D2G_K3_EXP == 4) continue;                       // timing experiment: counting only
+                const uint32_t ne = compact_elements<C32>(t, &sh.nelem, a.thr);
+                if (D2G_K3_EXP == 3) continue;                       // timing experiment: counting + compaction
                 for (uint32_t e = tid; e < ne; e += K3_THREADS) {
-                    const uint64_t d = sh.key[e];
+                    // the element's id is the masked key (maskfn, src/enums.h:136-140): on the compact path it is formed
+                    // here, once per DISTINCT k-mer, from the stored word and the bucket
+                    uint64_t d;
+                    if constexpr (C32) d = wang64(k3c_kmer(sh.key[e], tb - g_b0, bb, a.hb) ^ a.xormask);
+                    else d = sh.key[e];
                     const double w = (double)sh.cnt[e];
                     tw += w;
                     const int nt = top_count(w);
                     for (int tt = 0; tt < nt; ++tt) {
                         Proc P = top_proc(d, tt);
                         if (!proc_next(P, m, bound)) continue;
+                        if (D2G_K3_EXP == 5) continue;               // timing experiment: survivors dropped
                         const uint32_t slot = atomicAdd(&qn, 1u);
                         if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
                         else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
@@ -596,14 +814,14 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
         };
         bool fine;
         if (sbits == 0) {
-            fine = process(a.keys + o0, nk, 0);
+            fine = process((C32 ? (const KT *)a.keys32 : (const KT *)a.keys) + o0, nk, 0);
         } else {                                             // big inputs: the bucket's pre-split sub-ranges, one after the other
             fine = true;
             const uint64_t sub0 = a.g_sub[g] + ((uint64_t)(tb - a.g_boff[g]) << sbits);
             uint64_t lo = a.sub_off[sub0];
             for (uint32_t rg = 0; rg < (1u << sbits) && fine; ++rg) {
                 const uint64_t hi = a.sub_off[sub0 + rg + 1];
-                if (hi > lo) fine = process(a.skeys + lo, hi - lo, sbits);
+                if (hi > lo) fine = process((C32 ? (const KT *)a.skeys32 : (const KT *)a.skeys) + lo, hi - lo, sbits);
                 lo = hi;
             }
         }
@@ -645,31 +863,39 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_verify_kernel(BmhArgs a) {
 }
 
 // R11 alone: distinct (key, count) of every bucket, compacted to the front of the bucket's region
+template <bool C32>
 __global__ __launch_bounds__(K3_THREADS) void k3_count_kernel(BmhArgs a) {
-    __shared__ SharedK3 sh;
+    typedef typename K3Key<C32>::T KT;
+    __shared__ SharedK3<C32> sh;
     const int tid = threadIdx.x;
     const uint32_t tb = blockIdx.x;
     const uint64_t o0 = a.bucket_off[tb], nk = a.bucket_off[tb + 1] - o0;
     if (tid == 0) sh.misc = 0;
     if (nk == 0) { if (tid == 0) a.bucket_nd[tb] = 0; return; }
-    const CountTab t{sh.key, sh.cnt, &sh.ones};
-    const uint32_t g = a.g_split ? genome_of_bucket(a.g_boff, a.n, tb) : 0u;
+    const CountTab<C32> t{sh.key, sh.cnt, &sh.ones};
+    const uint32_t g = (a.g_split || C32) ? genome_of_bucket(a.g_boff, a.n, tb) : 0u;
     const uint32_t sbits = a.g_split ? a.g_split[g] : 0u;
+    const uint32_t bb = C32 ? a.g_bbits[g] : 0u;
     const uint32_t nranges = 1u << sbits;
     const uint64_t sub0 = sbits ? a.g_sub[g] + ((uint64_t)(tb - a.g_boff[g]) << sbits) : 0;
     for (uint32_t rg = 0; rg < nranges; ++rg) {
         const uint64_t lo = sbits ? a.sub_off[sub0 + rg] : o0;
         const uint64_t rn = sbits ? a.sub_off[sub0 + rg + 1] - lo : nk;
         if (rn == 0) continue;
-        const uint64_t *kb = (sbits ? a.skeys : a.keys) + lo;
+        const KT *kb = (C32 ? (const KT *)(sbits ? a.skeys32 : a.keys32) : (const KT *)(sbits ? a.skeys : a.keys)) + lo;
         uint32_t R = 1;
         while ((uint64_t)R * a.round_keys < rn) R <<= 1;
         for (uint32_t r = 0; r < R; ++r) {
-            if (!count_round(t, kb, rn, R, r, sbits)) { if (tid == 0) atomicExch(a.status, 1); return; }
-            const uint32_t ne = compact_elements(t, &sh.nelem, a.thr);
+            if (!count_round<C32>(t, kb, rn, R, r, sbits, bb)) { if (tid == 0) atomicExch(a.status, 1); return; }
+            const uint32_t ne = compact_elements<C32>(t, &sh.nelem, a.thr);
             const uint32_t j0 = sh.misc;
             if (a.out_keys)
-                for (uint32_t e = tid; e < ne; e += K3_THREADS) { a.out_keys[o0 + j0 + e] = sh.key[e]; a.out_counts[o0 + j0 + e] = sh.cnt[e]; }
+                for (uint32_t e = tid; e < ne; e += K3_THREADS) {
+                    uint64_t key;
+                    if constexpr (C32) key = wang64(k3c_kmer(sh.key[e], tb - a.g_boff[g], bb, a.hb) ^ a.xormask);
+                    else key = sh.key[e];
+                    a.out_keys[o0 + j0 + e] = key; a.out_counts[o0 + j0 + e] = sh.cnt[e];
+                }
             __syncthreads();
             if (tid == 0) sh.misc = j0 + ne;
             __syncthreads();
@@ -762,6 +988,9 @@ struct d2g_k3_state {
     uint64_t *d_cursor = nullptr; size_t cap_cursor = 0;
     uint64_t *d_keys = nullptr; size_t cap_keys = 0;
     uint64_t *d_skeys = nullptr; size_t cap_skeys = 0;      // big inputs: keys regrouped by sub-range
+    uint32_t *d_gblk = nullptr; size_t cap_gblk = 0;        // compact path: first launch-plan block of each genome
+    uint16_t *d_tile_cnt = nullptr; size_t cap_tile_cnt = 0;
+    uint32_t *d_tile_off = nullptr; size_t cap_tile_off = 0;
     uint64_t *d_sub_off = nullptr; size_t cap_sub_off = 0;
     uint32_t *d_gsplit = nullptr; size_t cap_gsplit = 0;
     uint64_t *d_gsub = nullptr; size_t cap_gsub = 0;
@@ -782,7 +1011,7 @@ void d2g_k3_state_destroy(d2g_k3_state *st) {
     (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor);
     (void)hipFree(st->d_keys); (void)hipFree(st->d_skeys); (void)hipFree(st->d_sub_off); (void)hipFree(st->d_gsplit); (void)hipFree(st->d_gsub); (void)hipFree(st->d_h); (void)hipFree(st->d_tw);
     (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
-    (void)hipFree(st->d_out_keys);
+    (void)hipFree(st->d_out_keys); (void)hipFree(st->d_gblk); (void)hipFree(st->d_tile_cnt); (void)hipFree(st->d_tile_off);
     delete st;
 }
 
@@ -794,6 +1023,9 @@ struct K3Host {
     std::vector<uint64_t> koff;        // [n+1] exclusive prefix of gk
     std::vector<uint32_t> gsplit;      // [n] log2(sub-ranges per bucket) of big genomes, 0 otherwise
     std::vector<uint64_t> gsub;        // [n+1] first sub-range of genome g
+    std::vector<uint32_t> gblk;        // [n+1] first launch-plan block of genome g (compact path)
+    bool compact = false;              // k <= 21: 4-byte stored words + tile-sorted split (k3c_*)
+    uint32_t hb = 0;                   // compact path: hi bits = max(0, 2k - 32)
     bool any_split = false;
     uint64_t total = 0;
     uint32_t TB = 0;
@@ -802,13 +1034,23 @@ struct K3Host {
 int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_off, size_t n, int k, K3Host &kh) {
     kh.gtab.assign(2 * n + 1, 0);
     kh.gk.assign(n, 0);
+    kh.gblk.assign(n + 1, 0);
+    kh.hb = k > 16 ? (uint32_t)(2 * k - 32) : 0u;
+    kh.compact = kh.hb <= (uint32_t)K3C_MAXBBITS;
+    if (const char *e = std::getenv("D2G_K3_GENERIC")) if (e[0] == '1') kh.compact = false;    // tests: the 64-bit path at small k
     uint64_t tb = 0;
     for (size_t g = 0; g < n; ++g) {
-        uint64_t nk = 0;
-        for (uint64_t r = genome_run_off[g]; r < genome_run_off[g + 1]; ++r) nk += (uint64_t)run_len[r] - k + 1;
+        uint64_t nk = 0, chunks = 0;
+        for (uint64_t r = genome_run_off[g]; r < genome_run_off[g + 1]; ++r) {
+            const uint64_t rk = (uint64_t)run_len[r] - k + 1;
+            nk += rk; chunks += div_up<uint64_t>(rk, K1_CHUNK);
+        }
         D2G_CHECK(ctx, nk < (1ull << 32), "--multiset: more than 2^32 k-mers in one input");
         kh.gk[g] = nk; kh.total += nk;
-        const uint32_t bb = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((nk + K3_TARGET - 1) / K3_TARGET));
+        kh.gblk[g + 1] = kh.gblk[g] + (uint32_t)div_up<uint64_t>(chunks, K1_BLOCK_CHUNKS);
+        uint32_t bb;
+        if (kh.compact) bb = std::max<uint32_t>(kh.hb, std::min<uint32_t>(K3C_MAXBBITS, ceil_log2((nk + K3C_TARGET - 1) / K3C_TARGET)));
+        else bb = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((nk + K3_TARGET - 1) / K3_TARGET));
         kh.gtab[g] = bb;
         kh.gtab[n + g] = (uint32_t)tb;
         tb += 1ull << bb;
@@ -820,7 +1062,10 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     for (size_t g = 0; g < n; ++g) kh.koff[g + 1] = kh.koff[g] + kh.gk[g];
     // big inputs: buckets averaging more than K3_SPLIT_MIN keys are split once more (k3_split_kernel)
     // into sub-ranges of ~K3_TARGET keys; D2G_K3_SPLIT_MIN lowers the limit so that tests reach the path
-    uint64_t split_min = K3_SPLIT_MIN;
+    // (the compact path aims for 4x larger buckets -- 64-byte runs in the tile sort -- and always splits them here into
+    // table-sized sub-ranges: a table round that re-reads its whole key range made the main pass 55 % slower, and a
+    // bucket staged in LDS for the rounds cost more in occupancy than it saved: 42 ms instead of 20)
+    uint64_t split_min = kh.compact ? K3_ROUND_KEYS : K3_SPLIT_MIN;
     if (const char *e = std::getenv("D2G_K3_SPLIT_MIN")) { const long v = std::atol(e); if (v >= 1) split_min = (uint64_t)v; }
     kh.gsplit.assign(n, 0);
     kh.gsub.assign(n + 1, 0);
@@ -830,7 +1075,10 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
             kh.gsplit[g] = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((mean + K3_TARGET - 1) / K3_TARGET));
             kh.any_split = true;
         }
-        kh.gsub[g + 1] = kh.gsub[g] + (kh.gsplit[g] ? (B << kh.gsplit[g]) : 0);
+        // + 1: the end of a genome's last sub-range gets its OWN entry.  Sharing it with the next split genome's first
+        // entry is only right when no unsplit genome lies between the two (their key ranges are then not adjacent and
+        // the two writers race with different values)
+        kh.gsub[g + 1] = kh.gsub[g] + (kh.gsplit[g] ? (B << kh.gsplit[g]) + 1 : 0);
     }
     return D2G_OK;
 }
@@ -843,37 +1091,61 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
     if (int rc = d2g_grow(ctx, &st->d_bucket_cnt, &st->cap_bcnt, (size_t)TB + 1)) return rc;
     if (int rc = d2g_grow(ctx, &st->d_bucket_off, &st->cap_boff, (size_t)TB + 1)) return rc;
     if (int rc = d2g_grow(ctx, &st->d_cursor, &st->cap_cursor, (size_t)TB + 1)) return rc;
-    if (int rc = d2g_grow(ctx, &st->d_keys, &st->cap_keys, std::max<uint64_t>(kh.total, 1))) return rc;
+    // 8 bytes of masked key per k-mer on the generic path, 4 bytes of stored word on the compact one
+    const uint64_t key_words = kh.compact ? (kh.total + 1) / 2 : kh.total;
+    if (int rc = d2g_grow(ctx, &st->d_keys, &st->cap_keys, std::max<uint64_t>(key_words, 1))) return rc;
     if (!st->d_status) D2G_HIP(ctx, hipMalloc((void **)&st->d_status, 2 * sizeof(int)));
     if (int rc = d2g_grow(ctx, &st->d_koff, &st->cap_koff, n + 1)) return rc;
     D2G_HIP(ctx, hipMemcpyAsync(st->d_gtab, kh.gtab.data(), (2 * n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     D2G_HIP(ctx, hipMemcpyAsync(st->d_koff, kh.koff.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
     D2G_HIP(ctx, hipMemsetAsync(st->d_bucket_cnt, 0, ((size_t)TB + 1) * sizeof(uint32_t), s));
     D2G_HIP(ctx, hipMemsetAsync(st->d_status, 0, 2 * sizeof(int), s));
-    K3Args a;
-    a.km = km; a.xormask = xormask;
-    a.g_bbits = st->d_gtab; a.g_boff = st->d_gtab + n; a.g_koff = st->d_koff;
-    a.bucket_cnt = st->d_bucket_cnt; a.bucket_off = st->d_bucket_off; a.cursor = st->d_cursor; a.keys = st->d_keys;
-    a.TB = TB;
     d2g_timer tm(ctx, &ctx->ev_k3, s);
-    if (nblk) hipLaunchKernelGGL(k3_hist_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k3_scan_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, a);
-    if (nblk) hipLaunchKernelGGL(k3_scatter_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
+    if (kh.compact) {
+        // 4-byte stored words, tile-sorted split: histogram per tile -> per-tile write offsets -> coalesced flush
+        D2G_CHECK(ctx, kh.gblk[n] == nblk, "internal: K3 block layout disagrees with the launch plan");
+        const size_t ntiles = nblk * K1_CPT;
+        if (int rc = d2g_grow(ctx, &st->d_gblk, &st->cap_gblk, n + 1)) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_tile_cnt, &st->cap_tile_cnt, std::max<size_t>(ntiles, 1) * K3C_MAXB)) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_tile_off, &st->cap_tile_off, std::max<size_t>(ntiles, 1) * K3C_MAXB)) return rc;
+        D2G_HIP(ctx, hipMemcpyAsync(st->d_gblk, kh.gblk.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        K3cArgs c;
+        c.km = km; c.g_bbits = st->d_gtab; c.g_boff = st->d_gtab + n; c.g_koff = st->d_koff; c.g_blk = st->d_gblk;
+        c.tile_cnt = st->d_tile_cnt; c.tile_off = st->d_tile_off; c.bucket_cnt = st->d_bucket_cnt; c.bucket_off = st->d_bucket_off;
+        c.keys32 = reinterpret_cast<uint32_t *>(st->d_keys); c.hb = kh.hb; c.TB = TB;
+        if (nblk) hipLaunchKernelGGL(k3c_hist_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, c);
+        hipLaunchKernelGGL(k3c_scan_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, c);
+        if (nblk) {
+            D2G_HIP(ctx, hipFuncSetAttribute((const void *)k3c_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K3cScatterLds)));
+            hipLaunchKernelGGL(k3c_scatter_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), sizeof(K3cScatterLds), s, c);
+        }
+    } else {
+        K3Args a;
+        a.km = km; a.xormask = xormask;
+        a.g_bbits = st->d_gtab; a.g_boff = st->d_gtab + n; a.g_koff = st->d_koff;
+        a.bucket_cnt = st->d_bucket_cnt; a.bucket_off = st->d_bucket_off; a.cursor = st->d_cursor; a.keys = st->d_keys;
+        a.TB = TB;
+        if (nblk) hipLaunchKernelGGL(k3_hist_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k3_scan_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, a);
+        if (nblk) hipLaunchKernelGGL(k3_scatter_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
+    }
     BmhArgs b;
     std::memset(&b, 0, sizeof(b));
-    b.keys = st->d_keys; b.bucket_off = st->d_bucket_off; b.g_boff = st->d_gtab + n;
+    b.keys = st->d_keys; b.keys32 = reinterpret_cast<const uint32_t *>(st->d_keys); b.g_bbits = st->d_gtab; b.hb = kh.hb; b.xormask = xormask;
+    b.bucket_off = st->d_bucket_off; b.g_boff = st->d_gtab + n;
     b.n = (uint32_t)n; b.TB = TB; b.m = (uint32_t)m; b.thr = thr; b.status = st->d_status;
     if (kh.any_split) {
         const uint64_t nsub = kh.gsub[n];
-        if (int rc = d2g_grow(ctx, &st->d_skeys, &st->cap_skeys, std::max<uint64_t>(kh.total, 1))) return rc;
+        if (int rc = d2g_grow(ctx, &st->d_skeys, &st->cap_skeys, std::max<uint64_t>(key_words, 1))) return rc;
         if (int rc = d2g_grow(ctx, &st->d_sub_off, &st->cap_sub_off, nsub + 1)) return rc;
         if (int rc = d2g_grow(ctx, &st->d_gsplit, &st->cap_gsplit, n)) return rc;
         if (int rc = d2g_grow(ctx, &st->d_gsub, &st->cap_gsub, n + 1)) return rc;
         D2G_HIP(ctx, hipMemcpyAsync(st->d_gsplit, kh.gsplit.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         D2G_HIP(ctx, hipMemcpyAsync(st->d_gsub, kh.gsub.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
         b.g_split = st->d_gsplit; b.g_sub = st->d_gsub; b.sub_off = st->d_sub_off; b.skeys = st->d_skeys;
+        b.skeys32 = reinterpret_cast<uint32_t *>(st->d_skeys);
         const unsigned gs = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * 8);
-        hipLaunchKernelGGL(k3_split_kernel, dim3(gs), dim3(K3_THREADS), 0, s, b);
+        hipLaunchKernelGGL(kh.compact ? k3_split_kernel<true> : k3_split_kernel<false>, dim3(gs), dim3(K3_THREADS), 0, s, b);
     }
     b.round_keys = K3_ROUND_KEYS;
     if (const char *e = std::getenv("D2G_K3_ROUND_KEYS")) { const int v = std::atoi(e); if (v >= 1 && v <= K3_ROUND_KEYS) b.round_keys = (uint32_t)v; }
@@ -885,7 +1157,7 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         }
         if (int rc = d2g_grow(ctx, &st->d_bucket_nd, &st->cap_nd, (size_t)TB + 1)) return rc;
         b.bucket_nd = st->d_bucket_nd;
-        if (TB) hipLaunchKernelGGL(k3_count_kernel, dim3(TB), dim3(K3_THREADS), 0, s, b);
+        if (TB) hipLaunchKernelGGL(kh.compact ? k3_count_kernel<true> : k3_count_kernel<false>, dim3(TB), dim3(K3_THREADS), 0, s, b);
     } else {
         if (int rc = d2g_grow(ctx, &st->d_h, &st->cap_h, std::max<size_t>(n * m, 1))) return rc;
         if (int rc = d2g_grow(ctx, &st->d_tw, &st->cap_tw, std::max<size_t>(n, 1))) return rc;
@@ -913,13 +1185,14 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         st->last_nredo = 0;
         for (int pass = 0;; ++pass) {
             b.redo_mode = pass > 0;
-            if (TB) hipLaunchKernelGGL(k3_bmh_main_kernel, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+            if (TB && D2G_K3_EXP != 1 && D2G_K3_EXP != 2 && D2G_K3_EXP != 6 && D2G_K3_EXP != 7)
+                hipLaunchKernelGGL(kh.compact ? k3_bmh_main_kernel<true> : k3_bmh_main_kernel<false>, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
             hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, b);
             int st2[2] = {0, 0};                                  // [0] kernel status, [1] genomes whose guess failed
             D2G_HIP(ctx, hipMemcpyAsync(st2, st->d_status, sizeof(st2), hipMemcpyDeviceToHost, s));
             D2G_HIP(ctx, hipStreamSynchronize(s));
             const int nredo = st2[1];
-            if (st2[0] || !nredo) break;
+            if (st2[0] || !nredo || D2G_K3_EXP) break;
             st->last_nredo += nredo;
             D2G_CHECK(ctx, pass < 40, "internal: BagMinHash bound did not converge");
             D2G_HIP(ctx, hipMemsetAsync(st->d_status + 1, 0, sizeof(int), s));

@@ -43,8 +43,9 @@ __device__ __forceinline__ uint32_t fsr(uint32_t hi, uint32_t lo, uint32_t sh) {
 
 // f(x) once per k-mer of the chunks this lane owns in workgroup blockIdx.x; x = canonical
 // (min(fwd, revcomp)) or forward 2-bit k-mer.  A lane owns chunk (it * K1_THREADS + tid).
+// IT0 <= it < IT1: the passes ("tiles" of K1_THREADS chunks = K1_THREADS * K1_CHUNK k-mers) of the workgroup to walk
 template <class F>
-__device__ __forceinline__ void d2g_for_each_kmer(const KmerArgs &a, F &&f) {
+__device__ __forceinline__ void d2g_for_each_kmer_its(const KmerArgs &a, int it0, int it1, F &&f) {
     const int tid = threadIdx.x;
     const uint32_t b = blockIdx.x;
     const uint64_t c0 = a.blk_chunk0[b];
@@ -55,7 +56,7 @@ __device__ __forceinline__ void d2g_for_each_kmer(const KmerArgs &a, F &&f) {
     const int rcshift = 2 * (k - 1);
     const bool canon = a.canon != 0;
 
-    for (int it = 0; it < K1_CPT; ++it) {
+    for (int it = it0; it < it1; ++it) {
         const uint32_t ci_blk = it * K1_THREADS + tid;
         if (ci_blk >= nc) break;
         const uint64_t c = c0 + ci_blk;
@@ -108,4 +109,9 @@ __device__ __forceinline__ void d2g_for_each_kmer(const KmerArgs &a, F &&f) {
             }
         }
     }
+}
+
+template <class F>
+__device__ __forceinline__ void d2g_for_each_kmer(const KmerArgs &a, F &&f) {
+    d2g_for_each_kmer_its(a, 0, K1_CPT, static_cast<F &&>(f));
 }

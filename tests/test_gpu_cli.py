@@ -169,15 +169,15 @@ def test_cli_cache_and_panel(oracle, genomes, tmp_path):
 
 
 def test_dist_tool_single_rank(oracle, genomes, tmp_path):
-    """python -m dashing2_amd.dist (the multi-GPU file tool) in its 1-rank form == dashing2 cmp --binary-output"""
+    """python -m dashing2_amd.dist cmp (launches the C++ CLI over every visible GPU: one here) == dashing2 cmp"""
     import sys
     k, S = 31, 256
     st = tmp_path / "s.bin"
     _run(["sketch", "-k", str(k), "-S", str(S), "-o", str(st)] + genomes)
     b1, b2 = tmp_path / "cli.bin", tmp_path / "dist.bin"
     _run(["cmp", "--presketched", "-k", str(k), "--binary-output", "--distance", "--cmpout", str(b1), str(st)])
-    r = subprocess.run([sys.executable, "-m", "dashing2_amd.dist", "--presketched", str(st), "--cmpout", str(b2), "-k", str(k), "--distance"],
-                       capture_output=True, text=True, cwd=ROOT)
+    r = subprocess.run([sys.executable, "-m", "dashing2_amd.dist", "cmp", "--presketched", "-k", str(k), "--binary-output", "--distance",
+                        "--cmpout", str(b2), str(st)], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(b1, "rb").read() == open(b2, "rb").read()
 

@@ -42,10 +42,10 @@ def main():
     rng = np.random.default_rng(seed)
     ctx = D.Context(0)
     t0 = time.time()
-    n = {"k1": 0, "k2": 0, "k3": 0, "byseq": 0}
+    n = {"k1": 0, "k2": 0, "k3": 0, "byseq": 0, "wsets": 0, "mgpu": 0}
     fails = 0
     while time.time() - t0 < budget:
-        which = rng.choice(["k1", "k2", "k3", "byseq"])
+        which = rng.choice(["k1", "k2", "k3", "k3", "byseq", "wsets", "mgpu"])
         try:
             if which == "k1":
                 k = int(rng.integers(1, 33)); S = int(rng.choice([8, 63, 64, 100, 1000, 1024, 4096])); canon = bool(rng.integers(0, 2))
@@ -76,7 +76,16 @@ def main():
             elif which == "k3":
                 k = int(rng.integers(3, 33)); S = int(rng.choice([16, 100, 256, 2048])); canon = bool(rng.integers(0, 2))
                 thr = float(rng.choice([0, 0, 1, 3]))
-                fa = [rand_fasta(rng, int(rng.choice([300, 5000, 80000]))) for _ in range(int(rng.integers(1, 5)))]
+                # library test hooks: small table rounds / split thresholds push small inputs through the big-input paths;
+                # D2G_K3_GENERIC selects the 64-bit key path where the compact (4-byte) one would apply
+                for var, choices in (("D2G_K3_ROUND_KEYS", [None, None, "40", "300"]), ("D2G_K3_SPLIT_MIN", [None, None, "20", "400"]),
+                                     ("D2G_K3_GENERIC", [None, None, "1"]), ("D2G_K3_GUESS_SCALE", [None, None, None, "0.02"])):
+                    v = choices[int(rng.integers(0, len(choices)))]
+                    if v is None:
+                        os.environ.pop(var, None)
+                    else:
+                        os.environ[var] = v
+                fa = [rand_fasta(rng, int(rng.choice([300, 5000, 80000, 400000]))) for _ in range(int(rng.integers(1, 6)))]
                 sp = D.SeqPack(k)
                 for f in fa:
                     sp.add_fastx(f)
@@ -88,6 +97,50 @@ def main():
                     keep = ec.astype(np.float64) > thr
                     assert tw[i] == et and np.array_equal(sig[i].view(np.uint64), es.view(np.uint64))
                     assert np.array_equal(kc[i][0], ek[keep]) and np.array_equal(kc[i][1], ec[keep])
+            elif which == "wsets":
+                S = int(rng.choice([8, 64, 200])); nsets = int(rng.integers(1, 6))
+                sizes = [int(rng.choice([0, 1, 50, 3000])) for _ in range(nsets)]
+                off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint64)
+                ids = rng.integers(0, 1 << 60, int(off[-1]), dtype=np.uint64)
+                w = None if rng.random() < 0.3 else np.where(rng.random(ids.size) < 0.1, 0.0, np.round(rng.gamma(1.5, 6.0, ids.size) * rng.choice([1, 1000])) / 4)
+                sig, tw, own = ctx.bmh_from_weighted_ids(ids, w, off, S)
+                for i in range(nsets):
+                    lo, hi = int(off[i]), int(off[i + 1])
+                    es, et, eo = O.bmh_from_weighted_ids(ids[lo:hi], None if w is None else w[lo:hi], S)
+                    assert tw[i] == et and np.array_equal(sig[i].view(np.uint64), es.view(np.uint64)) and np.array_equal(own[i], eo)
+            elif which == "mgpu":
+                W = int(rng.integers(1, 7)); N = int(rng.integers(2, 400)); S = int(rng.choice([32, 100, 256, 1000, 1024]))
+                regs = synth.synthetic_registers(N, S, nclusters=int(rng.integers(1, 9)), seed=int(rng.integers(0, 1 << 30)))
+                exp = O.eqcounts_ut(regs.view(np.float64))
+                ctxs = [D.Context(0) for _ in range(W)]
+                comms = D.Comm.create_all(ctxs)
+                engs = [D.AllPairs(ctxs[r], comms[r], N, S) for r in range(W)]
+                rows, outs = [], []
+                for r in range(W):
+                    lo, hi = engs[r].rows_held
+                    p = ctxs[r].malloc(max((hi - lo) * S * 8, 8))
+                    if hi > lo:
+                        ctxs[r].h2d(p, np.ascontiguousarray(regs[lo:hi]))
+                    rows.append(p)
+                    outs.append(ctxs[r].malloc(max(D.ut_count(N, *engs[r].rows_computed), 1) * 4))
+                D.allpairs_step_all(engs, rows, None, outs)
+                offp = np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
+                ok = True
+                for r in range(W):
+                    r0, r1 = engs[r].rows_computed
+                    got = np.empty(D.ut_count(N, r0, r1), np.uint32)
+                    ctxs[r].sync()
+                    if got.size:
+                        ctxs[r].d2h(got, outs[r])
+                    ok &= np.array_equal(got, exp[offp[r0]:offp[r1]])
+                    ctxs[r].free(rows[r]); ctxs[r].free(outs[r])
+                for e in engs:
+                    e.close()
+                for c in comms:
+                    c.close()
+                for c in ctxs:
+                    c.close()
+                assert ok
             else:
                 k = int(rng.integers(3, 33)); S = int(rng.choice([16, 64, 256]))
                 f = b"".join(rand_fasta(rng, 2000) for _ in range(int(rng.integers(1, 8))))
