@@ -675,7 +675,9 @@ def main():
                                                f"D2H of the registers (d2g_sketcher_run) in {idt:.3f}s; host-bound"},
                  "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": ach / HBM_PEAK_GBS,
-                              "traffic": (pe["hbm_read_bytes_x2_wide_load_correction"] + pe["hbm_write_bytes"]) if pe else None,
+                              "traffic": (2 * pe["largest_dispatch_hbm_read_bytes_raw"] + pe["largest_dispatch_hbm_write_bytes"]) if pe and "largest_dispatch_hbm_write_bytes" in pe else None,
+                              "traffic_note": "rocprofv3 --pmc FETCH_SIZE (x2: 16-byte coalesced loads are tallied at half their bytes on gfx950) + WRITE_SIZE of the "
+                                              "1000-genome launch, profiles/r02_pmc.json",
                               "kernel": "k1_oph_kernel",
                               "kernel_ms": k1_ms, "algorithmic_bytes": k1_bytes,
                               "note": "VALU-bound by the two mandated 64-bit Wang mixes per k-mer (~125 issue slots per base), not by HBM"}}
@@ -724,7 +726,7 @@ def main():
         if world == 1 and nb == 250 and L == 5_000_000:
             try:
                 d = json.load(open(PMC_FILE))
-                tr = [v["hbm_read_bytes_raw"] + v["hbm_write_bytes"] for kk, v in d.items() if kk.startswith("k3_") and "hbm_write_bytes" in v]
+                tr = [v["hbm_read_bytes_raw"] + v["hbm_write_bytes"] for kk, v in d.items() if ("k3_" in kk or "k3c_" in kk) and "hbm_write_bytes" in v]
                 traffic = float(sum(tr)) if tr else None
             except (OSError, ValueError, KeyError):
                 traffic = None
@@ -737,7 +739,7 @@ def main():
                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                 "traffic": traffic,
                                 "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE per call, same shape, profiles/r02_pmc.json",
-                                "kernel": "k3 chain (hist, scan, scatter, bmh_main, verify)",
+                                "kernel": "k3 chain (hist, scan, tile-sorted scatter, split, bmh_main, verify)",
                                 "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
                                 "note": "per call of %d genomes; the chain also writes and re-reads the bucketed k-mer keys, "
                                         "which the compulsory-byte figure does not count" % nb},

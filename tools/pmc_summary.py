@@ -16,13 +16,13 @@ import sys
 def main():
     d, out = sys.argv[1], sys.argv[2]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
+    for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {}
     for k, cs in agg.items():
         short = k.split("(")[0].split("::")[-1].split("<")[0].strip()
-        if not any(x in k for x in ("k1_oph", "k2_", "bs_rank", "bs_planes", "k3_")):
+        if not any(x in k for x in ("k1_oph", "k2_", "bs_rank", "bs_planes", "bs_derive", "k3_", "k3c_", "mg_pack")):
             continue
         e = {c: sum(v) / len(v) for c, v in cs.items()}
         e["dispatches"] = max(len(v) for v in cs.values())
@@ -30,9 +30,13 @@ def main():
             e["hbm_read_bytes_raw"] = e["FETCH_SIZE"] * 1024
             e["hbm_read_bytes_x2_wide_load_correction"] = e["FETCH_SIZE"] * 2048
             e["hbm_write_bytes"] = e["WRITE_SIZE"] * 1024
+            # the LARGEST dispatch (a kernel launched at several sizes in one run, e.g. K1: the 1000-genome launch next to the
+            # small launches of the ingest measurement)
+            e["largest_dispatch_hbm_read_bytes_raw"] = max(cs["FETCH_SIZE"]) * 1024
+            e["largest_dispatch_hbm_write_bytes"] = max(cs["WRITE_SIZE"]) * 1024
         if "TCC_HIT_sum" in e:
             e["l2_hit_rate"] = e["TCC_HIT_sum"] / max(e["TCC_HIT_sum"] + e["TCC_MISS_sum"], 1)
-        res[short + " :: " + k[:120]] = e
+        res[(short or k.split("(anonymous namespace)::")[-1].split("(")[0].split("<")[0]) + " :: " + k[:120]] = e
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, e in res.items():
         print(k[:60], {x: (round(y, 3) if isinstance(y, float) else y) for x, y in e.items() if "bytes" in x or "rate" in x or "VALU" in x})
