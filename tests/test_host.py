@@ -251,6 +251,15 @@ def test_cli_float_formatter_vs_fmt_golden():
     assert "0 bad" in out.stdout
 
 
+def test_host_code_under_sanitizers():
+    """ASan + UBSan builds of the x86 host half (seqpack ingest, x87 finalisation, densify, epilogues, partition: csrc
+    `make sanitize`) and of the CLI's float formatter (host `make sanitize`) run clean (reference Makefile:102-103)"""
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "dashing2_amd", "csrc"), "sanitize"], capture_output=True, text=True)
+    assert r.returncode == 0 and "host selftest OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "dashing2_amd", "host"), "sanitize"], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def _cli():
     exe = os.path.join(ROOT, "dashing2_amd", "bin", "dashing2")
     if not os.path.exists(exe):
