@@ -21,7 +21,8 @@ def main():
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {}
     for k, cs in agg.items():
-        short = k.split("(")[0].split("::")[-1].split("<")[0].strip()
+        import re
+        short = re.split(r"[(<]", re.sub(r"^void\s+", "", k).replace("(anonymous namespace)::", ""), 1)[0].strip()
         if not any(x in k for x in ("k1_oph", "k2_", "bs_rank", "bs_planes", "bs_derive", "k3_", "k3c_", "mg_pack")):
             continue
         e = {c: sum(v) / len(v) for c, v in cs.items()}
@@ -36,7 +37,7 @@ def main():
             e["largest_dispatch_hbm_write_bytes"] = max(cs["WRITE_SIZE"]) * 1024
         if "TCC_HIT_sum" in e:
             e["l2_hit_rate"] = e["TCC_HIT_sum"] / max(e["TCC_HIT_sum"] + e["TCC_MISS_sum"], 1)
-        res[(short or k.split("(anonymous namespace)::")[-1].split("(")[0].split("<")[0]) + " :: " + k[:120]] = e
+        res[short + " :: " + k[:120]] = e
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k, e in res.items():
         print(k[:60], {x: (round(y, 3) if isinstance(y, float) else y) for x, y in e.items() if "bytes" in x or "rate" in x or "VALU" in x})
