@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--sketches", type=int, default=10000)
     ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 1))
     ap.add_argument("--workdir", default="/tmp/d2e2e")
+    ap.add_argument("--big-sketches", type=int, default=0, help="also run cmp on this many presketched sketches (config 4: 50000 -> 5 GB of output)")
+    ap.add_argument("--no-sketch", action="store_true")
     a = ap.parse_args()
     import dashing2_amd as D
     from dashing2_amd import synth
@@ -49,13 +51,13 @@ def main():
     open(lst, "w").write("\n".join(paths) + "\n")
     print(f"generated {a.genomes} x {a.len} bp FASTA in {time.perf_counter() - t0:.1f}s")
     out = os.path.join(a.workdir, "stack.bin")
-    for rep in range(2):
+    bases = a.genomes * a.len
+    for rep in range(0 if a.no_sketch else 2):
         dt, info = run(["sketch", "-v", "-k", "31", "-S", "1024", "-p", str(a.threads), "-F", lst, "-o", out])
-        bases = a.genomes * a.len
         print(f"sketch run {rep}: {dt:.2f}s wall -> {bases / dt:.3e} bases/s end-to-end (FASTA on disk -> stacked sketches)")
         for l in info:
             print("   ", l)
-    for rep in range(2):
+    for rep in range(0 if a.no_sketch else 2):
         dt, info = run(["sketch", "--multiset", "-v", "-k", "21", "-S", "2048", "-p", str(a.threads), "-F", lst, "-o", out + ".bmh"])
         print(f"sketch --multiset run {rep}: {dt:.2f}s wall -> {bases / dt:.3e} bases/s end-to-end (FASTA on disk -> stacked BagMinHash sketches)")
         for l in info:
@@ -77,6 +79,28 @@ def main():
         print(f"cmp {name}: {dt:.2f}s wall -> {pairs / dt:.3e} pairs/s end-to-end ({os.path.getsize(o) / 1e6:.0f} MB out)")
         for l in info:
             print("   ", l)
+
+    if a.big_sketches:
+        N = a.big_sketches
+        regs = synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260929)
+        sigs, cards = D.oph_finalize(regs, S, nthreads=os.cpu_count() or 1)
+        st = os.path.join(a.workdir, "syn_big.bin")
+        with open(st, "wb") as f:
+            np.array([N, S], np.uint64).tofile(f)
+            cards.tofile(f)
+            sigs.tofile(f)
+        del regs, sigs
+        pairs = N * (N - 1) // 2
+        for name, flags, env in [("binary", ["--binary-output"], {}), ("binary, all GPUs (D2G_DEVICES=all)", ["--binary-output"], {"D2G_DEVICES": "all"})]:
+            o = os.path.join(a.workdir, "dist_big.out")
+            os.environ.update(env)
+            dt, info = run(["cmp", "-v", "--presketched", "-k", "31", "-p", str(a.threads), "--cmpout", o] + flags + [st])
+            for kk in env:
+                os.environ.pop(kk, None)
+            print(f"cmp {N} sketches {name}: {dt:.2f}s wall -> {pairs / dt:.3e} pairs/s end-to-end ({os.path.getsize(o) / 1e6:.0f} MB out)")
+            for l in info:
+                print("   ", l)
+            os.remove(o)
 
 
 if __name__ == "__main__":
