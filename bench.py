@@ -371,22 +371,37 @@ def main():
                     err = "failed on another rank"
             return err
 
+        # every collective below is entered by ALL ranks or by none: a rank that fails alone must not leave the others
+        # blocked inside an RCCL call, so each local stage is followed by a flag all-reduce before the next collective
         err = None
-        try:
-            uid = [D.comm_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(uid, src=0)
-            comm = D.Comm.create(ctx, rank, world, uid[0])
-            import ctypes
-            ctypes.CDLL(None).fflush(None)       # RCCL prints a version banner through C stdio: out now, not after the JSON line
-            eng = D.AllPairs(ctx, comm, N, S)
-            assert eng.rows_computed == (r0, r1)
-            lo, hi = eng.rows_held
-            my_rows = sig_dev[lo:hi].clone()
-            eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
-            torch.cuda.synchronize()
-        except Exception as e:                                   # noqa: BLE001 - reported in the JSON line
-            err = f"C-ABI engine: {type(e).__name__}: {e}"
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [D.comm_unique_id()]
+            except Exception as e:                               # noqa: BLE001
+                err = f"C-ABI engine: {type(e).__name__}: {e}"
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        if uid[0] is None and err is None:
+            err = "C-ABI engine: no RCCL unique id from rank 0"
+        if err is None:
+            try:
+                comm = D.Comm.create(ctx, rank, world, uid[0])   # ncclCommInitRank: collective, all ranks got the id
+                import ctypes
+                ctypes.CDLL(None).fflush(None)   # RCCL prints a version banner through C stdio: out now, not after the JSON line
+                eng = D.AllPairs(ctx, comm, N, S)
+                assert eng.rows_computed == (r0, r1)
+                lo, hi = eng.rows_held
+                my_rows = sig_dev[lo:hi].clone()
+            except Exception as e:                               # noqa: BLE001 - reported in the JSON line
+                err = f"C-ABI engine: {type(e).__name__}: {e}"
+        err = all_failed(err)
+        if err is None:
+            try:
+                eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
+                torch.cuda.synchronize()
+            except Exception as e:                               # noqa: BLE001
+                err = f"C-ABI engine: {type(e).__name__}: {e}"
         err = all_failed(err)
         if err is None:
             engine_kind = "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv groups)"

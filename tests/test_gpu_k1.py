@@ -101,6 +101,38 @@ def test_k1_full_size_cardinality(gpu_ctx, d2g):
     assert ((regs[0] & np.uint64(S - 1)) == np.arange(S, dtype=np.uint64)).all()   # id mod m == bucket
 
 
+def test_k1_config2_shaped_launch_vs_oracle(gpu_ctx, d2g, oracle):
+    """BASELINE config 2's launch shape -- MANY multi-megabase genomes in ONE launch (config 2: 1000 x 5 Mbp; here 160 x
+    1-5 Mbp = 0.45 Gbp, ~7000 workgroups, k = 31, S = 1024), ingested through d2g_seqpack: a sample of genomes (first,
+    last, the 5 Mbp ones, some in between) is compared register for register with the ORACLE, every genome with its own
+    single-genome launch result computed from the same pack order, and the x87 finalisation with the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    k, S, n = 31, 1024, 160
+    lens = [5_000_000 if i % 40 == 0 else 1_000_000 + 25_000 * (i % 37) for i in range(n)]
+    with ThreadPoolExecutor(16) as ex:
+        fastas = list(ex.map(lambda i: synth.fasta_bytes_fast("g%03d" % i, synth.random_genome(4000 + i, lens[i])), range(n)))
+    sp = d2g.SeqPack(k)
+    for f in fastas:
+        sp.add_fastx(f)
+    assert sp.ngenomes == n and sp.nbases == sum(lens)
+    regs = gpu_ctx.oph_sketch_seqpack(sp, S)
+    sigs, cards = d2g.oph_finalize(regs, S, nthreads=8)
+    sample = sorted({0, 1, 39, 40, 41, 79, 80, 120, 121, 158, 159})
+    with ThreadPoolExecutor(len(sample)) as ex:
+        exp = list(ex.map(lambda i: oracle.sketch_buffer(fastas[i], k=k, S=S), sample))
+    for i, (eregs, esig, ecard, enk) in zip(sample, exp):
+        assert enk == lens[i] - k + 1
+        np.testing.assert_array_equal(regs[i], eregs, err_msg=f"genome {i}")
+        np.testing.assert_array_equal(sigs[i].view(np.uint64), esig.view(np.uint64), err_msg=f"genome {i}")
+        assert cards[i] == ecard
+    # every genome: no empty bucket, id mod m == bucket, distinct sketches, cardinality near its k-mer count
+    assert (regs != np.uint64(2 ** 64 - 1)).all()
+    assert ((regs & np.uint64(S - 1)) == np.arange(S, dtype=np.uint64)[None, :]).all()
+    assert len({r.tobytes() for r in regs}) == n
+    nk = np.array(lens, np.float64) - k + 1
+    assert (np.abs(cards - nk) / nk < 5 / np.sqrt(S)).all()
+
+
 def test_k1_rejects_bad_input(gpu_ctx, d2g):
     sp = d2g.SeqPack(31)
     sp.add_sequence(synth.random_genome(1, 1000).tobytes())
