@@ -134,7 +134,7 @@ __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// COMPACT path (k <= 21): the multi-split stores 4 bytes per k-mer and writes them coalesced.
+// COMPACT path (k <= 21, D2G_K3_COMPACT=1): the multi-split stores 4 bytes per k-mer and writes them coalesced.
 //
 // Counting only needs a key that identifies the k-mer, so the split works on the 2k-bit k-mer x itself (the
 // masked key Wang(x ^ XORMASK) is a bijection of it and is computed once per DISTINCT k-mer in the main pass).
@@ -731,8 +731,11 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_init_kernel(uint64_t *h, si
 // rate W/m -- mean (m/W)(ln m + 0.58), sd 1.28 m/W; 1.25 x (mean + 6 sd) fails about once in 4000 genomes
 __host__ __device__ inline double bmh_guess(double W, double m, double lnm) { return 1.25 * (m / W) * (lnm + 0.58 + 8.0); }
 
+#ifndef D2G_K3_WPE
+#define D2G_K3_WPE 5
+#endif
 template <bool C32>
-__global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
+__global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_K3_WPE))) void k3_bmh_main_kernel(BmhArgs a) {
     typedef typename K3Key<C32>::T KT;
     __shared__ SharedK3<C32> sh;
     __shared__ QEntry queue[K3_QCAP];
@@ -790,15 +793,17 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
             for (uint32_t r = 0; r < R; ++r) {
                 if (!count_round<C32>(t, kb, rn, R, r, shift, bb)) return false;
                 if (D2G_K3_EXP == 4 || D2G_K3_EXP == 8) continue;   // timing experiment: counting only
-                const uint32_t ne = compact_elements<C32>(t, &sh.nelem, a.thr);
-                if (D2G_K3_EXP == 3) continue;                       // timing experiment: counting + compaction
-                for (uint32_t e = tid; e < ne; e += K3_THREADS) {
+                // Walk the table slots directly.  (r01 squeezed the occupied slots into a dense list first -- worth it when the
+                // per-element walk was heavy; since the strip structure made the first-point test ~40 instructions, the
+                // compaction, 3.5 ms per call with its three barriers per round, costs more than the 40 % idle lanes here.)
+                if (D2G_K3_EXP == 3) continue;                       // timing experiment: counting only (+ nothing)
+                auto element = [&](KT key, uint32_t cc) {
                     // the element's id is the masked key (maskfn, src/enums.h:136-140): on the compact path it is formed
                     // here, once per DISTINCT k-mer, from the stored word and the bucket
                     uint64_t d;
-                    if constexpr (C32) d = wang64(k3c_kmer(sh.key[e], tb - g_b0, bb, a.hb) ^ a.xormask);
-                    else d = sh.key[e];
-                    const double w = (double)sh.cnt[e];
+                    if constexpr (C32) d = wang64(k3c_kmer(key, tb - g_b0, bb, a.hb) ^ a.xormask);
+                    else d = key;
+                    const double w = (double)cc;
                     tw += w;
                     const int nt = top_count(w);
                     for (int tt = 0; tt < nt; ++tt) {
@@ -809,7 +814,12 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_main_kernel(BmhArgs a) {
                         if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
                         else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
                     }
+                };
+                for (uint32_t e = tid; e < (uint32_t)K3_TAB; e += K3_THREADS) {
+                    const uint32_t cc = sh.cnt[e];
+                    if (cc && (double)cc > a.thr) element(sh.key[e], cc);          // counter.h:123: pair.second > threshold
                 }
+                if (tid == 0) { const uint32_t ones = sh.ones; if (ones && (double)ones > a.thr) element(K3Key<C32>::EMPTY, ones); }
                 __syncthreads();
                 if (qn >= (uint32_t)K3_QDRAIN) drain();
             }
@@ -1039,8 +1049,10 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     kh.gk.assign(n, 0);
     kh.gblk.assign(n + 1, 0);
     kh.hb = k > 16 ? (uint32_t)(2 * k - 32) : 0u;
-    kh.compact = kh.hb <= (uint32_t)K3C_MAXBBITS;
-    if (const char *e = std::getenv("D2G_K3_GENERIC")) if (e[0] == '1') kh.compact = false;    // tests: the 64-bit path at small k
+    // the compact path (4-byte stored words, tile-sorted split) halves the chain's HBM traffic but is ~11 % slower end to
+    // end (one Wang mix per distinct k-mer moves into the issue-bound main pass): opt-in with D2G_K3_COMPACT=1, k <= 21
+    kh.compact = false;
+    if (const char *e = std::getenv("D2G_K3_COMPACT")) if (e[0] == '1') kh.compact = kh.hb <= (uint32_t)K3C_MAXBBITS;
     uint64_t tb = 0;
     for (size_t g = 0; g < n; ++g) {
         uint64_t nk = 0, chunks = 0;

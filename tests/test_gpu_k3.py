@@ -144,14 +144,14 @@ def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
         "sig, tw = ctx.bmh_sketch_seqpack(sp, 128); kc = ctx.kmer_count_seqpack(sp)\n"
         "print(json.dumps([sig.view(np.uint64).tolist(), tw.tolist(), kc[0][0].tolist(), kc[0][1].tolist()]))\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(fa))
-    # k = 17 takes the compact path (4-byte stored words, tile-sorted split) by default; D2G_K3_GENERIC=1 selects the
-    # 64-bit-key path that k >= 22 uses, so both are exercised with every hook
+    # D2G_K3_COMPACT=1 selects the low-traffic path (4-byte stored words, tile-sorted split; k <= 21) instead of the default
+    # 64-bit-key path, so both are exercised with every hook
     for env in ({"D2G_K3_ROUND_KEYS": "64"}, {"D2G_K3_GUESS_SCALE": "0.001"}, {"D2G_K3_ROUND_KEYS": "100", "D2G_K3_GUESS_SCALE": "0.01"},
                 {"D2G_K3_SPLIT_MIN": "100"},                                   # big-input path: buckets pre-split by low key bits
                 {"D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},        # ... and sub-ranges that still need rounds
-                {"D2G_K3_GENERIC": "1"}, {"D2G_K3_GENERIC": "1", "D2G_K3_ROUND_KEYS": "64"},
-                {"D2G_K3_GENERIC": "1", "D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},
-                {"D2G_K3_SPLIT_MIN": "100000"}):                               # compact path without the sub-range split: table rounds
+                {"D2G_K3_COMPACT": "1"}, {"D2G_K3_COMPACT": "1", "D2G_K3_ROUND_KEYS": "64"}, {"D2G_K3_COMPACT": "1", "D2G_K3_GUESS_SCALE": "0.001"},
+                {"D2G_K3_COMPACT": "1", "D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},
+                {"D2G_K3_COMPACT": "1", "D2G_K3_SPLIT_MIN": "100000"}):        # compact path without the sub-range split: table rounds
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, env={**os.environ, **env}, timeout=300)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         sig, tw, keys, counts = json.loads(r.stdout.decode().strip().splitlines()[-1])
