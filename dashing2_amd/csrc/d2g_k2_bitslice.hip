@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
 template <bool MULTI>   // MULTI: more than one partition (N > 21845)
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
                                                                   uint32_t T, int logT, uint32_t *ids_all, uint32_t *max_distinct,
-                                                                  uint32_t *status) {
+                                                                  uint32_t *status, int tagbits_max) {
     extern __shared__ __attribute__((aligned(16))) uint32_t own[];        // Tl owner slots
     const size_t t = blockIdx.x;
     const uint64_t *col = cols + t * Npad;
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
     const uint32_t Tl = 1u << logTl, mask = Tl - 1, nparts = MULTI ? (T >> logTl) : 1u;
     __shared__ uint32_t wave_tot[BS_RANK_THREADS / 64];
     __shared__ uint32_t running;
-    if (tid == 0) running = 1;                                           // id 0 is reserved for singletons
+    constexpr uint32_t BS_MAXFIX = 64;
+    __shared__ uint32_t nfix, fix_j[BS_MAXFIX], fix_h[BS_MAXFIX];
+    if (tid == 0) { running = 1; nfix = 0; }                             // id 0 is reserved for singletons
     const int lane = tid & 63, wave = tid >> 6;
 
     // the compaction of one table pass: slots whose value occurs >= 2 times get the next dense ranks,
@@ -97,14 +99,26 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         if (tid == 0) running += tot;
         __syncthreads();
     };
+    // Owner slot = [DUP:1][tag][owner sketch index:ib].  The tag (hash bits below the slot bits) lets a probe step
+    // over a slot that holds a DIFFERENT value without fetching the owner's value from the column: only a
+    // tag match -- practically always a true repeat -- pays the global load that decides equality exactly.
+    // The all-ones index is never a sketch index (2^ib > N), so EMPTY cannot be mistaken for an owner.
+    const int ib = 32 - __clz((uint32_t)N);
+    const uint32_t idxmask = (ib >= 32 ? 0xFFFFFFFFu : (1u << ib) - 1u) & ~BS_DUP;
+    // tagbits_max < 31 only in tests (D2G_BS_TAGBITS): a narrow tag makes tag collisions common
+    const uint32_t tagfield = ~BS_DUP & ~idxmask & (ib + tagbits_max >= 31 ? 0xFFFFFFFFu : (1u << (ib + tagbits_max)) - 1u);
+    auto slot_word = [&](uint64_t prod, uint32_t j) {                     // prod = v * K (bs_hash's product)
+        return j | ((uint32_t)((prod << logT) >> 33) & tagfield);         // the 31 bits below the slot bits, cut to the field
+    };
     // at most Tl probes: a partition that receives more than Tl distinct values (a skewed / adversarial
     // column; T >= 1.5 N only bounds the AVERAGE load) must not spin forever.  The overflow is
     // reported through *status; the host then falls back to the DIRECT algorithm or fails loudly.
     auto insert = [&](uint64_t v, uint32_t j, uint32_t h) {
+        const uint32_t mine = slot_word(v * 0x9E3779B97F4A7C15ull, j);
         for (uint32_t probes = 0; probes < Tl; ++probes) {
-            const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, j);
+            const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, mine);
             if (cur == BS_EMPTY) return h;                                // first occurrence: we own the slot
-            if (col[cur & ~BS_DUP] == v) {                                // same value seen again
+            if (!((cur ^ mine) & tagfield) && col[cur & idxmask] == v) {  // same value seen again
                 if (!(cur & BS_DUP)) atomicOr(&own[h], BS_DUP);
                 return h;
             }
@@ -116,9 +130,16 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
 
     constexpr int PF = 12;      // values a thread keeps in registers (fast path: N <= 12288, one partition)
     if (!MULTI && N <= (size_t)PF * BS_RANK_THREADS) {
-        // every value is fetched BEFORE the probe chains (a load inside the chain exposed a full
-        // HBM/L2 round trip per value: 76 us for the 1024 columns of config 3) and its slot stays in
-        // a register until the ids are written
+        // every value is fetched BEFORE the probe chains (a load inside the chain exposed a full HBM/L2 round
+        // trip per value) and its slot stays in a register until the ids are written.
+        // Two phases.  (1) claim: probe with LDS compare-and-swaps only; stop at the first slot that is won or
+        // whose tag matches (the CANDIDATE: same value, up to a tag collision).  (2) confirm: the owners' values
+        // of the candidates are fetched a few at a time -- independent loads, one exposed round trip per batch
+        // instead of one per value -- and compared exactly; a confirmed repeat flags the slot, the rare tag
+        // collision resumes the exact serial chain behind it.  Every thread holding the same value stops at the
+        // same candidate (claimed slots never change owner or tag), so the outcome is the exact ranking.
+        // (Probing a thread's values TOGETHER, round by round, was measured too: it needs > 64 VGPRs, i.e. one
+        // workgroup per CU instead of two, and is slower -- profiles/r02_k2_experiments.txt.)
         uint64_t v[PF];
         uint32_t hs[PF];
 #pragma unroll
@@ -128,18 +149,68 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         }
         for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
         __syncthreads();
+        uint32_t candidate = 0;                                           // bit i: value i stopped at a tag match
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const size_t j = (size_t)i * BS_RANK_THREADS + tid;
-            hs[i] = j < N ? insert(v[i], (uint32_t)j, bs_hash(v[i], logT) & mask) : 0u;
+            hs[i] = 0;
+            if (j < N) {
+                const uint64_t prod = v[i] * 0x9E3779B97F4A7C15ull;
+                const uint32_t mine = slot_word(prod, (uint32_t)j);
+                uint32_t h = (uint32_t)(prod >> (64 - logT)) & mask, probes = 0;
+                for (; probes < Tl; ++probes) {
+                    const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, mine);
+                    if (cur == BS_EMPTY) break;
+                    if (!((cur ^ mine) & tagfield)) { candidate |= 1u << i; break; }
+                    h = (h + 1) & mask;
+                }
+                if (probes == Tl) atomicOr(status, 1u);
+                hs[i] = h;
+            }
+        }
+        constexpr int CB = 2;                                             // owner fetches in flight per thread
+        uint32_t redo = 0;
+#pragma unroll
+        for (int c = 0; c < PF; c += CB) {
+            uint32_t o[CB];
+            uint64_t w[CB];
+#pragma unroll
+            for (int g = 0; g < CB; ++g)
+                if (candidate >> (c + g) & 1) o[g] = own[hs[c + g]];
+#pragma unroll
+            for (int g = 0; g < CB; ++g)
+                if (candidate >> (c + g) & 1) w[g] = col[o[g] & idxmask];
+#pragma unroll
+            for (int g = 0; g < CB; ++g)
+                if (candidate >> (c + g) & 1) {
+                    if (w[g] == v[c + g]) {
+                        if (!(o[g] & BS_DUP)) atomicOr(&own[hs[c + g]], BS_DUP);
+                    } else redo |= 1u << (c + g);
+                }
+            __builtin_amdgcn_sched_barrier(0);                            // one batch of fetches at a time (VGPRs: 2 workgroups per CU)
+        }
+        // tag collisions (about one value in 10^5): the exact serial chain from the value's home slot; it walks past
+        // the false candidate.  Their slots go through a small LDS list instead of hs[] (conditional updates of the
+        // register array made the compiler keep several copies of it).
+        const uint32_t skip = redo;
+        while (redo) {
+            const int i = __ffs(redo) - 1;
+            redo &= redo - 1;
+            const uint32_t j = (uint32_t)i * BS_RANK_THREADS + tid;
+            const uint64_t vv = col[j];
+            const uint32_t h2 = insert(vv, j, bs_hash(vv, logT) & mask);
+            const uint32_t k = atomicAdd(&nfix, 1u);
+            if (k < BS_MAXFIX) { fix_j[k] = j; fix_h[k] = h2; }
+            else atomicOr(status, 1u);                                    // cannot happen by chance; the host falls back to DIRECT
         }
         __syncthreads();
         compact();
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const size_t j = (size_t)i * BS_RANK_THREADS + tid;
-            if (j < N) ids[j] = own[hs[i]];
+            if (j < N && !(skip >> i & 1)) ids[j] = own[hs[i]];
         }
+        for (uint32_t k = tid; k < nfix && k < BS_MAXFIX; k += BS_RANK_THREADS) ids[fix_j[k]] = own[fix_h[k]];
         if (tid == 0) atomicMax(&max_distinct[t >> 5], running);
         return;
     }
@@ -495,10 +566,12 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         const int logTl = set->logT < BS_LOG_TLDS_MAX ? set->logT : BS_LOG_TLDS_MAX;
         const size_t lds = (size_t(1) << logTl) * sizeof(uint32_t);
         auto kern = set->logT > BS_LOG_TLDS_MAX ? bs_rank_kernel<true> : bs_rank_kernel<false>;
+        int tagbits_max = 31;
+        if (const char *e = std::getenv("D2G_BS_TAGBITS")) { const int v = std::atoi(e); if (v >= 0 && v < 31) tagbits_max = v; }   // tests
         if (lds > 48 * 1024)
             D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
-                           set->d_ids, set->d_meta, set->d_meta + set->ntb);
+                           set->d_ids, set->d_meta, set->d_meta + set->ntb, tagbits_max);
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, S, N, Npad, set->d_planes, set->d_stream, set->Nstride,

@@ -410,3 +410,29 @@ def test_row_sharded_pipelined_input_produced_on_main_stream(gpu_ctx, d2g, oracl
         exp = oracle.allpairs_ut(x, np.ones(N), measure=oracle.SIMILARITY, k=31, nthreads=4)
         np.testing.assert_array_equal(g.cpu().numpy().view(np.uint32), exp.view(np.uint32))
     eng.close()
+
+
+@pytest.mark.parametrize("tagbits", ["8", "0"])
+def test_k2_rank_tag_collisions(gpu_ctx, d2g, oracle, monkeypatch, tagbits):
+    """The rank kernel stops a probe chain at the first slot whose hash TAG matches and confirms the owner's value
+    afterwards; a tag collision resumes the exact chain through a small fix list.  D2G_BS_TAGBITS (test hook) narrows the
+    tag: 8 bits -> a handful of collisions per column, all through the list, same exact result; 0 bits -> every occupied
+    slot is a candidate, the list overflows, the status word is raised: AUTO falls back to DIRECT, an explicit BITSLICE
+    request fails loudly."""
+    monkeypatch.setenv("D2G_BS_TAGBITS", tagbits)
+    rng = np.random.default_rng(77)
+    N, S = 3000, 64
+    sigs = _planted(rng, N, S, nvals=40)
+    fresh = rng.random((N, S)) < 0.6                     # most values occur once: many occupied slots with other values
+    sigs[fresh] = rng.random(int(fresh.sum()))
+    exp = oracle.eqcounts_ut(sigs)
+    if tagbits == "8":
+        cs = gpu_ctx.cmp_set(sigs.view(np.uint64), algo=d2g.CMP_BITSLICE)
+        assert cs.algo == d2g.CMP_BITSLICE
+    else:
+        with pytest.raises(d2g.D2GError):
+            gpu_ctx.cmp_set(sigs.view(np.uint64), algo=d2g.CMP_BITSLICE)
+        cs = gpu_ctx.cmp_set(sigs.view(np.uint64), algo=d2g.CMP_AUTO)
+        assert cs.algo == d2g.CMP_DIRECT
+    np.testing.assert_array_equal(cs.eqcount_ut(), exp)
+    cs.close()
