@@ -43,6 +43,7 @@ constexpr int K3_MAXB = 1 << K3_MAXBBITS;   // buckets per genome (LDS histogram
 constexpr int K3_TAB = 2048;                // LDS count-table slots (24.6 KB with the counts: 6 workgroups per CU)
 constexpr int K3_ROUND_KEYS = 1400;         // keys one table round is sized for (load <= 0.69)
 constexpr int K3_TARGET = 1024;             // mean keys per bucket aimed for
+constexpr int K3_L1BITS = 8;                // write fronts of the scatter = 2^K3_L1BITS; the other bucket bits are resolved by k3_refine_kernel
 constexpr uint64_t K3_SPLIT_MIN = 4 * 1400; // mean bucket size above which a genome's buckets are split once more
 constexpr uint64_t BMH_INF = 0x7FF0000000000000ull;
 constexpr int BMH_STACK = 72;
@@ -58,6 +59,12 @@ struct K3Args {
     uint64_t *cursor;          // [TB]   scatter cursors (copy of bucket_off)
     uint64_t *keys;            // [total k-mers] bucketed keys
     uint32_t TB;
+    // two-level split (genomes with more than 2^l1bits buckets): the scatter writes by the top l1bits of the bucket index
+    // only, into `coarse`; k3_refine_kernel then spreads every coarse bucket over its 2^(bb - l1bits) buckets in `keys`
+    uint32_t l1bits;
+    uint64_t *coarse;          // [total k-mers] or nullptr (no genome needs the second level)
+    const uint32_t *l2_tb0;    // [nl2] first bucket of coarse bucket i (global bucket index)
+    const uint32_t *l2_bits;   // [nl2] (bb << 8) | (bb - l1bits) of its genome
 };
 
 __device__ __forceinline__ uint32_t bucket_of(uint64_t key, uint32_t bb) { return bb ? (uint32_t)(key >> (64 - bb)) : 0u; }
@@ -103,34 +110,64 @@ __global__ __launch_bounds__(K3_THREADS) void k3_scan_kernel(K3Args a) {
     if (g == gridDim.x - 1 && tid == K3_THREADS - 1) a.bucket_off[a.TB] = a.g_koff[g + 1];
 }
 
+// Write-combining decides this pass.  A workgroup's 65 536 k-mers leave ~16 keys = one 128-byte line in each of 4096
+// buckets, but every 8-byte store is a separate partial write and 4096 open lines per workgroup x 160 workgroups per XCD
+// do not live in a 4 MB L2 until they are full: measured 38 GB of HBM writes for 10 GB of keys, 14.4 ms.  With <= 256
+// write fronts per workgroup the L2 completes the lines before it evicts them (6.4 ms at 256 fronts, 5.1 ms at 64).  So
+// genomes with more than 2^l1bits buckets are split in two levels: here by the top l1bits of the bucket index -- the
+// coarse bucket's region is the union of its buckets' regions, reserved through the cursor of its first bucket -- and
+// then by the remaining bits, per coarse bucket, in k3_refine_kernel (<= 2^(12 - l1bits) fronts per workgroup there).
 __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
-    // ONE 16 KB LDS array: first the workgroup's count per bucket, then (after one 64-bit reservation
+    // ONE LDS array: first the workgroup's count per (coarse) bucket, then (after one 64-bit reservation
     // per bucket) the next write position relative to the genome's first key -- a genome holds < 2^32
-    // k-mers -- so that a key's slot is a single LDS atomic.  (Separate count and 64-bit base arrays
-    // cost 48 KB and left room for 3 workgroups per CU.)
+    // k-mers -- so that a key's slot is a single LDS atomic.
     __shared__ uint32_t pos[K3_MAXB];
     const int tid = threadIdx.x;
     const uint32_t g = a.km.blk_genome[blockIdx.x];
-    const uint32_t bb = a.g_bbits[g], B = 1u << bb, boff = a.g_boff[g];
+    const uint32_t bb = a.g_bbits[g], boff = a.g_boff[g];
+    const uint32_t b1 = bb < a.l1bits ? bb : a.l1bits, sb = bb - b1, B = 1u << b1;
     const uint64_t koff = a.g_koff[g];
     for (uint32_t i = tid; i < B; i += K1_THREADS) pos[i] = 0;
     __syncthreads();
     const uint64_t xormask = a.xormask;
-    d2g_for_each_kmer(a.km, [&](uint64_t x) { atomicAdd(&pos[bucket_of(wang64(x ^ xormask), bb)], 1u); });
+    d2g_for_each_kmer(a.km, [&](uint64_t x) { atomicAdd(&pos[bucket_of(wang64(x ^ xormask), b1)], 1u); });
     __syncthreads();
     for (uint32_t i = tid; i < B; i += K1_THREADS) {
         const uint32_t c = pos[i];
-        if (c) pos[i] = (uint32_t)(atomicAdd((unsigned long long *)&a.cursor[boff + i], (unsigned long long)c) - koff);
+        if (c) pos[i] = (uint32_t)(atomicAdd((unsigned long long *)&a.cursor[boff + (i << sb)], (unsigned long long)c) - koff);
     }
     __syncthreads();
-    uint64_t *keys = a.keys + koff;
+    uint64_t *keys = (sb ? a.coarse : a.keys) + koff;
     d2g_for_each_kmer(a.km, [&](uint64_t x) {
         const uint64_t key = wang64(x ^ xormask);
-        const uint32_t slot = atomicAdd(&pos[bucket_of(key, bb)], 1u);
+        const uint32_t slot = atomicAdd(&pos[bucket_of(key, b1)], 1u);
         if (D2G_K3_EXP == 1) { if (slot == 0xFFFFFFFFu) keys[slot] = key; }                      // timing experiment: no stores
         else if (D2G_K3_EXP == 2) reinterpret_cast<uint32_t *>(keys)[slot] = (uint32_t)key;      // timing experiment: 4-byte stores
         else keys[slot] = key;
     });
+}
+
+// second level: one workgroup per coarse bucket; the offsets of its 2^sb buckets are known from the histogram pass, so
+// this is ONE read of the region and one LDS atomic per key
+__global__ __launch_bounds__(K3_THREADS) void k3_refine_kernel(K3Args a) {
+    __shared__ uint32_t pos[K3_MAXB];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tb0 = a.l2_tb0[blockIdx.x], bits = a.l2_bits[blockIdx.x];
+    const uint32_t bb = bits >> 8, sb = bits & 255u, R = 1u << sb;
+    const uint64_t o0 = a.bucket_off[tb0], nk = a.bucket_off[tb0 + R] - o0;
+    for (uint32_t i = tid; i < R; i += K3_THREADS) pos[i] = (uint32_t)(a.bucket_off[tb0 + i] - o0);
+    __syncthreads();
+    const uint64_t *src = a.coarse + o0;
+    uint64_t *dst = a.keys + o0;
+    constexpr int PF = 8;
+    for (uint64_t b0 = 0; b0 < nk; b0 += (uint64_t)PF * K3_THREADS) {
+        uint64_t kk[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) { const uint64_t i = b0 + (uint64_t)j * K3_THREADS + tid; kk[j] = i < nk ? src[i] : 0; }
+#pragma unroll
+        for (int j = 0; j < PF; ++j)
+            if (b0 + (uint64_t)j * K3_THREADS + tid < nk) dst[atomicAdd(&pos[bucket_of(kk[j], bb) & (R - 1)], 1u)] = kk[j];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -304,7 +341,9 @@ template <bool C32> struct K3Key;
 template <> struct K3Key<false> {
     typedef uint64_t T;
     static constexpr uint64_t EMPTY = ~0ull;
-    static __device__ __forceinline__ uint32_t slot(uint64_t key) { return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53); }
+    // the key IS a hash (Wang of the masked k-mer): bits 32..42 are as good as any product of it, and are not the ones that
+    // chose the bucket (top 12), the sub-range or the round (low bits)
+    static __device__ __forceinline__ uint32_t slot(uint64_t key) { return (uint32_t)(key >> 32) & (K3_TAB - 1); }
     // R rounds: key bits [shift, shift + log2 R) (the bits below `shift` chose the sub-range)
     static __device__ __forceinline__ uint32_t round_of(uint64_t key, uint32_t R, uint32_t shift, uint32_t) { return (uint32_t)(key >> shift) & (R - 1); }
     static __device__ __forceinline__ uint32_t sub_of(uint64_t key, uint32_t R, uint32_t) { return (uint32_t)key & (R - 1); }
@@ -380,6 +419,50 @@ __device__ bool count_round(const CountTab<C32> &t, const typename K3Key<C32>::T
     }
     const bool res = !__syncthreads_or(!ok);
     return res;
+}
+
+// The main kernel's round: the table arrives CLEAN (the walk that follows each round empties the slots it reads), so a
+// round is insert -> barrier -> walk+clear -> barrier.  Probing goes compare-and-swap first: one LDS operation and two
+// compares per probe (the read-first loop of count_round spends twice the vector instructions; the kernel is bound by
+// instruction issue, not by the LDS atomic rate: profiles/r02_k3_ablation.txt).
+template <bool C32>
+__device__ bool insert_round(const CountTab<C32> &t, const typename K3Key<C32>::T *kb, uint64_t n, uint32_t R, uint32_t r, uint32_t shift,
+                             uint32_t bb) {
+    typedef typename K3Key<C32>::T KT;
+    constexpr KT EMPTY = K3Key<C32>::EMPTY;
+    const int tid = threadIdx.x;
+    bool ok = true;
+    constexpr int K3_KPF = C32 ? 8 : 6;
+    for (uint64_t base = 0; base < n && ok; base += (uint64_t)K3_KPF * K3_THREADS) {
+        KT kreg[K3_KPF];
+#pragma unroll
+        for (int j = 0; j < K3_KPF; ++j) {
+            const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
+            kreg[j] = i < n ? kb[i] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < K3_KPF; ++j) {
+            const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
+            const KT key = kreg[j];
+            const bool mine = i < n && (R == 1 || K3Key<C32>::round_of(key, R, shift, bb) == r);
+            if (mine && key == EMPTY) atomicAdd(t.ones, 1u);
+            if (!mine || key == EMPTY) continue;
+            if (D2G_K3_EXP == 8) { if (key == 12345) atomicAdd(t.ones, 1u); continue; }   // timing experiment: loads, no inserts
+            uint32_t s = K3Key<C32>::slot(key);
+            int probes = 0;
+            bool placed;
+            for (;;) {
+                KT old;
+                if constexpr (C32) old = atomicCAS(&t.key[s], EMPTY, key);
+                else old = (KT)atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)EMPTY, (unsigned long long)key);
+                placed = (old == EMPTY) | (old == key);
+                if (placed | (++probes >= K3_TAB)) break;
+                s = (s + 1) & (K3_TAB - 1);
+            }
+            if (placed) atomicAdd(&t.cnt[s], 1u); else ok = false;
+        }
+    }
+    return !__syncthreads_or(!ok);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -626,7 +709,7 @@ struct BmhArgs {
     uint64_t *h;             // [n][m] register bit patterns, +inf initially
     uint64_t *guess;         // [n] pruning bound of the current pass (bit pattern of a double)
     double *tw;              // [n] total weight
-    double *tw_bucket;       // [TB] per-bucket partial of the first pass (zeroed by the host)
+    uint64_t *tw_acc;        // [n] sum of the counted weights of the first pass (integers; zeroed by the host)
     uint32_t *redo;          // [n] 1 = the guess proved too small: walk this genome again
     uint32_t *nredo;         // [1]
     int redo_mode;           // 0 = first pass (every genome, weights are summed); 1 = only genomes with redo[g]
@@ -766,60 +849,102 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
     const uint32_t per = (a.TB + gridDim.x - 1) / gridDim.x;
     const uint32_t tb_lo = blockIdx.x * per, tb_hi = tb_lo + per < a.TB ? tb_lo + per : a.TB;
     if (tb_lo >= tb_hi) return;
+    // the count table is cleared ONCE; afterwards every walk hands it back clean
+    for (int e = tid; e < K3_TAB; e += K3_THREADS) { sh.key[e] = K3Key<C32>::EMPTY; sh.cnt[e] = 0; }
+    if (tid == 0) sh.ones = 0;
+    // counter.h:123 `pair.second > threshold` on integer counts: c > thr  <=>  c >= floor(thr) + 1
+    uint32_t cmin = 1;
+    if (a.thr >= 1.0) cmin = a.thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)a.thr + 1u;
     uint32_t g = genome_of_bucket(a.g_boff, a.n, tb_lo), g_end = a.g_boff[g + 1];
     bool skip_g = a.redo_mode && !a.redo[g];
     double bound = V(a.guess[g]);
     uint32_t sbits = a.g_split ? a.g_split[g] : 0u;
     uint32_t bb = C32 ? a.g_bbits[g] : 0u, g_b0 = a.g_boff[g];
     uint64_t o_next = a.bucket_off[tb_lo];
+    // Strip 0 = [0, 1) is relevant for EVERY element (counts are >= 1) and has width 1, so the early-out of proc_next,
+    // (1 - uu) > bound * 1 * 1.000000001 with uu = ((r1 >> 11) + 1) 2^-53, is an INTEGER test on r1 >> 11: both sides are
+    // multiples of 2^-53, 1 - uu exactly.  u0 = smallest r1 >> 11 that is NOT dropped, minus a margin of 2 (whatever passes
+    // here takes the unchanged proc_next, which decides): a k-mer seen once costs one xor, one generator step, one compare.
+    auto strip0_floor = [](double bnd) -> uint64_t {
+        const double b53 = bnd * 1.0 * 1.000000001 * 0x1p53;
+        if (!(b53 < 9007199254740988.0)) return 0;
+        return 9007199254740991ull - 2ull - (uint64_t)b53;
+    };
+    uint64_t u0 = strip0_floor(bound);
+    // total weight = sum of the counts that pass the threshold: integers, summed per thread over the workgroup's buckets
+    // of one genome and added to the genome's counter once (exact in any order; no block reduction per bucket)
+    uint64_t twi = 0;
+    auto flush_tw = [&](uint32_t gg) {
+        if (a.redo_mode) { twi = 0; return; }
+        uint64_t v = twi;
+        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0 && v) atomicAdd((unsigned long long *)&a.tw_acc[gg], (unsigned long long)v);
+        twi = 0;
+    };
+    __syncthreads();
     for (uint32_t tb = tb_lo; tb < tb_hi; ++tb) {
         const uint64_t o0 = o_next;
         o_next = a.bucket_off[tb + 1];
         const uint64_t nk = o_next - o0;
-        while (tb >= g_end) {
-            ++g; g_end = a.g_boff[g + 1];
-            skip_g = a.redo_mode && !a.redo[g];                          // second passes: only genomes whose guess failed
+        if (tb >= g_end) {
+            flush_tw(g);
+            while (tb >= g_end) { ++g; g_end = a.g_boff[g + 1]; }
+            skip_g = a.redo_mode && !a.redo[g];                              // second passes: only genomes whose guess failed
             bound = V(a.guess[g]);
+            u0 = strip0_floor(bound);
             sbits = a.g_split ? a.g_split[g] : 0u;
             bb = C32 ? a.g_bbits[g] : 0u; g_b0 = a.g_boff[g];
         }
         if (nk == 0 || skip_g) continue;
         uint64_t *h = a.h + (size_t)g * m;
-        double tw = 0.;
         // one range of keys: as many table rounds as its size asks for; each round's elements go through phase 1
         auto process = [&](const KT *kb, uint64_t rn, uint32_t shift) -> bool {
             uint32_t R = 1;
             while ((uint64_t)R * a.round_keys < rn) R <<= 1;
             for (uint32_t r = 0; r < R; ++r) {
-                if (!count_round<C32>(t, kb, rn, R, r, shift, bb)) return false;
-                if (D2G_K3_EXP == 4 || D2G_K3_EXP == 8) continue;   // timing experiment: counting only
-                // Walk the table slots directly.  (r01 squeezed the occupied slots into a dense list first -- worth it when the
-                // per-element walk was heavy; since the strip structure made the first-point test ~40 instructions, the
-                // compaction, 3.5 ms per call with its three barriers per round, costs more than the 40 % idle lanes here.)
-                if (D2G_K3_EXP == 3) continue;                       // timing experiment: counting only (+ nothing)
+                if (!insert_round<C32>(t, kb, rn, R, r, shift, bb)) return false;
+                // Walk the table slots directly, emptying them on the way.  (r01 squeezed the occupied slots into a dense list
+                // first -- worth it when the per-element walk was heavy; the compaction, 3.5 ms per call with its three
+                // barriers per round, costs more than the 40 % idle lanes here.)
+                auto survivor = [&](const Proc &P, uint64_t d, double w, int tt) {
+                    if (D2G_K3_EXP == 5) return;                         // timing experiment: survivors dropped
+                    const uint32_t slot = atomicAdd(&qn, 1u);
+                    if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
+                    else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
+                };
                 auto element = [&](KT key, uint32_t cc) {
                     // the element's id is the masked key (maskfn, src/enums.h:136-140): on the compact path it is formed
                     // here, once per DISTINCT k-mer, from the stored word and the bucket
                     uint64_t d;
                     if constexpr (C32) d = wang64(k3c_kmer(key, tb - g_b0, bb, a.hb) ^ a.xormask);
                     else d = key;
-                    const double w = (double)cc;
-                    tw += w;
-                    const int nt = top_count(w);
-                    for (int tt = 0; tt < nt; ++tt) {
-                        Proc P = top_proc(d, tt);
-                        if (!proc_next(P, m, bound)) continue;
-                        if (D2G_K3_EXP == 5) continue;               // timing experiment: survivors dropped
-                        const uint32_t slot = atomicAdd(&qn, 1u);
-                        if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
-                        else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
+                    twi += cc;
+                    uint64_t rng0 = d ^ (0xA0761D6478BD642Full ^ 0x8EBC6AF09C88C6E3ull);      // top_proc(d, 0).rng
+                    if ((wy_next(rng0) >> 11) >= u0) {
+                        Proc P = top_proc(d, 0);
+                        if (proc_next(P, m, bound)) survivor(P, d, (double)cc, 0);
+                    }
+                    if (cc > 1) {                                        // the strips above [0, 1)
+                        const double w = (double)cc;
+                        const int nt = top_count(w);
+                        for (int tt = 1; tt < nt; ++tt) {
+                            Proc P = top_proc(d, tt);
+                            if (proc_next(P, m, bound)) survivor(P, d, w, tt);
+                        }
                     }
                 };
                 for (uint32_t e = tid; e < (uint32_t)K3_TAB; e += K3_THREADS) {
                     const uint32_t cc = sh.cnt[e];
-                    if (cc && (double)cc > a.thr) element(sh.key[e], cc);          // counter.h:123: pair.second > threshold
+                    if (cc) {
+                        const KT key = sh.key[e];
+                        sh.key[e] = K3Key<C32>::EMPTY; sh.cnt[e] = 0;
+                        if (cc >= cmin && D2G_K3_EXP != 3 && D2G_K3_EXP != 4 && D2G_K3_EXP != 8) element(key, cc);
+                    }
                 }
-                if (tid == 0) { const uint32_t ones = sh.ones; if (ones && (double)ones > a.thr) element(K3Key<C32>::EMPTY, ones); }
+                if (tid == 0) {
+                    const uint32_t ones = sh.ones;
+                    if (ones) { sh.ones = 0; if (ones >= cmin) element(K3Key<C32>::EMPTY, ones); }
+                }
                 __syncthreads();
                 if (qn >= (uint32_t)K3_QDRAIN) drain();
             }
@@ -839,13 +964,10 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
             }
         }
         if (!fine) { if (tid == 0) atomicExch(a.status, 1); return; }
-        // per-bucket total weight (integers: exact in any order); summed per genome by the verify
-        // kernel.  The bound is never tightened per workgroup: thousands of same-address atomics per
-        // genome serialise in L2 (measured 25 ms per 4e5 workgroups) and the guess is already within
-        // ~2x of the final maximum.
-        tw = block_sum(tw, reinterpret_cast<double *>(sh.red));
-        if (tid == 0 && !a.redo_mode) a.tw_bucket[tb] = tw;
+        // The bound is never tightened per workgroup: thousands of same-address atomics per genome serialise in L2
+        // (measured 25 ms per 4e5 workgroups) and the guess is already within ~2x of the final maximum.
     }
+    flush_tw(g);
     __syncthreads();
     drain();
 }
@@ -857,13 +979,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_verify_kernel(BmhArgs a) {
     const uint32_t g = blockIdx.x;
     if (a.redo_mode && !a.redo[g]) return;
     const uint64_t hm = block_hmax(a.h + (size_t)g * a.m, a.m, red);
-    double tw = 0.;
-    if (!a.redo_mode) {
-        for (uint32_t tb = a.g_boff[g] + threadIdx.x; tb < a.g_boff[g + 1]; tb += K3_THREADS) tw += a.tw_bucket[tb];
-        tw = block_sum(tw, reinterpret_cast<double *>(red));
-    }
     if (threadIdx.x == 0) {
-        if (!a.redo_mode) a.tw[g] = tw; else tw = a.tw[g];
+        double tw;
+        if (!a.redo_mode) a.tw[g] = tw = (double)a.tw_acc[g]; else tw = a.tw[g];   // counts: exact below 2^53
         const double guess = V(a.guess[g]);
         const bool bad = tw > 0. && !(V(hm) <= guess);               // no element at all: registers stay +inf, nothing to redo
         a.redo[g] = bad;
@@ -999,6 +1117,7 @@ struct d2g_k3_state {
     uint32_t *d_bucket_cnt = nullptr; size_t cap_bcnt = 0;
     uint64_t *d_bucket_off = nullptr; size_t cap_boff = 0;
     uint64_t *d_cursor = nullptr; size_t cap_cursor = 0;
+    uint32_t *d_l2 = nullptr; size_t cap_l2 = 0;     // two-level split: coarse bucket table
     uint64_t *d_keys = nullptr; size_t cap_keys = 0;
     uint64_t *d_skeys = nullptr; size_t cap_skeys = 0;      // big inputs: keys regrouped by sub-range
     uint32_t *d_gblk = nullptr; size_t cap_gblk = 0;        // compact path: first launch-plan block of each genome
@@ -1021,7 +1140,7 @@ struct d2g_k3_state {
 
 void d2g_k3_state_destroy(d2g_k3_state *st) {
     if (!st) return;
-    (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor);
+    (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor); (void)hipFree(st->d_l2);
     (void)hipFree(st->d_keys); (void)hipFree(st->d_skeys); (void)hipFree(st->d_sub_off); (void)hipFree(st->d_gsplit); (void)hipFree(st->d_gsub); (void)hipFree(st->d_h); (void)hipFree(st->d_tw);
     (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
     (void)hipFree(st->d_out_keys); (void)hipFree(st->d_gblk); (void)hipFree(st->d_tile_cnt); (void)hipFree(st->d_tile_off);
@@ -1042,6 +1161,8 @@ struct K3Host {
     bool any_split = false;
     uint64_t total = 0;
     uint32_t TB = 0;
+    uint32_t l1bits = K3_L1BITS;        // generic path: bucket bits the scatter resolves itself
+    std::vector<uint32_t> l2_tb0, l2_bits;   // coarse buckets that k3_refine_kernel spreads over their buckets
 };
 
 int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_off, size_t n, int k, K3Host &kh) {
@@ -1054,6 +1175,11 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     kh.compact = false;
     if (const char *e = std::getenv("D2G_K3_COMPACT")) if (e[0] == '1') kh.compact = kh.hb <= (uint32_t)K3C_MAXBBITS;
     uint64_t tb = 0;
+    uint64_t bucket_keys = K3_TARGET, sub_keys = K3_TARGET;
+    kh.l1bits = K3_L1BITS; kh.l2_tb0.clear(); kh.l2_bits.clear();
+    if (const char *e = std::getenv("D2G_K3_L1BITS")) { const int v = std::atoi(e); if (v >= 0 && v <= K3_MAXBBITS) kh.l1bits = (uint32_t)v; }
+    if (const char *e = std::getenv("D2G_K3_BUCKET_KEYS")) { const long v = std::atol(e); if (v >= 1) bucket_keys = (uint64_t)v; }
+    if (const char *e = std::getenv("D2G_K3_SUB_KEYS")) { const long v = std::atol(e); if (v >= 1) sub_keys = (uint64_t)v; }
     for (size_t g = 0; g < n; ++g) {
         uint64_t nk = 0, chunks = 0;
         for (uint64_t r = genome_run_off[g]; r < genome_run_off[g + 1]; ++r) {
@@ -1065,9 +1191,14 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
         kh.gblk[g + 1] = kh.gblk[g] + (uint32_t)div_up<uint64_t>(chunks, K1_BLOCK_CHUNKS);
         uint32_t bb;
         if (kh.compact) bb = std::max<uint32_t>(kh.hb, std::min<uint32_t>(K3C_MAXBBITS, ceil_log2((nk + K3C_TARGET - 1) / K3C_TARGET)));
-        else bb = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((nk + K3_TARGET - 1) / K3_TARGET));
+        else bb = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((nk + bucket_keys - 1) / bucket_keys));
         kh.gtab[g] = bb;
         kh.gtab[n + g] = (uint32_t)tb;
+        if (!kh.compact && bb > kh.l1bits)
+            for (uint32_t c = 0; c < (1u << kh.l1bits); ++c) {
+                kh.l2_tb0.push_back((uint32_t)tb + (c << (bb - kh.l1bits)));
+                kh.l2_bits.push_back((bb << 8) | (bb - kh.l1bits));
+            }
         tb += 1ull << bb;
         D2G_CHECK(ctx, tb < (1ull << 31), "--multiset: too many buckets in one batch; use smaller batches");
     }
@@ -1087,7 +1218,7 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     for (size_t g = 0; g < n; ++g) {
         const uint64_t B = 1ull << kh.gtab[g], mean = kh.gk[g] / B;
         if (mean > split_min) {
-            kh.gsplit[g] = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((mean + K3_TARGET - 1) / K3_TARGET));
+            kh.gsplit[g] = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((mean + sub_keys - 1) / sub_keys));
             kh.any_split = true;
         }
         // + 1: the end of a genome's last sub-range gets its OWN entry.  Sharing it with the next split genome's first
@@ -1140,9 +1271,20 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         a.g_bbits = st->d_gtab; a.g_boff = st->d_gtab + n; a.g_koff = st->d_koff;
         a.bucket_cnt = st->d_bucket_cnt; a.bucket_off = st->d_bucket_off; a.cursor = st->d_cursor; a.keys = st->d_keys;
         a.TB = TB;
+        a.l1bits = kh.l1bits; a.coarse = nullptr; a.l2_tb0 = nullptr; a.l2_bits = nullptr;
+        const size_t nl2 = kh.l2_tb0.size();
+        if (nl2) {
+            // the coarse keys borrow the sub-range buffer: k3_split_kernel (big inputs) runs after the refinement
+            if (int rc = d2g_grow(ctx, &st->d_skeys, &st->cap_skeys, std::max<uint64_t>(key_words, 1))) return rc;
+            if (int rc = d2g_grow(ctx, &st->d_l2, &st->cap_l2, 2 * nl2)) return rc;
+            D2G_HIP(ctx, hipMemcpyAsync(st->d_l2, kh.l2_tb0.data(), nl2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            D2G_HIP(ctx, hipMemcpyAsync(st->d_l2 + nl2, kh.l2_bits.data(), nl2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            a.coarse = st->d_skeys; a.l2_tb0 = st->d_l2; a.l2_bits = st->d_l2 + nl2;
+        }
         if (nblk) hipLaunchKernelGGL(k3_hist_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
         hipLaunchKernelGGL(k3_scan_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, a);
         if (nblk) hipLaunchKernelGGL(k3_scatter_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
+        if (nblk && nl2 && D2G_K3_EXP != 1 && D2G_K3_EXP != 2) hipLaunchKernelGGL(k3_refine_kernel, dim3((unsigned)nl2), dim3(K3_THREADS), 0, s, a);
     }
     BmhArgs b;
     std::memset(&b, 0, sizeof(b));
@@ -1191,7 +1333,7 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
             std::memcpy(&guess[g], &gv, 8);
         }
         D2G_HIP(ctx, hipMemcpyAsync(st->d_guess, guess.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-        b.h = st->d_h; b.tw = st->d_tw; b.tw_bucket = st->d_tw_bucket; b.guess = st->d_guess; b.redo = st->d_redo;
+        b.h = st->d_h; b.tw = st->d_tw; b.tw_acc = reinterpret_cast<uint64_t *>(st->d_tw_bucket); b.guess = st->d_guess; b.redo = st->d_redo;
         b.nredo = reinterpret_cast<uint32_t *>(st->d_status + 1);
         const size_t ninit = std::max<size_t>(n * m, n);
         hipLaunchKernelGGL(k3_bmh_init_kernel, dim3((unsigned)div_up<size_t>(ninit, K3_THREADS)), dim3(K3_THREADS), 0, s,

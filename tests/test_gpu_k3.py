@@ -131,7 +131,8 @@ def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
     table rounds (the path genomes above ~5.7 Mbp take), D2G_K3_GUESS_SCALE=1e-3 makes the guessed
     pruning bound fail its verification so the main pass is repeated under a larger bound,
     D2G_K3_SPLIT_MIN lowers the bucket size above which buckets are split once more by their low key
-    bits (the path inputs above ~23 Mbp take).  Counts and BagMinHash registers must not change."""
+    bits (the path inputs above ~23 Mbp take), D2G_K3_L1BITS the number of bucket bits the scatter resolves itself before
+    k3_refine_kernel takes over (default 8: genomes above ~260 kbp).  Counts and BagMinHash registers must not change."""
     import os, subprocess, sys, json
     g = synth.fasta_bytes("a", synth.random_genome(31, 150000)) + synth.fasta_bytes("r", np.tile(synth.random_genome(32, 300), 30))
     fa = tmp_path / "x.fa"
@@ -149,6 +150,9 @@ def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
     for env in ({"D2G_K3_ROUND_KEYS": "64"}, {"D2G_K3_GUESS_SCALE": "0.001"}, {"D2G_K3_ROUND_KEYS": "100", "D2G_K3_GUESS_SCALE": "0.01"},
                 {"D2G_K3_SPLIT_MIN": "100"},                                   # big-input path: buckets pre-split by low key bits
                 {"D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},        # ... and sub-ranges that still need rounds
+                {"D2G_K3_L1BITS": "3"}, {"D2G_K3_L1BITS": "0"},                # two-level scatter (genomes above ~260 kbp): 8 / 1 write fronts, then k3_refine_kernel
+                {"D2G_K3_L1BITS": "12"},                                       # ... and never (the single-level scatter)
+                {"D2G_K3_L1BITS": "2", "D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},
                 {"D2G_K3_COMPACT": "1"}, {"D2G_K3_COMPACT": "1", "D2G_K3_ROUND_KEYS": "64"}, {"D2G_K3_COMPACT": "1", "D2G_K3_GUESS_SCALE": "0.001"},
                 {"D2G_K3_COMPACT": "1", "D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},
                 {"D2G_K3_COMPACT": "1", "D2G_K3_SPLIT_MIN": "100000"}):        # compact path without the sub-range split: table rounds
