@@ -65,6 +65,7 @@ struct K3Args {
     uint64_t *coarse;          // [total k-mers] or nullptr (no genome needs the second level)
     const uint32_t *l2_tb0;    // [nl2] first bucket of coarse bucket i (global bucket index)
     const uint32_t *l2_bits;   // [nl2] (bb << 8) | (bb - l1bits) of its genome
+    uint32_t *blk_coarse;      // [nblk << l1bits] k-mers of launch-plan block b in each of its genome's coarse buckets
 };
 
 __device__ __forceinline__ uint32_t bucket_of(uint64_t key, uint32_t bb) { return bb ? (uint32_t)(key >> (64 - bb)) : 0u; }
@@ -84,6 +85,14 @@ __global__ __launch_bounds__(K1_THREADS) void k3_hist_kernel(K3Args a) {
     __syncthreads();
     for (uint32_t i = tid; i < B; i += K1_THREADS)
         if (hist[i]) atomicAdd(&a.bucket_cnt[boff + i], hist[i]);
+    // the workgroup's count per COARSE bucket (the scatter's write fronts): saves the scatter its counting enumeration
+    const uint32_t b1 = bb < a.l1bits ? bb : a.l1bits, sb = bb - b1;
+    uint32_t *mine = a.blk_coarse + ((size_t)blockIdx.x << a.l1bits);
+    for (uint32_t i = tid; i < (1u << b1); i += K1_THREADS) {
+        uint32_t c = 0;
+        for (uint32_t j = 0; j < (1u << sb); ++j) c += hist[(i << sb) + j];
+        mine[i] = c;
+    }
 }
 
 // exclusive prefix of bucket_cnt: one workgroup per genome scans its <= 4096 buckets (coalesced, 16 per
@@ -127,14 +136,11 @@ __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
     const uint32_t bb = a.g_bbits[g], boff = a.g_boff[g];
     const uint32_t b1 = bb < a.l1bits ? bb : a.l1bits, sb = bb - b1, B = 1u << b1;
     const uint64_t koff = a.g_koff[g];
-    for (uint32_t i = tid; i < B; i += K1_THREADS) pos[i] = 0;
-    __syncthreads();
     const uint64_t xormask = a.xormask;
-    d2g_for_each_kmer(a.km, [&](uint64_t x) { atomicAdd(&pos[bucket_of(wang64(x ^ xormask), b1)], 1u); });
-    __syncthreads();
+    const uint32_t *mine = a.blk_coarse + ((size_t)blockIdx.x << a.l1bits);      // counted by k3_hist_kernel
     for (uint32_t i = tid; i < B; i += K1_THREADS) {
-        const uint32_t c = pos[i];
-        if (c) pos[i] = (uint32_t)(atomicAdd((unsigned long long *)&a.cursor[boff + (i << sb)], (unsigned long long)c) - koff);
+        const uint32_t c = mine[i];
+        pos[i] = c ? (uint32_t)(atomicAdd((unsigned long long *)&a.cursor[boff + (i << sb)], (unsigned long long)c) - koff) : 0u;
     }
     __syncthreads();
     uint64_t *keys = (sb ? a.coarse : a.keys) + koff;
@@ -723,6 +729,8 @@ struct BmhArgs {
     uint64_t *sub_off;        // [nsub + 1]
     uint64_t *skeys;          // [total k-mers]
     uint32_t *skeys32;        // compact path
+    // first pass, light form: survivors queue in HBM, one region per main workgroup
+    QEntry *gq; const uint64_t *gq_off; uint32_t *gq_n;
     // optional R11 output (k3_count_kernel): distinct (key,count) written in place of the bucket
     uint64_t *out_keys; uint32_t *out_counts; uint32_t *bucket_nd;
 };
@@ -817,20 +825,29 @@ __host__ __device__ inline double bmh_guess(double W, double m, double lnm) { re
 #ifndef D2G_K3_WPE
 #define D2G_K3_WPE 5
 #endif
-template <bool C32>
-__global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_K3_WPE))) void k3_bmh_main_kernel(BmhArgs a) {
+#ifndef D2G_K3_WPE_LIGHT
+#define D2G_K3_WPE_LIGHT 6
+#endif
+// LIGHT (the first pass): survivors are not walked here but appended to the workgroup's region of a queue in HBM and
+// walked by k3_bmh_survivor_kernel afterwards, one per lane with every lane busy.  Without the descent (its stack, its
+// LDS queue, its drains and their barriers) this kernel needs fewer registers and less LDS: 6 workgroups per CU instead of 5.
+// The heavy form stays for the repeat passes (guess too small: rare) and as the fallback when a region overflows.
+template <bool C32, bool LIGHT>
+__global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(LIGHT ? D2G_K3_WPE_LIGHT : D2G_K3_WPE))) void k3_bmh_main_kernel(BmhArgs a) {
     typedef typename K3Key<C32>::T KT;
     __shared__ SharedK3<C32> sh;
-    __shared__ QEntry queue[K3_QCAP];
+    __shared__ QEntry queue[LIGHT ? 1 : K3_QCAP];
     __shared__ uint32_t qn;
     const int tid = threadIdx.x;
     const uint32_t m = a.m;
     const CountTab<C32> t{sh.key, sh.cnt, &sh.ones};
-    Proc stk[BMH_STACK];
+    Proc stk[LIGHT ? 1 : BMH_STACK];
     if (tid == 0) qn = 0;
+    if (LIGHT && tid == 0) a.gq_n[blockIdx.x] = 0;
     __syncthreads();
     // phase 2: one queued survivor per lane
     auto drain = [&]() {
+        if constexpr (LIGHT) return;
         const uint32_t n = qn < (uint32_t)K3_QCAP ? qn : (uint32_t)K3_QCAP;
         for (uint32_t i = tid; i < n; i += K3_THREADS) {
             const QEntry q = queue[i];
@@ -849,6 +866,8 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
     const uint32_t per = (a.TB + gridDim.x - 1) / gridDim.x;
     const uint32_t tb_lo = blockIdx.x * per, tb_hi = tb_lo + per < a.TB ? tb_lo + per : a.TB;
     if (tb_lo >= tb_hi) return;
+    QEntry *gq = LIGHT ? a.gq + a.gq_off[blockIdx.x] : nullptr;
+    const uint32_t gq_cap = LIGHT ? (uint32_t)(a.gq_off[blockIdx.x + 1] - a.gq_off[blockIdx.x]) : 0u;
     // the count table is cleared ONCE; afterwards every walk hands it back clean
     for (int e = tid; e < K3_TAB; e += K3_THREADS) { sh.key[e] = K3Key<C32>::EMPTY; sh.cnt[e] = 0; }
     if (tid == 0) sh.ones = 0;
@@ -909,8 +928,13 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
                 auto survivor = [&](const Proc &P, uint64_t d, double w, int tt) {
                     if (D2G_K3_EXP == 5) return;                         // timing experiment: survivors dropped
                     const uint32_t slot = atomicAdd(&qn, 1u);
-                    if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
-                    else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
+                    if constexpr (LIGHT) {
+                        // the region's capacity is twice the expected count; qn keeps counting so that the end of the kernel sees an overflow
+                        if (slot < gq_cap) { QEntry *q = gq + slot; q->d = d; q->w = w; q->t = (uint32_t)tt; q->g = g; }
+                    } else {
+                        if (slot < (uint32_t)K3_QCAP) { queue[slot].d = d; queue[slot].w = w; queue[slot].t = (uint32_t)tt; queue[slot].g = g; }
+                        else walk_process(P, d, w, m, bound, h, stk, a.status);   // queue full: do it now
+                    }
                 };
                 auto element = [&](KT key, uint32_t cc) {
                     // the element's id is the masked key (maskfn, src/enums.h:136-140): on the compact path it is formed
@@ -946,7 +970,7 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
                     if (ones) { sh.ones = 0; if (ones >= cmin) element(K3Key<C32>::EMPTY, ones); }
                 }
                 __syncthreads();
-                if (qn >= (uint32_t)K3_QDRAIN) drain();
+                if constexpr (!LIGHT) { if (qn >= (uint32_t)K3_QDRAIN) drain(); }
             }
             return true;
         };
@@ -969,7 +993,25 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
     }
     flush_tw(g);
     __syncthreads();
-    drain();
+    if constexpr (LIGHT) {
+        if (tid == 0) {
+            a.gq_n[blockIdx.x] = qn < gq_cap ? qn : gq_cap;
+            if (qn > gq_cap) atomicExch(a.status, 4);                    // the host repeats the pass with the heavy kernel
+        }
+    } else drain();
+}
+
+// the survivors of the light first pass, region by region, one per lane
+__global__ __launch_bounds__(K3_THREADS) void k3_bmh_survivor_kernel(BmhArgs a) {
+    Proc stk[BMH_STACK];
+    const uint32_t n = a.gq_n[blockIdx.x];
+    const QEntry *q0 = a.gq + a.gq_off[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += K3_THREADS) {
+        const QEntry q = q0[i];
+        const double bound = V(a.guess[q.g]);
+        Proc P = top_proc(q.d, (int)q.t);
+        if (proc_next(P, a.m, bound)) walk_process(P, q.d, q.w, a.m, bound, a.h + (size_t)q.g * a.m, stk, a.status);
+    }
 }
 
 // after a pass: was the bound that pruned points at least the final maximum register?  The first
@@ -1118,6 +1160,10 @@ struct d2g_k3_state {
     uint64_t *d_bucket_off = nullptr; size_t cap_boff = 0;
     uint64_t *d_cursor = nullptr; size_t cap_cursor = 0;
     uint32_t *d_l2 = nullptr; size_t cap_l2 = 0;     // two-level split: coarse bucket table
+    uint32_t *d_blk_coarse = nullptr; size_t cap_blk_coarse = 0;
+    uint64_t *d_gq = nullptr; size_t cap_gq = 0;     // survivors of the light first pass (QEntry)
+    uint64_t *d_gq_off = nullptr; size_t cap_gq_off = 0;   // [grid+1] region offsets, then [grid] u32 counts
+    int light_overflows = 0;
     uint64_t *d_keys = nullptr; size_t cap_keys = 0;
     uint64_t *d_skeys = nullptr; size_t cap_skeys = 0;      // big inputs: keys regrouped by sub-range
     uint32_t *d_gblk = nullptr; size_t cap_gblk = 0;        // compact path: first launch-plan block of each genome
@@ -1140,7 +1186,7 @@ struct d2g_k3_state {
 
 void d2g_k3_state_destroy(d2g_k3_state *st) {
     if (!st) return;
-    (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor); (void)hipFree(st->d_l2);
+    (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor); (void)hipFree(st->d_l2); (void)hipFree(st->d_blk_coarse); (void)hipFree(st->d_gq); (void)hipFree(st->d_gq_off);
     (void)hipFree(st->d_keys); (void)hipFree(st->d_skeys); (void)hipFree(st->d_sub_off); (void)hipFree(st->d_gsplit); (void)hipFree(st->d_gsub); (void)hipFree(st->d_h); (void)hipFree(st->d_tw);
     (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
     (void)hipFree(st->d_out_keys); (void)hipFree(st->d_gblk); (void)hipFree(st->d_tile_cnt); (void)hipFree(st->d_tile_off);
@@ -1281,6 +1327,8 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
             D2G_HIP(ctx, hipMemcpyAsync(st->d_l2 + nl2, kh.l2_bits.data(), nl2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
             a.coarse = st->d_skeys; a.l2_tb0 = st->d_l2; a.l2_bits = st->d_l2 + nl2;
         }
+        if (int rc = d2g_grow(ctx, &st->d_blk_coarse, &st->cap_blk_coarse, std::max<size_t>(nblk, 1) << kh.l1bits)) return rc;
+        a.blk_coarse = st->d_blk_coarse;
         if (nblk) hipLaunchKernelGGL(k3_hist_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
         hipLaunchKernelGGL(k3_scan_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, a);
         if (nblk) hipLaunchKernelGGL(k3_scatter_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
@@ -1340,14 +1388,62 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
                            st->d_h, n * m, st->d_tw, st->d_redo, n);
         const unsigned main_grid = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * 8);
         st->last_nredo = 0;
+        // First pass in the light form: survivors go to per-workgroup regions of a queue in HBM.  A region holds twice the
+        // survivors its buckets are expected to produce: genome g yields at most gk strips in all (an element of count c has
+        // <= c strips) and about gk * guess of them survive, spread evenly over its buckets.
+        bool light = TB > 0 && !D2G_K3_EXP;
+        if (const char *e = std::getenv("D2G_K3_LIGHT")) if (e[0] == '0') light = false;
+        if (light) {
+            const uint32_t per = (TB + main_grid - 1) / main_grid;
+            std::vector<double> pre(TB ? n + 1 : 1, 0.);       // expected survivors per bucket, genome by genome
+            std::vector<uint64_t> off(main_grid + 1, 0);
+            size_t g = 0;
+            for (unsigned w = 0; w < main_grid; ++w) {
+                const uint64_t lo = (uint64_t)w * per, hi = std::min<uint64_t>(lo + per, TB);
+                double e = 0.;
+                while (g < n && kh.gtab[n + g] + (1ull << kh.gtab[g]) <= lo) ++g;
+                for (size_t gg = g; gg < n && kh.gtab[n + gg] < hi; ++gg) {
+                    const uint64_t b0 = kh.gtab[n + gg], B = 1ull << kh.gtab[gg];
+                    const uint64_t ov = std::min<uint64_t>(hi, b0 + B) - std::max<uint64_t>(lo, b0);
+                    double gv; std::memcpy(&gv, &guess[gg], 8);
+                    const double eg = (double)kh.gk[gg] * std::min(1.0, gv);
+                    e += eg * (double)ov / (double)B;
+                }
+                off[w + 1] = off[w] + (uint64_t)(2.0 * e) + 1024;
+            }
+            if (int rc = d2g_grow(ctx, &st->d_gq, &st->cap_gq, (size_t)off[main_grid] * (sizeof(QEntry) / 8))) return rc;
+            if (int rc = d2g_grow(ctx, &st->d_gq_off, &st->cap_gq_off, (size_t)main_grid + 1 + (main_grid + 1) / 2 + 1)) return rc;
+            D2G_HIP(ctx, hipMemcpyAsync(st->d_gq_off, off.data(), (main_grid + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+            b.gq = reinterpret_cast<QEntry *>(st->d_gq); b.gq_off = st->d_gq_off;
+            b.gq_n = reinterpret_cast<uint32_t *>(st->d_gq_off + main_grid + 1);
+        }
         for (int pass = 0;; ++pass) {
             b.redo_mode = pass > 0;
-            if (TB && D2G_K3_EXP != 1 && D2G_K3_EXP != 2 && D2G_K3_EXP != 6 && D2G_K3_EXP != 7)
-                hipLaunchKernelGGL(kh.compact ? k3_bmh_main_kernel<true> : k3_bmh_main_kernel<false>, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+            const bool lt = light && pass == 0;
+            if (TB && D2G_K3_EXP != 1 && D2G_K3_EXP != 2 && D2G_K3_EXP != 6 && D2G_K3_EXP != 7) {
+                void (*light_k)(BmhArgs) = k3_bmh_main_kernel<false, true>, (*heavy_k)(BmhArgs) = k3_bmh_main_kernel<false, false>;
+                if (kh.compact) { light_k = k3_bmh_main_kernel<true, true>; heavy_k = k3_bmh_main_kernel<true, false>; }
+                if (lt) {
+                    hipLaunchKernelGGL(light_k, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+                    hipLaunchKernelGGL(k3_bmh_survivor_kernel, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+                } else
+                    hipLaunchKernelGGL(heavy_k, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+            }
             hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, b);
             int st2[2] = {0, 0};                                  // [0] kernel status, [1] genomes whose guess failed
             D2G_HIP(ctx, hipMemcpyAsync(st2, st->d_status, sizeof(st2), hipMemcpyDeviceToHost, s));
             D2G_HIP(ctx, hipStreamSynchronize(s));
+            if (lt && st2[0] == 4) {
+                // a survivor region overflowed (the estimate above is an expectation): the pass again, in the heavy form
+                light = false;
+                D2G_HIP(ctx, hipMemsetAsync(st->d_status, 0, 2 * sizeof(int), s));
+                D2G_HIP(ctx, hipMemsetAsync(st->d_tw_bucket, 0, ((size_t)TB + 1) * sizeof(double), s));
+                hipLaunchKernelGGL(k3_bmh_init_kernel, dim3((unsigned)div_up<size_t>(ninit, K3_THREADS)), dim3(K3_THREADS), 0, s,
+                                   st->d_h, n * m, st->d_tw, st->d_redo, n);
+                st->light_overflows++;
+                --pass;
+                continue;
+            }
             const int nredo = st2[1];
             if (st2[0] || !nredo || D2G_K3_EXP) break;
             st->last_nredo += nredo;
