@@ -742,8 +742,9 @@ def main():
             """HBM bytes per call of this variant's kernels from the committed PMC passes, or None"""
             if not (world == 1 and nb == 250 and L == 5_000_000):
                 return None
-            want = (("k3c_hist", "k3c_scan", "k3c_scatter", "k3_split_kernel", "k3_bmh_main_kernel<true>", "k3_bmh_verify", "k3_bmh_init") if compact else
-                    ("k3_hist_kernel", "k3_scan_kernel", "k3_scatter_kernel", "k3_bmh_main_kernel<false>", "k3_bmh_verify", "k3_bmh_init"))
+            want = (("k3c_hist", "k3c_scan", "k3c_scatter", "k3_split_kernel", "k3_bmh_main_kernel<true, true>", "k3_bmh_survivor", "k3_bmh_verify", "k3_bmh_init") if compact else
+                    ("k3_hist_kernel", "k3_scan_kernel", "k3_scatter_kernel", "k3_refine_kernel", "k3_bmh_main_kernel<false, true>", "k3_bmh_survivor", "k3_bmh_verify",
+                     "k3_bmh_init"))
             try:
                 d = json.load(open(PMC_FILE))
                 tr = [v["hbm_read_bytes_raw"] + v["hbm_write_bytes"] for kk, v in d.items() if any(w in kk for w in want) and "hbm_write_bytes" in v]
@@ -768,8 +769,8 @@ def main():
         traffic = k3_traffic(False)
         low_traffic = {"switch": "D2G_K3_COMPACT=1 (k <= 21)", "value": n_g * L * world / (cdt / reps), "unit": "bases/s", "kernel_ms": ck3_ms,
                        "traffic": k3_traffic(True), "registers_identical_to_default": same,
-                       "note": "4-byte stored k-mer words, LDS tile sort, coalesced flush: about half the HBM traffic, ~10 % more time (a Wang mix per "
-                               "distinct k-mer moves into the issue-bound main pass) -- not the default"}
+                       "note": "4-byte stored k-mer words, LDS tile sort, coalesced flush: about half the HBM traffic, more time (a Wang mix per "
+                               "distinct k-mer moves into the issue-bound main pass, and every bucket is split once more) -- not the default"}
 
         def build(mdt):
             out = {"metric": "multiset sketch input bases/s (K3: exact k-mer counts + BagMinHash, packed bases resident in HBM)",
@@ -779,7 +780,7 @@ def main():
                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                 "traffic": traffic,
                                 "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE per call, same shape, profiles/r02_pmc.json",
-                                "kernel": "k3 chain (hist, scan, scatter, bmh_main, verify)",
+                                "kernel": "k3 chain (hist, scan, scatter, refine, bmh_main, survivors, verify)",
                                 "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
                                 "note": "per call of %d genomes; the chain also writes and re-reads the bucketed k-mer keys, "
                                         "which the compulsory-byte figure does not count" % nb},

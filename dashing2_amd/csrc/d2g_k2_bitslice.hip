@@ -36,6 +36,7 @@ constexpr int BS_RANK_THREADS = 1024;
 // storage and no reserved sentinel value is needed.
 constexpr uint32_t BS_DUP = 0x80000000u;       // owner-table flag: the value has been seen again
 constexpr uint32_t BS_UNIQ = 0x80000000u;      // id flag: value occurs once in its column (never equal)
+constexpr uint32_t BS_PENDING = 0x40000000u;   // multi-partition rank kernel: ids[] holds a table slot of the current pass
 constexpr int BS_LOG_TLDS_MAX = 15;            // LDS owner table: at most 32768 slots = 128 KiB
 
 __device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
@@ -52,7 +53,9 @@ __device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
 // *owner sketch indices* (equality is decided against the owner's value: no key storage, no
 // reserved sentinel), compacts the slots whose value was seen again into dense ranks, and
 // writes the ids of that partition.  T >= 1.5 N, so a partition holds <= 2/3 Tl values on average.
-template <bool MULTI>   // MULTI: more than one partition (N > 21845)
+// MULTI: more than one partition (N > 21845).  FAST: one partition and N <= 12288 -- a thread keeps all its values in
+// registers; a kernel of its own so that the general path's registers do not cost it the second workgroup per CU.
+template <bool MULTI, bool FAST>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
                                                                   uint32_t T, int logT, uint32_t *ids_all, uint32_t *max_distinct,
                                                                   uint32_t *status, int tagbits_max) {
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
     };
 
     constexpr int PF = 12;      // values a thread keeps in registers (fast path: N <= 12288, one partition)
-    if (!MULTI && N <= (size_t)PF * BS_RANK_THREADS) {
+    if constexpr (FAST) {
         // every value is fetched BEFORE the probe chains (a load inside the chain exposed a full HBM/L2 round
         // trip per value) and its slot stays in a register until the ids are written.
         // Two phases.  (1) claim: probe with LDS compare-and-swaps only; stop at the first slot that is won or
@@ -218,17 +221,86 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
     for (uint32_t part = 0; part < nparts; ++part) {
         for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
         __syncthreads();
-        for (size_t j = tid; j < N; j += BS_RANK_THREADS) {
-            const uint64_t v = col[j];
-            const uint32_t hh = bs_hash(v, logT);
-            if (MULTI && (hh >> logTl) != part) continue;
-            ids[j] = insert(v, (uint32_t)j, hh & mask);
+        // values are fetched PG at a time before their probe chains, and a batch goes through the same two phases as the
+        // fast path: claim with LDS compare-and-swaps only, then confirm the candidates with their owner fetches in flight
+        // together (with one 128 KiB-table workgroup per CU nothing else hides a round trip)
+        constexpr int PG = 8;
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)PG * BS_RANK_THREADS) {
+            uint64_t v[PG];
+            uint32_t hs[PG];
+#pragma unroll
+            for (int i = 0; i < PG; ++i) {
+                const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
+                v[i] = j < N ? col[j] : 0;
+            }
+            uint32_t mineb = 0, candidate = 0, redo = 0;
+#pragma unroll
+            for (int i = 0; i < PG; ++i) {
+                const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
+                const uint64_t prod = v[i] * 0x9E3779B97F4A7C15ull;
+                const uint32_t hh = (uint32_t)(prod >> (64 - logT));
+                hs[i] = 0;
+                if (j < N && (!MULTI || (hh >> logTl) == part)) {
+                    mineb |= 1u << i;
+                    const uint32_t mine = slot_word(prod, (uint32_t)j);
+                    uint32_t h = hh & mask, probes = 0;
+                    for (; probes < Tl; ++probes) {
+                        const uint32_t cur = atomicCAS(&own[h], BS_EMPTY, mine);
+                        if (cur == BS_EMPTY) break;
+                        if (!((cur ^ mine) & tagfield)) { candidate |= 1u << i; break; }
+                        h = (h + 1) & mask;
+                    }
+                    if (probes == Tl) atomicOr(status, 1u);
+                    hs[i] = h;
+                }
+            }
+            {
+                uint32_t o[PG];
+                uint64_t w[PG];
+#pragma unroll
+                for (int i = 0; i < PG; ++i)
+                    if (candidate >> i & 1) o[i] = own[hs[i]];
+#pragma unroll
+                for (int i = 0; i < PG; ++i)
+                    if (candidate >> i & 1) w[i] = col[o[i] & idxmask];
+#pragma unroll
+                for (int i = 0; i < PG; ++i)
+                    if (candidate >> i & 1) {
+                        if (w[i] == v[i]) { if (!(o[i] & BS_DUP)) atomicOr(&own[hs[i]], BS_DUP); }
+                        else redo |= 1u << i;
+                    }
+            }
+            // MULTI: a slot written in this pass carries BS_PENDING (never set in a final id: ranks stay below 2^30, BS_UNIQ is
+            // bit 31), so that the pass's second loop finds its values in ids[] alone, without re-reading and re-hashing the
+            // column -- the kernel is bound by its column reads at this size.  Pass 0 writes every id (0 = not yet placed).
+#pragma unroll
+            for (int i = 0; i < PG; ++i) {
+                const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
+                if ((mineb & ~redo) >> i & 1) ids[j] = hs[i] | (MULTI ? BS_PENDING : 0u);
+                else if (MULTI && part == 0 && j < N && !(redo >> i & 1)) ids[j] = 0;
+            }
+            while (redo) {                                                // tag collisions: the exact chain from the home slot
+                const int i = __ffs(redo) - 1;
+                redo &= redo - 1;
+                const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
+                const uint64_t vv = col[j];
+                ids[j] = insert(vv, (uint32_t)j, bs_hash(vv, logT) & mask) | (MULTI ? BS_PENDING : 0u);
+            }
         }
         __syncthreads();
         compact();
-        for (size_t j = tid; j < N; j += BS_RANK_THREADS) {
-            if (MULTI && (bs_hash(col[j], logT) >> logTl) != part) continue;
-            ids[j] = own[ids[j]];
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)PG * BS_RANK_THREADS) {
+            uint32_t sl[PG];
+#pragma unroll
+            for (int i = 0; i < PG; ++i) {
+                const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
+                sl[i] = j < N ? ids[j] : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < PG; ++i) {
+                const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
+                if (j < N && (!MULTI || (sl[i] & BS_PENDING))) ids[j] = own[sl[i] & ~BS_PENDING];
+            }
         }
         __syncthreads();
     }
@@ -565,7 +637,9 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     {
         const int logTl = set->logT < BS_LOG_TLDS_MAX ? set->logT : BS_LOG_TLDS_MAX;
         const size_t lds = (size_t(1) << logTl) * sizeof(uint32_t);
-        auto kern = set->logT > BS_LOG_TLDS_MAX ? bs_rank_kernel<true> : bs_rank_kernel<false>;
+        void (*kern)(const uint64_t *, size_t, size_t, uint32_t, int, uint32_t *, uint32_t *, uint32_t *, int) = bs_rank_kernel<false, false>;
+        if (set->logT > BS_LOG_TLDS_MAX) kern = bs_rank_kernel<true, false>;
+        else if (N <= (size_t)12 * BS_RANK_THREADS) kern = bs_rank_kernel<false, true>;     // PF * BS_RANK_THREADS
         int tagbits_max = 31;
         if (const char *e = std::getenv("D2G_BS_TAGBITS")) { const int v = std::atoi(e); if (v >= 0 && v < 31) tagbits_max = v; }   // tests
         if (lds > 48 * 1024)

@@ -260,10 +260,14 @@ def test_row_sharded_allpairs_world1(gpu_ctx, d2g, oracle):
     eng.close()
 
 
-def test_k2_large_n_multi_partition(gpu_ctx, d2g):
-    """N > 21 845 takes the multi-partition rank kernel (hash space walked in LDS-sized pieces).
-    Checked against the independent DIRECT algorithm and the column-count checksum."""
-    N, S = 23_000, 64
+@pytest.mark.parametrize("N,tagbits", [(23_000, None), (23_000, "9"), (14_000, None), (14_000, "9")])
+def test_k2_large_n_multi_partition(gpu_ctx, d2g, monkeypatch, N, tagbits):
+    """N > 21 845 takes the multi-partition rank kernel (hash space walked in LDS-sized pieces), 12 288 < N <= 21 845 the
+    general single-partition one; with D2G_BS_TAGBITS=9 a few hundred values per column collide on their tag and go
+    through the exact serial chain.  Checked against the independent DIRECT algorithm and the column-count checksum."""
+    if tagbits:
+        monkeypatch.setenv("D2G_BS_TAGBITS", tagbits)
+    S = 64
     regs = synth.synthetic_registers(N, S, nclusters=120, seed=3)
     cs = gpu_ctx.cmp_set(regs, algo=d2g.CMP_BITSLICE)
     a = cs.eqcount_ut()
