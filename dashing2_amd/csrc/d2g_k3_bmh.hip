@@ -431,14 +431,16 @@ __device__ bool count_round(const CountTab<C32> &t, const typename K3Key<C32>::T
 // round is insert -> barrier -> walk+clear -> barrier.  Probing goes compare-and-swap first: one LDS operation and two
 // compares per probe (the read-first loop of count_round spends twice the vector instructions; the kernel is bound by
 // instruction issue, not by the LDS atomic rate: profiles/r02_k3_ablation.txt).
-template <bool C32>
+// GUARD = false (single-round ranges: n <= round_keys < K3_TAB keys, the table cannot fill): the probe loop carries no
+// probe counter -- its bookkeeping was 13 scalar instructions per probe next to 6 vector ones.
+template <bool C32, bool GUARD>
 __device__ bool insert_round(const CountTab<C32> &t, const typename K3Key<C32>::T *kb, uint64_t n, uint32_t R, uint32_t r, uint32_t shift,
                              uint32_t bb) {
     typedef typename K3Key<C32>::T KT;
     constexpr KT EMPTY = K3Key<C32>::EMPTY;
     const int tid = threadIdx.x;
     bool ok = true;
-    constexpr int K3_KPF = C32 ? 8 : 6;
+    constexpr int K3_KPF = 6;
     for (uint64_t base = 0; base < n && ok; base += (uint64_t)K3_KPF * K3_THREADS) {
         KT kreg[K3_KPF];
 #pragma unroll
@@ -446,29 +448,44 @@ __device__ bool insert_round(const CountTab<C32> &t, const typename K3Key<C32>::
             const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
             kreg[j] = i < n ? kb[i] : 0;
         }
+        uint32_t n_ones = 0;                                              // the all-ones key cannot live in the table (rare: one branch per batch)
 #pragma unroll
         for (int j = 0; j < K3_KPF; ++j) {
             const uint64_t i = base + (uint64_t)j * K3_THREADS + tid;
             const KT key = kreg[j];
             const bool mine = i < n && (R == 1 || K3Key<C32>::round_of(key, R, shift, bb) == r);
-            if (mine && key == EMPTY) atomicAdd(t.ones, 1u);
+            n_ones += mine & (key == EMPTY);
             if (!mine || key == EMPTY) continue;
             if (D2G_K3_EXP == 8) { if (key == 12345) atomicAdd(t.ones, 1u); continue; }   // timing experiment: loads, no inserts
             uint32_t s = K3Key<C32>::slot(key);
-            int probes = 0;
-            bool placed;
-            for (;;) {
-                KT old;
-                if constexpr (C32) old = atomicCAS(&t.key[s], EMPTY, key);
-                else old = (KT)atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)EMPTY, (unsigned long long)key);
-                placed = (old == EMPTY) | (old == key);
-                if (placed | (++probes >= K3_TAB)) break;
-                s = (s + 1) & (K3_TAB - 1);
+            if constexpr (GUARD) {
+                int probes = 0;
+                bool placed;
+                for (;;) {
+                    KT old;
+                    if constexpr (C32) old = atomicCAS(&t.key[s], EMPTY, key);
+                    else old = (KT)atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)EMPTY, (unsigned long long)key);
+                    placed = (old == EMPTY) | (old == key);
+                    if (placed | (++probes >= K3_TAB)) break;
+                    s = (s + 1) & (K3_TAB - 1);
+                }
+                if (placed) atomicAdd(&t.cnt[s], 1u); else ok = false;
+            } else {
+                for (;;) {
+                    KT old;
+                    if constexpr (C32) old = atomicCAS(&t.key[s], EMPTY, key);
+                    else old = (KT)atomicCAS((unsigned long long *)&t.key[s], (unsigned long long)EMPTY, (unsigned long long)key);
+                    if ((old == EMPTY) | (old == key)) break;
+                    s = (s + 1) & (K3_TAB - 1);
+                }
+                atomicAdd(&t.cnt[s], 1u);
             }
-            if (placed) atomicAdd(&t.cnt[s], 1u); else ok = false;
         }
+        if (n_ones) atomicAdd(t.ones, n_ones);
     }
-    return !__syncthreads_or(!ok);
+    if constexpr (GUARD) return !__syncthreads_or(!ok);
+    __syncthreads();
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -921,7 +938,9 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(LIGH
             uint32_t R = 1;
             while ((uint64_t)R * a.round_keys < rn) R <<= 1;
             for (uint32_t r = 0; r < R; ++r) {
-                if (!insert_round<C32>(t, kb, rn, R, r, shift, bb)) return false;
+                // a single round over at most round_keys (< K3_TAB) keys cannot fill the table
+                if (R == 1 && rn < (uint64_t)K3_TAB) insert_round<C32, false>(t, kb, rn, 1, 0, shift, bb);
+                else if (!insert_round<C32, true>(t, kb, rn, R, r, shift, bb)) return false;
                 // Walk the table slots directly, emptying them on the way.  (r01 squeezed the occupied slots into a dense list
                 // first -- worth it when the per-element walk was heavy; the compaction, 3.5 ms per call with its three
                 // barriers per round, costs more than the 40 % idle lanes here.)
