@@ -1412,6 +1412,9 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         // <= c strips) and about gk * guess of them survive, spread evenly over its buckets.
         bool light = TB > 0 && !D2G_K3_EXP;
         if (const char *e = std::getenv("D2G_K3_LIGHT")) if (e[0] == '0') light = false;
+        double gq_scale = 2.0;
+        uint64_t gq_slack = 1024;
+        if (const char *e = std::getenv("D2G_K3_GQ_SCALE")) { gq_scale = std::max(0.0, std::atof(e)); gq_slack = 1; }   // tests force the overflow path
         if (light) {
             const uint32_t per = (TB + main_grid - 1) / main_grid;
             std::vector<double> pre(TB ? n + 1 : 1, 0.);       // expected survivors per bucket, genome by genome
@@ -1428,7 +1431,7 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
                     const double eg = (double)kh.gk[gg] * std::min(1.0, gv);
                     e += eg * (double)ov / (double)B;
                 }
-                off[w + 1] = off[w] + (uint64_t)(2.0 * e) + 1024;
+                off[w + 1] = off[w] + (uint64_t)(gq_scale * e) + gq_slack;
             }
             if (int rc = d2g_grow(ctx, &st->d_gq, &st->cap_gq, (size_t)off[main_grid] * (sizeof(QEntry) / 8))) return rc;
             if (int rc = d2g_grow(ctx, &st->d_gq_off, &st->cap_gq_off, (size_t)main_grid + 1 + (main_grid + 1) / 2 + 1)) return rc;

@@ -152,6 +152,9 @@ def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
                 {"D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},        # ... and sub-ranges that still need rounds
                 {"D2G_K3_L1BITS": "3"}, {"D2G_K3_L1BITS": "0"},                # two-level scatter (genomes above ~260 kbp): 8 / 1 write fronts, then k3_refine_kernel
                 {"D2G_K3_L1BITS": "12"},                                       # ... and never (the single-level scatter)
+                {"D2G_K3_LIGHT": "0"},                                         # first pass in the heavy form (survivors walked in the counting kernel)
+                {"D2G_K3_GQ_SCALE": "0.05"},                                   # survivor regions far too small: overflow -> the pass is repeated in the heavy form
+                {"D2G_K3_GQ_SCALE": "0.3", "D2G_K3_GUESS_SCALE": "0.01"},      # ... and together with a failed bound guess
                 {"D2G_K3_L1BITS": "2", "D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},
                 {"D2G_K3_COMPACT": "1"}, {"D2G_K3_COMPACT": "1", "D2G_K3_ROUND_KEYS": "64"}, {"D2G_K3_COMPACT": "1", "D2G_K3_GUESS_SCALE": "0.001"},
                 {"D2G_K3_COMPACT": "1", "D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},
