@@ -122,7 +122,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_scan_kernel(K3Args a) {
 // Write-combining decides this pass.  A workgroup's 65 536 k-mers leave ~16 keys = one 128-byte line in each of 4096
 // buckets, but every 8-byte store is a separate partial write and 4096 open lines per workgroup x 160 workgroups per XCD
 // do not live in a 4 MB L2 until they are full: measured 38 GB of HBM writes for 10 GB of keys, 14.4 ms.  With <= 256
-// write fronts per workgroup the L2 completes the lines before it evicts them (6.4 ms at 256 fronts, 5.1 ms at 64).  So
+// write fronts per workgroup most lines are completed first (6.4 ms at 256 fronts, 5.1 ms at 64; the number of workgroups per
+// CU makes no difference, 2 or 8: it is the fronts one workgroup keeps open that count).  So
 // genomes with more than 2^l1bits buckets are split in two levels: here by the top l1bits of the bucket index -- the
 // coarse bucket's region is the union of its buckets' regions, reserved through the cursor of its first bucket -- and
 // then by the remaining bits, per coarse bucket, in k3_refine_kernel (<= 2^(12 - l1bits) fronts per workgroup there).
@@ -1415,6 +1416,13 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         double gq_scale = 2.0;
         uint64_t gq_slack = 1024;
         if (const char *e = std::getenv("D2G_K3_GQ_SCALE")) { gq_scale = std::max(0.0, std::atof(e)); gq_slack = 1; }   // tests force the overflow path
+        if (light) {
+            // batches of read-sized inputs: the bound of a tiny input is above 1 and every element survives -- a queue of
+            // 24 bytes per k-mer would buy nothing; such batches keep the heavy form
+            double etot = 0.;
+            for (size_t g = 0; g < n; ++g) { double gv; std::memcpy(&gv, &guess[g], 8); etot += (double)kh.gk[g] * std::min(1.0, gv); }
+            if (etot > 0.125 * (double)kh.total) light = false;
+        }
         if (light) {
             const uint32_t per = (TB + main_grid - 1) / main_grid;
             std::vector<double> pre(TB ? n + 1 : 1, 0.);       // expected survivors per bucket, genome by genome
