@@ -449,6 +449,21 @@ def main():
             else:
                 exchange_fallback += " | " + err2
                 sharded = False
+    pipeline_probe = None
+    if sharded and pipelined:
+        # the overlapped form is probed (two steps + a sync) on every rank before anything is timed: if it fails anywhere, every
+        # rank drops to the plain step together instead of dying inside the timed loop
+        perr = None
+        try:
+            step(); step()
+            torch.cuda.synchronize()
+        except Exception as e:                                   # noqa: BLE001
+            perr = f"{type(e).__name__}: {e}"
+        perr = all_failed(perr)
+        if perr is not None:
+            pipeline_probe = "pipelined step failed (" + perr + "): measured with the plain step"
+            pipelined = False
+            step = plain_step
     if sharded:
         del sig_dev
     else:
@@ -811,7 +826,8 @@ def main():
                        "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count",
                        **({"exchange_engine": engine_kind} if engine_kind else {}),
                        **({"exchange_fallback": exchange_fallback} if exchange_fallback else {}),
-                       **({"pipelined_exchange": pipeline_check} if pipeline_check else {})},
+                       **({"pipelined_exchange": pipeline_check} if pipeline_check else {}),
+                       **({"pipelined_probe": pipeline_probe} if pipeline_probe else {})},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "config4_1gpu": config4,
             "sketch": sketch, "multiset_sketch": multiset,
         }
