@@ -904,7 +904,8 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(LIGH
     // here takes the unchanged proc_next, which decides): a k-mer seen once costs one xor, one generator step, one compare.
     auto strip0_floor = [](double bnd) -> uint64_t {
         const double b53 = bnd * 1.0 * 1.000000001 * 0x1p53;
-        if (!(b53 < 9007199254740988.0)) return 0;
+        if (!(b53 < 9007199254740988.0)) return 0;                       // large (or NaN) bound: everything goes to the exact test
+        if (!(b53 >= 0.)) return 9007199254740989ull;                      // (a negative bound drops everything there too)
         return 9007199254740991ull - 2ull - (uint64_t)b53;
     };
     uint64_t u0 = strip0_floor(bound);
