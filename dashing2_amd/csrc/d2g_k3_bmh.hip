@@ -7,14 +7,17 @@
 //
 // The reference counts with one robin-hood hash map per thread and feeds (kmer, count) to the
 // sketch one at a time.  Here:
-//   1. k3_hist / k3_scan / k3_scatter  : every masked k-mer key = Wang(kmer ^ XORMASK) of a genome is
-//      multi-split by its top bits into <= 4096 buckets of ~1-2 K keys (LDS-aggregated histogram,
-//      one global reservation per (workgroup, bucket)); k-mers are re-generated from the packed
-//      bases in each pass instead of being stored (generation is ~100 VALU slots, a store+load is 16 B).
-//   2. k3_bmh_main / k3_bmh_verify     : persistent workgroups walk the buckets; each bucket is counted
+//   1. k3_hist / k3_scan / k3_scatter / k3_refine : every masked k-mer key = Wang(kmer ^ XORMASK) of a genome is
+//      multi-split by its top bits into <= 4096 buckets of ~1-2 K keys (LDS-aggregated histogram, one global
+//      reservation per (workgroup, write front)), in two levels so that a workgroup keeps <= 256 write fronts open
+//      and the L2 completes the lines (see k3_scatter_kernel); k-mers are re-generated from the packed bases in
+//      each enumerating pass instead of being stored (generation is ~100 VALU slots, a store+load is 16 B).
+//   2. k3_bmh_main / k3_bmh_survivor / k3_bmh_verify : persistent workgroups walk the buckets; each bucket is counted
 //      exactly in a 2048-slot LDS open-addressing table (ds_cmpst_b64 claim + ds_add), then every occupied
-//      slot IS one (key, count) element and the BagMinHash Poisson-process tree is walked for it,
-//      depth-first with a private stack, pruned against a bound of the genome's final maximum register.
+//      slot IS one (key, count) element: the first point of each of its top-level strips is tested against a bound
+//      of the genome's final maximum register (99 % stop there), the survivors are queued -- in HBM, walked by the
+//      survivor kernel one per lane (first pass), or in LDS and drained in place (repeat passes) -- and the
+//      BagMinHash Poisson-process tree is walked for them depth-first with a private stack.
 //      Registers live in HBM/L2 as the bit patterns of non-negative doubles and are lowered with
 //      global_atomic_umin_x2 behind a read filter.
 //      min is order-free and pruning by ANY bound >= the final maximum only drops points that cannot win,
