@@ -17,6 +17,9 @@ CMP_AUTO, CMP_DIRECT, CMP_BITSLICE = 0, 1, 2
 BITSLICE_OPS_PER_GROUP_EXTRA = 1
 
 
+TIME_K1, TIME_K2, TIME_K2PREP, TIME_K3 = 2, 4, 8, 16          # include/d2g.h D2G_TIME_*
+
+
 class D2GError(RuntimeError):
     def __init__(self, status, detail=""):
         self.status = status
@@ -367,6 +370,8 @@ class Context:
         self._check(lib().d2g_sync(self._h, stream))
 
     def set_timing(self, on=True):
+        """True / False, or an OR of TIME_K1 / TIME_K2 / TIME_K2PREP / TIME_K3 (time only what is reported: an event pair in
+        the stream costs a few microseconds of device time per launch)"""
         self._check(lib().d2g_set_timing(self._h, int(on)))
 
     def kernel_ms(self, which, reset=True):

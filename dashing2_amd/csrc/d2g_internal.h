@@ -15,7 +15,7 @@ struct d2g_ctx {
     int device = -1;
     int num_cus = 0;
     std::string last_error;
-    bool timing = false;
+    int timing = 0;                         // D2G_TIME_* mask (d2g_set_timing)
     d2g_evlog ev_k1, ev_k2, ev_k2prep, ev_k3;
     struct d2g_k3_state *k3 = nullptr;      // work buffers of d2g_bmh_sketch_dev (d2g_k3_bmh.hip)
 };
@@ -42,7 +42,9 @@ void d2g_k3_state_destroy(struct d2g_k3_state *st);
 // elapsed times are read lazily by d2g_kernel_ms (which synchronises on the stop events).
 struct d2g_timer {
     d2g_evlog *ev; hipStream_t s; bool on;
-    d2g_timer(d2g_ctx *c, d2g_evlog *e, hipStream_t st) : ev(e), s(st), on(c->timing) {
+    d2g_timer(d2g_ctx *c, d2g_evlog *e, hipStream_t st) : ev(e), s(st), on(false) {
+        const int bit = e == &c->ev_k1 ? D2G_TIME_K1 : e == &c->ev_k2 ? D2G_TIME_K2 : e == &c->ev_k2prep ? D2G_TIME_K2PREP : D2G_TIME_K3;
+        on = (c->timing & bit) != 0;
         if (on) {
             hipEvent_t x = nullptr, y = nullptr;
             if (hipEventCreate(&x) != hipSuccess || hipEventCreate(&y) != hipSuccess) { on = false; return; }

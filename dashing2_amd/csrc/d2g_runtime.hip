@@ -93,7 +93,7 @@ int d2g_memcpy_d2h(d2g_ctx *c, void *dst, const void *src, size_t n, void *strea
 
 int d2g_set_timing(d2g_ctx *c, int enabled) {
     if (!c) return D2G_ERR_INVALID;
-    c->timing = enabled != 0;
+    c->timing = enabled == 1 ? (D2G_TIME_K1 | D2G_TIME_K2 | D2G_TIME_K2PREP | D2G_TIME_K3) : (enabled & ~1);
     return D2G_OK;
 }
 

@@ -78,6 +78,12 @@ int         d2g_memcpy_d2h(d2g_ctx *ctx, void *dst_host, const void *src_dev, si
  * bracketed by events recorded on the launch stream; nothing synchronises until d2g_kernel_ms,
  * which reports the number of logged launches, their average and the last duration (ms) and
  * optionally clears the log. */
+#define D2G_TIME_K1     2
+#define D2G_TIME_K2     4
+#define D2G_TIME_K2PREP 8
+#define D2G_TIME_K3     16
+/* enabled: 0 = off, 1 = every kernel above, or an OR of D2G_TIME_* (an event pair in the stream costs a few microseconds of
+ * device time per launch: time only what is being reported) */
 int         d2g_set_timing(d2g_ctx *ctx, int enabled);
 int         d2g_kernel_ms(d2g_ctx *ctx, const char *which, int reset, int *count, float *avg_ms, float *last_ms);
 
