@@ -22,6 +22,7 @@ struct d2g_cmp_set {
     uint32_t *d_ids = nullptr;    // workspace: [S][Npad] dense ids
     uint32_t T = 0; int logT = 0; // hash space of the rank kernel (power of two >= 1.5 N)
     bool borrowed = false;        // planes/meta belong to the caller (d2g_cmp_set_from_planes_dev)
+    bool want_exchange = false;   // d_planes is kept up to date by every prepare (set by the first export)
 };
 
 struct PairShape;
@@ -31,6 +32,7 @@ int  finish_shape(d2g_ctx *ctx, PairShape &sh, unsigned rb);   // d2g_k2.hip
 void d2g_bitslice_geometry(d2g_cmp_set *set);
 int  d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
+int  d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 void d2g_bitslice_free(d2g_cmp_set *set);
 int  d2g_bitslice_alloc_stream(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_status(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s);   // synchronises; D2G_ERR_INTERNAL on overflow

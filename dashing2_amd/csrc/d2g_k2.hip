@@ -405,6 +405,7 @@ int d2g_cmp_set_export_operand_dev(d2g_ctx *ctx, const d2g_cmp_set *set, uint32_
     D2G_CHECK(ctx, planes_out_dev && meta_out_dev, "export_operand: null output");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     const size_t words = (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride;
+    if (int rc = d2g_bitslice_export(ctx, const_cast<d2g_cmp_set *>(set), as_stream(stream))) return rc;
     D2G_HIP(ctx, hipMemcpyAsync(planes_out_dev, set->d_planes, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, as_stream(stream)));
     D2G_HIP(ctx, hipMemcpyAsync(meta_out_dev, set->d_meta, (size_t)set->ntb * sizeof(uint32_t), hipMemcpyDeviceToDevice, as_stream(stream)));
     return D2G_OK;

@@ -327,9 +327,10 @@ __device__ __forceinline__ size_t stream_slot(const uint32_t *meta, int tb) {
 //   stream  [sum_tb nbits_tb][2][Nstride] what the pair kernel walks: only the LIVE planes, in group order, each as the
 //                                        row-coded words followed by the column-coded words, so that the kernel's operand
 //                                        pointer simply advances by one block per plane (no per-plane address selection).
+constexpr int BS_FORM_STREAM = 1, BS_FORM_EXCHANGE = 2;
 __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t S, size_t N, size_t Npad,
                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
-                                                        size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta) {
+                                                        size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta, int forms) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tb = blockIdx.y;
     if (j >= Nstride) return;
@@ -343,17 +344,22 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
     uint32_t u = 0;                                    // the "unique" plane
 #pragma unroll
     for (int x = 0; x < 32; ++x) u |= (id[x] >> 31) << x;
+    // forms: BS_FORM_STREAM = what this GPU's pair kernel walks; BS_FORM_EXCHANGE = what ranks exchange -- written only
+    // once somebody has asked for it (d2g_bitslice_export: 29 MB of stores per prepare at config 3 that a single GPU never reads)
     uint32_t *dst = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
     uint32_t *sdst = stream + stream_slot(meta, (int)tb) * 2 * Nstride + j;
+    const bool ex = forms & BS_FORM_EXCHANGE, st = forms & BS_FORM_STREAM;
     for (int b = 0; b < nbits; ++b) {
         uint32_t w = 0;
 #pragma unroll
         for (int x = 0; x < 32; ++x) w |= ((id[x] >> b) & 1u) << x;
-        dst[(size_t)b * Nstride] = w;                  // row coding: unique = 0 (BS_UNIQ ids have zero low bits)
-        sdst[(size_t)(2 * b) * Nstride] = w;
-        sdst[(size_t)(2 * b + 1) * Nstride] = w | u;   // column coding: unique = all ones
+        if (ex) dst[(size_t)b * Nstride] = w;          // row coding: unique = 0 (BS_UNIQ ids have zero low bits)
+        if (st) {
+            sdst[(size_t)(2 * b) * Nstride] = w;
+            sdst[(size_t)(2 * b + 1) * Nstride] = w | u;   // column coding: unique = all ones
+        }
     }
-    dst[(size_t)nbits_cap * Nstride] = u;
+    if (ex) dst[(size_t)nbits_cap * Nstride] = u;
 }
 
 // plane stream of an operand that arrived in the exchanged form (the gathered operand of the multi-GPU path,
@@ -649,7 +655,18 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, S, N, Npad, set->d_planes, set->d_stream, set->Nstride,
-                       set->nbits_cap, set->d_meta);
+                       set->nbits_cap, set->d_meta, BS_FORM_STREAM | (set->want_exchange ? BS_FORM_EXCHANGE : 0));
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+// the exchange form of the operand last prepared: written from the ids on first request, by every prepare afterwards
+int d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
+    if (set->borrowed || set->want_exchange) return D2G_OK;
+    set->want_exchange = true;
+    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
+    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, set->S, set->N, set->Npad, set->d_planes, set->d_stream,
+                       set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
