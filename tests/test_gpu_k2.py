@@ -440,3 +440,22 @@ def test_k2_rank_tag_collisions(gpu_ctx, d2g, oracle, monkeypatch, tagbits):
         assert cs.algo == d2g.CMP_DIRECT
     np.testing.assert_array_equal(cs.eqcount_ut(), exp)
     cs.close()
+
+
+def test_timing_mask_brackets_only_what_is_asked(gpu_ctx, d2g):
+    """d2g_set_timing(mask): an event pair costs device time, so a caller brackets only the kernels it reports
+    (bench.py: the pair kernel inside the timed region, the prepare chain on the warmup steps)."""
+    rng = np.random.default_rng(5)
+    sigs = _planted(rng, 300, 64)
+    for mask, want in ((d2g.TIME_K2, (2, 0)), (d2g.TIME_K2PREP, (0, 1)), (True, (2, 1)), (False, (0, 0))):
+        gpu_ctx.set_timing(False)
+        gpu_ctx.kernel_ms("k2"), gpu_ctx.kernel_ms("k2prep")
+        gpu_ctx.set_timing(mask)
+        cs = gpu_ctx.cmp_set(sigs.view(np.uint64), algo=d2g.CMP_BITSLICE)       # one prepare
+        cs.eqcount_ut(), cs.eqcount_ut()                                         # two pair-kernel launches
+        gpu_ctx.set_timing(False)
+        n2, avg2, _ = gpu_ctx.kernel_ms("k2")
+        np_, avgp, _ = gpu_ctx.kernel_ms("k2prep")
+        assert (n2, np_) == want, (mask, n2, np_)
+        assert (avg2 > 0) == (n2 > 0) and (avgp > 0) == (np_ > 0)
+        cs.close()
