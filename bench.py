@@ -97,6 +97,31 @@ def pmc_traffic(kernel_substr, wide_loads):
     return rd + e["hbm_write_bytes"]
 
 
+def host_cores():
+    """CPUs this process may actually use: the visible CPUs, cut by the affinity mask and by the cgroup CPU quota (a GPU box
+    of this pool shows 256 CPUs and grants 16 of them; 256 threads under a 16-CPU quota only throttle each other)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -122,7 +147,7 @@ def cpu_baseline(sig_np, cards_np, S, seconds):
     """The oracle's OpenMP all-pairs (reference loop structure) on a bounded row sample."""
     lib, march = oracle_lib()
     import ctypes as C
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     N = sig_np.shape[0]
     P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
     bs = lib.d2o_default_batchsize(0, S, ncores)
@@ -156,7 +181,7 @@ def cpu_baseline_sketch(fastas, L, k, S, seconds):
     import tempfile
     from dashing2_amd import synth
     lib, march = oracle_lib()
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     m = S + (S & 1)
 
     def one(buf):
@@ -239,7 +264,7 @@ def cpu_baseline_multiset(L, k, S):
     from dashing2_amd import synth
     lib, march = oracle_lib()
     import ctypes as C
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
     Ls = min(L, 2_000_000)
     buf = synth.fasta_bytes_fast("g", synth.random_genome(7, Ls))
 
@@ -263,7 +288,7 @@ def pack_genomes(D, synth, first, count, L, k, keep=0, nthreads=None):
     """`count` synthetic genomes (indices first..) -> FASTA bytes -> d2g_seqpack (the product's ingest), on
     all host cores; returns one merged packed run stream + the first `keep` FASTA buffers."""
     from concurrent.futures import ThreadPoolExecutor
-    nthreads = nthreads or min(os.cpu_count() or 1, 64)
+    nthreads = nthreads or min(host_cores(), 64)
     chunks = [list(range(first + c, min(first + count, first + c + 8))) for c in range(0, count, 8)]
 
     def work(idx):
@@ -334,7 +359,7 @@ def main():
     my_pairs = D.ut_count(N, r0, r1)
     sharded = (world > 1 and args.exchange == "alltoall") or args.force_sharded
     stream = torch.cuda.current_stream().cuda_stream
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
 
     def make_sketches(n, seed=20260928):
         regs = synth.synthetic_registers(n, S, nclusters=max(8, n // 150), seed=seed)

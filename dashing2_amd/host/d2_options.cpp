@@ -1,4 +1,8 @@
 #include "d2_options.h"
+#include <sched.h>
+#include <cstdio>
+#include <fstream>
+#include <thread>
 #include "../../include/d2g.h"
 #include <algorithm>
 #include <cstdio>
@@ -204,6 +208,40 @@ int parse_options(int argc, char **argv, Options &o) {
         return 1 + 1;
     }
     return 0;
+}
+
+}  // namespace d2h
+
+
+namespace d2h {
+
+static unsigned usable_cpus() {
+    static const unsigned cached = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, unsigned(c)); }
+        {   // cgroup v2: "<quota> <period>" or "max <period>"
+            std::ifstream f("/sys/fs/cgroup/cpu.max");
+            std::string q; long long per = 0;
+            if (f >> q >> per && q != "max" && per > 0) {
+                const long long quota = std::atoll(q.c_str());
+                if (quota > 0) n = std::min(n, unsigned(std::max<long long>(1, (quota + per / 2) / per)));
+            }
+        }
+        {   // cgroup v1
+            std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+            long long quota = -1, per = 0;
+            if (fq >> quota && fp >> per && quota > 0 && per > 0) n = std::min(n, unsigned(std::max<long long>(1, (quota + per / 2) / per)));
+        }
+        return std::max(1u, n);
+    }();
+    return cached;
+}
+
+unsigned Options::workers() const {
+    const unsigned req = nthreads();
+    if (const char *e = std::getenv("D2G_NO_CPU_CAP")) if (e[0] == '1') return req;
+    return std::min(req, usable_cpus());
 }
 
 }  // namespace d2h

@@ -180,7 +180,7 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
     std::condition_variable cv_ready, cv_space;
     std::atomic<size_t> next_group{0};
     std::string parse_error;
-    const size_t nparsers = std::max<size_t>(1, std::min<size_t>({size_t(o.nthreads()), groups.size(), size_t(192)}));
+    const size_t nparsers = std::max<size_t>(1, std::min<size_t>({size_t(o.workers()), groups.size(), size_t(192)}));
     const size_t max_ready = 2 * nparsers + 2;
     std::vector<std::thread> parsers;
     for (size_t t = 0; t < nparsers; ++t) parsers.emplace_back([&]() {
@@ -313,7 +313,7 @@ void sketch_core_byseq(Result &res, const Options &o, d2g_ctx *ctx) {
             regs.resize(n * m);
             check(ctx, d2g_sketcher_run(sk, pk, pk_bytes, rs_rel.data(), run_len + r0, nrun, goff_rel.data(), n, o.k, o.canon,
                                         xormask, S, regs.data()), "d2g_sketcher_run");
-            check(ctx, d2g_oph_finalize(regs.data(), n, m, S, sigs.data(), cards.data(), int(o.nthreads())), "d2g_oph_finalize");
+            check(ctx, d2g_oph_finalize(regs.data(), n, m, S, sigs.data(), cards.data(), int(o.workers())), "d2g_oph_finalize");
             bool need = false;
             for (size_t i = 0; i < n; ++i) {
                 if (std::isnan(cards[i])) cards[i] = 0.;                              // fastxsketchbyseq.cpp:410-414
@@ -430,7 +430,7 @@ struct Emitter {
         for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + nvals(r0 + i);
         std::vector<std::string> text(n);
 #ifdef _OPENMP
-        #pragma omp parallel for schedule(dynamic, 8) num_threads(o.nthreads())
+        #pragma omp parallel for schedule(dynamic, 8) num_threads(o.workers())
 #endif
         for (size_t r = 0; r < n; ++r) {                                 // emitrect.cpp:172-187
             const size_t i = r0 + r;
@@ -555,7 +555,7 @@ void cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
                 else {
                     uint32_t *ca = hca[b]->as<uint32_t>();
                     check(ctxs[b], d2g_memcpy_d2h(ctxs[b], ca, da[b]->p, bt.cnt * 4, nullptr), "d2h");
-                    check(ctxs[b], d2g_epilogue_ut(ca, nullptr, cards, ns, S, bt.r0, bt.r1, o.measure, o.k, multiset, int(o.nthreads()), out),
+                    check(ctxs[b], d2g_epilogue_ut(ca, nullptr, cards, ns, S, bt.r0, bt.r1, o.measure, o.k, multiset, int(o.workers()), out),
                           "d2g_epilogue_ut");
                 }
             }
@@ -576,7 +576,7 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     const bool multiset = o.sspace != SPACE_SET;
     if (o.kmer_result == ONE_PERM) {                                // cmp_core.cpp:686-718
         size_t nfilled = 0;
-        check(ctx, d2g_densify(res.signatures.data(), ns, S, &nfilled, int(o.nthreads())), "d2g_densify");
+        check(ctx, d2g_densify(res.signatures.data(), ns, S, &nfilled, int(o.workers())), "d2g_densify");
         if (o.verbosity && nfilled) std::fprintf(stderr, "Densified a total of %zu/%zu entries\n", nfilled, S * ns);
     }
     const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.signatures.data());
@@ -626,7 +626,7 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                     check(ctx, d2g_memcpy_d2h(ctx, ca, da.p, cnt * 4, nullptr), "d2h");
                     // x87 epilogue on the host (cmp_core.cpp:458-517)
                     check(ctx, d2g_epilogue_ut(ca, need_gtlt ? cb : nullptr, cards, ns, S, r0, r1, o.measure, o.k, multiset,
-                                               int(o.nthreads()), out), "d2g_epilogue_ut");
+                                               int(o.workers()), out), "d2g_epilogue_ut");
                 }
             }
             const double tb = now();
@@ -656,7 +656,7 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                 }
                 check(ctx, d2g_memcpy_d2h(ctx, ca, da.p, cnt * 4, nullptr), "d2h");
 #ifdef _OPENMP
-                #pragma omp parallel for schedule(dynamic, 4) num_threads(o.nthreads())
+                #pragma omp parallel for schedule(dynamic, 4) num_threads(o.workers())
 #endif
                 for (size_t i = r0; i < r1; ++i)
                     for (size_t j = c0; j < c1; ++j) {
