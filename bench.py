@@ -265,7 +265,7 @@ def cpu_baseline_multiset(L, k, S):
     lib, march = oracle_lib()
     import ctypes as C
     ncores = host_cores()
-    Ls = min(L, 2_000_000)
+    Ls = L                                                # config 5's own input size: ~20 s of CPU work on 16 cores
     buf = synth.fasta_bytes_fast("g", synth.random_genome(7, Ls))
 
     def one(_):
