@@ -309,6 +309,27 @@ __attribute__((target("avx2"))) static inline bool pack16_avx2(const char *s, ui
     return true;
 }
 
+// AVX-512 (BW + VL + VBMI2): 64 ASCII bytes that are all bases or '\n' -> the bases, line feeds squeezed out
+// (vpcompressb), 2 bits each in a 128-bit little-endian bit string; returns the number of bases, or -1 when
+// the block holds anything else (header, 'N', '\r', quality, ...), which the per-line code then takes.
+__attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi2"))) static inline int pack64_skip_newlines(const char *s, uint64_t out[2]) {
+    const __m512i v = _mm512_loadu_si512(s);
+    const __m512i u = _mm512_and_si512(v, _mm512_set1_epi8((char)0xDF));
+    const __mmask64 base = _mm512_cmpeq_epi8_mask(u, _mm512_set1_epi8('A')) | _mm512_cmpeq_epi8_mask(u, _mm512_set1_epi8('C')) |
+                           _mm512_cmpeq_epi8_mask(u, _mm512_set1_epi8('G')) | _mm512_cmpeq_epi8_mask(u, _mm512_set1_epi8('T'));
+    const __mmask64 nl = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('\n'));
+    if ((base | nl) != ~(__mmask64)0) return -1;
+    const __m512i c1 = _mm512_and_si512(_mm512_srli_epi16(u, 1), _mm512_set1_epi8(3));
+    const __m512i c2 = _mm512_and_si512(_mm512_srli_epi16(u, 2), _mm512_set1_epi8(1));
+    const __m512i code = _mm512_maskz_compress_epi8(base, _mm512_xor_si512(c1, c2));
+    const __m512i p16 = _mm512_maddubs_epi16(code, _mm512_set1_epi16(0x0401));        // c0 + 4 c1 per 16-bit lane
+    const __m512i p32 = _mm512_madd_epi16(p16, _mm512_set1_epi32(0x00100001));         // 4 bases per 32-bit lane (its low byte)
+    const __m128i bytes = _mm512_cvtepi32_epi8(p32);                                    // 16 bytes = 64 bases
+    out[0] = (uint64_t)_mm_cvtsi128_si64(bytes);
+    out[1] = (uint64_t)_mm_extract_epi64(bytes, 1);
+    return (int)_mm_popcnt_u64(base);
+}
+
 struct d2g_seqpack {
     int k;
     std::vector<uint8_t> packed;       // 4 bases / byte
@@ -405,6 +426,42 @@ struct d2g_seqpack {
         }
         nbases = nb; cur_len = clen;
     }
+    // Sequence bytes from `s` in 64-byte blocks while every block is bases and line feeds only (the body of a FASTA record
+    // with any line width); returns the bytes consumed and adds the bases taken to *nseq.  Runs are not broken by line
+    // feeds, exactly as with one feed() per line.
+    __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi2,popcnt"))) size_t feed_blocks(const char *s, size_t n, size_t *nseq) {
+        const size_t need = (nbases + n + 3) / 4 + 24;
+        if (packed.size() < need) packed.resize(std::max(need, packed.size() + packed.size() / 2));
+        uint8_t *pk = packed.data();
+        uint64_t nb = nbases, clen = cur_len;
+        size_t i = 0;
+        uint64_t w[2];
+        while (i + 64 <= n) {
+            const int cnt = pack64_skip_newlines(s + i, w);
+            if (cnt < 0) break;
+            if (cnt) {
+                if (!clen) cur_start = nb;
+                const unsigned sh = (unsigned)(nb & 3) * 2;
+                uint8_t *dst = pk + (nb >> 2);
+                if (sh == 0) {
+                    std::memcpy(dst, w, 16);
+                } else {
+                    const uint64_t lo = (w[0] << sh) | dst[0];           // dst[0]: the stream's partially filled last byte
+                    const uint64_t hi = (w[1] << sh) | (w[0] >> (64 - sh));
+                    std::memcpy(dst, &lo, 8);
+                    std::memcpy(dst + 8, &hi, 8);
+                    dst[16] = uint8_t(w[1] >> (64 - sh));
+                }
+                nb += (uint64_t)cnt; clen += (uint64_t)cnt;
+            }
+            i += 64;
+        }
+        *nseq += (size_t)(nb - nbases);
+        nbases = nb; cur_len = clen;
+        // bytes written past the stream's end are zero except where codes of THIS block landed: the next write ORs its
+        // low bits into the last partial byte, like feed() does
+        return i;
+    }
     void end_record() { if (cur_len) close_run(); }
     void end_genome() {
         end_record();
@@ -439,9 +496,22 @@ struct d2g_seqpack {
             skip_line();                                   // header
             size_t seqlen = 0;
             int c = -1;
+            static const bool have_vbmi2 = __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("avx512bw") &&
+                                           __builtin_cpu_supports("avx512vl") && !std::getenv("D2G_NO_AVX512");
+            bool at_line_start = true;
             while (pos < len) {
                 c = (unsigned char)buf[pos];
-                if (c == '>' || c == '+' || c == '@') break;
+                // a record boundary is only looked for at the start of a line (the block path may stop inside one)
+                if (at_line_start && (c == '>' || c == '+' || c == '@')) break;
+                if (have_vbmi2 && len - pos >= 64) {
+                    const size_t took = feed_blocks(buf + pos, len - pos, &seqlen);
+                    if (took) {
+                        pos += took;
+                        at_line_start = buf[pos - 1] == '\n';
+                        c = -1;
+                        continue;
+                    }
+                }
                 const char *nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
                 const size_t e = nl ? size_t(nl - buf) : len;
                 size_t ll = e - pos;
@@ -449,6 +519,7 @@ struct d2g_seqpack {
                 feed(buf + pos, ll);
                 seqlen += ll;
                 pos = nl ? e + 1 : len;
+                at_line_start = true;
                 c = -1;
             }
             if (by_record) end_genome(); else end_record();

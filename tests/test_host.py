@@ -165,6 +165,58 @@ def test_seqpack_runs_and_kmer_counts(d2g, oracle):
         d2g.SeqPack(33)                        # k > 32 is the reference's rolling-hash path: unsupported
 
 
+def _random_fastx(rng, nrec):
+    """records with random line widths (1..200), lower case, sprinkled non-ACGT bytes, LF or CRLF, FASTA or FASTQ
+    (quality lines starting with '>' '@' '+'); returns the bytes and, per record, the concatenated sequence"""
+    out, seqs = [], []
+    for r in range(nrec):
+        n = int(rng.choice([0, 1, 5, 63, 64, 65, 127, 128, 129, 300, 1000, 5000]))
+        seq = rng.choice(np.frombuffer(b"ACGTacgt", np.uint8), n)
+        if n and rng.random() < 0.6:                                   # other bytes: N, IUPAC, '-', '*'
+            pos = rng.integers(0, n, max(1, n // int(rng.choice([7, 50, 400]))))
+            seq[pos] = rng.choice(np.frombuffer(b"NnRYK-*.", np.uint8), pos.size)
+        seq = seq.tobytes()
+        width = int(rng.choice([1, 7, 60, 63, 64, 65, 70, 80, 128, 200, 10 ** 6]))
+        eol = b"\r\n" if rng.random() < 0.2 else b"\n"
+        fastq = rng.random() < 0.3
+        lines = [seq[i:i + width] for i in range(0, len(seq), width)] if not fastq else [seq]
+        rec = (b"@" if fastq else b">") + b"rec%d some description >@+" % r + eol + b"".join(l + eol for l in lines)
+        if fastq:
+            q = rng.choice(np.frombuffer(b">@+I5#", np.uint8), n).tobytes()
+            rec += b"+" + eol + q + eol
+        out.append(rec)
+        seqs.append(seq)
+    buf = b"".join(out)
+    if rng.random() < 0.3 and buf.endswith(b"\n"):
+        buf = buf[:-1]                                                  # no final line feed
+    return buf, seqs
+
+
+def test_seqpack_random_fastx_block_and_line_paths(d2g):
+    """The packer takes 64-byte blocks of bases + line feeds in one step (AVX-512 VBMI2, where the CPU has it) and everything
+    else line by line; the two alternate inside a record wherever a block holds another byte.  Runs must equal the maximal
+    ACGT runs (>= k) of every record's concatenated sequence, in order, whatever the line width and line ends."""
+    import re as _re
+    rng = np.random.default_rng(20260929)
+    for trial in range(60):
+        k = int(rng.choice([1, 3, 11, 31]))
+        buf, seqs = _random_fastx(rng, int(rng.integers(1, 8)))
+        sp = d2g.SeqPack(k)
+        sp.add_fastx(buf)
+        packed, rs, rl, go = sp.arrays()
+        exp = [r.upper() for seq in seqs for r in _re.split(rb"[^ACGTacgt]+", seq) if len(r) >= k]
+        assert _decode_runs(packed, rs, rl) == exp, (trial, k)
+        assert sp.nkmers(0) == sum(len(r) - k + 1 for r in exp)
+        sp.close()
+        spr = d2g.SeqPack(k)
+        spr.add_fastx_by_record(buf)                                   # one genome per record: the same runs, grouped
+        packed, rs, rl, go = spr.arrays()
+        assert _decode_runs(packed, rs, rl) == exp and spr.ngenomes == len(seqs)
+        per = [sum(len(r) - k + 1 for r in _re.split(rb"[^ACGTacgt]+", seq) if len(r) >= k) for seq in seqs]
+        assert [spr.nkmers(i) for i in range(spr.ngenomes)] == per
+        spr.close()
+
+
 def test_seqpack_gz_and_multipath(d2g, oracle, tmp_path):
     import gzip
     from dashing2_amd import synth
