@@ -1410,7 +1410,12 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         const size_t ninit = std::max<size_t>(n * m, n);
         hipLaunchKernelGGL(k3_bmh_init_kernel, dim3((unsigned)div_up<size_t>(ninit, K3_THREADS)), dim3(K3_THREADS), 0, s,
                            st->d_h, n * m, st->d_tw, st->d_redo, n);
-        const unsigned main_grid = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * 8);
+        // Workgroups own contiguous bucket ranges; 6 are resident per CU.  A grid of 8 per CU (r01) left a third of the ranges
+        // to a second, three-quarters-empty round: 9.0 ms.  With many more, smaller ranges the hardware's dispatch evens the
+        // tail out: 8.3 ms at 6 per CU, 7.9 at 12, 7.6 at 24, 7.3 at 48 and 64 (the survivor kernel follows: 1.9 -> 1.7 ms).
+        size_t per_cu = 48;
+        if (const char *e = std::getenv("D2G_K3_GRID_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) per_cu = (size_t)v; }
+        const unsigned main_grid = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * per_cu);
         st->last_nredo = 0;
         // First pass in the light form: survivors go to per-workgroup regions of a queue in HBM.  A region holds twice the
         // survivors its buckets are expected to produce: genome g yields at most gk strips in all (an element of count c has
@@ -1418,7 +1423,7 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         bool light = TB > 0 && !D2G_K3_EXP;
         if (const char *e = std::getenv("D2G_K3_LIGHT")) if (e[0] == '0') light = false;
         double gq_scale = 2.0;
-        uint64_t gq_slack = 1024;
+        uint64_t gq_slack = per_cu > 24 ? 256 : 1024;
         if (const char *e = std::getenv("D2G_K3_GQ_SCALE")) { gq_scale = std::max(0.0, std::atof(e)); gq_slack = 1; }   // tests force the overflow path
         if (light) {
             // batches of read-sized inputs: the bound of a tiny input is above 1 and every element survives -- a queue of
