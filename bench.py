@@ -725,6 +725,21 @@ def main():
         cpu = cpu_baseline_sketch(fastas[:min(len(fastas), 2 * ncores)], L, k, S, args.cpu_seconds) \
             if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
         pe = pmc_entry("k1_oph_kernel") if (world == 1 and n_g == 1000 and L == 5_000_000) else None
+        # the compare half of BASELINE configs[1] on exactly these sketches: registers in HBM -> host x87 finalisation ->
+        # all-pairs float32 Jaccard back on the host (upload, prepare, pair kernel, D2H), through the host-pointer C ABI
+        c2 = None
+        if rank == 0 and world == 1 and n_g >= 2:
+            try:
+                t0 = time.perf_counter()
+                regs_h = regs_dev.cpu().numpy().view(np.uint64)
+                sg, cd = D.oph_finalize(regs_h, S, nthreads=ncores)
+                dm = ctx.cmp_dist_ut(sg.view(np.uint64), cd, nthreads=ncores)
+                c2 = {"pairs": int(n_g * (n_g - 1) // 2), "seconds": time.perf_counter() - t0,
+                      "note": "the compare half of configs[1] on the sketches just built: D2H of the registers, x87 finalisation (getcard/data), "
+                              "d2g_cmp_dist_ut from host pointers (upload + prepare + pair kernel + D2H); values finite: "
+                              + str(bool(np.isfinite(dm).all()))}
+            except Exception as e:                               # noqa: BLE001
+                c2 = {"error": f"{type(e).__name__}: {e}"}
 
         def build(sdt):
             o = {"metric": "sketch input bases/s (K1 kernel, packed bases resident in HBM)", "value": bases * world / (sdt / reps),
@@ -745,6 +760,8 @@ def main():
                               "note": "VALU-bound by the two mandated 64-bit Wang mixes per k-mer (~125 issue slots per base), not by HBM"}}
             if cpu is not None:
                 o["cpu_baseline"] = cpu
+            if c2 is not None:
+                o["allpairs_of_these_sketches"] = c2
             return o
         return sdt, build
 
