@@ -37,7 +37,7 @@ inline KmerArgs d2g_plan_args(const d2g_oph_plan *plan, const uint8_t *packed_de
     a.run_start = plan->d_run_start; a.run_len = plan->d_run_len; a.run_chunk_off = plan->d_run_chunk_off;
     a.blk_genome = plan->d_blk_genome; a.blk_chunk0 = plan->d_blk_chunk0; a.blk_nchunks = plan->d_blk_nchunks;
     a.blk_run_lo = plan->d_blk_run_lo; a.blk_run_hi = plan->d_blk_run_hi;
-    a.k = plan->k; a.canon = canon;
+    a.k = plan->k; a.canon = canon; a.blk0 = 0;
     return a;
 }
 

@@ -348,7 +348,7 @@ int d2g_sketcher_stage(d2g_sketcher *sk, const uint8_t *packed, size_t packed_by
     out->blk_nchunks = reinterpret_cast<const uint32_t *>(sk->d_arena + o_bn);
     out->blk_run_lo = reinterpret_cast<const uint32_t *>(sk->d_arena + o_lo);
     out->blk_run_hi = reinterpret_cast<const uint32_t *>(sk->d_arena + o_hi);
-    out->k = k; out->canon = canon;
+    out->k = k; out->canon = canon; out->blk0 = 0;
     *nblk_out = nblk;
     return D2G_OK;
 }

@@ -69,6 +69,7 @@ struct K3Args {
     const uint32_t *l2_tb0;    // [nl2] first bucket of coarse bucket i (global bucket index)
     const uint32_t *l2_bits;   // [nl2] (bb << 8) | (bb - l1bits) of its genome
     uint32_t *blk_coarse;      // [nblk << l1bits] k-mers of launch-plan block b in each of its genome's coarse buckets
+    uint32_t g0, n_genomes;    // k3_scan_kernel: first genome of this launch, genomes of the whole batch
 };
 
 __device__ __forceinline__ uint32_t bucket_of(uint64_t key, uint32_t bb) { return bb ? (uint32_t)(key >> (64 - bb)) : 0u; }
@@ -76,7 +77,8 @@ __device__ __forceinline__ uint32_t bucket_of(uint64_t key, uint32_t bb) { retur
 __global__ __launch_bounds__(K1_THREADS) void k3_hist_kernel(K3Args a) {
     __shared__ uint32_t hist[K3_MAXB];
     const int tid = threadIdx.x;
-    const uint32_t g = a.km.blk_genome[blockIdx.x];
+    const uint32_t blk = blockIdx.x + a.km.blk0;
+    const uint32_t g = a.km.blk_genome[blk];
     const uint32_t bb = a.g_bbits[g], B = 1u << bb, boff = a.g_boff[g];
     for (uint32_t i = tid; i < B; i += K1_THREADS) hist[i] = 0;
     __syncthreads();
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(K1_THREADS) void k3_hist_kernel(K3Args a) {
         if (hist[i]) atomicAdd(&a.bucket_cnt[boff + i], hist[i]);
     // the workgroup's count per COARSE bucket (the scatter's write fronts): saves the scatter its counting enumeration
     const uint32_t b1 = bb < a.l1bits ? bb : a.l1bits, sb = bb - b1;
-    uint32_t *mine = a.blk_coarse + ((size_t)blockIdx.x << a.l1bits);
+    uint32_t *mine = a.blk_coarse + ((size_t)blk << a.l1bits);
     for (uint32_t i = tid; i < (1u << b1); i += K1_THREADS) {
         uint32_t c = 0;
         for (uint32_t j = 0; j < (1u << sb); ++j) c += hist[(i << sb) + j];
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(K1_THREADS) void k3_hist_kernel(K3Args a) {
 // lane); the genome's first key offset comes from the host, which knows every genome's k-mer count
 __global__ __launch_bounds__(K3_THREADS) void k3_scan_kernel(K3Args a) {
     __shared__ uint32_t wsum[K3_THREADS / 64];
-    const uint32_t tid = threadIdx.x, g = blockIdx.x;
+    const uint32_t tid = threadIdx.x, g = blockIdx.x + a.g0;
     const uint32_t b0 = a.g_boff[g], B = a.g_boff[g + 1] - b0;
     const uint32_t per = (B + K3_THREADS - 1) / K3_THREADS;             // <= 16
     const uint32_t lo = min(B, tid * per), hi = min(B, lo + per);
@@ -119,7 +121,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_scan_kernel(K3Args a) {
         a.bucket_off[b0 + i] = run; a.cursor[b0 + i] = run;
         run += a.bucket_cnt[b0 + i];
     }
-    if (g == gridDim.x - 1 && tid == K3_THREADS - 1) a.bucket_off[a.TB] = a.g_koff[g + 1];
+    // the end of this launch's last bucket = the first key of the next genome (the whole batch: bucket_off[TB]).  A later
+    // launch over the next genomes writes the same value there; the counting pass of THIS range may already be reading it.
+    if (blockIdx.x == gridDim.x - 1 && tid == K3_THREADS - 1) a.bucket_off[b0 + B] = a.g_koff[g + 1];
 }
 
 // Write-combining decides this pass.  A workgroup's 65 536 k-mers leave ~16 keys = one 128-byte line in each of 4096
@@ -136,12 +140,13 @@ __global__ __launch_bounds__(K1_THREADS) void k3_scatter_kernel(K3Args a) {
     // k-mers -- so that a key's slot is a single LDS atomic.
     __shared__ uint32_t pos[K3_MAXB];
     const int tid = threadIdx.x;
-    const uint32_t g = a.km.blk_genome[blockIdx.x];
+    const uint32_t blk = blockIdx.x + a.km.blk0;
+    const uint32_t g = a.km.blk_genome[blk];
     const uint32_t bb = a.g_bbits[g], boff = a.g_boff[g];
     const uint32_t b1 = bb < a.l1bits ? bb : a.l1bits, sb = bb - b1, B = 1u << b1;
     const uint64_t koff = a.g_koff[g];
     const uint64_t xormask = a.xormask;
-    const uint32_t *mine = a.blk_coarse + ((size_t)blockIdx.x << a.l1bits);      // counted by k3_hist_kernel
+    const uint32_t *mine = a.blk_coarse + ((size_t)blk << a.l1bits);              // counted by k3_hist_kernel
     for (uint32_t i = tid; i < B; i += K1_THREADS) {
         const uint32_t c = mine[i];
         pos[i] = c ? (uint32_t)(atomicAdd((unsigned long long *)&a.cursor[boff + (i << sb)], (unsigned long long)c) - koff) : 0u;
@@ -750,6 +755,8 @@ struct BmhArgs {
     uint64_t *sub_off;        // [nsub + 1]
     uint64_t *skeys;          // [total k-mers]
     uint32_t *skeys32;        // compact path
+    uint32_t tb0, tb1;        // buckets this launch of the main kernel walks (a sub-batch, or [0, TB))
+    uint32_t g0;              // first genome of this launch of the verify kernel
     // first pass, light form: survivors queue in HBM, one region per main workgroup
     QEntry *gq; const uint64_t *gq_off; uint32_t *gq_n;
     // optional R11 output (k3_count_kernel): distinct (key,count) written in place of the bucket
@@ -884,8 +891,8 @@ __global__ __launch_bounds__(K3_THREADS) __attribute__((amdgpu_waves_per_eu(LIGH
     // each workgroup owns a contiguous range of buckets: the genome (and with it bound and
     // registers) changes rarely and is tracked incrementally -- a binary search plus four dependent
     // scalar loads per bucket cost 16 us of exposed latency per bucket
-    const uint32_t per = (a.TB + gridDim.x - 1) / gridDim.x;
-    const uint32_t tb_lo = blockIdx.x * per, tb_hi = tb_lo + per < a.TB ? tb_lo + per : a.TB;
+    const uint32_t per = (a.tb1 - a.tb0 + gridDim.x - 1) / gridDim.x;    // this launch walks buckets [tb0, tb1)
+    const uint32_t tb_lo = a.tb0 + blockIdx.x * per, tb_hi = tb_lo + per < a.tb1 ? tb_lo + per : a.tb1;
     if (tb_lo >= tb_hi) return;
     QEntry *gq = LIGHT ? a.gq + a.gq_off[blockIdx.x] : nullptr;
     const uint32_t gq_cap = LIGHT ? (uint32_t)(a.gq_off[blockIdx.x + 1] - a.gq_off[blockIdx.x]) : 0u;
@@ -1042,7 +1049,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_bmh_survivor_kernel(BmhArgs a) 
 // pass also sums the genome's total weight, from which a failed guess is recomputed.
 __global__ __launch_bounds__(K3_THREADS) void k3_bmh_verify_kernel(BmhArgs a) {
     __shared__ uint64_t red[8];
-    const uint32_t g = blockIdx.x;
+    const uint32_t g = blockIdx.x + a.g0;
     if (a.redo_mode && !a.redo[g]) return;
     const uint64_t hm = block_hmax(a.h + (size_t)g * a.m, a.m, red);
     if (threadIdx.x == 0) {
@@ -1188,6 +1195,9 @@ struct d2g_k3_state {
     uint64_t *d_gq = nullptr; size_t cap_gq = 0;     // survivors of the light first pass (QEntry)
     uint64_t *d_gq_off = nullptr; size_t cap_gq_off = 0;   // [grid+1] region offsets, then [grid] u32 counts
     int light_overflows = 0;
+    hipStream_t xs = nullptr;                        // second stream of the sub-batch pipeline
+    hipEvent_t ev_a[8] = {}, ev_b = nullptr;
+    int pipelined_calls = 0;
     uint64_t *d_keys = nullptr; size_t cap_keys = 0;
     uint64_t *d_skeys = nullptr; size_t cap_skeys = 0;      // big inputs: keys regrouped by sub-range
     uint32_t *d_gblk = nullptr; size_t cap_gblk = 0;        // compact path: first launch-plan block of each genome
@@ -1211,6 +1221,9 @@ struct d2g_k3_state {
 void d2g_k3_state_destroy(d2g_k3_state *st) {
     if (!st) return;
     (void)hipFree(st->d_gtab); (void)hipFree(st->d_koff); (void)hipFree(st->d_bucket_cnt); (void)hipFree(st->d_bucket_off); (void)hipFree(st->d_cursor); (void)hipFree(st->d_l2); (void)hipFree(st->d_blk_coarse); (void)hipFree(st->d_gq); (void)hipFree(st->d_gq_off);
+    for (auto &e : st->ev_a) if (e) (void)hipEventDestroy(e);
+    if (st->ev_b) (void)hipEventDestroy(st->ev_b);
+    if (st->xs) (void)hipStreamDestroy(st->xs);
     (void)hipFree(st->d_keys); (void)hipFree(st->d_skeys); (void)hipFree(st->d_sub_off); (void)hipFree(st->d_gsplit); (void)hipFree(st->d_gsub); (void)hipFree(st->d_h); (void)hipFree(st->d_tw);
     (void)hipFree(st->d_status); (void)hipFree(st->d_guess); (void)hipFree(st->d_tw_bucket); (void)hipFree(st->d_redo); (void)hipFree(st->d_out_counts); (void)hipFree(st->d_bucket_nd);
     (void)hipFree(st->d_out_keys); (void)hipFree(st->d_gblk); (void)hipFree(st->d_tile_cnt); (void)hipFree(st->d_tile_off);
@@ -1233,6 +1246,7 @@ struct K3Host {
     uint32_t TB = 0;
     uint32_t l1bits = K3_L1BITS;        // generic path: bucket bits the scatter resolves itself
     std::vector<uint32_t> l2_tb0, l2_bits;   // coarse buckets that k3_refine_kernel spreads over their buckets
+    std::vector<uint32_t> l2_start;          // [n+1] first entry of genome g in the two arrays above
 };
 
 int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_off, size_t n, int k, K3Host &kh) {
@@ -1246,7 +1260,7 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     if (const char *e = std::getenv("D2G_K3_COMPACT")) if (e[0] == '1') kh.compact = kh.hb <= (uint32_t)K3C_MAXBBITS;
     uint64_t tb = 0;
     uint64_t bucket_keys = K3_TARGET, sub_keys = K3_TARGET;
-    kh.l1bits = K3_L1BITS; kh.l2_tb0.clear(); kh.l2_bits.clear();
+    kh.l1bits = K3_L1BITS; kh.l2_tb0.clear(); kh.l2_bits.clear(); kh.l2_start.assign(n + 1, 0);
     if (const char *e = std::getenv("D2G_K3_L1BITS")) { const int v = std::atoi(e); if (v >= 0 && v <= K3_MAXBBITS) kh.l1bits = (uint32_t)v; }
     if (const char *e = std::getenv("D2G_K3_BUCKET_KEYS")) { const long v = std::atol(e); if (v >= 1) bucket_keys = (uint64_t)v; }
     if (const char *e = std::getenv("D2G_K3_SUB_KEYS")) { const long v = std::atol(e); if (v >= 1) sub_keys = (uint64_t)v; }
@@ -1264,6 +1278,7 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
         else bb = std::min<uint32_t>(K3_MAXBBITS, ceil_log2((nk + bucket_keys - 1) / bucket_keys));
         kh.gtab[g] = bb;
         kh.gtab[n + g] = (uint32_t)tb;
+        kh.l2_start[g] = (uint32_t)kh.l2_tb0.size();
         if (!kh.compact && bb > kh.l1bits)
             for (uint32_t c = 0; c < (1u << kh.l1bits); ++c) {
                 kh.l2_tb0.push_back((uint32_t)tb + (c << (bb - kh.l1bits)));
@@ -1274,6 +1289,7 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     }
     kh.gtab[2 * n] = (uint32_t)tb;
     kh.TB = (uint32_t)tb;
+    kh.l2_start[n] = (uint32_t)kh.l2_tb0.size();
     kh.koff.assign(n + 1, 0);
     for (size_t g = 0; g < n; ++g) kh.koff[g + 1] = kh.koff[g] + kh.gk[g];
     // big inputs: buckets averaging more than K3_SPLIT_MIN keys are split once more (k3_split_kernel)
@@ -1317,6 +1333,42 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
     D2G_HIP(ctx, hipMemsetAsync(st->d_bucket_cnt, 0, ((size_t)TB + 1) * sizeof(uint32_t), s));
     D2G_HIP(ctx, hipMemsetAsync(st->d_status, 0, 2 * sizeof(int), s));
     d2g_timer tm(ctx, &ctx->ev_k3, s);
+    // Sub-batch pipeline (generic path, sketching): the batch is cut into genome ranges; the bucketing passes of range j + 1
+    // (hist, scan, scatter, refine: bound by memory) run on the caller's stream while the counting pass of range j (bound by
+    // latency and instruction issue) runs on a second stream.  Ranges are independent: disjoint genomes, buckets, key regions.
+    K3Args ka;
+    std::memset(&ka, 0, sizeof(ka));
+    std::vector<size_t> sub{0, n};                                       // genome boundaries of the ranges
+    bool pipeline = false;
+    if (!kh.compact && !kh.any_split && !count_only && !D2G_K3_EXP && n >= 2 && kh.gblk[n] == nblk) {
+        size_t want = (n >= 8 && kh.total >= 200000000ull) ? 4 : 1;
+        if (const char *e = std::getenv("D2G_K3_SUBBATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) want = (size_t)v; }
+        want = std::min(want, n);
+        if (want > 1) {
+            sub.assign(1, 0);
+            for (size_t j = 1; j < want; ++j) {                          // cut by k-mer count
+                const uint64_t target = kh.total / want * j;
+                size_t g = sub.back() + 1;
+                while (g < n - (want - j) && kh.koff[g] < target) ++g;
+                sub.push_back(g);
+            }
+            sub.push_back(n);
+            pipeline = true;
+        }
+    }
+    auto stage_a = [&](size_t g_lo, size_t g_hi) {
+        K3Args a = ka;
+        const unsigned blk_lo = kh.gblk[g_lo], nb = (g_lo == 0 && g_hi == n) ? (unsigned)nblk : kh.gblk[g_hi] - blk_lo;
+        a.km.blk0 = blk_lo; a.g0 = (uint32_t)g_lo;
+        if (nb) hipLaunchKernelGGL(k3_hist_kernel, dim3(nb), dim3(K1_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k3_scan_kernel, dim3((unsigned)(g_hi - g_lo)), dim3(K3_THREADS), 0, s, a);
+        if (nb) hipLaunchKernelGGL(k3_scatter_kernel, dim3(nb), dim3(K1_THREADS), 0, s, a);
+        const unsigned l2_lo = kh.l2_start[g_lo], nl = kh.l2_start[g_hi] - l2_lo;
+        if (nb && nl && D2G_K3_EXP != 1 && D2G_K3_EXP != 2) {
+            a.l2_tb0 += l2_lo; a.l2_bits += l2_lo;
+            hipLaunchKernelGGL(k3_refine_kernel, dim3(nl), dim3(K3_THREADS), 0, s, a);
+        }
+    };
     if (kh.compact) {
         // 4-byte stored words, tile-sorted split: histogram per tile -> per-tile write offsets -> coalesced flush
         D2G_CHECK(ctx, kh.gblk[n] == nblk, "internal: K3 block layout disagrees with the launch plan");
@@ -1353,10 +1405,9 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         }
         if (int rc = d2g_grow(ctx, &st->d_blk_coarse, &st->cap_blk_coarse, std::max<size_t>(nblk, 1) << kh.l1bits)) return rc;
         a.blk_coarse = st->d_blk_coarse;
-        if (nblk) hipLaunchKernelGGL(k3_hist_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
-        hipLaunchKernelGGL(k3_scan_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, a);
-        if (nblk) hipLaunchKernelGGL(k3_scatter_kernel, dim3((unsigned)nblk), dim3(K1_THREADS), 0, s, a);
-        if (nblk && nl2 && D2G_K3_EXP != 1 && D2G_K3_EXP != 2) hipLaunchKernelGGL(k3_refine_kernel, dim3((unsigned)nl2), dim3(K3_THREADS), 0, s, a);
+        a.g0 = 0; a.n_genomes = (uint32_t)n;
+        ka = a;
+        if (!pipeline) stage_a(0, n);
     }
     BmhArgs b;
     std::memset(&b, 0, sizeof(b));
@@ -1432,16 +1483,18 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
             for (size_t g = 0; g < n; ++g) { double gv; std::memcpy(&gv, &guess[g], 8); etot += (double)kh.gk[g] * std::min(1.0, gv); }
             if (etot > 0.125 * (double)kh.total) light = false;
         }
-        if (light) {
-            const uint32_t per = (TB + main_grid - 1) / main_grid;
-            std::vector<double> pre(TB ? n + 1 : 1, 0.);       // expected survivors per bucket, genome by genome
-            std::vector<uint64_t> off(main_grid + 1, 0);
+        b.tb0 = 0; b.tb1 = TB; b.g0 = 0;
+        if (pipeline && !light) { stage_a(0, n); pipeline = false; }       // heavy first pass: one range
+        // per-workgroup survivor regions of one light launch over buckets [t0, t1): offsets relative to the launch's first region
+        auto gq_offsets = [&](uint32_t t0, uint32_t t1, unsigned grid, std::vector<uint64_t> &off) {
+            const uint32_t per = (t1 - t0 + grid - 1) / grid;
+            off.assign((size_t)grid + 1, 0);
             size_t g = 0;
-            for (unsigned w = 0; w < main_grid; ++w) {
-                const uint64_t lo = (uint64_t)w * per, hi = std::min<uint64_t>(lo + per, TB);
+            for (unsigned w = 0; w < grid; ++w) {
+                const uint64_t lo = (uint64_t)t0 + (uint64_t)w * per, hi = std::min<uint64_t>(lo + per, t1);
                 double e = 0.;
                 while (g < n && kh.gtab[n + g] + (1ull << kh.gtab[g]) <= lo) ++g;
-                for (size_t gg = g; gg < n && kh.gtab[n + gg] < hi; ++gg) {
+                for (size_t gg = g; lo < hi && gg < n && kh.gtab[n + gg] < hi; ++gg) {
                     const uint64_t b0 = kh.gtab[n + gg], B = 1ull << kh.gtab[gg];
                     const uint64_t ov = std::min<uint64_t>(hi, b0 + B) - std::max<uint64_t>(lo, b0);
                     double gv; std::memcpy(&gv, &guess[gg], 8);
@@ -1450,25 +1503,78 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
                 }
                 off[w + 1] = off[w] + (uint64_t)(gq_scale * e) + gq_slack;
             }
-            if (int rc = d2g_grow(ctx, &st->d_gq, &st->cap_gq, (size_t)off[main_grid] * (sizeof(QEntry) / 8))) return rc;
-            if (int rc = d2g_grow(ctx, &st->d_gq_off, &st->cap_gq_off, (size_t)main_grid + 1 + (main_grid + 1) / 2 + 1)) return rc;
-            D2G_HIP(ctx, hipMemcpyAsync(st->d_gq_off, off.data(), (main_grid + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s));
-            b.gq = reinterpret_cast<QEntry *>(st->d_gq); b.gq_off = st->d_gq_off;
-            b.gq_n = reinterpret_cast<uint32_t *>(st->d_gq_off + main_grid + 1);
+        };
+        // launches of the light first pass: one over everything, or one per range of the pipeline
+        struct LightLaunch { uint32_t t0, t1, g0, g1; unsigned grid; size_t off_at, n_at; uint64_t entry0; };
+        std::vector<LightLaunch> ll;
+        if (light) {
+            std::vector<uint64_t> all_off;
+            uint64_t entries = 0;
+            size_t n_words = 0;
+            const size_t nr = sub.size() - 1;
+            for (size_t j = 0; j < nr; ++j) {
+                LightLaunch L;
+                L.g0 = (uint32_t)sub[j]; L.g1 = (uint32_t)sub[j + 1];
+                L.t0 = kh.gtab[n + sub[j]]; L.t1 = sub[j + 1] < n ? kh.gtab[n + sub[j + 1]] : TB;
+                const size_t cap_grid = std::max<size_t>(1, (size_t)ctx->num_cus * per_cu / (nr > 1 ? 2 : 1));
+                L.grid = (unsigned)std::min<size_t>(std::max<uint32_t>(L.t1 - L.t0, 1), cap_grid);
+                std::vector<uint64_t> off;
+                gq_offsets(L.t0, L.t1, L.grid, off);
+                L.off_at = all_off.size(); L.n_at = n_words; L.entry0 = entries;
+                all_off.insert(all_off.end(), off.begin(), off.end());
+                entries += off.back(); n_words += L.grid;
+                ll.push_back(L);
+            }
+            if (int rc = d2g_grow(ctx, &st->d_gq, &st->cap_gq, (size_t)entries * (sizeof(QEntry) / 8) + 8)) return rc;
+            if (int rc = d2g_grow(ctx, &st->d_gq_off, &st->cap_gq_off, all_off.size() + (n_words + 1) / 2 + 1)) return rc;
+            D2G_HIP(ctx, hipMemcpyAsync(st->d_gq_off, all_off.data(), all_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+            for (auto &L : ll) L.n_at += 2 * all_off.size();                 // u32 index into the same buffer, behind the offsets
         }
+        auto light_args = [&](const LightLaunch &L) {
+            BmhArgs x = b;
+            x.tb0 = L.t0; x.tb1 = L.t1; x.g0 = L.g0; x.redo_mode = 0;
+            x.gq = reinterpret_cast<QEntry *>(st->d_gq) + L.entry0;
+            x.gq_off = st->d_gq_off + L.off_at;
+            x.gq_n = reinterpret_cast<uint32_t *>(st->d_gq_off) + L.n_at;
+            return x;
+        };
+        void (*light_k)(BmhArgs) = k3_bmh_main_kernel<false, true>, (*heavy_k)(BmhArgs) = k3_bmh_main_kernel<false, false>;
+        if (kh.compact) { light_k = k3_bmh_main_kernel<true, true>; heavy_k = k3_bmh_main_kernel<true, false>; }
         for (int pass = 0;; ++pass) {
             b.redo_mode = pass > 0;
             const bool lt = light && pass == 0;
-            if (TB && D2G_K3_EXP != 1 && D2G_K3_EXP != 2 && D2G_K3_EXP != 6 && D2G_K3_EXP != 7) {
-                void (*light_k)(BmhArgs) = k3_bmh_main_kernel<false, true>, (*heavy_k)(BmhArgs) = k3_bmh_main_kernel<false, false>;
-                if (kh.compact) { light_k = k3_bmh_main_kernel<true, true>; heavy_k = k3_bmh_main_kernel<true, false>; }
-                if (lt) {
-                    hipLaunchKernelGGL(light_k, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
-                    hipLaunchKernelGGL(k3_bmh_survivor_kernel, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
-                } else
-                    hipLaunchKernelGGL(heavy_k, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+            const bool run = TB && D2G_K3_EXP != 1 && D2G_K3_EXP != 2 && D2G_K3_EXP != 6 && D2G_K3_EXP != 7;
+            if (lt && pipeline) {
+                if (!st->xs) {
+                    D2G_HIP(ctx, hipStreamCreateWithFlags(&st->xs, hipStreamNonBlocking));
+                    for (auto &e : st->ev_a) D2G_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    D2G_HIP(ctx, hipEventCreateWithFlags(&st->ev_b, hipEventDisableTiming));
+                }
+                for (size_t j = 0; j < ll.size(); ++j) {
+                    stage_a(ll[j].g0, ll[j].g1);
+                    D2G_HIP(ctx, hipEventRecord(st->ev_a[j], s));
+                    D2G_HIP(ctx, hipStreamWaitEvent(st->xs, st->ev_a[j], 0));
+                    const BmhArgs x = light_args(ll[j]);
+                    if (run && ll[j].t1 > ll[j].t0) {
+                        hipLaunchKernelGGL(light_k, dim3(ll[j].grid), dim3(K3_THREADS), 0, st->xs, x);
+                        hipLaunchKernelGGL(k3_bmh_survivor_kernel, dim3(ll[j].grid), dim3(K3_THREADS), 0, st->xs, x);
+                    }
+                    hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3(ll[j].g1 - ll[j].g0), dim3(K3_THREADS), 0, st->xs, x);
+                }
+                D2G_HIP(ctx, hipEventRecord(st->ev_b, st->xs));
+                D2G_HIP(ctx, hipStreamWaitEvent(s, st->ev_b, 0));
+                st->pipelined_calls++;
+            } else {
+                if (run) {
+                    if (lt) {
+                        const BmhArgs x = light_args(ll[0]);
+                        hipLaunchKernelGGL(light_k, dim3(ll[0].grid), dim3(K3_THREADS), 0, s, x);
+                        hipLaunchKernelGGL(k3_bmh_survivor_kernel, dim3(ll[0].grid), dim3(K3_THREADS), 0, s, x);
+                    } else
+                        hipLaunchKernelGGL(heavy_k, dim3(main_grid), dim3(K3_THREADS), 0, s, b);
+                }
+                hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, b);
             }
-            hipLaunchKernelGGL(k3_bmh_verify_kernel, dim3((unsigned)n), dim3(K3_THREADS), 0, s, b);
             int st2[2] = {0, 0};                                  // [0] kernel status, [1] genomes whose guess failed
             D2G_HIP(ctx, hipMemcpyAsync(st2, st->d_status, sizeof(st2), hipMemcpyDeviceToHost, s));
             D2G_HIP(ctx, hipStreamSynchronize(s));

@@ -34,6 +34,7 @@ struct KmerArgs {
     const uint32_t *blk_run_hi;
     int k;
     int canon;
+    uint32_t blk0;                 // first launch-plan block of this launch (a launch may cover a sub-range of the plan)
 };
 
 // funnel shift: low 32 bits of (hi:lo) >> sh, 0 <= sh < 32
@@ -47,7 +48,7 @@ __device__ __forceinline__ uint32_t fsr(uint32_t hi, uint32_t lo, uint32_t sh) {
 template <class F>
 __device__ __forceinline__ void d2g_for_each_kmer_its(const KmerArgs &a, int it0, int it1, F &&f) {
     const int tid = threadIdx.x;
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = blockIdx.x + a.blk0;
     const uint64_t c0 = a.blk_chunk0[b];
     const uint32_t nc = a.blk_nchunks[b];
     const uint32_t rlo = a.blk_run_lo[b], rhi = a.blk_run_hi[b];

@@ -152,6 +152,9 @@ def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
                 {"D2G_K3_SPLIT_MIN": "40", "D2G_K3_ROUND_KEYS": "200"},        # ... and sub-ranges that still need rounds
                 {"D2G_K3_L1BITS": "3"}, {"D2G_K3_L1BITS": "0"},                # two-level scatter (genomes above ~260 kbp): 8 / 1 write fronts, then k3_refine_kernel
                 {"D2G_K3_L1BITS": "12"},                                       # ... and never (the single-level scatter)
+                {"D2G_K3_SUBBATCH": "2"},                                      # sub-batch pipeline: bucketing of range 2 under the counting of range 1 (two streams)
+                {"D2G_K3_SUBBATCH": "2", "D2G_K3_L1BITS": "3"}, {"D2G_K3_SUBBATCH": "2", "D2G_K3_GQ_SCALE": "0.05"},
+                {"D2G_K3_SUBBATCH": "2", "D2G_K3_GUESS_SCALE": "0.001"}, {"D2G_K3_SUBBATCH": "1"},
                 {"D2G_K3_LIGHT": "0"},                                         # first pass in the heavy form (survivors walked in the counting kernel)
                 {"D2G_K3_GQ_SCALE": "0.05"},                                   # survivor regions far too small: overflow -> the pass is repeated in the heavy form
                 {"D2G_K3_GQ_SCALE": "0.3", "D2G_K3_GUESS_SCALE": "0.01"},      # ... and together with a failed bound guess
@@ -168,9 +171,13 @@ def test_k3_multi_round_buckets_and_redo_paths(d2g, oracle, tmp_path):
         np.testing.assert_array_equal(np.array(counts, np.uint32), ec, err_msg=str(env))
 
 
-def test_k3_many_small_and_one_large_input(gpu_ctx, d2g, oracle):
+@pytest.mark.parametrize("subbatch", [None, "3", "8"])
+def test_k3_many_small_and_one_large_input(gpu_ctx, d2g, oracle, monkeypatch, subbatch):
     """batch shapes: 300 read-sized inputs (one bucket each, many workgroup-less genomes) next to a
-    12 Mbp genome (4096 buckets of ~2900 keys: 4 table rounds each)"""
+    12 Mbp genome (4096 buckets of ~2900 keys: 4 table rounds each); D2G_K3_SUBBATCH cuts the batch into that many
+    genome ranges for the two-stream pipeline (ranges of very different weight, empty inputs at their borders)"""
+    if subbatch:
+        monkeypatch.setenv("D2G_K3_SUBBATCH", subbatch)
     rng = np.random.default_rng(9)
     sp = d2g.SeqPack(21)
     small = [synth.fasta_bytes(f"s{i}", synth.random_genome(1000 + i, int(rng.integers(30, 3000)))) for i in range(300)]

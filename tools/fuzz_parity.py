@@ -81,7 +81,7 @@ def main():
                 for var, choices in (("D2G_K3_ROUND_KEYS", [None, None, "40", "300"]), ("D2G_K3_SPLIT_MIN", [None, None, "20", "400"]),
                                      ("D2G_K3_COMPACT", [None, "1", "1"]), ("D2G_K3_GUESS_SCALE", [None, None, None, "0.02"]),
                                      ("D2G_K3_L1BITS", [None, None, "0", "2", "5"]), ("D2G_K3_LIGHT", [None, None, None, "0"]),
-                                     ("D2G_K3_GQ_SCALE", [None, None, None, "0.1"])):
+                                     ("D2G_K3_GQ_SCALE", [None, None, None, "0.1"]), ("D2G_K3_SUBBATCH", [None, "2", "3", "5"])):
                     v = choices[int(rng.integers(0, len(choices)))]
                     if v is None:
                         os.environ.pop(var, None)
