@@ -803,17 +803,32 @@ def main():
             return d, nc, ms
 
         def k3_traffic(compact):
-            """HBM bytes per call of this variant's kernels from the committed PMC passes, or None"""
+            """HBM bytes per call of this variant's kernels from the committed PMC passes, or None.  A call launches some
+            kernels once per genome range of its pipeline, so the figure is (bytes summed over all dispatches) / (calls); the PMC
+            run makes the same number of calls of either variant, each with one k3_bmh_init_kernel launch."""
             if not (world == 1 and nb == 250 and L == 5_000_000):
                 return None
-            want = (("k3c_hist", "k3c_scan", "k3c_scatter", "k3_split_kernel", "k3_bmh_main_kernel<true, true>", "k3_bmh_survivor", "k3_bmh_verify", "k3_bmh_init") if compact else
-                    ("k3_hist_kernel", "k3_scan_kernel", "k3_scatter_kernel", "k3_refine_kernel", "k3_bmh_main_kernel<false, true>", "k3_bmh_survivor", "k3_bmh_verify",
-                     "k3_bmh_init"))
+            own = (("k3c_hist", "k3c_scan", "k3c_scatter", "k3_split_kernel", "k3_bmh_main_kernel<true, true>") if compact else
+                   ("k3_hist_kernel", "k3_scan_kernel", "k3_scatter_kernel", "k3_refine_kernel", "k3_bmh_main_kernel<false, true>"))
+            shared = ("k3_bmh_survivor", "k3_bmh_verify", "k3_bmh_init")
             try:
                 d = json.load(open(PMC_FILE))
-                tr = [v["hbm_read_bytes_raw"] + v["hbm_write_bytes"] for kk, v in d.items() if any(w in kk for w in want) and "hbm_write_bytes" in v]
-                return float(sum(tr)) if len(tr) >= len(want) - 1 else None
-            except (OSError, ValueError, KeyError):
+                ent = lambda w: [v for kk, v in d.items() if w in kk and "hbm_write_bytes" in v and "dispatches" in v]
+                init = ent("k3_bmh_init")
+                if not init:
+                    return None
+                calls = init[0]["dispatches"] / 2.0                          # per variant
+                tot = lambda v: (v["hbm_read_bytes_raw"] + v["hbm_write_bytes"]) * v["dispatches"]
+                t = 0.0
+                for w in own:
+                    e = ent(w)
+                    if not e:
+                        return None
+                    t += sum(tot(v) for v in e) / calls
+                for w in shared:
+                    t += sum(tot(v) for v in ent(w)) / (2.0 * calls)
+                return float(t)
+            except (OSError, ValueError, KeyError, ZeroDivisionError):
                 return None
 
         os.environ.pop("D2G_K3_COMPACT", None)
