@@ -124,6 +124,8 @@ SIGNATURES = {
     "d2g_allpairs_prepare_dev": (_int, [_vp, _vp, _vp]),
     "d2g_allpairs_prepare_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_vp)]),
     "d2g_allpairs_operand": (_vp, [_vp]),
+    "d2g_allpairs_status": (_int, [_vp, _vp]),
+    "d2g_allpairs_chunks": (_int, [_vp]),
     "d2g_allpairs_step_lut_dev": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "d2g_allpairs_step_eqcount_dev": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_allpairs_step_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -786,6 +788,14 @@ class AllPairs:
     def operand(self):
         """the gathered operand as a (non-owning) CmpSet"""
         return CmpSet(self.ctx, _vp(lib().d2g_allpairs_operand(self._h)), self.N, self.S, owned=False)
+
+    def status(self, stream=None):
+        """synchronises; raises if ANY rank's sharded prepare overflowed its rank table (results invalid everywhere)"""
+        self.ctx._check(lib().d2g_allpairs_status(self._h, stream))
+
+    @property
+    def chunks(self):
+        return lib().d2g_allpairs_chunks(self._h)
 
     def step_lut_dev(self, rows_ptr, lut_ptr, out_ptr, stream=None):
         self.ctx._check(lib().d2g_allpairs_step_lut_dev(self._h, rows_ptr, lut_ptr, out_ptr, stream))

@@ -23,7 +23,21 @@ struct d2g_cmp_set {
     uint32_t T = 0; int logT = 0; // hash space of the rank kernel (power of two >= 1.5 N)
     bool borrowed = false;        // planes/meta belong to the caller (d2g_cmp_set_from_planes_dev)
     bool want_exchange = false;   // d_planes is kept up to date by every prepare (set by the first export)
+    // column plan (bs_colplan_kernel): the 32-register groups are formed from the columns SORTED by their live-plane class, so
+    // that meta[tb] is the maximum over 32 similar columns (equality counts are a sum over columns: any permutation is exact)
+    uint32_t *d_colcnt = nullptr; // [S][BS_CC_STRIDE]: per column, slots 0..3 = rank offset of each split of the rank kernel, slot 4 = #shared values
+    uint32_t *d_perm = nullptr;   // [ntb*32]: the column that sits in each register slot of the operand, ~0 = padding
+    int nsplit = 1;               // workgroups per column in the multi-partition rank kernel (narrow slices of large N: fills the CUs)
+    // exporter sets (the multi-GPU engine's per-rank column slices): the prepare writes the exchange form, the group meta and its
+    // status word straight into the caller's gathered operand; no plane stream, no private d_planes
+    bool export_only = false;
+    uint32_t *ex_planes = nullptr, *ex_meta = nullptr, *ex_status = nullptr;
+    // engine-managed gathered sets (d2g_allpairs): the engine derives the plane stream itself (per chunk, as the groups arrive) and
+    // points the set at the status words every rank's prepare contributed
+    bool managed = false;
+    const uint32_t *status_words = nullptr; int n_status = 0;
 };
+constexpr int BS_CC_STRIDE = 8;
 
 struct PairShape;
 int  finish_shape(d2g_ctx *ctx, PairShape &sh, unsigned rb);   // d2g_k2.hip
@@ -36,6 +50,13 @@ int  d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 void d2g_bitslice_free(d2g_cmp_set *set);
 int  d2g_bitslice_alloc_stream(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_status(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s);   // synchronises; D2G_ERR_INTERNAL on overflow
+// exporter set over an N x S_local column slice (no operand of its own); d2g_bitslice_prepare_slice transposes + prepares it
+// into the target last given to d2g_bitslice_set_export_target
+int  d2g_bitslice_exporter_create(d2g_ctx *ctx, size_t N, size_t S_local, d2g_cmp_set **out);
+void d2g_bitslice_set_export_target(d2g_cmp_set *set, uint32_t *planes, uint32_t *meta, uint32_t *status);
+int  d2g_bitslice_prepare_slice(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *rows_dev, hipStream_t s);
+// plane stream of groups [g0, g1) of a gathered operand (the groups before g0 must have their meta in place)
+int  d2g_bitslice_derive_groups(d2g_ctx *ctx, const d2g_cmp_set *set, int g0, int g1, hipStream_t s);
 // exactly one of (eq_out) or (lut,fout) is non-null
 int  d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out,
                      const float *lut, float *fout, hipStream_t s);

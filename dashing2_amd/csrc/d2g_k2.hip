@@ -211,6 +211,22 @@ static int cmp_set_load(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits
     return D2G_OK;
 }
 
+}  // extern "C"
+
+// exporter sets (d2g_mgpu.hip): transpose the N x S_local slice and prepare it into the export target; timed as "k2prep"
+int d2g_bitslice_prepare_slice(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *rows_dev, hipStream_t s) {
+    d2g_timer tm(ctx, &ctx->ev_k2prep, s);
+    dim3 grid((unsigned)div_up<size_t>(set->S, 32), (unsigned)div_up<size_t>(set->Npad, 32));
+    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, rows_dev, set->d_cols, set->N, set->S, set->Npad);
+    const int rc = d2g_bitslice_prepare(ctx, set, s);
+    tm.stop();
+    if (rc) return rc;
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+extern "C" {
+
 int d2g_cmp_set_create_dev(d2g_ctx *ctx, const uint64_t *sig_bits_dev, size_t N, size_t S, int algo,
                            void *stream, d2g_cmp_set **out) {
     if (!ctx || !out) return D2G_ERR_INVALID;

@@ -55,17 +55,26 @@ __device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
 // writes the ids of that partition.  T >= 1.5 N, so a partition holds <= 2/3 Tl values on average.
 // MULTI: more than one partition (N > 21845).  FAST: one partition and N <= 12288 -- a thread keeps all its values in
 // registers; a kernel of its own so that the general path's registers do not cost it the second workgroup per CU.
+// SPLIT (MULTI only): `nsplit` workgroups share one column, workgroup h = blockIdx.x / S walks the partitions
+// [h nparts/nsplit, (h+1) nparts/nsplit) and ranks its values from 1 on its own; the ids carry h in bits 28-29 and
+// bs_planes_kernel adds the offset of split h (the shared values the splits before it found: colcnt[t][h] after
+// bs_colplan_kernel).  A column slice of N = 50 000 sketches x 64 registers -- one chunk of one rank of the 8-GPU
+// exchange -- is 64 workgroups of one per CU otherwise: a quarter of the chip.
+constexpr uint32_t BS_SPLIT_SHIFT = 28, BS_RANK_MASK = (1u << BS_SPLIT_SHIFT) - 1u;
 template <bool MULTI, bool FAST>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
-                                                                  uint32_t T, int logT, uint32_t *ids_all, uint32_t *max_distinct,
-                                                                  uint32_t *status, int tagbits_max) {
+                                                                  uint32_t T, int logT, uint32_t *ids_all, uint32_t *colcnt,
+                                                                  uint32_t *status, int tagbits_max, uint32_t S, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) uint32_t own[];        // Tl owner slots
-    const size_t t = blockIdx.x;
+    const uint32_t split = MULTI ? blockIdx.x / S : 0u;
+    const size_t t = MULTI ? blockIdx.x - split * S : blockIdx.x;
+    const uint32_t htag = (MULTI && nsplit > 1) ? split << BS_SPLIT_SHIFT : 0u;
     const uint64_t *col = cols + t * Npad;
     uint32_t *ids = ids_all + t * Npad;
     const int tid = threadIdx.x;
     const int logTl = logT < BS_LOG_TLDS_MAX ? logT : BS_LOG_TLDS_MAX;
     const uint32_t Tl = 1u << logTl, mask = Tl - 1, nparts = MULTI ? (T >> logTl) : 1u;
+    const uint32_t part_lo = MULTI ? split * (nparts / (uint32_t)nsplit) : 0u, part_hi = MULTI ? part_lo + nparts / (uint32_t)nsplit : 1u;
     __shared__ uint32_t wave_tot[BS_RANK_THREADS / 64];
     __shared__ uint32_t running;
     constexpr uint32_t BS_MAXFIX = 64;
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         uint32_t r = running + woff + (incl - cnt);
         for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) {
             const uint32_t cur = own[h];
-            if (cur != BS_EMPTY) own[h] = (cur & BS_DUP) ? r++ : BS_UNIQ;
+            if (cur != BS_EMPTY) own[h] = (cur & BS_DUP) ? (r++ | htag) : BS_UNIQ;
         }
         __syncthreads();
         if (tid == 0) running += tot;
@@ -214,11 +223,16 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
             if (j < N && !(skip >> i & 1)) ids[j] = own[hs[i]];
         }
         for (uint32_t k = tid; k < nfix && k < BS_MAXFIX; k += BS_RANK_THREADS) ids[fix_j[k]] = own[fix_h[k]];
-        if (tid == 0) atomicMax(&max_distinct[t >> 5], running);
+        if (tid == 0) colcnt[t * BS_CC_STRIDE] = running - 1;             // #values shared by >= 2 sketches
         return;
     }
 
-    for (uint32_t part = 0; part < nparts; ++part) {
+    // split workgroups write the same ids[] concurrently: a pending word names its partition (bits 15..29; N < 2^28 there), so
+    // that a pass only resolves its own, and nobody initialises ids[] for the others (the buffer is zeroed once, at
+    // allocation; afterwards it only ever holds final ids, which have bit 30 clear)
+    const bool tagged = MULTI && nsplit > 1;
+    for (uint32_t part = part_lo; part < part_hi; ++part) {
+        const uint32_t ptag = BS_PENDING | (tagged ? part << 15 : 0u);
         for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
         __syncthreads();
         // values are fetched PG at a time before their probe chains, and a batch goes through the same two phases as the
@@ -276,15 +290,15 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
 #pragma unroll
             for (int i = 0; i < PG; ++i) {
                 const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
-                if ((mineb & ~redo) >> i & 1) ids[j] = hs[i] | (MULTI ? BS_PENDING : 0u);
-                else if (MULTI && part == 0 && j < N && !(redo >> i & 1)) ids[j] = 0;
+                if ((mineb & ~redo) >> i & 1) ids[j] = hs[i] | (MULTI ? ptag : 0u);
+                else if (MULTI && !tagged && part == 0 && j < N && !(redo >> i & 1)) ids[j] = 0;
             }
             while (redo) {                                                // tag collisions: the exact chain from the home slot
                 const int i = __ffs(redo) - 1;
                 redo &= redo - 1;
                 const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
                 const uint64_t vv = col[j];
-                ids[j] = insert(vv, (uint32_t)j, bs_hash(vv, logT) & mask) | (MULTI ? BS_PENDING : 0u);
+                ids[j] = insert(vv, (uint32_t)j, bs_hash(vv, logT) & mask) | (MULTI ? ptag : 0u);
             }
         }
         __syncthreads();
@@ -299,12 +313,13 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
 #pragma unroll
             for (int i = 0; i < PG; ++i) {
                 const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
-                if (j < N && (!MULTI || (sl[i] & BS_PENDING))) ids[j] = own[sl[i] & ~BS_PENDING];
+                if (j < N && (!MULTI || (tagged ? (sl[i] & ~0x7FFFu) == ptag : (sl[i] & BS_PENDING) != 0)))
+                    ids[j] = own[sl[i] & (tagged ? 0x7FFFu : ~BS_PENDING)];
             }
         }
         __syncthreads();
     }
-    if (tid == 0) atomicMax(&max_distinct[t >> 5], running);              // per 32-register group
+    if (tid == 0) colcnt[t * BS_CC_STRIDE + split] = running - 1;          // #values shared by >= 2 sketches (this split's)
 }
 
 // ------------------------------------------------------------------ 2. 32 x nbits bit transpose
@@ -321,16 +336,116 @@ __device__ __forceinline__ size_t stream_slot(const uint32_t *meta, int tb) {
     return q;
 }
 
+// ------------------------------------------------------------------ 1b. column plan
+// One workgroup.  Input: colcnt[t][h] = shared values split h of the rank kernel found in column t.  Output:
+//   colcnt[t][0..nsplit)  exclusive prefix over the splits (the rank offset bs_planes_kernel adds), colcnt[t][4] = D2(t)
+//   perm[slot]            the column that sits in register slot `slot` of the operand (~0 = padding): the columns in
+//                         DESCENDING order of their live-plane class (stable), so that a 32-register group holds
+//                         columns of similar plane counts and meta[tb] -- a maximum -- does not let one busy column tax
+//                         31 quiet ones.  Equality counts are sums over columns (reference src/cmp_core.cpp:461,506):
+//                         any permutation gives the same counts.
+//   meta[tb]              max over the group's columns of D2 + 1 (also to the export target, with the status word)
+constexpr int BS_PLAN_THREADS = 1024;
+constexpr int BS_PLAN_MAXS = 4096;                // slots sorted in LDS; larger sketches keep the identity order
+constexpr uint32_t BS_NOCOL = 0xFFFFFFFFu;
+__device__ __forceinline__ int plane_class(uint32_t d2) { return d2 == 0 ? 1 : 32 - __clz(d2 + 1); }   // = live_planes(D2 + 1)
+
+__global__ __launch_bounds__(BS_PLAN_THREADS) void bs_colplan_kernel(uint32_t *__restrict__ colcnt, uint32_t S, int ntb, int nsplit,
+                                                                       uint32_t *__restrict__ perm, uint32_t *__restrict__ meta,
+                                                                       const uint32_t *__restrict__ status, uint32_t *__restrict__ ex_meta,
+                                                                       uint32_t *__restrict__ ex_status, int sort) {
+    __shared__ uint32_t d2s[BS_PLAN_MAXS];
+    __shared__ uint16_t perm_s[BS_PLAN_MAXS];
+    __shared__ uint32_t cell[32 * (BS_PLAN_MAXS / 64)];   // (class, 64-slot chunk) counts, then their exclusive prefix
+    __shared__ uint32_t wave_tot[BS_PLAN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t Spad = (uint32_t)ntb * 32u;
+    auto column_total = [&](uint32_t t) {             // D2 of column t; leaves the per-split offsets behind
+        uint32_t run = 0;
+        for (int h = 0; h < nsplit; ++h) { const uint32_t c = colcnt[(size_t)t * BS_CC_STRIDE + h]; colcnt[(size_t)t * BS_CC_STRIDE + h] = run; run += c; }
+        colcnt[(size_t)t * BS_CC_STRIDE + 4] = run;
+        return run;
+    };
+    if (tid == 0 && ex_status) *ex_status = *status;
+    if (!sort || Spad > BS_PLAN_MAXS) {                // identity order
+        for (uint32_t t = tid; t < S; t += BS_PLAN_THREADS) (void)column_total(t);
+        for (uint32_t p = tid; p < Spad; p += BS_PLAN_THREADS) perm[p] = p < S ? p : BS_NOCOL;
+        __threadfence();
+        __syncthreads();
+        for (int g = tid; g < ntb; g += BS_PLAN_THREADS) {
+            uint32_t mx = 0;
+            for (uint32_t x = 0; x < 32; ++x) { const uint32_t t = (uint32_t)g * 32 + x; if (t < S) mx = max(mx, colcnt[(size_t)t * BS_CC_STRIDE + 4]); }
+            meta[g] = mx + 1;
+            if (ex_meta) ex_meta[g] = mx + 1;
+        }
+        return;
+    }
+    const uint32_t nchunk = (Spad + 63) / 64, ncell = 32 * nchunk;
+    for (uint32_t c = tid; c < ncell; c += BS_PLAN_THREADS) cell[c] = 0;
+    __syncthreads();
+    constexpr int IT = BS_PLAN_MAXS / BS_PLAN_THREADS;
+    uint32_t mycell[IT], myrank[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const uint32_t t = (uint32_t)it * BS_PLAN_THREADS + tid;      // a wave covers the 64 consecutive slots of chunk t / 64
+        mycell[it] = 0; myrank[it] = 0;
+        if (t - lane < Spad) {                                         // wave-uniform
+            uint32_t d2 = 0;
+            int cls = 0;                                               // class 0 = padding: sorted behind every real column
+            if (t < S) { d2 = column_total(t); cls = plane_class(d2); }
+            if (t < Spad) d2s[t] = d2;
+            unsigned long long todo = __ballot(t < Spad);
+            while (todo) {                                             // one round per distinct class in the wave
+                const int k = __shfl(cls, __ffsll((long long)todo) - 1);
+                const unsigned long long m = __ballot(cls == k && t < Spad);
+                const uint32_t ci = (uint32_t)(31 - k) * nchunk + t / 64;   // descending class, ascending slot
+                if (cls == k && t < Spad) { mycell[it] = ci; myrank[it] = __popcll(m & ((1ull << lane) - 1)); }
+                if (lane == 0) cell[(uint32_t)(31 - k) * nchunk + (t - lane) / 64] = __popcll(m);
+                todo &= ~m;
+            }
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix over the cells (<= 2048): two per thread
+        const uint32_t c0 = 2u * tid, a = c0 < ncell ? cell[c0] : 0u, b = c0 + 1 < ncell ? cell[c0 + 1] : 0u;
+        uint32_t incl = a + b;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_tot[w];
+        const uint32_t ex = woff + incl - (a + b);
+        if (c0 < ncell) cell[c0] = ex;
+        if (c0 + 1 < ncell) cell[c0 + 1] = ex + a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const uint32_t t = (uint32_t)it * BS_PLAN_THREADS + tid;
+        if (t < Spad) perm_s[cell[mycell[it]] + myrank[it]] = (uint16_t)t;
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < Spad; p += BS_PLAN_THREADS) { const uint32_t t = perm_s[p]; perm[p] = t < S ? t : BS_NOCOL; }
+    for (int g = tid; g < ntb; g += BS_PLAN_THREADS) {
+        uint32_t mx = 0;
+        for (uint32_t x = 0; x < 32; ++x) mx = max(mx, d2s[perm_s[(uint32_t)g * 32 + x]]);
+        meta[g] = mx + 1;
+        if (ex_meta) ex_meta[g] = mx + 1;
+    }
+}
+
 // Writes both forms of the operand:
 //   planes  [ntb][nbits_cap+1][Nstride]  fixed geometry (a function of N only): row-coded id planes + the unique plane in the
 //                                        last slot -- the form ranks exchange (independent per group);
 //   stream  [sum_tb nbits_tb][2][Nstride] what the pair kernel walks: only the LIVE planes, in group order, each as the
 //                                        row-coded words followed by the column-coded words, so that the kernel's operand
 //                                        pointer simply advances by one block per plane (no per-plane address selection).
+// Register slot x of group tb holds column perm[32 tb + x] (bs_colplan_kernel).
 constexpr int BS_FORM_STREAM = 1, BS_FORM_EXCHANGE = 2;
-__global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t S, size_t N, size_t Npad,
+__global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad,
                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
-                                                        size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta, int forms) {
+                                                        size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta, int forms,
+                                                        const uint32_t *__restrict__ perm, const uint32_t *__restrict__ colcnt, int nsplit) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tb = blockIdx.y;
     if (j >= Nstride) return;
@@ -338,8 +453,10 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
     uint32_t id[32];
 #pragma unroll
     for (int x = 0; x < 32; ++x) {
-        const size_t t = tb * 32 + x;
-        id[x] = (t < S && j < N) ? ids[t * Npad + j] : 0u;     // padded registers/sketches: id 0 in both codings
+        const uint32_t t = perm[tb * 32 + x];                 // uniform: scalar loads
+        uint32_t w = (t != BS_NOCOL && j < N) ? ids[(size_t)t * Npad + j] : 0u;     // padded registers/sketches: id 0 in both codings
+        if (nsplit > 1 && !(w >> 31)) w = (w & BS_RANK_MASK) + colcnt[(size_t)t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)];
+        id[x] = w;
     }
     uint32_t u = 0;                                    // the "unique" plane
 #pragma unroll
@@ -347,8 +464,8 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
     // forms: BS_FORM_STREAM = what this GPU's pair kernel walks; BS_FORM_EXCHANGE = what ranks exchange -- written only
     // once somebody has asked for it (d2g_bitslice_export: 29 MB of stores per prepare at config 3 that a single GPU never reads)
     uint32_t *dst = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
-    uint32_t *sdst = stream + stream_slot(meta, (int)tb) * 2 * Nstride + j;
     const bool ex = forms & BS_FORM_EXCHANGE, st = forms & BS_FORM_STREAM;
+    uint32_t *sdst = st ? stream + stream_slot(meta, (int)tb) * 2 * Nstride + j : nullptr;
     for (int b = 0; b < nbits; ++b) {
         uint32_t w = 0;
 #pragma unroll
@@ -365,9 +482,9 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
 // plane stream of an operand that arrived in the exchanged form (the gathered operand of the multi-GPU path,
 // d2g_cmp_set_from_planes_dev)
 __global__ __launch_bounds__(256) void bs_derive_kernel(const uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
-                                                        size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta) {
+                                                        size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta, int tb0) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t tb = blockIdx.y;
+    const size_t tb = (size_t)tb0 + blockIdx.y;
     if (j >= Nstride) return;
     const int nbits = live_planes(meta, (int)tb);
     const uint32_t *src = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
@@ -563,11 +680,8 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
 // Done before EVERY launch on such a set -- the library cannot know when the caller re-gathered into the
 // buffer, and the pass is ~2 % of the pair kernel it precedes.
 int refresh_borrowed(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s) {
-    if (!set->borrowed) return D2G_OK;
-    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(bs_derive_kernel, grid, dim3(256), 0, s, set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta);
-    D2G_HIP(ctx, hipGetLastError());
-    return D2G_OK;
+    if (!set->borrowed || set->managed) return D2G_OK;       // managed: the engine derived the stream as the groups arrived
+    return d2g_bitslice_derive_groups(ctx, set, 0, set->ntb, s);
 }
 
 template <class Store>
@@ -590,7 +704,9 @@ void d2g_bitslice_free(d2g_cmp_set *set) {
     if (!set->borrowed) { (void)hipFree(set->d_planes); (void)hipFree(set->d_meta); }
     (void)hipFree(set->d_stream);
     (void)hipFree(set->d_ids);
-    set->d_planes = set->d_stream = set->d_meta = set->d_ids = nullptr;
+    (void)hipFree(set->d_colcnt);
+    (void)hipFree(set->d_perm);
+    set->d_planes = set->d_stream = set->d_meta = set->d_ids = set->d_colcnt = set->d_perm = nullptr;
 }
 
 // geometry of the bit-sliced operand: a function of N (and S) only, identical on every rank.
@@ -614,18 +730,50 @@ int d2g_bitslice_alloc_stream(d2g_ctx *ctx, d2g_cmp_set *set) {
     return D2G_OK;
 }
 
-// one-time allocation of the bit-sliced operand and its workspace
-int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
+namespace {
+// workspace every preparing set needs (ids, per-column counts, column plan, meta + status); the rank kernel's hash space
+int alloc_prepare_workspace(d2g_ctx *ctx, d2g_cmp_set *set) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
     if (N >= (1ull << 30)) { ctx->last_error = "bitslice: N too large"; return D2G_ERR_UNSUPPORTED; }
     d2g_bitslice_geometry(set);
     // hash space: power of two >= 1.5 N (load <= 2/3), at least 64 slots; walked in LDS-sized partitions
     set->T = 64; set->logT = 6;
     while ((uint64_t)set->T * 2 < (uint64_t)N * 3) { set->T <<= 1; ++set->logT; }
+    // narrow slices of large N: several workgroups per column (each walks its share of the hash partitions) until the CUs are covered
+    set->nsplit = 1;
+    if (set->logT > BS_LOG_TLDS_MAX && N < (1ull << BS_SPLIT_SHIFT)) {
+        const uint32_t nparts = set->T >> BS_LOG_TLDS_MAX;
+        int want = 1;
+        while (want < 4 && (uint32_t)want * 2 <= nparts && S * (size_t)want < (size_t)std::max(ctx->num_cus, 1)) want *= 2;
+        if (const char *e = std::getenv("D2G_BS_NSPLIT")) {                 // tests / experiments
+            const int v = std::atoi(e);
+            if ((v == 1 || v == 2 || v == 4) && (uint32_t)v <= nparts) want = v;
+        }
+        set->nsplit = want;
+    }
     hipError_t e;
     if ((e = hipMalloc((void **)&set->d_ids, S * Npad * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_meta, (size_t)(set->ntb + 4) * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_planes, (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride * sizeof(uint32_t))) != hipSuccess) {
+        (e = hipMemset(set->d_ids, 0, S * Npad * sizeof(uint32_t))) != hipSuccess ||     // split rank passes rely on "no stale pending word"
+        (e = hipMalloc((void **)&set->d_colcnt, S * BS_CC_STRIDE * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_perm, (size_t)set->ntb * 32 * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_meta, (size_t)(set->ntb + 4) * sizeof(uint32_t))) != hipSuccess) {
+        ctx->last_error = std::string("bitslice alloc: ") + hipGetErrorString(e);
+        d2g_bitslice_free(set);
+        return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
+    }
+    return D2G_OK;
+}
+bool sort_columns() {
+    const char *e = std::getenv("D2G_BS_SORT");       // "0": keep the caller's column order (A/B measurements, tests)
+    return !(e && e[0] == '0');
+}
+}  // namespace
+
+// one-time allocation of the bit-sliced operand and its workspace
+int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
+    if (int rc = alloc_prepare_workspace(ctx, set)) return rc;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&set->d_planes, (size_t)set->ntb * (set->nbits_cap + 1) * set->Nstride * sizeof(uint32_t))) != hipSuccess) {
         ctx->last_error = std::string("bitslice alloc: ") + hipGetErrorString(e);
         d2g_bitslice_free(set);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
@@ -634,49 +782,91 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     return D2G_OK;
 }
 
-// ids + planes for the operand currently in set->d_cols.  Fully asynchronous on `s`.
+// ids + column plan + planes for the operand currently in set->d_cols.  Fully asynchronous on `s`.
 // meta[0..ntb) = per-group shared-value counts; meta[ntb] = status word (bit 0: the rank kernel's LDS table
 // overflowed on some column -- see d2g_bitslice_status)
 int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
-    D2G_HIP(ctx, hipMemsetAsync(set->d_meta, 0, (size_t)(set->ntb + 4) * sizeof(uint32_t), s));
+    D2G_HIP(ctx, hipMemsetAsync(set->d_meta + set->ntb, 0, 4 * sizeof(uint32_t), s));
     {
         const int logTl = set->logT < BS_LOG_TLDS_MAX ? set->logT : BS_LOG_TLDS_MAX;
         const size_t lds = (size_t(1) << logTl) * sizeof(uint32_t);
-        void (*kern)(const uint64_t *, size_t, size_t, uint32_t, int, uint32_t *, uint32_t *, uint32_t *, int) = bs_rank_kernel<false, false>;
-        if (set->logT > BS_LOG_TLDS_MAX) kern = bs_rank_kernel<true, false>;
+        void (*kern)(const uint64_t *, size_t, size_t, uint32_t, int, uint32_t *, uint32_t *, uint32_t *, int, uint32_t, int) = bs_rank_kernel<false, false>;
+        const bool multi = set->logT > BS_LOG_TLDS_MAX;
+        if (multi) kern = bs_rank_kernel<true, false>;
         else if (N <= (size_t)12 * BS_RANK_THREADS) kern = bs_rank_kernel<false, true>;     // PF * BS_RANK_THREADS
         int tagbits_max = 31;
         if (const char *e = std::getenv("D2G_BS_TAGBITS")) { const int v = std::atoi(e); if (v >= 0 && v < 31) tagbits_max = v; }   // tests
         if (lds > 48 * 1024)
             D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
-                           set->d_ids, set->d_meta, set->d_meta + set->ntb, tagbits_max);
+        const int nsplit = multi ? set->nsplit : 1;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(S * nsplit)), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
+                           set->d_ids, set->d_colcnt, set->d_meta + set->ntb, tagbits_max, (uint32_t)S, nsplit);
+        hipLaunchKernelGGL(bs_colplan_kernel, dim3(1), dim3(BS_PLAN_THREADS), 0, s, set->d_colcnt, (uint32_t)S, set->ntb, nsplit, set->d_perm,
+                           set->d_meta, set->d_meta + set->ntb, set->ex_meta, set->ex_status, sort_columns() ? 1 : 0);
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, S, N, Npad, set->d_planes, set->d_stream, set->Nstride,
-                       set->nbits_cap, set->d_meta, BS_FORM_STREAM | (set->want_exchange ? BS_FORM_EXCHANGE : 0));
+    const int forms = set->export_only ? BS_FORM_EXCHANGE : (BS_FORM_STREAM | (set->want_exchange ? BS_FORM_EXCHANGE : 0));
+    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, N, Npad, set->export_only ? set->ex_planes : set->d_planes,
+                       set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, forms, set->d_perm, set->d_colcnt,
+                       set->logT > BS_LOG_TLDS_MAX ? set->nsplit : 1);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
 
 // the exchange form of the operand last prepared: written from the ids on first request, by every prepare afterwards
 int d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
-    if (set->borrowed || set->want_exchange) return D2G_OK;
+    if (set->borrowed || set->want_exchange || set->export_only) return D2G_OK;
     set->want_exchange = true;
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, set->S, set->N, set->Npad, set->d_planes, set->d_stream,
-                       set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE);
+    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, set->N, set->Npad, set->d_planes, set->d_stream,
+                       set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE, set->d_perm, set->d_colcnt,
+                       set->logT > BS_LOG_TLDS_MAX ? set->nsplit : 1);
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+// ---- exporter sets: the multi-GPU engine's per-rank column slices (d2g_mgpu.hip)
+int d2g_bitslice_exporter_create(d2g_ctx *ctx, size_t N, size_t S_local, d2g_cmp_set **out) {
+    *out = nullptr;
+    d2g_cmp_set *set = new (std::nothrow) d2g_cmp_set();
+    if (!set) return D2G_ERR_NOMEM;
+    set->ctx = ctx; set->N = N; set->S = S_local;
+    set->Npad = div_up<size_t>(N, BS_CB) * BS_CB;
+    set->algo = D2G_CMP_BITSLICE;
+    set->export_only = true;
+    hipError_t e = hipMalloc((void **)&set->d_cols, set->Npad * S_local * sizeof(uint64_t));
+    if (e != hipSuccess) { ctx->last_error = std::string("bitslice exporter alloc: ") + hipGetErrorString(e); delete set; return D2G_ERR_NOMEM; }
+    if (int rc = alloc_prepare_workspace(ctx, set)) { (void)hipFree(set->d_cols); delete set; return rc; }
+    *out = set;
+    return D2G_OK;
+}
+void d2g_bitslice_set_export_target(d2g_cmp_set *set, uint32_t *planes, uint32_t *meta, uint32_t *status) {
+    set->ex_planes = planes; set->ex_meta = meta; set->ex_status = status;
+}
+
+int d2g_bitslice_derive_groups(d2g_ctx *ctx, const d2g_cmp_set *set, int g0, int g1, hipStream_t s) {
+    if (g1 <= g0) return D2G_OK;
+    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)(g1 - g0));
+    hipLaunchKernelGGL(bs_derive_kernel, grid, dim3(256), 0, s, set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, g0);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
 
 // synchronises `s`; D2G_ERR_INTERNAL when the last prepare overflowed its hash partitions
 int d2g_bitslice_status(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s) {
-    if (set->borrowed) return D2G_OK;                 // a gathered operand has no status word of its own
     uint32_t st = 0;
-    D2G_HIP(ctx, hipMemcpyAsync(&st, set->d_meta + set->ntb, sizeof(st), hipMemcpyDeviceToHost, s));
-    D2G_HIP(ctx, hipStreamSynchronize(s));
+    if (set->borrowed) {
+        // a gathered operand has no status word of its own; the multi-GPU engine's carries one per preparing rank and chunk
+        if (!set->status_words || set->n_status <= 0) { D2G_HIP(ctx, hipStreamSynchronize(s)); return D2G_OK; }
+        std::vector<uint32_t> w((size_t)set->n_status);
+        D2G_HIP(ctx, hipMemcpyAsync(w.data(), set->status_words, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        D2G_HIP(ctx, hipStreamSynchronize(s));
+        for (uint32_t x : w) st |= x;
+    } else {
+        D2G_HIP(ctx, hipMemcpyAsync(&st, set->d_meta + set->ntb, sizeof(st), hipMemcpyDeviceToHost, s));
+        D2G_HIP(ctx, hipStreamSynchronize(s));
+    }
     if (st & 1u) {
         ctx->last_error = "bitslice prepare: a register column put more distinct values into one hash partition than its LDS table holds "
                           "(adversarial / extremely skewed column); use D2G_CMP_DIRECT for this matrix";

@@ -52,9 +52,19 @@ Rccl *rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // a copy already loaded
-        if (!r.lib) for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-        if (!r.lib) { r.err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "not found"); return; }
+        // D2G_RCCL_LIB: an explicit library path (deployments with a private RCCL; tests point it at a missing file to
+        // exercise the "no RCCL" error path)
+        const char *forced = std::getenv("D2G_RCCL_LIB");
+        if (forced && forced[0]) r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        else {
+            for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;   // a copy already loaded
+            if (!r.lib) for (const char *n : names) if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        }
+        if (!r.lib) {                                 // dlerror() clears the message it returns: read it ONCE
+            const char *e = dlerror();
+            r.err = std::string("cannot load RCCL: ") + (e ? e : "not found");
+            return;
+        }
         auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("RCCL lacks ") + n; return p; };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
@@ -167,17 +177,17 @@ int comm_group_end(d2g_comm *c) {
 }
 
 // ------------------------------------------------------------------------------------------- pack kernel
-// rows [n][S] -> W consecutive blocks, block q = [n][cols_q] with cols_q = [colstart[q], colstart[q+1]):
-// the send layout of the row-slice -> column-slice exchange, one launch.
-__global__ __launch_bounds__(256) void mg_pack_kernel(const uint64_t *__restrict__ rows, size_t n, size_t S, int W,
-                                                      const uint32_t *__restrict__ colstart, uint64_t *__restrict__ out) {
+// rows [n][S] -> consecutive blocks, block b = [n][cols_b] with cols_b = [colstart[b], colstart[b+1]) (blocks are in
+// ascending column order, so block b starts at n * colstart[b]): the send layout of the row-slice -> column-slice
+// exchange, one launch.  colblk[c] = block of column c.
+__global__ __launch_bounds__(256) void mg_pack_kernel(const uint64_t *__restrict__ rows, size_t n, size_t S,
+                                                      const uint32_t *__restrict__ colstart, const uint16_t *__restrict__ colblk,
+                                                      uint64_t *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n * S) return;
     const size_t r = i / S;
     const uint32_t c = (uint32_t)(i - r * S);
-    int q = 0;
-    while (q + 1 < W && colstart[q + 1] <= c) ++q;                     // W is small; uniform-ish scalar walk
-    const uint32_t c0 = colstart[q], wq = colstart[q + 1] - c0;
+    const uint32_t q = colblk[c], c0 = colstart[q], wq = colstart[q + 1] - c0;
     out[(size_t)n * c0 + r * wq + (c - c0)] = rows[i];
 }
 
@@ -187,33 +197,48 @@ template <class T> std::vector<T> even_split(T total, int parts) {     // [parts
     return b;
 }
 
+constexpr int MG_MAX_CHUNKS = 4;
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- the engine
+// Inside ONE step the exchanges overlap the sharded prepare: a rank's column slice is cut into C chunks of whole
+// 32-register groups, and chunk c+1 is on the wire (engine stream `xs`) while chunk c is ranked and bit-sliced
+// (compute stream); its planes leave while chunk c+1 is prepared.  The gathered operand keeps its groups in
+// CHUNK-MAJOR order (all ranks' chunk 0, then chunk 1, ...): the pair kernel does not care about the order of
+// groups, and the plane stream of chunk c can be derived as soon as chunk c has arrived.
 struct d2g_allpairs {
     d2g_ctx *ctx = nullptr;
     d2g_comm *comm = nullptr;
     size_t N = 0, S = 0;
-    int W = 1, rank = 0;
+    int W = 1, rank = 0, C = 1;
     std::vector<size_t> row_lo;          // [W+1] rows each rank holds
-    std::vector<size_t> grp_lo;          // [W+1] 32-register groups each rank prepares
-    std::vector<uint32_t> colstart;      // [W+1] first register column of each rank's slice (last = S)
+    std::vector<size_t> blk_g;           // [W*C+1] natural group bounds of block q*C + c (rank q, chunk c)
+    std::vector<uint32_t> colstart;      // [W*C+1] first register column of each block (last = S)
+    std::vector<size_t> gpos;            // [W*C] first group of each block in the gathered (chunk-major) order
+    std::vector<size_t> chunk_g0;        // [C+1] gathered groups of chunk c = [chunk_g0[c], chunk_g0[c+1])
     size_t r0 = 0, r1 = 0;               // rows of the triangle this rank computes
     size_t gw = 0, ng = 0;               // words per exchanged group, number of groups
     uint32_t *d_colstart = nullptr;
+    uint16_t *d_colblk = nullptr;
     uint64_t *d_send = nullptr, *d_recv = nullptr;
-    d2g_cmp_set *local = nullptr;        // my column slice (N x S_me), bit-sliced
+    d2g_cmp_set *local[MG_MAX_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};   // my column slice, chunk by chunk (exporter sets)
     // two operand buffers: the pipelined form prepares buffer i+1 while the pair kernel reads buffer i
-    uint32_t *d_planes[2] = {nullptr, nullptr}, *d_meta[2] = {nullptr, nullptr};
+    uint32_t *d_planes[2] = {nullptr, nullptr}, *d_meta[2] = {nullptr, nullptr};   // meta: [ng] groups + [W*C] status words
     d2g_cmp_set *full[2] = {nullptr, nullptr};
-    hipStream_t xs = nullptr;            // exchange/prepare stream of the pipelined form
-    hipEvent_t x_done[2] = {nullptr, nullptr}, p_done[2] = {nullptr, nullptr}, in_ready = nullptr;
-    bool p_valid[2] = {false, false};
+    hipStream_t xs = nullptr;            // exchange stream
+    hipStream_t ps = nullptr;            // compute stream of the pipelined form's prepare
+    hipEvent_t ev_pack = nullptr, ev_x1[MG_MAX_CHUNKS] = {}, ev_prep[MG_MAX_CHUNKS] = {}, ev_x2[MG_MAX_CHUNKS] = {};
+    hipEvent_t x_done[2] = {nullptr, nullptr}, p_done[2] = {nullptr, nullptr}, in_ready = nullptr, plain_done = nullptr;
+    bool p_valid[2] = {false, false}, plain_valid = false;
     unsigned long long nsteps = 0;
     int last = 0;                        // buffer of the most recent prepare
+    int blk(int q, int c) const { return q * C + c; }
     size_t n_me() const { return row_lo[rank + 1] - row_lo[rank]; }
-    size_t s_me() const { return colstart[rank + 1] - colstart[rank]; }
-    size_t g_me() const { return grp_lo[rank + 1] - grp_lo[rank]; }
+    size_t w_blk(int b) const { return colstart[b + 1] - colstart[b]; }
+    size_t g_blk(int b) const { return blk_g[b + 1] - blk_g[b]; }
+    size_t s_me() const { return colstart[blk(rank, C - 1) + 1] - colstart[blk(rank, 0)]; }
+    uint64_t *recv_chunk(int c) const { return d_recv + N * (colstart[blk(rank, c)] - colstart[blk(rank, 0)]); }
 };
 
 namespace {
@@ -221,74 +246,117 @@ namespace {
 int eng_alloc_buffer(d2g_allpairs *e, int b) {
     d2g_ctx *ctx = e->ctx;
     if (e->full[b]) return D2G_OK;
+    const size_t nstat = (size_t)e->W * e->C;
     D2G_HIP(ctx, hipMalloc((void **)&e->d_planes[b], std::max<size_t>(e->ng * e->gw, 1) * 4));
-    D2G_HIP(ctx, hipMalloc((void **)&e->d_meta[b], std::max<size_t>(e->ng, 1) * 4));
-    return d2g_cmp_set_from_planes_dev(ctx, e->N, e->S, e->d_planes[b], e->d_meta[b], &e->full[b]);
-}
-
-// phases of one step on buffer b, all enqueued on stream s
-int phase_pack(d2g_allpairs *e, const uint64_t *rows_dev, hipStream_t s) {
-    const size_t n = e->n_me();
-    if (!n) return D2G_OK;
-    D2G_CHECK(e->ctx, rows_dev != nullptr, "allpairs: null row block");
-    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
-    hipLaunchKernelGGL(mg_pack_kernel, dim3((unsigned)div_up<size_t>(n * e->S, 256)), dim3(256), 0, s, rows_dev, n, e->S, e->W,
-                       e->d_colstart, e->d_send);
-    D2G_HIP(e->ctx, hipGetLastError());
+    D2G_HIP(ctx, hipMalloc((void **)&e->d_meta[b], (e->ng + nstat + 4) * 4));
+    D2G_HIP(ctx, hipMemset(e->d_meta[b], 0, (e->ng + nstat + 4) * 4));      // blocks without groups never write their status word
+    if (int rc = d2g_cmp_set_from_planes_dev(ctx, e->N, e->S, e->d_planes[b], e->d_meta[b], &e->full[b])) return rc;
+    e->full[b]->managed = true;                                             // the engine derives the plane stream, chunk by chunk
+    e->full[b]->status_words = e->d_meta[b] + e->ng;
+    e->full[b]->n_status = (int)nstat;
     return D2G_OK;
 }
-int phase_x1(d2g_allpairs *e, hipStream_t s) {                         // inside a comm group
-    const size_t n = e->n_me(), sm = e->s_me();
+
+// phases of one step on buffer b
+int phase_pack(d2g_allpairs *e, const uint64_t *rows_dev, hipStream_t s) {
+    const size_t n = e->n_me();
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    if (n) {
+        D2G_CHECK(e->ctx, rows_dev != nullptr, "allpairs: null row block");
+        hipLaunchKernelGGL(mg_pack_kernel, dim3((unsigned)div_up<size_t>(n * e->S, 256)), dim3(256), 0, s, rows_dev, n, e->S,
+                           e->d_colstart, e->d_colblk, e->d_send);
+        D2G_HIP(e->ctx, hipGetLastError());
+    }
+    return D2G_OK;
+}
+int phase_x1(d2g_allpairs *e, int c, hipStream_t s) {                  // inside a comm group: chunk c of everybody's column slice
+    const size_t n = e->n_me(), wm = e->w_blk(e->blk(e->rank, c));
     D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
     for (int q = 0; q < e->W; ++q) {
-        const size_t wq = e->colstart[q + 1] - e->colstart[q];
-        const uint64_t *src = e->d_send + n * e->colstart[q];          // block q of my rows
-        uint64_t *dst = e->d_recv + e->row_lo[q] * sm;                  // rows of rank q, my columns
+        const int bq = e->blk(q, c);
+        const size_t wq = e->w_blk(bq);
+        const uint64_t *src = e->d_send + n * e->colstart[bq];          // my rows x the columns of block (q, c)
+        uint64_t *dst = e->recv_chunk(c) + e->row_lo[q] * wm;           // rows of rank q x my chunk-c columns
         const size_t nq = e->row_lo[q + 1] - e->row_lo[q];
         if (q == e->rank) {
             if (n * wq) D2G_HIP(e->ctx, hipMemcpyAsync(dst, src, n * wq * 8, hipMemcpyDeviceToDevice, s));
             continue;
         }
         if (int rc = comm_send(e->comm, q, src, n * wq * 8, s)) return rc;
-        if (int rc = comm_recv(e->comm, q, dst, nq * sm * 8, s)) return rc;
+        if (int rc = comm_recv(e->comm, q, dst, nq * wm * 8, s)) return rc;
     }
     return D2G_OK;
 }
-int phase_prepare(d2g_allpairs *e, int b, hipStream_t s) {
-    if (!e->s_me()) return D2G_OK;                                     // more ranks than register groups: nothing to prepare here
-    int rc;
-    if (!e->local) rc = d2g_cmp_set_create_dev(e->ctx, e->d_recv, e->N, e->s_me(), D2G_CMP_BITSLICE, s, &e->local);
-    else rc = d2g_cmp_set_update_dev(e->ctx, e->local, e->d_recv, s);
-    if (rc) return rc;
-    // my groups go straight to their place in the gathered operand
-    return d2g_cmp_set_export_operand_dev(e->ctx, e->local, e->d_planes[b] + e->grp_lo[e->rank] * e->gw, e->d_meta[b] + e->grp_lo[e->rank], s);
-}
-int phase_x2(d2g_allpairs *e, int b, hipStream_t s) {                  // inside a comm group
+int phase_prepare(d2g_allpairs *e, int c, int b, hipStream_t s) {
+    const int bm = e->blk(e->rank, c);
+    if (!e->w_blk(bm)) return D2G_OK;                                  // more ranks (x chunks) than register groups: nothing here
     D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
-    const size_t gm = e->g_me();
+    if (!e->local[c])
+        if (int rc = d2g_bitslice_exporter_create(e->ctx, e->N, e->w_blk(bm), &e->local[c])) return rc;
+    // my groups go straight to their place in the gathered operand, with their meta and this block's status word
+    d2g_bitslice_set_export_target(e->local[c], e->d_planes[b] + e->gpos[bm] * e->gw, e->d_meta[b] + e->gpos[bm], e->d_meta[b] + e->ng + bm);
+    return d2g_bitslice_prepare_slice(e->ctx, e->local[c], e->recv_chunk(c), s);
+}
+int phase_x2(d2g_allpairs *e, int c, int b, hipStream_t s) {           // inside a comm group: chunk c of everybody's groups
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    const int bm = e->blk(e->rank, c);
+    const size_t gm = e->g_blk(bm);
     for (int q = 0; q < e->W; ++q) {
         if (q == e->rank) continue;
-        const size_t gq = e->grp_lo[q + 1] - e->grp_lo[q];
-        if (int rc = comm_send(e->comm, q, e->d_planes[b] + e->grp_lo[e->rank] * e->gw, gm * e->gw * 4, s)) return rc;
-        if (int rc = comm_send(e->comm, q, e->d_meta[b] + e->grp_lo[e->rank], gm * 4, s)) return rc;
-        if (int rc = comm_recv(e->comm, q, e->d_planes[b] + e->grp_lo[q] * e->gw, gq * e->gw * 4, s)) return rc;
-        if (int rc = comm_recv(e->comm, q, e->d_meta[b] + e->grp_lo[q], gq * 4, s)) return rc;
+        const int bq = e->blk(q, c);
+        const size_t gq = e->g_blk(bq);
+        if (int rc = comm_send(e->comm, q, e->d_planes[b] + e->gpos[bm] * e->gw, gm * e->gw * 4, s)) return rc;
+        if (int rc = comm_send(e->comm, q, e->d_meta[b] + e->gpos[bm], gm * 4, s)) return rc;
+        if (int rc = comm_send(e->comm, q, e->d_meta[b] + e->ng + bm, gm ? 4 : 0, s)) return rc;
+        if (int rc = comm_recv(e->comm, q, e->d_planes[b] + e->gpos[bq] * e->gw, gq * e->gw * 4, s)) return rc;
+        if (int rc = comm_recv(e->comm, q, e->d_meta[b] + e->gpos[bq], gq * 4, s)) return rc;
+        if (int rc = comm_recv(e->comm, q, e->d_meta[b] + e->ng + bq, gq ? 4 : 0, s)) return rc;
     }
     return D2G_OK;
 }
 
-// exchange + sharded prepare for n ranks driven by this thread (n = 1: one process per GPU)
-int prepare_many(d2g_allpairs **es, int n, const uint64_t *const *rows, const int *bufs, hipStream_t const *ss) {
-    int rc;
-    for (int i = 0; i < n; ++i) if ((rc = eng_alloc_buffer(es[i], bufs[i]))) return rc;
-    for (int i = 0; i < n; ++i) if ((rc = phase_pack(es[i], rows[i], ss[i]))) return rc;
-    if ((rc = comm_group_begin(es[0]->comm))) return rc;
-    for (int i = 0; i < n; ++i) if ((rc = phase_x1(es[i], ss[i]))) { (void)comm_group_end(es[0]->comm); return rc; }
-    if ((rc = comm_group_end(es[0]->comm))) return rc;
-    for (int i = 0; i < n; ++i) if ((rc = phase_prepare(es[i], bufs[i], ss[i]))) return rc;
-    if ((rc = comm_group_begin(es[0]->comm))) return rc;
-    for (int i = 0; i < n; ++i) if ((rc = phase_x2(es[i], bufs[i], ss[i]))) { (void)comm_group_end(es[0]->comm); return rc; }
-    if ((rc = comm_group_end(es[0]->comm))) return rc;
+#define MG_TRY(call) do { if (int rc__ = (call)) return rc__; } while (0)
+
+// exchange + sharded prepare for n ranks driven by this thread (n = 1: one process per GPU).  cs[i] = the stream the
+// compute phases of engine i are enqueued on (the caller's stream, or the engine's own in the pipelined form); the
+// exchanges run on the engines' xs streams.  Afterwards cs[i] holds the complete plane stream of buffer bufs[i].
+int prepare_many(d2g_allpairs **es, int n, const uint64_t *const *rows, const int *bufs, hipStream_t const *cs) {
+    const int C = es[0]->C;
+    for (int i = 0; i < n; ++i) MG_TRY(eng_alloc_buffer(es[i], bufs[i]));
+    for (int i = 0; i < n; ++i) {
+        d2g_allpairs *e = es[i];
+        MG_TRY(phase_pack(e, rows[i], cs[i]));
+        D2G_HIP(e->ctx, hipEventRecord(e->ev_pack, cs[i]));
+        D2G_HIP(e->ctx, hipStreamWaitEvent(e->xs, e->ev_pack, 0));
+    }
+    for (int c = 0; c < C; ++c) {                                       // all row->column exchanges, back to back on xs
+        MG_TRY(comm_group_begin(es[0]->comm));
+        for (int i = 0; i < n; ++i) if (int rc = phase_x1(es[i], c, es[i]->xs)) { (void)comm_group_end(es[0]->comm); return rc; }
+        MG_TRY(comm_group_end(es[0]->comm));
+        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipEventRecord(es[i]->ev_x1[c], es[i]->xs)); }
+    }
+    for (int c = 0; c < C; ++c)                                         // chunk c is prepared while chunk c+1 is still arriving
+        for (int i = 0; i < n; ++i) {
+            d2g_allpairs *e = es[i];
+            D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+            D2G_HIP(e->ctx, hipStreamWaitEvent(cs[i], e->ev_x1[c], 0));
+            MG_TRY(phase_prepare(e, c, bufs[i], cs[i]));
+            D2G_HIP(e->ctx, hipEventRecord(e->ev_prep[c], cs[i]));
+        }
+    for (int c = 0; c < C; ++c) {                                       // its planes leave while chunk c+1 is prepared
+        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipStreamWaitEvent(es[i]->xs, es[i]->ev_prep[c], 0)); }
+        MG_TRY(comm_group_begin(es[0]->comm));
+        for (int i = 0; i < n; ++i) if (int rc = phase_x2(es[i], c, bufs[i], es[i]->xs)) { (void)comm_group_end(es[0]->comm); return rc; }
+        MG_TRY(comm_group_end(es[0]->comm));
+        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipEventRecord(es[i]->ev_x2[c], es[i]->xs)); }
+    }
+    for (int c = 0; c < C; ++c)                                         // plane stream of chunk c as soon as it is complete
+        for (int i = 0; i < n; ++i) {
+            d2g_allpairs *e = es[i];
+            D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+            D2G_HIP(e->ctx, hipStreamWaitEvent(cs[i], e->ev_x2[c], 0));
+            MG_TRY(d2g_bitslice_derive_groups(e->ctx, e->full[bufs[i]], (int)e->chunk_g0[c], (int)e->chunk_g0[c + 1], cs[i]));
+        }
     for (int i = 0; i < n; ++i) es[i]->last = bufs[i];
     return D2G_OK;
 }
@@ -297,7 +365,7 @@ int check_group(d2g_allpairs **es, int n) {
     if (!es || n < 1 || !es[0]) return D2G_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
         if (!es[i]) return D2G_ERR_INVALID;
-        D2G_CHECK(es[i]->ctx, es[i]->N == es[0]->N && es[i]->S == es[0]->S && es[i]->W == es[0]->W, "allpairs: engines of different shapes");
+        D2G_CHECK(es[i]->ctx, es[i]->N == es[0]->N && es[i]->S == es[0]->S && es[i]->W == es[0]->W && es[i]->C == es[0]->C, "allpairs: engines of different shapes");
     }
     return D2G_OK;
 }
@@ -386,12 +454,9 @@ int d2g_comm_is_rccl(const d2g_comm *c) { return c && c->nccl != nullptr; }
 
 // the whole matrix from the host to every GPU of this process -- one H2D to ctxs[0], then ONE
 // RCCL broadcast over xGMI (loopback: plain copies).  sig_dev_out[i] is allocated on ctxs[i] (d2g_free).
-int d2g_bcast_sigs(d2g_ctx **ctxs, d2g_comm **comms, int nctx, const uint64_t *host_sig, size_t N, size_t S, uint64_t **sig_dev_out) {
-    if (!ctxs || !comms || nctx < 1 || !sig_dev_out || !ctxs[0]) return D2G_ERR_INVALID;
+// On failure nothing stays allocated and sig_dev_out[] is all NULL.
+static int bcast_sigs_impl(d2g_ctx **ctxs, d2g_comm **comms, int nctx, const uint64_t *host_sig, size_t bytes, uint64_t **sig_dev_out) {
     d2g_ctx *c0 = ctxs[0];
-    D2G_CHECK(c0, host_sig != nullptr && N >= 1 && S >= 1, "bcast_sigs: empty matrix");
-    const size_t bytes = N * S * 8;
-    for (int i = 0; i < nctx; ++i) sig_dev_out[i] = nullptr;
     for (int i = 0; i < nctx; ++i) {
         D2G_CHECK(c0, ctxs[i] && comms[i] && comms[i]->ctx == ctxs[i] && comms[i]->world == nctx && comms[i]->rank == i, "bcast_sigs: comm/ctx mismatch");
         D2G_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
@@ -409,12 +474,14 @@ int d2g_bcast_sigs(d2g_ctx **ctxs, d2g_comm **comms, int nctx, const uint64_t *h
             }
             D2G_NCCL(c0, rccl()->GroupEnd());
         } else {
-            if (int rc = comm_group_begin(comms[0])) return rc;
-            for (int i = 1; i < nctx; ++i) {
-                if (int rc = comm_send(comms[0], i, sig_dev_out[0], bytes, nullptr)) return rc;
-                if (int rc = comm_recv(comms[i], 0, sig_dev_out[i], bytes, nullptr)) return rc;
+            // the group is always closed again: an error in between must not leave stale operations for the next group
+            int rc = comm_group_begin(comms[0]);
+            for (int i = 1; i < nctx && rc == D2G_OK; ++i) {
+                rc = comm_send(comms[0], i, sig_dev_out[0], bytes, nullptr);
+                if (rc == D2G_OK) rc = comm_recv(comms[i], 0, sig_dev_out[i], bytes, nullptr);
             }
-            if (int rc = comm_group_end(comms[0])) return rc;
+            if (rc != D2G_OK) { if (comms[0]->lg) { comms[0]->lg->pending.clear(); comms[0]->lg->depth = 0; } return rc; }
+            if ((rc = comm_group_end(comms[0]))) return rc;
         }
     }
     for (int i = 0; i < nctx; ++i) {
@@ -422,6 +489,16 @@ int d2g_bcast_sigs(d2g_ctx **ctxs, d2g_comm **comms, int nctx, const uint64_t *h
         D2G_HIP(ctxs[i], hipStreamSynchronize(nullptr));
     }
     return D2G_OK;
+}
+int d2g_bcast_sigs(d2g_ctx **ctxs, d2g_comm **comms, int nctx, const uint64_t *host_sig, size_t N, size_t S, uint64_t **sig_dev_out) {
+    if (!ctxs || !comms || nctx < 1 || !sig_dev_out || !ctxs[0]) return D2G_ERR_INVALID;
+    D2G_CHECK(ctxs[0], host_sig != nullptr && N >= 1 && S >= 1, "bcast_sigs: empty matrix");
+    for (int i = 0; i < nctx; ++i) sig_dev_out[i] = nullptr;
+    const int rc = bcast_sigs_impl(ctxs, comms, nctx, host_sig, N * S * 8, sig_dev_out);
+    if (rc != D2G_OK)
+        for (int i = 0; i < nctx; ++i)
+            if (sig_dev_out[i] && ctxs[i]) { (void)hipSetDevice(ctxs[i]->device); (void)hipDeviceSynchronize(); (void)hipFree(sig_dev_out[i]); sig_dev_out[i] = nullptr; }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------- engine
@@ -436,21 +513,55 @@ int d2g_allpairs_create(d2g_ctx *ctx, d2g_comm *comm, size_t N, size_t S, d2g_al
     e->ctx = ctx; e->comm = comm; e->N = N; e->S = S; e->W = comm->world; e->rank = comm->rank;
     e->row_lo = even_split<size_t>(N, e->W);
     if (int rc = d2g_operand_layout(N, S, &e->gw, &e->ng)) { delete e; return rc; }
-    e->grp_lo = even_split<size_t>(e->ng, e->W);
-    e->colstart.resize(e->W + 1);
-    for (int q = 0; q <= e->W; ++q) e->colstart[q] = (uint32_t)std::min<size_t>(S, e->grp_lo[q] * 32);
+    // chunks per rank: at least two 32-register groups each, at most MG_MAX_CHUNKS (a function of the shape only: every rank agrees)
+    e->C = e->W == 1 ? 1 : (int)std::min<size_t>(MG_MAX_CHUNKS, std::max<size_t>(1, e->ng / e->W / 2));
+    if (const char *env = std::getenv("D2G_MGPU_CHUNKS")) { const int v = std::atoi(env); if (v >= 1 && v <= MG_MAX_CHUNKS) e->C = v; }
+    const int nb = e->W * e->C;
+    const std::vector<size_t> grp_lo = even_split<size_t>(e->ng, e->W);
+    e->blk_g.assign(nb + 1, e->ng);
+    for (int q = 0; q < e->W; ++q) {
+        const std::vector<size_t> cb = even_split<size_t>(grp_lo[q + 1] - grp_lo[q], e->C);
+        for (int c = 0; c < e->C; ++c) e->blk_g[e->blk(q, c)] = grp_lo[q] + cb[c];
+    }
+    e->colstart.resize(nb + 1);
+    for (int b = 0; b <= nb; ++b) e->colstart[b] = (uint32_t)std::min<size_t>(S, e->blk_g[b] * 32);
+    e->gpos.resize(nb);
+    e->chunk_g0.assign(e->C + 1, 0);
+    {
+        size_t g = 0;
+        for (int c = 0; c < e->C; ++c) {
+            e->chunk_g0[c] = g;
+            for (int q = 0; q < e->W; ++q) { e->gpos[e->blk(q, c)] = g; g += e->g_blk(e->blk(q, c)); }
+        }
+        e->chunk_g0[e->C] = g;                                       // == ng
+    }
+    std::vector<uint16_t> colblk(S);
+    for (int b = 0; b < nb; ++b) for (uint32_t c = e->colstart[b]; c < e->colstart[b + 1]; ++c) colblk[c] = (uint16_t)b;
     std::vector<size_t> ob(e->W + 1);
     d2g_ut_partition(N, e->W, ob.data());
     e->r0 = ob[e->rank]; e->r1 = ob[e->rank + 1];
     hipError_t he;
-    if ((he = hipMalloc((void **)&e->d_colstart, (e->W + 1) * 4)) != hipSuccess ||
-        (he = hipMemcpy(e->d_colstart, e->colstart.data(), (e->W + 1) * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+    if ((he = hipMalloc((void **)&e->d_colstart, (nb + 1) * 4)) != hipSuccess ||
+        (he = hipMemcpy(e->d_colstart, e->colstart.data(), (nb + 1) * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (he = hipMalloc((void **)&e->d_colblk, S * 2)) != hipSuccess ||
+        (he = hipMemcpy(e->d_colblk, colblk.data(), S * 2, hipMemcpyHostToDevice)) != hipSuccess ||
         (he = hipMalloc((void **)&e->d_send, std::max<size_t>(e->n_me() * S, 1) * 8)) != hipSuccess ||
-        (he = hipMalloc((void **)&e->d_recv, std::max<size_t>(N * e->s_me(), 1) * 8)) != hipSuccess) {
+        (he = hipMalloc((void **)&e->d_recv, std::max<size_t>(N * e->s_me(), 1) * 8)) != hipSuccess ||
+        (he = hipStreamCreateWithFlags(&e->xs, hipStreamNonBlocking)) != hipSuccess ||
+        (he = hipEventCreateWithFlags(&e->ev_pack, hipEventDisableTiming)) != hipSuccess ||
+        (he = hipEventCreateWithFlags(&e->plain_done, hipEventDisableTiming)) != hipSuccess) {
         ctx->last_error = std::string("allpairs alloc: ") + hipGetErrorString(he);
         d2g_allpairs_destroy(e);
         return he == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
+    for (int c = 0; c < e->C; ++c)
+        if ((he = hipEventCreateWithFlags(&e->ev_x1[c], hipEventDisableTiming)) != hipSuccess ||
+            (he = hipEventCreateWithFlags(&e->ev_prep[c], hipEventDisableTiming)) != hipSuccess ||
+            (he = hipEventCreateWithFlags(&e->ev_x2[c], hipEventDisableTiming)) != hipSuccess) {
+            ctx->last_error = std::string("allpairs alloc: ") + hipGetErrorString(he);
+            d2g_allpairs_destroy(e);
+            return D2G_ERR_HIP;
+        }
     if (int rc = eng_alloc_buffer(e, 0)) { d2g_allpairs_destroy(e); return rc; }
     *out = e;
     return D2G_OK;
@@ -466,10 +577,18 @@ void d2g_allpairs_destroy(d2g_allpairs *e) {
         if (e->x_done[b]) (void)hipEventDestroy(e->x_done[b]);
         if (e->p_done[b]) (void)hipEventDestroy(e->p_done[b]);
     }
+    for (int c = 0; c < MG_MAX_CHUNKS; ++c) {
+        d2g_cmp_set_destroy(e->local[c]);
+        if (e->ev_x1[c]) (void)hipEventDestroy(e->ev_x1[c]);
+        if (e->ev_prep[c]) (void)hipEventDestroy(e->ev_prep[c]);
+        if (e->ev_x2[c]) (void)hipEventDestroy(e->ev_x2[c]);
+    }
+    if (e->ev_pack) (void)hipEventDestroy(e->ev_pack);
     if (e->in_ready) (void)hipEventDestroy(e->in_ready);
-    d2g_cmp_set_destroy(e->local);
-    (void)hipFree(e->d_colstart); (void)hipFree(e->d_send); (void)hipFree(e->d_recv);
+    if (e->plain_done) (void)hipEventDestroy(e->plain_done);
+    (void)hipFree(e->d_colstart); (void)hipFree(e->d_colblk); (void)hipFree(e->d_send); (void)hipFree(e->d_recv);
     if (e->xs) (void)hipStreamDestroy(e->xs);
+    if (e->ps) (void)hipStreamDestroy(e->ps);
     delete e;
 }
 
@@ -486,13 +605,35 @@ int d2g_allpairs_rows_computed(const d2g_allpairs *e, size_t *r0, size_t *r1) {
     return D2G_OK;
 }
 const d2g_cmp_set *d2g_allpairs_operand(const d2g_allpairs *e) { return e ? e->full[e->last] : nullptr; }
+int d2g_allpairs_chunks(const d2g_allpairs *e) { return e ? e->C : D2G_ERR_INVALID; }
+// every rank's (and chunk's) prepare reports through the gathered status words: the same answer on every rank
+int d2g_allpairs_status(d2g_allpairs *e, void *stream) {
+    if (!e) return D2G_ERR_INVALID;
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    return d2g_cmp_set_status(e->ctx, e->full[e->last], stream);
+}
 
 int d2g_allpairs_prepare_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, void *const *streams) {
     if (int rc = check_group(engs, n)) return rc;
     std::vector<int> bufs(n, 0);
     std::vector<hipStream_t> ss(n);
-    for (int i = 0; i < n; ++i) ss[i] = as_stream(streams ? streams[i] : nullptr);
-    return prepare_many(engs, n, rows_dev, bufs.data(), ss.data());
+    for (int i = 0; i < n; ++i) {
+        ss[i] = as_stream(streams ? streams[i] : nullptr);
+        // the pipelined form shares the send/receive buffers and the exporter sets: whatever it still has in flight on the
+        // engine's own stream must be done before this step's pack overwrites them
+        d2g_allpairs *e = engs[i];
+        if (e->ps) {
+            D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+            for (int b = 0; b < 2; ++b) if (e->p_valid[b]) D2G_HIP(e->ctx, hipStreamWaitEvent(ss[i], e->x_done[b], 0));
+        }
+    }
+    if (int rc = prepare_many(engs, n, rows_dev, bufs.data(), ss.data())) return rc;
+    for (int i = 0; i < n; ++i) {
+        D2G_HIP(engs[i]->ctx, hipSetDevice(engs[i]->ctx->device));
+        D2G_HIP(engs[i]->ctx, hipEventRecord(engs[i]->plain_done, ss[i]));
+        engs[i]->plain_valid = true;
+    }
+    return D2G_OK;
 }
 int d2g_allpairs_prepare_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, void *stream) {
     return d2g_allpairs_prepare_all(&e, 1, &my_rows_dev, &stream);
@@ -520,12 +661,14 @@ int d2g_allpairs_step_eqcount_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, 
     return d2g_allpairs_step_all(&e, 1, &my_rows_dev, nullptr, &o, &stream);
 }
 
-// Software-pipelined step (one rank per calling thread): the exchange + prepare of this call run on the
-// engine's own stream over the operand buffer the PREVIOUS call is not using, so they overlap the previous
+// Software-pipelined step for a STREAM of matrices (one rank per calling thread): the exchange + prepare of this call
+// run on the engine's own streams over the operand buffer the PREVIOUS call is not using, so they overlap the previous
 // call's pair kernel, which is still busy on `stream`.  Results land in out_dev in call order on `stream`.
 // input_ready: 0 = my_rows_dev may have been produced by work queued on `stream` just before this call (the
 // exchange waits for everything queued there so far -- safe, but it then also waits for the previous pair
 // kernel); 1 = the input is already complete (synchronised earlier): no dependency, full overlap.
+// Plain steps (prepare/step entry points) and pipelined ones may be mixed freely: each form waits for what the other
+// still has in flight on the buffers they share.
 int d2g_allpairs_enqueue_lut_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, const float *lut_dev, float *out_dev, void *stream,
                                  int input_ready) {
     if (!e) return D2G_ERR_INVALID;
@@ -533,8 +676,8 @@ int d2g_allpairs_enqueue_lut_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, c
     D2G_CHECK(ctx, lut_dev && out_dev, "allpairs: null lut/output");
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t main = as_stream(stream);
-    if (!e->xs) {
-        D2G_HIP(ctx, hipStreamCreateWithFlags(&e->xs, hipStreamNonBlocking));
+    if (!e->ps) {
+        D2G_HIP(ctx, hipStreamCreateWithFlags(&e->ps, hipStreamNonBlocking));
         for (int b = 0; b < 2; ++b) {
             D2G_HIP(ctx, hipEventCreateWithFlags(&e->x_done[b], hipEventDisableTiming));
             D2G_HIP(ctx, hipEventCreateWithFlags(&e->p_done[b], hipEventDisableTiming));
@@ -544,14 +687,15 @@ int d2g_allpairs_enqueue_lut_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, c
     const int b = (int)(e->nsteps & 1);
     if (!input_ready) {
         D2G_HIP(ctx, hipEventRecord(e->in_ready, main));
-        D2G_HIP(ctx, hipStreamWaitEvent(e->xs, e->in_ready, 0));
+        D2G_HIP(ctx, hipStreamWaitEvent(e->ps, e->in_ready, 0));
     }
-    if (e->p_valid[b]) D2G_HIP(ctx, hipStreamWaitEvent(e->xs, e->p_done[b], 0));      // buffer b is free once pair(step - 2) is done
-    // send/recv/local are shared by consecutive steps: the exchange stream runs them in order, and the operand
+    if (e->plain_valid) D2G_HIP(ctx, hipStreamWaitEvent(e->ps, e->plain_done, 0));    // a plain step queued earlier still owns the shared buffers
+    if (e->p_valid[b]) D2G_HIP(ctx, hipStreamWaitEvent(e->ps, e->p_done[b], 0));      // buffer b is free once pair(step - 2) is done
+    // send/recv/exporter sets are shared by consecutive steps: ps runs their users in order, and the operand
     // buffer is the only thing the pair kernel on `main` still reads
-    hipStream_t xs = e->xs;
-    if (int rc = prepare_many(&e, 1, &my_rows_dev, &b, &xs)) return rc;
-    D2G_HIP(ctx, hipEventRecord(e->x_done[b], e->xs));
+    hipStream_t ps = e->ps;
+    if (int rc = prepare_many(&e, 1, &my_rows_dev, &b, &ps)) return rc;
+    D2G_HIP(ctx, hipEventRecord(e->x_done[b], e->ps));
     D2G_HIP(ctx, hipStreamWaitEvent(main, e->x_done[b], 0));
     if (int rc = d2g_cmp_lut_ut_dev(ctx, e->full[b], e->r0, e->r1, lut_dev, out_dev, stream)) return rc;
     D2G_HIP(ctx, hipEventRecord(e->p_done[b], main));

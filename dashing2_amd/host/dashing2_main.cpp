@@ -484,7 +484,10 @@ std::vector<int> cmp_devices(const Options &o) {
 // signature matrix; one exchange (d2g_allpairs_prepare_all: all-to-all of column slices, sharded prepare, all-gather
 // of the bit planes over RCCL/xGMI) leaves the whole operand on every GPU; row batches of the condensed triangle are
 // then dealt to the GPUs round-robin, computed concurrently and emitted in row order.
-void cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs, bool have_lut, const std::vector<float> &lut,
+// Returns false (nothing emitted yet) when the sharded bit-sliced prepare overflowed its rank table on some rank -- an
+// adversarial / extremely skewed register column at N > 21 845: the caller then takes the single-GPU path, whose AUTO
+// algorithm falls back to the direct kernel.
+bool cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs, bool have_lut, const std::vector<float> &lut,
                     bool multiset) {
     const size_t ns = res.names.size(), S = o.sketchsize;
     const int W = int(devs.size());
@@ -510,9 +513,17 @@ void cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
         rows[r] = static_cast<const uint64_t *>(rowbuf[r]);
     }
     check(ctxs[0], d2g_allpairs_prepare_all(engs.data(), W, rows.data(), nullptr), "d2g_allpairs_prepare_all");
+    bool overflow = false;
     for (int r = 0; r < W; ++r) {
-        check(ctxs[r], d2g_cmp_set_status(ctxs[r], d2g_allpairs_operand(engs[r]), nullptr), "prepare");
+        const int st = d2g_allpairs_status(engs[r], nullptr);      // every rank sees every rank's status word
+        if (st == D2G_ERR_INTERNAL) overflow = true;
+        else check(ctxs[r], st, "d2g_allpairs_status");
         check(ctxs[r], d2g_free(ctxs[r], rowbuf[r]), "d2g_free");
+    }
+    if (overflow) {
+        std::fprintf(stderr, "[d2g] multi-GPU bit-sliced prepare overflowed on a skewed register column: falling back to one GPU\n");
+        for (int r = 0; r < W; ++r) { d2g_allpairs_destroy(engs[r]); d2g_comm_destroy(comms[r]); d2g_ctx_destroy(ctxs[r]); }
+        return false;
     }
     const double t_prep = now() - t0;
     Emitter em(o, res);
@@ -568,6 +579,7 @@ void cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
                                   W, d2g_comm_is_rccl(comms[0]) ? "RCCL" : "loopback", ns, S, t_prep, t_dev, t_emit);
     da.clear(); dlut.clear(); hout.clear(); hca.clear();
     for (int r = 0; r < W; ++r) { d2g_allpairs_destroy(engs[r]); d2g_comm_destroy(comms[r]); d2g_ctx_destroy(ctxs[r]); }
+    return true;
 }
 
 void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_core.cpp:615-751 (dense outputs)
@@ -587,8 +599,7 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     {
         const std::vector<int> devs = cmp_devices(o);
         if (devs.size() > 1 && (o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP) && !need_gtlt && ns >= 2) {
-            cmp_core_multi(o, res, devs, have_lut, lut, multiset);
-            return;
+            if (cmp_core_multi(o, res, devs, have_lut, lut, multiset)) return;
         }
         if (devs.size() > 1 && o.verbosity)
             std::fprintf(stderr, "[d2g] D2G_DEVICES ignored: only symmetric all-pairs with equality counts spreads over GPUs\n");

@@ -118,3 +118,18 @@ def paired_registers(N, S, seed=98):
     base = np.tile(np.arange(N, dtype=np.uint64) // np.uint64(2), (S, 1))
     v = (rng.permuted(base, axis=1).T << np.uint64(20))
     return np.ascontiguousarray(v | np.arange(S, dtype=np.uint64)[None, :]) + np.uint64(1 << 40)
+
+
+def skewed_registers(N, S, seed=97, max_shared=64, share=0.7):
+    """a collection whose register columns differ widely in how many values they share: column t has K_t shared values,
+    K_t log-uniform in [0, max_shared] (K_t + 1 = exp(U(0, ln(max_shared + 1)))); a sketch takes one of them with
+    probability `share`, else a value of its own.  The bit-sliced operand needs ceil(log2(K_t + 2)) id planes for such a
+    column; a 32-register group needs the maximum over its columns -- which column lands in which group matters."""
+    rng = np.random.default_rng(seed)
+    K = np.floor(np.exp(rng.uniform(0.0, np.log(max_shared + 1.0), size=S))).astype(np.int64) - 1
+    K = np.clip(K, 0, max_shared)
+    own = (np.arange(N, dtype=np.uint64)[:, None] + np.uint64(1 << 20)) << np.uint64(24)        # distinct per sketch
+    pick = rng.integers(0, np.maximum(K, 1)[None, :], size=(N, S)).astype(np.uint64) << np.uint64(24)
+    take = (rng.random((N, S)) < share) & (K[None, :] > 0)
+    v = np.where(take, pick, own)
+    return np.ascontiguousarray(v | np.arange(S, dtype=np.uint64)[None, :]) + np.uint64(1 << 50)

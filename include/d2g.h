@@ -374,6 +374,14 @@ int  d2g_allpairs_rows_computed(const d2g_allpairs *eng, size_t *r0, size_t *r1)
 int  d2g_allpairs_prepare_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev /* [hi-lo][S] */, void *stream);
 int  d2g_allpairs_prepare_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, void *const *streams);
 const d2g_cmp_set *d2g_allpairs_operand(const d2g_allpairs *eng);
+/* The sharded prepare can fail for the reason d2g_cmp_set_status documents (rank-table overflow on an adversarial column), on
+ * ANY rank; every rank's status word travels with its groups, so each rank learns it.  Synchronises `stream`; D2G_ERR_INTERNAL
+ * means the results of the last prepare/step are invalid on every rank (fall back to one GPU with D2G_CMP_DIRECT).
+ * d2g_cmp_set_status(d2g_allpairs_operand(eng)) returns the same. */
+int  d2g_allpairs_status(d2g_allpairs *eng, void *stream);
+/* chunks the engine cuts a rank's column slice into: the exchange of chunk c+1 overlaps the prepare of chunk c inside ONE step
+ * (a function of N, S and the world size; D2G_MGPU_CHUNKS overrides it -- identically on every rank) */
+int  d2g_allpairs_chunks(const d2g_allpairs *eng);
 /* one whole step: prepare + this rank's slab (rows_computed) of the condensed triangle; out has
  * d2g_ut_count(N, r0, r1) entries.  lut_dev == NULL (or lut_dev[i] == NULL): u32 equality counts. */
 int  d2g_allpairs_step_lut_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev, const float *lut_dev, float *out_dev, void *stream);
@@ -382,7 +390,9 @@ int  d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *ro
                            void *const *out_dev, void *const *streams);
 /* software-pipelined step for a stream of matrices: the exchange + prepare of this call overlap the pair kernel
  * of the previous call (own stream, two operand buffers); results land in out_dev in call order on `stream`.
- * input_ready != 0: my_rows_dev is already complete (no dependency on work queued on `stream`). */
+ * input_ready != 0: my_rows_dev is already complete (no dependency on work queued on `stream`).
+ * Plain (prepare/step) and pipelined calls may be mixed on one engine: each form waits, through events, for what the
+ * other still has in flight on the buffers they share. */
 int  d2g_allpairs_enqueue_lut_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev, const float *lut_dev, float *out_dev,
                                   void *stream, int input_ready);
 

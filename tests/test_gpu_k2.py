@@ -459,3 +459,51 @@ def test_timing_mask_brackets_only_what_is_asked(gpu_ctx, d2g):
         assert (n2, np_) == want, (mask, n2, np_)
         assert (avg2 > 0) == (n2 > 0) and (avgp > 0) == (np_ > 0)
         cs.close()
+
+
+def test_k2_column_sort_reduces_planes_counts_unchanged(gpu_ctx, d2g, oracle, monkeypatch):
+    """meta[tb] is a per-group MAX, so one busy column used to tax the 31 quiet ones that happened to share
+    its group.  bs_colplan_kernel sorts the columns by their live-plane class before grouping (equality counts are sums
+    over columns -- reference src/cmp_core.cpp:461,506 -- so any permutation is exact).  On a matrix whose columns share
+    between 0 and 64 values (log-uniform) the mean plane count must drop by >= 25 % and every count must stay bit-exact."""
+    N, S = 1500, 1024
+    regs = synth.skewed_registers(N, S, seed=5)
+    exp = oracle.eqcounts_ut(regs.view(np.float64))
+    res = {}
+    for sort in ("0", "1"):
+        monkeypatch.setenv("D2G_BS_SORT", sort)
+        cs = gpu_ctx.cmp_set(regs, algo=d2g.CMP_BITSLICE)
+        np.testing.assert_array_equal(cs.eqcount_ut(), exp, err_msg=f"sort={sort}")
+        res[sort] = cs.planes()
+        cs.close()
+    assert res["1"][0] == res["0"][0] and res["1"][1] == res["0"][1]         # the busiest column is the same column
+    assert res["1"][2] <= 0.75 * res["0"][2], res
+    # odd sketch sizes: the padding slots of the last group sort behind every real column
+    for S2 in (1000, 33, 31):
+        monkeypatch.setenv("D2G_BS_SORT", "1")
+        r2 = np.ascontiguousarray(regs[:300, :S2])
+        np.testing.assert_array_equal(gpu_ctx.cmp_eqcount_ut(r2, algo=d2g.CMP_BITSLICE), oracle.eqcounts_ut(r2.view(np.float64)))
+
+
+@pytest.mark.parametrize("N,S,nsplit", [(23_000, 64, "2"), (44_000, 32, "4"), (44_000, 40, "2"), (44_000, 32, "1")])
+def test_k2_split_rank_kernel(gpu_ctx, d2g, monkeypatch, N, S, nsplit):
+    """Narrow column slices of large N (one chunk of one rank of the 8-GPU exchange: 50 000 x 64) gave the multi-partition
+    rank kernel 64 workgroups of one per CU.  Several workgroups now share a column, each walking its share of the hash
+    partitions and ranking from 1; the planes kernel adds the offsets.  Checked against DIRECT and the column checksum."""
+    monkeypatch.setenv("D2G_BS_NSPLIT", nsplit)
+    regs = synth.synthetic_registers(N, S, nclusters=150, seed=int(nsplit) + S)
+    cs = gpu_ctx.cmp_set(regs, algo=d2g.CMP_BITSLICE)
+    rows = [(0, 300), (N // 2, N // 2 + 300), (N - 2000, N)]
+    got = [cs.eqcount_ut(a, b) for a, b in rows]
+    md, nb, mean = cs.planes()
+    cs.close()
+    # the largest number of shared values in any column, counted independently
+    want_md = 0
+    for t in range(S):
+        _, cnt = np.unique(regs[:, t], return_counts=True)
+        want_md = max(want_md, int((cnt >= 2).sum()))
+    assert md == want_md + 1
+    ref = gpu_ctx.cmp_set(regs, algo=d2g.CMP_DIRECT)
+    for (a, b), g in zip(rows, got):
+        np.testing.assert_array_equal(g, ref.eqcount_ut(a, b))
+    ref.close()

@@ -143,3 +143,123 @@ def test_rccl_communicator_world1_and_bcast(d2g, oracle, gpu_ctx):
     gpu_ctx.free(ptrs[0])
     eng.close()
     comm.close()
+
+
+def _one_step_counts(d2g, ctxs, comms, bits, N, S):
+    """one eqcount step of a W-rank loopback group; returns (engines, per-rank outputs as numpy)"""
+    W = len(ctxs)
+    engs = [d2g.AllPairs(ctxs[r], comms[r], N, S) for r in range(W)]
+    held = [e.rows_held for e in engs]
+    rows = [_upload(ctxs[r], bits[held[r][0]:held[r][1]]) for r in range(W)]
+    outs = [ctxs[r].malloc(max(d2g.ut_count(N, *engs[r].rows_computed), 1) * 4) for r in range(W)]
+    d2g.allpairs_step_all(engs, rows, None, outs)
+    got = []
+    for r in range(W):
+        r0, r1 = engs[r].rows_computed
+        g = np.empty(d2g.ut_count(N, r0, r1), np.uint32)
+        ctxs[r].sync()
+        if g.size:
+            ctxs[r].d2h(g, outs[r])
+        got.append(g)
+    for r in range(W):
+        ctxs[r].free(rows[r])
+        ctxs[r].free(outs[r])
+    return engs, got
+
+
+@pytest.mark.parametrize("chunks", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("W,N,S", [(2, 301, 1000), (3, 200, 512), (8, 77, 1024), (4, 64, 96)])
+def test_allpairs_chunked_exchange(d2g, oracle, monkeypatch, chunks, W, N, S):
+    """Inside one step a rank's column slice travels and is prepared in C chunks (the exchange of chunk c+1 under the
+    prepare of chunk c); the gathered operand keeps its groups in chunk-major order.  Every chunk count, including ones
+    that leave some (rank, chunk) blocks without a register group, must count exactly like the oracle."""
+    monkeypatch.setenv("D2G_MGPU_CHUNKS", chunks)
+    rng = np.random.default_rng(int(chunks) * 7 + W + N)
+    sigs = _planted(rng, N, S, nvals=int(rng.integers(2, 9)))
+    exp = oracle.eqcounts_ut(sigs)
+    off = np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
+    ctxs = [d2g.Context(0) for _ in range(W)]
+    comms = d2g.Comm.create_all(ctxs)
+    engs, got = _one_step_counts(d2g, ctxs, comms, sigs.view(np.uint64), N, S)
+    assert all(e.chunks == int(chunks) for e in engs)
+    for r in range(W):
+        r0, r1 = engs[r].rows_computed
+        np.testing.assert_array_equal(got[r], exp[off[r0]:off[r1]], err_msg=f"rank {r}")
+        engs[r].status()                                              # no overflow anywhere
+    np.testing.assert_array_equal(engs[0].operand().eqcount_ut(), exp)
+    for x in engs + comms + ctxs:
+        x.close()
+
+
+def test_allpairs_default_chunks_follow_the_shape(d2g):
+    """chunks per rank = groups per rank / 2, clamped to [1, 4]; one rank never chunks"""
+    want = {(1, 1024): 1, (2, 1024): 4, (4, 1024): 4, (8, 1024): 2, (8, 256): 1, (3, 2048): 4}
+    for (W, S), c in want.items():
+        ctxs = [d2g.Context(0) for _ in range(W)]
+        comms = d2g.Comm.create_all(ctxs)
+        engs = [d2g.AllPairs(ctxs[r], comms[r], 100, S) for r in range(W)]
+        assert [e.chunks for e in engs] == [c] * W, (W, S)
+        for x in engs + comms + ctxs:
+            x.close()
+
+
+def test_allpairs_status_reaches_every_rank(d2g, oracle, monkeypatch):
+    """the sharded prepare's overflow status used to stay private to the rank that raised it.  Every block's
+    status word now travels with its groups: a rank whose own slice is harmless still learns that the operand is invalid.
+    D2G_BS_TAGBITS=0 (test hook) makes every occupied slot a candidate, so a column with many distinct values overflows
+    the fix list of the rank kernel; constant columns never do."""
+    monkeypatch.setenv("D2G_BS_TAGBITS", "0")
+    rng = np.random.default_rng(12)
+    N, S, W = 3000, 128, 2
+    sigs = np.empty((N, S))
+    sigs[:, :64] = rng.random((N, 64))                                # rank 0's slice: all distinct -> overflow
+    sigs[:, 64:] = rng.random(64)[None, :]                            # rank 1's slice: constant columns -> clean
+    ctxs = [d2g.Context(0) for _ in range(W)]
+    comms = d2g.Comm.create_all(ctxs)
+    engs, _ = _one_step_counts(d2g, ctxs, comms, sigs.view(np.uint64), N, S)
+    for e in engs:
+        with pytest.raises(d2g.D2GError):
+            e.status()
+        with pytest.raises(d2g.D2GError):
+            e.operand().status()
+    monkeypatch.delenv("D2G_BS_TAGBITS")
+    # the same engines recover on the next (clean) step: the status words are rewritten by every prepare
+    held = [e.rows_held for e in engs]
+    rows = [_upload(ctxs[r], sigs.view(np.uint64)[held[r][0]:held[r][1]]) for r in range(W)]
+    d2g.allpairs_prepare_all(engs, rows)
+    for e in engs:
+        e.status()
+    exp = oracle.eqcounts_ut(sigs[:400])
+    np.testing.assert_array_equal(engs[1].operand().eqcount_ut(0, 1)[:399], exp[:399])
+    for r in range(W):
+        ctxs[r].free(rows[r])
+    for x in engs + comms + ctxs:
+        x.close()
+
+
+def test_allpairs_plain_and_pipelined_steps_mix(d2g, oracle, gpu_ctx):
+    """plain and pipelined steps share the send/receive buffers and the exporter sets; each form now waits
+    (events) for what the other still has in flight, so they can be interleaved without a device synchronisation."""
+    rng = np.random.default_rng(31)
+    N, S = 700, 256
+    mats = [_planted(rng, N, S, nvals=3 + i) for i in range(4)]
+    exps = [oracle.eqcounts_ut(m) for m in mats]
+    lut = np.arange(S + 1, dtype=np.float32)                          # value = neq as a float
+    comm = d2g.Comm.create(gpu_ctx, 0, 1)
+    eng = d2g.AllPairs(gpu_ctx, comm, N, S)
+    rows = [_upload(gpu_ctx, m.view(np.uint64)) for m in mats]
+    outs = [gpu_ctx.malloc(N * (N - 1) // 2 * 4) for _ in mats]
+    lut_d = _upload(gpu_ctx, lut)
+    eng.enqueue_lut_dev(rows[0], lut_d, outs[0], None, input_ready=True)
+    eng.step_lut_dev(rows[1], lut_d, outs[1], None)                   # plain right behind a pipelined one
+    eng.enqueue_lut_dev(rows[2], lut_d, outs[2], None, input_ready=True)   # pipelined right behind a plain one
+    eng.enqueue_lut_dev(rows[3], lut_d, outs[3], None, input_ready=True)
+    gpu_ctx.sync()
+    for i in range(4):
+        got = np.empty(N * (N - 1) // 2, np.float32)
+        gpu_ctx.d2h(got, outs[i])
+        np.testing.assert_array_equal(got.astype(np.uint32), exps[i], err_msg=f"step {i}")
+    for p in rows + outs + [lut_d]:
+        gpu_ctx.free(p)
+    eng.close()
+    comm.close()

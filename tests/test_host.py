@@ -404,3 +404,19 @@ def test_public_header_is_plain_c_and_links(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
     assert r.stdout.split()[2:] == ["internal", "invariant", "failed"]
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """with no loadable RCCL the communicator entry points must return D2G_ERR_UNSUPPORTED (the loader
+    once read dlerror() twice and dereferenced the NULL of the second call).  Fresh process: the lookup is cached."""
+    code = ("import os, sys, ctypes as C\n"
+            "os.environ['D2G_NO_TORCH_PRELOAD'] = '1'\n"
+            "sys.path.insert(0, %r)\n"
+            "import dashing2_amd as D\n"
+            "buf = C.create_string_buffer(128)\n"
+            "rc = D.lib().d2g_comm_unique_id(buf)\n"
+            "print('rc', rc)\n" % ROOT)
+    env = dict(os.environ, D2G_RCCL_LIB="/nonexistent/librccl-missing.so")
+    r = subprocess.run([os.environ.get("PYTHON", "python3"), "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert "rc -5" in r.stdout, r.stdout
