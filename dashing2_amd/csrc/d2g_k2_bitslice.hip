@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
     for (int x = 0; x < 32; ++x) {
         const uint32_t t = perm[tb * 32 + x];                 // uniform: scalar loads
         uint32_t w = (t != BS_NOCOL && j < N) ? ids[(size_t)t * Npad + j] : 0u;     // padded registers/sketches: id 0 in both codings
-        if (nsplit > 1 && !(w >> 31)) w = (w & BS_RANK_MASK) + colcnt[(size_t)t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)];
+        if (nsplit > 1 && t != BS_NOCOL && !(w >> 31)) w = (w & BS_RANK_MASK) + colcnt[(size_t)t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)];
         id[x] = w;
     }
     uint32_t u = 0;                                    // the "unique" plane

@@ -33,7 +33,7 @@ static const char *const VALID_LONG[] = {
 
 enum {
     OPT_CMPOUT = 1000, OPT_OUTPREF, OPT_BINARY, OPT_PHYLIP, OPT_ASYM, OPT_ISZ, OPT_USZ, OPT_MASH, OPT_SYMCONTAIN,
-    OPT_CONTAIN, OPT_SEED, OPT_HELP, OPT_BATCH, OPT_PRESKETCHED, OPT_MULTISET, OPT_PARSEBYSEQ, OPT_UNSUPPORTED
+    OPT_CONTAIN, OPT_SEED, OPT_HELP, OPT_BATCH, OPT_PRESKETCHED, OPT_MULTISET, OPT_PARSEBYSEQ, OPT_FMTCOMPAT, OPT_UNSUPPORTED
 };
 
 void sketch_usage() {
@@ -46,7 +46,9 @@ void sketch_usage() {
                          "  --no-canon/-C  --seed s  --cache/-W  --outprefix dir  --oph/-Z\n"
                          "  --multiset/--bagminhash/-B [-m/--count-threshold c]   --parse-by-seq (one sketch per record of ONE file)\n"
                          "  --distance/--mash-distance --containment --symmetric-containment --intersection --union-size\n"
-                         "  --batch-size n  -v\n");
+                         "  --batch-size n  -v\n"
+                         "  --fmt-compat {10,11}   float text of PHYLIP/TSV output as fmt < 11 (default: fixed notation below 1e16) or\n"
+                         "                         fmt >= 11 (exponent form from 1e7) prints it -- the reference's fmt is an unpinned submodule\n");
 }
 void cmp_usage() {
     std::fprintf(stderr, "dashing2 cmp <opts> [fastas... (optional)]\n"
@@ -61,6 +63,7 @@ static bool validate_long_flags(char **argv, bool is_cmp) {
         if (len > 2 && std::memcmp(*p, "--", 2) == 0) {
             const std::string flag(*p + 2);
             if (is_cmp && flag == "presketched") continue;
+            if (flag == "fmt-compat") continue;              // this build's own flag (float text generation of the fmt library)
             bool ok = false;
             for (const char *v : VALID_LONG) if (flag == v) { ok = true; break; }
             if (!ok) {   // src/options.h:298-301
@@ -116,6 +119,7 @@ int parse_options(int argc, char **argv, Options &o) {
         {"BMH", no_argument, 0, OPT_MULTISET},
         {"count-threshold", required_argument, 0, 'm'}, {"threshold", required_argument, 0, 'm'},
         {"parse-by-seq", no_argument, 0, OPT_PARSEBYSEQ},
+        {"fmt-compat", required_argument, 0, OPT_FMTCOMPAT},
         {0, 0, 0, 0}};
     // every other valid reference flag is recognised but outside the hot-path scope
     std::vector<struct option> all(longopts, longopts + sizeof(longopts) / sizeof(longopts[0]) - 1);
@@ -164,6 +168,13 @@ int parse_options(int argc, char **argv, Options &o) {
             case OPT_MULTISET: case 'B': o.sspace = SPACE_MULTISET; break;         // options.h:111
             case 'm': o.count_threshold = unsigned(std::atoi(optarg)); break;      // options.h:352
             case OPT_PARSEBYSEQ: o.parse_by_seq = true; break;                     // options.h:378
+            case OPT_FMTCOMPAT:
+                o.fmt_compat = std::atoi(optarg);
+                if (o.fmt_compat != 10 && o.fmt_compat != 11) {
+                    std::fprintf(stderr, "dashing2 (MI355X): --fmt-compat takes 10 (float text of fmt < 11, default) or 11 (fmt >= 11)\n");
+                    return 1 + 1;
+                }
+                break;
             case OPT_HELP: case 'h': case '?': o.is_cmp ? cmp_usage() : sketch_usage(); return 1 + 1;
             case OPT_UNSUPPORTED:
                 std::fprintf(stderr, "dashing2 (MI355X): option --%s is outside the hot-path scope of this build "

@@ -73,7 +73,12 @@ std::string makedest(const Options &o, const std::string &path) {
     if (o.canon) ret += ".rc_canon";
     ret += ".sketchsize" + std::to_string(o.sketchsize);
     ret += ".k" + std::to_string(o.k);
-    if (o.count_threshold > 0) ret += ".ct_threshold" + std::to_string(int(o.count_threshold));   // fastxmerge.cpp:91-95
+    if (o.count_threshold > 0) {
+        // fastxmerge.cpp:91-95 prints std::to_string(double) when fmod(threshold, 1) != 0 -- but Dashing2Options::count_threshold_ is a
+        // uint32_t (d2.h:103) filled by std::atoi (options.h:352), so that branch cannot be reached from the reference's CLI
+        // either: `-m 2.7` is 2 there and here.  The integer branch: std::to_string(int(count_threshold_)).
+        ret += ".ct_threshold" + std::to_string(int(o.count_threshold));
+    }
     if (o.sspace != SPACE_SET) ret += ".ExactCounting";   // to_string(ct()), src/enums.cpp:47; fastxmerge.cpp:96-100
     ret += o.sspace == SPACE_SET ? ".SetSpace" : ".MultisetSpace";   // to_string(sspace), src/enums.cpp:40-46
     ret += ".DNA";                                        // bns::to_string(rht_) (absent bonsai; expected "DNA")
@@ -413,6 +418,9 @@ struct Emitter {
         const char *label = o.ok == ASYMMETRIC_ALL_PAIRS ? "Asymmetric pairwise" : o.ok == PANEL ? "Panel (Query/Refernce)" : "Symmetric pairwise";
         std::fprintf(fp, "#Dashing2 %s Output\n", label);
         std::fprintf(fp, "#Dashing2Options: %s\n", o.to_string().c_str());
+        // not a reference line: written only when --fmt-compat was given, so that the default output stays byte-identical to
+        // emitrect.cpp:138-147 while a deliberate choice of float layout is on record in the file it shaped
+        if (o.fmt_compat) std::fprintf(fp, "#Dashing2FloatText: fmt-compat=%d\n", o.fmt_compat);
         std::fputs("#Sources", fp);
         for (size_t i = 0; i < ns; ++i) { std::fputc('\t', fp); std::fwrite(res.names[i].data(), 1, res.names[i].size(), fp); }
         std::fputc('\n', fp);
@@ -699,6 +707,7 @@ int sketch_main(int argc, char **argv) {                          // src/sketch_
     const double t_start = now();
     Options o;
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
+    if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
     if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); sketch_usage(); return 1; }
     d2g_ctx *ctx = make_ctx(o);
     if (o.verbosity) std::fprintf(stderr, "[d2g] options + GPU context: %.3fs\n", now() - t_start);
@@ -714,6 +723,7 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
     Options o;
     o.is_cmp = true;
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
+    if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
     d2g_ctx *ctx = make_ctx(o);
     Result res;
     if (o.presketched) {

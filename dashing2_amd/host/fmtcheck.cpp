@@ -1,9 +1,11 @@
-// fmtcheck: reads "<hexbits>\t<expected>" lines, checks d2h::format_float; used by tests/test_host.py
+// fmtcheck <table> [fmt-compat]: reads "<hexbits>\t<expected>" lines, checks d2h::format_float; used by tests/test_host.py
 #include "fmtfloat.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 int main(int argc, char **argv) {
     if (argc < 2) return 2;
+    if (argc > 2 && !d2h::set_fmt_compat(std::atoi(argv[2]))) return 2;
     std::FILE *f = std::fopen(argv[1], "r");
     if (!f) return 2;
     char line[256]; int bad = 0, n = 0;

@@ -6,11 +6,16 @@
 
 namespace d2h {
 
-static int g_exp_upper = [] {
-    const char *e = std::getenv("D2_FMT_EXP_UPPER");
-    return e ? std::atoi(e) : 7;
-}();
-void set_exp_upper(int e) { g_exp_upper = e; }
+// fmt < 11 prints every floating type in fixed notation up to 1e16 (exp_upper = 16); fmt >= 11 made the bound
+// digits10 + 1 of the type, 7 for float.  dashing2 v2.1.x (2021-23) vendored fmt as an unpinned submodule
+// (.gitmodules:7-9): releases 8-10 of that period => 16 is the default here; `--fmt-compat 11` selects 7.
+static int g_exp_upper = 16;
+bool set_fmt_compat(int fmt_major) {
+    if (fmt_major == 10) { g_exp_upper = 16; return true; }
+    if (fmt_major == 11) { g_exp_upper = 7; return true; }
+    return false;
+}
+int fmt_compat() { return g_exp_upper == 16 ? 10 : 11; }
 
 size_t format_float(float v, char *out) {
     char *p = out;

@@ -1,13 +1,16 @@
 """Oracle-side text rendering (TEST INFRASTRUCTURE ONLY): what the reference's emit_rectangular
 prints (src/emitrect.cpp:136-151,172-187) given the float matrix, with fmt's "{}" float layout
-(shortest round-trip digits; fixed notation for decimal exponents in [-4, 7), else d.ddde±XX).
-Pinned against fmt 12.1.0 by tests/golden/fmt_float.tsv."""
+(shortest round-trip digits; fixed notation for decimal exponents in [-4, exp_upper), else d.ddde±XX).
+exp_upper = 16 in fmt < 11 (the default here: a 2.1.x-era dashing2 predates fmt 11), 7 for float in
+fmt >= 11.  Pinned against fmt 12.1.0 itself by tests/golden/fmt_float.tsv (EXP_UPPER = 7) and against
+the fmt < 11 table derived from it by rule, tests/golden/fmt10_float.tsv."""
 import numpy as np
 
-EXP_UPPER = 7      # fmt >= 11: numeric_limits<float>::digits10 + 1
+EXP_UPPER = 16     # module default: fmt < 11.  fmt >= 11: numeric_limits<float>::digits10 + 1 = 7
 
 
-def fmt_float(x):
+def fmt_float(x, exp_upper=None):
+    exp_upper = EXP_UPPER if exp_upper is None else exp_upper
     x = np.float32(x)
     if np.isnan(x):
         return "nan"
@@ -22,7 +25,7 @@ def fmt_float(x):
     e = int(exp)
     digits = mant.replace(".", "")
     nd = len(digits)
-    if -4 <= e < EXP_UPPER:
+    if -4 <= e < exp_upper:
         if e >= nd - 1:
             return s + digits + "0" * (e - (nd - 1))
         if e >= 0:

@@ -485,3 +485,91 @@ def test_cli_cmp_multi_gpu_loopback(oracle, genomes, tmp_path):
     r = subprocess.run([EXE, "cmp", "--presketched", "--multiset", "-k", "21", "--intersection", str(ms)], capture_output=True,
                        env=dict(os.environ, D2G_DEVICES="0,0"))
     assert r.returncode == 0 and r.stdout == ref
+
+
+def _write_stacked(path, sigs, cards):
+    """format F-b (src/fastxsketch.cpp:236-240, src/sketch_core.cpp:130-140): [u64 N][u64 S][f64 card x N][f64 x N*S]"""
+    N, S = sigs.shape
+    with open(path, "wb") as f:
+        np.array([N, S], np.uint64).tofile(f)
+        np.ascontiguousarray(cards, np.float64).tofile(f)
+        np.ascontiguousarray(sigs, np.float64).tofile(f)
+
+
+def test_cli_float_text_of_large_values_both_fmt_generations(oracle, tmp_path):
+    """--union-size / --intersection on real genomes exceed 1e7 routinely, where fmt < 11 (fixed
+    notation below 1e16 -- what a 2.1.x-era dashing2 linked, and this CLI's default) and fmt >= 11 (exponent form from 1e7
+    for float) print different text.  Both layouts are checked value for value against the oracle's renderer, the default
+    carries no extra header line, and an explicit --fmt-compat is recorded in the TSV header."""
+    from oracle import textfmt
+    rng = np.random.default_rng(4)
+    N, S, k = 9, 256, 31
+    regs = synth.synthetic_registers(N, S, nclusters=2, seed=9, share_lo=0.3, share_hi=0.9)
+    import dashing2_amd as D
+    sigs, _ = D.oph_finalize(regs, S)
+    cards = rng.uniform(2.0e6, 9.0e7, N)                       # genome-sized cardinalities: unions well above 1e7
+    st = tmp_path / "big.bin"
+    _write_stacked(st, sigs, cards)
+    names = [str(i) for i in range(N)]
+    for measure_flag, meas in (("--union-size", oracle.UNION_SIZE), ("--intersection", oracle.INTERSECTION)):
+        exp = oracle.allpairs_ut(sigs, cards, measure=meas, k=k, nthreads=2)
+        assert meas != oracle.UNION_SIZE or (exp >= 1e7).sum() > 10
+        for compat, eu in ((None, 16), ("10", 16), ("11", 7)):
+            flags = [measure_flag] + (["--fmt-compat", compat] if compat else [])
+            got = _run(["cmp", "--presketched", "-k", str(k), "--phylip"] + flags + [str(st)]).stdout.decode()
+            old = textfmt.EXP_UPPER
+            textfmt.EXP_UPPER = eu
+            try:
+                want = textfmt.render_symmetric(names, exp, phylip=True)
+                opt = "Dashing2Options;k:%d;parsebyfile;trimchr;sketchsize:%d;sketchtype:onepermsetsketch;Fastx;canon" % (k, S)
+                want_tsv = textfmt.render_symmetric(names, exp, phylip=False, options_string=opt)
+            finally:
+                textfmt.EXP_UPPER = old
+            assert got == want, (measure_flag, compat)
+            tsv = _run(["cmp", "--presketched", "-k", str(k)] + flags + [str(st)]).stdout.decode()
+            if compat:
+                lines = tsv.split("\n")
+                assert lines[2] == "#Dashing2FloatText: fmt-compat=" + compat
+                tsv = "\n".join(lines[:2] + lines[3:])
+            assert tsv == want_tsv, (measure_flag, compat)
+    a = _run(["cmp", "--presketched", "-k", str(k), "--phylip", "--union-size", str(st)]).stdout
+    b = _run(["cmp", "--presketched", "-k", str(k), "--phylip", "--union-size", "--fmt-compat", "11", str(st)]).stdout
+    assert a != b and b"e+07" in b and b"e+07" not in a
+    r = subprocess.run([EXE, "cmp", "--presketched", "--fmt-compat", "9", str(st)], capture_output=True)
+    assert r.returncode == 1 and b"--fmt-compat takes 10" in r.stderr
+
+
+def test_cli_cmp_multi_gpu_overflow_falls_back_to_one_gpu(tmp_path):
+    """with D2G_DEVICES the bit-sliced prepare's overflow status was never seen and the distances came out wrong
+    silently.  Every rank's status word now travels with its groups; `cmp` checks it and takes the single-GPU path (whose AUTO
+    algorithm falls back to the direct kernel).  D2G_BS_TAGBITS=0 (test hook) forces the overflow."""
+    rng = np.random.default_rng(3)
+    N, S = 2500, 128
+    sigs = rng.random((N, S))
+    sigs[:, ::2] = rng.random((40, S // 2))[rng.integers(0, 40, N)]      # some equalities, many distinct values per column
+    st = tmp_path / "adv.bin"
+    _write_stacked(st, sigs, np.ones(N))
+    ref = tmp_path / "ref.bin"
+    _run(["cmp", "--presketched", "-k", "31", "--binary-output", "--cmpout", str(ref), str(st)])
+    got = tmp_path / "got.bin"
+    r = subprocess.run([EXE, "cmp", "--presketched", "-k", "31", "--binary-output", "--cmpout", str(got), str(st)],
+                       capture_output=True, env=dict(os.environ, D2G_DEVICES="0,0,0", D2G_BS_TAGBITS="0"))
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    assert b"falling back to one GPU" in r.stderr
+    assert got.read_bytes() == ref.read_bytes()
+
+
+def test_cli_cache_names_with_count_threshold(genomes, tmp_path):
+    """cache file names follow src/fastxmerge.cpp:70-120; `-m c` adds `.ct_threshold<int>` -- the reference parses -m with atoi
+    into a uint32_t (options.h:352, d2.h:103), so `-m 2.7` is 2 there and here and the fractional branch at fastxmerge.cpp:93
+    is unreachable from its CLI"""
+    import shutil
+    d = tmp_path / "fa"
+    d.mkdir()
+    g = d / "a.fa"
+    shutil.copy(genomes[0], g)
+    for m, tag in (("3", ".ct_threshold3"), ("2.7", ".ct_threshold2")):
+        _run(["sketch", "--multiset", "-k", "21", "-S", "64", "-m", m, "--cache", str(g)])
+        want = str(g) + ".rc_canon.sketchsize64.k21" + tag + ".ExactCounting.MultisetSpace.DNA.d2gbmh"
+        assert os.path.exists(want), sorted(os.listdir(d))
+        os.remove(want)

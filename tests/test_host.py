@@ -294,13 +294,18 @@ def test_format_fixture_roundtrip():
 
 
 def test_cli_float_formatter_vs_fmt_golden():
-    """the CLI's text path (dashing2_amd/host/fmtfloat.cpp) against fmt 12.1.0 goldens"""
+    """the CLI's text path (dashing2_amd/host/fmtfloat.cpp) in both float layouts: `--fmt-compat 11` against the table fmt 12.1.0
+    itself produced, the default (fmt < 11: fixed notation below 1e16) against the table derived from it by rule
+    (tests/golden/make_fmt10_golden.py).  The two tables differ exactly in the values >= 1e7."""
     exe = os.path.join(ROOT, "dashing2_amd", "bin", "fmtcheck")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "dashing2_amd", "host")])
-    out = subprocess.run([exe, os.path.join(GOLDEN, "fmt_float.tsv")], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout
-    assert "0 bad" in out.stdout
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "dashing2_amd", "host")])
+    for table, compat in (("fmt_float.tsv", ["11"]), ("fmt10_float.tsv", ["10"]), ("fmt10_float.tsv", [])):
+        out = subprocess.run([exe, os.path.join(GOLDEN, table)] + compat, capture_output=True, text=True)
+        assert out.returncode == 0, (table, compat, out.stdout)
+        assert "0 bad" in out.stdout
+    out = subprocess.run([exe, os.path.join(GOLDEN, "fmt_float.tsv"), "10"], capture_output=True, text=True)
+    assert out.returncode != 0 and "1.2345678e+07" in out.stdout            # the layouts really differ there
+    assert subprocess.run([exe, os.path.join(GOLDEN, "fmt_float.tsv"), "12"]).returncode == 2   # only 10 and 11 exist
 
 
 def test_host_code_under_sanitizers():

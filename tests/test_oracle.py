@@ -171,13 +171,15 @@ def test_allpairs_matches_pairwise(oracle):
 
 
 def test_text_formatter_vs_fmt_golden():
-    """tests/golden/fmt_float.tsv was produced by fmt 12.1.0 `fmt::format("{}", float)`."""
+    """tests/golden/fmt_float.tsv was produced by fmt 12.1.0 `fmt::format("{}", float)` (exp_upper = 7);
+    fmt10_float.tsv is the fmt < 11 layout (exp_upper = 16, the oracle's and the CLI's default)."""
     from oracle import textfmt
     import struct
-    n = 0
-    for line in open(os.path.join(GOLDEN, "fmt_float.tsv")):
-        bits, exp = line.rstrip("\n").split("\t")
-        v = struct.unpack("<f", struct.pack("<I", int(bits, 16)))[0]
-        assert textfmt.fmt_float(v) == exp, (bits, exp)
-        n += 1
-    assert n > 12000
+    for table, eu in (("fmt_float.tsv", 7), ("fmt10_float.tsv", None)):
+        n = 0
+        for line in open(os.path.join(GOLDEN, table)):
+            bits, exp = line.rstrip("\n").split("\t")
+            v = struct.unpack("<f", struct.pack("<I", int(bits, 16)))[0]
+            assert textfmt.fmt_float(v, eu) == exp, (table, bits, exp)
+            n += 1
+        assert n > 12000
