@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X dashing2 hot paths.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one process per GPU: either launched by the caller (`python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N`: RANK / WORLD_SIZE in the environment) or -- when WORLD_SIZE is not set -- by bench.py itself, which
+re-executes under torch.distributed.run with N ranks after checking that N devices are visible (fewer: a JSON line with
+"error" and exit code 2, never a silent 1-GPU measurement).
 
 Primary metric (BASELINE.json): all-pairs sketch comparison throughput, **pairs/s**.
 N = 1: BASELINE config 3 -- 10 000 pre-built OPH sketches, S = 1024 (49 995 000 pairs), float32
@@ -11,7 +16,11 @@ prepare (transpose, per-column dense ids, bit planes) + the pair kernel with its
 N > 1 (default --scaling strong): BASELINE config 4 -- 50 000 sketches, S = 1024 (1 249 975 000 pairs),
 the SAME total work at every N > 1; rank r holds rows [r N/W, (r+1) N/W) (what sharded sketching leaves
 in HBM), one all-to-all + one all-gather of the compact bit-plane operand per step, every rank computes
-its pair-balanced row range of the upper triangle.  `--scaling weak` keeps pairs per GPU constant
+its pair-balanced row range of the upper triangle.  `value` / `ms_per_step` are ONE JOB's step, the same
+definition as at N = 1: exchange + prepare + pair kernel of one matrix, nothing carried over between steps
+(inside the step the exchange of chunk c+1 overlaps the prepare of chunk c).  The software-pipelined rate
+for a STREAM of matrices (exchange + prepare of step i+1 under the pair kernel of step i) is reported
+beside it as `stream_of_matrices`, never as `value`.  `--scaling weak` keeps pairs per GPU constant
 instead (N_sketches = 10000 * sqrt(N)).  The N = 1 line also carries `config4_1gpu`: config 4 on one GPU,
 the base a strong-scaling curve should be read against.
 
@@ -40,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py
 
 
 def parse_args():
@@ -66,8 +75,8 @@ def parse_args():
                     help="N>1: row-sharded sketches + all-to-all/all-gather of the compact operand (default), "
                          "or rank-0 sketches broadcast whole")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="sharded path: run exchange+prepare and the pair kernel of a step back to back instead of "
-                         "overlapping step i+1's exchange with step i's pair kernel")
+                    help="sharded path: skip the secondary stream-of-matrices measurement (exchange + prepare of step i+1 "
+                         "under the pair kernel of step i); the headline is always the one-job step")
     ap.add_argument("--force-sharded", action="store_true", help="debug: run the N>1 code path at N=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -87,14 +96,16 @@ def pmc_entry(kernel_substr):
 
 
 def pmc_traffic(kernel_substr, wide_loads):
-    """HBM bytes per launch.  MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE
-    tallies wide (16 B/lane) coalesced reads at half their bytes -> doubled for such kernels; narrow-load
-    kernels are reported raw (uncalibrated per the guide)."""
+    """HBM bytes of the LARGEST dispatch of the kernel in the PMC run of this command -- the launch of the headline
+    workload: the same run also launches the kernel on small inputs (the compare half of configs[1], the config-1 CLI),
+    and a mean over dispatches mixes those in (345 MB was (7 x 394 + 3) / 8).
+    MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies wide (16 B/lane) coalesced
+    reads at half their bytes -> doubled for such kernels; narrow-load kernels are reported raw (uncalibrated per the guide)."""
     e = pmc_entry(kernel_substr)
-    if e is None:
+    if e is None or "largest_dispatch_hbm_write_bytes" not in e:
         return None
-    rd = e["hbm_read_bytes_x2_wide_load_correction"] if wide_loads else e["hbm_read_bytes_raw"]
-    return rd + e["hbm_write_bytes"]
+    rd = e["largest_dispatch_hbm_read_bytes_raw"] * (2 if wide_loads else 1)
+    return rd + e["largest_dispatch_hbm_write_bytes"]
 
 
 def host_cores():
@@ -320,8 +331,33 @@ def pack_genomes(D, synth, first, count, L, k, keep=0, nthreads=None):
     return np.concatenate(packed), np.concatenate(rs), np.concatenate(rl), np.concatenate(go), kept
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE: run N ranks under torch.distributed.run ourselves (one process per
+    GPU, 127.0.0.1 rendezvous) -- after checking that N devices are there.  Returns the exit code."""
+    import socket
+    import subprocess
+    import dashing2_amd as D
+    have = int(D.lib().d2g_device_count())
+    if have < args.gpus:
+        print(json.dumps({"metric": "all-pairs sketch comparison throughput (pairs/s)", "value": None, "unit": "pairs/s",
+                          "n_gpus": args.gpus, "error": f"--gpus {args.gpus} requested but {have} HIP device(s) visible: refusing to "
+                                                         "measure a smaller job under that label"}), flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_sharded:
+        raise SystemExit(self_launch(args))
     import torch
     import torch.distributed as dist
     import dashing2_amd as D
@@ -379,7 +415,7 @@ def main():
     if world > 1:
         dist.broadcast(sig_dev, 0)                           # untimed distribution of the synthetic input
     eng = cs = comm = None
-    pipelined = not args.no_pipeline
+    pipelined = False                 # the headline step is always ONE job's step; the stream form is measured afterwards
     exchange_fallback = None
     engine_kind = None
     if sharded:
@@ -432,16 +468,14 @@ def main():
             engine_kind = "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv groups)"
 
             def step():
-                # all-to-all (rows -> column slices), prepare S/W columns, all-gather planes, pair kernel; pipelined: the
-                # exchange + prepare of the next step overlap this step's pair kernel (two operand buffers, own stream)
-                # -- every step still does all of its work inside the timed region
-                if pipelined:
-                    eng.enqueue_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream, input_ready=True)
-                else:
-                    eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
-
-            def plain_step():
+                # ONE job: all-to-all (rows -> column slices), prepare of S/W columns, all-gather of the planes, pair kernel --
+                # chunk by chunk inside the step (the exchange of chunk c+1 under the prepare of chunk c), nothing carried over
                 eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
+
+            def stream_step():
+                # a STREAM of matrices: exchange + prepare of the next step under this step's pair kernel (two operand buffers)
+                eng.enqueue_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream, input_ready=True)
+            plain_step = step
             cs = eng.operand()
         else:
             exchange_fallback = err
@@ -463,32 +497,15 @@ def main():
                 eng = teng
 
                 def step():
-                    if pipelined:
-                        teng.enqueue_lut(my_rows, lut, out, ready=False)    # my_rows was complete before the timed region
-                    else:
-                        teng.step_lut(my_rows, lut, out, stream)
-
-                def plain_step():
                     teng.step_lut(my_rows, lut, out, stream)
+
+                def stream_step():
+                    teng.enqueue_lut(my_rows, lut, out, ready=False)    # my_rows was complete before the timed region
+                plain_step = step
                 cs = teng.full
             else:
                 exchange_fallback += " | " + err2
                 sharded = False
-    pipeline_probe = None
-    if sharded and pipelined:
-        # the overlapped form is probed (two steps + a sync) on every rank before anything is timed: if it fails anywhere, every
-        # rank drops to the plain step together instead of dying inside the timed loop
-        perr = None
-        try:
-            step(); step()
-            torch.cuda.synchronize()
-        except Exception as e:                                   # noqa: BLE001
-            perr = f"{type(e).__name__}: {e}"
-        perr = all_failed(perr)
-        if perr is not None:
-            pipeline_probe = "pipelined step failed (" + perr + "): measured with the plain step"
-            pipelined = False
-            step = plain_step
     if sharded:
         del sig_dev
     else:
@@ -506,7 +523,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run():
+    def timed_run(step):
         # An event pair in the stream costs a few microseconds of device time per launch (measured: 0.530 ms per step with no
         # events, 0.549 with the pair kernel AND the prepare chain bracketed): the timed region brackets only the kernel the
         # roofline reports -- every launch of it --, the prepare chain is timed during the (untimed) warmup steps.
@@ -525,25 +542,41 @@ def main():
         ctx.set_timing(False)
         return dt
 
-    dt = timed_run()
-    pipeline_check = None
-    if sharded and pipelined:
-        # the pipelined steps must have produced exactly what one plain step produces; if they did not,
-        # the measurement is repeated unpipelined so that the reported number is never from a wrong run
-        got = out.clone()
-        plain_step()
-        torch.cuda.synchronize()
-        same = torch.tensor([1.0 if torch.equal(got, out) else 0.0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
-        pipeline_check = "ok"
-        if same.item() != 1.0:
-            pipeline_check = "MISMATCH: re-measured without the overlap"
-            pipelined = False
-            dt = timed_run()
-        del got
+    dt = timed_run(step)
     nk2, k2_ms, _ = ctx.kernel_ms("k2")
     _, prep_ms, _ = ctx.kernel_ms("k2prep")
+    # the gathered prepare status: a rank-table overflow on ANY rank invalidates the step everywhere (never silent)
+    if sharded and engine_kind and engine_kind.startswith("libd2g"):
+        eng.status(stream)
+    stream_of_matrices = None
+    if sharded and not args.no_pipeline:
+        # secondary: the software-pipelined rate for a stream of matrices.  Probed on every rank first (a failure anywhere
+        # skips it everywhere), timed like the headline, and its output checked against the plain step's.
+        want = out.clone()
+        perr = None
+        try:
+            stream_step(); stream_step()
+            torch.cuda.synchronize()
+        except Exception as e:                                   # noqa: BLE001
+            perr = f"{type(e).__name__}: {e}"
+        perr = all_failed(perr)
+        if perr is None:
+            sdt = timed_run(stream_step)
+            ctx.kernel_ms("k2")
+            if world > 1:
+                t = torch.tensor([sdt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sdt = float(t.item())
+            same = torch.tensor([1.0 if torch.equal(want, out) else 0.0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            stream_of_matrices = {"value": pairs_total / (sdt / args.steps), "unit": "pairs/s", "ms_per_step": sdt / args.steps * 1e3,
+                                  "outputs_identical_to_the_one_job_step": bool(same.item() == 1.0),
+                                  "note": "NOT the headline: throughput over repeated matrices with the exchange + prepare of step i+1 hidden "
+                                          "under the pair kernel of step i (d2g_allpairs_enqueue_lut_dev); BASELINE config 4 is one job"}
+        else:
+            stream_of_matrices = {"error": perr}
+        del want
     max_distinct, nbits, mean_nbits = cs.planes(stream)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -559,11 +592,15 @@ def main():
     achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
     kname = "k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2_direct_kernel"
     pmc_ok = (algo_used == D.CMP_BITSLICE and world == 1 and N == 10000 and S == 1024)
+    with_prep = alg_bytes / ((k2_ms + prep_ms) * 1e-3) / 1e9 if (k2_ms + prep_ms) > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                # the 8 S N bytes of the sketches are read by the PREPARE chain, not by the pair kernel: the same algorithmic
+                # bytes over pair kernel + prepare
+                "frac_with_prepare": with_prep / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(kname, False) if pmc_ok else None,
-                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of this command, profiles/r02_pmc.json "
-                                "(round 2 kernels); dword loads: read side raw/uncalibrated",
+                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of this command, the config-3-sized (largest) "
+                                "dispatch, profiles/" + os.path.basename(PMC_FILE) + "; dword loads: read side raw/uncalibrated",
                 "kernel": kname, "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
                 "prep_ms": prep_ms,
                 "note": "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute"}
@@ -626,6 +663,17 @@ def main():
                     "hbm_frac": achieved / HBM_PEAK_GBS, "valu_frac": vf}
                 mats["unrelated (no value shared by two sketches)"] = measure_matrix(synth.unrelated_registers(N, S), N)
                 mats["adversarial (every value occurs exactly twice in its column)"] = measure_matrix(synth.paired_registers(N, S), N)
+                # columns that share between 0 and 64 values (log-uniform): which column lands in which 32-register group matters,
+                # since a group walks the MAXIMUM plane count of its columns.  Measured with the column plan (columns sorted by
+                # plane class before grouping, the default) and with the caller's column order (D2G_BS_SORT=0).
+                sk = synth.skewed_registers(N, S)
+                mats["skewed (columns share 0..64 values, log-uniform)"] = measure_matrix(sk, N)
+                os.environ["D2G_BS_SORT"] = "0"
+                try:
+                    mats["skewed, columns left in the caller's order (D2G_BS_SORT=0)"] = measure_matrix(sk, N)
+                finally:
+                    os.environ.pop("D2G_BS_SORT", None)
+                del sk
             except Exception as e:                               # noqa: BLE001 - reported in the line
                 mats["error"] = f"{type(e).__name__}: {e}"
             compute["matrices"] = mats
@@ -754,7 +802,7 @@ def main():
                               "frac": ach / HBM_PEAK_GBS,
                               "traffic": (2 * pe["largest_dispatch_hbm_read_bytes_raw"] + pe["largest_dispatch_hbm_write_bytes"]) if pe and "largest_dispatch_hbm_write_bytes" in pe else None,
                               "traffic_note": "rocprofv3 --pmc FETCH_SIZE (x2: 16-byte coalesced loads are tallied at half their bytes on gfx950) + WRITE_SIZE of the "
-                                              "1000-genome launch, profiles/r02_pmc.json",
+                                              "1000-genome launch, profiles/" + os.path.basename(PMC_FILE),
                               "kernel": "k1_oph_kernel",
                               "kernel_ms": k1_ms, "algorithmic_bytes": k1_bytes,
                               "note": "VALU-bound by the two mandated 64-bit Wang mixes per k-mer (~125 issue slots per base), not by HBM"}}
@@ -858,7 +906,7 @@ def main():
                                           f"--multiset (BagMinHash), canonical, {nb} genomes per call"},
                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                 "traffic": traffic,
-                                "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE per call, same shape, profiles/r02_pmc.json",
+                                "traffic_note": "sum over the chain's kernels of rocprofv3 --pmc FETCH_SIZE (raw) + WRITE_SIZE per call, same shape, profiles/" + os.path.basename(PMC_FILE),
                                 "kernel": "k3 chain (hist, scan, scatter, refine, bmh_main, survivors, verify)",
                                 "kernel_ms": k3_ms, "launches": ncalls, "algorithmic_bytes": k3_bytes,
                                 "note": "per call of %d genomes; the chain also writes and re-reads the bucketed k-mer keys, "
@@ -890,11 +938,29 @@ def main():
                        "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count",
                        **({"exchange_engine": engine_kind} if engine_kind else {}),
                        **({"exchange_fallback": exchange_fallback} if exchange_fallback else {}),
-                       **({"pipelined_exchange": pipeline_check} if pipeline_check else {}),
-                       **({"pipelined_probe": pipeline_probe} if pipeline_probe else {})},
+                       **({"exchange_chunks": eng.chunks} if (eng is not None and hasattr(eng, "chunks")) else {})},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "config4_1gpu": config4,
             "sketch": sketch, "multiset_sketch": multiset,
         }
+        if stream_of_matrices is not None:
+            line["stream_of_matrices"] = stream_of_matrices
+        # compact copies of the two secondary legs INSIDE roofline / cpu_baseline: these two objects are what the driver's
+        # record keeps of the line (the full legs stay at top level)
+        def brief(leg):
+            if not isinstance(leg, dict) or "roofline" not in leg:
+                return None, None
+            r = leg["roofline"]
+            b = {"value": leg.get("value"), "unit": leg.get("unit"), "kernel": r.get("kernel"), "kernel_ms": r.get("kernel_ms"),
+                 "achieved": r.get("achieved"), "frac": r.get("frac"), "algorithmic_bytes": r.get("algorithmic_bytes"), "traffic": r.get("traffic")}
+            c = leg.get("cpu_baseline")
+            cb = {"value": c.get("value"), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind")} if isinstance(c, dict) else None
+            return b, cb
+        for key, leg in (("sketch", sketch), ("multiset_sketch", multiset)):
+            b, cb = brief(leg)
+            if b is not None:
+                roofline[key] = b
+            if cb is not None and isinstance(cpu, dict):
+                cpu[key] = cb
         import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)

@@ -425,3 +425,18 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     r = subprocess.run([os.environ.get("PYTHON", "python3"), "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-400:]
     assert "rc -5" in r.stdout, r.stdout
+
+
+def test_bench_refuses_to_mislabel_a_smaller_job(d2g):
+    """`python bench.py --gpus N` without a launcher used to run the 1-GPU job and report n_gpus: 1.
+    It now launches N ranks itself -- or, with fewer than N devices visible, prints a JSON line with "error" and exits 2."""
+    import json
+    import sys
+    have = d2g.lib().d2g_device_count()
+    want = have + 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == want and line["value"] is None and "refusing" in line["error"]
