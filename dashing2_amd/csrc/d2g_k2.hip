@@ -50,9 +50,11 @@ int finish_shape(d2g_ctx *ctx, PairShape &sh, unsigned rb) {
 namespace {
 
 // ---------------------------------------------------------------- transpose [N][S] -> [S][Npad]
+// zero2: two words the bit-sliced prepare that follows wants cleared (its status word and the plan ticket), or null
 __global__ __launch_bounds__(256) void k2_transpose_kernel(const uint64_t *__restrict__ rows, uint64_t *__restrict__ cols,
-                                                           size_t N, size_t S, size_t Npad) {
+                                                           size_t N, size_t S, size_t Npad, uint32_t *zero2) {
     __shared__ uint64_t tile[32][33];
+    if (zero2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
     const size_t n0 = (size_t)blockIdx.y * 32, s0 = (size_t)blockIdx.x * 32;
     for (int r = ty; r < 32; r += 8) {
@@ -202,7 +204,8 @@ static int cmp_set_load(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits
     if (set->d_rows) D2G_HIP(ctx, hipMemcpyAsync(set->d_rows, sig_bits_dev, N * S * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
     d2g_timer tm(ctx, &ctx->ev_k2prep, s);
     dim3 grid((unsigned)div_up<size_t>(S, 32), (unsigned)div_up<size_t>(set->Npad, 32));
-    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, sig_bits_dev, set->d_cols, N, S, set->Npad);
+    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, sig_bits_dev, set->d_cols, N, S, set->Npad,
+                       set->algo == D2G_CMP_BITSLICE ? set->d_meta + set->ntb : nullptr);
     int rc = D2G_OK;
     if (set->algo == D2G_CMP_BITSLICE) rc = d2g_bitslice_prepare(ctx, set, s);
     tm.stop();
@@ -217,7 +220,7 @@ static int cmp_set_load(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits
 int d2g_bitslice_prepare_slice(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *rows_dev, hipStream_t s) {
     d2g_timer tm(ctx, &ctx->ev_k2prep, s);
     dim3 grid((unsigned)div_up<size_t>(set->S, 32), (unsigned)div_up<size_t>(set->Npad, 32));
-    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, rows_dev, set->d_cols, set->N, set->S, set->Npad);
+    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, rows_dev, set->d_cols, set->N, set->S, set->Npad, set->d_meta + set->ntb);
     const int rc = d2g_bitslice_prepare(ctx, set, s);
     tm.stop();
     if (rc) return rc;

@@ -27,6 +27,8 @@
 
 namespace {
 
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef u32x16 __attribute__((aligned(4))) u32x16_u;
 constexpr uint32_t BS_EMPTY = 0xFFFFFFFFu;
 constexpr int BS_RANK_THREADS = 1024;
 
@@ -337,7 +339,10 @@ __device__ __forceinline__ size_t stream_slot(const uint32_t *meta, int tb) {
 }
 
 // ------------------------------------------------------------------ 1b. column plan
-// One workgroup.  Input: colcnt[t][h] = shared values split h of the rank kernel found in column t.  Output:
+// One workgroup, a kernel of its own.  (Letting the LAST workgroup of the rank kernel do this -- ticket counter -- was
+// measured: with an agent-scope fence per workgroup the rank kernel went 52 -> 111 us at config 3, every fence writes the
+// XCD's L2 back; fence-free, with returning device-scope atomics for the counts and the ticket, 52 -> 81 us.  The
+// separate launch costs ~7 us.)  Input: colcnt[t][h] = shared values split h of the rank kernel found in column t.  Output:
 //   colcnt[t][0..nsplit)  exclusive prefix over the splits (the rank offset bs_planes_kernel adds), colcnt[t][4] = D2(t)
 //   perm[slot]            the column that sits in register slot `slot` of the operand (~0 = padding): the columns in
 //                         DESCENDING order of their live-plane class (stable), so that a 32-register group holds
@@ -442,20 +447,26 @@ __global__ __launch_bounds__(BS_PLAN_THREADS) void bs_colplan_kernel(uint32_t *_
 //                                        pointer simply advances by one block per plane (no per-plane address selection).
 // Register slot x of group tb holds column perm[32 tb + x] (bs_colplan_kernel).
 constexpr int BS_FORM_STREAM = 1, BS_FORM_EXCHANGE = 2;
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad,
                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
                                                         size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta, int forms,
-                                                        const uint32_t *__restrict__ perm, const uint32_t *__restrict__ colcnt, int nsplit) {
+                                                        const uint32_t *__restrict__ perm, const uint32_t *__restrict__ colcnt) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t tb = blockIdx.y;
     if (j >= Nstride) return;
     const int nbits = live_planes(meta, (int)tb);
+    // the group's 32 columns: two s_load_dwordx16 (constant address space: never written while this kernel runs), all in
+    // flight before the first id is requested
+    typedef const u32x16_u __attribute__((address_space(4))) *slots_ptr;
+    const u32x16_u pa = *(slots_ptr)(uintptr_t)(perm + tb * 32), pb = *(slots_ptr)(uintptr_t)(perm + tb * 32 + 16);
     uint32_t id[32];
 #pragma unroll
     for (int x = 0; x < 32; ++x) {
-        const uint32_t t = perm[tb * 32 + x];                 // uniform: scalar loads
-        uint32_t w = (t != BS_NOCOL && j < N) ? ids[(size_t)t * Npad + j] : 0u;     // padded registers/sketches: id 0 in both codings
-        if (nsplit > 1 && t != BS_NOCOL && !(w >> 31)) w = (w & BS_RANK_MASK) + colcnt[(size_t)t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)];
+        const uint32_t t = x < 16 ? pa[x] : pb[x - 16];
+        const bool real = t != BS_NOCOL && j < N;             // padded registers/sketches: id 0 in both codings
+        uint32_t w = real ? ids[(size_t)t * Npad + j] : 0u;
+        if (SPLIT && real && !(w >> 31)) w = (w & BS_RANK_MASK) + colcnt[(size_t)t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)];
         id[x] = w;
     }
     uint32_t u = 0;                                    // the "unique" plane
@@ -501,8 +512,6 @@ __global__ __launch_bounds__(256) void bs_derive_kernel(const uint32_t *__restri
 constexpr int BS_THREADS = 256;
 constexpr int BS_CB = 256;                // columns per workgroup tile (all variants)
 
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-typedef u32x16 __attribute__((aligned(4))) u32x16_u;
 // v_bitop3_b32 truth table: src0 = 0xF0, src1 = 0xCC, src2 = 0xAA
 constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);   // mismatch accumulation
 
@@ -756,7 +765,8 @@ int alloc_prepare_workspace(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMemset(set->d_ids, 0, S * Npad * sizeof(uint32_t))) != hipSuccess ||     // split rank passes rely on "no stale pending word"
         (e = hipMalloc((void **)&set->d_colcnt, S * BS_CC_STRIDE * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_perm, (size_t)set->ntb * 32 * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_meta, (size_t)(set->ntb + 4) * sizeof(uint32_t))) != hipSuccess) {
+        (e = hipMalloc((void **)&set->d_meta, (size_t)(set->ntb + 4) * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemset(set->d_meta, 0, (size_t)(set->ntb + 4) * sizeof(uint32_t))) != hipSuccess) {
         ctx->last_error = std::string("bitslice alloc: ") + hipGetErrorString(e);
         d2g_bitslice_free(set);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
@@ -787,7 +797,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 // overflowed on some column -- see d2g_bitslice_status)
 int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
-    D2G_HIP(ctx, hipMemsetAsync(set->d_meta + set->ntb, 0, 4 * sizeof(uint32_t), s));
+    // the status word meta[ntb] was zeroed by the transpose kernel that filled d_cols (no memset node in the chain)
     {
         const int logTl = set->logT < BS_LOG_TLDS_MAX ? set->logT : BS_LOG_TLDS_MAX;
         const size_t lds = (size_t(1) << logTl) * sizeof(uint32_t);
@@ -807,9 +817,10 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const int forms = set->export_only ? BS_FORM_EXCHANGE : (BS_FORM_STREAM | (set->want_exchange ? BS_FORM_EXCHANGE : 0));
-    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, N, Npad, set->export_only ? set->ex_planes : set->d_planes,
-                       set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, forms, set->d_perm, set->d_colcnt,
-                       set->logT > BS_LOG_TLDS_MAX ? set->nsplit : 1);
+    const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
+    hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
+                       set->export_only ? set->ex_planes : set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, forms,
+                       set->d_perm, set->d_colcnt);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
@@ -819,9 +830,9 @@ int d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     if (set->borrowed || set->want_exchange || set->export_only) return D2G_OK;
     set->want_exchange = true;
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(bs_planes_kernel, grid, dim3(256), 0, s, set->d_ids, set->N, set->Npad, set->d_planes, set->d_stream,
-                       set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE, set->d_perm, set->d_colcnt,
-                       set->logT > BS_LOG_TLDS_MAX ? set->nsplit : 1);
+    const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
+    hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, set->N, set->Npad,
+                       set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE, set->d_perm, set->d_colcnt);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
