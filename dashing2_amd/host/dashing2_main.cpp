@@ -27,6 +27,9 @@
 #include <stdexcept>
 #include <memory>
 #include <string>
+#include <fcntl.h>
+#include <functional>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
@@ -110,6 +113,16 @@ void write_cached(const std::string &path, const double *sig, double card, size_
 
 // ------------------------------------------------------------------------------------ sketch
 // stacked output: [u64 N][u64 S][f64 card x N][f64 x N*S]   (sketch_core.cpp:130-140, fastxsketch.cpp:236-240)
+d2g_ctx *make_ctx(const Options &o);
+// The GPU context (HIP runtime start-up, 0.06-0.2 s) is created on a helper thread as soon as the options are parsed, while
+// this thread stats / reads / parses the inputs; get() joins.  There is still no CPU fallback: a failure ends the process.
+struct LazyCtx {
+    const Options &o; std::thread th; d2g_ctx *ctx = nullptr; double t_create = 0;
+    explicit LazyCtx(const Options &oo) : o(oo) { th = std::thread([this] { const double t = now(); ctx = make_ctx(o); t_create = now() - t; }); }
+    d2g_ctx *get() { if (th.joinable()) th.join(); return ctx; }
+    ~LazyCtx() { get(); if (ctx) d2g_ctx_destroy(ctx); }
+};
+
 void write_stacked(const Result &res, const Options &o) {
     const size_t N = res.names.size(), S = o.sketchsize;
     if (!o.outfile.empty()) {
@@ -134,7 +147,8 @@ void write_stacked(const Result &res, const Options &o) {
     }
 }
 
-void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
+void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
+    d2g_ctx *ctx = nullptr;                                             // joined once the parser threads are running
     const double t_enter = now();
     const size_t N = o.paths.size(), S = o.sketchsize, m = d2g_oph_m(S);
     if (!N) die("Can't sketch empty path set");
@@ -177,7 +191,6 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
     double t_parse = 0, t_gpu = 0, t_fin = 0;
     uint64_t total_bases = 0;
     d2g_sketcher *sk = nullptr;
-    check(ctx, d2g_sketcher_create(ctx, &sk), "d2g_sketcher_create");
     struct Ready { size_t g; d2g_seqpack *sp; double tparse; };
     std::deque<Ready> ready;
     std::vector<d2g_seqpack *> pool;                                    // recycled packers (allocations kept)
@@ -212,6 +225,8 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
             cv_ready.notify_one();
         }
     });
+    ctx = lctx.get();                                                    // the parsers are busy: now wait for the GPU context
+    check(ctx, d2g_sketcher_create(ctx, &sk), "d2g_sketcher_create");
     std::vector<uint64_t> regs;
     std::vector<double> sigs, cards;
     for (size_t done = 0; done < groups.size(); ++done) {
@@ -269,14 +284,15 @@ void sketch_core(Result &res, const Options &o, d2g_ctx *ctx) {
 // --parse-by-seq (sketch_core.cpp:23-29 -> fastxsketchbyseq.cpp:102-268,270-531): one sketch per record of
 // ONE input file; OPH set sketches (cardinality = exact distinct k-mer count when the estimate is below
 // 10 S, lines 415-430) or multiset sketches; names are the record names.
-void sketch_core_byseq(Result &res, const Options &o, d2g_ctx *ctx) {
+void sketch_core_byseq(Result &res, const Options &o, LazyCtx &lctx) {
     if (o.paths.size() != 1)
         die("parse-by-seq currently only handles one file at a time. To process multiple files, simply concatenate them into one file, and run dashing2 on that.");
     const size_t S = o.sketchsize, m = d2g_oph_m(S);
     const uint64_t xormask = d2g_seed_mask(o.seedseed);
     d2g_seqpack *sp = nullptr;
-    check(ctx, d2g_seqpack_create(o.k, &sp), "d2g_seqpack_create");
+    check(nullptr, d2g_seqpack_create(o.k, &sp), "d2g_seqpack_create");
     if (d2g_seqpack_add_path_by_record(sp, o.paths[0].c_str()) != D2G_OK) die("Failed to read from " + o.paths[0]);
+    d2g_ctx *ctx = lctx.get();
     const size_t N = d2g_seqpack_ngenomes(sp);
     res.names.resize(N);
     for (size_t i = 0; i < N; ++i) res.names[i] = d2g_seqpack_name(sp, i);
@@ -402,6 +418,20 @@ struct Emitter {
     const Result &res;
     std::FILE *fp = nullptr;
     bool own = false;
+    // binary output to a regular file: the file is sized once and mapped; rows are copied into the mapping by all worker
+    // threads at once (buffered write()s to one file serialise on its inode lock, page faults on a shared mapping do not:
+    // 5 GB at config 4 took 0.74 s through fwrite)
+    unsigned char *map = nullptr; size_t map_bytes = 0, map_pos = 0;
+    void expect_binary_values(size_t nvalues) {
+        if (o.of != MACHINE_READABLE || !own || !nvalues || std::getenv("D2G_NO_MMAP_OUT")) return;
+        std::fflush(fp);
+        const int fd = fileno(fp);
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || ftruncate(fd, off_t(nvalues * sizeof(float))) != 0) return;
+        void *m = mmap(nullptr, nvalues * sizeof(float), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) { if (ftruncate(fd, 0) != 0) die("ftruncate failed"); return; }
+        map = static_cast<unsigned char *>(m); map_bytes = nvalues * sizeof(float);
+    }
     Emitter(const Options &oo, const Result &r) : o(oo), res(r) {
         const std::string outp = (o.cmpout.empty() || o.cmpout.front() == '-') ? "/dev/stdout" : o.cmpout;   // emitrect.cpp:114-115
         if (outp == "/dev/stdout") fp = stdout;
@@ -410,7 +440,14 @@ struct Emitter {
         static std::vector<char> buf(1 << 22);
         std::setvbuf(fp, buf.data(), _IOFBF, buf.size());
     }
-    ~Emitter() { if (fp) { std::fflush(fp); if (own) std::fclose(fp); } }
+    ~Emitter() {
+        if (map) {
+            if (map_pos != map_bytes) std::fprintf(stderr, "[d2g] warning: wrote %zu of %zu expected matrix bytes\n", map_pos, map_bytes);
+            munmap(map, map_bytes);
+            if (map_pos != map_bytes && ftruncate(fileno(fp), off_t(map_pos)) != 0) std::fprintf(stderr, "[d2g] ftruncate failed\n");
+        }
+        if (fp) { std::fflush(fp); if (own) std::fclose(fp); }
+    }
     void header() {                                                     // emitrect.cpp:136-151
         if (o.of != HUMAN_READABLE) return;
         const size_t ns = res.names.size();
@@ -430,6 +467,20 @@ struct Emitter {
         if (o.of == MACHINE_READABLE) {                                  // emitrect.cpp:189-192
             size_t tot = 0;
             for (size_t i = r0; i < r1; ++i) tot += nvals(i);
+            if (map) {
+                const size_t bytes = tot * sizeof(float);
+                if (map_pos + bytes > map_bytes) die("binary output larger than announced");
+                const size_t chunk = size_t(1) << 21;
+                const long nchunk = long((bytes + chunk - 1) / chunk);
+                unsigned char *dst = map + map_pos;
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(data);
+#ifdef _OPENMP
+                #pragma omp parallel for schedule(static) num_threads(o.workers())
+#endif
+                for (long c = 0; c < nchunk; ++c) std::memcpy(dst + size_t(c) * chunk, src + size_t(c) * chunk, std::min(chunk, bytes - size_t(c) * chunk));
+                map_pos += bytes;
+                return;
+            }
             if (std::fwrite(data, sizeof(float), tot, fp) != tot) die("Failed to write rows " + std::to_string(r0) + "-" + std::to_string(r1) + " to disk");
             return;
         }
@@ -473,6 +524,50 @@ struct PinnedBuf {                            // page-locked host staging, reuse
     PinnedBuf(d2g_ctx *c, size_t n) : ctx(c) { check(c, d2g_malloc_host(c, n ? n : 4, &p), "d2g_malloc_host"); }
     ~PinnedBuf() { d2g_free_host(ctx, p); }
     template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+// Row batches flow device -> pinned slot -> emitter thread: the kernel + D2H (+ host x87 epilogue) of batch i+1 run while
+// batch i is formatted / written (the CLI ran kernel -> D2H -> emit strictly in series per 512 MiB batch).
+struct EmitQueue {
+    struct Job { int slot; size_t r0, r1; const float *data; std::function<size_t(size_t)> nvals; };
+    Emitter &em;
+    std::mutex m; std::condition_variable cv;
+    std::deque<Job> q; std::deque<int> free_slots;
+    bool closing = false;
+    double t_emit = 0;
+    std::thread th;
+    EmitQueue(Emitter &e, int nslots) : em(e) {
+        for (int i = 0; i < nslots; ++i) free_slots.push_back(i);
+        th = std::thread([this] {
+            for (;;) {
+                Job j;
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return closing || !q.empty(); });
+                    if (q.empty()) return;
+                    j = std::move(q.front()); q.pop_front();
+                }
+                const double t0 = now();
+                em.rows(j.r0, j.r1, j.data, j.nvals);
+                t_emit += now() - t0;
+                { std::lock_guard<std::mutex> lk(m); free_slots.push_back(j.slot); }
+                cv.notify_all();
+            }
+        });
+    }
+    int acquire() {                                   // a slot whose previous content has been emitted
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !free_slots.empty(); });
+        const int s = free_slots.front(); free_slots.pop_front();
+        return s;
+    }
+    void submit(Job j) { { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(j)); } cv.notify_all(); }
+    void finish() {
+        { std::lock_guard<std::mutex> lk(m); closing = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    ~EmitQueue() { finish(); }
 };
 
 // D2G_DEVICES = "all" | "0,1,2": the GPUs `cmp` may spread a symmetric all-pairs job over (default: the one device
@@ -538,6 +633,7 @@ bool cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
     em.header();
     const size_t max_vals = size_t(1) << 27;
     const size_t total_pairs = ns * (ns - 1) / 2, cap = std::min(std::max<size_t>(total_pairs, 1), max_vals + ns);
+    em.expect_binary_values(total_pairs);
     std::vector<std::unique_ptr<DevBuf>> da(W), dlut(W);
     std::vector<std::unique_ptr<PinnedBuf>> hout(W), hca(W);
     for (int r = 0; r < W; ++r) {
@@ -619,19 +715,41 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     if (have_lut) check(ctx, d2g_memcpy_h2d(ctx, dlut.p, lut.data(), (S + 1) * sizeof(float), nullptr), "h2d lut");
     Emitter em(o, res);
     em.header();
-    const size_t max_vals = size_t(1) << 27;                        // values per device batch (512 MiB of floats)
-    double t_dev = 0, t_emit = 0;
-    if (o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP) {            // emitrect.cpp:290-323
-        const size_t total_pairs = ns * (ns - 1) / 2, cap = std::min(std::max<size_t>(total_pairs, 1), max_vals + ns);
-        PinnedBuf hout(ctx, cap * 4), hca(ctx, have_lut ? 4 : cap * 4), hcb(ctx, need_gtlt ? cap * 4 : 4);
-        DevBuf da(ctx, cap * 4), db(ctx, need_gtlt ? cap * 4 : 4);
-        float *out = hout.as<float>();
-        uint32_t *ca = hca.as<uint32_t>(), *cb = hcb.as<uint32_t>();
-        for (size_t r0 = 0; r0 < ns;) {
+    // values per device batch: 64 MiB of floats per slot, three slots in flight (device / D2H + epilogue / emit).  Small
+    // slots keep the page-locked allocations cheap (pinning 3 x 512 MiB cost more than the whole device work of config 3).
+    size_t slot_vals = size_t(1) << 24;
+    if (const char *e = std::getenv("D2G_CMP_SLOT_VALUES")) { const long long v = std::atoll(e); if (v >= 1) slot_vals = size_t(v); }   // tests: tiny slots
+    const bool symmetric = o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP;
+    const size_t nq = res.nq, nf = o.ok == PANEL ? ns - nq : ns;
+    const size_t c0 = o.ok == PANEL ? nf : 0, c1 = ns, ncol = symmetric ? 0 : c1 - c0;
+    const size_t nrows = symmetric ? ns : nf;
+    const size_t total_vals = symmetric ? ns * (ns - 1) / 2 : nf * ncol;
+    const size_t widest = symmetric ? (ns ? ns - 1 : 0) : ncol;
+    const size_t cap = std::max<size_t>(1, std::min(std::max(slot_vals, widest), std::max<size_t>(total_vals, 1)));
+    em.expect_binary_values(total_vals);
+    constexpr int NSLOT = 3;
+    struct Slot { std::unique_ptr<PinnedBuf> out, ca, cb; };
+    Slot slots[NSLOT];
+    for (auto &sl : slots) {
+        sl.out.reset(new PinnedBuf(ctx, cap * 4));
+        sl.ca.reset(new PinnedBuf(ctx, have_lut && symmetric ? 4 : cap * 4));
+        sl.cb.reset(new PinnedBuf(ctx, need_gtlt ? cap * 4 : 4));
+    }
+    DevBuf da(ctx, cap * 4), db(ctx, need_gtlt ? cap * 4 : 4);
+    double t_dev = 0;
+    const double t_loop = now();
+    {
+        EmitQueue eq(em, NSLOT);
+        for (size_t r0 = 0; r0 < nrows;) {
             size_t r1 = r0, cnt = 0;
-            while (r1 < ns && (cnt == 0 || cnt + (ns - 1 - r1) <= max_vals)) { cnt += ns - 1 - r1; ++r1; }
+            if (symmetric) while (r1 < ns && (cnt == 0 || cnt + (ns - 1 - r1) <= cap)) { cnt += ns - 1 - r1; ++r1; }
+            else { r1 = std::min(nrows, r0 + std::max<size_t>(1, cap / std::max<size_t>(ncol, 1))); cnt = (r1 - r0) * ncol; }
+            const int si = eq.acquire();
+            Slot &sl = slots[si];
+            float *out = sl.out->as<float>();
+            uint32_t *ca = sl.ca->as<uint32_t>(), *cb = sl.cb->as<uint32_t>();
             const double ta = now();
-            if (cnt) {
+            if (cnt && symmetric) {                                     // emitrect.cpp:290-323
                 if (have_lut) {
                     check(ctx, d2g_cmp_lut_ut_dev(ctx, set, r0, r1, (const float *)dlut.p, (float *)da.p, nullptr), "d2g_cmp_lut_ut_dev");
                     check(ctx, d2g_memcpy_d2h(ctx, out, da.p, cnt * 4, nullptr), "d2h");
@@ -647,26 +765,7 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                     check(ctx, d2g_epilogue_ut(ca, need_gtlt ? cb : nullptr, cards, ns, S, r0, r1, o.measure, o.k, multiset,
                                                int(o.workers()), out), "d2g_epilogue_ut");
                 }
-            }
-            const double tb = now();
-            em.rows(r0, r1, out, [&](size_t i) { return ns - 1 - i; });
-            t_dev += tb - ta; t_emit += now() - tb;
-            r0 = r1;
-        }
-    } else {                                                        // asymmetric / panel: emitrect.cpp:211-268
-        const size_t nq = res.nq, nf = o.ok == PANEL ? ns - nq : ns;
-        const size_t c0 = o.ok == PANEL ? nf : 0, c1 = ns, ncol = c1 - c0;
-        if (ncol == 0 || nf == 0) { check(ctx, D2G_OK, ""); }
-        const size_t rows_per = std::max<size_t>(1, max_vals / std::max<size_t>(ncol, 1));
-        const size_t cap = std::max<size_t>(1, std::min(rows_per, std::max<size_t>(nf, 1)) * ncol);
-        PinnedBuf hout(ctx, cap * 4), hca(ctx, cap * 4), hcb(ctx, need_gtlt ? cap * 4 : 4);
-        DevBuf da(ctx, cap * 4), db(ctx, need_gtlt ? cap * 4 : 4);
-        float *out = hout.as<float>();
-        uint32_t *ca = hca.as<uint32_t>(), *cb = hcb.as<uint32_t>();
-        for (size_t r0 = 0; r0 < nf; r0 += rows_per) {
-            const size_t r1 = std::min(nf, r0 + rows_per), cnt = (r1 - r0) * ncol;
-            const double ta = now();
-            if (cnt) {
+            } else if (cnt) {                                           // asymmetric / panel: emitrect.cpp:211-268
                 if (need_gtlt) {
                     check(ctx, d2g_cmp_gtlt_rect_dev(ctx, set, r0, r1, c0, c1, (uint32_t *)da.p, (uint32_t *)db.p, nullptr), "d2g_cmp_gtlt_rect_dev");
                     check(ctx, d2g_memcpy_d2h(ctx, cb, db.p, cnt * 4, nullptr), "d2h");
@@ -680,19 +779,21 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                 for (size_t i = r0; i < r1; ++i)
                     for (size_t j = c0; j < c1; ++j) {
                         const size_t p = (i - r0) * ncol + (j - c0);
-                        out[p] = have_lut ? lut[ca[p]]
-                               : multiset ? d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k)
-                               : need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
-                                           : d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], o.measure, o.k);
+                        // compare(i, j): sketch i is the left-hand side (cmp_core.cpp:349-361); the diagonal of a square matrix is compare(i, i)
+                        out[p] = need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
+                                           : d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k);
                     }
             }
-            const double tb = now();
-            em.rows(r0, r1, out, [&](size_t) { return ncol; });
-            t_dev += tb - ta; t_emit += now() - tb;
+            t_dev += now() - ta;
+            if (symmetric) eq.submit({si, r0, r1, out, [ns](size_t i) { return ns - 1 - i; }});
+            else eq.submit({si, r0, r1, out, [ncol](size_t) { return ncol; }});
+            r0 = r1;
         }
+        eq.finish();
+        if (o.verbosity) std::fprintf(stderr, "[d2g] cmp: %zu sketches x S=%zu: upload+prepare+buffers %.3fs, batches %.3fs wall (device+D2H+epilogue %.3fs busy, emit %.3fs busy, "
+                                              "overlapped) (algo %s)\n", ns, S, t_loop - t0, now() - t_loop, t_dev, eq.t_emit,
+                                      d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE ? "bitslice" : "direct");
     }
-    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp: %zu sketches x S=%zu: upload+prepare+buffers %.3fs, device+D2H+epilogue %.3fs, emit %.3fs (algo %s)\n", ns, S,
-                                  0.0 + (now() - t0 - t_dev - t_emit), t_dev, t_emit, d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE ? "bitslice" : "direct");
     d2g_cmp_set_destroy(set);
 }
 
@@ -704,18 +805,16 @@ d2g_ctx *make_ctx(const Options &o) {
 }
 
 int sketch_main(int argc, char **argv) {                          // src/sketch_main.cpp:23-152
-    const double t_start = now();
     Options o;
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
     if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
     if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); sketch_usage(); return 1; }
-    d2g_ctx *ctx = make_ctx(o);
-    if (o.verbosity) std::fprintf(stderr, "[d2g] options + GPU context: %.3fs\n", now() - t_start);
+    LazyCtx lctx(o);
     Result res;
-    if (o.parse_by_seq) sketch_core_byseq(res, o, ctx); else sketch_core(res, o, ctx);
+    if (o.parse_by_seq) sketch_core_byseq(res, o, lctx); else sketch_core(res, o, lctx);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] GPU context %.3fs on a helper thread, under the host ingest\n", lctx.t_create);
     res.nq = o.nq;
-    if (!o.cmpout.empty()) cmp_core(o, res, ctx);                  // sketch_main.cpp:144-148
-    d2g_ctx_destroy(ctx);
+    if (!o.cmpout.empty()) cmp_core(o, res, lctx.get());           // sketch_main.cpp:144-148
     return 0;
 }
 
@@ -724,7 +823,7 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
     o.is_cmp = true;
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
     if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
-    d2g_ctx *ctx = make_ctx(o);
+    LazyCtx lctx(o);                                               // under the reading of the sketch file(s)
     Result res;
     if (o.presketched) {
         // suffix sniffing, cmp_main.cpp:305-351
@@ -751,11 +850,13 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
         load_results(o, res);
     } else {
         if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); cmp_usage(); return 1; }
-        if (o.parse_by_seq) sketch_core_byseq(res, o, ctx); else sketch_core(res, o, ctx);
+        if (o.parse_by_seq) sketch_core_byseq(res, o, lctx); else sketch_core(res, o, lctx);
         res.nq = o.nq;
     }
+    const double t_wait = now();
+    d2g_ctx *ctx = lctx.get();
+    if (o.verbosity) std::fprintf(stderr, "[d2g] GPU context %.3fs on a helper thread (%.3fs of it after the inputs were loaded)\n", lctx.t_create, now() - t_wait);
     cmp_core(o, res, ctx);
-    d2g_ctx_destroy(ctx);
     return 0;
 }
 

@@ -573,3 +573,33 @@ def test_cli_cache_names_with_count_threshold(genomes, tmp_path):
         want = str(g) + ".rc_canon.sketchsize64.k21" + tag + ".ExactCounting.MultisetSpace.DNA.d2gbmh"
         assert os.path.exists(want), sorted(os.listdir(d))
         os.remove(want)
+
+
+def test_cli_cmp_batches_and_mmap_output_are_invisible(genomes, tmp_path):
+    """`cmp` now runs device batch i+1 under the emit of batch i (three pinned slots, an emitter thread) and
+    writes binary matrices through a shared mapping filled by all worker threads.  Neither may change a byte: tiny slots
+    (many batches, D2G_CMP_SLOT_VALUES) and the plain fwrite path (D2G_NO_MMAP_OUT) against the default, for every shape,
+    text and binary, table-epilogue and host-epilogue measures."""
+    rng = np.random.default_rng(21)
+    N, S = 157, 128
+    sigs = rng.random((12, S))[rng.integers(0, 12, (N, S)), np.arange(S)[None, :]]
+    cards = rng.uniform(1e3, 1e6, N)
+    st = tmp_path / "m.bin"
+    _write_stacked(st, sigs, cards)
+    shapes = [[], ["--phylip"], ["--asymmetric-all-pairs"]]
+    for shape in shapes:
+        for meas in ([], ["--containment"], ["--distance"]):
+            for binary in ([], ["--binary-output"]):
+                if binary and shape == ["--phylip"]:
+                    continue
+                outs = []
+                for env in ({}, {"D2G_CMP_SLOT_VALUES": "999"}, {"D2G_NO_MMAP_OUT": "1"}, {"D2G_CMP_SLOT_VALUES": "1", "D2G_NO_MMAP_OUT": "1"}):
+                    o = tmp_path / "o.out"
+                    r = subprocess.run([EXE, "cmp", "--presketched", "-k", "31", "-p", "4", "--cmpout", str(o)] + shape + meas + binary + [str(st)],
+                                       capture_output=True, env=dict(os.environ, **env))
+                    assert r.returncode == 0, r.stderr.decode()[-800:]
+                    outs.append(o.read_bytes())
+                assert all(x == outs[0] for x in outs[1:]), (shape, meas, binary)
+                if binary:
+                    nv = N * N if shape else N * (N - 1) // 2
+                    assert len(outs[0]) == 4 * nv
