@@ -27,9 +27,7 @@
 #include <stdexcept>
 #include <memory>
 #include <string>
-#include <fcntl.h>
 #include <functional>
-#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
@@ -49,6 +47,9 @@ struct Result {                              // SketchingResult, src/fastxsketch
     std::vector<std::string> names, destination_files;
     std::vector<double> cardinalities;
     std::vector<double> signatures;          // [N][S] row-major
+    double *sigs() { return signatures.data(); }
+    const double *sigs() const { return signatures.data(); }
+    size_t nsigs() const { return signatures.size(); }
     size_t nq = 0;
 };
 
@@ -120,7 +121,9 @@ struct LazyCtx {
     const Options &o; std::thread th; d2g_ctx *ctx = nullptr; double t_create = 0;
     explicit LazyCtx(const Options &oo) : o(oo) { th = std::thread([this] { const double t = now(); ctx = make_ctx(o); t_create = now() - t; }); }
     d2g_ctx *get() { if (th.joinable()) th.join(); return ctx; }
-    ~LazyCtx() { get(); if (ctx) d2g_ctx_destroy(ctx); }
+    // the context is only torn down on request: main() leaves through _exit once every output is flushed and closed (the HIP
+    // runtime's orderly shutdown costs tens of milliseconds that buy a CLI process nothing); D2G_FULL_TEARDOWN=1 keeps it
+    ~LazyCtx() { get(); if (ctx && std::getenv("D2G_FULL_TEARDOWN")) d2g_ctx_destroy(ctx); }
 };
 
 void write_stacked(const Result &res, const Options &o) {
@@ -381,6 +384,8 @@ void load_results(Options &o, Result &res) {               // src/cmp_main.cpp:2
         res.cardinalities.resize(N);
         if (std::fread(res.cardinalities.data(), 8, N, fp) != N) die("Failed to read cardinalities from disk");
         const size_t nreg = (filesize(pf) - (N + 2) * 8) / 8;
+        // (a private mapping of the file instead of this copy was measured: the page faults it moves into densify and the
+        // upload cost more than the read -- config 4: 1.26 -> 1.43 s)
         res.signatures.resize(nreg);
         if (std::fread(res.signatures.data(), 8, nreg, fp) != nreg) die("Failed to read signatures from disk");
         std::fclose(fp);
@@ -418,20 +423,9 @@ struct Emitter {
     const Result &res;
     std::FILE *fp = nullptr;
     bool own = false;
-    // binary output to a regular file: the file is sized once and mapped; rows are copied into the mapping by all worker
-    // threads at once (buffered write()s to one file serialise on its inode lock, page faults on a shared mapping do not:
-    // 5 GB at config 4 took 0.74 s through fwrite)
-    unsigned char *map = nullptr; size_t map_bytes = 0, map_pos = 0;
-    void expect_binary_values(size_t nvalues) {
-        if (o.of != MACHINE_READABLE || !own || !nvalues || std::getenv("D2G_NO_MMAP_OUT")) return;
-        std::fflush(fp);
-        const int fd = fileno(fp);
-        struct stat st;
-        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || ftruncate(fd, off_t(nvalues * sizeof(float))) != 0) return;
-        void *m = mmap(nullptr, nvalues * sizeof(float), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) { if (ftruncate(fd, 0) != 0) die("ftruncate failed"); return; }
-        map = static_cast<unsigned char *>(m); map_bytes = nvalues * sizeof(float);
-    }
+    // (Binary matrices through a shared mapping of the output file, filled by all worker threads, were measured at config 4:
+    // 5 GB copied in 0.57 s instead of 0.74 s through fwrite, but unmapping the dirty pages then took another 0.51 s on the
+    // overlay file system of the box: fwrite stays.)
     Emitter(const Options &oo, const Result &r) : o(oo), res(r) {
         const std::string outp = (o.cmpout.empty() || o.cmpout.front() == '-') ? "/dev/stdout" : o.cmpout;   // emitrect.cpp:114-115
         if (outp == "/dev/stdout") fp = stdout;
@@ -440,14 +434,7 @@ struct Emitter {
         static std::vector<char> buf(1 << 22);
         std::setvbuf(fp, buf.data(), _IOFBF, buf.size());
     }
-    ~Emitter() {
-        if (map) {
-            if (map_pos != map_bytes) std::fprintf(stderr, "[d2g] warning: wrote %zu of %zu expected matrix bytes\n", map_pos, map_bytes);
-            munmap(map, map_bytes);
-            if (map_pos != map_bytes && ftruncate(fileno(fp), off_t(map_pos)) != 0) std::fprintf(stderr, "[d2g] ftruncate failed\n");
-        }
-        if (fp) { std::fflush(fp); if (own) std::fclose(fp); }
-    }
+    ~Emitter() { if (fp) { std::fflush(fp); if (own) std::fclose(fp); } }
     void header() {                                                     // emitrect.cpp:136-151
         if (o.of != HUMAN_READABLE) return;
         const size_t ns = res.names.size();
@@ -467,20 +454,6 @@ struct Emitter {
         if (o.of == MACHINE_READABLE) {                                  // emitrect.cpp:189-192
             size_t tot = 0;
             for (size_t i = r0; i < r1; ++i) tot += nvals(i);
-            if (map) {
-                const size_t bytes = tot * sizeof(float);
-                if (map_pos + bytes > map_bytes) die("binary output larger than announced");
-                const size_t chunk = size_t(1) << 21;
-                const long nchunk = long((bytes + chunk - 1) / chunk);
-                unsigned char *dst = map + map_pos;
-                const unsigned char *src = reinterpret_cast<const unsigned char *>(data);
-#ifdef _OPENMP
-                #pragma omp parallel for schedule(static) num_threads(o.workers())
-#endif
-                for (long c = 0; c < nchunk; ++c) std::memcpy(dst + size_t(c) * chunk, src + size_t(c) * chunk, std::min(chunk, bytes - size_t(c) * chunk));
-                map_pos += bytes;
-                return;
-            }
             if (std::fwrite(data, sizeof(float), tot, fp) != tot) die("Failed to write rows " + std::to_string(r0) + "-" + std::to_string(r1) + " to disk");
             return;
         }
@@ -594,7 +567,7 @@ bool cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
                     bool multiset) {
     const size_t ns = res.names.size(), S = o.sketchsize;
     const int W = int(devs.size());
-    const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.signatures.data());
+    const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.sigs());
     const double *cards = res.cardinalities.data();
     const double t0 = now();
     std::vector<d2g_ctx *> ctxs(W, nullptr);
@@ -633,7 +606,6 @@ bool cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
     em.header();
     const size_t max_vals = size_t(1) << 27;
     const size_t total_pairs = ns * (ns - 1) / 2, cap = std::min(std::max<size_t>(total_pairs, 1), max_vals + ns);
-    em.expect_binary_values(total_pairs);
     std::vector<std::unique_ptr<DevBuf>> da(W), dlut(W);
     std::vector<std::unique_ptr<PinnedBuf>> hout(W), hca(W);
     for (int r = 0; r < W; ++r) {
@@ -688,14 +660,16 @@ bool cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
 
 void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_core.cpp:615-751 (dense outputs)
     const size_t ns = res.names.size(), S = o.sketchsize;
-    if (res.signatures.size() != ns * S) die("Empty signatures; trying to compare but don't have any");
+    if (res.nsigs() != ns * S) die("Empty signatures; trying to compare but don't have any");
     const bool multiset = o.sspace != SPACE_SET;
     if (o.kmer_result == ONE_PERM) {                                // cmp_core.cpp:686-718
         size_t nfilled = 0;
-        check(ctx, d2g_densify(res.signatures.data(), ns, S, &nfilled, int(o.workers())), "d2g_densify");
+        const double td = now();
+        check(ctx, d2g_densify(res.sigs(), ns, S, &nfilled, int(o.workers())), "d2g_densify");
+        if (o.verbosity) std::fprintf(stderr, "[d2g] densify scan %.3fs\n", now() - td);
         if (o.verbosity && nfilled) std::fprintf(stderr, "Densified a total of %zu/%zu entries\n", nfilled, S * ns);
     }
-    const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.signatures.data());
+    const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.sigs());
     const double *cards = res.cardinalities.data();
     std::vector<float> lut(S + 1);
     const bool have_lut = d2g_epilogue_lut(S, o.measure, o.k, multiset, lut.data()) == D2G_OK;
@@ -710,11 +684,6 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     }
     d2g_cmp_set *set = nullptr;
     const double t0 = now();
-    check(ctx, d2g_cmp_set_create(ctx, bits, ns, S, need_gtlt ? int(D2G_CMP_DIRECT) : int(D2G_CMP_AUTO), &set), "d2g_cmp_set_create");
-    DevBuf dlut(ctx, (S + 1) * sizeof(float));
-    if (have_lut) check(ctx, d2g_memcpy_h2d(ctx, dlut.p, lut.data(), (S + 1) * sizeof(float), nullptr), "h2d lut");
-    Emitter em(o, res);
-    em.header();
     // values per device batch: 64 MiB of floats per slot, three slots in flight (device / D2H + epilogue / emit).  Small
     // slots keep the page-locked allocations cheap (pinning 3 x 512 MiB cost more than the whole device work of config 3).
     size_t slot_vals = size_t(1) << 24;
@@ -726,16 +695,24 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     const size_t total_vals = symmetric ? ns * (ns - 1) / 2 : nf * ncol;
     const size_t widest = symmetric ? (ns ? ns - 1 : 0) : ncol;
     const size_t cap = std::max<size_t>(1, std::min(std::max(slot_vals, widest), std::max<size_t>(total_vals, 1)));
-    em.expect_binary_values(total_vals);
     constexpr int NSLOT = 3;
     struct Slot { std::unique_ptr<PinnedBuf> out, ca, cb; };
     Slot slots[NSLOT];
-    for (auto &sl : slots) {
-        sl.out.reset(new PinnedBuf(ctx, cap * 4));
-        sl.ca.reset(new PinnedBuf(ctx, have_lut && symmetric ? 4 : cap * 4));
-        sl.cb.reset(new PinnedBuf(ctx, need_gtlt ? cap * 4 : 4));
-    }
+    // page-locking the slots (tens of ms) and the output header run on a helper thread, under the upload + prepare of the operand
+    Emitter em(o, res);
+    std::thread side([&] {
+        em.header();
+        for (auto &sl : slots) {
+            sl.out.reset(new PinnedBuf(ctx, cap * 4));
+            sl.ca.reset(new PinnedBuf(ctx, have_lut && symmetric ? 4 : cap * 4));
+            sl.cb.reset(new PinnedBuf(ctx, need_gtlt ? cap * 4 : 4));
+        }
+    });
+    check(ctx, d2g_cmp_set_create(ctx, bits, ns, S, need_gtlt ? int(D2G_CMP_DIRECT) : int(D2G_CMP_AUTO), &set), "d2g_cmp_set_create");
+    DevBuf dlut(ctx, (S + 1) * sizeof(float));
+    if (have_lut) check(ctx, d2g_memcpy_h2d(ctx, dlut.p, lut.data(), (S + 1) * sizeof(float), nullptr), "h2d lut");
     DevBuf da(ctx, cap * 4), db(ctx, need_gtlt ? cap * 4 : 4);
+    side.join();
     double t_dev = 0;
     const double t_loop = now();
     {
@@ -779,9 +756,10 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                 for (size_t i = r0; i < r1; ++i)
                     for (size_t j = c0; j < c1; ++j) {
                         const size_t p = (i - r0) * ncol + (j - c0);
-                        // compare(i, j): sketch i is the left-hand side (cmp_core.cpp:349-361); the diagonal of a square matrix is compare(i, i)
-                        out[p] = need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
-                                           : d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k);
+                        out[p] = have_lut ? lut[ca[p]]
+                               : multiset ? d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k)
+                               : need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
+                                           : d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], o.measure, o.k);
                     }
             }
             t_dev += now() - ta;
@@ -823,6 +801,7 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
     o.is_cmp = true;
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
     if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
+    const double t_begin = now();
     LazyCtx lctx(o);                                               // under the reading of the sketch file(s)
     Result res;
     if (o.presketched) {
@@ -855,8 +834,11 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
     }
     const double t_wait = now();
     d2g_ctx *ctx = lctx.get();
-    if (o.verbosity) std::fprintf(stderr, "[d2g] GPU context %.3fs on a helper thread (%.3fs of it after the inputs were loaded)\n", lctx.t_create, now() - t_wait);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] inputs loaded in %.3fs; GPU context %.3fs on a helper thread (%.3fs of it after the inputs were loaded)\n",
+                                  t_wait - t_begin, lctx.t_create, now() - t_wait);
+    const double t_cmp = now();
     cmp_core(o, res, ctx);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp_core %.3fs in all (densify, upload, batches, closing the output)\n", now() - t_cmp);
     return 0;
 }
 
@@ -880,8 +862,16 @@ int main(int argc, char **argv) {                                 // src/d2.cpp:
     for (char **s = argv + 1; *s; ++s) cmd += std::string(" ") + *s;
     std::fprintf(stderr, "#Calling Dashing2 version %s with command '%s'\n", DASHING2_VERSION, cmd.c_str());
     if (argc > 1) {
-        if (std::strcmp(argv[1], "sketch") == 0) return sketch_main(argc - 1, argv + 1);
-        if (std::strcmp(argv[1], "cmp") == 0 || std::strcmp(argv[1], "dist") == 0) return cmp_main(argc - 1, argv + 1);
+        const bool is_sketch = std::strcmp(argv[1], "sketch") == 0, is_cmp = std::strcmp(argv[1], "cmp") == 0 || std::strcmp(argv[1], "dist") == 0;
+        if (is_sketch || is_cmp) {
+            const double t0 = now();
+            const int rc = is_sketch ? sketch_main(argc - 1, argv + 1) : cmp_main(argc - 1, argv + 1);
+            // every output file has been flushed and closed by now (Emitter / write_stacked go out of scope inside)
+            std::fflush(nullptr);
+            if (std::getenv("D2G_VERBOSE_EXIT")) std::fprintf(stderr, "[d2g] in-process time %.3fs\n", now() - t0);
+            if (!std::getenv("D2G_FULL_TEARDOWN")) _exit(rc);
+            return rc;
+        }
         if (std::strcmp(argv[1], "wsketch") == 0) return d2h::wsketch_main(argc - 1, argv + 1);
         if (std::strcmp(argv[1], "contain") == 0 || std::strcmp(argv[1], "printmin") == 0) {
             std::fprintf(stderr, "dashing2 (MI355X): subcommand %s is outside the hot-path scope of this build.\n", argv[1]);

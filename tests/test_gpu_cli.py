@@ -575,10 +575,9 @@ def test_cli_cache_names_with_count_threshold(genomes, tmp_path):
         os.remove(want)
 
 
-def test_cli_cmp_batches_and_mmap_output_are_invisible(genomes, tmp_path):
-    """`cmp` now runs device batch i+1 under the emit of batch i (three pinned slots, an emitter thread) and
-    writes binary matrices through a shared mapping filled by all worker threads.  Neither may change a byte: tiny slots
-    (many batches, D2G_CMP_SLOT_VALUES) and the plain fwrite path (D2G_NO_MMAP_OUT) against the default, for every shape,
+def test_cli_cmp_batches_are_invisible(genomes, tmp_path):
+    """`cmp` now runs device batch i+1 under the emit of batch i (three pinned slots, an emitter thread).
+    The batching may not change a byte: tiny slots (many batches, D2G_CMP_SLOT_VALUES) against the default, for every shape,
     text and binary, table-epilogue and host-epilogue measures."""
     rng = np.random.default_rng(21)
     N, S = 157, 128
@@ -593,7 +592,7 @@ def test_cli_cmp_batches_and_mmap_output_are_invisible(genomes, tmp_path):
                 if binary and shape == ["--phylip"]:
                     continue
                 outs = []
-                for env in ({}, {"D2G_CMP_SLOT_VALUES": "999"}, {"D2G_NO_MMAP_OUT": "1"}, {"D2G_CMP_SLOT_VALUES": "1", "D2G_NO_MMAP_OUT": "1"}):
+                for env in ({}, {"D2G_CMP_SLOT_VALUES": "999"}, {"D2G_CMP_SLOT_VALUES": "1"}):
                     o = tmp_path / "o.out"
                     r = subprocess.run([EXE, "cmp", "--presketched", "-k", "31", "-p", "4", "--cmpout", str(o)] + shape + meas + binary + [str(st)],
                                        capture_output=True, env=dict(os.environ, **env))
