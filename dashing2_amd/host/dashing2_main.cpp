@@ -10,6 +10,7 @@
 #include "../../include/d2g.h"
 #include "d2_options.h"
 #include "fmtfloat.h"
+#include "slot_queue.h"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -501,46 +502,13 @@ struct PinnedBuf {                            // page-locked host staging, reuse
 
 // Row batches flow device -> pinned slot -> emitter thread: the kernel + D2H (+ host x87 epilogue) of batch i+1 run while
 // batch i is formatted / written (the CLI ran kernel -> D2H -> emit strictly in series per 512 MiB batch).
-struct EmitQueue {
-    struct Job { int slot; size_t r0, r1; const float *data; std::function<size_t(size_t)> nvals; };
-    Emitter &em;
-    std::mutex m; std::condition_variable cv;
-    std::deque<Job> q; std::deque<int> free_slots;
-    bool closing = false;
-    double t_emit = 0;
-    std::thread th;
-    EmitQueue(Emitter &e, int nslots) : em(e) {
-        for (int i = 0; i < nslots; ++i) free_slots.push_back(i);
-        th = std::thread([this] {
-            for (;;) {
-                Job j;
-                {
-                    std::unique_lock<std::mutex> lk(m);
-                    cv.wait(lk, [&] { return closing || !q.empty(); });
-                    if (q.empty()) return;
-                    j = std::move(q.front()); q.pop_front();
-                }
-                const double t0 = now();
-                em.rows(j.r0, j.r1, j.data, j.nvals);
-                t_emit += now() - t0;
-                { std::lock_guard<std::mutex> lk(m); free_slots.push_back(j.slot); }
-                cv.notify_all();
-            }
-        });
+// The queue itself is slot_queue.h (exercised under ThreadSanitizer by `make tsan`).
+struct EmitJob { size_t r0, r1; const float *data; std::function<size_t(size_t)> nvals; };
+struct EmitQueue : SlotQueue<EmitJob> {
+    EmitQueue(Emitter &em, int nslots) : SlotQueue<EmitJob>(nslots, [&em](const EmitJob &j) { em.rows(j.r0, j.r1, j.data, j.nvals); }) {}
+    void submit_rows(int slot, size_t r0, size_t r1, const float *data, std::function<size_t(size_t)> nvals) {
+        submit(slot, EmitJob{r0, r1, data, std::move(nvals)});
     }
-    int acquire() {                                   // a slot whose previous content has been emitted
-        std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return !free_slots.empty(); });
-        const int s = free_slots.front(); free_slots.pop_front();
-        return s;
-    }
-    void submit(Job j) { { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(j)); } cv.notify_all(); }
-    void finish() {
-        { std::lock_guard<std::mutex> lk(m); closing = true; }
-        cv.notify_all();
-        if (th.joinable()) th.join();
-    }
-    ~EmitQueue() { finish(); }
 };
 
 // D2G_DEVICES = "all" | "0,1,2": the GPUs `cmp` may spread a symmetric all-pairs job over (default: the one device
@@ -763,13 +731,13 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                     }
             }
             t_dev += now() - ta;
-            if (symmetric) eq.submit({si, r0, r1, out, [ns](size_t i) { return ns - 1 - i; }});
-            else eq.submit({si, r0, r1, out, [ncol](size_t) { return ncol; }});
+            if (symmetric) eq.submit_rows(si, r0, r1, out, [ns](size_t i) { return ns - 1 - i; });
+            else eq.submit_rows(si, r0, r1, out, [ncol](size_t) { return ncol; });
             r0 = r1;
         }
         eq.finish();
         if (o.verbosity) std::fprintf(stderr, "[d2g] cmp: %zu sketches x S=%zu: upload+prepare+buffers %.3fs, batches %.3fs wall (device+D2H+epilogue %.3fs busy, emit %.3fs busy, "
-                                              "overlapped) (algo %s)\n", ns, S, t_loop - t0, now() - t_loop, t_dev, eq.t_emit,
+                                              "overlapped) (algo %s)\n", ns, S, t_loop - t0, now() - t_loop, t_dev, eq.t_busy,
                                       d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE ? "bitslice" : "direct");
     }
     d2g_cmp_set_destroy(set);

@@ -427,6 +427,14 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     assert "rc -5" in r.stdout, r.stdout
 
 
+def test_host_threading_under_thread_sanitizer():
+    """the two host pipelines of the CLI -- parser pool -> bounded queue -> consumer over d2g_seqpack, and producer -> slot
+    queue -> emitter thread over the float formatter -- built with -fsanitize=thread (csrc `make tsan`): no report, exit 0"""
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "dashing2_amd", "csrc"), "tsan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "host threads selftest OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert "ThreadSanitizer" not in r.stdout + r.stderr
+
+
 def test_bench_refuses_to_mislabel_a_smaller_job(d2g):
     """`python bench.py --gpus N` without a launcher used to run the 1-GPU job and report n_gpus: 1.
     It now launches N ranks itself -- or, with fewer than N devices visible, prints a JSON line with "error" and exits 2."""
