@@ -10,7 +10,7 @@ from .capi import (  # noqa: F401
     D2GError, Context, CmpSet, SeqPack, Comm, AllPairs, lib, build, LIB_PATH,
     comm_unique_id, allpairs_step_all, allpairs_prepare_all, bcast_sigs,
     SIMILARITY, CONTAINMENT, SYMMETRIC_CONTAINMENT, POISSON_LLR, INTERSECTION, UNION_SIZE,
-    CMP_AUTO, CMP_DIRECT, CMP_BITSLICE, BITSLICE_OPS_PER_GROUP_EXTRA, TIME_K1, TIME_K2, TIME_K2PREP, TIME_K3,
+    CMP_AUTO, CMP_DIRECT, CMP_BITSLICE, BITSLICE_OPS_PER_GROUP_EXTRA, TIME_K1, TIME_K2, TIME_K2PREP, TIME_K3, TIME_K0, PinnedArray,
     wang_hash, seed_mask, oph_xor_const, oph_m, oph_finalize, densify, epilogue_lut,
     epilogue_gtlt, epilogue_neq, host_epilogue_ut, operand_layout, ut_count, ut_partition,
 )
@@ -19,7 +19,7 @@ __all__ = [
     "D2GError", "Context", "CmpSet", "SeqPack", "Comm", "AllPairs", "lib", "build", "LIB_PATH",
     "comm_unique_id", "allpairs_step_all", "allpairs_prepare_all", "bcast_sigs",
     "SIMILARITY", "CONTAINMENT", "SYMMETRIC_CONTAINMENT", "POISSON_LLR", "INTERSECTION", "UNION_SIZE",
-    "CMP_AUTO", "CMP_DIRECT", "CMP_BITSLICE", "BITSLICE_OPS_PER_GROUP_EXTRA", "TIME_K1", "TIME_K2", "TIME_K2PREP", "TIME_K3",
+    "CMP_AUTO", "CMP_DIRECT", "CMP_BITSLICE", "BITSLICE_OPS_PER_GROUP_EXTRA", "TIME_K1", "TIME_K2", "TIME_K2PREP", "TIME_K3", "TIME_K0", "PinnedArray",
     "wang_hash", "seed_mask", "oph_xor_const", "oph_m", "oph_finalize", "densify", "epilogue_lut",
     "epilogue_gtlt", "epilogue_neq", "host_epilogue_ut", "operand_layout", "ut_count", "ut_partition",
 ]

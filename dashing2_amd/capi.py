@@ -17,7 +17,7 @@ CMP_AUTO, CMP_DIRECT, CMP_BITSLICE = 0, 1, 2
 BITSLICE_OPS_PER_GROUP_EXTRA = 1
 
 
-TIME_K1, TIME_K2, TIME_K2PREP, TIME_K3 = 2, 4, 8, 16          # include/d2g.h D2G_TIME_*
+TIME_K1, TIME_K2, TIME_K2PREP, TIME_K3, TIME_K0 = 2, 4, 8, 16, 32          # include/d2g.h D2G_TIME_*
 
 
 class D2GError(RuntimeError):
@@ -51,6 +51,8 @@ SIGNATURES = {
     "d2g_malloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "d2g_free": (_int, [_vp, _vp]),
     "d2g_malloc_host": (_int, [_vp, _sz, C.POINTER(_vp)]),
+    "d2g_host_register": (_int, [_vp, _vp, _sz]),
+    "d2g_host_unregister": (_int, [_vp, _vp]),
     "d2g_free_host": (_int, [_vp, _vp]),
     "d2g_memcpy_h2d": (_int, [_vp, _vp, _vp, _sz, _vp]),
     "d2g_memcpy_d2h": (_int, [_vp, _vp, _vp, _sz, _vp]),
@@ -98,6 +100,8 @@ SIGNATURES = {
     "d2g_kmer_count": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, C.c_double, _vp, _vp, _sz, _vp]),
     "d2g_kmer_distinct": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _vp]),
     "d2g_sketcher_run_distinct": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int, _int, _u64, _vp]),
+    "d2g_sketcher_ingest_fasta": (_int, [_vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int]),
+    "d2g_sketcher_ingested_runs": (_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u64)]),
     "d2g_seqpack_add_path_by_record": (_int, [_vp, C.c_char_p]),
     "d2g_seqpack_add_fastx_by_record": (_int, [_vp, C.c_char_p, _sz]),
     "d2g_seqpack_name": (C.c_char_p, [_vp, _sz]),
@@ -573,10 +577,88 @@ class Sketcher:
                                                    _np_ptr(sig), _np_ptr(tw)))
         return sig, tw
 
+    # -- K0: FASTA bytes -> packed run stream on the GPU ------------------------------------------
+    def ingest_fasta(self, buffers, k, genome_nfiles=None, pinned=None):
+        """buffers: list of bytes-like FASTA inputs; genome_nfiles: files per genome (default one each).  The bytes are laid out
+        16-byte aligned in ONE host buffer (`pinned`: a PinnedArray to reuse, else a plain numpy array) and parsed on the
+        device.  Raises D2GError(D2G_ERR_UNSUPPORTED) for inputs only the host parser handles.
+        -> (run_start u64, run_len u32, genome_run_off u64, genome_nkmers u64, nbases)"""
+        nf = len(buffers)
+        lens = np.array([len(b) for b in buffers], np.uint64)
+        offs = np.zeros(nf, np.uint64)
+        pos = 0
+        for i in range(nf):
+            offs[i] = pos
+            pos += (int(lens[i]) + 15) // 16 * 16
+        total = max(pos, 16)
+        raw = pinned.array[:total] if pinned is not None else np.empty(total, np.uint8)
+        for i, b in enumerate(buffers):
+            raw[int(offs[i]):int(offs[i]) + int(lens[i])] = np.frombuffer(b, np.uint8)
+        gn = np.ones(nf, np.uint64) if genome_nfiles is None else np.asarray(genome_nfiles, np.uint64)
+        gfo = np.concatenate([[0], np.cumsum(gn)]).astype(np.uint64)
+        n = gfo.size - 1
+        self.ingest_raw(raw, pos, offs, lens, gfo, k)
+        return self.ingested_runs(n)
+
+    def ingest_raw(self, raw, raw_bytes, file_off, file_len, genome_file_off, k):
+        file_off = np.ascontiguousarray(file_off, np.uint64)
+        file_len = np.ascontiguousarray(file_len, np.uint64)
+        genome_file_off = np.ascontiguousarray(genome_file_off, np.uint64)
+        self.k = k
+        self.ctx._check(lib().d2g_sketcher_ingest_fasta(self._h, _np_ptr(raw), raw_bytes, _np_ptr(file_off), _np_ptr(file_len), file_off.size,
+                                                        _np_ptr(genome_file_off), genome_file_off.size - 1, k))
+
+    def ingested_runs(self, n):
+        rs, rl, go, nk = _vp(), _vp(), _vp(), _vp()
+        nrun, nb = _sz(), _u64()
+        self.ctx._check(lib().d2g_sketcher_ingested_runs(self._h, C.byref(rs), C.byref(rl), C.byref(nrun), C.byref(go), C.byref(nk), C.byref(nb)))
+        nr = nrun.value
+
+        def arr(p, cnt, dt):
+            if not cnt:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cnt * np.dtype(dt).itemsize,)).view(dt).copy()
+        return arr(rs, nr, np.uint64), arr(rl, nr, np.uint32), arr(go, n + 1, np.uint64), arr(nk, n, np.uint64), int(nb.value)
+
+    def run_ingested(self, runs, S, canon=True, xormask=0):
+        """K1 over the stream ingested last (packed == NULL): -> regs u64 [n][m]"""
+        rs, rl, go = runs[0], runs[1], runs[2]
+        n = go.size - 1
+        regs = np.empty((n, oph_m(S)), np.uint64)
+        self.ctx._check(lib().d2g_sketcher_run(self._h, None, 0, _np_ptr(rs), _np_ptr(rl), rs.size, _np_ptr(go), n, self.k, int(canon),
+                                               xormask, S, _np_ptr(regs)))
+        return regs
+
+    def run_bmh_ingested(self, runs, S, canon=True, xormask=0, count_threshold=0.0):
+        rs, rl, go = runs[0], runs[1], runs[2]
+        n = go.size - 1
+        sig = np.empty((n, S), np.float64)
+        tw = np.empty(n, np.float64)
+        self.ctx._check(lib().d2g_sketcher_run_bmh(self._h, None, 0, _np_ptr(rs), _np_ptr(rl), rs.size, _np_ptr(go), n, self.k, int(canon),
+                                                   xormask, S, count_threshold, _np_ptr(sig), _np_ptr(tw)))
+        return sig, tw
+
     def close(self):
         if getattr(self, "_h", None):
             lib().d2g_sketcher_destroy(self._h)
             self._h = None
+
+    __del__ = close
+
+
+class PinnedArray:
+    """page-locked host bytes (d2g_malloc_host) as a numpy uint8 array: uploads from it are one DMA"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self._p = ctx, _vp()
+        ctx._check(lib().d2g_malloc_host(ctx._h, nbytes, C.byref(self._p)))
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            lib().d2g_free_host(self.ctx._h, self._p)
+            self._p = None
 
     __del__ = close
 

@@ -16,7 +16,7 @@ struct d2g_ctx {
     int num_cus = 0;
     std::string last_error;
     int timing = 0;                         // D2G_TIME_* mask (d2g_set_timing)
-    d2g_evlog ev_k1, ev_k2, ev_k2prep, ev_k3;
+    d2g_evlog ev_k1, ev_k2, ev_k2prep, ev_k3, ev_k0;
     struct d2g_k3_state *k3 = nullptr;      // work buffers of d2g_bmh_sketch_dev (d2g_k3_bmh.hip)
 };
 void d2g_k3_state_destroy(struct d2g_k3_state *st);
@@ -43,7 +43,7 @@ void d2g_k3_state_destroy(struct d2g_k3_state *st);
 struct d2g_timer {
     d2g_evlog *ev; hipStream_t s; bool on;
     d2g_timer(d2g_ctx *c, d2g_evlog *e, hipStream_t st) : ev(e), s(st), on(false) {
-        const int bit = e == &c->ev_k1 ? D2G_TIME_K1 : e == &c->ev_k2 ? D2G_TIME_K2 : e == &c->ev_k2prep ? D2G_TIME_K2PREP : D2G_TIME_K3;
+        const int bit = e == &c->ev_k1 ? D2G_TIME_K1 : e == &c->ev_k2 ? D2G_TIME_K2 : e == &c->ev_k2prep ? D2G_TIME_K2PREP : e == &c->ev_k0 ? D2G_TIME_K0 : D2G_TIME_K3;
         on = (c->timing & bit) != 0;
         if (on) {
             hipEvent_t x = nullptr, y = nullptr;

@@ -54,6 +54,7 @@ template <class T> inline int d2g_grow(d2g_ctx *ctx, T **p, size_t *cap, size_t 
 // small tables per group costs ~20 ms, the kernel ~0.1 ms.  The sketcher keeps grow-only device
 // buffers and ships all launch tables in ONE copy from a pinned arena.
 struct d2g_k3_state;
+struct d2g_k0_state;
 struct d2g_sketcher {
     d2g_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;
@@ -62,11 +63,16 @@ struct d2g_sketcher {
     uint8_t *d_arena = nullptr, *h_arena = nullptr; size_t cap_arena = 0;
     uint8_t *h_stage = nullptr; size_t cap_stage = 0;      // pinned staging of the packed stream
     d2g_k3_state *k3 = nullptr;                            // --multiset work buffers (d2g_k3_bmh.hip)
+    d2g_k0_state *k0 = nullptr;                            // device FASTA ingest (d2g_k0.hip): raw bytes, tile tables, the last run table
 };
+void d2g_k0_state_destroy(d2g_k0_state *st);
+bool d2g_k0_ingested(const d2g_sketcher *sk, uint64_t *nbases);   // d_packed holds a stream ingested by K0 (and how many bases)
+void d2g_k0_invalidate(d2g_sketcher *sk);
 
 
 // validate + upload one batch (launch tables in one pinned-arena copy, packed stream through the
-// pinned stage) on sk->stream; fills `out` with device pointers, `nblk` with the grid size
+// pinned stage) on sk->stream; fills `out` with device pointers, `nblk` with the grid size.
+// packed == nullptr: the stream d2g_sketcher_ingest_fasta left in the device buffer is used as it is.
 int d2g_sketcher_stage(d2g_sketcher *sk, const uint8_t *packed, size_t packed_bytes, const uint64_t *run_start,
                        const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
                        KmerArgs *out, size_t *nblk, PlanHost *ph_out);

@@ -236,6 +236,7 @@ void d2g_sketcher_destroy(d2g_sketcher *sk) {
     if (sk->h_arena) (void)hipHostFree(sk->h_arena);
     if (sk->h_stage) (void)hipHostFree(sk->h_stage);
     if (sk->k3) d2g_k3_state_destroy(sk->k3);
+    if (sk->k0) d2g_k0_state_destroy(sk->k0);
     if (sk->stream) (void)hipStreamDestroy(sk->stream);
     delete sk;
 }
@@ -284,7 +285,11 @@ int d2g_sketcher_stage(d2g_sketcher *sk, const uint8_t *packed, size_t packed_by
                        const uint32_t *run_len, size_t nrun, const uint64_t *genome_run_off, size_t n, int k, int canon,
                        KmerArgs *out, size_t *nblk_out, PlanHost *ph_out) {
     d2g_ctx *ctx = sk->ctx;
-    D2G_CHECK(ctx, nrun == 0 || (run_start && packed), "null input");
+    uint64_t ingested_bases = 0;
+    const bool use_ingested = packed == nullptr && d2g_k0_ingested(sk, &ingested_bases);
+    D2G_CHECK(ctx, nrun == 0 || (run_start && (packed || use_ingested)), "null input");
+    if (use_ingested) packed_bytes = (size_t)((ingested_bases + 3) / 4 + 64);        // the device stream's extent (zero-padded by the ingest)
+    else d2g_k0_invalidate(sk);                                                       // the device buffer is about to be overwritten
     PlanHost ph_local;
     PlanHost &ph = ph_out ? *ph_out : ph_local;
     if (int rc = d2g_build_plan_host(ctx, run_len, nrun, genome_run_off, n, k, ph)) return rc;
@@ -295,7 +300,8 @@ int d2g_sketcher_stage(d2g_sketcher *sk, const uint8_t *packed, size_t packed_by
     }
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nblk = ph.bg.size();
-    if (int rc = d2g_grow(ctx, &sk->d_packed, &sk->cap_packed, std::max<size_t>(packed_bytes, 4))) return rc;
+    if (!use_ingested)
+        if (int rc = d2g_grow(ctx, &sk->d_packed, &sk->cap_packed, std::max<size_t>(packed_bytes, 4))) return rc;
     // arena layout (256-byte aligned pieces)
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     size_t off = 0;
@@ -326,7 +332,7 @@ int d2g_sketcher_stage(d2g_sketcher *sk, const uint8_t *packed, size_t packed_by
     }
     hipStream_t s = sk->stream;
     D2G_HIP(ctx, hipMemcpyAsync(sk->d_arena, h, off, hipMemcpyHostToDevice, s));
-    if (packed_bytes) {
+    if (packed_bytes && !use_ingested) {
         // pageable source: stage through our own pinned buffer (the runtime would otherwise pin the
         // caller's pages on the fly, which contends with parser threads on the process' mm locks)
         if (packed_bytes > sk->cap_stage) {

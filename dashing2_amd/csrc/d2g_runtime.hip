@@ -33,7 +33,7 @@ int d2g_ctx_create(int device, d2g_ctx **out) {
 void d2g_ctx_destroy(d2g_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (d2g_evlog *e : {&c->ev_k1, &c->ev_k2, &c->ev_k2prep, &c->ev_k3}) {
+    for (d2g_evlog *e : {&c->ev_k1, &c->ev_k2, &c->ev_k2prep, &c->ev_k3, &c->ev_k0}) {
         for (hipEvent_t x : e->a) (void)hipEventDestroy(x);
         for (hipEvent_t x : e->b) (void)hipEventDestroy(x);
     }
@@ -70,6 +70,18 @@ int d2g_malloc_host(d2g_ctx *c, size_t nbytes, void **hptr) {
     D2G_HIP(c, hipHostMalloc(hptr, nbytes ? nbytes : 1, hipHostMallocDefault));
     return D2G_OK;
 }
+// page-lock memory the caller already owns (e.g. staging buffers that were being filled before the context existed)
+int d2g_host_register(d2g_ctx *c, void *hptr, size_t nbytes) {
+    if (!c || !hptr || !nbytes) return D2G_ERR_INVALID;
+    D2G_HIP(c, hipSetDevice(c->device));
+    D2G_HIP(c, hipHostRegister(hptr, nbytes, hipHostRegisterDefault));
+    return D2G_OK;
+}
+int d2g_host_unregister(d2g_ctx *c, void *hptr) {
+    if (!c || !hptr) return D2G_ERR_INVALID;
+    D2G_HIP(c, hipHostUnregister(hptr));
+    return D2G_OK;
+}
 int d2g_free_host(d2g_ctx *c, void *hptr) {
     if (!c) return D2G_ERR_INVALID;
     if (!hptr) return D2G_OK;
@@ -104,6 +116,7 @@ int d2g_kernel_ms(d2g_ctx *c, const char *which, int reset, int *count, float *a
     else if (!std::strcmp(which, "k2")) e = &c->ev_k2;
     else if (!std::strcmp(which, "k2prep")) e = &c->ev_k2prep;
     else if (!std::strcmp(which, "k3")) e = &c->ev_k3;
+    else if (!std::strcmp(which, "k0")) e = &c->ev_k0;
     D2G_CHECK(c, e != nullptr, "d2g_kernel_ms: unknown kernel name");
     D2G_HIP(c, hipSetDevice(c->device));
     double sum = 0;

@@ -169,10 +169,14 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
             continue;                                                   // fastxsketch.cpp:327-373
         todo.push_back(i);
     }
-    // groups of files bounded by input bytes: parsed in parallel on the host, sketched one group per launch
+    // groups of inputs bounded by input bytes: read in parallel on the host, sketched one group per launch
+    struct FileRef { std::string path; size_t size; };
+    std::vector<std::vector<FileRef>> files_of(todo.size());            // the space-separated paths of every input line
     std::vector<std::pair<size_t, size_t>> groups;                      // [begin,end) into todo
+    std::vector<size_t> group_bytes;
+    size_t limit = size_t(48) << 20;
+    if (const char *e = std::getenv("D2G_GROUP_BYTES")) { const long long v = std::atoll(e); if (v >= 1) limit = size_t(v); }   // tests: many small groups
     {
-        const size_t limit = size_t(48) << 20;
         size_t b = 0, acc = 0;
         for (size_t t = 0; t < todo.size(); ++t) {
             size_t fs = 0;
@@ -180,107 +184,246 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
             for (size_t s = 0; s <= line.size();) {
                 size_t e = line.find(' ', s);
                 if (e == std::string::npos) e = line.size();
-                if (e > s) fs += filesize(line.substr(s, e - s));
+                if (e > s) { const std::string p = line.substr(s, e - s); const size_t z = filesize(p); files_of[t].push_back({p, z}); fs += (z + 15) / 16 * 16; }
                 s = e + 1;
             }
-            if (acc && acc + fs > limit) { groups.emplace_back(b, t); b = t; acc = 0; }
+            if (acc && acc + fs > limit) { groups.emplace_back(b, t); group_bytes.push_back(acc); b = t; acc = 0; }
             acc += fs;
         }
-        if (b < todo.size()) groups.emplace_back(b, todo.size());
+        if (b < todo.size()) { groups.emplace_back(b, todo.size()); group_bytes.push_back(acc); }
     }
     const double t_setup = now();
-    // Host ingest pipeline: parser threads turn groups of files into packed run streams
-    // (d2g_seqpack); ONE device thread (this one) owns the GPU context and feeds K1 through a persistent
-    // d2g_sketcher, finalises (x87) and writes caches.  A bounded queue keeps memory in check.
+    // Host ingest pipeline.  Reader threads read() whole groups of FASTA files into page-locked staging
+    // buffers; ONE device thread (this one) owns the GPU context: it uploads a group's raw bytes, K0 parses and 2-bit-packs them
+    // on the device (d2g_sketcher_ingest_fasta), K1 / K3 sketch the stream, the registers are finalised (x87) and cached.
+    // Inputs the device parser refuses (gz members, FASTQ, leading junk: first byte is not '>') are parsed by the host parser
+    // (d2g_seqpack) on the reader thread instead, group by group -- the round-2 path.  D2G_HOST_PARSE=1 forces it for all.
+    // The staging buffers are plain memory the readers fill at once; they are page-locked (d2g_host_register) as soon as the
+    // GPU context exists, so neither the context creation nor the pinning delays the reading.
     double t_parse = 0, t_gpu = 0, t_fin = 0;
     uint64_t total_bases = 0;
+    size_t n_dev_groups = 0, n_host_groups = 0;
     d2g_sketcher *sk = nullptr;
-    struct Ready { size_t g; d2g_seqpack *sp; double tparse; };
+    struct Ready { size_t g; d2g_seqpack *sp; int buf; std::vector<uint64_t> foff, flen, gfo; size_t raw_bytes; double tparse; };
     std::deque<Ready> ready;
     std::vector<d2g_seqpack *> pool;                                    // recycled packers (allocations kept)
     std::mutex mu;
-    std::condition_variable cv_ready, cv_space;
+    std::condition_variable cv_ready, cv_space, cv_buf;
     std::atomic<size_t> next_group{0};
     std::string parse_error;
+    const bool force_host = std::getenv("D2G_HOST_PARSE") != nullptr;
     const size_t nparsers = std::max<size_t>(1, std::min<size_t>({size_t(o.workers()), groups.size(), size_t(192)}));
     const size_t max_ready = 2 * nparsers + 2;
+    size_t max_group = 16;
+    for (size_t gb : group_bytes) max_group = std::max(max_group, gb);
+    const size_t buf_bytes = (max_group + 4095) / 4096 * 4096 + 4096;
+    const size_t nbufs = force_host ? 0 : std::min<size_t>(groups.size(), std::max<size_t>(3, std::min<size_t>(nparsers + 2, (size_t(1) << 30) / buf_bytes)));
+    std::vector<uint8_t *> bufs(nbufs, nullptr);
+    std::deque<int> free_bufs;
+    for (size_t i = 0; i < nbufs; ++i) {
+        void *p = nullptr;
+        if (posix_memalign(&p, 4096, buf_bytes) != 0) die("out of memory (ingest staging)");
+        bufs[i] = static_cast<uint8_t *>(p);
+        free_bufs.push_back(int(i));
+    }
     std::vector<std::thread> parsers;
     for (size_t t = 0; t < nparsers; ++t) parsers.emplace_back([&]() {
         for (;;) {
             const size_t g = next_group.fetch_add(1);
             if (g >= groups.size()) break;
-            d2g_seqpack *sp = nullptr;
             const double t0 = now();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (!pool.empty()) { sp = pool.back(); pool.pop_back(); }
-            }
-            int rc = sp ? int(D2G_OK) : d2g_seqpack_create(o.k, &sp);
+            Ready r{g, nullptr, -1, {}, {}, {}, 0, 0.0};
+            // eligible for the device parser: every file of the group is a plain file whose first byte is '>'
+            bool dev = !force_host && nbufs > 0;
+            for (size_t x = groups[g].first; dev && x < groups[g].second; ++x)
+                for (const FileRef &fr : files_of[x]) {
+                    if (!isfile(fr.path)) { dev = false; break; }         // missing / not a regular file (FIFO, ...): the host path reports or reads it
+                    if (fr.size == 0) continue;
+                    char c0 = 0;
+                    std::FILE *fp = std::fopen(fr.path.c_str(), "rb");
+                    if (!fp || std::fread(&c0, 1, 1, fp) != 1 || c0 != '>') dev = false;
+                    if (fp) std::fclose(fp);
+                }
             std::string bad;
-            for (size_t x = groups[g].first; rc == D2G_OK && x < groups[g].second; ++x) {
-                rc = d2g_seqpack_add_path(sp, o.paths[todo[x]].c_str());
-                if (rc) bad = o.paths[todo[x]];
+            int rc = D2G_OK;
+            if (dev) {
+                // a staging buffer that is free RIGHT NOW, else this thread packs the group itself: while the GPU context is still
+                // being created (or the device threads are behind) the host cores keep producing sketchable groups instead of waiting
+                std::lock_guard<std::mutex> lk(mu);
+                if (!free_bufs.empty()) { r.buf = free_bufs.front(); free_bufs.pop_front(); } else dev = false;
             }
-            if (rc == D2G_OK) (void)d2g_seqpack_packed_bytes(sp);            // pad now, off the device thread
+            if (dev) {
+                uint8_t *dst = bufs[r.buf];
+                size_t pos = 0;
+                r.gfo.push_back(0);
+                for (size_t x = groups[g].first; rc == D2G_OK && x < groups[g].second; ++x) {
+                    for (const FileRef &fr : files_of[x]) {
+                        r.foff.push_back(pos); r.flen.push_back(fr.size);
+                        if (fr.size) {
+                            std::FILE *fp = std::fopen(fr.path.c_str(), "rb");
+                            // a file that changed size since the stat goes to the host parser's error handling
+                            if (!fp || pos + fr.size > buf_bytes || std::fread(dst + pos, 1, fr.size, fp) != fr.size) { rc = D2G_ERR_IO; bad = fr.path; }
+                            if (fp) std::fclose(fp);
+                        }
+                        pos += (fr.size + 15) / 16 * 16;
+                    }
+                    r.gfo.push_back(r.foff.size());
+                }
+                r.raw_bytes = pos;
+            } else {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (!pool.empty()) { r.sp = pool.back(); pool.pop_back(); }
+                }
+                rc = r.sp ? int(D2G_OK) : d2g_seqpack_create(o.k, &r.sp);
+                for (size_t x = groups[g].first; rc == D2G_OK && x < groups[g].second; ++x) {
+                    rc = d2g_seqpack_add_path(r.sp, o.paths[todo[x]].c_str());
+                    if (rc) bad = o.paths[todo[x]];
+                }
+                if (rc == D2G_OK) (void)d2g_seqpack_packed_bytes(r.sp);          // pad now, off the device thread
+            }
             std::unique_lock<std::mutex> lk(mu);
-            if (rc) { if (parse_error.empty()) parse_error = "Failed to open " + bad; d2g_seqpack_destroy(sp); sp = nullptr; }
+            if (rc) {
+                if (parse_error.empty()) parse_error = "Failed to open " + bad;
+                if (r.sp) d2g_seqpack_destroy(r.sp);
+                r.sp = nullptr;
+                if (r.buf >= 0) { free_bufs.push_back(r.buf); r.buf = -1; cv_buf.notify_one(); }
+            }
             cv_space.wait(lk, [&] { return ready.size() < max_ready; });
-            ready.push_back({g, sp, now() - t0});
+            r.tparse = now() - t0;
+            ready.push_back(std::move(r));
             cv_ready.notify_one();
         }
     });
-    ctx = lctx.get();                                                    // the parsers are busy: now wait for the GPU context
-    check(ctx, d2g_sketcher_create(ctx, &sk), "d2g_sketcher_create");
-    std::vector<uint64_t> regs;
-    std::vector<double> sigs, cards;
-    for (size_t done = 0; done < groups.size(); ++done) {
-        Ready r;
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv_ready.wait(lk, [&] { return !ready.empty(); });
-            r = ready.front();
-            ready.pop_front();
-            cv_space.notify_one();
-        }
-        if (!r.sp) continue;                                                // error recorded; drain the queue
-        const size_t b = groups[r.g].first, e = groups[r.g].second, n = e - b;
-        const double t1 = now();
-        sigs.resize(n * S); cards.resize(n);
-        double t2;
-        if (o.sspace == SPACE_MULTISET) {
-            // fastxsketch.cpp:425-445: Counter -> BagMinHash; cardinality = total weight, signature = data()[0..S)
-            const int rc = d2g_sketcher_run_bmh(sk, d2g_seqpack_packed(r.sp), d2g_seqpack_packed_bytes(r.sp), d2g_seqpack_run_start(r.sp),
-                                                d2g_seqpack_run_len(r.sp), d2g_seqpack_nruns(r.sp), d2g_seqpack_genome_run_off(r.sp), n,
-                                                o.k, o.canon, xormask, S, double(o.count_threshold), sigs.data(), cards.data());
-            check(ctx, rc, "d2g_sketcher_run_bmh");
-            t2 = now();
-        } else {
-            regs.resize(n * m);
-            const int rc = d2g_sketcher_run(sk, d2g_seqpack_packed(r.sp), d2g_seqpack_packed_bytes(r.sp), d2g_seqpack_run_start(r.sp),
-                                            d2g_seqpack_run_len(r.sp), d2g_seqpack_nruns(r.sp), d2g_seqpack_genome_run_off(r.sp), n, o.k,
-                                            o.canon, xormask, S, regs.data());
-            check(ctx, rc, "d2g_sketcher_run");
-            t2 = now();
-            check(ctx, d2g_oph_finalize(regs.data(), n, m, S, sigs.data(), cards.data(), 1), "d2g_oph_finalize");
-        }
+    ctx = lctx.get();                                                    // the readers are busy: now wait for the GPU context
+    double t_pin = now();
+    for (size_t i = 0; i < nbufs; ++i) check(ctx, d2g_host_register(ctx, bufs[i], buf_bytes), "d2g_host_register");
+    t_pin = now() - t_pin;
+    // x87 finalisation (getcard / data, src/oph.h:240-263) and cache files leave the device threads through a small queue
+    struct Fin { size_t g; std::vector<uint64_t> regs; std::vector<double> sigs, cards; };
+    std::deque<Fin> finq;
+    std::mutex fmu;
+    std::condition_variable fcv;
+    bool fin_closing = false;
+    auto store_group = [&](size_t g, const double *sg, const double *cd) {
+        const size_t b = groups[g].first, e = groups[g].second;
         for (size_t t = b; t < e; ++t) {
             const size_t i = todo[t];
-            std::memcpy(&res.signatures[i * S], &sigs[(t - b) * S], S * sizeof(double));   // fastxsketch.cpp:610
-            res.cardinalities[i] = cards[t - b];
-            if (o.cache) write_cached(res.destination_files[i], &sigs[(t - b) * S], cards[t - b], S);
+            std::memcpy(&res.signatures[i * S], &sg[(t - b) * S], S * sizeof(double));   // fastxsketch.cpp:610
+            res.cardinalities[i] = cd[t - b];
+            if (o.cache) write_cached(res.destination_files[i], &sg[(t - b) * S], cd[t - b], S);
         }
-        t_parse += r.tparse; t_gpu += t2 - t1; t_fin += now() - t2; total_bases += d2g_seqpack_nbases(r.sp);
-        d2g_seqpack_clear(r.sp);
-        { std::lock_guard<std::mutex> lk(mu); pool.push_back(r.sp); }
+    };
+    std::thread finisher([&] {
+        for (;;) {
+            Fin f;
+            {
+                std::unique_lock<std::mutex> lk(fmu);
+                fcv.wait(lk, [&] { return fin_closing || !finq.empty(); });
+                if (finq.empty()) return;
+                f = std::move(finq.front()); finq.pop_front();
+            }
+            const double t0 = now();
+            const size_t n = groups[f.g].second - groups[f.g].first;
+            if (!f.regs.empty()) {
+                f.sigs.resize(n * S); f.cards.resize(n);
+                check(nullptr, d2g_oph_finalize(f.regs.data(), n, m, S, f.sigs.data(), f.cards.data(), 2), "d2g_oph_finalize");
+            }
+            store_group(f.g, f.sigs.data(), f.cards.data());
+            t_fin += now() - t0;                                            // (only this thread writes it)
+        }
+    });
+    // Two device threads, each with its own context + sketcher (a d2g_ctx is used by one thread at a time): the upload of one
+    // group overlaps the kernels and the synchronisations of the other
+    const int ndev = groups.size() > 1 ? 2 : 1;
+    std::atomic<size_t> taken{0};
+    std::mutex smu;
+    auto device_loop = [&](d2g_ctx *dctx) {
+        d2g_sketcher *dsk = nullptr;
+        check(dctx, d2g_sketcher_create(dctx, &dsk), "d2g_sketcher_create");
+        double gpu = 0; uint64_t bases = 0; size_t ndevg = 0, nhostg = 0; double tp = 0;
+        for (;;) {
+            if (taken.fetch_add(1) >= groups.size()) break;
+            Ready r;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_ready.wait(lk, [&] { return !ready.empty(); });
+                r = std::move(ready.front());
+                ready.pop_front();
+                cv_space.notify_one();
+            }
+            if (!r.sp && r.buf < 0) continue;                               // error recorded; drain the queue
+            const size_t b = groups[r.g].first, e = groups[r.g].second, n = e - b;
+            const double t1 = now();
+            Fin f{r.g, {}, {}, {}};
+            // the packed run stream of the group: parsed on the device (packed == NULL below), or by the host parser
+            const uint8_t *packed = nullptr; size_t packed_bytes = 0, nrun = 0;
+            const uint64_t *run_start = nullptr, *goff = nullptr; const uint32_t *run_len = nullptr;
+            uint64_t nb = 0;
+            if (r.buf >= 0) {
+                const int rc = d2g_sketcher_ingest_fasta(dsk, bufs[r.buf], r.raw_bytes, r.foff.data(), r.flen.data(), r.foff.size(), r.gfo.data(), n, o.k);
+                if (rc == D2G_OK) check(dctx, d2g_sketcher_ingested_runs(dsk, &run_start, &run_len, &nrun, &goff, nullptr, &nb), "d2g_sketcher_ingested_runs");
+                { std::lock_guard<std::mutex> lk(mu); free_bufs.push_back(r.buf); }
+                if (rc == D2G_ERR_UNSUPPORTED) {                            // e.g. a '+' line further down: the host parser takes the group
+                    check(dctx, d2g_seqpack_create(o.k, &r.sp), "d2g_seqpack_create");
+                    for (size_t x = b; x < e; ++x)
+                        if (d2g_seqpack_add_path(r.sp, o.paths[todo[x]].c_str()) != D2G_OK) die("Failed to open " + o.paths[todo[x]]);
+                } else check(dctx, rc, "d2g_sketcher_ingest_fasta");
+                if (rc == D2G_OK) ++ndevg;
+            }
+            if (r.sp) {
+                packed = d2g_seqpack_packed(r.sp); packed_bytes = d2g_seqpack_packed_bytes(r.sp);
+                run_start = d2g_seqpack_run_start(r.sp); run_len = d2g_seqpack_run_len(r.sp); nrun = d2g_seqpack_nruns(r.sp);
+                goff = d2g_seqpack_genome_run_off(r.sp); nb = d2g_seqpack_nbases(r.sp);
+                ++nhostg;
+            }
+            if (o.sspace == SPACE_MULTISET) {
+                // fastxsketch.cpp:425-445: Counter -> BagMinHash; cardinality = total weight, signature = data()[0..S)
+                f.sigs.resize(n * S); f.cards.resize(n);
+                check(dctx, d2g_sketcher_run_bmh(dsk, packed, packed_bytes, run_start, run_len, nrun, goff, n, o.k, o.canon, xormask, S,
+                                                 double(o.count_threshold), f.sigs.data(), f.cards.data()), "d2g_sketcher_run_bmh");
+            } else {
+                f.regs.resize(n * m);
+                check(dctx, d2g_sketcher_run(dsk, packed, packed_bytes, run_start, run_len, nrun, goff, n, o.k, o.canon, xormask, S, f.regs.data()),
+                      "d2g_sketcher_run");
+            }
+            gpu += now() - t1; bases += nb; tp += r.tparse;
+            { std::lock_guard<std::mutex> lk(fmu); finq.push_back(std::move(f)); }
+            fcv.notify_one();
+            if (r.sp) {
+                d2g_seqpack_clear(r.sp);
+                std::lock_guard<std::mutex> lk(mu);
+                pool.push_back(r.sp);
+            }
+        }
+        d2g_sketcher_destroy(dsk);
+        std::lock_guard<std::mutex> lk(smu);
+        t_gpu += gpu; total_bases += bases; n_dev_groups += ndevg; n_host_groups += nhostg; t_parse += tp;
+    };
+    std::thread second;
+    d2g_ctx *ctx2 = nullptr;
+    if (ndev > 1) {
+        const int rc2 = d2g_ctx_create(o.device, &ctx2);
+        if (rc2 != D2G_OK) die(std::string("d2g_ctx_create (second device thread): ") + d2g_strerror(rc2));
+        second = std::thread(device_loop, ctx2);
     }
+    device_loop(ctx);
+    if (second.joinable()) second.join();
+    { std::lock_guard<std::mutex> lk(fmu); fin_closing = true; }
+    fcv.notify_all();
+    finisher.join();
+    if (ctx2) d2g_ctx_destroy(ctx2);
+    (void)sk;
     for (auto &th : parsers) th.join();
     for (d2g_seqpack *p : pool) d2g_seqpack_destroy(p);
-    d2g_sketcher_destroy(sk);
+    for (size_t i = 0; i < nbufs; ++i) { (void)d2g_host_unregister(ctx, bufs[i]); std::free(bufs[i]); }
     const double t_pipe = now();
     if (!parse_error.empty()) die(parse_error);
-    if (o.verbosity) std::fprintf(stderr, "[d2g] sketched %zu inputs (%" PRIu64 " ACGT bases) in %zu groups: host parse %.3fs over %zu threads, "
-                                          "device thread: H2D+K1+D2H %.3fs, x87 finalise+cache %.3fs\n",
-                                  todo.size(), total_bases, groups.size(), t_parse, nparsers, t_gpu, t_fin);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] sketched %zu inputs (%" PRIu64 " bases in the packed streams) in %zu groups (%zu parsed on the device, %zu by the host "
+                                          "parser): host read/parse %.3fs over %zu threads, 2 device threads: H2D+K0+K1+D2H %.3fs busy, finisher thread: x87 finalise+cache %.3fs; "
+                                          "%zu staging buffers of %zu MiB page-locked in %.3fs\n",
+                                  todo.size(), total_bases, groups.size(), n_dev_groups, n_host_groups, t_parse, nparsers, t_gpu, t_fin,
+                                  nbufs, buf_bytes >> 20, t_pin);
     if (o.verbosity) std::fprintf(stderr, "[d2g] sketch wall: setup (stat, cache probe) %.3fs, ingest pipeline %.3fs\n", t_setup - t_enter, t_pipe - t_setup);
     write_stacked(res, o);
 }

@@ -71,10 +71,14 @@ int         d2g_free(d2g_ctx *ctx, void *dptr);
 /* page-locked host memory: D2H/H2D at PCIe rate, no per-batch page faults */
 int         d2g_malloc_host(d2g_ctx *ctx, size_t nbytes, void **hptr);
 int         d2g_free_host(d2g_ctx *ctx, void *hptr);
+/* page-lock / release memory the caller owns (an ingest pipeline can start filling its staging buffers before the context
+ * exists and register them once it does) */
+int         d2g_host_register(d2g_ctx *ctx, void *hptr, size_t nbytes);
+int         d2g_host_unregister(d2g_ctx *ctx, void *hptr);
 int         d2g_memcpy_h2d(d2g_ctx *ctx, void *dst_dev, const void *src_host, size_t nbytes, void *stream);
 int         d2g_memcpy_d2h(d2g_ctx *ctx, void *dst_host, const void *src_dev, size_t nbytes, void *stream);
 /* Per-launch HIP-event timing of the dominant kernels.  With timing enabled every launch of
- * the K1 kernel ("k1"), the K2 pair kernel ("k2") and the K2 prepare chain ("k2prep") is
+ * the K1 kernel ("k1"), the K0 ingest chain ("k0"), the K3 chain ("k3"), the K2 pair kernel ("k2") and the K2 prepare chain ("k2prep") is
  * bracketed by events recorded on the launch stream; nothing synchronises until d2g_kernel_ms,
  * which reports the number of logged launches, their average and the last duration (ms) and
  * optionally clears the log. */
@@ -82,6 +86,7 @@ int         d2g_memcpy_d2h(d2g_ctx *ctx, void *dst_host, const void *src_dev, si
 #define D2G_TIME_K2     4
 #define D2G_TIME_K2PREP 8
 #define D2G_TIME_K3     16
+#define D2G_TIME_K0     32
 /* enabled: 0 = off, 1 = every kernel above, or an OR of D2G_TIME_* (an event pair in the stream costs a few microseconds of
  * device time per launch: time only what is being reported) */
 int         d2g_set_timing(d2g_ctx *ctx, int enabled);
@@ -192,6 +197,23 @@ int  d2g_sketcher_run(d2g_sketcher *sk, const uint8_t *packed, size_t packed_byt
                       const uint64_t *run_start, const uint32_t *run_len, size_t nrun,
                       const uint64_t *genome_run_off, size_t n, int k, int canon, uint64_t xormask,
                       size_t sketchsize, uint64_t *regs_out /* host [n][m] */);
+
+/* ---- K0: FASTA bytes -> packed run stream on the GPU (host ingest pipelines) ------
+ * Replaces, for plain FASTA inputs, the host parser + 2-bit packer (d2g_seqpack_*; reference call sites
+ * src/fastxsketch.cpp:383-424, src/d2.h:273-305): the caller read()s the files into ONE host buffer (page-locked memory from
+ * d2g_malloc_host makes the upload a single DMA), file f at raw + file_off[f] (16-byte aligned), file_len[f] bytes; genome g =
+ * files [genome_file_off[g], genome_file_off[g+1]) (several files can feed one sketch, like a reference input line with
+ * spaces).  The packed stream stays in the sketcher's device buffer; the run table comes back to the host.  Then
+ * d2g_sketcher_run / d2g_sketcher_run_bmh / d2g_sketcher_run_distinct with packed == NULL and the table of
+ * d2g_sketcher_ingested_runs sketch it: registers bit-identical to the host-parsed path.
+ * Returns D2G_ERR_UNSUPPORTED -- and stages nothing -- for what only the host parser handles: inputs that do not begin
+ * with '>' (gzip members, FASTQ, leading junk), lines that begin with '+' (FASTQ quality sections), files of 4 GiB and more.
+ * The pointers of d2g_sketcher_ingested_runs stay valid until the next ingest on this sketcher. */
+int d2g_sketcher_ingest_fasta(d2g_sketcher *sk, const uint8_t *raw, size_t raw_bytes, const uint64_t *file_off,
+                              const uint64_t *file_len, size_t nfiles, const uint64_t *genome_file_off /* [n+1] */, size_t n, int k);
+int d2g_sketcher_ingested_runs(const d2g_sketcher *sk, const uint64_t **run_start, const uint32_t **run_len, size_t *nrun,
+                               const uint64_t **genome_run_off /* [n+1] */, const uint64_t **genome_nkmers /* [n] */,
+                               uint64_t *nbases /* bases in the stream */);
 
 /* ---- K3: --multiset sketches: exact k-mer counts (R11) -> BagMinHash (R12) ------
  * Replaces, per input, the reference chain

@@ -602,3 +602,41 @@ def test_cli_cmp_batches_are_invisible(genomes, tmp_path):
                 if binary:
                     nv = N * N if shape else N * (N - 1) // 2
                     assert len(outs[0]) == 4 * nv
+
+
+def test_cli_sketch_device_parser_equals_host_parser(genomes, tmp_path):
+    """`dashing2 sketch` parses plain FASTA on the device (K0) and everything else -- gz members, FASTQ, leading junk -- with
+    the host parser, group by group.  The stacked sketches of a mixed input list must be byte-identical to the all-host run
+    (D2G_HOST_PARSE=1), for set and multiset sketches; the verbose line must show both kinds of groups at work."""
+    import gzip
+    d = tmp_path / "mix"
+    d.mkdir()
+    paths = list(genomes)
+    gz = d / "g0.fa.gz"
+    gz.write_bytes(gzip.compress(open(genomes[0], "rb").read()))
+    fq = d / "reads.fq"
+    rng = np.random.default_rng(2)
+    with open(fq, "wb") as f:
+        for i in range(300):
+            s = bytes(synth.random_genome(1000 + i, 150))
+            f.write(b"@r%d\n" % i + s + b"\n+\n" + b"I" * 150 + b"\n")
+    plus = d / "plus.fa"                                              # starts like FASTA, turns FASTQ-like: refused on the device, host takes it
+    plus.write_bytes(open(genomes[1], "rb").read() + b"+\nIIII\n")
+    empty = d / "empty.fa"
+    empty.write_bytes(b"")
+    two = genomes[2] + " " + genomes[3]                               # one sketch from two files (an input line with a space)
+    paths += [str(gz), str(fq), str(plus), str(empty)]
+    lst = tmp_path / "l.txt"
+    lst.write_text("".join(p + "\n" for p in paths) + two + "\n")
+    for extra in ([], ["--multiset", "-k", "21", "-S", "256"]):
+        outs = []
+        for env in ({"D2G_GROUP_BYTES": "100000"}, {"D2G_HOST_PARSE": "1"}):       # one input per group / everything on the host parser
+            o = tmp_path / "s.bin"
+            r = subprocess.run([EXE, "sketch", "-v", "-p", "3", "-F", str(lst), "-o", str(o)] + extra, capture_output=True, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr.decode()[-1500:]
+            outs.append((o.read_bytes(), open(str(o) + ".names.txt", "rb").read(), r.stderr.decode()))
+        assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+        assert "parsed on the device" in outs[0][2] and "(0 parsed on the device" not in outs[0][2] and " 0 by the host" not in outs[0][2]
+        assert "(0 parsed on the device" in outs[1][2]
+    r = subprocess.run([EXE, "sketch", "-o", str(tmp_path / "x.bin"), str(d / "missing.fa")], capture_output=True)
+    assert r.returncode != 0 and b"Failed to open" in r.stderr
