@@ -197,10 +197,16 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     // buffers; ONE device thread (this one) owns the GPU context: it uploads a group's raw bytes, K0 parses and 2-bit-packs them
     // on the device (d2g_sketcher_ingest_fasta), K1 / K3 sketch the stream, the registers are finalised (x87) and cached.
     // Inputs the device parser refuses (gz members, FASTQ, leading junk: first byte is not '>') are parsed by the host parser
-    // (d2g_seqpack) on the reader thread instead, group by group -- the round-2 path.  D2G_HOST_PARSE=1 forces it for all.
+    // (d2g_seqpack) on the reader thread instead, group by group -- the round-2 path.
+    // WHICH PARSER IS THE DEFAULT -- measured, 1000 x 5 Mbp FASTA in the page cache, 16 usable cores (profiles/r03_e2e_cli.txt):
+    // read()ing a group into staging costs a core as much as read()ing + packing it (22 vs 19 ms per 43 MB: the copy out of the
+    // page cache into memory that is not cache-resident is the expensive half, and the packer works on a 5 MB buffer that
+    // stays in L2), the device threads are not the bottleneck either way, and 0.8 GB of page-locked staging adds ~0.07 s of
+    // teardown when the process exits.  So the device parser buys nothing end to end on this host and the HOST parser stays
+    // the default; D2G_DEVICE_PARSE=1 selects the hybrid (device parser whenever a staging buffer is free).
     // The staging buffers are plain memory the readers fill at once; they are page-locked (d2g_host_register) as soon as the
     // GPU context exists, so neither the context creation nor the pinning delays the reading.
-    double t_parse = 0, t_gpu = 0, t_fin = 0;
+    double t_parse = 0, t_gpu = 0, t_fin = 0, t_read_raw = 0, t_host_pack = 0;
     uint64_t total_bases = 0;
     size_t n_dev_groups = 0, n_host_groups = 0;
     d2g_sketcher *sk = nullptr;
@@ -211,7 +217,7 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     std::condition_variable cv_ready, cv_space, cv_buf;
     std::atomic<size_t> next_group{0};
     std::string parse_error;
-    const bool force_host = std::getenv("D2G_HOST_PARSE") != nullptr;
+    const bool force_host = std::getenv("D2G_DEVICE_PARSE") == nullptr || std::getenv("D2G_HOST_PARSE") != nullptr;
     const size_t nparsers = std::max<size_t>(1, std::min<size_t>({size_t(o.workers()), groups.size(), size_t(192)}));
     const size_t max_ready = 2 * nparsers + 2;
     size_t max_group = 16;
@@ -282,7 +288,9 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
                 }
                 if (rc == D2G_OK) (void)d2g_seqpack_packed_bytes(r.sp);          // pad now, off the device thread
             }
+            const double t_work = now() - t0;
             std::unique_lock<std::mutex> lk(mu);
+            (r.buf >= 0 ? t_read_raw : t_host_pack) += t_work;
             if (rc) {
                 if (parse_error.empty()) parse_error = "Failed to open " + bad;
                 if (r.sp) d2g_seqpack_destroy(r.sp);
@@ -402,27 +410,34 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     };
     std::thread second;
     d2g_ctx *ctx2 = nullptr;
+    const double t_dev0 = now();
     if (ndev > 1) {
         const int rc2 = d2g_ctx_create(o.device, &ctx2);
         if (rc2 != D2G_OK) die(std::string("d2g_ctx_create (second device thread): ") + d2g_strerror(rc2));
         second = std::thread(device_loop, ctx2);
     }
+    const double t_dev1 = now();
     device_loop(ctx);
     if (second.joinable()) second.join();
+    const double t_dev2 = now();
     { std::lock_guard<std::mutex> lk(fmu); fin_closing = true; }
     fcv.notify_all();
     finisher.join();
-    if (ctx2) d2g_ctx_destroy(ctx2);
+    if (ctx2 && std::getenv("D2G_FULL_TEARDOWN")) d2g_ctx_destroy(ctx2);
     (void)sk;
+    if (o.verbosity) std::fprintf(stderr, "[d2g] device side: second context %.3fs, device loops %.3fs wall, drain of the finisher %.3fs\n", t_dev1 - t_dev0, t_dev2 - t_dev1,
+                                  now() - t_dev2);
     for (auto &th : parsers) th.join();
     for (d2g_seqpack *p : pool) d2g_seqpack_destroy(p);
-    for (size_t i = 0; i < nbufs; ++i) { (void)d2g_host_unregister(ctx, bufs[i]); std::free(bufs[i]); }
     const double t_pipe = now();
+    // the staging buffers stay page-locked until the process ends (it leaves through _exit): unpinning 0.8 GB costs more than
+    // the whole device work of a small job; D2G_FULL_TEARDOWN=1 releases them
+    if (std::getenv("D2G_FULL_TEARDOWN")) for (size_t i = 0; i < nbufs; ++i) { (void)d2g_host_unregister(ctx, bufs[i]); std::free(bufs[i]); }
     if (!parse_error.empty()) die(parse_error);
     if (o.verbosity) std::fprintf(stderr, "[d2g] sketched %zu inputs (%" PRIu64 " bases in the packed streams) in %zu groups (%zu parsed on the device, %zu by the host "
-                                          "parser): host read/parse %.3fs over %zu threads, 2 device threads: H2D+K0+K1+D2H %.3fs busy, finisher thread: x87 finalise+cache %.3fs; "
+                                          "parser): reader threads %.3fs in all (%.3fs reading raw groups, %.3fs reading + packing, the rest waiting for queue space) over %zu threads, 2 device threads: H2D+K0+K1+D2H %.3fs busy, finisher thread: x87 finalise+cache %.3fs; "
                                           "%zu staging buffers of %zu MiB page-locked in %.3fs\n",
-                                  todo.size(), total_bases, groups.size(), n_dev_groups, n_host_groups, t_parse, nparsers, t_gpu, t_fin,
+                                  todo.size(), total_bases, groups.size(), n_dev_groups, n_host_groups, t_parse, t_read_raw, t_host_pack, nparsers, t_gpu, t_fin,
                                   nbufs, buf_bytes >> 20, t_pin);
     if (o.verbosity) std::fprintf(stderr, "[d2g] sketch wall: setup (stat, cache probe) %.3fs, ingest pipeline %.3fs\n", t_setup - t_enter, t_pipe - t_setup);
     write_stacked(res, o);

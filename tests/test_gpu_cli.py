@@ -605,9 +605,9 @@ def test_cli_cmp_batches_are_invisible(genomes, tmp_path):
 
 
 def test_cli_sketch_device_parser_equals_host_parser(genomes, tmp_path):
-    """`dashing2 sketch` parses plain FASTA on the device (K0) and everything else -- gz members, FASTQ, leading junk -- with
-    the host parser, group by group.  The stacked sketches of a mixed input list must be byte-identical to the all-host run
-    (D2G_HOST_PARSE=1), for set and multiset sketches; the verbose line must show both kinds of groups at work."""
+    """With D2G_DEVICE_PARSE=1 `dashing2 sketch` parses plain FASTA on the device (K0) and everything else -- gz members, FASTQ,
+    leading junk -- with the host parser, group by group.  The stacked sketches of a mixed input list must be byte-identical
+    to the default all-host run, for set and multiset sketches; the verbose line must show both kinds of groups at work."""
     import gzip
     d = tmp_path / "mix"
     d.mkdir()
@@ -630,7 +630,7 @@ def test_cli_sketch_device_parser_equals_host_parser(genomes, tmp_path):
     lst.write_text("".join(p + "\n" for p in paths) + two + "\n")
     for extra in ([], ["--multiset", "-k", "21", "-S", "256"]):
         outs = []
-        for env in ({"D2G_GROUP_BYTES": "100000"}, {"D2G_HOST_PARSE": "1"}):       # one input per group / everything on the host parser
+        for env in ({"D2G_GROUP_BYTES": "100000", "D2G_DEVICE_PARSE": "1"}, {}):    # device parser, one input per group / the default: host parser
             o = tmp_path / "s.bin"
             r = subprocess.run([EXE, "sketch", "-v", "-p", "3", "-F", str(lst), "-o", str(o)] + extra, capture_output=True, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stderr.decode()[-1500:]
