@@ -263,3 +263,58 @@ def test_allpairs_plain_and_pipelined_steps_mix(d2g, oracle, gpu_ctx):
         gpu_ctx.free(p)
     eng.close()
     comm.close()
+
+
+def test_allpairs_config4_shape_world8_vs_single_gpu(d2g, gpu_ctx):
+    """BASELINE config 4's 8-rank form (N = 50 000, S = 1024: 2 chunks per rank, the split multi-partition rank kernel on
+    64-column chunks, the column plan per chunk) through the loopback transport on one GPU: every rank's slab of the
+    condensed triangle must equal the single-GPU result on the same rows -- first rows, rows around every partition seam,
+    last rows -- for the fused float epilogue and the integer counts."""
+    from dashing2_amd import synth
+    N, S, W = 50_000, 1024, 8
+    regs = synth.synthetic_registers(N, S, nclusters=N // 150, seed=20260929)
+    bits = d2g.oph_finalize(regs, S, nthreads=16)[0].view(np.uint64)
+    del regs
+    lut = d2g.epilogue_lut(S, d2g.SIMILARITY, 31)
+    ref = gpu_ctx.cmp_set(bits, algo=d2g.CMP_BITSLICE)
+    ctxs = [d2g.Context(0) for _ in range(W)]
+    comms = d2g.Comm.create_all(ctxs)
+    engs = [d2g.AllPairs(ctxs[r], comms[r], N, S) for r in range(W)]
+    assert all(e.chunks == 2 for e in engs)
+    held = [e.rows_held for e in engs]
+    rows = [_upload(ctxs[r], bits[held[r][0]:held[r][1]]) for r in range(W)]
+    outs = [ctxs[r].malloc(max(d2g.ut_count(N, *engs[r].rows_computed), 1) * 4) for r in range(W)]
+    luts = [_upload(ctxs[r], lut) for r in range(W)]
+    d2g.allpairs_step_all(engs, rows, luts, outs)
+    for r in range(W):
+        ctxs[r].sync()
+        engs[r].status()
+    b = d2g.ut_partition(N, W)
+    off = lambda r0, i: d2g.ut_count(N, r0, i)                       # offset of row i inside a slab that starts at row r0
+    for r in range(W):
+        r0, r1 = engs[r].rows_computed
+        assert (r0, r1) == (b[r], b[r + 1])
+        for a, z in ((r0, min(r0 + 3, r1)), (max(r0, r1 - 3), r1)):  # the first and the last rows of the slab (the seams)
+            if z <= a:
+                continue
+            want = ref.lut_ut(lut, a, z) if hasattr(ref, "lut_ut") else None
+            n = d2g.ut_count(N, a, z)
+            got = np.empty(n, np.float32)
+            ctxs[r].d2h(got, outs[r] + 4 * off(r0, a))
+            if want is None:
+                want = lut[ref.eqcount_ut(a, z)]
+            np.testing.assert_array_equal(got.view(np.uint32), np.asarray(want, np.float32).view(np.uint32), err_msg=f"rank {r} rows [{a},{z})")
+    # integer counts of one rank through the step form
+    d2g.allpairs_step_all(engs, rows, None, outs)
+    r = 5
+    ctxs[r].sync()
+    r0, r1 = engs[r].rows_computed
+    got = np.empty(d2g.ut_count(N, r0, r0 + 2), np.uint32)
+    ctxs[r].d2h(got, outs[r])
+    np.testing.assert_array_equal(got, ref.eqcount_ut(r0, r0 + 2))
+    ref.close()
+    for r in range(W):
+        for p in (rows[r], outs[r], luts[r]):
+            ctxs[r].free(p)
+    for x in engs + comms + ctxs:
+        x.close()

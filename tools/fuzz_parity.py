@@ -42,12 +42,35 @@ def main():
     rng = np.random.default_rng(seed)
     ctx = D.Context(0)
     t0 = time.time()
-    n = {"k1": 0, "k2": 0, "k3": 0, "byseq": 0, "wsets": 0, "mgpu": 0}
+    n = {"k0": 0, "k1": 0, "k2": 0, "k3": 0, "byseq": 0, "wsets": 0, "mgpu": 0}
+    sk0 = ctx.sketcher()
     fails = 0
     while time.time() - t0 < budget:
-        which = rng.choice(["k1", "k2", "k3", "k3", "byseq", "wsets", "mgpu"])
+        which = rng.choice(["k0", "k1", "k2", "k3", "k3", "byseq", "wsets", "mgpu"])
         try:
-            if which == "k1":
+            if which == "k0":
+                # device FASTA parser (K0) -> K1 / K3 on the ingested stream, vs the oracle on the same bytes
+                k = int(rng.integers(1, 33)); S = int(rng.choice([8, 64, 100, 1024]))
+                fa = []
+                for _ in range(int(rng.integers(1, 6))):
+                    f = rand_fasta(rng, int(rng.choice([300, 5000, 120000])))
+                    # what the device parser accepts: starts with '>', no line starts with '+' (FASTQ records are rewritten as FASTA)
+                    f = f.replace(b"\n+\n", b"\n>q\n").replace(b"\n@", b"\n>")
+                    f = (b">" + f[1:]) if f[:1] == b"@" else f
+                    if rng.random() < 0.3:
+                        f = f.replace(b"\n", b"\r\n")
+                    fa.append(f)
+                runs = sk0.ingest_fasta(fa, k)
+                regs = sk0.run_ingested(runs, S)
+                for i, f in enumerate(fa):
+                    er, _, _, enk = O.sketch_buffer(f, k=k, S=S)
+                    assert int(runs[3][i]) == enk and np.array_equal(regs[i], er)
+                if k >= 3 and rng.random() < 0.4:
+                    sig, tw = sk0.run_bmh_ingested(runs, 64)
+                    for i, f in enumerate(fa):
+                        es, et, _ = O.bmh_sketch_buffer(f, k, 64)
+                        assert tw[i] == et and np.array_equal(sig[i].view(np.uint64), es.view(np.uint64))
+            elif which == "k1":
                 k = int(rng.integers(1, 33)); S = int(rng.choice([8, 63, 64, 100, 1000, 1024, 4096])); canon = bool(rng.integers(0, 2))
                 xm = int(rng.choice([0, 0x724526e320f9967d, int(rng.integers(1, 1 << 62))]))
                 fa = [rand_fasta(rng, int(rng.choice([300, 5000, 120000]))) for _ in range(int(rng.integers(1, 5)))]
@@ -61,7 +84,11 @@ def main():
                     assert np.array_equal(regs[i], er) and np.array_equal(sig[i].view(np.uint64), es.view(np.uint64)) and card[i] == ec
             elif which == "k2":
                 N = int(rng.integers(2, 700)); S = int(rng.choice([32, 64, 100, 128, 1000, 1024])); meas = int(rng.integers(0, 6))
-                regs = synth.synthetic_registers(N, S, nclusters=int(rng.integers(1, 12)), seed=int(rng.integers(0, 1 << 30)))
+                os.environ["D2G_BS_SORT"] = str(int(rng.integers(0, 2)))                    # column plan on / off
+                if rng.random() < 0.3:
+                    regs = synth.skewed_registers(N, S, seed=int(rng.integers(0, 1 << 30)), max_shared=int(rng.choice([4, 64, 300])))
+                else:
+                    regs = synth.synthetic_registers(N, S, nclusters=int(rng.integers(1, 12)), seed=int(rng.integers(0, 1 << 30)))
                 sig, card = D.oph_finalize(regs, S)
                 multiset = bool(rng.integers(0, 2))
                 got = ctx.cmp_dist_ut(sig.view(np.uint64), card, measure=meas, k=int(rng.integers(1, 33)) if False else 31,
@@ -112,6 +139,7 @@ def main():
                     assert tw[i] == et and np.array_equal(sig[i].view(np.uint64), es.view(np.uint64)) and np.array_equal(own[i], eo)
             elif which == "mgpu":
                 W = int(rng.integers(1, 7)); N = int(rng.integers(2, 400)); S = int(rng.choice([32, 100, 256, 1000, 1024]))
+                os.environ["D2G_MGPU_CHUNKS"] = str(int(rng.integers(1, 5)))                # chunked exchange inside the step
                 regs = synth.synthetic_registers(N, S, nclusters=int(rng.integers(1, 9)), seed=int(rng.integers(0, 1 << 30)))
                 exp = O.eqcounts_ut(regs.view(np.float64))
                 ctxs = [D.Context(0) for _ in range(W)]
