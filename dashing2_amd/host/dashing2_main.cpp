@@ -835,10 +835,14 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
         }
     });
     check(ctx, d2g_cmp_set_create(ctx, bits, ns, S, need_gtlt ? int(D2G_CMP_DIRECT) : int(D2G_CMP_AUTO), &set), "d2g_cmp_set_create");
+    const double t_set = now();
     DevBuf dlut(ctx, (S + 1) * sizeof(float));
     if (have_lut) check(ctx, d2g_memcpy_h2d(ctx, dlut.p, lut.data(), (S + 1) * sizeof(float), nullptr), "h2d lut");
     DevBuf da(ctx, cap * 4), db(ctx, need_gtlt ? cap * 4 : 4);
+    const double t_bufs = now();
     side.join();
+    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp set-up: operand upload + prepare %.3fs, device buffers %.3fs, waiting for the page-locked slots %.3fs\n",
+                                  t_set - t0, t_bufs - t_set, now() - t_bufs);
     double t_dev = 0;
     const double t_loop = now();
     {
