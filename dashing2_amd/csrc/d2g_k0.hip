@@ -87,12 +87,20 @@ __device__ __forceinline__ K0Chunk k0_load(const uint8_t *raw, const K0File &f, 
     return c;
 }
 
-// position + 1 of the last line feed in the chunk (file-relative, 32-bit: files below 4 GiB), 0 = none
-__device__ __forceinline__ uint32_t k0_last_nl(const K0Chunk &c) {
-    uint32_t r = 0;
+// Scan key of the last line feed in the chunk: ((file-relative position + 1) << 1) | (the line that FOLLOWS it is a header:
+// its first byte is '>' or '@'); 0 = no line feed.  Files stay below 2 GiB so that the key fits 32 bits; carrying the flag in
+// the key spares every thread a dependent gather of its line's first byte.
+__device__ __forceinline__ uint32_t k0_last_nl(const uint8_t *raw, const K0File &f, const K0Chunk &c) {
+    int last = -1;
 #pragma unroll
-    for (int i = 0; i < K0_PER; ++i) if (i < (int)c.nvalid && c.b[i] == '\n') r = (uint32_t)c.fpos + i + 1;
-    return r;
+    for (int i = 0; i < K0_PER; ++i) if (i < (int)c.nvalid && c.b[i] == '\n') last = i;
+    if (last < 0) return 0u;
+    const uint64_t p1 = c.fpos + (uint64_t)last + 1;                     // position of the byte after the line feed
+    uint8_t nx = 0;
+    if (p1 < f.len) {
+        nx = raw[f.off + p1];                                            // (a register select over b[] costs more than this cached byte)
+    }
+    return ((uint32_t)p1 << 1) | (uint32_t)(nx == '>' || nx == '@');
 }
 
 __device__ __forceinline__ int k0_code(uint8_t ch) {                    // A0 C1 G2 T3 (either case), -1 otherwise
@@ -101,34 +109,53 @@ __device__ __forceinline__ int k0_code(uint8_t ch) {                    // A0 C1
     return -1;
 }
 
-// Walks the chunk with the line state known at its start.  nl1 = (position + 1) of the last line feed before the chunk
-// (0 = none: the line began at the start of the file).  emit(i, code, cls) is called for every valid byte.
-template <class F>
-__device__ __forceinline__ void k0_walk(const uint8_t *raw, const K0File &f, const K0Chunk &c, uint32_t nl1, uint32_t *plus, F emit) {
-    if (!c.nvalid) return;
-    bool at_ls = (uint64_t)nl1 == c.fpos;                               // the chunk starts a line (nl1 = 0 and fpos = 0: start of file)
+// One walk over the chunk with the line state known at its start: the chunk's bytes as three masks.  key = scan key of the
+// last line feed before the chunk (0 = none: the current line is the file's first).
+struct K0Masks { uint32_t base, brk, codes; };                          // bit i: byte i is a base / a break; codes: 2 bits per byte position
+__device__ __forceinline__ K0Masks k0_classify(const uint8_t *raw, const K0File &f, const K0Chunk &c, uint32_t key, uint32_t *plus) {
+    K0Masks m{0u, 0u, 0u};
+    if (!c.nvalid) return m;
+    bool at_ls = (uint64_t)(key >> 1) == c.fpos;                        // the chunk starts a line (key 0 and fpos 0: start of file)
     bool hdr = false;
-    if (!at_ls) { const uint8_t first = raw[f.off + nl1]; hdr = first == '>' || first == '@'; }
+    if (!at_ls) {
+        if (key) hdr = key & 1u;
+        else { const uint8_t first = raw[f.off]; hdr = first == '>' || first == '@'; }   // still on the file's first line
+    }
+    // branch-free per byte (neighbouring lanes see different bytes: every branch here would diverge); only the rare carriage
+    // return takes one
+    uint32_t hd = hdr, ls = at_ls, pl = 0;
 #pragma unroll
     for (int i = 0; i < K0_PER; ++i) {
-        if (i < (int)c.nvalid) {                                        // (no break: the loop must unroll, b[] lives in registers)
-            const uint8_t ch = c.b[i];
-            if (at_ls) { hdr = ch == '>' || ch == '@'; if (ch == '+') *plus = 1; at_ls = false; }
-            uint32_t cls;
-            int code = -1;
-            if (ch == '\n') { cls = hdr ? K0_BREAK : K0_NONE; at_ls = true; }
-            else if (hdr) cls = K0_BREAK;
-            else if ((code = k0_code(ch)) >= 0) cls = K0_BASE;
-            else if (ch == '\r') {
-                // kseq-style line ends: ONE carriage return right before the line feed (or as the last byte of a file without a
-                // final line feed) belongs to the line end; anywhere else it is just a byte that is not a base
-                const uint64_t p = c.fpos + i;
-                const bool at_end = p + 1 == f.len || (i + 1 < K0_PER ? c.b[i + 1 < K0_PER ? i + 1 : i] == '\n' : raw[f.off + p + 1] == '\n');
-                cls = at_end ? K0_NONE : K0_BREAK;
-            } else cls = K0_BREAK;
-            emit(i, code, cls);
+        const uint32_t ch = c.b[i], u = ch & 0xDFu;
+        const uint32_t valid = i < (int)c.nvalid;
+        const uint32_t gt = (ch == '>') | (ch == '@');
+        hd = ls ? gt : hd;                                               // a line start decides whether the line is a header
+        pl |= ls & (uint32_t)(ch == '+') & valid;
+        const uint32_t nl = ch == '\n';
+        const uint32_t isb = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+        uint32_t other = (nl | isb) ^ 1u;                                // neither a line feed nor a base
+        if (ch == '\r' && valid) {
+            // kseq-style line ends: ONE carriage return right before the line feed (or as the last byte of a file without a
+            // final line feed) belongs to the line end; anywhere else it is just a byte that is not a base
+            const uint64_t p = c.fpos + i;
+            const bool at_end = p + 1 == f.len || (i + 1 < K0_PER ? c.b[i + 1 < K0_PER ? i + 1 : i] == '\n' : raw[f.off + p + 1] == '\n');
+            other = at_end ? 0u : 1u;
         }
+        const uint32_t base = isb & (hd ^ 1u) & valid;
+        const uint32_t brk = (hd | other) & valid;                       // every byte of a header line, and what is neither base nor line end
+        m.base |= base << i;
+        m.brk |= (brk & (base ^ 1u)) << i;
+        m.codes |= ((((u >> 1) & 3u) ^ ((u >> 2) & 1u)) & (0u - base)) << (2 * i);
+        ls = nl & valid ? 1u : (valid ? 0u : ls);
     }
+    if (pl) *plus = 1;
+    return m;
+}
+// class of the chunk's LAST base-or-break byte (K0_NONE if it has neither)
+__device__ __forceinline__ uint32_t k0_last_class(const K0Masks &m) {
+    const uint32_t e = m.base | m.brk;
+    if (!e) return K0_NONE;
+    return (m.brk >> (31 - __clz(e))) & 1u ? K0_BREAK : K0_BASE;
 }
 
 // ---------------------------------------------------------------------------------------------- pass A
@@ -139,7 +166,7 @@ __global__ __launch_bounds__(K0_THREADS) void k0_newline_kernel(const uint8_t *_
     const uint32_t fi = k0_file_of_tile(files, nf, tile);
     const K0File f = files[fi];
     const K0Chunk c = k0_load(raw, f, tile - f.tile0);
-    uint32_t v = k0_last_nl(c);
+    uint32_t v = k0_last_nl(raw, f, c);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
     if (lane == 0) wt[wave] = v;
@@ -175,16 +202,18 @@ __global__ __launch_bounds__(K0_THREADS) void k0_count_kernel(const uint8_t *__r
     const uint32_t fi = k0_file_of_tile(files, nf, tile);
     const K0File f = files[fi];
     const K0Chunk c = k0_load(raw, f, tile - f.tile0);
-    const uint32_t nl1 = max(tile_nl[tile], k0_excl_max(k0_last_nl(c), wt));
-    uint32_t nbase = 0, last = K0_NONE, plus = 0;
-    k0_walk(raw, f, c, nl1, &plus, [&](int, int, uint32_t cls) { nbase += cls == K0_BASE; if (cls != K0_NONE) last = cls; });
+    const uint32_t key = max(tile_nl[tile], k0_excl_max(k0_last_nl(raw, f, c), wt));
+    uint32_t plus = 0;
+    const K0Masks mk = k0_classify(raw, f, c, key, &plus);
+    uint32_t nbase = __popc(mk.base);
+    const uint32_t last = k0_last_class(mk);
     if (plus) atomicOr(status, K0_ST_PLUS);
     // tile totals: base count; the class of the LAST base-or-break byte of the tile (key = thread order)
-    uint32_t key = last ? ((threadIdx.x + 1u) << 2 | last) : 0u;
+    uint32_t ckey = last ? ((threadIdx.x + 1u) << 2 | last) : 0u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = 32; o > 0; o >>= 1) { nbase += __shfl_xor(nbase, o); key = max(key, __shfl_xor(key, o)); }
+    for (int o = 32; o > 0; o >>= 1) { nbase += __shfl_xor(nbase, o); ckey = max(ckey, __shfl_xor(ckey, o)); }
     __shared__ uint32_t wk[K0_THREADS / 64];
-    if (lane == 0) { wt[wave] = nbase; wk[wave] = key; }
+    if (lane == 0) { wt[wave] = nbase; wk[wave] = ckey; }
     __syncthreads();
     if (threadIdx.x == 0) {
         tile_nbase[tile] = wt[0] + wt[1] + wt[2] + wt[3];
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(64) void k0_carry_base_kernel(const K0File *__restr
         uint32_t kex = __shfl_up(kin, 1);
         if (lane == 0) kex = 0;
         if (t < t1) {
-            // file-relative base offsets fit 32 bits (a file is below 4 GiB); the file's own offset is added in pass C
+            // file-relative base offsets fit 32 bits (a file is below 2 GiB); the file's own offset is added in pass C
             tile_nbase[t] = (uint32_t)(run + incl - n);
             tile_cls[t] = kex ? ((kex & 3u) == K0_BREAK ? 1u : 0u) : pend;
         }
@@ -252,30 +281,34 @@ __global__ __launch_bounds__(K0_THREADS) void k0_emit_kernel(const uint8_t *__re
     const K0File f = files[fi];
     const K0Chunk c = k0_load(raw, f, tile - f.tile0);
     for (int i = threadIdx.x; i < K0_TILE / 16 + 2; i += K0_THREADS) words[i] = 0;
-    const uint32_t nl1 = max(tile_nl[tile], k0_excl_max(k0_last_nl(c), wt));
-    // first walk: this thread's base count and last class
-    uint32_t nbase = 0, last = K0_NONE, plus = 0;
-    k0_walk(raw, f, c, nl1, &plus, [&](int, int, uint32_t cls) { nbase += cls == K0_BASE; if (cls != K0_NONE) last = cls; });
+    const uint32_t key = max(tile_nl[tile], k0_excl_max(k0_last_nl(raw, f, c), wt));
+    uint32_t plus = 0;
+    const K0Masks mk = k0_classify(raw, f, c, key, &plus);               // ONE walk; everything below works on its masks
+    const uint32_t nbase = __popc(mk.base), last = k0_last_class(mk);
     uint32_t tile_total = 0;
     const uint32_t before = k0_excl_sum(nbase, wt, &tile_total);
     const uint32_t kex = k0_excl_max(last ? ((threadIdx.x + 1u) << 2 | last) : 0u, wt);
     bool pend = kex ? (kex & 3u) == K0_BREAK : tile_pend[tile] != 0;
     const uint64_t o_tile = file_base[fi] + tile_base[tile];            // stream index of the tile's first base
     const uint32_t shift0 = (uint32_t)(o_tile & 15u);                   // its place in the first word
-    // second walk: codes into the staged words, run starts into the list
-    uint32_t w = 0, nw = 0;
-    uint64_t o = o_tile + before;
-    k0_walk(raw, f, c, nl1, &plus, [&](int, int code, uint32_t cls) {
-        if (cls == K0_BASE) {
-            if (pend) {
-                const uint32_t slot = atomicAdd(run_count, 1u);
-                if (slot < run_cap) run_list[slot] = o + nw; else atomicOr(status, K0_ST_RUNLIST);
-                pend = false;
-            }
-            w |= (uint32_t)code << (2 * nw);
-            ++nw;
-        } else if (cls == K0_BREAK) pend = true;
-    });
+    // the chunk's bases in order: codes squeezed together into one word, run starts into the list.  A base starts a run if a
+    // break lies between it and the base before it (or, for the chunk's first base, if one was pending)
+    uint32_t w = 0, nw = 0, todo = mk.base, below = 0;                  // below: mask of the byte positions up to the previous base
+    const uint64_t o = o_tile + before;
+    while (todo) {
+        const int i = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const uint32_t upto = (1u << i) - 1u;
+        if (mk.brk & upto & ~below) pend = true;
+        if (pend) {
+            const uint32_t slot = atomicAdd(run_count, 1u);
+            if (slot < run_cap) run_list[slot] = o + nw; else atomicOr(status, K0_ST_RUNLIST);
+            pend = false;
+        }
+        w |= ((mk.codes >> (2 * i)) & 3u) << (2 * nw);
+        ++nw;
+        below = upto | (1u << i);
+    }
     if (nw) {
         const uint32_t bit = (shift0 + before) * 2, d = bit >> 5, sh = bit & 31;
         atomicOr(&words[d], w << sh);
@@ -341,7 +374,7 @@ int d2g_sketcher_ingest_fasta(d2g_sketcher *sk, const uint8_t *raw, size_t raw_b
     uint64_t ntiles = 0;
     for (size_t f = 0; f < nfiles; ++f) {
         D2G_CHECK(ctx, (file_off[f] & 15) == 0 && file_off[f] + file_len[f] <= raw_bytes, "ingest: file offsets must be 16-byte aligned and inside the buffer");
-        if (file_len[f] >= (1ull << 32)) { ctx->last_error = "ingest: inputs of 4 GiB and more go through the host parser"; return D2G_ERR_UNSUPPORTED; }
+        if (file_len[f] >= (1ull << 31)) { ctx->last_error = "ingest: inputs of 2 GiB and more go through the host parser"; return D2G_ERR_UNSUPPORTED; }
         if (file_len[f] && raw[file_off[f]] != '>') { ctx->last_error = "ingest: input does not start with '>' (gz / FASTQ / other): host parser"; return D2G_ERR_UNSUPPORTED; }
         files[f] = {file_off[f], file_len[f], ntiles};
         ntiles += (file_len[f] + K0_TILE - 1) / K0_TILE;

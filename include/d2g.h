@@ -207,7 +207,7 @@ int  d2g_sketcher_run(d2g_sketcher *sk, const uint8_t *packed, size_t packed_byt
  * d2g_sketcher_run / d2g_sketcher_run_bmh / d2g_sketcher_run_distinct with packed == NULL and the table of
  * d2g_sketcher_ingested_runs sketch it: registers bit-identical to the host-parsed path.
  * Returns D2G_ERR_UNSUPPORTED -- and stages nothing -- for what only the host parser handles: inputs that do not begin
- * with '>' (gzip members, FASTQ, leading junk), lines that begin with '+' (FASTQ quality sections), files of 4 GiB and more.
+ * with '>' (gzip members, FASTQ, leading junk), lines that begin with '+' (FASTQ quality sections), files of 2 GiB and more.
  * The pointers of d2g_sketcher_ingested_runs stay valid until the next ingest on this sketcher. */
 int d2g_sketcher_ingest_fasta(d2g_sketcher *sk, const uint8_t *raw, size_t raw_bytes, const uint64_t *file_off,
                               const uint64_t *file_len, size_t nfiles, const uint64_t *genome_file_off /* [n+1] */, size_t n, int k);
