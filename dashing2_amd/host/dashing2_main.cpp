@@ -54,6 +54,9 @@ struct Result {                              // SketchingResult, src/fastxsketch
     size_t nq = 0;
 };
 
+// The process leaves through _exit once its outputs are closed (main): releasing device memory and unpinning hundreds of MB
+// one buffer at a time just before that costs tens of milliseconds and buys nothing.  D2G_FULL_TEARDOWN=1 releases everything.
+static const bool g_release_at_exit = std::getenv("D2G_FULL_TEARDOWN") != nullptr;
 [[noreturn]] void die(const std::string &msg) {          // THROW_EXCEPTION: src/enums.h:59-63
     std::fprintf(stderr, "Exception %s\n", msg.c_str());
     std::exit(1);
@@ -124,7 +127,7 @@ struct LazyCtx {
     d2g_ctx *get() { if (th.joinable()) th.join(); return ctx; }
     // the context is only torn down on request: main() leaves through _exit once every output is flushed and closed (the HIP
     // runtime's orderly shutdown costs tens of milliseconds that buy a CLI process nothing); D2G_FULL_TEARDOWN=1 keeps it
-    ~LazyCtx() { get(); if (ctx && std::getenv("D2G_FULL_TEARDOWN")) d2g_ctx_destroy(ctx); }
+    ~LazyCtx() { get(); if (ctx && g_release_at_exit) d2g_ctx_destroy(ctx); }
 };
 
 void write_stacked(const Result &res, const Options &o) {
@@ -404,7 +407,7 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
                 pool.push_back(r.sp);
             }
         }
-        d2g_sketcher_destroy(dsk);
+        if (g_release_at_exit) d2g_sketcher_destroy(dsk);
         std::lock_guard<std::mutex> lk(smu);
         t_gpu += gpu; total_bases += bases; n_dev_groups += ndevg; n_host_groups += nhostg; t_parse += tp;
     };
@@ -423,7 +426,7 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     { std::lock_guard<std::mutex> lk(fmu); fin_closing = true; }
     fcv.notify_all();
     finisher.join();
-    if (ctx2 && std::getenv("D2G_FULL_TEARDOWN")) d2g_ctx_destroy(ctx2);
+    if (ctx2 && g_release_at_exit) d2g_ctx_destroy(ctx2);
     (void)sk;
     if (o.verbosity) std::fprintf(stderr, "[d2g] device side: second context %.3fs, device loops %.3fs wall, drain of the finisher %.3fs\n", t_dev1 - t_dev0, t_dev2 - t_dev1,
                                   now() - t_dev2);
@@ -432,7 +435,7 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     const double t_pipe = now();
     // the staging buffers stay page-locked until the process ends (it leaves through _exit): unpinning 0.8 GB costs more than
     // the whole device work of a small job; D2G_FULL_TEARDOWN=1 releases them
-    if (std::getenv("D2G_FULL_TEARDOWN")) for (size_t i = 0; i < nbufs; ++i) { (void)d2g_host_unregister(ctx, bufs[i]); std::free(bufs[i]); }
+    if (g_release_at_exit) for (size_t i = 0; i < nbufs; ++i) { (void)d2g_host_unregister(ctx, bufs[i]); std::free(bufs[i]); }
     if (!parse_error.empty()) die(parse_error);
     if (o.verbosity) std::fprintf(stderr, "[d2g] sketched %zu inputs (%" PRIu64 " bases in the packed streams) in %zu groups (%zu parsed on the device, %zu by the host "
                                           "parser): reader threads %.3fs in all (%.3fs reading raw groups, %.3fs reading + packing, the rest waiting for queue space) over %zu threads, 2 device threads: H2D+K0+K1+D2H %.3fs busy, finisher thread: x87 finalise+cache %.3fs; "
@@ -649,12 +652,12 @@ struct Emitter {
 struct DevBuf {
     d2g_ctx *ctx; void *p = nullptr;
     DevBuf(d2g_ctx *c, size_t n) : ctx(c) { check(c, d2g_malloc(c, n ? n : 4, &p), "d2g_malloc"); }
-    ~DevBuf() { d2g_free(ctx, p); }
+    ~DevBuf() { if (g_release_at_exit) d2g_free(ctx, p); }
 };
 struct PinnedBuf {                            // page-locked host staging, reused across row batches
     d2g_ctx *ctx; void *p = nullptr;
     PinnedBuf(d2g_ctx *c, size_t n) : ctx(c) { check(c, d2g_malloc_host(c, n ? n : 4, &p), "d2g_malloc_host"); }
-    ~PinnedBuf() { d2g_free_host(ctx, p); }
+    ~PinnedBuf() { if (g_release_at_exit) d2g_free_host(ctx, p); }
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -902,7 +905,7 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                                               "overlapped) (algo %s)\n", ns, S, t_loop - t0, now() - t_loop, t_dev, eq.t_busy,
                                       d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE ? "bitslice" : "direct");
     }
-    d2g_cmp_set_destroy(set);
+    if (g_release_at_exit) d2g_cmp_set_destroy(set);
 }
 
 d2g_ctx *make_ctx(const Options &o) {
