@@ -507,3 +507,17 @@ def test_k2_split_rank_kernel(gpu_ctx, d2g, monkeypatch, N, S, nsplit):
     for (a, b), g in zip(rows, got):
         np.testing.assert_array_equal(g, ref.eqcount_ut(a, b))
     ref.close()
+
+
+@pytest.mark.parametrize("S", [4096, 4100, 8200])
+def test_k2_column_plan_large_sketch_sizes(gpu_ctx, d2g, oracle, S):
+    """the column plan sorts up to 4096 register slots in LDS; larger sketches keep the caller's column order (identity plan).
+    Both sides of that limit, with a padded last group, against the oracle."""
+    N = 70
+    regs = synth.skewed_registers(N, S, seed=S, max_shared=20)
+    exp = oracle.eqcounts_ut(regs.view(np.float64))
+    cs = gpu_ctx.cmp_set(regs, algo=d2g.CMP_BITSLICE)
+    np.testing.assert_array_equal(cs.eqcount_ut(), exp)
+    md, nb, mean = cs.planes()
+    assert 1 <= nb <= 6 and mean <= nb
+    cs.close()
