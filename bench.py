@@ -24,7 +24,7 @@ beside it as `stream_of_matrices`, never as `value`.  `--scaling weak` keeps pai
 instead (N_sketches = 10000 * sqrt(N)).  The N = 1 line also carries `config4_1gpu`: config 4 on one GPU,
 the base a strong-scaling curve should be read against.
 
-Secondary objects in the same JSON line (N = 1 measures all of them; N > 1 shards them by input):
+Secondary objects in the same JSON line (N = 1 measures all of them; N > 1 only with --all-legs, sharded by input):
   compute.matrices  the pair kernel on three matrices: unrelated sketches (1 id plane), the stated one,
                     and an adversarial one where every value occurs exactly twice per column
   sketch            K1 bases/s on BASELINE config 2's shape (1 000 x 5 Mbp, k=31, S=1024): synthetic
@@ -78,6 +78,9 @@ def parse_args():
                     help="sharded path: skip the secondary stream-of-matrices measurement (exchange + prepare of step i+1 "
                          "under the pair kernel of step i); the headline is always the one-job step")
     ap.add_argument("--force-sharded", action="store_true", help="debug: run the N>1 code path at N=1")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="N > 1: also run the secondary sketch / multiset legs (sharded by input, no collectives in their data path); by default an "
+                         "N > 1 run measures the all-pairs job only, so that nothing unrelated to it can delay or lose the scaling line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -850,7 +853,8 @@ def main():
             return o
         return sdt, build
 
-    sketch = None if args.no_sketch else guarded(sketch_leg)
+    secondary = world == 1 or args.all_legs
+    sketch = None if (args.no_sketch or not secondary) else guarded(sketch_leg)
 
     # ---- secondary: K3 --multiset sketch construction (BASELINE config 5: k=21, S=2048, exact k-mer
     # counts -> BagMinHash), packed bases resident in HBM
@@ -956,7 +960,7 @@ def main():
             return out
         return mdt, build
 
-    multiset = None if args.no_multiset else guarded(multiset_leg)
+    multiset = None if (args.no_multiset or not secondary) else guarded(multiset_leg)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
