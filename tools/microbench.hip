@@ -44,6 +44,37 @@ __global__ void k_xor_or(uint32_t *out, const uint32_t *__restrict__ sc) {
     uint32_t s = 0; for (int i = 0; i < 16; ++i) s ^= z[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// two planes per step without v_bitop3: t1 = s0 ^ v1, t2 = s1 ^ v2 (VOP2, scalar source), z = or3(z, t1, t2)
+__global__ void k_xor2_or3(uint32_t *out, const uint32_t *__restrict__ sc) {
+    uint32_t z[16], v = threadIdx.x * 2654435761u, v2 = v ^ 0x5bd1e995u;
+    uint32_t s0 = sc[0], s1 = sc[1];
+    for (int i = 0; i < 16; ++i) z[i] = i;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint32_t t1, t2;
+            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(t1) : "s"(s0), "v"(v));
+            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(t2) : "s"(s1), "v"(v2));
+            asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(z[i]) : "v"(t1), "v"(t2));
+        }
+        v = v * 3 + 1; v2 = v2 * 5 + 1;
+    }
+    uint32_t s = 0; for (int i = 0; i < 16; ++i) s ^= z[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// the same two planes with v_bitop3 (what the pair kernel does): z = z | (s0 ^ v1); z = z | (s1 ^ v2)
+__global__ void k_bitop3_x2(uint32_t *out, const uint32_t *__restrict__ sc) {
+    uint32_t z[16], v = threadIdx.x * 2654435761u, v2 = v ^ 0x5bd1e995u;
+    uint32_t s0 = sc[0], s1 = sc[1];
+    for (int i = 0; i < 16; ++i) z[i] = i;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { z[i] = __builtin_amdgcn_bitop3_b32(s0, v, z[i], 0xBE); z[i] = __builtin_amdgcn_bitop3_b32(s1, v2, z[i], 0xBE); }
+        v = v * 3 + 1; v2 = v2 * 5 + 1; asm volatile("" : "+v"(v), "+v"(v2));
+    }
+    uint32_t s = 0; for (int i = 0; i < 16; ++i) s ^= z[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 __global__ void k_bcnt(uint32_t *out) {
     uint32_t z[16], v = threadIdx.x * 2654435761u;
     for (int i = 0; i < 16; ++i) z[i] = i;
@@ -230,6 +261,8 @@ int main() {
         rep("v_fma_f32", time_kernel([&] { k_fma<<<blocks, threads>>>((float *)out, 1.0001f, 0.5f); }));
         rep("v_bitop3_b32(s,v,v)", time_kernel([&] { k_bitop3<<<blocks, threads>>>((uint32_t *)out, (uint32_t *)sc); }));
         rep("v_xor+v_or", time_kernel([&] { k_xor_or<<<blocks, threads>>>((uint32_t *)out, (uint32_t *)sc); }), 2.0);
+        rep("2 planes: 2xor+or3 (per plane)", time_kernel([&] { k_xor2_or3<<<blocks, threads>>>((uint32_t *)out, (uint32_t *)sc); }), 2.0);
+        rep("2 planes: 2 bitop3 (per plane)", time_kernel([&] { k_bitop3_x2<<<blocks, threads>>>((uint32_t *)out, (uint32_t *)sc); }), 2.0);
         rep("v_bcnt_u32_b32", time_kernel([&] { k_bcnt<<<blocks, threads>>>((uint32_t *)out); }));
         rep("v_cmp_eq_u64 only", time_kernel([&] { k_cmp64_only<<<blocks, threads>>>((uint32_t *)out, (uint64_t *)sc); }));
         rep("cmp_eq_u64+addc (2)", time_kernel([&] { k_cmp64_addc<<<blocks, threads>>>((uint32_t *)out, (uint64_t *)sc); }), 2.0);
