@@ -222,6 +222,8 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     std::string parse_error;
     const bool force_host = std::getenv("D2G_DEVICE_PARSE") == nullptr || std::getenv("D2G_HOST_PARSE") != nullptr;
     const size_t nparsers = std::max<size_t>(1, std::min<size_t>({size_t(o.workers()), groups.size(), size_t(192)}));
+    // (A byte-bounded queue deep enough to parse all of 1000 x 5 Mbp before the first launch, with four device threads to drain it,
+    // was measured: the 112 freshly allocated packers fault in 1.3 GB and the pipeline went 0.21 -> 0.34 s.  The recycled pool stays.)
     const size_t max_ready = 2 * nparsers + 2;
     size_t max_group = 16;
     for (size_t gb : group_bytes) max_group = std::max(max_group, gb);
