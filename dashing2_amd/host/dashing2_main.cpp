@@ -348,7 +348,8 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     });
     // Two device threads, each with its own context + sketcher (a d2g_ctx is used by one thread at a time): the upload of one
     // group overlaps the kernels and the synchronisations of the other
-    const int ndev = groups.size() > 1 ? 2 : 1;
+    int ndev = groups.size() > 1 ? 2 : 1;
+    if (const char *e = std::getenv("D2G_DEVICE_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ndev = int(std::min<size_t>(size_t(v), std::max<size_t>(groups.size(), 1))); }
     std::atomic<size_t> taken{0};
     std::mutex smu;
     auto device_loop = [&](d2g_ctx *dctx) {
@@ -413,25 +414,27 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
         std::lock_guard<std::mutex> lk(smu);
         t_gpu += gpu; total_bases += bases; n_dev_groups += ndevg; n_host_groups += nhostg; t_parse += tp;
     };
-    std::thread second;
-    d2g_ctx *ctx2 = nullptr;
+    std::vector<std::thread> more;
+    std::vector<d2g_ctx *> more_ctx;
     const double t_dev0 = now();
-    if (ndev > 1) {
-        const int rc2 = d2g_ctx_create(o.device, &ctx2);
-        if (rc2 != D2G_OK) die(std::string("d2g_ctx_create (second device thread): ") + d2g_strerror(rc2));
-        second = std::thread(device_loop, ctx2);
+    for (int d = 1; d < ndev; ++d) {
+        d2g_ctx *c2 = nullptr;
+        const int rc2 = d2g_ctx_create(o.device, &c2);
+        if (rc2 != D2G_OK) die(std::string("d2g_ctx_create (device thread): ") + d2g_strerror(rc2));
+        more_ctx.push_back(c2);
+        more.emplace_back(device_loop, c2);
     }
     const double t_dev1 = now();
     device_loop(ctx);
-    if (second.joinable()) second.join();
+    for (auto &th : more) th.join();
     const double t_dev2 = now();
     { std::lock_guard<std::mutex> lk(fmu); fin_closing = true; }
     fcv.notify_all();
     finisher.join();
-    if (ctx2 && g_release_at_exit) d2g_ctx_destroy(ctx2);
+    if (g_release_at_exit) for (d2g_ctx *c2 : more_ctx) d2g_ctx_destroy(c2);
     (void)sk;
-    if (o.verbosity) std::fprintf(stderr, "[d2g] device side: second context %.3fs, device loops %.3fs wall, drain of the finisher %.3fs\n", t_dev1 - t_dev0, t_dev2 - t_dev1,
-                                  now() - t_dev2);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] device side: %d device threads (extra contexts %.3fs), device loops %.3fs wall, drain of the finisher %.3fs\n", ndev,
+                                  t_dev1 - t_dev0, t_dev2 - t_dev1, now() - t_dev2);
     for (auto &th : parsers) th.join();
     for (d2g_seqpack *p : pool) d2g_seqpack_destroy(p);
     const double t_pipe = now();
@@ -440,7 +443,7 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     if (g_release_at_exit) for (size_t i = 0; i < nbufs; ++i) { (void)d2g_host_unregister(ctx, bufs[i]); std::free(bufs[i]); }
     if (!parse_error.empty()) die(parse_error);
     if (o.verbosity) std::fprintf(stderr, "[d2g] sketched %zu inputs (%" PRIu64 " bases in the packed streams) in %zu groups (%zu parsed on the device, %zu by the host "
-                                          "parser): reader threads %.3fs in all (%.3fs reading raw groups, %.3fs reading + packing, the rest waiting for queue space) over %zu threads, 2 device threads: H2D+K0+K1+D2H %.3fs busy, finisher thread: x87 finalise+cache %.3fs; "
+                                          "parser): reader threads %.3fs in all (%.3fs reading raw groups, %.3fs reading + packing, the rest waiting for queue space) over %zu threads, device threads: H2D+K0+K1+D2H %.3fs busy in all, finisher thread: x87 finalise+cache %.3fs; "
                                           "%zu staging buffers of %zu MiB page-locked in %.3fs\n",
                                   todo.size(), total_bases, groups.size(), n_dev_groups, n_host_groups, t_parse, t_read_raw, t_host_pack, nparsers, t_gpu, t_fin,
                                   nbufs, buf_bytes >> 20, t_pin);
