@@ -46,6 +46,8 @@ def _inputs(rng):
         b">a\n" + bytes(synth.random_genome(3, 4096 * 3 - 3)) + b"\n>b\n" + bytes(synth.random_genome(4, 5000)) + b"\n",   # header exactly at a tile edge
         b">w\n" + b"\n".join(bytes(synth.random_genome(50 + i, 15)) for i in range(2000)) + b"\n",   # 15-base lines: line feeds in every chunk
         b">n\n" + b"N" * 9000 + bytes(synth.random_genome(5, 20000)) + b"N" * 5000 + b"\n",   # break runs spanning tiles
+        b">" + b"h" * 10_000 + b" ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT\n" + bytes(synth.random_genome(6, 300_000)) + b"\n>" + b"ACGT" * 3000,   # a header
+        # line longer than two tiles (its ACGT text is not sequence), an unwrapped 300 kb sequence line, a last header without a line feed
     ]
 
 
