@@ -509,7 +509,32 @@ def main():
             else:
                 exchange_fallback += " | " + err2
                 sharded = False
+    slab_check = None
     if sharded:
+        # The multi-GPU exchange has never run on hardware before the driver's scaling run: every rank checks the first and the
+        # last rows of the slab the sharded step just wrote against a single-GPU computation over the WHOLE matrix (which it still
+        # holds from the untimed distribution).  A mismatch anywhere is reported in the line ("valid": false), never hidden.
+        try:
+            ref = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
+            ok = True
+            for a, z in ((r0, min(r0 + 2, r1)), (max(r0, r1 - 2), r1)):
+                if z <= a:
+                    continue
+                n_chk = D.ut_count(N, a, z)
+                want = torch.empty(n_chk, dtype=torch.float32, device=dev)
+                ref.lut_ut_dev(lut.data_ptr(), want.data_ptr(), a, z, stream)
+                torch.cuda.synchronize()
+                o0 = D.ut_count(N, r0, a)
+                ok = ok and bool(torch.equal(want.view(torch.int32), out[o0:o0 + n_chk].view(torch.int32)))
+            ref.close()
+            del ref
+        except Exception as e:                                   # noqa: BLE001
+            ok = False
+            exchange_fallback = (exchange_fallback or "") + f" | slab check failed to run: {type(e).__name__}: {e}"
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        slab_check = bool(flag.item() == 1.0)
         del sig_dev
     else:
         cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
@@ -979,10 +1004,15 @@ def main():
                        "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count",
                        **({"exchange_engine": engine_kind} if engine_kind else {}),
                        **({"exchange_fallback": exchange_fallback} if exchange_fallback else {}),
-                       **({"exchange_chunks": eng.chunks} if (eng is not None and hasattr(eng, "chunks")) else {})},
+                       **({"exchange_chunks": eng.chunks} if (eng is not None and hasattr(eng, "chunks")) else {}),
+                       **({"slab_check": "every rank's first and last slab rows equal a single-GPU computation" if slab_check
+                           else "MISMATCH between the sharded step and a single-GPU computation: this line is NOT a valid measurement"}
+                          if slab_check is not None else {})},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "config4_1gpu": config4,
             "sketch": sketch, "multiset_sketch": multiset,
         }
+        if slab_check is False:
+            line["valid"] = False
         if stream_of_matrices is not None:
             line["stream_of_matrices"] = stream_of_matrices
         # compact copies of the two secondary legs INSIDE roofline / cpu_baseline: these two objects are what the driver's
