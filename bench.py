@@ -3,11 +3,6 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 runs one process per GPU: either launched by the caller (`python -m torch.distributed.run --nproc-per-node N ...
-bench.py --gpus N`: RANK / WORLD_SIZE in the environment) or -- when WORLD_SIZE is not set -- by bench.py itself, which
-re-executes under torch.distributed.run with N ranks after checking that N devices are visible (fewer: a JSON line with
-"error" and exit code 2, never a silent 1-GPU measurement).
-
 Primary metric (BASELINE.json): all-pairs sketch comparison throughput, **pairs/s**.
 N = 1: BASELINE config 3 -- 10 000 pre-built OPH sketches, S = 1024 (49 995 000 pairs), float32
 Jaccard output.  One step = one whole pass of the path over sketches already resident in HBM:
@@ -17,20 +12,36 @@ N > 1 (default --scaling strong): BASELINE config 4 -- 50 000 sketches, S = 1024
 the SAME total work at every N > 1; rank r holds rows [r N/W, (r+1) N/W) (what sharded sketching leaves
 in HBM), one all-to-all + one all-gather of the compact bit-plane operand per step, every rank computes
 its pair-balanced row range of the upper triangle.  `value` / `ms_per_step` are ONE JOB's step, the same
-definition as at N = 1: exchange + prepare + pair kernel of one matrix, nothing carried over between steps
-(inside the step the exchange of chunk c+1 overlaps the prepare of chunk c).  The software-pipelined rate
-for a STREAM of matrices (exchange + prepare of step i+1 under the pair kernel of step i) is reported
-beside it as `stream_of_matrices`, never as `value`.  `--scaling weak` keeps pairs per GPU constant
-instead (N_sketches = 10000 * sqrt(N)).  The N = 1 line also carries `config4_1gpu`: config 4 on one GPU,
-the base a strong-scaling curve should be read against.
+definition as at N = 1: exchange + prepare + pair kernel of one matrix, nothing carried over between steps.
+Every N > 1 line carries its own base: the same job timed on ONE GPU in the same run (`scaling_base`), the
+per-phase times of one step on every rank (`phases`) and the cost model's prediction for that world size
+(`model`).  The N = 1 line also carries `config4_1gpu`.
 
-Secondary objects in the same JSON line (N = 1 measures all of them; N > 1 only with --all-legs, sharded by input):
+**How N > 1 runs -- a supervisor with a watchdog ladder.**  The measuring processes are always CHILDREN of a
+supervisor that touches no GPU: started by hand (`python bench.py --gpus N`) the supervisor is this process;
+started by the driver under `torch.distributed.run` (RANK / WORLD_SIZE set) rank 0 is the supervisor and the
+other ranks exit 0 at once.  The supervisor writes the synthetic matrix to a scratch file once, then tries, each
+rung under a timeout, killing the rung's process group on a timeout or a non-zero exit:
+  1. `cabi`      one process per GPU; libd2g's own RCCL communicator (ncclCommInitRank) + the row-sharded engine
+                 (d2g_allpairs_*); torch.distributed (gloo, CPU) only carries the 128-byte id, barriers, reductions
+  2. `inproc`    ONE process driving all N GPUs through d2g_comm_create_all + d2g_allpairs_step_all (ncclCommInitAll;
+                 no rendezvous, no second communicator) -- the path the C++ `dashing2 cmp` CLI uses
+  3. `torch`     one process per GPU, the same exchange written against torch collectives (backend nccl = RCCL)
+  4. `broadcast` one process per GPU, the whole matrix broadcast per step (torch nccl), single-GPU prepare everywhere
+and prints the first rung's line that succeeds (`launcher.ladder` says what happened on the way) -- or, if every
+rung failed, a JSON line with "error" and exit code 2.  It never exits without a line.  Fewer than N devices
+visible: a line with "error", exit code 2, never a smaller job under an `n_gpus: N` label.
+
+Secondary objects in the same JSON line (N = 1 measures all of them):
   compute.matrices  the pair kernel on three matrices: unrelated sketches (1 id plane), the stated one,
                     and an adversarial one where every value occurs exactly twice per column
   sketch            K1 bases/s on BASELINE config 2's shape (1 000 x 5 Mbp, k=31, S=1024): synthetic
                     genomes -> FASTA bytes -> d2g_seqpack (the product's ingest) -> HBM; kernel-only and
                     parse-inclusive rates, and the oracle timed on the host cores beside it
   multiset_sketch   K3 bases/s on BASELINE config 5's shape (k=21, S=2048, --multiset)
+`roofline.traffic` (and the legs') is measured IN THIS RUN when rocprofv3 is on the box: a child re-runs one launch
+of each reported kernel under `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes); `traffic_source` says so,
+or names the committed profile the figure was read from instead.
 
 PyTorch is plumbing only (device memory, streams, torch.distributed); all computation goes through
 the C ABI of libd2g.so.  The oracle is used ONLY for the cpu_baseline legs.
@@ -49,7 +60,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py: the fallback when rocprofv3 cannot run here
 
 
 def parse_args():
@@ -71,16 +82,22 @@ def parse_args():
     ap.add_argument("--no-multiset", action="store_true", help="skip the secondary K3 (--multiset / BagMinHash) measurement")
     ap.add_argument("--multiset-genomes", type=int, default=1000)
     ap.add_argument("--multiset-batch", type=int, default=250, help="genomes per d2g_bmh_sketch_dev call (8 B of key per k-mer live in HBM)")
-    ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "broadcast"],
-                    help="N>1: row-sharded sketches + all-to-all/all-gather of the compact operand (default), "
-                         "or rank-0 sketches broadcast whole")
+    ap.add_argument("--engines", default=None,
+                    help="N > 1: comma-separated rungs of the watchdog ladder to try, in order (default cabi,inproc,torch,broadcast)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="N > 1 on ONE GPU (tests): all N contexts on device 0 through libd2g's loopback transport; only the `inproc` rung")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="sharded path: skip the secondary stream-of-matrices measurement (exchange + prepare of step i+1 "
+                    help="`cabi` rung: skip the secondary stream-of-matrices measurement (exchange + prepare of step i+1 "
                          "under the pair kernel of step i); the headline is always the one-job step")
-    ap.add_argument("--force-sharded", action="store_true", help="debug: run the N>1 code path at N=1")
     ap.add_argument("--all-legs", action="store_true",
-                    help="N > 1: also run the secondary sketch / multiset legs (sharded by input, no collectives in their data path); by default an "
-                         "N > 1 run measures the all-pairs job only, so that nothing unrelated to it can delay or lose the scaling line")
+                    help="N > 1: after the all-pairs line is out, also run the K1 sketch leg sharded by input (no collectives) and print the line again with it")
+    ap.add_argument("--no-traffic", action="store_true", help="do not re-run the reported kernels under rocprofv3 --pmc for roofline.traffic")
+    # internal: set by the supervisor for its measuring children
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--engine", default=None, choices=["cabi", "inproc", "torch", "broadcast"], help=argparse.SUPPRESS)
+    ap.add_argument("--sig-file", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cards-file", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -334,69 +351,728 @@ def pack_genomes(D, synth, first, count, L, k, keep=0, nthreads=None):
     return np.concatenate(packed), np.concatenate(rs), np.concatenate(rl), np.concatenate(go), kept
 
 
-def self_launch(args):
-    """`python bench.py --gpus N` with no WORLD_SIZE: run N ranks under torch.distributed.run ourselves (one process per
-    GPU, 127.0.0.1 rendezvous) -- after checking that N devices are there.  Returns the exit code."""
-    import socket
-    import subprocess
-    import dashing2_amd as D
-    have = int(D.lib().d2g_device_count())
-    if have < args.gpus:
-        print(json.dumps({"metric": "all-pairs sketch comparison throughput (pairs/s)", "value": None, "unit": "pairs/s",
-                          "n_gpus": args.gpus, "error": f"--gpus {args.gpus} requested but {have} HIP device(s) visible: refusing to "
-                                                         "measure a smaller job under that label"}), flush=True)
-        return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
-    return subprocess.call(cmd, env=env)
+# ======================================================================================================================
+# N > 1: supervisor + watchdog ladder
+# ======================================================================================================================
+LADDER = ("cabi", "inproc", "torch", "broadcast")
+# seconds a rung may take before its process group is killed; the first rung also pays the first `import torch` of N processes on a
+# fresh box (1-2 min).  D2G_BENCH_RUNG_TIMEOUT overrides all of them (tests).
+RUNG_TIMEOUT = {"cabi": 420.0, "inproc": 300.0, "torch": 300.0, "broadcast": 240.0}
+ENGINE_NAME = {"cabi": "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv groups), one process per GPU",
+               "inproc": "libd2g (d2g_comm_create_all + d2g_allpairs_step_all), ONE process driving every GPU",
+               "torch": "torch.distributed (dashing2_amd.dist.RowShardedAllPairs), one process per GPU",
+               "broadcast": "whole-matrix torch.distributed broadcast per step + single-GPU prepare on every rank"}
+# profiles/r03_mgpu_model.txt (tools/mgpu_model.sh): ONE rank's step of BASELINE config 4 replayed from loopback kernel durations +
+# every exchange at (bytes over the busiest link) / 50 GB/s + 6 us per enqueued operation.  ms per phase INSTANCE (a chunked phase
+# runs `chunks` times); step_ms = the replayed one-job step; speedup vs the model's own 1-GPU step (15.602 ms).
+MODEL_R03 = {
+    2: {"chunks": 4, "pack": 0.090, "x1": 0.512, "prepare": 0.188, "x2": 0.257, "derive": 0.014, "pair": 6.769, "step_ms": 10.016, "speedup": 1.56},
+    4: {"chunks": 4, "pack": 0.049, "x1": 0.128, "prepare": 0.107, "x2": 0.129, "derive": 0.016, "pair": 3.430, "step_ms": 4.587, "speedup": 3.40},
+    8: {"chunks": 2, "pack": 0.026, "x1": 0.064, "prepare": 0.103, "x2": 0.129, "derive": 0.023, "pair": 1.745, "step_ms": 2.278, "speedup": 6.85},
+}
 
 
-def main():
-    args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_sharded:
-        raise SystemExit(self_launch(args))
-    import torch
-    import torch.distributed as dist
-    import dashing2_amd as D
-    from dashing2_amd import synth
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    ctx = D.Context(local_rank)
-    algo = {"auto": D.CMP_AUTO, "direct": D.CMP_DIRECT, "bitslice": D.CMP_BITSLICE}[args.algo]
+def multi_shape(args):
+    """(N, S, scaling, workload) of an N > 1 run -- the same in the supervisor and in every worker"""
     S = args.sketchsize
+    W = args.gpus
     scaling = args.scaling or "strong"
-    if world == 1:
-        N = args.sketches or 10000
-        workload = "BASELINE config 3" if (N, S) == (10000, 1024) else "custom"
-    elif scaling == "strong":
+    if scaling == "strong":
         N = args.sketches or 50000
         workload = "BASELINE config 4" if (N, S) == (50000, 1024) else "custom"
     else:
-        N = int(round((args.sketches or 10000) * math.sqrt(world)))
+        N = int(round((args.sketches or 10000) * math.sqrt(W)))
         workload = "BASELINE config 3 x sqrt(n_gpus) sketches (constant pairs per GPU)"
-    if world > 1:
-        N = (N + world - 1) // world * world                 # equal row blocks per rank
+    N = (N + W - 1) // W * W                                   # equal row blocks per rank (the torch rung needs it; config 4 is unaffected)
+    return N, S, scaling, workload
+
+
+def error_line(args, msg, extra=None):
+    line = {"metric": "all-pairs sketch comparison throughput (pairs/s)", "value": None, "unit": "pairs/s", "n_gpus": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "error": msg}
+    if extra:
+        line.update(extra)
+    return line
+
+
+def last_json_line(path):
+    """the last line of a worker's stdout that parses as a bench line (RCCL prints banners through C stdio)"""
+    try:
+        txt = open(path, "rb").read().decode("utf-8", "replace")
+    except OSError:
+        return None
+    for ln in reversed(txt.splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def run_rung(engine, args, tmp, extra_argv, timeout):
+    """one rung: spawn its measuring process(es) in their own session, wait under a watchdog, kill what is left.
+    -> (line or None, outcome string, seconds)"""
+    import signal
+    import socket
+    import subprocess
+    nproc = 1 if engine == "inproc" else args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base_env = {k: v for k, v in os.environ.items()
+                if not (k.startswith("TORCHELASTIC_") or k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE",
+                                                                "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS",
+                                                                "TORCH_NCCL_ASYNC_ERROR_HANDLING", "NCCL_ASYNC_ERROR_HANDLING"))}
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base_env["OMP_NUM_THREADS"] = str(max(1, host_cores() // nproc))
+    procs, files = [], []
+    t0 = time.monotonic()
+    for r in range(nproc):
+        env = dict(base_env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        fo = open(os.path.join(tmp, f"{engine}.{r}.out"), "wb")
+        fe = open(os.path.join(tmp, f"{engine}.{r}.err"), "wb")
+        files += [fo, fe]
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker", "--engine", engine] + extra_argv
+        procs.append(subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, start_new_session=True))
+    outcome = None
+    while outcome is None:
+        rcs = [p.poll() for p in procs]
+        bad = [(i, rc) for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            outcome = "rank %d exited with code %d" % bad[0]
+        elif all(rc == 0 for rc in rcs):
+            outcome = "ok"
+        elif time.monotonic() - t0 > timeout:
+            outcome = "timeout after %.0f s (hung: ranks %s)" % (timeout, [i for i, rc in enumerate(rcs) if rc is None])
+        else:
+            time.sleep(0.1)
+    for p in procs:                                             # whatever is still alive: the whole session of that worker
+        if p.poll() is None:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except Exception:                                       # noqa: BLE001
+            pass
+    for f in files:
+        f.close()
+    line = last_json_line(os.path.join(tmp, f"{engine}.0.out"))
+    if outcome != "ok":
+        tails = []
+        for r in range(nproc):
+            try:
+                t = open(os.path.join(tmp, f"{engine}.{r}.err"), "rb").read().decode("utf-8", "replace").strip().splitlines()
+                if t:
+                    tails.append(f"rank {r}: " + " | ".join(t[-3:])[-400:])
+            except OSError:
+                pass
+        if tails:
+            outcome += " :: " + " ;; ".join(tails[:3])
+    for r in range(nproc):                                      # the workers' stderr is ours (RCCL warnings, tracebacks)
+        try:
+            sys.stderr.write(open(os.path.join(tmp, f"{engine}.{r}.err"), "rb").read().decode("utf-8", "replace")[-4000:])
+        except OSError:
+            pass
+    return line, outcome, time.monotonic() - t0, [p.pid for p in procs]
+
+
+def supervise(args):
+    """N > 1: never measures anything itself.  Returns the exit code; prints exactly one JSON line."""
+    import shutil
+    import tempfile
+    launched_by = "bench.py (no launcher)"
+    if "WORLD_SIZE" in os.environ:
+        launched_by = "torch.distributed.run ranks (rank 0 supervises, the others exit 0)"
+        if int(os.environ["WORLD_SIZE"]) != args.gpus:
+            print(json.dumps(error_line(args, f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")), flush=True)
+            return 2
+        if int(os.environ.get("RANK", "0")) != 0:
+            return 0
+    import dashing2_amd as D
+    from dashing2_amd import synth
+    skip_check = args.loopback or os.environ.get("D2G_BENCH_TEST_SKIP_DEVICE_CHECK") == "1"
+    have = int(D.lib().d2g_device_count())
+    if have < args.gpus and not skip_check:
+        print(json.dumps(error_line(args, f"--gpus {args.gpus} requested but {have} HIP device(s) visible: refusing to "
+                                          "measure a smaller job under that label")), flush=True)
+        return 2
+    engines = [e for e in (args.engines.split(",") if args.engines else (("inproc",) if args.loopback else LADDER)) if e]
+    bad = [e for e in engines if e not in LADDER]
+    if bad or (args.loopback and engines != ["inproc"]):
+        print(json.dumps(error_line(args, f"unknown / unusable rung(s) {bad or engines} (--loopback runs the `inproc` rung only)")), flush=True)
+        return 2
+    N, S, _, _ = multi_shape(args)
+    # scratch: the synthetic matrix, written ONCE for every rung (and the workers' stdout / stderr)
+    where = None
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            st = os.statvfs(cand)
+            if st.f_bavail * st.f_frsize > N * S * 8 + (64 << 20):
+                where = cand
+                break
+        except OSError:
+            continue
+    tmp = tempfile.mkdtemp(prefix="d2g_bench_", dir=where)
+    ladder, rc, out_line = [], 2, None
+    try:
+        t0 = time.monotonic()
+        regs = synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260929 if N == 50000 else 20260928)
+        sig, cards = D.oph_finalize(regs, S, nthreads=host_cores())
+        del regs
+        sig_file, cards_file = os.path.join(tmp, "sig.npy"), os.path.join(tmp, "cards.npy")
+        np.save(sig_file, sig.view(np.uint64))
+        np.save(cards_file, cards)
+        del sig
+        gen_s = time.monotonic() - t0
+        forced = os.environ.get("D2G_BENCH_RUNG_TIMEOUT")
+        for engine in engines:
+            timeout = float(forced) if forced else RUNG_TIMEOUT[engine]
+            line, outcome, secs, pids = run_rung(engine, args, tmp, ["--sig-file", sig_file, "--cards-file", cards_file], timeout)
+            usable = isinstance(line, dict) and line.get("value") is not None and line.get("n_gpus") == args.gpus
+            ladder.append({"engine": engine, "outcome": outcome, "seconds": round(secs, 1), "line": bool(usable), "pids": pids})
+            if usable:
+                # a rung that was killed AFTER its headline line was out (a secondary leg hung) still delivered the measurement
+                out_line, rc = line, 0
+                break
+        if out_line is None:
+            out_line = error_line(args, "every rung of the multi-GPU ladder failed: " + " || ".join(f"{l['engine']}: {l['outcome']}" for l in ladder)[:3000])
+        out_line["launcher"] = {"launched_by": launched_by, "ladder": ladder, "input_generation_s": round(gen_s, 1), "scratch": where,
+                                "note": "the measuring processes are children of a supervisor that touches no GPU; each rung runs under a timeout "
+                                        "and its whole process group is killed on a timeout or a non-zero exit"}
+    except Exception as e:                                      # noqa: BLE001 - the supervisor itself must not lose the line
+        out_line = error_line(args, f"supervisor: {type(e).__name__}: {e}", {"launcher": {"launched_by": launched_by, "ladder": ladder}})
+        rc = 2
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    print(json.dumps(out_line), flush=True)
+    return rc
+
+
+# ======================================================================================================================
+# N > 1: one measuring process (a rank of `cabi` / `torch` / `broadcast`, or the single `inproc` process)
+# ======================================================================================================================
+def run_multi(args):
+    engine = args.engine
+    hooks = os.environ.get("D2G_BENCH_TEST_HANG", "").split(",")
+    if engine in hooks:                                          # test hook: a rung that never comes back (before any import)
+        while True:
+            time.sleep(3600)
+    if engine in os.environ.get("D2G_BENCH_TEST_FAIL", "").split(","):
+        raise SystemExit(3)
+    if engine in os.environ.get("D2G_BENCH_TEST_LINE_THEN_HANG", "").split(","):      # test hook: the headline is out, a secondary leg hangs
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "all-pairs sketch comparison throughput (pairs/s)", "value": 1.0, "unit": "pairs/s", "n_gpus": args.gpus,
+                              "config": {"exchange_engine": "test hook"}}), flush=True)
+        while True:
+            time.sleep(3600)
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    import dashing2_amd as D
+
+    W = args.gpus
+    ranked = engine != "inproc"
+    N, S, scaling, workload = multi_shape(args)
     pairs_total = N * (N - 1) // 2
-    bounds = D.ut_partition(N, world)
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    my_pairs = D.ut_count(N, r0, r1)
-    sharded = (world > 1 and args.exchange == "alltoall") or args.force_sharded
+    bounds = D.ut_partition(N, W)
+    algo = {"auto": D.CMP_AUTO, "direct": D.CMP_DIRECT, "bitslice": D.CMP_BITSLICE}[args.algo]
+    ncores = host_cores()
+    if ranked:
+        rank0 = int(os.environ["RANK"])
+        local_dev = int(os.environ.get("LOCAL_RANK", rank0))
+        torch.cuda.set_device(local_dev)
+        backend = "gloo" if engine == "cabi" else "nccl"
+        kw = {"device_id": torch.device("cuda", local_dev)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank0, world_size=W, **kw)
+        ranks = [rank0]
+        ctrl = torch.device("cpu") if backend == "gloo" else torch.device("cuda", local_dev)
+    else:
+        rank0, ranks, ctrl = 0, list(range(W)), torch.device("cpu")
+    is_root = rank0 == 0
+
+    def dev_of(r):
+        return 0 if args.loopback else (r if not ranked else local_dev)
+
+    # ---- control-plane reductions (gloo / CPU for the libd2g engines: nothing but the engine touches RCCL)
+    def allreduce(x, op):
+        if not ranked:
+            return x
+        t = torch.tensor([float(x)], dtype=torch.float64, device=ctrl)
+        dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op])
+        return float(t.item())
+
+    def gather_obj(o):
+        """per-rank python objects -> list indexed by rank (on every rank)"""
+        if not ranked:
+            return o
+        res = [None] * W
+        dist.all_gather_object(res, o[0])
+        return res
+
+    def sync_all():
+        for r in ranks:
+            torch.cuda.synchronize(dev_of(r))
+
+    def barrier():
+        sync_all()
+        if ranked:
+            dist.barrier()
+        sync_all()
+
+    # ---- input: the supervisor's scratch file (memory-mapped); rank r uploads the rows it HOLDS
+    sig_np = np.load(args.sig_file, mmap_mode="r")
+    assert sig_np.shape == (N, S) and sig_np.dtype == np.uint64
+    lut_np = D.epilogue_lut(S, D.SIMILARITY, 31)
+    L = {}                                                       # per local rank: everything that lives on its GPU
+    for r in ranks:
+        d = dev_of(r)
+        torch.cuda.set_device(d)
+        ctx = D.Context(d)
+        tdev = torch.device("cuda", d)
+        L[r] = {"ctx": ctx, "dev": tdev, "r0": bounds[r], "r1": bounds[r + 1], "pairs": D.ut_count(N, bounds[r], bounds[r + 1]),
+                "lut": torch.from_numpy(lut_np).to(tdev)}
+        L[r]["out"] = torch.empty(max(L[r]["pairs"], 1), dtype=torch.float32, device=tdev)
+    stream = None                                                # the NULL stream of each engine's device
+    comms = engs = None
+    eng_of = {}
+    if engine == "cabi":
+        uid = [D.comm_unique_id() if is_root else None]
+        dist.broadcast_object_list(uid, src=0)
+        r = ranks[0]
+        comm = D.Comm.create(L[r]["ctx"], r, W, uid[0])         # ncclCommInitRank: collective
+        ctypes.CDLL(None).fflush(None)                          # RCCL's version banner (C stdio): out now, not after the JSON line
+        eng_of[r] = D.AllPairs(L[r]["ctx"], comm, N, S)         # exchanges (N, S, world, chunks) with every rank: the first traffic
+        comms = [comm]
+    elif engine == "inproc":
+        if args.loopback:
+            os.environ["D2G_COMM_LOOPBACK"] = "1"
+        comms = D.Comm.create_all([L[r]["ctx"] for r in ranks])  # ncclCommInitAll (or the loopback transport)
+        ctypes.CDLL(None).fflush(None)
+        for r in ranks:
+            eng_of[r] = D.AllPairs(L[r]["ctx"], comms[r], N, S)
+    for r in ranks:
+        if r in eng_of:
+            assert eng_of[r].rows_computed == (L[r]["r0"], L[r]["r1"])
+            lo, hi = eng_of[r].rows_held
+        else:
+            lo, hi = r * (N // W), (r + 1) * (N // W)
+        torch.cuda.set_device(dev_of(r))
+        L[r]["rows"] = torch.from_numpy(np.ascontiguousarray(sig_np[lo:hi]).view(np.int64)).to(L[r]["dev"])
+    teng = None
+    if engine == "torch":
+        from dashing2_amd import dist as DD
+        r = ranks[0]
+        teng = DD.RowShardedAllPairs(L[r]["ctx"], N, S, L[r]["dev"])
+        assert (teng.r0, teng.r1) == (L[r]["r0"], L[r]["r1"])
+    full_dev = {}
+    if engine == "broadcast":
+        r = ranks[0]
+        full_dev[r] = (torch.from_numpy(np.ascontiguousarray(sig_np).view(np.int64)).to(L[r]["dev"]) if is_root
+                       else torch.empty((N, S), dtype=torch.int64, device=L[r]["dev"]))
+        dist.broadcast(full_dev[r], 0)
+        L[r]["cs"] = L[r]["ctx"].cmp_set_dev(full_dev[r].data_ptr(), N, S, algo=algo, stream=stream)
+
+    # ---- ONE job's step, enqueued for every local rank
+    if engine == "cabi":
+        r = ranks[0]
+
+        def step():
+            eng_of[r].step_lut_dev(L[r]["rows"].data_ptr(), L[r]["lut"].data_ptr(), L[r]["out"].data_ptr(), stream)
+    elif engine == "inproc":
+        e_list = [eng_of[r] for r in ranks]
+        p_rows, p_lut, p_out = ([L[r][k].data_ptr() for r in ranks] for k in ("rows", "lut", "out"))
+
+        def step():
+            D.allpairs_step_all(e_list, p_rows, p_lut, p_out, None)
+    elif engine == "torch":
+        r = ranks[0]
+        tstream = torch.cuda.current_stream().cuda_stream
+
+        def step():
+            teng.step_lut(L[r]["rows"], L[r]["lut"], L[r]["out"], tstream)
+    else:
+        r = ranks[0]
+        tstream = torch.cuda.current_stream().cuda_stream
+
+        def step():
+            dist.broadcast(full_dev[r], 0)                       # the path's one exchange (RCCL over xGMI)
+            L[r]["cs"].update_dev(full_dev[r].data_ptr(), tstream)
+            L[r]["cs"].lut_ut_dev(L[r]["lut"].data_ptr(), L[r]["out"].data_ptr(), L[r]["r0"], L[r]["r1"], tstream)
+
+    step()                                                       # first pass: allocations, code objects, the first exchange
+    barrier()
+    for r in ranks:
+        if r in eng_of:
+            eng_of[r].status(stream)                             # a rank-table overflow on ANY rank invalidates the step everywhere
+
+    # ---- every rank's WHOLE slab against a single-GPU computation over the whole matrix (the exchange has never run on
+    # hardware before the driver's scaling run); rank 0 times that single-GPU job: the base of this line's speedup
+    base = None
+    ok = True
+    for r in ranks:
+        d = L[r]
+        torch.cuda.set_device(dev_of(r))
+        full = full_dev.get(r)
+        if full is None:
+            full = torch.from_numpy(np.ascontiguousarray(sig_np).view(np.int64)).to(d["dev"])
+        ref = d["ctx"].cmp_set_dev(full.data_ptr(), N, S, algo=algo, stream=stream)
+        want = torch.empty(pairs_total, dtype=torch.float32, device=d["dev"])
+        ref.lut_ut_dev(d["lut"].data_ptr(), want.data_ptr(), 0, N, stream)
+        torch.cuda.synchronize(dev_of(r))
+        o0 = D.ut_count(N, 0, d["r0"])
+        ok = ok and bool(torch.equal(want[o0:o0 + d["pairs"]].view(torch.int32), d["out"][:d["pairs"]].view(torch.int32)))
+        if r == 0:
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ref.update_dev(full.data_ptr(), stream)
+                ref.lut_ut_dev(d["lut"].data_ptr(), want.data_ptr(), 0, N, stream)
+            torch.cuda.synchronize(dev_of(r))
+            bdt = (time.perf_counter() - t0) / reps
+            base = {"base_1gpu_same_config_pairs_per_s": pairs_total / bdt, "base_1gpu_ms_per_step": bdt * 1e3,
+                    "note": f"the SAME {N} x {S} job (prepare + pair kernel over the whole triangle, sketches resident in HBM) on GPU 0 alone, "
+                            f"mean of {reps} steps, timed in this run before the sharded steps"}
+        ref.close()
+        del ref, want
+        if r not in full_dev:
+            del full
+        torch.cuda.empty_cache()
+    slab_check = allreduce(1.0 if ok else 0.0, "min") == 1.0
+
+    # ---- per-phase times of ONE untimed step (libd2g engines), every rank
+    phases = None
+    if eng_of:
+        for r in ranks:
+            eng_of[r].set_phase_timing(True)
+        barrier()
+        step()
+        sync_all()
+        mine = [[[p["phase"], p["chunk"], round(p["start_ms"], 4), round(p["ms"], 4)] for p in eng_of[r].phase_times()] for r in ranks]
+        for r in ranks:
+            eng_of[r].set_phase_timing(False)
+        allp = gather_obj(mine)
+        worst = {}
+        for rec in allp:
+            for ph, c, st, ms in rec:
+                worst.setdefault(ph, {}).setdefault(c, 0.0)
+                worst[ph][c] = max(worst[ph][c], ms)
+        phases = {"per_rank": allp, "fields": ["phase", "chunk", "start_ms (after the step's first enqueue reached the GPU)", "ms"],
+                  "max_over_ranks_ms": {ph: [worst[ph][c] for c in sorted(worst[ph])] for ph in worst},
+                  "note": "one untimed step with timing events around every phase on the stream it runs on (compute stream: pack, prepare, derive, pair; "
+                          "exchange stream: x1 = rows -> column slices, x2 = bit-plane groups to everyone); an exchange's time includes waiting for "
+                          "the slowest peer" + ("; ONE process enqueues all ranks here, so start_ms also carries the enqueue order" if not ranked else "")}
+
+    # ---- the timed region
+    def timed_run(fn):
+        for r in ranks:
+            L[r]["ctx"].set_timing(D.TIME_K2PREP)
+            L[r]["ctx"].kernel_ms("k2prep")
+        for _ in range(max(args.warmup, 1)):
+            fn()
+        barrier()
+        for r in ranks:
+            L[r]["ctx"].set_timing(D.TIME_K2)
+            L[r]["ctx"].kernel_ms("k2")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        for r in ranks:
+            L[r]["ctx"].set_timing(False)
+        return allreduce(dt, "max")
+
+    dt = timed_run(step)
+    per_rank = gather_obj([{"rank": r, "pair_kernel_ms": L[r]["ctx"].kernel_ms("k2")[1], "prepare_chain_ms": L[r]["ctx"].kernel_ms("k2prep")[1],
+                            "pairs": L[r]["pairs"]} for r in ranks])
+    for r in ranks:
+        if r in eng_of:
+            eng_of[r].status(stream)
+    ms_per_step = dt / args.steps * 1e3
+    value = pairs_total / (dt / args.steps)
+
+    cs0 = None
+    if is_root:
+        cs0 = eng_of[0].operand() if eng_of else (teng.full if teng is not None else L[0]["cs"])
+        max_distinct, nbits, mean_nbits = cs0.planes(stream)
+        algo_used = cs0.algo
+        k2_ms, prep_ms, my_pairs = per_rank[0]["pair_kernel_ms"], per_rank[0]["prepare_chain_ms"], per_rank[0]["pairs"]
+        alg_bytes = 8 * S * N + 4 * my_pairs
+        achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
+        kname = "k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2_direct_kernel"
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "traffic_source": "not measured at N > 1 (the N = 1 line measures the same kernel's traffic in its own run)",
+                    "kernel": kname, "kernel_ms": k2_ms, "algorithmic_bytes": alg_bytes, "prep_ms": prep_ms,
+                    "note": "rank 0's launch: 8*S*N bytes of sketches + 4 bytes per pair of ITS slab; equality counting is VALU-bound, not HBM-bound (SURVEY 8d)"}
+        ops = my_pairs * ((S + 31) // 32) * (mean_nbits + getattr(D, "BITSLICE_OPS_PER_GROUP_EXTRA", 2)) if algo_used == D.CMP_BITSLICE else my_pairs * S * 2
+        va = ops / (k2_ms * 1e-3) if k2_ms > 0 else 0.0
+        compute = {"bound": "valu", "unit": "lane-ops/s", "achieved": va, "peak": VALU_PEAK_LANEOPS, "frac": va / VALU_PEAK_LANEOPS,
+                   "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct}
+        if base is not None:
+            base["speedup"] = value / base["base_1gpu_same_config_pairs_per_s"]
+        model = None
+        if (N, S) == (50000, 1024) and W in MODEL_R03 and eng_of:
+            m = MODEL_R03[W]
+            model = dict(m, source="profiles/r03_mgpu_model.txt (loopback kernel durations + exchanges at 50 GB/s per link + 6 us per enqueue)",
+                         note="ms per phase instance; compare with phases.max_over_ranks_ms term by term")
+        line = {
+            "metric": "all-pairs sketch comparison throughput (pairs/s)", "value": value, "unit": "pairs/s",
+            "n_gpus": W, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{workload}: {N} pre-built OPH sketches, S={S}, all-pairs cmp only, {pairs_total} pairs, float32 Jaccard",
+                       "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if algo_used == D.CMP_BITSLICE else "direct",
+                       "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + pair kernel w/ fused epilogue; "
+                                "row-sharded sketches resident in HBM" if engine != "broadcast" else
+                                "RCCL broadcast of the whole matrix + prepare + pair kernel w/ fused epilogue on every rank"),
+                       "parallelism": f"upper-triangle rows sharded over {W} GPU(s) by pair count",
+                       "exchange_engine": ENGINE_NAME[engine],
+                       **({"transport": "loopback (all contexts on ONE device: a functional run, not a scaling measurement)"} if args.loopback else {}),
+                       **({"exchange_chunks": eng_of[0].chunks} if eng_of else {}),
+                       "slab_check": ("every rank's WHOLE slab equals a single-GPU computation over the whole matrix" if slab_check else
+                                      "MISMATCH between the sharded step and a single-GPU computation: this line is NOT a valid measurement")},
+            "scaling_base": base, "phases": phases, "model": model, "per_rank": per_rank,
+            "roofline": roofline, "compute": compute, "cpu_baseline": None,
+        }
+        if not slab_check:
+            line["valid"] = False
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)                      # the headline is OUT before any secondary leg can hang
+
+    # ---- secondary (cabi): the software-pipelined rate for a stream of matrices
+    if engine == "cabi" and not args.no_pipeline:
+        r = ranks[0]
+        want = L[r]["out"].clone()
+
+        def stream_step():
+            eng_of[r].enqueue_lut_dev(L[r]["rows"].data_ptr(), L[r]["lut"].data_ptr(), L[r]["out"].data_ptr(), stream, input_ready=True)
+        stream_step(); stream_step()
+        sync_all()
+        sdt = timed_run(stream_step)
+        same = allreduce(1.0 if torch.equal(want, L[r]["out"]) else 0.0, "min") == 1.0
+        if is_root:
+            line["stream_of_matrices"] = {"value": pairs_total / (sdt / args.steps), "unit": "pairs/s", "ms_per_step": sdt / args.steps * 1e3,
+                                          "outputs_identical_to_the_one_job_step": same,
+                                          "note": "NOT the headline: throughput over repeated matrices with the exchange + prepare of step i+1 hidden "
+                                                  "under the pair kernel of step i (d2g_allpairs_enqueue_lut_dev); BASELINE config 4 is one job"}
+            print(json.dumps(line), flush=True)
+        del want
+
+    # ---- secondary (--all-legs): K1 sketch construction sharded by input, no collectives
+    if args.all_legs and not args.no_sketch:
+        from dashing2_amd import synth
+        n_all, Lg, k = args.sketch_genomes, args.sketch_len, 31
+        n_g = max(1, n_all // W)
+        secs, bases, k1 = 0.0, 0, []
+        for r in ranks:
+            d = L[r]
+            torch.cuda.set_device(dev_of(r))
+            packed_np, run_start, run_len, goff, _ = pack_genomes(D, synth, r * n_g, n_g, Lg, k)
+            packed = torch.from_numpy(packed_np).to(d["dev"])
+            plan = d["ctx"].oph_plan(run_start, run_len, goff, k)
+            regs_dev = torch.empty((n_g, D.oph_m(S)), dtype=torch.int64, device=d["dev"])
+            d["k1"] = (plan, packed, regs_dev)
+            bases += int(plan.nbases)
+        for rep in range(2):
+            barrier()
+            for r in ranks:
+                L[r]["ctx"].set_timing(D.TIME_K1)
+                L[r]["ctx"].kernel_ms("k1")
+            t0 = time.perf_counter()
+            for _ in range(5):
+                for r in ranks:
+                    plan, packed, regs_dev = L[r]["k1"]
+                    L[r]["ctx"].oph_sketch_dev(plan, packed.data_ptr(), S, regs_dev.data_ptr(), stream=stream)
+            barrier()
+            secs = allreduce((time.perf_counter() - t0) / 5, "max")
+        k1 = gather_obj([L[r]["ctx"].kernel_ms("k1")[1] for r in ranks])
+        bases_all = bases * (W if ranked else 1)
+        if is_root:
+            line["sketch"] = {"metric": "sketch input bases/s (K1 kernel, packed bases resident in HBM), inputs sharded one block per GPU, no collectives",
+                              "value": bases_all / secs, "unit": "bases/s", "ms_per_step": secs * 1e3, "k1_kernel_ms_per_rank": k1,
+                              "config": {"workload": f"BASELINE config 2 shape: {n_g * W} synthetic random genomes x {Lg} bp, k=31, S={S}, OPH, canonical; {n_g} genomes per GPU"}}
+            print(json.dumps(line), flush=True)
+
+    for r in ranks:
+        if r in eng_of:
+            eng_of[r].close()
+    if teng is not None:
+        teng.close()
+    for c in comms or []:
+        c.close()
+    for r in ranks:
+        if "cs" in L[r]:
+            L[r]["cs"].close()
+        L[r]["ctx"].close()
+    if ranked:
+        dist.destroy_process_group()
+
+
+# ======================================================================================================================
+# roofline.traffic measured in THIS run: a child under rocprofv3 --pmc re-runs one launch of each reported kernel
+# ======================================================================================================================
+def pmc_child(args):
+    """`bench.py --pmc-child k2,k1,k3` (run under rocprofv3 by measure_traffic): ONE launch of each reported kernel on the shapes
+    the line reports -- the config-3 prepare chain + pair kernel, the 1000-genome K1 launch, one 250-genome K3 call of either key
+    path.  K1 / K3 read random 2-bit bases generated on the device (the same bytes per base as packed genomes)."""
+    import torch
+    import dashing2_amd as D
+    from dashing2_amd import synth
+    which = set(args.pmc_child.split(","))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = D.Context(0)
+    S = args.sketchsize
+    if "k2" in which:
+        N = args.sketches or 10000
+        regs = synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928)
+        sig, _ = D.oph_finalize(regs, S, nthreads=host_cores())
+        sig_dev = torch.from_numpy(sig.view(np.int64)).to(dev)
+        lut = torch.from_numpy(D.epilogue_lut(S, D.SIMILARITY, 31)).to(dev)
+        out = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
+        cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=D.CMP_AUTO, stream=None)
+        cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), 0, N, None)
+        torch.cuda.synchronize()
+        cs.close()
+        del sig_dev, out
+    L = args.sketch_len
+    Lb = ((L + 3) // 4 + 63) // 64 * 64
+
+    def plan_for(n, k):
+        return ctx.oph_plan(np.arange(n, dtype=np.uint64) * np.uint64(Lb * 4), np.full(n, L, np.uint32), np.arange(n + 1, dtype=np.uint64), k)
+
+    if "k1" in which:
+        n = args.sketch_genomes
+        packed = torch.randint(0, 256, (n * Lb + 64,), dtype=torch.uint8, device=dev)
+        regs_dev = torch.empty((n, D.oph_m(S)), dtype=torch.int64, device=dev)
+        ctx.oph_sketch_dev(plan_for(n, 31), packed.data_ptr(), S, regs_dev.data_ptr(), stream=None)
+        torch.cuda.synchronize()
+        del packed, regs_dev
+    if "k3" in which:
+        nb = max(1, min(args.multiset_batch, args.multiset_genomes))
+        packed = torch.randint(0, 256, (nb * Lb + 64,), dtype=torch.uint8, device=dev)
+        sig3 = torch.empty((nb, 2048), dtype=torch.float64, device=dev)
+        tw3 = torch.empty((nb,), dtype=torch.float64, device=dev)
+        plan = plan_for(nb, 21)
+        for compact in ("0", "1"):
+            os.environ["D2G_K3_COMPACT"] = compact
+            ctx.bmh_sketch_dev(plan, packed.data_ptr(), 2048, sig3.data_ptr(), tw3.data_ptr(), stream=None)
+            torch.cuda.synchronize()
+            print("PMC-CHILD k3 compact=%s done" % compact, flush=True)     # a marker per call; the CSV keeps dispatch order
+    ctx.close()
+
+
+K3_DEFAULT = ("k3_hist_kernel", "k3_scan_kernel", "k3_scatter_kernel", "k3_refine_kernel", "k3_split_kernel", "k3_bmh_main_kernel", "k3_bmh_survivor", "k3_bmh_verify", "k3_bmh_init")
+K3_COMPACT_ONLY = ("k3c_hist", "k3c_scan", "k3c_scatter")
+
+
+def measure_traffic(args, which=("k2", "k1", "k3"), timeout=240.0):
+    """-> {"k2": bytes, "k2_prepare": bytes, "k1": bytes, "k3": bytes, "k3_compact": bytes, "seconds": s} measured now, or
+    {"error": why}.  FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md: TCC has 4 slots, they cost 3 + 2): two
+    passes of the same child, counters only beside --kernel-trace.  rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies wide
+    (16 B per lane) coalesced reads at half their bytes: doubled for K1 (dwordx4 loads), raw for K2 / K3 (dword / dwordx2 loads)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not found"}
+    t0 = time.monotonic()
+    tmp = tempfile.mkdtemp(prefix="d2g_pmc_", dir="/tmp")
+    rows = {}                                                   # counter -> [(kernel name, dispatch id, value)]
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            od = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-f", "csv", "-d", od, "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", ",".join(which), "--sketches", str(args.sketches or 10000), "--sketchsize", str(args.sketchsize),
+                   "--sketch-genomes", str(args.sketch_genomes), "--sketch-len", str(args.sketch_len),
+                   "--multiset-genomes", str(args.multiset_genomes), "--multiset-batch", str(args.multiset_batch)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for kk in ("D2G_K3_COMPACT", "D2G_BS_SORT"):
+                env.pop(kk, None)
+            left = timeout - (time.monotonic() - t0)
+            if left < 20:
+                return {"error": "time budget for the counter passes used up"}
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=left, start_new_session=True)
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {ctr} exited with {r.returncode}: " + r.stdout.decode("utf-8", "replace")[-300:]}
+            got = []
+            for f in sorted(glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True)):
+                for rec in csv.DictReader(open(f)):
+                    if rec.get("Counter_Name") == ctr:
+                        got.append((rec["Kernel_Name"], int(rec.get("Dispatch_Id", 0) or 0), float(rec["Counter_Value"]) * 1024.0))
+            if not got:
+                return {"error": f"no {ctr} rows in rocprofv3's output"}
+            rows[ctr] = sorted(got, key=lambda x: x[1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"rocprofv3 pass timed out ({timeout:.0f} s budget)"}
+    except Exception as e:                                      # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def total(ctr, pred, largest=False):
+        v = [b for (k, _, b) in rows[ctr] if pred(k)]
+        if not v:
+            return None
+        return max(v) if largest else sum(v)
+
+    def both(pred, wide=False, largest=False):
+        rd, wr = total("FETCH_SIZE", pred, largest), total("WRITE_SIZE", pred, largest)
+        if rd is None or wr is None:
+            return None
+        return rd * (2 if wide else 1) + wr
+
+    res = {"seconds": round(time.monotonic() - t0, 1)}
+    if "k2" in which:
+        res["k2"] = both(lambda k: "k2_bitslice_kernel" in k or "k2_direct_kernel" in k, largest=True)
+        res["k2_prepare"] = both(lambda k: any(x in k for x in ("bs_transpose", "bs_rank", "bs_colplan", "bs_planes", "k2_transpose")))
+    if "k1" in which:
+        res["k1"] = both(lambda k: "k1_oph_kernel" in k, wide=True, largest=True)
+    if "k3" in which:
+        # the child makes ONE default call, then ONE compact call: split the k3 dispatches at the first compact-only kernel
+        def split(ctr):
+            d, c, seen_c = 0.0, 0.0, False
+            for (k, _, b) in rows[ctr]:
+                if not ("k3_" in k or "k3c_" in k):
+                    continue
+                if any(x in k for x in K3_COMPACT_ONLY):
+                    seen_c = True
+                # the second call starts with its init kernel; everything after the first call's verify belongs to it
+                if seen_c:
+                    c += b
+                else:
+                    d += b
+            return d, c
+        (rd_d, rd_c), (wr_d, wr_c) = split("FETCH_SIZE"), split("WRITE_SIZE")
+        # k3_bmh_init of the second call precedes its first compact-only kernel: negligible (it writes n*S*8 bytes), left with the default call
+        res["k3"] = rd_d + wr_d if (rd_d + wr_d) > 0 else None
+        res["k3_compact"] = rd_c + wr_c if (rd_c + wr_c) > 0 else None
+    return res
+
+
+def run_single(args):
+    import torch
+    import dashing2_amd as D
+    from dashing2_amd import synth
+
+    rank, world = 0, 1
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ctx = D.Context(0)
+    algo = {"auto": D.CMP_AUTO, "direct": D.CMP_DIRECT, "bitslice": D.CMP_BITSLICE}[args.algo]
+    S = args.sketchsize
+    N = args.sketches or 10000
+    workload = "BASELINE config 3" if (N, S) == (10000, 1024) else "custom"
+    pairs_total = N * (N - 1) // 2
+    r0, r1 = 0, N
+    my_pairs = pairs_total
     stream = torch.cuda.current_stream().cuda_stream
     ncores = host_cores()
 
@@ -404,151 +1080,18 @@ def main():
         regs = synth.synthetic_registers(n, S, nclusters=max(8, n // 150), seed=seed)
         return D.oph_finalize(regs, S, nthreads=ncores)
 
-    # ---- synthetic pre-built sketches, resident in HBM before the timed region.
-    # N == 1 or --exchange broadcast: the whole matrix lives on rank 0.
-    # N > 1 (default): rank r holds rows [r N/W, (r+1) N/W) -- what sharded sketching leaves behind.
-    sig_np = cards_np = None
-    if rank == 0:
-        sig_np, cards_np = make_sketches(N)
-        sig_dev = torch.from_numpy(sig_np.view(np.int64)).to(dev)
-    else:
-        sig_dev = torch.empty((N, S), dtype=torch.int64, device=dev)
+    # ---- synthetic pre-built sketches, resident in HBM before the timed region
+    sig_np, cards_np = make_sketches(N)
+    sig_dev = torch.from_numpy(sig_np.view(np.int64)).to(dev)
     lut = torch.from_numpy(D.epilogue_lut(S, D.SIMILARITY, 31)).to(dev)
     out = torch.empty(max(my_pairs, 1), dtype=torch.float32, device=dev)
-    if world > 1:
-        dist.broadcast(sig_dev, 0)                           # untimed distribution of the synthetic input
-    eng = cs = comm = None
-    pipelined = False                 # the headline step is always ONE job's step; the stream form is measured afterwards
-    exchange_fallback = None
-    engine_kind = None
-    if sharded:
-        # The N > 1 data path: the row-sharded engine behind the C ABI (d2g_comm_* / d2g_allpairs_*: RCCL linked by
-        # libd2g itself; torch.distributed only carries the 128-byte unique id, the barrier and the timing reductions).
-        # First (untimed) pass under a guard: a failure on any rank (every rank learns it through one flag all-reduce)
-        # falls back to the torch.distributed form of the same exchange, then to the whole-matrix broadcast, instead of
-        # losing the measurement.
-        def all_failed(err):
-            if world > 1:
-                flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float64, device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                if flag.item() > 0 and err is None:
-                    err = "failed on another rank"
-            return err
+    cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
 
-        # every collective below is entered by ALL ranks or by none: a rank that fails alone must not leave the others
-        # blocked inside an RCCL call, so each local stage is followed by a flag all-reduce before the next collective
-        err = None
-        uid = [None]
-        if rank == 0:
-            try:
-                uid = [D.comm_unique_id()]
-            except Exception as e:                               # noqa: BLE001
-                err = f"C-ABI engine: {type(e).__name__}: {e}"
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)
-        if uid[0] is None and err is None:
-            err = "C-ABI engine: no RCCL unique id from rank 0"
-        if err is None:
-            try:
-                comm = D.Comm.create(ctx, rank, world, uid[0])   # ncclCommInitRank: collective, all ranks got the id
-                import ctypes
-                ctypes.CDLL(None).fflush(None)   # RCCL prints a version banner through C stdio: out now, not after the JSON line
-                eng = D.AllPairs(ctx, comm, N, S)
-                assert eng.rows_computed == (r0, r1)
-                lo, hi = eng.rows_held
-                my_rows = sig_dev[lo:hi].clone()
-            except Exception as e:                               # noqa: BLE001 - reported in the JSON line
-                err = f"C-ABI engine: {type(e).__name__}: {e}"
-        err = all_failed(err)
-        if err is None:
-            try:
-                eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
-                torch.cuda.synchronize()
-            except Exception as e:                               # noqa: BLE001
-                err = f"C-ABI engine: {type(e).__name__}: {e}"
-        err = all_failed(err)
-        if err is None:
-            engine_kind = "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv groups)"
-
-            def step():
-                # ONE job: all-to-all (rows -> column slices), prepare of S/W columns, all-gather of the planes, pair kernel --
-                # chunk by chunk inside the step (the exchange of chunk c+1 under the prepare of chunk c), nothing carried over
-                eng.step_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream)
-
-            def stream_step():
-                # a STREAM of matrices: exchange + prepare of the next step under this step's pair kernel (two operand buffers)
-                eng.enqueue_lut_dev(my_rows.data_ptr(), lut.data_ptr(), out.data_ptr(), stream, input_ready=True)
-            plain_step = step
-            cs = eng.operand()
-        else:
-            exchange_fallback = err
-            eng = None
-            err2 = None
-            try:
-                from dashing2_amd import dist as DD
-                n_loc = N // world
-                my_rows = sig_dev[rank * n_loc:(rank + 1) * n_loc].clone()
-                teng = DD.RowShardedAllPairs(ctx, N, S, dev)
-                assert (teng.r0, teng.r1) == (r0, r1)
-                teng.step_lut(my_rows, lut, out, stream)
-                torch.cuda.synchronize()
-            except Exception as e:                               # noqa: BLE001
-                err2 = f"torch engine: {type(e).__name__}: {e}"
-            err2 = all_failed(err2)
-            if err2 is None:
-                engine_kind = "torch.distributed (dashing2_amd.dist.RowShardedAllPairs)"
-                eng = teng
-
-                def step():
-                    teng.step_lut(my_rows, lut, out, stream)
-
-                def stream_step():
-                    teng.enqueue_lut(my_rows, lut, out, ready=False)    # my_rows was complete before the timed region
-                plain_step = step
-                cs = teng.full
-            else:
-                exchange_fallback += " | " + err2
-                sharded = False
-    slab_check = None
-    if sharded:
-        # The multi-GPU exchange has never run on hardware before the driver's scaling run: every rank checks the first and the
-        # last rows of the slab the sharded step just wrote against a single-GPU computation over the WHOLE matrix (which it still
-        # holds from the untimed distribution).  A mismatch anywhere is reported in the line ("valid": false), never hidden.
-        try:
-            ref = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
-            ok = True
-            for a, z in ((r0, min(r0 + 2, r1)), (max(r0, r1 - 2), r1)):
-                if z <= a:
-                    continue
-                n_chk = D.ut_count(N, a, z)
-                want = torch.empty(n_chk, dtype=torch.float32, device=dev)
-                ref.lut_ut_dev(lut.data_ptr(), want.data_ptr(), a, z, stream)
-                torch.cuda.synchronize()
-                o0 = D.ut_count(N, r0, a)
-                ok = ok and bool(torch.equal(want.view(torch.int32), out[o0:o0 + n_chk].view(torch.int32)))
-            ref.close()
-            del ref
-        except Exception as e:                                   # noqa: BLE001
-            ok = False
-            exchange_fallback = (exchange_fallback or "") + f" | slab check failed to run: {type(e).__name__}: {e}"
-        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        slab_check = bool(flag.item() == 1.0)
-        del sig_dev
-    else:
-        cs = ctx.cmp_set_dev(sig_dev.data_ptr(), N, S, algo=algo, stream=stream)
-
-        def step():
-            if world > 1:
-                dist.broadcast(sig_dev, 0)                      # the path's one exchange (RCCL over xGMI)
-            cs.update_dev(sig_dev.data_ptr(), stream)           # transpose + ids + planes (async)
-            cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), r0, r1, stream)   # pair kernel + fused epilogue
+    def step():
+        cs.update_dev(sig_dev.data_ptr(), stream)           # transpose + ids + planes (async)
+        cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), r0, r1, stream)   # pair kernel + fused epilogue
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
 
     def timed_run(step):
@@ -573,43 +1116,7 @@ def main():
     dt = timed_run(step)
     nk2, k2_ms, _ = ctx.kernel_ms("k2")
     _, prep_ms, _ = ctx.kernel_ms("k2prep")
-    # the gathered prepare status: a rank-table overflow on ANY rank invalidates the step everywhere (never silent)
-    if sharded and engine_kind and engine_kind.startswith("libd2g"):
-        eng.status(stream)
-    stream_of_matrices = None
-    if sharded and not args.no_pipeline:
-        # secondary: the software-pipelined rate for a stream of matrices.  Probed on every rank first (a failure anywhere
-        # skips it everywhere), timed like the headline, and its output checked against the plain step's.
-        want = out.clone()
-        perr = None
-        try:
-            stream_step(); stream_step()
-            torch.cuda.synchronize()
-        except Exception as e:                                   # noqa: BLE001
-            perr = f"{type(e).__name__}: {e}"
-        perr = all_failed(perr)
-        if perr is None:
-            sdt = timed_run(stream_step)
-            ctx.kernel_ms("k2")
-            if world > 1:
-                t = torch.tensor([sdt], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                sdt = float(t.item())
-            same = torch.tensor([1.0 if torch.equal(want, out) else 0.0], dtype=torch.float64, device=dev)
-            if world > 1:
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            stream_of_matrices = {"value": pairs_total / (sdt / args.steps), "unit": "pairs/s", "ms_per_step": sdt / args.steps * 1e3,
-                                  "outputs_identical_to_the_one_job_step": bool(same.item() == 1.0),
-                                  "note": "NOT the headline: throughput over repeated matrices with the exchange + prepare of step i+1 hidden "
-                                          "under the pair kernel of step i (d2g_allpairs_enqueue_lut_dev); BASELINE config 4 is one job"}
-        else:
-            stream_of_matrices = {"error": perr}
-        del want
     max_distinct, nbits, mean_nbits = cs.planes(stream)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = pairs_total / (dt / args.steps)
     algo_used = cs.algo
@@ -619,16 +1126,17 @@ def main():
     alg_bytes = 8 * S * N + 4 * my_pairs          # each sketch read once + one float per pair
     achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
     kname = "k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2_direct_kernel"
-    pmc_ok = (algo_used == D.CMP_BITSLICE and world == 1 and N == 10000 and S == 1024)
+    pmc_ok = (algo_used == D.CMP_BITSLICE and N == 10000 and S == 1024)
     with_prep = alg_bytes / ((k2_ms + prep_ms) * 1e-3) / 1e9 if (k2_ms + prep_ms) > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 # the 8 S N bytes of the sketches are read by the PREPARE chain, not by the pair kernel: the same algorithmic
                 # bytes over pair kernel + prepare
                 "frac_with_prepare": with_prep / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(kname, False) if pmc_ok else None,
-                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes) of this command, the config-3-sized (largest) "
-                                "dispatch, profiles/" + os.path.basename(PMC_FILE) + "; dword loads: read side raw/uncalibrated",
+                "traffic": pmc_traffic(kname, False) if pmc_ok else None,          # replaced below by this run's own counter passes
+                "traffic_source": ("profiles/" + os.path.basename(PMC_FILE) + " (committed)") if pmc_ok else None,
+                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), the config-3-sized (largest) dispatch of the pair kernel; "
+                                "dword loads: read side raw/uncalibrated",
                 "kernel": kname, "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
                 "prep_ms": prep_ms,
                 "note": "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute"}
@@ -677,7 +1185,7 @@ def main():
                 "valu_frac": valu(npairs, mean, kms)[1]}
 
     config4 = None
-    if world == 1 and not args.force_sharded:
+    if True:
         del out
         torch.cuda.empty_cache()
         if not args.no_matrices:
@@ -717,21 +1225,12 @@ def main():
         torch.cuda.empty_cache()
 
     def guarded(fn):
-        """A secondary leg does LOCAL work only and returns (seconds, build(seconds_max) -> dict).  One
-        collective afterwards carries the failure flag and the max time, so an exception on any rank
-        becomes {"error": ...} on all of them instead of hanging the others or losing the primary line."""
-        err, secs, build = None, 0.0, None
+        """a secondary leg returns (seconds, build(seconds) -> dict); an exception becomes {"error": ...} instead of losing the primary line"""
         try:
             secs, build = fn()
+            return build(secs)
         except Exception as e:                                   # noqa: BLE001 - reported, not swallowed
-            err = f"{type(e).__name__}: {e}"
-        if world > 1:
-            t = torch.tensor([1.0 if err else 0.0, secs], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            if t[0].item() > 0 and err is None:
-                err = "failed on another rank"
-            secs = float(t[1].item())
-        return {"error": err} if err else build(secs)
+            return {"error": f"{type(e).__name__}: {e}"}
 
     # ---- secondary: K1 sketch construction (config 2's shape).  Inputs: synthetic genomes rendered as FASTA
     # and ingested by the product's own parser/packer (d2g_seqpack); the packed run stream is resident in
@@ -878,8 +1377,7 @@ def main():
             return o
         return sdt, build
 
-    secondary = world == 1 or args.all_legs
-    sketch = None if (args.no_sketch or not secondary) else guarded(sketch_leg)
+    sketch = None if args.no_sketch else guarded(sketch_leg)
 
     # ---- secondary: K3 --multiset sketch construction (BASELINE config 5: k=21, S=2048, exact k-mer
     # counts -> BagMinHash), packed bases resident in HBM
@@ -985,36 +1483,55 @@ def main():
             return out
         return mdt, build
 
-    multiset = None if (args.no_multiset or not secondary) else guarded(multiset_leg)
+    multiset = None if args.no_multiset else guarded(multiset_leg)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         cpu = cpu_baseline(sig_np, cards_np, S, args.cpu_seconds)
 
-    if rank == 0:
+    # ---- HBM traffic of the reported kernels, measured NOW: a child under rocprofv3 --pmc (two passes) re-runs one launch of each
+    # on the shapes reported above; the committed profile is only the fallback (and says so)
+    if not args.no_traffic:
+        del sig_dev
+        torch.cuda.empty_cache()
+        want = ["k2"] + (["k1"] if isinstance(sketch, dict) and "roofline" in sketch else []) + \
+               (["k3"] if isinstance(multiset, dict) and "roofline" in multiset else [])
+        tm = measure_traffic(args, which=want)
+        src_ok = "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes, %.0f s) over one launch of the same shape" % tm.get("seconds", 0.0)
+        src_bad = "profiles/" + os.path.basename(PMC_FILE) + " (committed; this run's counter passes failed: %s)" % tm.get("error", "no rows for this kernel")
+
+        def put(rf, key, shape_ok=True):
+            if tm.get(key) and shape_ok:
+                rf["traffic"], rf["traffic_source"] = tm[key], src_ok
+            elif rf.get("traffic") is not None:
+                rf["traffic_source"] = src_bad
+        put(roofline, "k2")
+        if tm.get("k2_prepare"):
+            roofline["traffic_prepare_chain"] = tm["k2_prepare"]
+        if isinstance(sketch, dict) and "roofline" in sketch:
+            put(sketch["roofline"], "k1")
+        if isinstance(multiset, dict) and "roofline" in multiset:
+            put(multiset["roofline"], "k3")
+            if isinstance(multiset.get("low_traffic_variant"), dict):
+                put(multiset["low_traffic_variant"], "k3_compact")
+    else:
+        for leg in (sketch, multiset):
+            if isinstance(leg, dict) and isinstance(leg.get("roofline"), dict) and leg["roofline"].get("traffic") is not None:
+                leg["roofline"]["traffic_source"] = "profiles/" + os.path.basename(PMC_FILE) + " (committed; --no-traffic)"
+
+    if True:
         line = {
             "metric": "all-pairs sketch comparison throughput (pairs/s)", "value": value, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak" if (world > 1 and scaling == "weak") else "strong", "vs_baseline": None, "dtype": "u64",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": f"{workload}: {N} pre-built OPH sketches, S={S}, all-pairs cmp only, {pairs_total} pairs, float32 Jaccard",
                        "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if algo_used == D.CMP_BITSLICE else "direct",
-                       "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + pair kernel w/ fused epilogue; row-sharded sketches resident in HBM"
-                                if sharded else "RCCL broadcast (n_gpus>1) + prepare + pair kernel w/ fused epilogue; sketches resident in HBM"),
-                       "parallelism": f"upper-triangle rows sharded over {world} GPU(s) by pair count",
-                       **({"exchange_engine": engine_kind} if engine_kind else {}),
-                       **({"exchange_fallback": exchange_fallback} if exchange_fallback else {}),
-                       **({"exchange_chunks": eng.chunks} if (eng is not None and hasattr(eng, "chunks")) else {}),
-                       **({"slab_check": "every rank's first and last slab rows equal a single-GPU computation" if slab_check
-                           else "MISMATCH between the sharded step and a single-GPU computation: this line is NOT a valid measurement"}
-                          if slab_check is not None else {})},
+                       "step": "prepare + pair kernel w/ fused epilogue; sketches resident in HBM",
+                       "parallelism": "one GPU"},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "config4_1gpu": config4,
             "sketch": sketch, "multiset_sketch": multiset,
         }
-        if slab_check is False:
-            line["valid"] = False
-        if stream_of_matrices is not None:
-            line["stream_of_matrices"] = stream_of_matrices
         # compact copies of the two secondary legs INSIDE roofline / cpu_baseline: these two objects are what the driver's
         # record keeps of the line (the full legs stay at top level)
         def brief(leg):
@@ -1035,15 +1552,19 @@ def main():
         import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
-    if eng is not None:
-        eng.close()
-        if comm is not None:
-            comm.close()
-    else:
-        cs.close()
+    cs.close()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.gpus > 1:
+        if args.worker:
+            return run_multi(args)
+        raise SystemExit(supervise(args))
+    run_single(args)
 
 
 if __name__ == "__main__":

@@ -130,6 +130,8 @@ SIGNATURES = {
     "d2g_allpairs_operand": (_vp, [_vp]),
     "d2g_allpairs_status": (_int, [_vp, _vp]),
     "d2g_allpairs_chunks": (_int, [_vp]),
+    "d2g_allpairs_set_phase_timing": (_int, [_vp, _int]),
+    "d2g_allpairs_phase_times": (_int, [_vp, _int, C.POINTER(_int), _vp, _vp, _vp, _vp]),
     "d2g_allpairs_step_lut_dev": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "d2g_allpairs_step_eqcount_dev": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_allpairs_step_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -878,6 +880,23 @@ class AllPairs:
     @property
     def chunks(self):
         return lib().d2g_allpairs_chunks(self._h)
+
+    PHASE_NAMES = ("pack", "x1", "prepare", "x2", "derive", "pair")
+
+    def set_phase_timing(self, on=True):
+        """bracket every phase of the next prepare/step with timing events (switch off again for timed runs)"""
+        self.ctx._check(lib().d2g_allpairs_set_phase_timing(self._h, int(bool(on))))
+
+    def phase_times(self):
+        """synchronises; -> [{"phase", "chunk", "start_ms", "ms"}] of the last step enqueued with phase timing on"""
+        cap = 64
+        kind, chunk = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        start, dur = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        n = _int()
+        self.ctx._check(lib().d2g_allpairs_phase_times(self._h, cap, C.byref(n), kind.ctypes.data, chunk.ctypes.data,
+                                                       start.ctypes.data, dur.ctypes.data))
+        return [{"phase": self.PHASE_NAMES[int(kind[i])], "chunk": int(chunk[i]), "start_ms": float(start[i]), "ms": float(dur[i])}
+                for i in range(n.value)]
 
     def step_lut_dev(self, rows_ptr, lut_ptr, out_ptr, stream=None):
         self.ctx._check(lib().d2g_allpairs_step_lut_dev(self._h, rows_ptr, lut_ptr, out_ptr, stream))

@@ -23,6 +23,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -98,6 +99,7 @@ struct d2g_comm {
     d2g_ctx *ctx = nullptr;
     int rank = 0, world = 1;
     ncclComm_t nccl = nullptr;                 // RCCL transport (distinct devices)
+    bool ranked = false;                       // created by d2g_comm_create: its peers are other processes / threads
     std::shared_ptr<LocalGroup> lg;            // loopback transport (one process, any devices)
 };
 
@@ -233,6 +235,12 @@ struct d2g_allpairs {
     bool p_valid[2] = {false, false}, plain_valid = false;
     unsigned long long nsteps = 0;
     int last = 0;                        // buffer of the most recent prepare
+    // per-phase timing of ONE step (d2g_allpairs_set_phase_timing): timing-enabled event pairs around every phase, on the
+    // stream the phase is enqueued on; nothing synchronises until d2g_allpairs_phase_times
+    struct PhaseEv { hipEvent_t a, b; int kind, chunk; };
+    bool phase_timing = false;
+    hipEvent_t ev_step0 = nullptr;
+    std::vector<PhaseEv> pev;
     int blk(int q, int c) const { return q * C + c; }
     size_t n_me() const { return row_lo[rank + 1] - row_lo[rank]; }
     size_t w_blk(int b) const { return colstart[b + 1] - colstart[b]; }
@@ -255,6 +263,38 @@ int eng_alloc_buffer(d2g_allpairs *e, int b) {
     e->full[b]->status_words = e->d_meta[b] + e->ng;
     e->full[b]->n_status = (int)nstat;
     return D2G_OK;
+}
+
+// phase timing: begin/end bracket a phase's enqueue on stream s (no-ops unless enabled)
+void pt_clear(d2g_allpairs *e) {
+    for (auto &p : e->pev) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
+    e->pev.clear();
+    if (e->ev_step0) { (void)hipEventDestroy(e->ev_step0); e->ev_step0 = nullptr; }
+}
+int pt_step_begin(d2g_allpairs *e, hipStream_t s) {
+    if (!e->phase_timing) return D2G_OK;
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    pt_clear(e);
+    D2G_HIP(e->ctx, hipEventCreate(&e->ev_step0));
+    D2G_HIP(e->ctx, hipEventRecord(e->ev_step0, s));
+    return D2G_OK;
+}
+int pt_begin(d2g_allpairs *e, int kind, int chunk, hipStream_t s) {
+    if (!e->phase_timing) return D2G_OK;
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    d2g_allpairs::PhaseEv p{nullptr, nullptr, kind, chunk};
+    D2G_HIP(e->ctx, hipEventCreate(&p.a));
+    D2G_HIP(e->ctx, hipEventCreate(&p.b));
+    e->pev.push_back(p);
+    D2G_HIP(e->ctx, hipEventRecord(p.a, s));
+    return D2G_OK;
+}
+int pt_end(d2g_allpairs *e, int kind, int chunk, hipStream_t s) {
+    if (!e->phase_timing) return D2G_OK;
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    for (size_t i = e->pev.size(); i-- > 0;)
+        if (e->pev[i].kind == kind && e->pev[i].chunk == chunk) { D2G_HIP(e->ctx, hipEventRecord(e->pev[i].b, s)); return D2G_OK; }
+    return D2G_ERR_INTERNAL;
 }
 
 // phases of one step on buffer b
@@ -325,39 +365,87 @@ int prepare_many(d2g_allpairs **es, int n, const uint64_t *const *rows, const in
     for (int i = 0; i < n; ++i) MG_TRY(eng_alloc_buffer(es[i], bufs[i]));
     for (int i = 0; i < n; ++i) {
         d2g_allpairs *e = es[i];
+        MG_TRY(pt_step_begin(e, cs[i]));
+        MG_TRY(pt_begin(e, D2G_PHASE_PACK, 0, cs[i]));
         MG_TRY(phase_pack(e, rows[i], cs[i]));
+        MG_TRY(pt_end(e, D2G_PHASE_PACK, 0, cs[i]));
         D2G_HIP(e->ctx, hipEventRecord(e->ev_pack, cs[i]));
         D2G_HIP(e->ctx, hipStreamWaitEvent(e->xs, e->ev_pack, 0));
     }
     for (int c = 0; c < C; ++c) {                                       // all row->column exchanges, back to back on xs
+        for (int i = 0; i < n; ++i) MG_TRY(pt_begin(es[i], D2G_PHASE_X1, c, es[i]->xs));
         MG_TRY(comm_group_begin(es[0]->comm));
         for (int i = 0; i < n; ++i) if (int rc = phase_x1(es[i], c, es[i]->xs)) { (void)comm_group_end(es[0]->comm); return rc; }
         MG_TRY(comm_group_end(es[0]->comm));
-        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipEventRecord(es[i]->ev_x1[c], es[i]->xs)); }
+        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipEventRecord(es[i]->ev_x1[c], es[i]->xs)); MG_TRY(pt_end(es[i], D2G_PHASE_X1, c, es[i]->xs)); }
     }
     for (int c = 0; c < C; ++c)                                         // chunk c is prepared while chunk c+1 is still arriving
         for (int i = 0; i < n; ++i) {
             d2g_allpairs *e = es[i];
             D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
             D2G_HIP(e->ctx, hipStreamWaitEvent(cs[i], e->ev_x1[c], 0));
+            MG_TRY(pt_begin(e, D2G_PHASE_PREPARE, c, cs[i]));
             MG_TRY(phase_prepare(e, c, bufs[i], cs[i]));
+            MG_TRY(pt_end(e, D2G_PHASE_PREPARE, c, cs[i]));
             D2G_HIP(e->ctx, hipEventRecord(e->ev_prep[c], cs[i]));
         }
     for (int c = 0; c < C; ++c) {                                       // its planes leave while chunk c+1 is prepared
-        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipStreamWaitEvent(es[i]->xs, es[i]->ev_prep[c], 0)); }
+        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipStreamWaitEvent(es[i]->xs, es[i]->ev_prep[c], 0)); MG_TRY(pt_begin(es[i], D2G_PHASE_X2, c, es[i]->xs)); }
         MG_TRY(comm_group_begin(es[0]->comm));
         for (int i = 0; i < n; ++i) if (int rc = phase_x2(es[i], c, bufs[i], es[i]->xs)) { (void)comm_group_end(es[0]->comm); return rc; }
         MG_TRY(comm_group_end(es[0]->comm));
-        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipEventRecord(es[i]->ev_x2[c], es[i]->xs)); }
+        for (int i = 0; i < n; ++i) { D2G_HIP(es[i]->ctx, hipSetDevice(es[i]->ctx->device)); D2G_HIP(es[i]->ctx, hipEventRecord(es[i]->ev_x2[c], es[i]->xs)); MG_TRY(pt_end(es[i], D2G_PHASE_X2, c, es[i]->xs)); }
     }
     for (int c = 0; c < C; ++c)                                         // plane stream of chunk c as soon as it is complete
         for (int i = 0; i < n; ++i) {
             d2g_allpairs *e = es[i];
             D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
             D2G_HIP(e->ctx, hipStreamWaitEvent(cs[i], e->ev_x2[c], 0));
+            MG_TRY(pt_begin(e, D2G_PHASE_DERIVE, c, cs[i]));
             MG_TRY(d2g_bitslice_derive_groups(e->ctx, e->full[bufs[i]], (int)e->chunk_g0[c], (int)e->chunk_g0[c + 1], cs[i]));
+            MG_TRY(pt_end(e, D2G_PHASE_DERIVE, c, cs[i]));
         }
     for (int i = 0; i < n; ++i) es[i]->last = bufs[i];
+    return D2G_OK;
+}
+
+// One process per GPU: every rank derives the exchange lists from its OWN (N, S, world, chunks) -- chunks can be overridden by an
+// environment variable -- and a disagreement would post transfers of different sizes and counts (a hang or silent corruption).
+// Each rank sends its four numbers to every other rank once (fixed-size messages: this exchange itself cannot mismatch) and
+// compares.  It is also the first traffic over the communicator: a transport that cannot move bytes fails here, at create.
+int verify_shape_across_ranks(d2g_allpairs *e) {
+    d2g_comm *c = e->comm;
+    if (!c->ranked || !c->nccl || e->W < 2) return D2G_OK;
+    d2g_ctx *ctx = e->ctx;
+    const int W = e->W;
+    uint64_t *d_v = nullptr;
+    std::vector<uint64_t> all((size_t)W * 4, 0);
+    const uint64_t mine[4] = {(uint64_t)e->N, (uint64_t)e->S, (uint64_t)e->W, (uint64_t)e->C};
+    D2G_HIP(ctx, hipMalloc((void **)&d_v, (size_t)W * 32));
+    int rc = D2G_OK;
+    auto fail = [&](int r) { (void)hipFree(d_v); return r; };
+    if (hipMemcpy(d_v + (size_t)e->rank * 4, mine, 32, hipMemcpyHostToDevice) != hipSuccess) return fail(D2G_ERR_HIP);
+    if ((rc = comm_group_begin(c))) return fail(rc);
+    for (int q = 0; q < W && rc == D2G_OK; ++q) {
+        if (q == e->rank) continue;
+        rc = comm_send(c, q, d_v + (size_t)e->rank * 4, 32, e->xs);
+        if (rc == D2G_OK) rc = comm_recv(c, q, d_v + (size_t)q * 4, 32, e->xs);
+    }
+    const int rc2 = comm_group_end(c);
+    if (rc == D2G_OK) rc = rc2;
+    if (rc != D2G_OK) return fail(rc);
+    if (hipStreamSynchronize(e->xs) != hipSuccess || hipMemcpy(all.data(), d_v, (size_t)W * 32, hipMemcpyDeviceToHost) != hipSuccess) return fail(D2G_ERR_HIP);
+    (void)hipFree(d_v);
+    for (int q = 0; q < W; ++q)
+        if (std::memcmp(&all[(size_t)q * 4], mine, 32) != 0) {
+            char buf[256];
+            std::snprintf(buf, sizeof buf, "allpairs: rank %d has (N=%llu, S=%llu, world=%llu, chunks=%llu), rank %d has (N=%llu, S=%llu, world=%llu, chunks=%llu)"
+                          " -- the same shape and D2G_MGPU_CHUNKS are required on every rank", e->rank, (unsigned long long)mine[0], (unsigned long long)mine[1],
+                          (unsigned long long)mine[2], (unsigned long long)mine[3], q, (unsigned long long)all[(size_t)q * 4], (unsigned long long)all[(size_t)q * 4 + 1],
+                          (unsigned long long)all[(size_t)q * 4 + 2], (unsigned long long)all[(size_t)q * 4 + 3]);
+            ctx->last_error = buf;
+            return D2G_ERR_INVALID;
+        }
     return D2G_OK;
 }
 
@@ -402,6 +490,7 @@ int d2g_comm_create(d2g_ctx *ctx, const void *id, int rank, int world, d2g_comm 
         if (hipSetDevice(ctx->device) != hipSuccess) { delete c; return D2G_ERR_HIP; }
         const ncclResult_t rc = r->CommInitRank(&c->nccl, world, uid, rank);
         if (rc != ncclSuccess) { ctx->last_error = std::string("ncclCommInitRank: ") + r->GetErrorString(rc); delete c; return D2G_ERR_HIP; }
+        c->ranked = true;
     }
     *out = c;
     return D2G_OK;
@@ -563,6 +652,7 @@ int d2g_allpairs_create(d2g_ctx *ctx, d2g_comm *comm, size_t N, size_t S, d2g_al
             return D2G_ERR_HIP;
         }
     if (int rc = eng_alloc_buffer(e, 0)) { d2g_allpairs_destroy(e); return rc; }
+    if (int rc = verify_shape_across_ranks(e)) { d2g_allpairs_destroy(e); return rc; }
     *out = e;
     return D2G_OK;
 }
@@ -583,6 +673,7 @@ void d2g_allpairs_destroy(d2g_allpairs *e) {
         if (e->ev_prep[c]) (void)hipEventDestroy(e->ev_prep[c]);
         if (e->ev_x2[c]) (void)hipEventDestroy(e->ev_x2[c]);
     }
+    pt_clear(e);
     if (e->ev_pack) (void)hipEventDestroy(e->ev_pack);
     if (e->in_ready) (void)hipEventDestroy(e->in_ready);
     if (e->plain_done) (void)hipEventDestroy(e->plain_done);
@@ -611,6 +702,35 @@ int d2g_allpairs_status(d2g_allpairs *e, void *stream) {
     if (!e) return D2G_ERR_INVALID;
     D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
     return d2g_cmp_set_status(e->ctx, e->full[e->last], stream);
+}
+
+// per-phase times of one step: see d2g.h
+int d2g_allpairs_set_phase_timing(d2g_allpairs *e, int on) {
+    if (!e) return D2G_ERR_INVALID;
+    e->phase_timing = on != 0;
+    if (!on) { (void)hipSetDevice(e->ctx->device); (void)hipDeviceSynchronize(); pt_clear(e); }
+    return D2G_OK;
+}
+int d2g_allpairs_phase_times(d2g_allpairs *e, int cap, int *n_out, int *kind, int *chunk, float *start_ms, float *dur_ms) {
+    if (!e || !n_out) return D2G_ERR_INVALID;
+    *n_out = 0;
+    if (!e->ev_step0) return D2G_OK;
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    D2G_HIP(e->ctx, hipDeviceSynchronize());
+    int n = 0;
+    for (const auto &p : e->pev) {
+        if (n >= cap) break;
+        float t0 = 0.f, dt = 0.f;
+        D2G_HIP(e->ctx, hipEventElapsedTime(&t0, e->ev_step0, p.a));
+        D2G_HIP(e->ctx, hipEventElapsedTime(&dt, p.a, p.b));
+        if (kind) kind[n] = p.kind;
+        if (chunk) chunk[n] = p.chunk;
+        if (start_ms) start_ms[n] = t0;
+        if (dur_ms) dur_ms[n] = dt;
+        ++n;
+    }
+    *n_out = n;
+    return D2G_OK;
 }
 
 int d2g_allpairs_prepare_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, void *const *streams) {
@@ -646,9 +766,11 @@ int d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *row
     for (int i = 0; i < n; ++i) {
         d2g_allpairs *e = engs[i];
         void *s = streams ? streams[i] : nullptr;
+        MG_TRY(pt_begin(e, D2G_PHASE_PAIR, 0, as_stream(s)));
         int rc = (lut_dev && lut_dev[i]) ? d2g_cmp_lut_ut_dev(e->ctx, e->full[e->last], e->r0, e->r1, lut_dev[i], (float *)out_dev[i], s)
                                          : d2g_cmp_eqcount_ut_dev(e->ctx, e->full[e->last], e->r0, e->r1, (uint32_t *)out_dev[i], s);
         if (rc) return rc;
+        MG_TRY(pt_end(e, D2G_PHASE_PAIR, 0, as_stream(s)));
     }
     return D2G_OK;
 }

@@ -402,7 +402,9 @@ const d2g_cmp_set *d2g_allpairs_operand(const d2g_allpairs *eng);
  * d2g_cmp_set_status(d2g_allpairs_operand(eng)) returns the same. */
 int  d2g_allpairs_status(d2g_allpairs *eng, void *stream);
 /* chunks the engine cuts a rank's column slice into: the exchange of chunk c+1 overlaps the prepare of chunk c inside ONE step
- * (a function of N, S and the world size; D2G_MGPU_CHUNKS overrides it -- identically on every rank) */
+ * (a function of N, S and the world size; D2G_MGPU_CHUNKS overrides it -- identically on every rank: with one process per GPU
+ * d2g_allpairs_create exchanges (N, S, world, chunks) over the communicator once and fails with D2G_ERR_INVALID on every rank
+ * whose view differs from rank 0's instead of posting mismatched transfers later) */
 int  d2g_allpairs_chunks(const d2g_allpairs *eng);
 /* one whole step: prepare + this rank's slab (rows_computed) of the condensed triangle; out has
  * d2g_ut_count(N, r0, r1) entries.  lut_dev == NULL (or lut_dev[i] == NULL): u32 equality counts. */
@@ -410,6 +412,20 @@ int  d2g_allpairs_step_lut_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev, c
 int  d2g_allpairs_step_eqcount_dev(d2g_allpairs *eng, const uint64_t *my_rows_dev, uint32_t *out_dev, void *stream);
 int  d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, const float *const *lut_dev,
                            void *const *out_dev, void *const *streams);
+/* Per-phase times of ONE step (what a scaling run needs to check a cost model term by term).  With phase timing on, every phase
+ * the next prepare/step enqueues for this engine is bracketed by timing events on the stream it runs on (a few microseconds
+ * each: switch it off for timed runs); d2g_allpairs_phase_times synchronises the device and returns one record per phase in
+ * enqueue order: kind (D2G_PHASE_*), chunk, start (ms after the step's first enqueue reached the GPU) and duration (ms).
+ * An exchange phase's duration includes waiting for the slowest peer. */
+#define D2G_PHASE_PACK    0
+#define D2G_PHASE_X1      1   /* rows -> column slices ("all-to-all-v"), per chunk */
+#define D2G_PHASE_PREPARE 2   /* transpose + rank + plan + planes of this rank's column chunk */
+#define D2G_PHASE_X2      3   /* bit-plane groups to everyone ("all-gather-v"), per chunk */
+#define D2G_PHASE_DERIVE  4   /* plane stream of a gathered chunk */
+#define D2G_PHASE_PAIR    5   /* the pair kernel over this rank's rows (d2g_allpairs_step_* only) */
+int  d2g_allpairs_set_phase_timing(d2g_allpairs *eng, int on);
+int  d2g_allpairs_phase_times(d2g_allpairs *eng, int cap, int *n_out, int *kind /* [cap] */, int *chunk /* [cap] */,
+                              float *start_ms /* [cap] */, float *dur_ms /* [cap] */);
 /* software-pipelined step for a stream of matrices: the exchange + prepare of this call overlap the pair kernel
  * of the previous call (own stream, two operand buffers); results land in out_dev in call order on `stream`.
  * input_ready != 0: my_rows_dev is already complete (no dependency on work queued on `stream`).

@@ -318,3 +318,83 @@ def test_allpairs_config4_shape_world8_vs_single_gpu(d2g, gpu_ctx):
             ctxs[r].free(p)
     for x in engs + comms + ctxs:
         x.close()
+
+
+def _run_bench(*argv, env=None, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, env=e, timeout=timeout)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("W", [2, 8])
+def test_bench_inprocess_rung_over_loopback(d2g, W):
+    """bench.py's second rung -- ONE process driving W ranks through d2g_comm_create_all + d2g_allpairs_step_all, here
+    over the loopback transport on one GPU -- produces a complete N > 1 line: every rank's WHOLE slab equal to a single-GPU
+    computation, the same-config 1-GPU base, the per-phase times of one step on every rank (each phase of each chunk present), and
+    the supervisor's record of the ladder."""
+    N, S = 3000 + 8 * W, 1024
+    line = _run_bench("--gpus", str(W), "--loopback", "--sketches", str(N), "--steps", "3", "--warmup", "1")
+    assert line["n_gpus"] == W and line["value"] > 0 and "valid" not in line
+    cfg = line["config"]
+    assert cfg["sketches"] == (N + W - 1) // W * W and "WHOLE slab equals" in cfg["slab_check"] and "ONE process" in cfg["exchange_engine"]
+    assert [l["engine"] for l in line["launcher"]["ladder"]] == ["inproc"] and line["launcher"]["ladder"][0]["outcome"] == "ok"
+    base = line["scaling_base"]
+    assert base["base_1gpu_same_config_pairs_per_s"] > 0 and abs(base["speedup"] - line["value"] / base["base_1gpu_same_config_pairs_per_s"]) < 1e-9
+    ph = line["phases"]
+    C = cfg["exchange_chunks"]
+    assert len(ph["per_rank"]) == W
+    for rec in ph["per_rank"]:
+        kinds = [(p[0], p[1]) for p in rec]
+        want = [("pack", 0)] + [(k, c) for k in ("x1", "prepare", "x2", "derive") for c in range(C)] + [("pair", 0)]
+        assert sorted(kinds) == sorted(want), kinds
+        assert all(p[3] >= 0 and p[2] >= 0 for p in rec)
+    assert set(ph["max_over_ranks_ms"]) == {"pack", "x1", "prepare", "x2", "derive", "pair"}
+    assert len(line["per_rank"]) == W and sum(p["pairs"] for p in line["per_rank"]) == cfg["pairs"]
+
+
+def test_allpairs_phase_times_cover_the_step(d2g, oracle):
+    """d2g_allpairs_set_phase_timing / d2g_allpairs_phase_times: one record per phase and chunk, non-negative, the pair kernel last;
+    switching it off again leaves the step's results untouched"""
+    rng = np.random.default_rng(77)
+    W, N, S = 3, 700, 256
+    sigs = _planted(rng, N, S)
+    bits = sigs.view(np.uint64)
+    exp = oracle.eqcounts_ut(sigs)
+    off = np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
+    ctxs = [d2g.Context(0) for _ in range(W)]
+    comms = d2g.Comm.create_all(ctxs)
+    engs = [d2g.AllPairs(ctxs[r], comms[r], N, S) for r in range(W)]
+    rows = [_upload(ctxs[r], bits[engs[r].rows_held[0]:engs[r].rows_held[1]]) for r in range(W)]
+    outs = [ctxs[r].malloc(max(d2g.ut_count(N, *engs[r].rows_computed), 1) * 4) for r in range(W)]
+    for e in engs:
+        e.set_phase_timing(True)
+    d2g.allpairs_step_all(engs, rows, None, outs)
+    C = engs[0].chunks
+    for r, e in enumerate(engs):
+        recs = e.phase_times()
+        assert [p["phase"] for p in recs][-1] == "pair" and recs[0]["phase"] == "pack"
+        assert sorted((p["phase"], p["chunk"]) for p in recs) == sorted([("pack", 0), ("pair", 0)] + [(k, c) for k in ("x1", "prepare", "x2", "derive") for c in range(C)])
+        assert all(p["ms"] >= 0 and p["start_ms"] >= 0 for p in recs)
+        e.set_phase_timing(False)
+        assert e.phase_times() == []
+    d2g.allpairs_step_all(engs, rows, None, outs)
+    for r in range(W):
+        r0, r1 = engs[r].rows_computed
+        got = np.empty(d2g.ut_count(N, r0, r1), np.uint32)
+        ctxs[r].sync()
+        ctxs[r].d2h(got, outs[r])
+        np.testing.assert_array_equal(got, exp[off[r0]:off[r1]])
+    for e in engs:
+        e.close()
+    for c in comms:
+        c.close()
+    for c in ctxs:
+        c.close()

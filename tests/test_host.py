@@ -3,6 +3,7 @@ and of the C-ABI surface: every symbol include/d2g.h declares is exported and bo
 import os
 import re
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -448,3 +449,56 @@ def test_bench_refuses_to_mislabel_a_smaller_job(d2g):
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == want and line["value"] is None and "refusing" in line["error"]
+
+
+def _bench(extra_env, *argv, timeout=300):
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, env=env, timeout=timeout)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None), time.monotonic() - t0
+
+
+def test_bench_ladder_survives_hung_and_failing_rungs(d2g):
+    """the first hardware N > 1 run must not be lost to a hang.  Every rung of the multi-GPU ladder runs as a child
+    process group under a watchdog: rungs that hang (test hook) are killed at the timeout, rungs that exit non-zero are abandoned at
+    once, and with every rung gone the supervisor still prints ONE JSON line with "error" and the story of the ladder, exit code 2."""
+    hooks = {"D2G_BENCH_TEST_SKIP_DEVICE_CHECK": "1", "D2G_BENCH_TEST_HANG": "cabi,inproc", "D2G_BENCH_TEST_FAIL": "torch,broadcast",
+             "D2G_BENCH_RUNG_TIMEOUT": "3"}
+    r, line, secs = _bench(hooks, "--gpus", "2", "--sketches", "64", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 2 and secs < 120, (r.returncode, secs, r.stderr[-500:])
+    assert line["value"] is None and line["n_gpus"] == 2 and "every rung" in line["error"]
+    lad = line["launcher"]["ladder"]
+    assert [l["engine"] for l in lad] == ["cabi", "inproc", "torch", "broadcast"]
+    assert lad[0]["outcome"].startswith("timeout") and lad[1]["outcome"].startswith("timeout")
+    assert "exited with code 3" in lad[2]["outcome"] and "exited with code 3" in lad[3]["outcome"]
+    # no child of a killed rung is left behind
+    left = [pid for l in lad for pid in l["pids"] if os.path.exists("/proc/%d" % pid)]
+    assert not left, left
+
+
+def test_bench_ladder_keeps_a_headline_that_was_already_out(d2g):
+    """a rung whose headline line is out before something later hangs (a secondary leg) still delivers the measurement: the
+    supervisor kills it at the timeout and prints that line, exit code 0; an earlier rung that failed is recorded beside it"""
+    hooks = {"D2G_BENCH_TEST_SKIP_DEVICE_CHECK": "1", "D2G_BENCH_TEST_FAIL": "cabi", "D2G_BENCH_TEST_LINE_THEN_HANG": "inproc",
+             "D2G_BENCH_RUNG_TIMEOUT": "3"}
+    r, line, secs = _bench(hooks, "--gpus", "2", "--sketches", "64", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 0 and secs < 120, (r.returncode, r.stderr[-500:])
+    assert line["value"] == 1.0 and [l["engine"] for l in line["launcher"]["ladder"]] == ["cabi", "inproc"]
+    assert line["launcher"]["ladder"][1]["line"] is True and line["launcher"]["ladder"][1]["outcome"].startswith("timeout")
+
+
+def test_bench_under_a_launcher_only_rank0_supervises(d2g):
+    """started by `torch.distributed.run` (RANK / WORLD_SIZE set): ranks other than 0 exit 0 at once without output, rank 0 is the
+    supervisor; a WORLD_SIZE that contradicts --gpus is an error line"""
+    r, line, _ = _bench({"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}, "--gpus", "2")
+    assert r.returncode == 0 and line is None and r.stdout.strip() == ""
+    r, line, _ = _bench({"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, "--gpus", "2")
+    assert r.returncode == 2 and "WORLD_SIZE=4" in line["error"]
+    hooks = {"D2G_BENCH_TEST_SKIP_DEVICE_CHECK": "1", "D2G_BENCH_TEST_FAIL": "cabi,inproc,torch,broadcast", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
+             "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}
+    r, line, _ = _bench(hooks, "--gpus", "2", "--sketches", "64")
+    assert r.returncode == 2 and "torch.distributed.run" in line["launcher"]["launched_by"]
