@@ -479,63 +479,96 @@ struct d2g_seqpack {
         }
         return t;
     }
-    // kseq-style record walk over an in-memory FASTA/FASTQ buffer
+    // kseq_read()'s record walk over an in-memory FASTA/FASTQ buffer (klib kseq.h as published -- the copy bonsai vendors is
+    // absent: UNVERIFIED-AGAINST-SOURCE; reference call site src/fastxsketch.cpp:416-417, holder src/d2.h:273-305; the oracle's
+    // d2o_walk_fastx_records restates the same rules):
+    //  * at the start of the input and after every FASTQ record (kseq's last_char == 0) the next header is searched BYTE BY BYTE:
+    //    "junk>name" starts a record in the middle of a line; after a FASTA record the header character was consumed by the
+    //    sequence loop, which only looks at the first character of each line;
+    //  * a trailing '\r' of a sequence / quality line is dropped while the accumulated string is longer than one character;
+    //  * after '+': the rest of that line, then AT LEAST ONE quality line, until qual.l >= seq.l; a record whose input ends inside
+    //    the '+' line or whose quality length differs is an error (-2): `while (kseq_read(ks) >= 0)` stops there, so the record is
+    //    not sketched (its bases are rewound out of the stream) and the rest of the file is ignored.
     void feed_fastx(const char *buf, size_t len) {
         size_t pos = 0;
         auto skip_line = [&]() {
             const char *nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
             pos = nl ? size_t(nl - buf) + 1 : len;
         };
-        while (pos < len && buf[pos] != '>' && buf[pos] != '@') skip_line();
-        while (pos < len) {
-            if (by_record) {                               // fastxsketchbyseq.cpp:243-244: names_ = kseq name
-                size_t e = pos + 1;
-                while (e < len && !std::isspace((unsigned char)buf[e])) ++e;
-                names.emplace_back(buf + pos + 1, e - pos - 1);
+        static const bool have_vbmi2 = __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("avx512bw") &&
+                                       __builtin_cpu_supports("avx512vl") && !std::getenv("D2G_NO_AVX512");
+        int last_char = 0;
+        for (;;) {
+            if (!last_char) {
+                while (pos < len && buf[pos] != '>' && buf[pos] != '@') ++pos;     // usually the very next byte
+                if (pos >= len) break;
+                last_char = (unsigned char)buf[pos++];
             }
+            if (pos >= len) break;                         // a header character at the very end: kseq returns -1, no record
+            // state to return to if this record turns out to be an error
+            const uint64_t snap_bases = nbases, snap_kmers = cur_kmers;
+            const size_t snap_runs = run_start.size();
+            size_t name_end = pos;
+            while (name_end < len && !std::isspace((unsigned char)buf[name_end])) ++name_end;
+            const size_t name_pos = pos;
             skip_line();                                   // header
             size_t seqlen = 0;
-            int c = -1;
-            static const bool have_vbmi2 = __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("avx512bw") &&
-                                           __builtin_cpu_supports("avx512vl") && !std::getenv("D2G_NO_AVX512");
+            int term = -1;                                 // the line-start character that ended the sequence, -1 = end of input
             bool at_line_start = true;
             while (pos < len) {
-                c = (unsigned char)buf[pos];
+                const int c = (unsigned char)buf[pos];
                 // a record boundary is only looked for at the start of a line (the block path may stop inside one)
-                if (at_line_start && (c == '>' || c == '+' || c == '@')) break;
+                if (at_line_start && (c == '>' || c == '+' || c == '@')) { term = c; ++pos; break; }
                 if (have_vbmi2 && len - pos >= 64) {
                     const size_t took = feed_blocks(buf + pos, len - pos, &seqlen);
                     if (took) {
                         pos += took;
                         at_line_start = buf[pos - 1] == '\n';
-                        c = -1;
                         continue;
                     }
                 }
                 const char *nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
                 const size_t e = nl ? size_t(nl - buf) : len;
                 size_t ll = e - pos;
-                if (ll && buf[pos + ll - 1] == '\r') --ll;
+                if (ll && buf[pos + ll - 1] == '\r' && seqlen + ll > 1) --ll;
                 feed(buf + pos, ll);
                 seqlen += ll;
                 pos = nl ? e + 1 : len;
                 at_line_start = true;
-                c = -1;
             }
-            if (by_record) end_genome(); else end_record();
-            if (pos < len && c == '+') {
-                skip_line();
-                size_t ql = 0;
-                while (pos < len && ql < seqlen) {
-                    const char *nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
-                    const size_t e = nl ? size_t(nl - buf) : len;
-                    size_t ll = e - pos;
-                    if (ll && buf[pos + ll - 1] == '\r') --ll;
-                    ql += ll;
-                    pos = nl ? e + 1 : len;
+            bool ok = true;
+            if (term == '>' || term == '@') last_char = term;
+            else if (term == '+') {
+                const char *nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
+                if (!nl) ok = false;                       // the input ends inside the '+' line
+                else {
+                    pos = size_t(nl - buf) + 1;
+                    size_t ql = 0;
+                    do {
+                        if (pos >= len) break;
+                        nl = (const char *)std::memchr(buf + pos, '\n', len - pos);
+                        const size_t e = nl ? size_t(nl - buf) : len;
+                        const size_t ll = e - pos;
+                        ql += ll;
+                        if (ql > 1 && ll && buf[pos + ll - 1] == '\r') --ql;
+                        pos = nl ? e + 1 : len;
+                    } while (ql < seqlen);
+                    last_char = 0;
+                    ok = ql == seqlen;
                 }
-                while (pos < len && buf[pos] != '>' && buf[pos] != '@') skip_line();
             }
+            if (!ok) {                                     // kseq_read() == -2: drop the record, stop reading this input
+                if (cur_len) { cur_len = 0; }
+                run_start.resize(snap_runs); run_len.resize(snap_runs);
+                cur_kmers = snap_kmers;
+                rewind_to(snap_bases);
+                break;
+            }
+            if (by_record) {                               // fastxsketchbyseq.cpp:243-244: names_ = kseq name
+                names.emplace_back(buf + name_pos, name_end - name_pos);
+                end_genome();
+            } else end_record();
+            if (term == -1) break;
         }
     }
     void finalize_pad() {

@@ -208,61 +208,76 @@ size_t d2o_encode_seq(const char *seq, size_t len, int k, int canon, d2o_kmer_cb
     return n;
 }
 
-/* kseq.h semantics (klib, absent): records start at '>' or '@'; the sequence is every
- * following line (newline and trailing '\r' stripped) until a line starting with
- * '>', '@' or '+'; after '+', quality lines are consumed until qual.l >= seq.l. */
+/* UNVERIFIED-AGAINST-SOURCE: kseq.h (klib, vendored by the absent bonsai submodule; call site fastxsketch.cpp:416-417 through
+ * bns::Encoder::for_each, holder d2.h:273-305).  Restated from the published klib kseq_read():
+ *  - with last_char == 0 (file start, and after every FASTQ record) the reader scans BYTE BY BYTE for the next '>' or '@' -- a
+ *    header may start in the middle of a line ("junk>name") --; otherwise the header character was already consumed by the
+ *    previous record's sequence loop, which only looks at the FIRST character of each line;
+ *  - name = up to the first whitespace, the rest of the header line is the comment; a header character that is the last byte of
+ *    the input yields no record;
+ *  - the sequence is every following line (line feed stripped; a trailing '\r' stripped while the accumulated sequence is longer
+ *    than one character -- ks_getuntil2's `str->l > 1`) until a line starts with '>', '@' or '+'; empty lines are skipped;
+ *  - after '+': the rest of that line is skipped, then quality lines are read -- at least one -- until qual.l >= seq.l; the record
+ *    is an ERROR (-2) when the input ends inside the '+' line or when qual.l != seq.l, and the encoder's loop
+ *    `while (kseq_read(ks) >= 0)` then stops: the bad record is not sketched and the rest of the file is ignored. */
 size_t d2o_walk_fastx_records(const char *buf, size_t len, d2o_record_cb rcb, void *ud) {
     size_t pos = 0, nrec = 0;
     char *seq = NULL; size_t cap = 0;
-    /* jump to first header */
-    while (pos < len && buf[pos] != '>' && buf[pos] != '@') {
-        const char *nl = memchr(buf + pos, '\n', len - pos);
-        pos = nl ? (size_t)(nl - buf) + 1 : len;
-    }
-    while (pos < len) {
+    int last_char = 0;
+    for (;;) {
+        if (last_char == 0) {
+            while (pos < len && buf[pos] != '>' && buf[pos] != '@') ++pos;
+            if (pos >= len) break;
+            last_char = (unsigned char)buf[pos++];
+        }
+        if (pos >= len) break;                              /* ks_getuntil(name) meets the end of the input: -1 */
         /* header line: name = up to the first whitespace (kseq name/comment split) */
         const char *nl = memchr(buf + pos, '\n', len - pos);
         const size_t hend = nl ? (size_t)(nl - buf) : len;
-        const char *name = buf + pos + 1;
+        const char *name = buf + pos;
         size_t name_len = 0;
-        while (pos + 1 + name_len < hend && !isspace((unsigned char)name[name_len])) ++name_len;
+        while (pos + name_len < hend && !isspace((unsigned char)name[name_len])) ++name_len;
         pos = nl ? hend + 1 : len;
         size_t sl = 0;
         int c = -1;
         while (pos < len) {
             c = (unsigned char)buf[pos];
-            if (c == '>' || c == '+' || c == '@') break;
+            if (c == '>' || c == '+' || c == '@') { ++pos; break; }
             if (c == '\n') { ++pos; c = -1; continue; }
             nl = memchr(buf + pos, '\n', len - pos);
             size_t e = nl ? (size_t)(nl - buf) : len;
             size_t ll = e - pos;
-            if (ll && buf[pos + ll - 1] == '\r') --ll;
             if (sl + ll + 1 > cap) { cap = (sl + ll + 1) * 2; seq = (char *)realloc(seq, cap); }
             memcpy(seq + sl, buf + pos, ll);
             sl += ll;
+            if (sl > 1 && seq[sl - 1] == '\r') --sl;
             pos = nl ? e + 1 : len;
             c = -1;
         }
+        if (c == '>' || c == '@') last_char = c;           /* the next record's header character has been read */
+        if (c != '+') {                                    /* FASTA record (or the input ended) */
+            rcb(name, name_len, seq, sl, ud);
+            ++nrec;
+            if (c == -1) break;
+            continue;
+        }
+        nl = memchr(buf + pos, '\n', len - pos);           /* rest of the '+' line */
+        if (!nl) break;                                    /* -2: no quality string */
+        pos = (size_t)(nl - buf) + 1;
+        size_t ql = 0;
+        do {
+            if (pos >= len) break;                         /* ks_getuntil2 at the end of the input: -1, the loop ends */
+            nl = memchr(buf + pos, '\n', len - pos);
+            size_t e = nl ? (size_t)(nl - buf) : len;
+            size_t ll = e - pos;
+            ql += ll;
+            if (ql > 1 && ll && buf[pos + ll - 1] == '\r') --ql;
+            pos = nl ? e + 1 : len;
+        } while (ql < sl);
+        last_char = 0;
+        if (ql != sl) break;                               /* -2: quality string of a different length */
         rcb(name, name_len, seq, sl, ud);
         ++nrec;
-        if (pos < len && c == '+') {
-            nl = memchr(buf + pos, '\n', len - pos);       /* rest of '+' line */
-            pos = nl ? (size_t)(nl - buf) + 1 : len;
-            size_t ql = 0;
-            while (pos < len && ql < sl) {
-                nl = memchr(buf + pos, '\n', len - pos);
-                size_t e = nl ? (size_t)(nl - buf) : len;
-                size_t ll = e - pos;
-                if (ll && buf[pos + ll - 1] == '\r') --ll;
-                ql += ll;
-                pos = nl ? e + 1 : len;
-            }
-            /* next record must start with a header; skip anything else */
-            while (pos < len && buf[pos] != '>' && buf[pos] != '@') {
-                nl = memchr(buf + pos, '\n', len - pos);
-                pos = nl ? (size_t)(nl - buf) + 1 : len;
-            }
-        }
     }
     free(seq);
     return nrec;

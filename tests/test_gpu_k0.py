@@ -103,7 +103,8 @@ def test_k0_refuses_what_only_the_host_parser_handles(gpu_ctx, d2g):
     sk = gpu_ctx.sketcher()
     fa = synth.fasta_bytes("g", synth.random_genome(1, 5000))
     fq = b"@r1\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n"
-    for bad in (fq, gzip.compress(fa), b"junk first\n" + fa, fa + b"+\nIIII\n"):
+    # "junk" + fa: kseq finds the header in the MIDDLE of the first line (byte-wise search) -- the host parser follows it, K0 refuses
+    for bad in (fq, gzip.compress(fa), b"junk first\n" + fa, b"junk" + fa, fa + b"+\nIIII\n"):
         with pytest.raises(d2g.D2GError) as ei:
             sk.ingest_fasta([fa, bad], 21)
         assert ei.value.status == -5                                   # D2G_ERR_UNSUPPORTED

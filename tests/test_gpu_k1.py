@@ -195,3 +195,19 @@ def test_k1_sketcher_reuse(gpu_ctx, d2g, oracle):
         for i, f in enumerate(fas):
             np.testing.assert_array_equal(regs[i], oracle.sketch_buffer(f, k=k, S=S)[0], err_msg=f"round {rnd} genome {i}")
     sk.close()
+
+
+def test_k1_registers_on_kseq_oddities(gpu_ctx, d2g, oracle):
+    """the record-walk oddities of tests/test_host.py (headers inside lines, junk around FASTQ records, bad quality strings ending
+    the input, CR LF) through the product path: host parser -> K1 registers, bit for bit the oracle's"""
+    from test_host import KSEQ_ODDITIES
+    k, S = 5, 64
+    sp = d2g.SeqPack(k)
+    for buf in KSEQ_ODDITIES:
+        sp.add_fastx(buf)
+    regs = gpu_ctx.oph_sketch_seqpack(sp, S)
+    for i, buf in enumerate(KSEQ_ODDITIES):
+        eregs, _, _, nk = oracle.sketch_buffer(buf, k=k, S=S)
+        assert sp.nkmers(i) == nk
+        np.testing.assert_array_equal(regs[i], eregs, err_msg=repr(buf))
+    sp.close()

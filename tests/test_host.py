@@ -502,3 +502,130 @@ def test_bench_under_a_launcher_only_rank0_supervises(d2g):
              "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}
     r, line, _ = _bench(hooks, "--gpus", "2", "--sketches", "64")
     assert r.returncode == 2 and "torch.distributed.run" in line["launcher"]["launched_by"]
+
+
+def _kseq_records(buf):
+    """klib kseq_read() restated character by character from the published macro (a third restatement, next to the oracle's line-wise
+    C and the product's block-wise C++): -> [(name, sequence)] of every record a `while (kseq_read(ks) >= 0)` loop sees."""
+    n, pos, last, out = len(buf), 0, 0, []
+
+    def getc():
+        nonlocal pos
+        if pos >= n:
+            return -1
+        pos += 1
+        return buf[pos - 1]
+
+    def until_line(acc):                                     # ks_getuntil2(KS_SEP_LINE, append = 1)
+        nonlocal pos
+        if pos >= n:
+            return -1
+        e = buf.find(b"\n", pos)
+        acc += buf[pos:e if e >= 0 else n]
+        pos = e + 1 if e >= 0 else n
+        if len(acc) > 1 and acc[-1] == 13:
+            del acc[-1]
+        return len(acc)
+
+    while True:
+        if last == 0:
+            c = getc()
+            while c != -1 and c not in (62, 64):
+                c = getc()
+            if c == -1:
+                return out
+            last = c
+        if pos >= n:
+            return out                                       # ks_getuntil(name) < 0
+        name, c = bytearray(), None
+        while pos < n:
+            ch = buf[pos]
+            pos += 1
+            if ch in b" \t\n\v\f\r":
+                c = ch
+                break
+            name.append(ch)
+        if c is not None and c != 10:
+            until_line(bytearray())                          # the comment
+        seq = bytearray()
+        c = getc()
+        while c != -1 and c not in (62, 43, 64):
+            if c != 10:
+                seq.append(c)
+                until_line(seq)
+            c = getc()
+        if c in (62, 64):
+            last = c
+        if c != 43:
+            out.append((bytes(name), bytes(seq)))
+            continue
+        c = getc()
+        while c != -1 and c != 10:
+            c = getc()
+        if c == -1:
+            return out                                       # -2: no quality string
+        qual = bytearray()
+        while until_line(qual) >= 0 and len(qual) < len(seq):
+            pass
+        last = 0
+        if len(qual) != len(seq):
+            return out                                       # -2: quality of a different length
+        out.append((bytes(name), bytes(seq)))
+
+
+KSEQ_ODDITIES = [
+    b"junk>r1 c\nACGTACGTAC\nGGTTA\n",                                   # header in the middle of the first line
+    b"ACGTACGT\nxx@r1\nACGTTGCAAC\n+\nIIIIIIIIII\ntrailing junk with @r2 inside\nACGTACGTAC\n",   # '@' inside junk after a quality block
+    b"@r1\nACGTACGTAC\n+\nIIIII\n@r2\nTTTTTGGGGG\n+\nIIIIIIIIII\n",       # quality too short: swallows the next header, then too long -> error
+    b"@r1\nACGTACGTAC\n+\nIIIIIIIIIIII\n@r2\nTTTTTGGGGG\n+\nIIIIIIIIII\n",  # quality too long -> error, r2 never read
+    b"@r1\nACGTACGTAC\n+",                                                # the input ends inside the '+' line
+    b"@r1\nACGTACGTAC\n+\n",                                              # no quality line at all
+    b"@r1\n+\n@r2\nACGTACGTAC\n+\nIIIIIIIIII\n",                          # empty sequence: one quality line is read anyway
+    b">r1\nACGTACGTAC\n>",                                                # a header character as the last byte
+    b">r1\r\nACGTA\r\nCGTAC\r\n\r\n>r2\r\nA\r\nC\r\n",                    # CR LF, an empty CR LF line, one-character lines
+    b">r1\n\rACGTACGTAC\n",                                               # a lone CR first: kept while the sequence has one character
+    b"@r1\nACGTACGTAC\n+r1\nIIIII\nIIIII\n@r2\nGGGGGCCCCC\n+\n>>>>>>>>>>\n>r3\nACGTAACGTA\n",  # multi-line quality, '>' quality, FASTA after FASTQ
+    b"\n\n  >r1\nACGTACGTAC\n",                                           # leading blank lines and spaces
+    b"",
+    b"no header at all\nACGT\n",
+]
+
+
+def test_seqpack_and_oracle_follow_kseq_read(d2g, oracle):
+    """the record walk of the product's host parser and of the oracle against klib's kseq_read() restated
+    character by character: byte-wise search for the first header (and after every FASTQ record), headers inside lines, quality read
+    by length with at least one line, a record with a bad quality string ends the input (kseq returns -2) -- names and per-record
+    k-mer counts (parse-by-seq), and the k-mers of the whole input, on hand-made oddities and 300 random messy inputs."""
+    import re as _re
+    rng = np.random.default_rng(4242)
+    cases = list(KSEQ_ODDITIES)
+    for t in range(300):
+        buf, _ = _random_fastx(rng, int(rng.integers(1, 6)))
+        r = rng.random()
+        if r < 0.25:
+            buf = rng.choice(np.frombuffer(b"ACGT xyz\n", np.uint8), int(rng.integers(1, 40))).tobytes() + buf      # leading junk
+        elif r < 0.5 and len(buf) > 4:
+            buf = buf[:int(rng.integers(1, len(buf)))]                                                            # truncated anywhere
+        elif r < 0.65 and b"+" in buf:
+            i = buf.rfind(b"\n", 0, len(buf) - 1)
+            buf = buf[:i] + b"#" + buf[i:]                                                                        # one quality line too long
+        cases.append(buf)
+    k = 5
+    for buf in cases:
+        recs = _kseq_records(buf)
+        per = [sum(len(r) - k + 1 for r in _re.split(rb"[^ACGTacgt]+", s) if len(r) >= k) for _, s in recs]
+        names, _, mcards = oracle.sketch_buffer_byseq(buf, k, 8, multiset=True)
+        assert names == [nm.decode("latin1") for nm, _ in recs], buf
+        assert mcards.tolist() == [float(p) for p in per], buf
+        sp = d2g.SeqPack(k)
+        sp.add_fastx_by_record(buf)
+        assert [sp.name(i) for i in range(sp.ngenomes)] == names, buf
+        assert [sp.nkmers(i) for i in range(sp.ngenomes)] == per, buf
+        sp.close()
+        sp = d2g.SeqPack(k)
+        sp.add_fastx(buf)
+        packed, rs, rl, go = sp.arrays()
+        exp = [r.upper() for _, s in recs for r in _re.split(rb"[^ACGTacgt]+", s) if len(r) >= k]
+        assert _decode_runs(packed, rs, rl) == exp, buf
+        assert sp.nkmers(0) == sum(per) == oracle.sketch_buffer(buf, k=k, S=8)[3], buf
+        sp.close()
