@@ -113,6 +113,8 @@ SIGNATURES = {
     "d2g_cmp_set_update_dev": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int), C.POINTER(_f32)]),
     "d2g_cmp_set_status": (_int, [_vp, _vp, _vp]),
+    "d2g_warmup": (_int, [_vp, _int]),
+    "d2g_device_name": (_int, [_int, C.c_char_p, _sz]),
     "d2g_comm_unique_id": (_int, [_vp]),
     "d2g_comm_create": (_int, [_vp, _vp, _int, _int, C.POINTER(_vp)]),
     "d2g_comm_create_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_vp)]),

@@ -55,6 +55,10 @@ struct d2g_timer {
     void stop() { if (on) (void)hipEventRecord(ev->b.back(), s); }
 };
 
+// one per translation unit with kernels: makes the runtime load that unit's code object now (hipFuncGetAttributes on one of
+// its kernels) instead of at its first launch
+void d2g_warm_k0(); void d2g_warm_k1(); void d2g_warm_k2(); void d2g_warm_k2_bitslice(); void d2g_warm_k3();
+
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 template <class T> static inline T div_up(T a, T b) { return (a + b - 1) / b; }

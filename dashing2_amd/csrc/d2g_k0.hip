@@ -497,3 +497,5 @@ int d2g_sketcher_ingested_runs(const d2g_sketcher *sk, const uint64_t **run_star
 }
 
 }  // extern "C"
+
+void d2g_warm_k0() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k0_newline_kernel)); }

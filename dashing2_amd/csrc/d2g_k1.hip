@@ -358,3 +358,5 @@ int d2g_sketcher_stage(d2g_sketcher *sk, const uint8_t *packed, size_t packed_by
     *nblk_out = nblk;
     return D2G_OK;
 }
+
+void d2g_warm_k1() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k1_oph_kernel<true, true>)); }

@@ -540,3 +540,5 @@ int d2g_cmp_dist_ut(d2g_ctx *ctx, const uint64_t *sig_bits, const double *cards,
 }
 
 }  // extern "C"
+
+void d2g_warm_k2() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k2_transpose_kernel)); }

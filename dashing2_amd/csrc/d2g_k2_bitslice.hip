@@ -900,3 +900,5 @@ int d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1
     sh.N = set->N; sh.i_lo = a0; sh.i_hi = a1; sh.j_lo = b0; sh.j_hi = b1; sh.ut = 0;
     return launch_bitslice(ctx, set, sh, StoreEq{eq_out}, s);
 }
+
+void d2g_warm_k2_bitslice() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&bs_colplan_kernel)); }

@@ -1895,3 +1895,5 @@ int d2g_bmh_from_weighted_ids(d2g_ctx *ctx, const uint64_t *ids, const double *w
 }
 
 }  // extern "C"
+
+void d2g_warm_k3() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k3_scan_kernel)); }

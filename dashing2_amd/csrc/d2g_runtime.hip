@@ -103,6 +103,35 @@ int d2g_memcpy_d2h(d2g_ctx *c, void *dst, const void *src, size_t n, void *strea
     return D2G_OK;
 }
 
+// see d2g.h
+int d2g_warmup(d2g_ctx *c, int what) {
+    if (!c) return D2G_ERR_INVALID;
+    D2G_HIP(c, hipSetDevice(c->device));
+    if (what & D2G_WARM_COPY) {
+        // the first host<->device copy of a process sets up the runtime's copy machinery (~30 ms on MI355X / ROCm 7: measured with any
+        // size and with pinned or pageable memory alike; a 4 KB copy leaves part of it to the first large one, 1 MB does not)
+        static char src[1 << 20];
+        void *d = nullptr;
+        D2G_HIP(c, hipMalloc(&d, sizeof src));
+        hipError_t e = hipMemcpy(d, src, sizeof src, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(src, d, 4096, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        D2G_HIP(c, e);
+    }
+    if (what & D2G_WARM_K0) d2g_warm_k0();
+    if (what & D2G_WARM_K1) d2g_warm_k1();
+    if (what & D2G_WARM_K2) { d2g_warm_k2(); d2g_warm_k2_bitslice(); }
+    if (what & D2G_WARM_K3) d2g_warm_k3();
+    return D2G_OK;
+}
+int d2g_device_name(int device, char *buf, size_t cap) {
+    if (!buf || !cap) return D2G_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return D2G_ERR_NODEVICE;
+    std::snprintf(buf, cap, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return D2G_OK;
+}
+
 int d2g_set_timing(d2g_ctx *c, int enabled) {
     if (!c) return D2G_ERR_INVALID;
     c->timing = enabled == 1 ? (D2G_TIME_K1 | D2G_TIME_K2 | D2G_TIME_K2PREP | D2G_TIME_K3) : (enabled & ~1);

@@ -33,7 +33,7 @@ static const char *const VALID_LONG[] = {
 
 enum {
     OPT_CMPOUT = 1000, OPT_OUTPREF, OPT_BINARY, OPT_PHYLIP, OPT_ASYM, OPT_ISZ, OPT_USZ, OPT_MASH, OPT_SYMCONTAIN,
-    OPT_CONTAIN, OPT_SEED, OPT_HELP, OPT_BATCH, OPT_PRESKETCHED, OPT_MULTISET, OPT_PARSEBYSEQ, OPT_FMTCOMPAT, OPT_UNSUPPORTED
+    OPT_CONTAIN, OPT_SEED, OPT_HELP, OPT_BATCH, OPT_PRESKETCHED, OPT_MULTISET, OPT_PARSEBYSEQ, OPT_FMTCOMPAT, OPT_GPUSTATS, OPT_UNSUPPORTED
 };
 
 void sketch_usage() {
@@ -48,7 +48,9 @@ void sketch_usage() {
                          "  --distance/--mash-distance --containment --symmetric-containment --intersection --union-size\n"
                          "  --batch-size n  -v\n"
                          "  --fmt-compat {10,11}   float text of PHYLIP/TSV output as fmt < 11 (default: fixed notation below 1e16) or\n"
-                         "                         fmt >= 11 (exponent form from 1e7) prints it -- the reference's fmt is an unpinned submodule\n");
+                         "                         fmt >= 11 (exponent form from 1e7) prints it -- the reference's fmt is an unpinned submodule\n"
+                         "  --gpu-stats file.json  one JSON object per run: device(s), kernel milliseconds, bit-plane counts, algorithmic bytes, wall phases\n"
+                         "  D2G_DEVICES=all|0,1,..  spread `sketch` (inputs dealt to the GPUs) and `cmp` (rows of the matrix) over several GPUs\n");
 }
 void cmp_usage() {
     std::fprintf(stderr, "dashing2 cmp <opts> [fastas... (optional)]\n"
@@ -64,6 +66,7 @@ static bool validate_long_flags(char **argv, bool is_cmp) {
             const std::string flag(*p + 2);
             if (is_cmp && flag == "presketched") continue;
             if (flag == "fmt-compat") continue;              // this build's own flag (float text generation of the fmt library)
+            if (flag == "gpu-stats") continue;               // this build's own flag (machine-readable per-run record)
             bool ok = false;
             for (const char *v : VALID_LONG) if (flag == v) { ok = true; break; }
             if (!ok) {   // src/options.h:298-301
@@ -120,6 +123,7 @@ int parse_options(int argc, char **argv, Options &o) {
         {"count-threshold", required_argument, 0, 'm'}, {"threshold", required_argument, 0, 'm'},
         {"parse-by-seq", no_argument, 0, OPT_PARSEBYSEQ},
         {"fmt-compat", required_argument, 0, OPT_FMTCOMPAT},
+        {"gpu-stats", required_argument, 0, OPT_GPUSTATS},
         {0, 0, 0, 0}};
     // every other valid reference flag is recognised but outside the hot-path scope
     std::vector<struct option> all(longopts, longopts + sizeof(longopts) / sizeof(longopts[0]) - 1);
@@ -175,6 +179,7 @@ int parse_options(int argc, char **argv, Options &o) {
                     return 1 + 1;
                 }
                 break;
+            case OPT_GPUSTATS: o.gpu_stats = optarg; break;
             case OPT_HELP: case 'h': case '?': o.is_cmp ? cmp_usage() : sketch_usage(); return 1 + 1;
             case OPT_UNSUPPORTED:
                 std::fprintf(stderr, "dashing2 (MI355X): option --%s is outside the hot-path scope of this build "

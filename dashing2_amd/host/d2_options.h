@@ -34,6 +34,7 @@ struct Options {
     std::vector<std::string> paths;       // references then queries
     size_t nq = 0;                        // number of query paths (-Q)
     int device = 0;                       // D2G_DEVICE env (not a reference flag)
+    std::string gpu_stats;                // --gpu-stats FILE (not a reference flag): machine-readable record of the run (SURVEY 5 "Metrics")
     int fmt_compat = 0;                   // --fmt-compat {10,11} (not a reference flag): float text layout of fmt < 11 / >= 11; 0 = not given (10)
 
     unsigned nthreads() const { return nt < 1 ? 1u : unsigned(nt); }      // as requested (-p / OMP_NUM_THREADS): what is printed

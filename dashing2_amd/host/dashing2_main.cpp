@@ -12,6 +12,7 @@
 #include "fmtfloat.h"
 #include "slot_queue.h"
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -73,6 +74,63 @@ std::string trim_folder(const std::string &s) {          // src/enums.cpp:22-26
 }
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// --gpu-stats FILE (SURVEY 5 "Metrics / logging"; the reference only has its verbosity levels, src/enums.h:106-111, and the
+// banner of src/d2.cpp:136): what -v prints, machine-readable -- ONE JSON object per run with the device(s), the HIP-event
+// milliseconds of every timed kernel family (d2g_set_timing / d2g_kernel_ms), bit-plane counts, algorithmic bytes, wall phases.
+struct Stats {
+    bool on = false;
+    std::string path;
+    std::mutex mu;
+    std::vector<std::pair<std::string, std::string>> kv;      // key -> value already rendered as JSON
+    static std::string esc(const std::string &x) {
+        std::string r = "\"";
+        for (unsigned char c : x) {
+            if (c == '"' || c == '\\') { r += '\\'; r += char(c); }
+            else if (c < 0x20) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", c); r += b; }
+            else r += char(c);
+        }
+        return r + "\"";
+    }
+    static std::string numstr(double v) { char b[40]; if (!std::isfinite(v)) return "null"; std::snprintf(b, sizeof b, "%.9g", v); return b; }
+    void raw(const std::string &k, const std::string &json) { if (!on) return; std::lock_guard<std::mutex> lk(mu); kv.emplace_back(k, json); }
+    void num(const std::string &k, double v) { raw(k, numstr(v)); }
+    void str(const std::string &k, const std::string &v) { raw(k, esc(v)); }
+    // {"launches": n, "avg_ms": a, "total_ms": n a} of one timed kernel family on one context (synchronises on its events)
+    static std::string kernel_json(d2g_ctx *ctx, const char *which) {
+        int n = 0; float avg = 0, last = 0;
+        if (d2g_kernel_ms(ctx, which, 1, &n, &avg, &last) != D2G_OK) return "null";
+        return "{\"launches\": " + std::to_string(n) + ", \"avg_ms\": " + numstr(avg) + ", \"total_ms\": " + numstr(double(avg) * n) + "}";
+    }
+    void write() {
+        if (!on) return;
+        std::FILE *fp = std::fopen(path.c_str(), "wb");
+        if (!fp) { std::fprintf(stderr, "dashing2 (MI355X): cannot write --gpu-stats file %s\n", path.c_str()); return; }
+        std::fputs("{", fp);
+        for (size_t i = 0; i < kv.size(); ++i) std::fprintf(fp, "%s%s: %s", i ? ", " : "", esc(kv[i].first).c_str(), kv[i].second.c_str());
+        std::fputs("}\n", fp);
+        std::fclose(fp);
+    }
+};
+Stats g_stats;
+constexpr int TIME_ALL = D2G_TIME_K0 | D2G_TIME_K1 | D2G_TIME_K2 | D2G_TIME_K2PREP | D2G_TIME_K3;
+
+// D2G_DEVICES = "all" | "0,1,2": the GPUs a job may spread over -- `sketch` deals its input groups to them (no collectives),
+// `cmp` shards the rows of the matrix (one exchange).  Default: the one device D2G_DEVICE names.  A list that repeats
+// a device is allowed (cmp: loopback transport; used by the tests on one GPU).
+std::vector<int> job_devices(const Options &o) {
+    std::vector<int> d;
+    const char *e = std::getenv("D2G_DEVICES");
+    if (!e || !*e) return {o.device};
+    if (std::strcmp(e, "all") == 0) { for (int i = 0; i < d2g_device_count(); ++i) d.push_back(i); }
+    else for (const char *p = e; *p;) { char *q; const long v = std::strtol(p, &q, 10); if (q == p) break; d.push_back(int(v)); p = *q == ',' ? q + 1 : q; }
+    if (d.empty()) d.push_back(o.device);
+    return d;
+}
+std::string device_label(int dev) {
+    char b[256];
+    return d2g_device_name(dev, b, sizeof b) == D2G_OK ? std::string(b) : std::string("?");
+}
+
 // src/fastxmerge.cpp:70-120 for DNA, unspaced, w <= k: OPH set sketches and exact-counting multiset sketches
 std::string makedest(const Options &o, const std::string &path) {
     std::string ret = path.substr(0, path.find_first_of(' '));
@@ -122,8 +180,20 @@ d2g_ctx *make_ctx(const Options &o);
 // The GPU context (HIP runtime start-up, 0.06-0.2 s) is created on a helper thread as soon as the options are parsed, while
 // this thread stats / reads / parses the inputs; get() joins.  There is still no CPU fallback: a failure ends the process.
 struct LazyCtx {
-    const Options &o; std::thread th; d2g_ctx *ctx = nullptr; double t_create = 0;
-    explicit LazyCtx(const Options &oo) : o(oo) { th = std::thread([this] { const double t = now(); ctx = make_ctx(o); t_create = now() - t; }); }
+    const Options &o; std::thread th; d2g_ctx *ctx = nullptr; double t_create = 0, t_warm = 0;
+    // `warm`: one-time costs the helper pays right after the context exists (D2G_WARM_*): the first host<->device copy of a process
+    // costs ~30 ms whatever its size (tools/cmp_setup_time2.py), code objects ~1 ms per kernel family -- under the input reading
+    LazyCtx(const Options &oo, int warm) : o(oo) {
+        th = std::thread([this, warm] {
+            double t = now();
+            ctx = make_ctx(o);
+            t_create = now() - t;
+            t = now();
+            if (warm) (void)d2g_warmup(ctx, warm);
+            if (g_stats.on) (void)d2g_set_timing(ctx, TIME_ALL);
+            t_warm = now() - t;
+        });
+    }
     d2g_ctx *get() { if (th.joinable()) th.join(); return ctx; }
     // the context is only torn down on request: main() leaves through _exit once every output is flushed and closed (the HIP
     // runtime's orderly shutdown costs tens of milliseconds that buy a CLI process nothing); D2G_FULL_TEARDOWN=1 keeps it
@@ -220,7 +290,7 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
     std::condition_variable cv_ready, cv_space, cv_buf;
     std::atomic<size_t> next_group{0};
     std::string parse_error;
-    const bool force_host = std::getenv("D2G_DEVICE_PARSE") == nullptr || std::getenv("D2G_HOST_PARSE") != nullptr;
+    const bool force_host = std::getenv("D2G_DEVICE_PARSE") == nullptr || std::getenv("D2G_HOST_PARSE") != nullptr || job_devices(o).size() > 1;
     const size_t nparsers = std::max<size_t>(1, std::min<size_t>({size_t(o.workers()), groups.size(), size_t(192)}));
     // (A byte-bounded queue deep enough to parse all of 1000 x 5 Mbp before the first launch, with four device threads to drain it,
     // was measured: the 112 freshly allocated packers fault in 1.3 GB and the pipeline went 0.21 -> 0.34 s.  The recycled pool stays.)
@@ -346,13 +416,26 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
             t_fin += now() - t0;                                            // (only this thread writes it)
         }
     });
-    // Two device threads, each with its own context + sketcher (a d2g_ctx is used by one thread at a time): the upload of one
-    // group overlaps the kernels and the synchronisations of the other
+    // Device threads: two per GPU, each with its own context + sketcher (a d2g_ctx is used by one thread at a time) -- the upload
+    // of one group overlaps the kernels and the synchronisations of the other.  D2G_DEVICES names several GPUs: every GPU gets its
+    // pair of threads and all of them take groups from the one queue (inputs dealt to the GPUs as they come free: file-sharded, no
+    // collectives -- SURVEY 8e; the loop being sharded is the reference's `for` over files, src/fastxsketch.cpp:302); results land by
+    // input index, so the stacked output is in input order whatever GPU sketched a group.
+    const std::vector<int> devs = job_devices(o);
     int ndev = groups.size() > 1 ? 2 : 1;
-    if (const char *e = std::getenv("D2G_DEVICE_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ndev = int(std::min<size_t>(size_t(v), std::max<size_t>(groups.size(), 1))); }
+    if (const char *e = std::getenv("D2G_DEVICE_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ndev = v; }
+    const size_t nthreads_dev = std::max<size_t>(1, std::min<size_t>(size_t(ndev) * devs.size(), std::max<size_t>(groups.size(), 1)));
     std::atomic<size_t> taken{0};
     std::mutex smu;
-    auto device_loop = [&](d2g_ctx *dctx) {
+    struct KAcc { int launches = 0; double total_ms = 0; };
+    std::vector<std::array<KAcc, 3>> kacc(devs.size());                    // per device: k0, k1, k3
+    std::vector<size_t> groups_of(devs.size(), 0);
+    auto device_loop = [&](d2g_ctx *dctx, size_t di) {
+        if (!dctx) {                                                        // every thread but the first makes its own context, in parallel
+            const int rc2 = d2g_ctx_create(devs[di], &dctx);
+            if (rc2 != D2G_OK) die(std::string("d2g_ctx_create (device thread, GPU ") + std::to_string(devs[di]) + "): " + d2g_strerror(rc2));
+            if (g_stats.on) (void)d2g_set_timing(dctx, TIME_ALL);
+        }
         d2g_sketcher *dsk = nullptr;
         check(dctx, d2g_sketcher_create(dctx, &dsk), "d2g_sketcher_create");
         double gpu = 0; uint64_t bases = 0; size_t ndevg = 0, nhostg = 0; double tp = 0;
@@ -410,31 +493,30 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
                 pool.push_back(r.sp);
             }
         }
-        if (g_release_at_exit) d2g_sketcher_destroy(dsk);
+        std::array<KAcc, 3> mine;
+        if (g_stats.on) {
+            const char *names[3] = {"k0", "k1", "k3"};
+            for (int x = 0; x < 3; ++x) { int n = 0; float avg = 0, last = 0; if (d2g_kernel_ms(dctx, names[x], 1, &n, &avg, &last) == D2G_OK) { mine[x].launches = n; mine[x].total_ms = double(avg) * n; } }
+        }
+        if (g_release_at_exit) { d2g_sketcher_destroy(dsk); if (dctx != ctx) d2g_ctx_destroy(dctx); }
         std::lock_guard<std::mutex> lk(smu);
         t_gpu += gpu; total_bases += bases; n_dev_groups += ndevg; n_host_groups += nhostg; t_parse += tp;
+        groups_of[di] += ndevg + nhostg;
+        for (int x = 0; x < 3; ++x) { kacc[di][x].launches += mine[x].launches; kacc[di][x].total_ms += mine[x].total_ms; }
     };
     std::vector<std::thread> more;
-    std::vector<d2g_ctx *> more_ctx;
     const double t_dev0 = now();
-    for (int d = 1; d < ndev; ++d) {
-        d2g_ctx *c2 = nullptr;
-        const int rc2 = d2g_ctx_create(o.device, &c2);
-        if (rc2 != D2G_OK) die(std::string("d2g_ctx_create (device thread): ") + d2g_strerror(rc2));
-        more_ctx.push_back(c2);
-        more.emplace_back(device_loop, c2);
-    }
+    for (size_t t = 1; t < nthreads_dev; ++t) more.emplace_back(device_loop, (d2g_ctx *)nullptr, t / size_t(ndev));
     const double t_dev1 = now();
-    device_loop(ctx);
+    device_loop(ctx, 0);
     for (auto &th : more) th.join();
     const double t_dev2 = now();
     { std::lock_guard<std::mutex> lk(fmu); fin_closing = true; }
     fcv.notify_all();
     finisher.join();
-    if (g_release_at_exit) for (d2g_ctx *c2 : more_ctx) d2g_ctx_destroy(c2);
     (void)sk;
-    if (o.verbosity) std::fprintf(stderr, "[d2g] device side: %d device threads (extra contexts %.3fs), device loops %.3fs wall, drain of the finisher %.3fs\n", ndev,
-                                  t_dev1 - t_dev0, t_dev2 - t_dev1, now() - t_dev2);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] device side: %zu device threads over %zu GPU(s) (started in %.3fs), device loops %.3fs wall, drain of the finisher %.3fs\n", nthreads_dev,
+                                  devs.size(), t_dev1 - t_dev0, t_dev2 - t_dev1, now() - t_dev2);
     for (auto &th : parsers) th.join();
     for (d2g_seqpack *p : pool) d2g_seqpack_destroy(p);
     const double t_pipe = now();
@@ -448,6 +530,27 @@ void sketch_core(Result &res, const Options &o, LazyCtx &lctx) {
                                   todo.size(), total_bases, groups.size(), n_dev_groups, n_host_groups, t_parse, t_read_raw, t_host_pack, nparsers, t_gpu, t_fin,
                                   nbufs, buf_bytes >> 20, t_pin);
     if (o.verbosity) std::fprintf(stderr, "[d2g] sketch wall: setup (stat, cache probe) %.3fs, ingest pipeline %.3fs\n", t_setup - t_enter, t_pipe - t_setup);
+    if (g_stats.on) {
+        std::string dj = "[";
+        const char *names[3] = {"k0", "k1", "k3"};
+        for (size_t d = 0; d < devs.size(); ++d) {
+            dj += std::string(d ? ", " : "") + "{\"index\": " + std::to_string(devs[d]) + ", \"name\": " + Stats::esc(device_label(devs[d])) + ", \"groups\": " + std::to_string(groups_of[d]);
+            for (int x = 0; x < 3; ++x)
+                dj += std::string(", \"") + names[x] + "\": {\"launches\": " + std::to_string(kacc[d][x].launches) + ", \"total_ms\": " + Stats::numstr(kacc[d][x].total_ms) + "}";
+            dj += "}";
+        }
+        dj += "]";
+        const size_t mm = d2g_oph_m(S);
+        // ceil(L/4) + 8 m per input (set sketches), + 8 for the total weight of a multiset sketch
+        const double alg = double((total_bases + 3) / 4) + double(todo.size()) * (8.0 * double(o.sspace == SPACE_MULTISET ? S : mm) + (o.sspace == SPACE_MULTISET ? 8.0 : 0.0));
+        g_stats.raw("sketch", std::string("{\"inputs\": ") + std::to_string(N) + ", \"sketched\": " + std::to_string(todo.size()) + ", \"from_cache\": " + std::to_string(N - todo.size()) +
+                    ", \"k\": " + std::to_string(o.k) + ", \"sketchsize\": " + std::to_string(S) + ", \"space\": " + (o.sspace == SPACE_MULTISET ? "\"multiset (K3: counts + BagMinHash)\"" : "\"set (K1: OPH)\"") +
+                    ", \"groups\": " + std::to_string(groups.size()) + ", \"groups_parsed_on_device\": " + std::to_string(n_dev_groups) + ", \"bases\": " + std::to_string(total_bases) +
+                    ", \"algorithmic_bytes\": " + Stats::numstr(alg) + ", \"device_threads\": " + std::to_string(nthreads_dev) + ", \"parser_threads\": " + std::to_string(nparsers) +
+                    ", \"devices\": " + dj +
+                    ", \"wall_s\": {\"setup\": " + Stats::numstr(t_setup - t_enter) + ", \"ingest_pipeline\": " + Stats::numstr(t_pipe - t_setup) + ", \"device_loops\": " + Stats::numstr(t_dev2 - t_dev1) +
+                    ", \"device_threads_busy_sum\": " + Stats::numstr(t_gpu) + ", \"parser_threads_sum\": " + Stats::numstr(t_parse) + ", \"finisher_x87_and_cache\": " + Stats::numstr(t_fin) + "}}");
+    }
     write_stacked(res, o);
 }
 
@@ -590,9 +693,10 @@ struct Emitter {
     const Result &res;
     std::FILE *fp = nullptr;
     bool own = false;
-    // (Binary matrices through a shared mapping of the output file, filled by all worker threads, were measured at config 4:
-    // 5 GB copied in 0.57 s instead of 0.74 s through fwrite, but unmapping the dirty pages then took another 0.51 s on the
-    // overlay file system of the box: fwrite stays.)
+    // Binary matrices leave through ONE buffered stream.  Measured and dropped: (round 3) a shared mapping of the output filled by
+    // all threads -- copy 0.74 -> 0.57 s for config 4's 5 GB, but unmapping the dirty pages cost another 0.51 s on the box's overlay
+    // file system; (round 4) the batch cut into 4 MiB pieces that 8 threads pwrite() at their offsets -- no gain at all (config 3:
+    // 22 ms either way, config 4: 0.50 s either way, ~10 GB/s): buffered writes to one file serialise on its inode lock.
     Emitter(const Options &oo, const Result &r) : o(oo), res(r) {
         const std::string outp = (o.cmpout.empty() || o.cmpout.front() == '-') ? "/dev/stdout" : o.cmpout;   // emitrect.cpp:114-115
         if (outp == "/dev/stdout") fp = stdout;
@@ -659,10 +763,16 @@ struct DevBuf {
     DevBuf(d2g_ctx *c, size_t n) : ctx(c) { check(c, d2g_malloc(c, n ? n : 4, &p), "d2g_malloc"); }
     ~DevBuf() { if (g_release_at_exit) d2g_free(ctx, p); }
 };
-struct PinnedBuf {                            // page-locked host staging, reused across row batches
-    d2g_ctx *ctx; void *p = nullptr;
-    PinnedBuf(d2g_ctx *c, size_t n) : ctx(c) { check(c, d2g_malloc_host(c, n ? n : 4, &p), "d2g_malloc_host"); }
-    ~PinnedBuf() { if (g_release_at_exit) d2g_free_host(ctx, p); }
+// Host staging of a row batch: PLAIN page-aligned memory.  Rounds 2-3 page-locked these slots (hipHostMalloc); measured on MI355X /
+// ROCm 7 (tools/cmp_setup_time2.py): a pageable D2H of 16 MiB takes 0.32 ms (1.1 ms the first time a buffer is touched) -- the
+// same 50 GB/s as from page-locked memory -- while page-locking costs 0.2-0.28 ms per MiB (3 x 64 MiB = 56 ms) AND serialises
+// with the operand upload inside the runtime (the upload of config 3 took 86 ms next to it instead of 30).
+struct HostBuf {
+    void *p = nullptr;
+    explicit HostBuf(size_t n) { if (posix_memalign(&p, 4096, std::max<size_t>(n, 4096)) != 0) die("out of memory (row-batch staging)"); }
+    ~HostBuf() { if (g_release_at_exit) std::free(p); }
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -677,29 +787,70 @@ struct EmitQueue : SlotQueue<EmitJob> {
     }
 };
 
-// D2G_DEVICES = "all" | "0,1,2": the GPUs `cmp` may spread a symmetric all-pairs job over (default: the one device
-// D2G_DEVICE names).  A list that repeats a device is allowed (loopback transport: used by the tests on one GPU).
-std::vector<int> cmp_devices(const Options &o) {
-    std::vector<int> d;
-    const char *e = std::getenv("D2G_DEVICES");
-    if (!e || !*e) return {o.device};
-    if (std::strcmp(e, "all") == 0) { for (int i = 0; i < d2g_device_count(); ++i) d.push_back(i); }
-    else for (const char *p = e; *p;) { char *q; const long v = std::strtol(p, &q, 10); if (q == p) break; d.push_back(int(v)); p = *q == ',' ? q + 1 : q; }
-    if (d.empty()) d.push_back(o.device);
-    return d;
+// values per row batch: a slot is one batch's staging; three slots cycle device -> host epilogue -> emitter.  Small jobs take small
+// slots (more batches cost little: the pair kernel is launched per row range), big jobs 64 MiB ones.
+size_t cmp_slot_values(size_t total_vals) {
+    size_t v = std::min<size_t>(size_t(1) << 24, std::max<size_t>(size_t(1) << 22, total_vals / 12));
+    if (const char *e = std::getenv("D2G_CMP_SLOT_VALUES")) { const long long x = std::atoll(e); if (x >= 1) v = size_t(x); }   // tests: tiny slots
+    return v;
 }
 
-// Symmetric all-pairs over several GPUs from ONE process (the reference's seam is the single call
-// emit_rectangular(opts, result), src/cmp_core.cpp:746-751).  Every GPU gets a contiguous block of rows of the
-// signature matrix; one exchange (d2g_allpairs_prepare_all: all-to-all of column slices, sharded prepare, all-gather
-// of the bit planes over RCCL/xGMI) leaves the whole operand on every GPU; row batches of the condensed triangle are
-// then dealt to the GPUs round-robin, computed concurrently and emitted in row order.
-// Returns false (nothing emitted yet) when the sharded bit-sliced prepare overflowed its rank table on some rank -- an
-// adversarial / extremely skewed register column at N > 21 845: the caller then takes the single-GPU path, whose AUTO
-// algorithm falls back to the direct kernel.
+// the shape of a dense comparison job (src/emitrect.cpp:211-323): which rows are emitted, how many values each has
+struct CmpShape {
+    bool symmetric; size_t ns, nrows, c0, c1, ncol, total_vals, widest;
+    CmpShape(const Options &o, const Result &res) {
+        ns = res.names.size();
+        symmetric = o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP;
+        const size_t nq = res.nq, nf = o.ok == PANEL ? ns - nq : ns;
+        c0 = o.ok == PANEL ? nf : 0; c1 = ns; ncol = symmetric ? 0 : c1 - c0;
+        nrows = symmetric ? ns : nf;
+        total_vals = symmetric ? ns * (ns - 1) / 2 : nf * ncol;
+        widest = symmetric ? (ns ? ns - 1 : 0) : ncol;
+    }
+    // the batch of rows starting at r0 that fits `cap` values -> (r1, values)
+    std::pair<size_t, size_t> batch(size_t r0, size_t cap) const {
+        size_t r1 = r0, cnt = 0;
+        if (symmetric) while (r1 < ns && (cnt == 0 || cnt + (ns - 1 - r1) <= cap)) { cnt += ns - 1 - r1; ++r1; }
+        else { r1 = std::min(nrows, r0 + std::max<size_t>(1, cap / std::max<size_t>(ncol, 1))); cnt = (r1 - r0) * ncol; }
+        return {r1, cnt};
+    }
+};
+
+// counts of a rectangular batch -> floats (emitrect.cpp:211-268 call compare(i, j) per cell: cmp_core.cpp:458-517)
+void rect_epilogue(const Options &o, const CmpShape &sh, size_t r0, size_t r1, const uint32_t *ca, const uint32_t *cb, const double *cards, size_t S,
+                   bool have_lut, const std::vector<float> &lut, bool multiset, bool need_gtlt, float *out) {
+#ifdef _OPENMP
+    #pragma omp parallel for schedule(dynamic, 4) num_threads(o.workers())
+#endif
+    for (size_t i = r0; i < r1; ++i)
+        for (size_t j = sh.c0; j < sh.c1; ++j) {
+            const size_t p = (i - r0) * sh.ncol + (j - sh.c0);
+            out[p] = have_lut ? lut[ca[p]]
+                   : multiset ? d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k)
+                   : need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
+                               : d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], o.measure, o.k);
+        }
+}
+
+std::string planes_json(d2g_ctx *ctx, const d2g_cmp_set *set) {
+    unsigned md = 0; int nb = 0; float mean = 0;
+    if (d2g_cmp_set_planes(ctx, set, nullptr, &md, &nb, &mean) != D2G_OK) return "null";
+    return "{\"max\": " + std::to_string(nb) + ", \"mean\": " + Stats::numstr(mean) + ", \"max_shared_values_per_column_plus1\": " + std::to_string(md) + "}";
+}
+
+// A dense comparison job over several GPUs from ONE process (the reference's seam is the single call
+// emit_rectangular(opts, result), src/cmp_core.cpp:746-751).  Every GPU gets a contiguous block of rows of the signature matrix; one
+// exchange (d2g_allpairs_prepare_all: all-to-all of column slices, sharded prepare, all-gather of the bit planes over RCCL/xGMI)
+// leaves the whole bit-sliced operand on every GPU; row batches -- of the condensed triangle (emitrect.cpp:290-323), of the square
+// matrix (--square, :249-268) or of the reference x query panel (-Q, :211-247) -- are then dealt to the GPUs round-robin, computed
+// concurrently, and emitted in row order through the slot queue: byte-identical to the single-GPU output.
+// Returns false (nothing emitted yet) when the sharded bit-sliced prepare overflowed its rank table on some rank -- an adversarial /
+// extremely skewed register column at N > 21 845: the caller then takes the single-GPU path, whose AUTO algorithm falls back to the
+// direct kernel.
 bool cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs, bool have_lut, const std::vector<float> &lut,
                     bool multiset) {
-    const size_t ns = res.names.size(), S = o.sketchsize;
+    const CmpShape sh(o, res);
+    const size_t ns = sh.ns, S = o.sketchsize;
     const int W = int(devs.size());
     const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.sigs());
     const double *cards = res.cardinalities.data();
@@ -708,6 +859,7 @@ bool cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
     for (int r = 0; r < W; ++r) {
         const int rc = d2g_ctx_create(devs[r], &ctxs[r]);
         if (rc != D2G_OK) die(std::string("D2G_DEVICES: d2g_ctx_create(") + std::to_string(devs[r]) + "): " + d2g_strerror(rc));
+        if (g_stats.on) (void)d2g_set_timing(ctxs[r], TIME_ALL);
     }
     std::vector<d2g_comm *> comms(W, nullptr);
     check(ctxs[0], d2g_comm_create_all(ctxs.data(), W, comms.data()), "d2g_comm_create_all");
@@ -738,56 +890,80 @@ bool cmp_core_multi(const Options &o, Result &res, const std::vector<int> &devs,
     const double t_prep = now() - t0;
     Emitter em(o, res);
     em.header();
-    const size_t max_vals = size_t(1) << 27;
-    const size_t total_pairs = ns * (ns - 1) / 2, cap = std::min(std::max<size_t>(total_pairs, 1), max_vals + ns);
+    const size_t cap = std::max<size_t>(1, std::min(std::max(cmp_slot_values(sh.total_vals), sh.widest), std::max<size_t>(sh.total_vals, 1)));
+    const bool fused = have_lut && sh.symmetric;                    // device floats (table epilogue inside the pair kernel)
     std::vector<std::unique_ptr<DevBuf>> da(W), dlut(W);
-    std::vector<std::unique_ptr<PinnedBuf>> hout(W), hca(W);
     for (int r = 0; r < W; ++r) {
         da[r].reset(new DevBuf(ctxs[r], cap * 4));
         dlut[r].reset(new DevBuf(ctxs[r], (S + 1) * sizeof(float)));
-        hout[r].reset(new PinnedBuf(ctxs[r], cap * 4));
-        hca[r].reset(new PinnedBuf(ctxs[r], have_lut ? 4 : cap * 4));
         if (have_lut) check(ctxs[r], d2g_memcpy_h2d(ctxs[r], dlut[r]->p, lut.data(), (S + 1) * sizeof(float), nullptr), "h2d lut");
     }
-    double t_dev = 0, t_emit = 0;
+    const int NSLOT = 2 * W + 1;
+    std::vector<std::unique_ptr<HostBuf>> hout(NSLOT), hca(NSLOT);
+    for (int i = 0; i < NSLOT; ++i) { hout[i].reset(new HostBuf(cap * 4)); hca[i].reset(new HostBuf(fused ? 4 : cap * 4)); }
+    double t_dev = 0;
+    const double t_loop = now();
     struct Batch { size_t r0, r1, cnt; };
-    for (size_t next = 0; next < ns;) {
-        // one round: up to W consecutive row batches, one per GPU, launched back to back (asynchronous)
-        std::vector<Batch> round;
-        const double ta = now();
-        for (int r = 0; r < W && next < ns; ++r) {
-            size_t r1 = next, cnt = 0;
-            while (r1 < ns && (cnt == 0 || cnt + (ns - 1 - r1) <= max_vals)) { cnt += ns - 1 - r1; ++r1; }
-            round.push_back({next, r1, cnt});
-            if (cnt) {
-                const d2g_cmp_set *set = d2g_allpairs_operand(engs[r]);
-                if (have_lut) check(ctxs[r], d2g_cmp_lut_ut_dev(ctxs[r], set, next, r1, (const float *)dlut[r]->p, (float *)da[r]->p, nullptr), "d2g_cmp_lut_ut_dev");
-                else check(ctxs[r], d2g_cmp_eqcount_ut_dev(ctxs[r], set, next, r1, (uint32_t *)da[r]->p, nullptr), "d2g_cmp_eqcount_ut_dev");
-            }
-            next = r1;
-        }
-        t_dev += now() - ta;
-        for (size_t b = 0; b < round.size(); ++b) {                 // drain in row order
-            const Batch &bt = round[b];
-            const double tb = now();
-            float *out = hout[b]->as<float>();
-            if (bt.cnt) {
-                if (have_lut) check(ctxs[b], d2g_memcpy_d2h(ctxs[b], out, da[b]->p, bt.cnt * 4, nullptr), "d2h");
-                else {
-                    uint32_t *ca = hca[b]->as<uint32_t>();
-                    check(ctxs[b], d2g_memcpy_d2h(ctxs[b], ca, da[b]->p, bt.cnt * 4, nullptr), "d2h");
-                    check(ctxs[b], d2g_epilogue_ut(ca, nullptr, cards, ns, S, bt.r0, bt.r1, o.measure, o.k, multiset, int(o.workers()), out),
-                          "d2g_epilogue_ut");
+    size_t nbatches = 0;
+    double emit_busy = 0;
+    {
+        EmitQueue eq(em, NSLOT);
+        for (size_t next = 0; next < sh.nrows;) {
+            // one round: up to W consecutive row batches, one per GPU, launched back to back (asynchronous) ...
+            std::vector<Batch> round;
+            const double ta = now();
+            for (int r = 0; r < W && next < sh.nrows; ++r) {
+                const auto b = sh.batch(next, cap);
+                round.push_back({next, b.first, b.second});
+                if (b.second) {
+                    const d2g_cmp_set *set = d2g_allpairs_operand(engs[r]);
+                    if (!sh.symmetric) check(ctxs[r], d2g_cmp_eqcount_rect_dev(ctxs[r], set, next, b.first, sh.c0, sh.c1, (uint32_t *)da[r]->p, nullptr), "d2g_cmp_eqcount_rect_dev");
+                    else if (have_lut) check(ctxs[r], d2g_cmp_lut_ut_dev(ctxs[r], set, next, b.first, (const float *)dlut[r]->p, (float *)da[r]->p, nullptr), "d2g_cmp_lut_ut_dev");
+                    else check(ctxs[r], d2g_cmp_eqcount_ut_dev(ctxs[r], set, next, b.first, (uint32_t *)da[r]->p, nullptr), "d2g_cmp_eqcount_ut_dev");
                 }
+                next = b.first;
             }
-            const double tc = now();
-            em.rows(bt.r0, bt.r1, out, [&](size_t i) { return ns - 1 - i; });
-            t_dev += tc - tb; t_emit += now() - tc;
+            // ... drained in row order into free slots; the emitter thread writes slot i while the next ones are copied / finished
+            for (size_t b = 0; b < round.size(); ++b) {
+                const Batch &bt = round[b];
+                const int si = eq.acquire();
+                float *out = hout[si]->as<float>();
+                if (bt.cnt) {
+                    if (fused) check(ctxs[b], d2g_memcpy_d2h(ctxs[b], out, da[b]->p, bt.cnt * 4, nullptr), "d2h");
+                    else {
+                        uint32_t *ca = hca[si]->as<uint32_t>();
+                        check(ctxs[b], d2g_memcpy_d2h(ctxs[b], ca, da[b]->p, bt.cnt * 4, nullptr), "d2h");
+                        if (sh.symmetric) check(ctxs[b], d2g_epilogue_ut(ca, nullptr, cards, ns, S, bt.r0, bt.r1, o.measure, o.k, multiset, int(o.workers()), out), "d2g_epilogue_ut");
+                        else rect_epilogue(o, sh, bt.r0, bt.r1, ca, nullptr, cards, S, have_lut, lut, multiset, false, out);
+                    }
+                }
+                if (sh.symmetric) eq.submit_rows(si, bt.r0, bt.r1, out, [ns](size_t i) { return ns - 1 - i; });
+                else { const size_t ncol = sh.ncol; eq.submit_rows(si, bt.r0, bt.r1, out, [ncol](size_t) { return ncol; }); }
+                ++nbatches;
+            }
+            t_dev += now() - ta;
         }
+        eq.finish();
+        emit_busy = eq.t_busy;
     }
-    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp on %d GPUs (%s): %zu sketches x S=%zu: upload+exchange+prepare %.3fs, device+D2H+epilogue %.3fs, emit %.3fs\n",
-                                  W, d2g_comm_is_rccl(comms[0]) ? "RCCL" : "loopback", ns, S, t_prep, t_dev, t_emit);
-    da.clear(); dlut.clear(); hout.clear(); hca.clear();
+    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp on %d GPUs (%s): %zu sketches x S=%zu: upload+exchange+prepare %.3fs, %zu batches %.3fs wall (device+D2H+epilogue %.3fs busy, emit %.3fs busy, overlapped)\n",
+                                  W, d2g_comm_is_rccl(comms[0]) ? "RCCL" : "loopback", ns, S, t_prep, nbatches, now() - t_loop, t_dev, emit_busy);
+    if (g_stats.on) {
+        std::string dj = "[";
+        for (int r = 0; r < W; ++r)
+            dj += std::string(r ? ", " : "") + "{\"index\": " + std::to_string(devs[r]) + ", \"name\": " + Stats::esc(device_label(devs[r])) +
+                  ", \"k2\": " + Stats::kernel_json(ctxs[r], "k2") + ", \"k2prep\": " + Stats::kernel_json(ctxs[r], "k2prep") + "}";
+        dj += "]";
+        g_stats.raw("cmp", std::string("{\"sketches\": ") + std::to_string(ns) + ", \"sketchsize\": " + std::to_string(S) + ", \"values\": " + std::to_string(sh.total_vals) +
+                    ", \"shape\": " + (sh.symmetric ? "\"upper triangle\"" : o.ok == PANEL ? "\"panel\"" : "\"square\"") + ", \"algo\": \"bitslice\", \"transport\": " +
+                    (d2g_comm_is_rccl(comms[0]) ? "\"RCCL\"" : "\"loopback\"") + ", \"exchange_chunks\": " + std::to_string(d2g_allpairs_chunks(engs[0])) +
+                    ", \"bit_planes\": " + planes_json(ctxs[0], d2g_allpairs_operand(engs[0])) +
+                    ", \"algorithmic_bytes\": " + Stats::numstr(8.0 * double(S) * double(ns) + 4.0 * double(sh.total_vals)) + ", \"batches\": " + std::to_string(nbatches) +
+                    ", \"slot_values\": " + std::to_string(cap) + ", \"devices\": " + dj +
+                    ", \"wall_s\": {\"upload_exchange_prepare\": " + Stats::numstr(t_prep) + ", \"batches\": " + Stats::numstr(now() - t_loop) + ", \"device_d2h_epilogue_busy\": " +
+                    Stats::numstr(t_dev) + ", \"emit_busy\": " + Stats::numstr(emit_busy) + "}}");
+    }
+    da.clear(); dlut.clear();
     for (int r = 0; r < W; ++r) { d2g_allpairs_destroy(engs[r]); d2g_comm_destroy(comms[r]); d2g_ctx_destroy(ctxs[r]); }
     return true;
 }
@@ -796,11 +972,13 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     const size_t ns = res.names.size(), S = o.sketchsize;
     if (res.nsigs() != ns * S) die("Empty signatures; trying to compare but don't have any");
     const bool multiset = o.sspace != SPACE_SET;
+    double t_densify = 0;
     if (o.kmer_result == ONE_PERM) {                                // cmp_core.cpp:686-718
         size_t nfilled = 0;
         const double td = now();
         check(ctx, d2g_densify(res.sigs(), ns, S, &nfilled, int(o.workers())), "d2g_densify");
-        if (o.verbosity) std::fprintf(stderr, "[d2g] densify scan %.3fs\n", now() - td);
+        t_densify = now() - td;
+        if (o.verbosity) std::fprintf(stderr, "[d2g] densify scan %.3fs\n", t_densify);
         if (o.verbosity && nfilled) std::fprintf(stderr, "Densified a total of %zu/%zu entries\n", nfilled, S * ns);
     }
     const uint64_t *bits = reinterpret_cast<const uint64_t *>(res.sigs());
@@ -809,62 +987,53 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
     const bool have_lut = d2g_epilogue_lut(S, o.measure, o.k, multiset, lut.data()) == D2G_OK;
     const bool need_gtlt = !multiset && (S & (S - 1)) != 0;
     {
-        const std::vector<int> devs = cmp_devices(o);
-        if (devs.size() > 1 && (o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP) && !need_gtlt && ns >= 2) {
+        const std::vector<int> devs = job_devices(o);
+        if (devs.size() > 1 && !need_gtlt && ns >= 2) {
             if (cmp_core_multi(o, res, devs, have_lut, lut, multiset)) return;
+        } else if (devs.size() > 1) {
+            // said without -v: the user asked for several GPUs and gets one
+            std::fprintf(stderr, "[d2g] D2G_DEVICES ignored for this job (%s): it runs on GPU %d alone\n",
+                         need_gtlt ? "a sketch size that is not a power of two needs (gt, lt) counts from the raw registers, which the gathered bit-plane operand does not hold"
+                                   : "fewer than two sketches", o.device);
         }
-        if (devs.size() > 1 && o.verbosity)
-            std::fprintf(stderr, "[d2g] D2G_DEVICES ignored: only symmetric all-pairs with equality counts spreads over GPUs\n");
     }
     d2g_cmp_set *set = nullptr;
     const double t0 = now();
-    // values per device batch: 64 MiB of floats per slot, three slots in flight (device / D2H + epilogue / emit).  Small
-    // slots keep the page-locked allocations cheap (pinning 3 x 512 MiB cost more than the whole device work of config 3).
-    size_t slot_vals = size_t(1) << 24;
-    if (const char *e = std::getenv("D2G_CMP_SLOT_VALUES")) { const long long v = std::atoll(e); if (v >= 1) slot_vals = size_t(v); }   // tests: tiny slots
-    const bool symmetric = o.ok == SYMMETRIC_ALL_PAIRS || o.ok == PHYLIP;
-    const size_t nq = res.nq, nf = o.ok == PANEL ? ns - nq : ns;
-    const size_t c0 = o.ok == PANEL ? nf : 0, c1 = ns, ncol = symmetric ? 0 : c1 - c0;
-    const size_t nrows = symmetric ? ns : nf;
-    const size_t total_vals = symmetric ? ns * (ns - 1) / 2 : nf * ncol;
-    const size_t widest = symmetric ? (ns ? ns - 1 : 0) : ncol;
-    const size_t cap = std::max<size_t>(1, std::min(std::max(slot_vals, widest), std::max<size_t>(total_vals, 1)));
+    const CmpShape sh(o, res);
+    const size_t cap = std::max<size_t>(1, std::min(std::max(cmp_slot_values(sh.total_vals), sh.widest), std::max<size_t>(sh.total_vals, 1)));
     constexpr int NSLOT = 3;
-    struct Slot { std::unique_ptr<PinnedBuf> out, ca, cb; };
+    const bool fused = have_lut && sh.symmetric;
+    struct Slot { std::unique_ptr<HostBuf> out, ca, cb; };
     Slot slots[NSLOT];
-    // page-locking the slots (tens of ms) and the output header run on a helper thread, under the upload + prepare of the operand
+    for (auto &sl : slots) {                                        // plain memory: nothing to page-lock, nothing for a helper thread to do
+        sl.out.reset(new HostBuf(cap * 4));
+        sl.ca.reset(new HostBuf(fused ? 4 : cap * 4));
+        sl.cb.reset(new HostBuf(need_gtlt ? cap * 4 : 4));
+    }
     Emitter em(o, res);
-    std::thread side([&] {
-        em.header();
-        for (auto &sl : slots) {
-            sl.out.reset(new PinnedBuf(ctx, cap * 4));
-            sl.ca.reset(new PinnedBuf(ctx, have_lut && symmetric ? 4 : cap * 4));
-            sl.cb.reset(new PinnedBuf(ctx, need_gtlt ? cap * 4 : 4));
-        }
-    });
+    em.header();
     check(ctx, d2g_cmp_set_create(ctx, bits, ns, S, need_gtlt ? int(D2G_CMP_DIRECT) : int(D2G_CMP_AUTO), &set), "d2g_cmp_set_create");
     const double t_set = now();
     DevBuf dlut(ctx, (S + 1) * sizeof(float));
     if (have_lut) check(ctx, d2g_memcpy_h2d(ctx, dlut.p, lut.data(), (S + 1) * sizeof(float), nullptr), "h2d lut");
     DevBuf da(ctx, cap * 4), db(ctx, need_gtlt ? cap * 4 : 4);
     const double t_bufs = now();
-    side.join();
-    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp set-up: operand upload + prepare %.3fs, device buffers %.3fs, waiting for the page-locked slots %.3fs\n",
-                                  t_set - t0, t_bufs - t_set, now() - t_bufs);
-    double t_dev = 0;
+    if (o.verbosity) std::fprintf(stderr, "[d2g] cmp set-up: host slots + header + operand upload + prepare %.3fs, device buffers %.3fs (slots of %zu values)\n",
+                                  t_set - t0, t_bufs - t_set, cap);
+    double t_dev = 0, emit_busy = 0;
+    size_t nbatches = 0;
     const double t_loop = now();
     {
         EmitQueue eq(em, NSLOT);
-        for (size_t r0 = 0; r0 < nrows;) {
-            size_t r1 = r0, cnt = 0;
-            if (symmetric) while (r1 < ns && (cnt == 0 || cnt + (ns - 1 - r1) <= cap)) { cnt += ns - 1 - r1; ++r1; }
-            else { r1 = std::min(nrows, r0 + std::max<size_t>(1, cap / std::max<size_t>(ncol, 1))); cnt = (r1 - r0) * ncol; }
+        for (size_t r0 = 0; r0 < sh.nrows;) {
+            const auto bt = sh.batch(r0, cap);
+            const size_t r1 = bt.first, cnt = bt.second;
             const int si = eq.acquire();
             Slot &sl = slots[si];
             float *out = sl.out->as<float>();
             uint32_t *ca = sl.ca->as<uint32_t>(), *cb = sl.cb->as<uint32_t>();
             const double ta = now();
-            if (cnt && symmetric) {                                     // emitrect.cpp:290-323
+            if (cnt && sh.symmetric) {                                  // emitrect.cpp:290-323
                 if (have_lut) {
                     check(ctx, d2g_cmp_lut_ut_dev(ctx, set, r0, r1, (const float *)dlut.p, (float *)da.p, nullptr), "d2g_cmp_lut_ut_dev");
                     check(ctx, d2g_memcpy_d2h(ctx, out, da.p, cnt * 4, nullptr), "d2h");
@@ -882,33 +1051,37 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
                 }
             } else if (cnt) {                                           // asymmetric / panel: emitrect.cpp:211-268
                 if (need_gtlt) {
-                    check(ctx, d2g_cmp_gtlt_rect_dev(ctx, set, r0, r1, c0, c1, (uint32_t *)da.p, (uint32_t *)db.p, nullptr), "d2g_cmp_gtlt_rect_dev");
+                    check(ctx, d2g_cmp_gtlt_rect_dev(ctx, set, r0, r1, sh.c0, sh.c1, (uint32_t *)da.p, (uint32_t *)db.p, nullptr), "d2g_cmp_gtlt_rect_dev");
                     check(ctx, d2g_memcpy_d2h(ctx, cb, db.p, cnt * 4, nullptr), "d2h");
                 } else {
-                    check(ctx, d2g_cmp_eqcount_rect_dev(ctx, set, r0, r1, c0, c1, (uint32_t *)da.p, nullptr), "d2g_cmp_eqcount_rect_dev");
+                    check(ctx, d2g_cmp_eqcount_rect_dev(ctx, set, r0, r1, sh.c0, sh.c1, (uint32_t *)da.p, nullptr), "d2g_cmp_eqcount_rect_dev");
                 }
                 check(ctx, d2g_memcpy_d2h(ctx, ca, da.p, cnt * 4, nullptr), "d2h");
-#ifdef _OPENMP
-                #pragma omp parallel for schedule(dynamic, 4) num_threads(o.workers())
-#endif
-                for (size_t i = r0; i < r1; ++i)
-                    for (size_t j = c0; j < c1; ++j) {
-                        const size_t p = (i - r0) * ncol + (j - c0);
-                        out[p] = have_lut ? lut[ca[p]]
-                               : multiset ? d2g_epilogue_neq(ca[p], S, cards[i], cards[j], o.measure, o.k)
-                               : need_gtlt ? d2g_epilogue_gtlt(ca[p], cb[p], S, cards[i], cards[j], o.measure, o.k)
-                                           : d2g_epilogue_gtlt(S - ca[p], 0, S, cards[i], cards[j], o.measure, o.k);
-                    }
+                rect_epilogue(o, sh, r0, r1, ca, cb, cards, S, have_lut, lut, multiset, need_gtlt, out);
             }
             t_dev += now() - ta;
-            if (symmetric) eq.submit_rows(si, r0, r1, out, [ns](size_t i) { return ns - 1 - i; });
-            else eq.submit_rows(si, r0, r1, out, [ncol](size_t) { return ncol; });
+            if (sh.symmetric) eq.submit_rows(si, r0, r1, out, [ns](size_t i) { return ns - 1 - i; });
+            else { const size_t ncol = sh.ncol; eq.submit_rows(si, r0, r1, out, [ncol](size_t) { return ncol; }); }
             r0 = r1;
+            ++nbatches;
         }
         eq.finish();
-        if (o.verbosity) std::fprintf(stderr, "[d2g] cmp: %zu sketches x S=%zu: upload+prepare+buffers %.3fs, batches %.3fs wall (device+D2H+epilogue %.3fs busy, emit %.3fs busy, "
-                                              "overlapped) (algo %s)\n", ns, S, t_loop - t0, now() - t_loop, t_dev, eq.t_busy,
+        emit_busy = eq.t_busy;
+        if (o.verbosity) std::fprintf(stderr, "[d2g] cmp: %zu sketches x S=%zu: upload+prepare+buffers %.3fs, %zu batches %.3fs wall (device+D2H+epilogue %.3fs busy, emit %.3fs busy, "
+                                              "overlapped) (algo %s)\n", ns, S, t_loop - t0, nbatches, now() - t_loop, t_dev, emit_busy,
                                       d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE ? "bitslice" : "direct");
+    }
+    if (g_stats.on) {
+        const bool bs = d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE;
+        g_stats.raw("cmp", std::string("{\"sketches\": ") + std::to_string(ns) + ", \"sketchsize\": " + std::to_string(S) + ", \"values\": " + std::to_string(sh.total_vals) +
+                    ", \"shape\": " + (sh.symmetric ? "\"upper triangle\"" : o.ok == PANEL ? "\"panel\"" : "\"square\"") + ", \"algo\": " + (bs ? "\"bitslice\"" : "\"direct\"") +
+                    ", \"bit_planes\": " + (bs ? planes_json(ctx, set) : std::string("null")) +
+                    ", \"algorithmic_bytes\": " + Stats::numstr(8.0 * double(S) * double(ns) + 4.0 * double(sh.total_vals)) + ", \"batches\": " + std::to_string(nbatches) +
+                    ", \"slot_values\": " + std::to_string(cap) +
+                    ", \"devices\": [{\"index\": " + std::to_string(o.device) + ", \"name\": " + Stats::esc(device_label(o.device)) + ", \"k2\": " + Stats::kernel_json(ctx, "k2") +
+                    ", \"k2prep\": " + Stats::kernel_json(ctx, "k2prep") + "}]" +
+                    ", \"wall_s\": {\"densify_scan\": " + Stats::numstr(t_densify) + ", \"slots_header_upload_prepare\": " + Stats::numstr(t_set - t0) + ", \"batches\": " + Stats::numstr(now() - t_loop) +
+                    ", \"device_d2h_epilogue_busy\": " + Stats::numstr(t_dev) + ", \"emit_busy\": " + Stats::numstr(emit_busy) + "}}");
     }
     if (g_release_at_exit) d2g_cmp_set_destroy(set);
 }
@@ -925,12 +1098,16 @@ int sketch_main(int argc, char **argv) {                          // src/sketch_
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
     if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
     if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); sketch_usage(); return 1; }
-    LazyCtx lctx(o);
+    o.device = job_devices(o)[0];
+    g_stats.on = !o.gpu_stats.empty(); g_stats.path = o.gpu_stats;
+    g_stats.str("command", "sketch");
+    LazyCtx lctx(o, D2G_WARM_COPY | (o.sspace == SPACE_MULTISET ? D2G_WARM_K3 : D2G_WARM_K1) | (o.cmpout.empty() ? 0 : D2G_WARM_K2));
     Result res;
     if (o.parse_by_seq) sketch_core_byseq(res, o, lctx); else sketch_core(res, o, lctx);
-    if (o.verbosity) std::fprintf(stderr, "[d2g] GPU context %.3fs on a helper thread, under the host ingest\n", lctx.t_create);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] GPU context %.3fs + warm-up %.3fs on a helper thread, under the host ingest\n", lctx.t_create, lctx.t_warm);
     res.nq = o.nq;
     if (!o.cmpout.empty()) cmp_core(o, res, lctx.get());           // sketch_main.cpp:144-148
+    g_stats.raw("context", std::string("{\"create_s\": ") + Stats::numstr(lctx.t_create) + ", \"warmup_s\": " + Stats::numstr(lctx.t_warm) + "}");
     return 0;
 }
 
@@ -940,7 +1117,10 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
     if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
     const double t_begin = now();
-    LazyCtx lctx(o);                                               // under the reading of the sketch file(s)
+    o.device = job_devices(o)[0];
+    g_stats.on = !o.gpu_stats.empty(); g_stats.path = o.gpu_stats;
+    g_stats.str("command", "cmp");
+    LazyCtx lctx(o, D2G_WARM_COPY | D2G_WARM_K2 | (o.presketched ? 0 : (o.sspace == SPACE_MULTISET ? D2G_WARM_K3 : D2G_WARM_K1)));   // under the reading of the sketch file(s)
     Result res;
     if (o.presketched) {
         // suffix sniffing, cmp_main.cpp:305-351
@@ -972,8 +1152,10 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
     }
     const double t_wait = now();
     d2g_ctx *ctx = lctx.get();
-    if (o.verbosity) std::fprintf(stderr, "[d2g] inputs loaded in %.3fs; GPU context %.3fs on a helper thread (%.3fs of it after the inputs were loaded)\n",
-                                  t_wait - t_begin, lctx.t_create, now() - t_wait);
+    if (o.verbosity) std::fprintf(stderr, "[d2g] inputs loaded in %.3fs; GPU context %.3fs + warm-up (first copy, code objects) %.3fs on a helper thread (%.3fs of it after the inputs were loaded)\n",
+                                  t_wait - t_begin, lctx.t_create, lctx.t_warm, now() - t_wait);
+    g_stats.raw("context", std::string("{\"create_s\": ") + Stats::numstr(lctx.t_create) + ", \"warmup_s\": " + Stats::numstr(lctx.t_warm) + ", \"inputs_loaded_s\": " + Stats::numstr(t_wait - t_begin) +
+                ", \"waited_for_context_s\": " + Stats::numstr(now() - t_wait) + "}");
     const double t_cmp = now();
     cmp_core(o, res, ctx);
     if (o.verbosity) std::fprintf(stderr, "[d2g] cmp_core %.3fs in all (densify, upload, batches, closing the output)\n", now() - t_cmp);
@@ -1006,6 +1188,9 @@ int main(int argc, char **argv) {                                 // src/d2.cpp:
             const int rc = is_sketch ? sketch_main(argc - 1, argv + 1) : cmp_main(argc - 1, argv + 1);
             // every output file has been flushed and closed by now (Emitter / write_stacked go out of scope inside)
             std::fflush(nullptr);
+            g_stats.num("in_process_s", now() - t0);
+            g_stats.str("version", DASHING2_VERSION);
+            g_stats.write();
             if (std::getenv("D2G_VERBOSE_EXIT")) std::fprintf(stderr, "[d2g] in-process time %.3fs\n", now() - t0);
             if (!std::getenv("D2G_FULL_TEARDOWN")) _exit(rc);
             return rc;

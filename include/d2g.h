@@ -75,6 +75,17 @@ int         d2g_free_host(d2g_ctx *ctx, void *hptr);
  * exists and register them once it does) */
 int         d2g_host_register(d2g_ctx *ctx, void *hptr, size_t nbytes);
 int         d2g_host_unregister(d2g_ctx *ctx, void *hptr);
+/* Pays one-time costs NOW -- on whatever thread calls it, e.g. a helper thread that has just created the context while the main
+ * thread is still reading its inputs -- instead of inside the first real operation: D2G_WARM_COPY = the runtime's copy machinery
+ * (the first host<->device copy of a process costs ~30 ms, whatever its size), D2G_WARM_K* = the code objects of a kernel family. */
+#define D2G_WARM_COPY 1
+#define D2G_WARM_K0   2
+#define D2G_WARM_K1   4
+#define D2G_WARM_K2   8
+#define D2G_WARM_K3   16
+int         d2g_warmup(d2g_ctx *ctx, int what);
+/* "<marketing name> (<gcn arch>, <n> CUs)" of a device, for logs and --gpu-stats */
+int         d2g_device_name(int device, char *buf, size_t cap);
 int         d2g_memcpy_h2d(d2g_ctx *ctx, void *dst_dev, const void *src_host, size_t nbytes, void *stream);
 int         d2g_memcpy_d2h(d2g_ctx *ctx, void *dst_host, const void *src_dev, size_t nbytes, void *stream);
 /* Per-launch HIP-event timing of the dominant kernels.  With timing enabled every launch of
