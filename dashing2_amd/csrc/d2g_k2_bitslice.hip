@@ -810,6 +810,10 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         if (lds > 48 * 1024)
             D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int nsplit = multi ? set->nsplit : 1;
+        // split passes tell their pending words from final ids by a tag and trust that ids[] holds nothing else that looks pending.  A
+        // prepare that overflowed (status bit 0) may leave pending words behind, and the multi-GPU engine re-uses its exporter sets step
+        // after step: ids[] starts from zero in every split prepare -- a few MB for the narrow column slices that are split
+        if (nsplit > 1) D2G_HIP(ctx, hipMemsetAsync(set->d_ids, 0, S * Npad * sizeof(uint32_t), s));
         hipLaunchKernelGGL(kern, dim3((unsigned)(S * nsplit)), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
                            set->d_ids, set->d_colcnt, set->d_meta + set->ntb, tagbits_max, (uint32_t)S, nsplit);
         hipLaunchKernelGGL(bs_colplan_kernel, dim3(1), dim3(BS_PLAN_THREADS), 0, s, set->d_colcnt, (uint32_t)S, set->ntb, nsplit, set->d_perm,

@@ -1093,10 +1093,24 @@ d2g_ctx *make_ctx(const Options &o) {
     return ctx;
 }
 
+// D2_FMT_EXP_UPPER was the round-2 switch for the float text layout (7 = fmt >= 11, 16 = fmt < 11); --fmt-compat replaced it.  It is
+// still honoured -- with a warning -- when --fmt-compat is not given, so that scripts written against round 2 keep their output.
+void apply_fmt_compat(Options &o) {
+    if (!o.fmt_compat)
+        if (const char *e = std::getenv("D2_FMT_EXP_UPPER")) {
+            const int v = std::atoi(e);
+            if (v == 7 || v == 16) {
+                o.fmt_compat = v == 7 ? 11 : 10;
+                std::fprintf(stderr, "dashing2 (MI355X): D2_FMT_EXP_UPPER=%d is deprecated; use --fmt-compat %d\n", v, o.fmt_compat);
+            } else std::fprintf(stderr, "dashing2 (MI355X): D2_FMT_EXP_UPPER=%s ignored (7 or 16; use --fmt-compat 10|11)\n", e);
+        }
+    if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
+}
+
 int sketch_main(int argc, char **argv) {                          // src/sketch_main.cpp:23-152
     Options o;
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
-    if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
+    apply_fmt_compat(o);
     if (o.paths.empty()) { std::fprintf(stderr, "No paths provided. See usage.\n"); sketch_usage(); return 1; }
     o.device = job_devices(o)[0];
     g_stats.on = !o.gpu_stats.empty(); g_stats.path = o.gpu_stats;
@@ -1115,7 +1129,7 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
     Options o;
     o.is_cmp = true;
     if (int rc = parse_options(argc, argv, o)) return rc - 1;
-    if (o.fmt_compat) set_fmt_compat(o.fmt_compat);
+    apply_fmt_compat(o);
     const double t_begin = now();
     o.device = job_devices(o)[0];
     g_stats.on = !o.gpu_stats.empty(); g_stats.path = o.gpu_stats;

@@ -217,8 +217,10 @@ int  d2g_sketcher_run(d2g_sketcher *sk, const uint8_t *packed, size_t packed_byt
  * spaces).  The packed stream stays in the sketcher's device buffer; the run table comes back to the host.  Then
  * d2g_sketcher_run / d2g_sketcher_run_bmh / d2g_sketcher_run_distinct with packed == NULL and the table of
  * d2g_sketcher_ingested_runs sketch it: registers bit-identical to the host-parsed path.
- * Returns D2G_ERR_UNSUPPORTED -- and stages nothing -- for what only the host parser handles: inputs that do not begin
- * with '>' (gzip members, FASTQ, leading junk), lines that begin with '+' (FASTQ quality sections), files of 2 GiB and more.
+ * Returns D2G_ERR_UNSUPPORTED for what only the host parser handles: inputs that do not begin with '>' (gzip members, FASTQ,
+ * leading junk), lines that begin with '+' (FASTQ quality sections, found only after the device passes have run), files of 2 GiB
+ * and more.  After ANY failed ingest the sketcher's device stream is INVALID -- whatever an earlier ingest left there has been
+ * overwritten or discarded -- and d2g_sketcher_run* with packed == NULL fails until the next successful ingest: re-stage.
  * The pointers of d2g_sketcher_ingested_runs stay valid until the next ingest on this sketcher. */
 int d2g_sketcher_ingest_fasta(d2g_sketcher *sk, const uint8_t *raw, size_t raw_bytes, const uint64_t *file_off,
                               const uint64_t *file_len, size_t nfiles, const uint64_t *genome_file_off /* [n+1] */, size_t n, int k);
@@ -415,7 +417,7 @@ int  d2g_allpairs_status(d2g_allpairs *eng, void *stream);
 /* chunks the engine cuts a rank's column slice into: the exchange of chunk c+1 overlaps the prepare of chunk c inside ONE step
  * (a function of N, S and the world size; D2G_MGPU_CHUNKS overrides it -- identically on every rank: with one process per GPU
  * d2g_allpairs_create exchanges (N, S, world, chunks) over the communicator once and fails with D2G_ERR_INVALID on every rank
- * whose view differs from rank 0's instead of posting mismatched transfers later) */
+ * when any two ranks disagree, instead of posting mismatched transfers later) */
 int  d2g_allpairs_chunks(const d2g_allpairs *eng);
 /* one whole step: prepare + this rank's slab (rows_computed) of the condensed triangle; out has
  * d2g_ut_count(N, r0, r1) entries.  lut_dev == NULL (or lut_dev[i] == NULL): u32 equality counts. */

@@ -537,6 +537,12 @@ def test_cli_float_text_of_large_values_both_fmt_generations(oracle, tmp_path):
     assert a != b and b"e+07" in b and b"e+07" not in a
     r = subprocess.run([EXE, "cmp", "--presketched", "--fmt-compat", "9", str(st)], capture_output=True)
     assert r.returncode == 1 and b"--fmt-compat takes 10" in r.stderr
+    # the round-2 environment switch still selects the layout (with a deprecation warning) when --fmt-compat is absent
+    r = subprocess.run([EXE, "cmp", "--presketched", "-k", str(k), "--phylip", "--union-size", str(st)], capture_output=True, env=dict(os.environ, D2_FMT_EXP_UPPER="7"))
+    assert r.returncode == 0 and r.stdout == b and b"D2_FMT_EXP_UPPER=7 is deprecated" in r.stderr
+    r = subprocess.run([EXE, "cmp", "--presketched", "-k", str(k), "--phylip", "--union-size", "--fmt-compat", "10", str(st)], capture_output=True,
+                       env=dict(os.environ, D2_FMT_EXP_UPPER="7"))
+    assert r.returncode == 0 and r.stdout == a and b"deprecated" not in r.stderr
 
 
 def test_cli_cmp_multi_gpu_overflow_falls_back_to_one_gpu(tmp_path):
