@@ -1031,8 +1031,11 @@ def measure_traffic(args, which=("k2", "k1", "k3"), timeout=240.0):
 
     res = {"seconds": round(time.monotonic() - t0, 1)}
     if "k2" in which:
-        res["k2"] = both(lambda k: "k2_bitslice_kernel" in k or "k2_direct_kernel" in k, largest=True)
-        res["k2_prepare"] = both(lambda k: any(x in k for x in ("bs_transpose", "bs_rank", "bs_colplan", "bs_planes", "k2_transpose")))
+        # ONE compare launch in the child: the pair kernel, or -- sparse tiles -- the kernels of its chain together
+        res["k2"] = both(lambda k: any(x in k for x in ("k2_bitslice_kernel", "k2_direct_kernel", "k2_bitslice_sparse_kernel", "sp_fill", "sp_mark", "sp_or_",
+                                                         "sp_list", "sp_decide", "sp_rows", "sp_gather")))
+        res["k2_prepare"] = both(lambda k: any(x in k for x in ("bs_transpose", "bs_rank", "bs_colplan", "bs_planes", "k2_transpose", "sp_init", "sp_gmin", "sp_label",
+                                                                 "sp_jump", "sp_sort", "sp_permute")))
     if "k1" in which:
         res["k1"] = both(lambda k: "k1_oph_kernel" in k, wide=True, largest=True)
     if "k3" in which:
@@ -1117,6 +1120,7 @@ def run_single(args):
     nk2, k2_ms, _ = ctx.kernel_ms("k2")
     _, prep_ms, _ = ctx.kernel_ms("k2prep")
     max_distinct, nbits, mean_nbits = cs.planes(stream)
+    sparse_info = cs.sparse_info(stream)
     ms_per_step = dt / args.steps * 1e3
     value = pairs_total / (dt / args.steps)
     algo_used = cs.algo
@@ -1125,8 +1129,10 @@ def run_single(args):
     # ---- roofline of the dominant kernel (the pair kernel), rank 0's launch
     alg_bytes = 8 * S * N + 4 * my_pairs          # each sketch read once + one float per pair
     achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
-    kname = "k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2_direct_kernel"
-    pmc_ok = (algo_used == D.CMP_BITSLICE and N == 10000 and S == 1024)
+    sparse_ran = bool(sparse_info.get("sorted_operand")) and not sparse_info.get("dense_kernel_ran")
+    kname = ("k2 sparse chain (sp_fill + sp_mark + sp_or + sp_list + k2_bitslice_sparse_kernel over %d listed tiles)" % sparse_info.get("tiles_listed", 0) if sparse_ran
+             else "k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2_direct_kernel")
+    pmc_ok = (algo_used == D.CMP_BITSLICE and N == 10000 and S == 1024 and not sparse_ran)
     with_prep = alg_bytes / ((k2_ms + prep_ms) * 1e-3) / 1e9 if (k2_ms + prep_ms) > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
@@ -1139,7 +1145,9 @@ def run_single(args):
                                 "dword loads: read side raw/uncalibrated",
                 "kernel": kname, "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
                 "prep_ms": prep_ms,
-                "note": "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute"}
+                "note": ("sparse tiles: only the 32 x 256 tiles that hold a pair with a shared register value are walked, the rest of the output is a fill "
+                         "with the value of 0 equal registers; kernel_ms is the whole compare launch (fill, tile marking, list, pair kernel); D2G_BS_SPARSE=0 walks every tile"
+                         if sparse_ran else "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute")}
 
     def valu(pairs, mean_planes, ms):
         if algo_used == D.CMP_BITSLICE:
@@ -1151,7 +1159,7 @@ def run_single(args):
 
     va, vf = valu(my_pairs, mean_nbits, k2_ms)
     compute = {"bound": "valu", "unit": "lane-ops/s", "achieved": va, "peak": VALU_PEAK_LANEOPS, "frac": vf,
-               "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct}
+               "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct, "sparse": sparse_info}
 
     def measure_matrix(bits_np, n, steps=5):
         """prepare + pair kernel of an n x S matrix on this GPU, whole triangle; returns a small dict"""
@@ -1176,13 +1184,14 @@ def run_single(args):
         _, kms, _ = ctx.kernel_ms("k2")
         _, pms, _ = ctx.kernel_ms("k2prep")
         md, nb, mean = c.planes(stream)
+        sp = c.sparse_info(stream)
         c.close()
         npairs = n * (n - 1) // 2
         ab = 8 * S * n + 4 * npairs
         return {"sketches": n, "pairs_per_s": npairs / d, "ms_per_step": d * 1e3, "kernel_ms": kms, "prep_ms": pms,
                 "bit_planes_max": nb, "bit_planes_mean": mean, "max_shared_values_per_column_plus1": md,
                 "hbm_frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else 0.0,
-                "valu_frac": valu(npairs, mean, kms)[1]}
+                "valu_frac": valu(npairs, mean, kms)[1], "sparse": sp}
 
     config4 = None
     if True:

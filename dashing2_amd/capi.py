@@ -113,6 +113,7 @@ SIGNATURES = {
     "d2g_cmp_set_update_dev": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int), C.POINTER(_f32)]),
     "d2g_cmp_set_status": (_int, [_vp, _vp, _vp]),
+    "d2g_cmp_set_sparse_info": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_warmup": (_int, [_vp, _int]),
     "d2g_device_name": (_int, [_int, C.c_char_p, _sz]),
     "d2g_comm_unique_id": (_int, [_vp]),
@@ -714,6 +715,13 @@ class CmpSet:
     def status(self, stream=None):
         """synchronises; raises D2GError(D2G_ERR_INTERNAL) if the asynchronous prepare overflowed"""
         self.ctx._check(lib().d2g_cmp_set_status(self.ctx._h, self._h, stream))
+
+    def sparse_info(self, stream=None):
+        """-> dict of the sparse path's last upper-triangle launch (synchronises)"""
+        a = np.zeros(4, np.uint32)
+        self.ctx._check(lib().d2g_cmp_set_sparse_info(self.ctx._h, self._h, stream, a.ctypes.data))
+        return {"sorted_operand": bool(a[0]), "tiles_listed": int(a[1]), "marking_gave_up": bool(a[2] & 1), "dense_kernel_ran": bool(a[2] & 2),
+                "callers_order_kept": bool(a[3])}
 
     def planes(self, stream=None):
         """-> (max shared values per column + 1, max id planes of a group, mean id planes); zeros for DIRECT"""

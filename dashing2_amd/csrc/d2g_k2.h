@@ -36,6 +36,26 @@ struct d2g_cmp_set {
     // points the set at the status words every rank's prepare contributed
     bool managed = false;
     const uint32_t *status_words = nullptr; int n_status = 0;
+    // ---- sparse tiles (d2g_k2_bitslice.hip section 4; owning sets only).  The sketches are put in an order that brings sketches
+    // which share register values next to each other (labels = smallest sketch index reachable over shared values), the plane
+    // stream is built in THAT order, and an upper-triangle launch only walks the 32 x 256 tiles that hold at least one pair with a
+    // shared value (every other pair has 0 matches: the output is pre-filled with the value of 0).  Exact for any input; what the
+    // order and the tile list cost is paid back when similarity is block-structured (collections of related genomes).
+    bool sparse_ok = false;       // eligible and enabled (D2G_BS_SPARSE, D2G_BS_SPARSE_MIN_N)
+    bool srt_valid = false;       // d_stream_s / d_sperm describe the operand last prepared
+    bool nat_valid = false;       // d_stream (caller's order; rectangular launches, dense launches) is up to date
+    uint32_t *d_stream_s = nullptr;   // plane stream in sorted order
+    uint32_t *d_sperm = nullptr;      // [Nstride] sketch at sorted position p (0xFFFFFFFF = padding)
+    uint32_t *d_sinv = nullptr;       // [Npad]    sorted position of sketch j
+    uint32_t *d_label = nullptr;      // [2][Npad] labels (two buffers: pointer jumping)
+    uint32_t *d_lcnt = nullptr;       // [Npad+1]  counting sort: sketches per label, then their start positions
+    uint32_t *d_gmin = nullptr;       // [S][SP_GCAP] smallest key among the sketches that hold shared value r of column t
+    uint32_t *d_rowpos = nullptr;     // [Nstride] launch rows: sorted position of launch row k
+    uint32_t *d_rowk = nullptr;       // [Npad]    launch row of sketch j (0xFFFFFFFF = not a row of this launch)
+    uint32_t *d_rowstream = nullptr;  // [planes][Nstride] row-coded words of the launch rows, gathered (partial launches)
+    uint32_t *d_tilebm = nullptr, *d_tiles = nullptr, *d_spctl = nullptr;   // tile bitmap, worklist, {ntiles, flags}
+    uint32_t *d_slots = nullptr;      // [S][tile bitmap] one copy per register column (sp_mark_kernel), folded by sp_or_kernel
+    size_t tilebm_words = 0, tiles_cap = 0;
 };
 constexpr int BS_CC_STRIDE = 8;
 
@@ -49,6 +69,8 @@ int  d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 int  d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 void d2g_bitslice_free(d2g_cmp_set *set);
 int  d2g_bitslice_alloc_stream(d2g_ctx *ctx, d2g_cmp_set *set);
+int  d2g_bitslice_ensure_natural(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s);   // caller's-order stream of a sparse set, on demand
+int  d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint32_t *out4);
 int  d2g_bitslice_status(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s);   // synchronises; D2G_ERR_INTERNAL on overflow
 // exporter set over an N x S_local column slice (no operand of its own); d2g_bitslice_prepare_slice transposes + prepares it
 // into the target last given to d2g_bitslice_set_export_target

@@ -327,6 +327,13 @@ int d2g_cmp_set_create(d2g_ctx *ctx, const uint64_t *sig_bits_host, size_t N, si
     return rc;
 }
 
+int d2g_cmp_set_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, uint32_t *info4) {
+    if (!ctx || !set || !info4) return D2G_ERR_INVALID;
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    if (set->algo != D2G_CMP_BITSLICE) { info4[0] = info4[1] = info4[2] = info4[3] = 0; return D2G_OK; }
+    return d2g_bitslice_sparse_info(ctx, set, as_stream(stream), info4);
+}
+
 int d2g_cmp_set_status(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream) {
     if (!ctx) return D2G_ERR_INVALID;
     D2G_CHECK(ctx, set && set->ctx == ctx, "cmp_set_status: set belongs to another context");

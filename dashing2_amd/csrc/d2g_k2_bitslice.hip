@@ -451,10 +451,13 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad,
                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
                                                         size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta, int forms,
-                                                        const uint32_t *__restrict__ perm, const uint32_t *__restrict__ colcnt) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                        const uint32_t *__restrict__ perm, const uint32_t *__restrict__ colcnt,
+                                                        const uint32_t *__restrict__ sperm) {
+    const size_t jpos = (size_t)blockIdx.x * 256 + threadIdx.x;   // position in the operand
     const size_t tb = blockIdx.y;
-    if (j >= Nstride) return;
+    if (jpos >= Nstride) return;
+    // sperm: the operand is written in the sparse path's sorted order -- position p holds sketch sperm[p] (stream form only)
+    const size_t j = sperm ? (size_t)sperm[jpos] : jpos;          // 0xFFFFFFFF (padding) fails j < N below
     const int nbits = live_planes(meta, (int)tb);
     // the group's 32 columns: two s_load_dwordx16 (constant address space: never written while this kernel runs), all in
     // flight before the first id is requested
@@ -474,9 +477,9 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
     for (int x = 0; x < 32; ++x) u |= (id[x] >> 31) << x;
     // forms: BS_FORM_STREAM = what this GPU's pair kernel walks; BS_FORM_EXCHANGE = what ranks exchange -- written only
     // once somebody has asked for it (d2g_bitslice_export: 29 MB of stores per prepare at config 3 that a single GPU never reads)
-    uint32_t *dst = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
+    uint32_t *dst = planes + tb * (size_t)(nbits_cap + 1) * Nstride + jpos;
     const bool ex = forms & BS_FORM_EXCHANGE, st = forms & BS_FORM_STREAM;
-    uint32_t *sdst = st ? stream + stream_slot(meta, (int)tb) * 2 * Nstride + j : nullptr;
+    uint32_t *sdst = st ? stream + stream_slot(meta, (int)tb) * 2 * Nstride + jpos : nullptr;
     for (int b = 0; b < nbits; ++b) {
         uint32_t w = 0;
 #pragma unroll
@@ -610,11 +613,13 @@ __device__ __forceinline__ void bs_group(int nbits, const uint32_t *&ptr, uint32
 
 template <int JR, class Store>
 __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_kernel(
-    const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb, uint32_t S, PairShape sh, Store store) {
+    const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb, uint32_t S, PairShape sh, Store store,
+    const uint32_t *__restrict__ gate) {
     constexpr int IW = BS_IW;
     constexpr int WC = BS_CB / (64 * JR);          // waves along columns: 2 (JR=2)
     constexpr int WR = 4 / WC;                     // waves along rows
     constexpr int RB = WR * IW;                    // rows per workgroup tile
+    if (gate && !(gate[1] & 2u)) return;           // launched behind the sparse path: only when it decided for the dense walk
     unsigned ct, rt;
     if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
     const size_t i0 = sh.i_lo + (size_t)rt * RB;
@@ -685,6 +690,529 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
     }
 }
 
+// ------------------------------------------------------------------ 4. sparse tiles
+// An equality count is zero unless the two sketches share a value in at least one register column.  In a collection of related
+// genomes most pairs share nothing (different species), and the ones that do come in families.  So:
+//   prepare  labels: label[j] = smallest sketch index among the sketches that share a value with j (one sweep over the ids, then
+//            pointer jumping); the sketches are counting-sorted by label and the plane stream is written in THAT order
+//            (bs_planes_kernel gathers its ids through d_sperm) -- families become runs of adjacent positions;
+//   launch   per register column, every shared value marks the (32-row block x 256-column block) tiles its holders meet in
+//            (sp_mark_kernel: bit sets per value in LDS); the marked tiles become a work list; the output is pre-filled with the
+//            value of "0 equal registers"; the pair kernel walks the listed tiles only and stores where the count is not 0.
+// Nothing here is approximate: an unmarked tile holds no pair with a common value, whatever the labels look like -- the order
+// only decides how FEW tiles get marked.  If one label would take more than half of the sketches (everything is connected) the
+// caller's order is kept.  Rows of a partial launch [r0, r1) are gathered (in sorted order) into a row operand of their own.
+constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
+constexpr int SP_GCAP = 1024;                   // shared values per column that take part in the labelling
+constexpr int SP_LABEL_TSPLIT = 32;
+#ifndef SP_EXP_NO_GLOBAL_MARKS
+#define SP_EXP_NO_GLOBAL_MARKS 0       // timing experiment (tools/build_variant.sh): the mark kernel without its global phase
+#endif
+
+__device__ __forceinline__ uint32_t sp_rank(uint32_t w, const uint32_t *__restrict__ colcnt, size_t t, bool split) {
+    if ((w >> 31) || w == 0) return 0;          // unique (or padding): never equal to anything
+    return split ? (w & BS_RANK_MASK) + colcnt[t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)] : w;
+}
+
+__global__ __launch_bounds__(256) void sp_init_kernel(uint32_t *__restrict__ label, size_t N, uint32_t *__restrict__ ctl) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < N) label[j] = (uint32_t)j;
+    if (j < 8) ctl[j] = 0;
+}
+
+// gmin[t][r-1] = min over the holders j of shared value r of column t of key[j]
+__global__ __launch_bounds__(256) void sp_gmin_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt,
+                                                      int split, const uint32_t *__restrict__ key, uint32_t *__restrict__ gmin) {
+    __shared__ uint32_t g[SP_GCAP];
+    const size_t t = blockIdx.x;
+    for (int r = threadIdx.x; r < SP_GCAP; r += 256) g[r] = SP_NONE;
+    __syncthreads();
+    const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
+    if (d2) {
+        for (size_t j = threadIdx.x; j < N; j += 256) {
+            const uint32_t r = sp_rank(ids[t * Npad + j], colcnt, t, split != 0);
+            if (r && r <= SP_GCAP) atomicMin(&g[r - 1], key[j]);
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < SP_GCAP; r += 256) gmin[t * SP_GCAP + r] = g[r];
+}
+
+__global__ __launch_bounds__(256) void sp_label_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, size_t S, const uint32_t *__restrict__ colcnt,
+                                                       int split, const uint32_t *__restrict__ gmin, uint32_t *__restrict__ label) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const size_t t0 = S * blockIdx.y / SP_LABEL_TSPLIT, t1 = S * (blockIdx.y + 1) / SP_LABEL_TSPLIT;
+    uint32_t lab = SP_NONE;
+    size_t t = t0;
+    for (; t + 4 <= t1; t += 4) {                   // four columns in flight: the loop is bound by the latency of its two dependent loads
+        uint32_t w[4], r[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) w[x] = ids[(t + x) * Npad + j];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) r[x] = sp_rank(w[x], colcnt, t + x, split != 0);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) if (r[x] && r[x] <= SP_GCAP) lab = min(lab, gmin[(t + x) * SP_GCAP + r[x] - 1]);
+    }
+    for (; t < t1; ++t) {
+        const uint32_t r = sp_rank(ids[t * Npad + j], colcnt, t, split != 0);
+        if (r && r <= SP_GCAP) lab = min(lab, gmin[t * SP_GCAP + r - 1]);
+    }
+    if (lab != SP_NONE) atomicMin(&label[j], lab);
+}
+
+__global__ __launch_bounds__(256) void sp_jump_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t N) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < N) out[j] = in[in[j]];
+}
+
+// pointer jumping: label[] maps a sketch to the smallest sketch it shares a value with; four hops reach the root of most chains
+__device__ __forceinline__ uint32_t sp_root(const uint32_t *__restrict__ label, size_t j) {
+    uint32_t l = label[j];
+    l = label[l]; l = label[l]; l = label[l];
+    return l;
+}
+__device__ __forceinline__ uint32_t sp_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, *total = the sum
+__device__ __forceinline__ uint32_t sp_block_scan(uint32_t v, uint32_t *wave_tot, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t x = wave_tot[w]; if (w < wave) woff += x; tot += x; }
+    *total = tot;
+    return woff + incl - v;
+}
+
+// counting sort of the sketches by label (one workgroup; histogram and cursors live in LDS, SP_SORT_LDS labels per pass: the
+// labels of a family collection are few, so global atomics on them would serialise).  sperm[p] = sketch at sorted position p,
+// sinv = its inverse.  One label holding more than half of the sketches (everything is connected) keeps the caller's order.
+constexpr uint32_t SP_SORT_LDS = 12288;
+__global__ __launch_bounds__(1024) void sp_sort_kernel(const uint32_t *__restrict__ label, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
+                                                       uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, uint32_t *__restrict__ ctl) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t h[SP_SORT_LDS];
+    __shared__ uint32_t s_big, s_run;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_big = 0; s_run = 0; }
+    __syncthreads();
+    // pass A: sketches per label -> cnt[] (global, plain stores), the largest label
+    for (size_t base = 0; base < N; base += SP_SORT_LDS) {
+        const uint32_t n = (uint32_t)min((size_t)SP_SORT_LDS, N - base);
+        for (uint32_t x = tid; x < n; x += 1024) h[x] = 0;
+        __syncthreads();
+        for (size_t j = tid; j < N; j += 1024) { const uint32_t l = sp_root(label, j); if (l >= base && l < base + n) atomicAdd(&h[l - base], 1u); }
+        __syncthreads();
+        // exclusive prefix of this range, continued from the ranges before it
+        const uint32_t per = (n + 1023) / 1024, a = min(n, (uint32_t)tid * per), b = min(n, a + per);
+        uint32_t sum = 0, big = 0;
+        for (uint32_t x = a; x < b; ++x) { sum += h[x]; big = max(big, h[x]); }
+        if ((size_t)big * 2 > N) s_big = 1;
+        uint32_t total;
+        uint32_t run = sp_block_scan(sum, wave_tot, &total) + s_run;
+        for (uint32_t x = a; x < b; ++x) { cnt[base + x] = run; run += h[x]; }
+        __syncthreads();
+        if (tid == 0) s_run += total;
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    const bool identity = s_big != 0;
+    if (tid == 0) ctl[2] = identity ? 1u : 0u;
+    // pass B: place; the start positions of a label range are cursors in LDS
+    if (identity) {
+        for (size_t j = tid; j < N; j += 1024) { sperm[j] = (uint32_t)j; sinv[j] = (uint32_t)j; }
+    } else {
+        for (size_t base = 0; base < N; base += SP_SORT_LDS) {
+            const uint32_t n = (uint32_t)min((size_t)SP_SORT_LDS, N - base);
+            for (uint32_t x = tid; x < n; x += 1024) h[x] = sp_ld(&cnt[base + x]);
+            __syncthreads();
+            for (size_t j = tid; j < N; j += 1024) {
+                const uint32_t l = sp_root(label, j);
+                if (l >= base && l < base + n) { const uint32_t p = atomicAdd(&h[l - base], 1u); sperm[p] = (uint32_t)j; sinv[j] = p; }
+            }
+            __syncthreads();
+        }
+    }
+    for (size_t p = N + tid; p < Nstride; p += 1024) sperm[p] = SP_NONE;
+}
+
+// the sorted stream from the caller's-order stream: position p takes the words of sketch sperm[p].  Only the row-coded words and
+// ONE column-coded word per group are gathered (the unique plane is their difference in any plane: r ^ c = u where the register
+// is column-unique, 0 elsewhere); both codings are written.
+__global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restrict__ nat, uint32_t *__restrict__ srt, size_t Nstride, const uint32_t *__restrict__ meta,
+                                                         const uint32_t *__restrict__ sperm) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int tb = blockIdx.y;
+    if (p >= Nstride) return;
+    const int nbits = live_planes(meta, tb);
+    const size_t slot = stream_slot(meta, tb);
+    const uint32_t j = sperm[p];
+    uint32_t *dst = srt + slot * 2 * Nstride + p;
+    if (j == SP_NONE) {
+        for (int b = 0; b < nbits; ++b) { dst[(size_t)(2 * b) * Nstride] = 0; dst[(size_t)(2 * b + 1) * Nstride] = 0; }
+        return;
+    }
+    const uint32_t *src = nat + slot * 2 * Nstride + j;
+    const uint32_t u = src[0] ^ src[Nstride];
+    for (int b = 0; b < nbits; ++b) {
+        const uint32_t w = src[(size_t)(2 * b) * Nstride];
+        dst[(size_t)(2 * b) * Nstride] = w;
+        dst[(size_t)(2 * b + 1) * Nstride] = w | u;
+    }
+}
+
+// launch rows: the sorted positions whose sketch lies in [r0, r1), in sorted order (stable compaction, one workgroup)
+__global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restrict__ sperm, size_t N, uint32_t r0, uint32_t r1, uint32_t nrows_pad,
+                                                       uint32_t *__restrict__ rowpos, uint32_t *__restrict__ rowk) {
+    __shared__ uint32_t wave_tot[16];
+    const int tid = threadIdx.x;
+    const size_t per = (N + 1023) / 1024, a = (size_t)tid * per, b = min(N, a + per);
+    uint32_t n = 0;
+    for (size_t p = a; p < b; ++p) { const uint32_t j = sperm[p]; n += (j >= r0 && j < r1) ? 1u : 0u; }
+    uint32_t total;
+    uint32_t k = sp_block_scan(n, wave_tot, &total);
+    for (size_t p = a; p < b; ++p) {
+        const uint32_t j = sperm[p];
+        const bool w = j >= r0 && j < r1;
+        rowk[j] = w ? k : SP_NONE;
+        if (w) rowpos[k++] = (uint32_t)p;
+    }
+    for (uint32_t x = total + tid; x < nrows_pad; x += 1024) rowpos[x] = SP_NONE;
+}
+
+__global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb,
+                                                        const uint32_t *__restrict__ rowpos, uint32_t nrows_pad, uint32_t *__restrict__ rowstream, size_t rstride) {
+    const size_t q = blockIdx.y;
+    if (q >= stream_slot(meta, ntb)) return;
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nrows_pad) return;
+    const uint32_t p = rowpos[k];
+    rowstream[q * rstride + k] = p != SP_NONE ? stream[2 * q * Nstride + p] : 0u;
+}
+
+// Per register column: every shared value marks the tiles its holders meet in.  LDS: for `gm` values at a time, a bit set of the
+// launch-row blocks (32 rows) and one of the column blocks (256 sorted positions) the value occurs in.  A value whose holders
+// meet in more than a quarter of all tiles says the matrix is not sparse: it raises the ALL flag (ctl[1] bit 0) and marking stops.
+// The marks of a column go to the column's OWN copy of the tile bitmap (`slots`), which sp_or_kernel folds into one afterwards:
+// every column marks the same few hundred tiles, and 1024 workgroups testing / setting the same 2.5 KB through device-scope
+// operations all queue at one memory channel (measured: 48 of the kernel's 70 us at config 3).
+__global__ __launch_bounds__(256) void sp_mark_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
+                                                      const uint32_t *__restrict__ sinv, const uint32_t *__restrict__ rowk, uint32_t gm, uint32_t RW, uint32_t CW,
+                                                      uint32_t nrb, uint32_t ncb, uint32_t lbm_words, uint32_t *__restrict__ slots, uint32_t *__restrict__ ctl) {
+    extern __shared__ uint32_t sp_lds_all[];
+    __shared__ uint32_t s_stop;
+    // lbm_words != 0: the column's bitmap is built in LDS and stored once; otherwise (large N) it is built in the slot with atomics
+    uint32_t *lbm = sp_lds_all;
+    uint32_t *sp_lds = sp_lds_all + lbm_words;
+    const size_t t = blockIdx.x;
+    const uint32_t words = nrb * CW;
+    uint32_t *slot = slots + t * (size_t)words;
+    const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
+    // one family holds most sketches (the prepare kept the caller's order), or this column's shared values have fewer than four holders
+    // on average (pairs, not families), or it would take more than 32 passes of bit sets: not a matrix the tile list can help
+    if (d2 && (ctl[2] || (size_t)d2 * 4 > N || d2 > 32 * gm)) { if (threadIdx.x == 0) atomicOr(&ctl[1], 1u); return; }
+    if (d2 == 0 || !lbm_words) {
+        for (uint32_t x = threadIdx.x; x < words; x += 256) slot[x] = 0;
+        if (d2 == 0) return;
+        __threadfence();
+    }
+    const uint32_t W = RW + CW;
+    const uint32_t dense_limit = max(16u, (uint32_t)(((size_t)nrb * ncb) / 4));
+    for (uint32_t x = threadIdx.x; x < lbm_words; x += 256) lbm[x] = 0;
+    for (uint32_t base = 0; base < d2; base += gm) {
+        if (threadIdx.x == 0) s_stop = sp_ld(&ctl[1]) & 1u;            // marking stops for everybody once somebody gave up
+        const uint32_t n = min(gm, d2 - base);
+        for (uint32_t x = threadIdx.x; x < n * W; x += 256) sp_lds[x] = 0;
+        __syncthreads();
+        if (s_stop) return;
+        // 2048 sketches per step, eight per thread; the loads of the next step are issued before this step's bit sets are updated
+        constexpr int U = 8;
+        uint32_t w[U], k[U], c[U];
+        auto load = [&](size_t j0) {
+#pragma unroll
+            for (int x = 0; x < U; ++x) {
+                const size_t j = j0 + (size_t)x * 256 + threadIdx.x;
+                w[x] = j < N ? ids[t * Npad + j] : 0u;
+                c[x] = j < N ? sinv[j] : 0u;
+                k[x] = j < N ? (rowk ? rowk[j] : c[x]) : SP_NONE;
+            }
+        };
+        load(0);
+        for (size_t j0 = 0; j0 < N; j0 += 256 * U) {
+            uint32_t cw_[U], ck[U], cc[U];
+#pragma unroll
+            for (int x = 0; x < U; ++x) { cw_[x] = w[x]; ck[x] = k[x]; cc[x] = c[x]; }
+            if (j0 + 256 * U < N) load(j0 + 256 * U);
+#pragma unroll
+            for (int x = 0; x < U; ++x) {
+                const uint32_t r = sp_rank(cw_[x], colcnt, t, split != 0);
+                if (!r || r - 1 < base || r - 1 >= base + n) continue;
+                uint32_t *bits = sp_lds + (size_t)(r - 1 - base) * W;
+#if SP_EXP_NO_GLOBAL_MARKS == 2
+                if (ck[x] == 0x12345678u) atomicOr(&bits[0], cc[x]);          // timing experiment: the loop without its LDS atomics
+#else
+                if (ck[x] != SP_NONE) atomicOr(&bits[ck[x] >> 10], 1u << ((ck[x] >> 5) & 31));
+                atomicOr(&bits[RW + (cc[x] >> 13)], 1u << ((cc[x] >> 8) & 31));
+#endif
+            }
+        }
+        __syncthreads();
+        // density guard, one thread per value
+        for (uint32_t q = threadIdx.x; q < n; q += 256) {
+            const uint32_t *bits = sp_lds + (size_t)q * W;
+            uint32_t nr = 0, nc = 0;
+            for (uint32_t rw = 0; rw < RW; ++rw) nr += __popc(bits[rw]);
+            for (uint32_t cw = 0; cw < CW; ++cw) nc += __popc(bits[RW + cw]);
+            if (nr * nc > dense_limit) atomicOr(&ctl[1], 1u);
+        }
+        if (lbm_words) {
+            // fold into the LDS bitmap, one thread per value: row bits x column words, ds_or (typed LDS pointer: through a generic
+            // pointer that could also be the global slot these were flat atomics and cost 47 of the kernel's 69 us at config 3)
+            for (uint32_t q = threadIdx.x; q < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : n); q += 256) {
+                const uint32_t *bits = sp_lds + (size_t)q * W;
+                for (uint32_t rw = 0; rw < RW; ++rw) {
+                    uint32_t rbits = bits[rw];
+                    while (rbits) {
+                        const uint32_t rb = rw * 32 + (uint32_t)__ffs(rbits) - 1;
+                        rbits &= rbits - 1;
+                        for (uint32_t cw = 0; cw < CW; ++cw) { const uint32_t cbits = bits[RW + cw]; if (cbits) atomicOr(&lbm[(size_t)rb * CW + cw], cbits); }
+                    }
+                }
+            }
+        } else {
+            // fold into the global slot, one thread per ROW BLOCK: its bitmap row |= the column-block sets of every value that occurs in
+            // the row block.  No atomics: a row of the bitmap belongs to one thread, pass after pass.
+            for (uint32_t rb = threadIdx.x; rb < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : nrb); rb += 256) {
+                const uint32_t rw = rb >> 5, rbit = 1u << (rb & 31);
+                for (uint32_t cw0 = 0; cw0 < CW; cw0 += 8) {
+                    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const uint32_t ncw = min(8u, CW - cw0);
+                    for (uint32_t q = 0; q < n; ++q) {
+                        const uint32_t *bits = sp_lds + (size_t)q * W;
+                        if (!(bits[rw] & rbit)) continue;
+#pragma unroll
+                        for (uint32_t x = 0; x < 8; ++x) if (x < ncw) acc[x] |= bits[RW + cw0 + x];
+                    }
+#pragma unroll
+                    for (uint32_t x = 0; x < 8; ++x) if (x < ncw && acc[x]) slot[(size_t)rb * CW + cw0 + x] |= acc[x];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t x = threadIdx.x; x < lbm_words; x += 256) slot[x] = lbm[x];
+}
+
+// tile bitmap = OR over the columns' copies.  grid (words / 256, SP_OR_SPLIT): a thread folds S / SP_OR_SPLIT copies of one word.
+constexpr int SP_OR_SPLIT = 32;
+__global__ __launch_bounds__(256) void sp_or_kernel(const uint32_t *__restrict__ slots, uint32_t words, uint32_t S, uint32_t *__restrict__ tilebm,
+                                                    const uint32_t *__restrict__ ctl) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= words || (ctl[1] & 1u)) return;
+    const uint32_t t0 = (uint32_t)((size_t)S * blockIdx.y / SP_OR_SPLIT), t1 = (uint32_t)((size_t)S * (blockIdx.y + 1) / SP_OR_SPLIT);
+    uint32_t acc = 0;
+    uint32_t t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = slots[(size_t)(t + i) * words + x];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc |= v[i];
+    }
+    for (; t < t1; ++t) acc |= slots[(size_t)t * words + x];
+    if (acc) atomicOr(&tilebm[x], acc);
+}
+
+// the marked tiles as a work list (any order: a workgroup reserves the range of its tiles with one atomic).  full: rows are ALL
+// sorted positions and a pair is computed where row position < column position, so tiles entirely below that diagonal are not
+// candidates.  ctl[0] = tiles listed, ctl[3] = candidates seen (for the dense / sparse decision of sp_decide_kernel).
+__global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
+                                                       uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x;
+    if (sp_ld(&ctl[1]) & 1u) return;                                    // everything is marked: the dense kernel runs instead
+    const size_t ntile = (size_t)nrb * ncb;
+    const size_t a = ((size_t)blockIdx.x * 1024 + tid) * 8, b = min(ntile, a + 8);
+    uint32_t n = 0, mask = 0;
+    for (size_t x = a; x < b; ++x) {
+        const uint32_t rb = (uint32_t)(x / ncb), cb = (uint32_t)(x % ncb);
+        if (full && (size_t)rb * 32 > (size_t)cb * 256 + 255) continue;
+        if ((tilebm[(size_t)rb * CW + (cb >> 5)] >> (cb & 31)) & 1u) { mask |= 1u << (x - a); ++n; }
+    }
+    uint32_t total;
+    uint32_t o = sp_block_scan(n, wave_tot, &total);
+    if (tid == 0) s_base = total ? atomicAdd(&ctl[0], total) : 0u;
+    __syncthreads();
+    o += s_base;
+    for (uint32_t x = 0; x < 8; ++x) if ((mask >> x) & 1u) tiles[o++] = (uint32_t)(a + x);
+}
+
+// dense or sparse?  ctl[1] bit 1 = DENSE: the plain pair kernel walks every tile (and writes every output itself); otherwise the
+// output is pre-filled and the sparse kernel walks the list.  Dense when marking gave up (ALL) or when more than `cand * 0.4` tiles
+// are listed -- the sparse kernel pays for its generality with a per-element epilogue.
+__global__ void sp_decide_kernel(uint32_t *__restrict__ ctl, uint32_t cand) {
+    const uint32_t all = ctl[1] & 1u, n = ctl[0];
+    if (all || (size_t)n * 5 > (size_t)cand * 2) ctl[1] |= 2u;
+}
+
+template <class Store>
+__global__ __launch_bounds__(256) void sp_fill_kernel(uint32_t *__restrict__ out, size_t cnt, Store store, uint32_t S, const uint32_t *__restrict__ ctl) {
+    if (ctl[1] & 2u) return;                                        // dense mode: the pair kernel writes every output
+    const uint32_t v = store.value_from_mismatches(S, S);           // the value of "no register equal"
+    const size_t n4 = cnt / 4;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // the output pointer of a slab is only 4-byte aligned in general: head, 16-byte body, tail
+    const size_t head = min(cnt, (size_t)((16 - ((uintptr_t)out & 15)) & 15) / 4);
+    u32x4 *body = reinterpret_cast<u32x4 *>(out + head);
+    const size_t nb = (cnt - head) / 4;
+    (void)n4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (size_t)gridDim.x * 256) body[i] = u32x4{v, v, v, v};
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) out[threadIdx.x] = v;
+        const size_t tail0 = head + nb * 4;
+        if (tail0 + threadIdx.x < cnt) out[tail0 + threadIdx.x] = v;
+    }
+}
+
+// two-pointer operand fetch: 16 row words at a uniform pointer of the (possibly gathered) row operand, column words at a uniform
+// pointer + lane offset of the sorted stream's column coding
+template <int JR>
+__device__ __forceinline__ BsOperands<JR> sp_fetch(const uint32_t *&rp, size_t rstep, const uint32_t *&cp, uint32_t coff, size_t cstep) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_sched_barrier(0);
+    BsOperands<JR> o;
+    typedef const u32x16_u __attribute__((address_space(4))) *row_words_ptr;
+    o.sa = *(row_words_ptr)(uintptr_t)rp;
+    uint32_t co = coff;
+    asm volatile("" : "+v"(co));
+#pragma unroll
+    for (int c = 0; c < JR; ++c)
+        o.vb[c] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(cp) + co + 256 * c);
+    rp += rstep;
+    cp += cstep;
+    return o;
+}
+
+template <int JR>
+__device__ __forceinline__ void sp_group(int nbits, const uint32_t *&rp, size_t rstep, const uint32_t *&cp, uint32_t coff, size_t cstep, BsOperands<JR> &a,
+                                         uint32_t (&acc)[BS_IW][JR]) {
+    uint32_t z[BS_IW][JR];
+    BsOperands<JR> b = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+    bs_plane<JR, true>(a, z);
+    const int rest = nbits - 1;
+    for (int k = rest >> 1; k > 0; --k) {
+        a = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+        bs_plane<JR, false>(b, z);
+        b = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+        bs_plane<JR, false>(a, z);
+    }
+    if (rest & 1) {
+        a = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+        bs_plane<JR, false>(b, z);
+    } else {
+        a = b;
+    }
+#pragma unroll
+    for (int i = 0; i < BS_IW; ++i)
+#pragma unroll
+        for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);
+}
+
+struct SpArgs {
+    const uint32_t *stream;       // sorted plane stream
+    size_t Nstride;
+    const uint32_t *rowstream;    // gathered row words of a partial launch, or nullptr: the rows are all sorted positions
+    size_t rstride;
+    const uint32_t *meta;
+    int ntb;
+    uint32_t S, N;
+    const uint32_t *sperm, *rowpos, *tiles, *ctl;
+    uint32_t ncb;
+};
+
+// The sparse pair kernel.  A listed tile (32 launch rows x 256 sorted columns) is four 16 x 128 sub-tiles; a workgroup takes ONE
+// sub-tile and its four waves each walk a quarter of the 32-register groups, then add their mismatch counts in LDS.  (The dense
+// kernel gives every wave a sub-tile and all groups: with a few hundred listed tiles that leaves one or two waves per SIMD, each
+// waiting out the latency of every plane's loads -- measured 87 us for 432 tiles at config 3, 411 us for 2122 at config 4.)
+template <int JR, class Store>
+__global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_sparse_kernel(SpArgs a, PairShape sh, Store store) {
+    constexpr int IW = BS_IW;
+    constexpr int WC = BS_CB / (64 * JR);
+    constexpr int KS = 4;                                           // waves per sub-tile = splits of the group range
+    __shared__ uint32_t red[IW][64 * JR];
+    if (a.ctl[1] & 2u) return;                                      // dense mode
+    const uint32_t nsub = a.ctl[0] * 4u;
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool full = a.rowstream == nullptr;
+    const int g0 = a.ntb * ks / KS, g1 = a.ntb * (ks + 1) / KS;
+    const size_t slot0 = stream_slot(a.meta, g0);
+    for (uint32_t si = blockIdx.x; si < nsub; si += gridDim.x) {
+        const uint32_t tile = a.tiles[si >> 2], sub = si & 3u;
+        const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
+        const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
+        const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
+        if (full && k0 > c0 + 64 * JR - 1) continue;                             // entirely below the diagonal of sorted positions (uniform for the workgroup)
+        for (int x = threadIdx.x; x < IW * 64 * JR; x += BS_THREADS) (&red[0][0])[x] = 0;
+        __syncthreads();
+        uint32_t acc[IW][JR];
+#pragma unroll
+        for (int i = 0; i < IW; ++i)
+#pragma unroll
+            for (int c = 0; c < JR; ++c) acc[i][c] = 0;
+        if (g1 > g0) {
+            const size_t rstep = full ? 2 * a.Nstride : a.rstride;
+            const size_t cstep = 2 * a.Nstride;
+            const uint32_t *rp = (full ? a.stream : a.rowstream) + k0 + slot0 * rstep;
+            const uint32_t *cp = a.stream + a.Nstride + c0 + slot0 * cstep;
+            const uint32_t coff = (uint32_t)lane * 4u;
+            BsOperands<JR> nx = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+            int nbits_nx = live_planes(a.meta, g0);
+            for (int tb = g0; tb < g1; ++tb) {
+                const int nbits = nbits_nx;
+                nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
+                sp_group<JR>(nbits, rp, rstep, cp, coff, cstep, nx, acc);
+            }
+        }
+        if (ks != 0) {
+#pragma unroll
+            for (int i = 0; i < IW; ++i)
+#pragma unroll
+                for (int c = 0; c < JR; ++c) if (acc[i][c]) atomicAdd(&red[i][lane + 64 * c], acc[i][c]);
+        }
+        __syncthreads();
+        if (ks == 0) {
+            // epilogue: the pairs of this sub-tile in the CALLER's indices; stores only where at least one register is equal
+            uint32_t oj[JR];
+#pragma unroll
+            for (int c = 0; c < JR; ++c) oj[c] = a.sperm[c0 + lane + 64 * c];
+#pragma unroll
+            for (int i = 0; i < IW; ++i) {
+                const size_t k = k0 + i;
+                const uint32_t rpos = full ? (uint32_t)k : a.rowpos[k];               // uniform
+                if (rpos == SP_NONE || rpos >= a.N) continue;
+                const uint32_t oi = a.sperm[rpos];                                    // uniform
+#pragma unroll
+                for (int c = 0; c < JR; ++c) {
+                    const uint32_t mm = acc[i][c] + red[i][lane + 64 * c];
+                    if (mm == a.S || oj[c] == SP_NONE) continue;
+                    const bool want = full ? rpos < (uint32_t)(c0 + lane + 64 * c) : oj[c] > oi;
+                    if (!want) continue;
+                    const uint32_t lo = min(oi, oj[c]), hi = max(oi, oj[c]);
+                    store.put(out_pos(sh, lo, hi), store.value_from_mismatches(a.S, mm));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // gathered (caller-owned) operands carry the row coding + the unique plane only: derive the column coding.
 // Done before EVERY launch on such a set -- the library cannot know when the caller re-gathered into the
 // buffer, and the pass is ~2 % of the pair kernel it precedes.
@@ -693,14 +1221,132 @@ int refresh_borrowed(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s) {
     return d2g_bitslice_derive_groups(ctx, set, 0, set->ntb, s);
 }
 
+bool sparse_enabled(size_t N) {
+    const char *e = std::getenv("D2G_BS_SPARSE");             // "0": every launch walks every tile (A/B measurements, tests)
+    if (e && e[0] == '0') return false;
+    size_t min_n = 8192;                                        // below ~6000 sketches the extra launches cost more than the tiles they skip (measured: N = 4096 0.19 vs 0.15 ms, N = 8192 0.31 vs 0.37 ms)
+    if (const char *m = std::getenv("D2G_BS_SPARSE_MIN_N")) min_n = (size_t)std::atoll(m);
+    return N >= 2 && N >= min_n;
+}
+
+int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
+    const size_t Npad = set->Npad, Nstride = set->Nstride;
+    const size_t nrb = Npad / 32, ncb = Npad / BS_CB;
+    set->tilebm_words = nrb * ((ncb + 31) / 32) + 1;
+    set->tiles_cap = nrb * ncb;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&set->d_stream_s, ((size_t)set->ntb * set->nbits_cap + 1) * 2 * Nstride * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_sperm, Nstride * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_sinv, Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_label, 2 * Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_lcnt, (Npad + 1) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_gmin, set->S * SP_GCAP * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_tilebm, set->tilebm_words * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_slots, set->S * set->tilebm_words * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_tiles, std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_spctl, 8 * 4)) != hipSuccess) {
+        ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
+    }
+    return D2G_OK;
+}
+
+void sp_free(d2g_cmp_set *set) {
+    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_lcnt, &set->d_gmin, &set->d_rowpos, &set->d_rowk,
+                         &set->d_rowstream, &set->d_tilebm, &set->d_slots, &set->d_tiles, &set->d_spctl}) { (void)hipFree(*p); *p = nullptr; }
+}
+
+// labels -> counting sort -> d_sperm / d_sinv.  All on `s`, no host round trip.
+int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
+    const size_t N = set->N, Npad = set->Npad, S = set->S;
+    const unsigned nb = (unsigned)div_up<size_t>(N, 256);
+    int rounds = 1;
+    if (const char *e = std::getenv("D2G_BS_LABEL_ROUNDS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) rounds = v; }
+    uint32_t *la = set->d_label, *lb = set->d_label + Npad;
+    hipLaunchKernelGGL(sp_init_kernel, dim3(std::max(nb, 1u)), dim3(256), 0, s, la, N, set->d_spctl);
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(sp_gmin_kernel, dim3((unsigned)S), dim3(256), 0, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, la, set->d_gmin);
+        hipLaunchKernelGGL(sp_label_kernel, dim3(nb, SP_LABEL_TSPLIT), dim3(256), 0, s, set->d_ids, N, Npad, S, set->d_colcnt, split ? 1 : 0, set->d_gmin, la);
+        if (r + 1 < rounds) {                          // more rounds: the next one starts from the roots (the sort kernel hops by itself)
+            hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, la, lb, N);
+            hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, lb, la, N);
+        }
+    }
+    hipLaunchKernelGGL(sp_sort_kernel, dim3(1), dim3(1024), 0, s, la, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_spctl);
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+template <class Store>
+int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store store, uint32_t *out_words, hipStream_t s) {
+    d2g_cmp_set *set = const_cast<d2g_cmp_set *>(cset);
+    const size_t N = set->N, Npad = set->Npad, r0 = sh.i_lo, r1 = sh.i_hi;
+    if (r1 <= r0) return D2G_OK;
+    const bool full = r0 == 0 && r1 == N;
+    const size_t nrows = r1 - r0, nrows_pad = full ? Npad : div_up<size_t>(nrows, 32) * 32;
+    const uint32_t nrb = (uint32_t)(nrows_pad / 32), ncb = (uint32_t)(Npad / BS_CB);
+    const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
+    const size_t cnt = d2g_ut_count(N, r0, r1);
+    if (!cnt) return D2G_OK;
+    if (!full && !set->d_rowstream)
+        D2G_HIP(ctx, hipMalloc((void **)&set->d_rowstream, ((size_t)set->ntb * set->nbits_cap + 1) * set->Nstride * sizeof(uint32_t)));
+    PairShape dsh = sh;                                                                 // the dense walk of the same launch, behind the gate
+    if (int rc = finish_shape(ctx, dsh, BS_JR == 2 ? 32u : 64u)) return rc;
+    d2g_timer tm(ctx, &ctx->ev_k2, s);
+    const uint32_t RW = (nrb + 31) / 32, CW = (ncb + 31) / 32;                          // words of a value's row-block / column-block bit set
+    D2G_HIP(ctx, hipMemsetAsync(set->d_tilebm, 0, ((size_t)nrb * CW + 1) * 4, s));        // one row of CW words per row block
+    D2G_HIP(ctx, hipMemsetAsync(set->d_spctl, 0, 8, s));                              // ctl[0] = tiles listed, ctl[1] = flags (bit 0 ALL, bit 1 DENSE)
+    if (!full) {
+        hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk);
+        hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)div_up<size_t>(nrows_pad, 256), (unsigned)(set->ntb * set->nbits_cap)), dim3(256), 0, s,
+                           set->d_stream_s, set->Nstride, set->d_meta, set->ntb, set->d_rowpos, (uint32_t)nrows_pad, set->d_rowstream, set->Nstride);
+    }
+    const size_t ntile = (size_t)nrb * ncb;
+    // candidates: every tile of a partial launch; the tiles on or above the diagonal of sorted positions of a full one
+    size_t cand = ntile;
+    if (full) { cand = 0; for (uint32_t cb = 0; cb < ncb; ++cb) cand += std::min<size_t>(nrb, ((size_t)cb * 256 + 255) / 32 + 1); }
+    {
+        const uint32_t W = RW + CW;
+        // LDS: the column's copy of the tile bitmap (when it is small) + the bit sets; 40 KB in all: four columns per CU
+        uint32_t lbm_words = nrb * CW;
+        int lbm_max = 4096;                                                            // words (16 KB)
+        if (const char *e = std::getenv("D2G_SP_LOCALBM")) lbm_max = std::atoi(e);       // experiments: 0 = build it in the slot
+        if ((int)lbm_words > lbm_max) lbm_words = 0;
+        const uint32_t gm = std::max(1u, std::min(2048u, (10240u - lbm_words) / W));
+        const size_t lds = ((size_t)gm * W + lbm_words) * 4;
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_mark_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)set->S), dim3(256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
+                           full ? (const uint32_t *)nullptr : set->d_rowk, gm, RW, CW, nrb, ncb, lbm_words, set->d_slots, set->d_spctl);
+        hipLaunchKernelGGL(sp_or_kernel, dim3((unsigned)div_up<size_t>((size_t)nrb * CW, 256), SP_OR_SPLIT), dim3(256), 0, s, set->d_slots, nrb * CW, (uint32_t)set->S,
+                           set->d_tilebm, set->d_spctl);
+    }
+    hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, set->d_tilebm, nrb, ncb, CW, full ? 1 : 0, set->d_tiles, set->d_spctl);
+    hipLaunchKernelGGL(sp_decide_kernel, dim3(1), dim3(1), 0, s, set->d_spctl, (uint32_t)std::min<size_t>(cand, 0xFFFFFFFFu));
+    hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, 256), (size_t)ctx->num_cus * 16)), dim3(256), 0, s,
+                       out_words, cnt, store, (uint32_t)set->S, set->d_spctl);
+    SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
+             set->d_sperm, set->d_rowpos, set->d_tiles, set->d_spctl, ncb};
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ntile * 4, (size_t)ctx->num_cus * 7));
+    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(BS_THREADS), 0, s, a, sh, store);
+    if (dsh.nvalid_total)
+        hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
+                           set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, dsh, store, (const uint32_t *)set->d_spctl);
+    tm.stop();
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
 template <class Store>
 int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
     if (int rc = finish_shape(ctx, sh, BS_JR == 2 ? 32u : 64u)) return rc;   // workgroup tile = (16 * JR) rows x 256 columns (4 waves of 16 x 64*JR)
     if (sh.nvalid_total == 0) return D2G_OK;
     if (int rc = refresh_borrowed(ctx, set, s)) return rc;
+    if (int rc = d2g_bitslice_ensure_natural(ctx, set, s)) return rc;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
     hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
-                       set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, sh, store);
+                       set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, sh, store, (const uint32_t *)nullptr);
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -716,6 +1362,7 @@ void d2g_bitslice_free(d2g_cmp_set *set) {
     (void)hipFree(set->d_colcnt);
     (void)hipFree(set->d_perm);
     set->d_planes = set->d_stream = set->d_meta = set->d_ids = set->d_colcnt = set->d_perm = nullptr;
+    sp_free(set);
 }
 
 // geometry of the bit-sliced operand: a function of N (and S) only, identical on every rank.
@@ -789,6 +1436,8 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
     if (int rc = d2g_bitslice_alloc_stream(ctx, set)) { d2g_bitslice_free(set); return rc; }
+    set->sparse_ok = sparse_enabled(set->N) && set->S * (set->Npad / 32) * ((set->Npad / BS_CB + 31) / 32) * 4 <= ((size_t)1 << 30);   // the columns' tile bitmaps: <= 1 GiB
+    if (set->sparse_ok) if (int rc = sp_alloc(ctx, set)) { d2g_bitslice_free(set); return rc; }
     return D2G_OK;
 }
 
@@ -820,12 +1469,38 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
                            set->d_meta, set->d_meta + set->ntb, set->ex_meta, set->ex_status, sort_columns() ? 1 : 0);
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    const int forms = set->export_only ? BS_FORM_EXCHANGE : (BS_FORM_STREAM | (set->want_exchange ? BS_FORM_EXCHANGE : 0));
     const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
+    if (set->sparse_ok && !set->export_only && !set->want_exchange) {
+        // sparse path: the stream in label order (section 4); the caller's-order stream is only built if a launch asks for it
+        // (gathering the ids through d_sperm inside bs_planes_kernel was measured: 74 us instead of 18 at config 3 -- 1024 columns of
+        // uncoalesced 4-byte loads; permuting the finished stream touches 256 rows of words and leaves the caller's-order stream valid)
+        if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
+        hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
+                           set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm);
+        set->srt_valid = true; set->nat_valid = true;
+        D2G_HIP(ctx, hipGetLastError());
+        return D2G_OK;
+    }
+    const int forms = set->export_only ? BS_FORM_EXCHANGE : (BS_FORM_STREAM | (set->want_exchange ? BS_FORM_EXCHANGE : 0));
     hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
                        set->export_only ? set->ex_planes : set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, forms,
-                       set->d_perm, set->d_colcnt);
+                       set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
+    set->srt_valid = false; set->nat_valid = true;
     D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+// the caller's-order stream of a set whose last prepare only wrote the sorted one (rectangular launches, exports)
+int d2g_bitslice_ensure_natural(d2g_ctx *ctx, const d2g_cmp_set *cset, hipStream_t s) {
+    d2g_cmp_set *set = const_cast<d2g_cmp_set *>(cset);
+    if (set->nat_valid || set->borrowed || set->export_only) return D2G_OK;
+    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
+    const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
+    hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, set->N, set->Npad,
+                       set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
+    D2G_HIP(ctx, hipGetLastError());
+    set->nat_valid = true;
     return D2G_OK;
 }
 
@@ -836,7 +1511,7 @@ int d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
     hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, set->N, set->Npad,
-                       set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE, set->d_perm, set->d_colcnt);
+                       set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
@@ -894,6 +1569,10 @@ int d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, 
                     float *fout, hipStream_t s) {
     PairShape sh{};
     sh.N = set->N; sh.i_lo = r0; sh.i_hi = r1; sh.j_lo = r0 + 1 < set->N ? r0 + 1 : set->N; sh.j_hi = set->N; sh.ut = 1;
+    if (set->srt_valid && !set->borrowed) {
+        if (eq_out) return launch_sparse(ctx, set, sh, StoreEq{eq_out}, eq_out, s);
+        return launch_sparse(ctx, set, sh, StoreLut{fout, lut}, reinterpret_cast<uint32_t *>(fout), s);
+    }
     if (eq_out) return launch_bitslice(ctx, set, sh, StoreEq{eq_out}, s);
     return launch_bitslice(ctx, set, sh, StoreLut{fout, lut}, s);
 }
@@ -903,6 +1582,17 @@ int d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1
     PairShape sh{};
     sh.N = set->N; sh.i_lo = a0; sh.i_hi = a1; sh.j_lo = b0; sh.j_hi = b1; sh.ut = 0;
     return launch_bitslice(ctx, set, sh, StoreEq{eq_out}, s);
+}
+
+// diagnostics of the sparse path's LAST launch on this set (synchronises `s`): see d2g.h
+int d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint32_t *out4) {
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (!set->srt_valid || !set->d_spctl) { D2G_HIP(ctx, hipStreamSynchronize(s)); return D2G_OK; }
+    uint32_t c[4] = {0, 0, 0, 0};
+    D2G_HIP(ctx, hipMemcpyAsync(c, set->d_spctl, sizeof c, hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipStreamSynchronize(s));
+    out4[0] = 1; out4[1] = c[0]; out4[2] = c[1]; out4[3] = c[2];
+    return D2G_OK;
 }
 
 void d2g_warm_k2_bitslice() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&bs_colplan_kernel)); }

@@ -325,6 +325,14 @@ int  d2g_cmp_set_status(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream);
  * Synchronises `stream` and returns d2g_cmp_set_status's error, if any; all 0 for a DIRECT set. */
 int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits,
                         float *mean_nbits);
+/* Sparse tiles (bit-sliced sets of N >= 8192 sketches that own their operand; D2G_BS_SPARSE=0 switches it off, D2G_BS_SPARSE_MIN_N
+ * moves the threshold): an equality count is 0 unless the two sketches share a value in some register column, so the prepare puts
+ * the sketches in an order that brings sharers together and an upper-triangle launch walks only the 32 x 256 tiles that hold a pair
+ * with a shared value, after pre-filling the output with the value of "0 equal" -- or, when most tiles are marked, the plain kernel
+ * (decided on the device, no host round trip).  Results are identical either way.  info4 of the LAST upper-triangle launch on the
+ * set (synchronises `stream`): [0] 1 = the set has a sorted operand, [1] tiles listed, [2] flags (bit 0: marking gave up, bit 1:
+ * the dense kernel ran), [3] 1 = the caller's order was kept (one family holds most sketches). */
+int  d2g_cmp_set_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, uint32_t *info4);
 /* ---- sharded prepare (multi-GPU).  The bit-sliced operand is an array of independent
  * 32-register groups of `group_words` u32 each (+ one u32 of meta per group) whose geometry depends
  * on N only, so ranks can each build the groups of their own column slice and all-gather them:

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../dashing2_amd/csrc"
 name=$1; shift
 tmp=/tmp/d2g_variant_$name; mkdir -p $tmp
-for f in d2g_runtime d2g_k1 d2g_k2 d2g_k2_bitslice d2g_k3_bmh d2g_mgpu; do
+for f in d2g_runtime d2g_k0 d2g_k1 d2g_k2 d2g_k2_bitslice d2g_k3_bmh d2g_mgpu; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wall -Wno-unused-function -ffp-contract=off "$@" -c $f.hip -o $tmp/$f.o &
 done
 g++ -O2 -std=c++17 -fPIC -fopenmp -c d2g_host.cpp -o $tmp/d2g_host.o &

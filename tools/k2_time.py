@@ -11,7 +11,8 @@ ctx = D.Context(0)
 dev = torch.device("cuda", 0)
 which = os.environ.get("MATRIX", "stated")
 regs = {"stated": lambda: synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928),
-        "unrelated": lambda: synth.unrelated_registers(N, S), "paired": lambda: synth.paired_registers(N, S)}[which]()
+        "unrelated": lambda: synth.unrelated_registers(N, S), "paired": lambda: synth.paired_registers(N, S),
+        "skewed": lambda: synth.skewed_registers(N, S)}[which]()
 sig = D.oph_finalize(regs, S, nthreads=32)[0] if which == "stated" else regs.view(np.float64)
 t = torch.from_numpy(sig.view(np.int64)).to(dev)
 lut = torch.from_numpy(D.epilogue_lut(S, D.SIMILARITY, 31)).to(dev)
@@ -19,11 +20,16 @@ out = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 cs = ctx.cmp_set_dev(t.data_ptr(), N, S, algo=D.CMP_BITSLICE, stream=st)
 for _ in range(3):
+    cs.update_dev(t.data_ptr(), st)
     cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), 0, N, st)
 torch.cuda.synchronize()
 ctx.set_timing(True); ctx.kernel_ms("k2")
+t0 = time.perf_counter()
 for _ in range(20):
+    cs.update_dev(t.data_ptr(), st)
     cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), 0, N, st)
 torch.cuda.synchronize()
+step_ms = (time.perf_counter() - t0) / 20 * 1e3
 n, ms, _ = ctx.kernel_ms("k2")
+print(f"step (prepare + compare) {step_ms:.4f} ms; sparse: {cs.sparse_info(st)}")
 print(f"{which} N={N} D2G_BS_EXP={os.environ.get('D2G_BS_EXP','0')} planes={cs.planes(st)} pair kernel {ms:.4f} ms over {n} launches")
