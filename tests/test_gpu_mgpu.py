@@ -347,7 +347,7 @@ def test_bench_inprocess_rung_over_loopback(d2g, W):
     assert cfg["sketches"] == (N + W - 1) // W * W and "WHOLE slab equals" in cfg["slab_check"] and "ONE process" in cfg["exchange_engine"]
     assert [l["engine"] for l in line["launcher"]["ladder"]] == ["inproc"] and line["launcher"]["ladder"][0]["outcome"] == "ok"
     base = line["scaling_base"]
-    assert base["base_1gpu_same_config_pairs_per_s"] > 0 and abs(base["speedup"] - line["value"] / base["base_1gpu_same_config_pairs_per_s"]) < 1e-9
+    assert base["best_1gpu_pairs_per_s"] > 0 and base["base_1gpu_same_config_pairs_per_s"] > 0 and abs(base["speedup"] - line["value"] / base["base_1gpu_same_config_pairs_per_s"]) < 1e-9
     ph = line["phases"]
     C = cfg["exchange_chunks"]
     assert len(ph["per_rank"]) == W
