@@ -518,6 +518,8 @@ constexpr int BS_CB = 256;                // columns per workgroup tile (all var
 // v_bitop3_b32 truth table: src0 = 0xF0, src1 = 0xCC, src2 = 0xAA
 constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);   // mismatch accumulation
 
+__device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, uint32_t cand);   // section 4
+
 // IW = 16 rows per wave (one s_load_dwordx16 per plane), JR = 64-column groups per lane,
 // WC = waves side by side along the columns (WC * JR * 64 = 256).  Per 32-register group: plane 0
 // initialises z = r ^ c (no zeroing), planes 1.. accumulate with v_bitop3 z |= r ^ c, and one accumulating
@@ -614,12 +616,12 @@ __device__ __forceinline__ void bs_group(int nbits, const uint32_t *&ptr, uint32
 template <int JR, class Store>
 __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_kernel(
     const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb, uint32_t S, PairShape sh, Store store,
-    const uint32_t *__restrict__ gate) {
+    const uint32_t *__restrict__ gate, uint32_t gate_cand) {
     constexpr int IW = BS_IW;
     constexpr int WC = BS_CB / (64 * JR);          // waves along columns: 2 (JR=2)
     constexpr int WR = 4 / WC;                     // waves along rows
     constexpr int RB = WR * IW;                    // rows per workgroup tile
-    if (gate && !(gate[1] & 2u)) return;           // launched behind the sparse path: only when it decided for the dense walk
+    if (gate && !sp_dense_mode(gate, gate_cand)) return;   // launched behind the sparse path: only when that decided for the dense walk
     unsigned ct, rt;
     if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
     const size_t i0 = sh.i_lo + (size_t)rt * RB;
@@ -705,6 +707,9 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
 constexpr int SP_GCAP = 1024;                   // shared values per column that take part in the labelling
 constexpr int SP_LABEL_TSPLIT = 32;
+#ifndef D2G_SP_KS
+#define D2G_SP_KS 4
+#endif
 #ifndef SP_EXP_NO_GLOBAL_MARKS
 #define SP_EXP_NO_GLOBAL_MARKS 0       // timing experiment (tools/build_variant.sh): the mark kernel without its global phase
 #endif
@@ -714,10 +719,9 @@ __device__ __forceinline__ uint32_t sp_rank(uint32_t w, const uint32_t *__restri
     return split ? (w & BS_RANK_MASK) + colcnt[t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)] : w;
 }
 
-__global__ __launch_bounds__(256) void sp_init_kernel(uint32_t *__restrict__ label, size_t N, uint32_t *__restrict__ ctl) {
+__global__ __launch_bounds__(256) void sp_init_kernel(uint32_t *__restrict__ label, size_t N, uint32_t *__restrict__ cnt) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j < N) label[j] = (uint32_t)j;
-    if (j < 8) ctl[j] = 0;
+    if (j < N) { label[j] = (uint32_t)j; cnt[j] = 0; }
 }
 
 // gmin[t][r-1] = min over the holders j of shared value r of column t of key[j]
@@ -729,9 +733,19 @@ __global__ __launch_bounds__(256) void sp_gmin_kernel(const uint32_t *__restrict
     __syncthreads();
     const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
     if (d2) {
-        for (size_t j = threadIdx.x; j < N; j += 256) {
-            const uint32_t r = sp_rank(ids[t * Npad + j], colcnt, t, split != 0);
-            if (r && r <= SP_GCAP) atomicMin(&g[r - 1], key[j]);
+        for (size_t j0 = 0; j0 < N; j0 += 2048) {           // eight sketches per thread in flight
+            uint32_t w[8], kk[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const size_t j = j0 + (size_t)x * 256 + threadIdx.x;
+                w[x] = j < N ? ids[t * Npad + j] : 0u;
+                kk[x] = j < N ? key[j] : SP_NONE;
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
+                if (r && r <= SP_GCAP) atomicMin(&g[r - 1], kk[x]);
+            }
         }
     }
     __syncthreads();
@@ -788,57 +802,52 @@ __device__ __forceinline__ uint32_t sp_block_scan(uint32_t v, uint32_t *wave_tot
     return woff + incl - v;
 }
 
-// counting sort of the sketches by label (one workgroup; histogram and cursors live in LDS, SP_SORT_LDS labels per pass: the
-// labels of a family collection are few, so global atomics on them would serialise).  sperm[p] = sketch at sorted position p,
-// sinv = its inverse.  One label holding more than half of the sketches (everything is connected) keeps the caller's order.
-constexpr uint32_t SP_SORT_LDS = 12288;
-__global__ __launch_bounds__(1024) void sp_sort_kernel(const uint32_t *__restrict__ label, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
-                                                       uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, uint32_t *__restrict__ ctl) {
+// counting sort of the sketches by the root of their label, three small kernels (one thread per sketch, then one workgroup for the
+// prefix, then one thread per sketch again).  The roots of a family collection are few and their counters hot, but with a thread
+// per sketch every thread waits for ONE atomic; a single workgroup walking all sketches waited for ten in a row (N = 50 000: 225 us,
+// now ~25).  One root holding more than half of the sketches (everything is connected) keeps the caller's order: order[0] = 1.
+__global__ __launch_bounds__(256) void sp_count_kernel(const uint32_t *__restrict__ label, uint32_t *__restrict__ root, size_t N, uint32_t *__restrict__ cnt) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t r = sp_root(label, j);
+    root[j] = r;
+    atomicAdd(&cnt[r], 1u);
+}
+__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order) {
+    // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t h[SP_SORT_LDS];
+    __shared__ uint32_t tile[8192];
     __shared__ uint32_t s_big, s_run;
     const int tid = threadIdx.x;
     if (tid == 0) { s_big = 0; s_run = 0; }
     __syncthreads();
-    // pass A: sketches per label -> cnt[] (global, plain stores), the largest label
-    for (size_t base = 0; base < N; base += SP_SORT_LDS) {
-        const uint32_t n = (uint32_t)min((size_t)SP_SORT_LDS, N - base);
-        for (uint32_t x = tid; x < n; x += 1024) h[x] = 0;
+    for (size_t base = 0; base < N; base += 8192) {
+        const uint32_t n = (uint32_t)min((size_t)8192, N - base);
+        for (uint32_t x = tid; x < 8192; x += 1024) tile[x] = x < n ? cnt[base + x] : 0u;
         __syncthreads();
-        for (size_t j = tid; j < N; j += 1024) { const uint32_t l = sp_root(label, j); if (l >= base && l < base + n) atomicAdd(&h[l - base], 1u); }
-        __syncthreads();
-        // exclusive prefix of this range, continued from the ranges before it
-        const uint32_t per = (n + 1023) / 1024, a = min(n, (uint32_t)tid * per), b = min(n, a + per);
-        uint32_t sum = 0, big = 0;
-        for (uint32_t x = a; x < b; ++x) { sum += h[x]; big = max(big, h[x]); }
+        uint32_t v[8], sum = 0, big = 0;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { v[x] = tile[tid * 8 + x]; sum += v[x]; big = max(big, v[x]); }
         if ((size_t)big * 2 > N) s_big = 1;
         uint32_t total;
         uint32_t run = sp_block_scan(sum, wave_tot, &total) + s_run;
-        for (uint32_t x = a; x < b; ++x) { cnt[base + x] = run; run += h[x]; }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { tile[tid * 8 + x] = run; run += v[x]; }
         __syncthreads();
+        for (uint32_t x = tid; x < n; x += 1024) cnt[base + x] = tile[x];
         if (tid == 0) s_run += total;
         __syncthreads();
     }
-    __threadfence();
-    __syncthreads();
-    const bool identity = s_big != 0;
-    if (tid == 0) ctl[2] = identity ? 1u : 0u;
-    // pass B: place; the start positions of a label range are cursors in LDS
-    if (identity) {
-        for (size_t j = tid; j < N; j += 1024) { sperm[j] = (uint32_t)j; sinv[j] = (uint32_t)j; }
-    } else {
-        for (size_t base = 0; base < N; base += SP_SORT_LDS) {
-            const uint32_t n = (uint32_t)min((size_t)SP_SORT_LDS, N - base);
-            for (uint32_t x = tid; x < n; x += 1024) h[x] = sp_ld(&cnt[base + x]);
-            __syncthreads();
-            for (size_t j = tid; j < N; j += 1024) {
-                const uint32_t l = sp_root(label, j);
-                if (l >= base && l < base + n) { const uint32_t p = atomicAdd(&h[l - base], 1u); sperm[p] = (uint32_t)j; sinv[j] = p; }
-            }
-            __syncthreads();
-        }
-    }
-    for (size_t p = N + tid; p < Nstride; p += 1024) sperm[p] = SP_NONE;
+    if (tid == 0) order[0] = s_big;
+}
+__global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
+                                                        uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < N) {
+        const uint32_t p = order[0] ? (uint32_t)j : atomicAdd(&cnt[root[j]], 1u);
+        sperm[p] = (uint32_t)j;
+        sinv[j] = p;
+    } else if (j < Nstride) sperm[j] = SP_NONE;
 }
 
 // the sorted stream from the caller's-order stream: position p takes the words of sketch sperm[p].  Only the row-coded words and
@@ -901,33 +910,35 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restri
 // The marks of a column go to the column's OWN copy of the tile bitmap (`slots`), which sp_or_kernel folds into one afterwards:
 // every column marks the same few hundred tiles, and 1024 workgroups testing / setting the same 2.5 KB through device-scope
 // operations all queue at one memory channel (measured: 48 of the kernel's 70 us at config 3).
-__global__ __launch_bounds__(256) void sp_mark_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
+__global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
                                                       const uint32_t *__restrict__ sinv, const uint32_t *__restrict__ rowk, uint32_t gm, uint32_t RW, uint32_t CW,
-                                                      uint32_t nrb, uint32_t ncb, uint32_t lbm_words, uint32_t *__restrict__ slots, uint32_t *__restrict__ ctl) {
+                                                      uint32_t nrb, uint32_t ncb, uint32_t lbm_words, uint32_t *__restrict__ slots, uint32_t *__restrict__ ctl,
+                                                      const uint32_t *__restrict__ order_kept) {
     extern __shared__ uint32_t sp_lds_all[];
     __shared__ uint32_t s_stop;
     // lbm_words != 0: the column's bitmap is built in LDS and stored once; otherwise (large N) it is built in the slot with atomics
     uint32_t *lbm = sp_lds_all;
     uint32_t *sp_lds = sp_lds_all + lbm_words;
     const size_t t = blockIdx.x;
+    const uint32_t T = blockDim.x;                                    // 256, or 512 with a bigger share of the LDS (large N)
     const uint32_t words = nrb * CW;
     uint32_t *slot = slots + t * (size_t)words;
     const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
     // one family holds most sketches (the prepare kept the caller's order), or this column's shared values have fewer than four holders
     // on average (pairs, not families), or it would take more than 32 passes of bit sets: not a matrix the tile list can help
-    if (d2 && (ctl[2] || (size_t)d2 * 4 > N || d2 > 32 * gm)) { if (threadIdx.x == 0) atomicOr(&ctl[1], 1u); return; }
+    if (d2 && (order_kept[0] || (size_t)d2 * 4 > N || d2 > 32 * gm)) { if (threadIdx.x == 0) atomicOr(&ctl[1], 1u); return; }
     if (d2 == 0 || !lbm_words) {
-        for (uint32_t x = threadIdx.x; x < words; x += 256) slot[x] = 0;
+        for (uint32_t x = threadIdx.x; x < words; x += T) slot[x] = 0;
         if (d2 == 0) return;
         __threadfence();
     }
     const uint32_t W = RW + CW;
     const uint32_t dense_limit = max(16u, (uint32_t)(((size_t)nrb * ncb) / 4));
-    for (uint32_t x = threadIdx.x; x < lbm_words; x += 256) lbm[x] = 0;
+    for (uint32_t x = threadIdx.x; x < lbm_words; x += T) lbm[x] = 0;
     for (uint32_t base = 0; base < d2; base += gm) {
         if (threadIdx.x == 0) s_stop = sp_ld(&ctl[1]) & 1u;            // marking stops for everybody once somebody gave up
         const uint32_t n = min(gm, d2 - base);
-        for (uint32_t x = threadIdx.x; x < n * W; x += 256) sp_lds[x] = 0;
+        for (uint32_t x = threadIdx.x; x < n * W; x += T) sp_lds[x] = 0;
         __syncthreads();
         if (s_stop) return;
         // 2048 sketches per step, eight per thread; the loads of the next step are issued before this step's bit sets are updated
@@ -936,18 +947,18 @@ __global__ __launch_bounds__(256) void sp_mark_kernel(const uint32_t *__restrict
         auto load = [&](size_t j0) {
 #pragma unroll
             for (int x = 0; x < U; ++x) {
-                const size_t j = j0 + (size_t)x * 256 + threadIdx.x;
+                const size_t j = j0 + (size_t)x * T + threadIdx.x;
                 w[x] = j < N ? ids[t * Npad + j] : 0u;
                 c[x] = j < N ? sinv[j] : 0u;
                 k[x] = j < N ? (rowk ? rowk[j] : c[x]) : SP_NONE;
             }
         };
         load(0);
-        for (size_t j0 = 0; j0 < N; j0 += 256 * U) {
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * U) {
             uint32_t cw_[U], ck[U], cc[U];
 #pragma unroll
             for (int x = 0; x < U; ++x) { cw_[x] = w[x]; ck[x] = k[x]; cc[x] = c[x]; }
-            if (j0 + 256 * U < N) load(j0 + 256 * U);
+            if (j0 + (size_t)T * U < N) load(j0 + (size_t)T * U);
 #pragma unroll
             for (int x = 0; x < U; ++x) {
                 const uint32_t r = sp_rank(cw_[x], colcnt, t, split != 0);
@@ -963,7 +974,7 @@ __global__ __launch_bounds__(256) void sp_mark_kernel(const uint32_t *__restrict
         }
         __syncthreads();
         // density guard, one thread per value
-        for (uint32_t q = threadIdx.x; q < n; q += 256) {
+        for (uint32_t q = threadIdx.x; q < n; q += T) {
             const uint32_t *bits = sp_lds + (size_t)q * W;
             uint32_t nr = 0, nc = 0;
             for (uint32_t rw = 0; rw < RW; ++rw) nr += __popc(bits[rw]);
@@ -973,21 +984,21 @@ __global__ __launch_bounds__(256) void sp_mark_kernel(const uint32_t *__restrict
         if (lbm_words) {
             // fold into the LDS bitmap, one thread per value: row bits x column words, ds_or (typed LDS pointer: through a generic
             // pointer that could also be the global slot these were flat atomics and cost 47 of the kernel's 69 us at config 3)
-            for (uint32_t q = threadIdx.x; q < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : n); q += 256) {
+            // (one work item per value AND row word: 66 values alone would leave three of the four waves idle)
+            for (uint32_t it = threadIdx.x; it < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : n * RW); it += T) {
+                const uint32_t q = it / RW, rw = it - q * RW;
                 const uint32_t *bits = sp_lds + (size_t)q * W;
-                for (uint32_t rw = 0; rw < RW; ++rw) {
-                    uint32_t rbits = bits[rw];
-                    while (rbits) {
-                        const uint32_t rb = rw * 32 + (uint32_t)__ffs(rbits) - 1;
-                        rbits &= rbits - 1;
-                        for (uint32_t cw = 0; cw < CW; ++cw) { const uint32_t cbits = bits[RW + cw]; if (cbits) atomicOr(&lbm[(size_t)rb * CW + cw], cbits); }
-                    }
+                uint32_t rbits = bits[rw];
+                while (rbits) {
+                    const uint32_t rb = rw * 32 + (uint32_t)__ffs(rbits) - 1;
+                    rbits &= rbits - 1;
+                    for (uint32_t cw = 0; cw < CW; ++cw) { const uint32_t cbits = bits[RW + cw]; if (cbits) atomicOr(&lbm[(size_t)rb * CW + cw], cbits); }
                 }
             }
         } else {
             // fold into the global slot, one thread per ROW BLOCK: its bitmap row |= the column-block sets of every value that occurs in
             // the row block.  No atomics: a row of the bitmap belongs to one thread, pass after pass.
-            for (uint32_t rb = threadIdx.x; rb < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : nrb); rb += 256) {
+            for (uint32_t rb = threadIdx.x; rb < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : nrb); rb += T) {
                 const uint32_t rw = rb >> 5, rbit = 1u << (rb & 31);
                 for (uint32_t cw0 = 0; cw0 < CW; cw0 += 8) {
                     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1005,7 +1016,7 @@ __global__ __launch_bounds__(256) void sp_mark_kernel(const uint32_t *__restrict
         }
         __syncthreads();
     }
-    for (uint32_t x = threadIdx.x; x < lbm_words; x += 256) slot[x] = lbm[x];
+    for (uint32_t x = threadIdx.x; x < lbm_words; x += T) slot[x] = lbm[x];
 }
 
 // tile bitmap = OR over the columns' copies.  grid (words / 256, SP_OR_SPLIT): a thread folds S / SP_OR_SPLIT copies of one word.
@@ -1030,12 +1041,13 @@ __global__ __launch_bounds__(256) void sp_or_kernel(const uint32_t *__restrict__
 
 // the marked tiles as a work list (any order: a workgroup reserves the range of its tiles with one atomic).  full: rows are ALL
 // sorted positions and a pair is computed where row position < column position, so tiles entirely below that diagonal are not
-// candidates.  ctl[0] = tiles listed, ctl[3] = candidates seen (for the dense / sparse decision of sp_decide_kernel).
+// candidates.  ctl[0] = tiles listed, ctl[3] = candidates (what the dense / sparse decision compares it with).
 __global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
-                                                       uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl) {
+                                                       uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t cand) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) ctl[3] = cand;                  // for d2g_cmp_set_sparse_info
     if (sp_ld(&ctl[1]) & 1u) return;                                    // everything is marked: the dense kernel runs instead
     const size_t ntile = (size_t)nrb * ncb;
     const size_t a = ((size_t)blockIdx.x * 1024 + tid) * 8, b = min(ntile, a + 8);
@@ -1053,17 +1065,17 @@ __global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restric
     for (uint32_t x = 0; x < 8; ++x) if ((mask >> x) & 1u) tiles[o++] = (uint32_t)(a + x);
 }
 
-// dense or sparse?  ctl[1] bit 1 = DENSE: the plain pair kernel walks every tile (and writes every output itself); otherwise the
-// output is pre-filled and the sparse kernel walks the list.  Dense when marking gave up (ALL) or when more than `cand * 0.4` tiles
-// are listed -- the sparse kernel pays for its generality with a per-element epilogue.
-__global__ void sp_decide_kernel(uint32_t *__restrict__ ctl, uint32_t cand) {
-    const uint32_t all = ctl[1] & 1u, n = ctl[0];
-    if (all || (size_t)n * 5 > (size_t)cand * 2) ctl[1] |= 2u;
+// dense or sparse?  DENSE: the plain pair kernel walks every tile (and writes every output itself); otherwise the output is
+// pre-filled and the sparse kernel walks the list.  Dense when marking gave up (ALL) or when more than `cand * 0.4` tiles are
+// listed -- the sparse kernel pays for its generality with a per-element epilogue.
+// evaluated by every consumer of the list (fill, sparse kernel, gated dense kernel) from the same two words: no kernel of its own
+__device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, uint32_t cand) {
+    return (ctl[1] & 1u) != 0 || (size_t)ctl[0] * 5 > (size_t)cand * 2;
 }
 
 template <class Store>
-__global__ __launch_bounds__(256) void sp_fill_kernel(uint32_t *__restrict__ out, size_t cnt, Store store, uint32_t S, const uint32_t *__restrict__ ctl) {
-    if (ctl[1] & 2u) return;                                        // dense mode: the pair kernel writes every output
+__global__ __launch_bounds__(256) void sp_fill_kernel(uint32_t *__restrict__ out, size_t cnt, Store store, uint32_t S, const uint32_t *__restrict__ ctl, uint32_t cand) {
+    if (sp_dense_mode(ctl, cand)) return;                           // dense mode: the pair kernel writes every output
     const uint32_t v = store.value_from_mismatches(S, S);           // the value of "no register equal"
     const size_t n4 = cnt / 4;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1133,7 +1145,7 @@ struct SpArgs {
     int ntb;
     uint32_t S, N;
     const uint32_t *sperm, *rowpos, *tiles, *ctl;
-    uint32_t ncb;
+    uint32_t ncb, cand;
 };
 
 // The sparse pair kernel.  A listed tile (32 launch rows x 256 sorted columns) is four 16 x 128 sub-tiles; a workgroup takes ONE
@@ -1141,12 +1153,12 @@ struct SpArgs {
 // kernel gives every wave a sub-tile and all groups: with a few hundred listed tiles that leaves one or two waves per SIMD, each
 // waiting out the latency of every plane's loads -- measured 87 us for 432 tiles at config 3, 411 us for 2122 at config 4.)
 template <int JR, class Store>
-__global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_sparse_kernel(SpArgs a, PairShape sh, Store store) {
+__global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_sparse_kernel(SpArgs a, PairShape sh, Store store) {
     constexpr int IW = BS_IW;
     constexpr int WC = BS_CB / (64 * JR);
-    constexpr int KS = 4;                                           // waves per sub-tile = splits of the group range
+    constexpr int KS = D2G_SP_KS;                                   // waves per sub-tile = splits of the group range
     __shared__ uint32_t red[IW][64 * JR];
-    if (a.ctl[1] & 2u) return;                                      // dense mode
+    if (sp_dense_mode(a.ctl, a.cand)) return;                       // dense mode
     const uint32_t nsub = a.ctl[0] * 4u;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1159,7 +1171,7 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
         const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
         const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
         if (full && k0 > c0 + 64 * JR - 1) continue;                             // entirely below the diagonal of sorted positions (uniform for the workgroup)
-        for (int x = threadIdx.x; x < IW * 64 * JR; x += BS_THREADS) (&red[0][0])[x] = 0;
+        for (int x = threadIdx.x; x < IW * 64 * JR; x += 64 * KS) (&red[0][0])[x] = 0;
         __syncthreads();
         uint32_t acc[IW][JR];
 #pragma unroll
@@ -1180,27 +1192,26 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
                 sp_group<JR>(nbits, rp, rstep, cp, coff, cstep, nx, acc);
             }
         }
-        if (ks != 0) {
+        // every wave adds its share of the mismatch counts in LDS; afterwards wave ks finishes rows [ks IW/KS, (ks+1) IW/KS) -- the epilogue
+        // (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
+        // work while the other three wait
 #pragma unroll
-            for (int i = 0; i < IW; ++i)
+        for (int i = 0; i < IW; ++i)
 #pragma unroll
-                for (int c = 0; c < JR; ++c) if (acc[i][c]) atomicAdd(&red[i][lane + 64 * c], acc[i][c]);
-        }
+            for (int c = 0; c < JR; ++c) if (acc[i][c]) atomicAdd(&red[i][lane + 64 * c], acc[i][c]);
         __syncthreads();
-        if (ks == 0) {
-            // epilogue: the pairs of this sub-tile in the CALLER's indices; stores only where at least one register is equal
+        {
             uint32_t oj[JR];
 #pragma unroll
             for (int c = 0; c < JR; ++c) oj[c] = a.sperm[c0 + lane + 64 * c];
-#pragma unroll
-            for (int i = 0; i < IW; ++i) {
+            for (int i = ks * IW / KS; i < (ks + 1) * IW / KS; ++i) {
                 const size_t k = k0 + i;
                 const uint32_t rpos = full ? (uint32_t)k : a.rowpos[k];               // uniform
                 if (rpos == SP_NONE || rpos >= a.N) continue;
                 const uint32_t oi = a.sperm[rpos];                                    // uniform
 #pragma unroll
                 for (int c = 0; c < JR; ++c) {
-                    const uint32_t mm = acc[i][c] + red[i][lane + 64 * c];
+                    const uint32_t mm = red[i][lane + 64 * c];
                     if (mm == a.S || oj[c] == SP_NONE) continue;
                     const bool want = full ? rpos < (uint32_t)(c0 + lane + 64 * c) : oj[c] > oi;
                     if (!want) continue;
@@ -1243,19 +1254,21 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMalloc((void **)&set->d_gmin, set->S * SP_GCAP * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_tilebm, set->tilebm_words * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_spctl, (8 + set->tilebm_words) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_slots, set->S * set->tilebm_words * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_tiles, std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_spctl, 8 * 4)) != hipSuccess) {
+        (e = hipMalloc((void **)&set->d_order, 4)) != hipSuccess) {
         ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
+    set->d_tilebm = set->d_spctl + 8;
     return D2G_OK;
 }
 
 void sp_free(d2g_cmp_set *set) {
     for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_lcnt, &set->d_gmin, &set->d_rowpos, &set->d_rowk,
-                         &set->d_rowstream, &set->d_tilebm, &set->d_slots, &set->d_tiles, &set->d_spctl}) { (void)hipFree(*p); *p = nullptr; }
+                         &set->d_rowstream, &set->d_slots, &set->d_tiles, &set->d_spctl, &set->d_order}) { (void)hipFree(*p); *p = nullptr; }
+    set->d_tilebm = nullptr;
 }
 
 // labels -> counting sort -> d_sperm / d_sinv.  All on `s`, no host round trip.
@@ -1265,7 +1278,7 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
     int rounds = 1;
     if (const char *e = std::getenv("D2G_BS_LABEL_ROUNDS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) rounds = v; }
     uint32_t *la = set->d_label, *lb = set->d_label + Npad;
-    hipLaunchKernelGGL(sp_init_kernel, dim3(std::max(nb, 1u)), dim3(256), 0, s, la, N, set->d_spctl);
+    hipLaunchKernelGGL(sp_init_kernel, dim3(std::max(nb, 1u)), dim3(256), 0, s, la, N, set->d_lcnt);
     for (int r = 0; r < rounds; ++r) {
         hipLaunchKernelGGL(sp_gmin_kernel, dim3((unsigned)S), dim3(256), 0, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, la, set->d_gmin);
         hipLaunchKernelGGL(sp_label_kernel, dim3(nb, SP_LABEL_TSPLIT), dim3(256), 0, s, set->d_ids, N, Npad, S, set->d_colcnt, split ? 1 : 0, set->d_gmin, la);
@@ -1274,7 +1287,9 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
             hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, lb, la, N);
         }
     }
-    hipLaunchKernelGGL(sp_sort_kernel, dim3(1), dim3(1024), 0, s, la, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_spctl);
+    hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt);
+    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order);
+    hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
@@ -1296,8 +1311,9 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     if (int rc = finish_shape(ctx, dsh, BS_JR == 2 ? 32u : 64u)) return rc;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
     const uint32_t RW = (nrb + 31) / 32, CW = (ncb + 31) / 32;                          // words of a value's row-block / column-block bit set
-    D2G_HIP(ctx, hipMemsetAsync(set->d_tilebm, 0, ((size_t)nrb * CW + 1) * 4, s));        // one row of CW words per row block
-    D2G_HIP(ctx, hipMemsetAsync(set->d_spctl, 0, 8, s));                              // ctl[0] = tiles listed, ctl[1] = flags (bit 0 ALL, bit 1 DENSE)
+    // ONE memset: d_spctl is the 8 words in front of the bitmap.  ctl[0] = tiles listed, ctl[1] = flags (bit 0 ALL: marking gave up),
+    // [2] = the prepare kept the caller's order -- re-written below, it sits inside the cleared range --, [3] = candidates (the list kernel)
+    D2G_HIP(ctx, hipMemsetAsync(set->d_spctl, 0, (8 + (size_t)nrb * CW + 1) * 4, s));
     if (!full) {
         hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk);
         hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)div_up<size_t>(nrows_pad, 256), (unsigned)(set->ntb * set->nbits_cap)), dim3(256), 0, s,
@@ -1309,30 +1325,35 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     if (full) { cand = 0; for (uint32_t cb = 0; cb < ncb; ++cb) cand += std::min<size_t>(nrb, ((size_t)cb * 256 + 255) / 32 + 1); }
     {
         const uint32_t W = RW + CW;
-        // LDS: the column's copy of the tile bitmap (when it is small) + the bit sets; 40 KB in all: four columns per CU
+        // LDS: the column's copy of the tile bitmap (when it is small) + the bit sets; 36 KB in all: four columns per CU
         uint32_t lbm_words = nrb * CW;
         int lbm_max = 4096;                                                            // words (16 KB)
         if (const char *e = std::getenv("D2G_SP_LOCALBM")) lbm_max = std::atoi(e);       // experiments: 0 = build it in the slot
         if ((int)lbm_words > lbm_max) lbm_words = 0;
-        const uint32_t gm = std::max(1u, std::min(2048u, (10240u - lbm_words) / W));
+        // (36 KB, not 40: with the kernel's few static bytes on top a 40 KB request fits only three times into the CU's 160 KB.)  Wide bit
+        // sets (N above ~20 000: 56 words per value at N = 50 000) take 76 KB and 512 threads, two columns per CU: one pass over the
+        // sketches where three were needed (measured: 637 -> see profiles)
+        const bool wide = W > 24;
+        const uint32_t budget = wide ? 19456u : 9216u;
+        const uint32_t gm = std::max(1u, std::min(2048u, (budget - lbm_words) / W));
         const size_t lds = ((size_t)gm * W + lbm_words) * 4;
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_mark_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)set->S), dim3(256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
-                           full ? (const uint32_t *)nullptr : set->d_rowk, gm, RW, CW, nrb, ncb, lbm_words, set->d_slots, set->d_spctl);
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_mark_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)set->S), dim3(wide ? 512 : 256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
+                           full ? (const uint32_t *)nullptr : set->d_rowk, gm, RW, CW, nrb, ncb, lbm_words, set->d_slots, set->d_spctl, set->d_order);
         hipLaunchKernelGGL(sp_or_kernel, dim3((unsigned)div_up<size_t>((size_t)nrb * CW, 256), SP_OR_SPLIT), dim3(256), 0, s, set->d_slots, nrb * CW, (uint32_t)set->S,
                            set->d_tilebm, set->d_spctl);
     }
-    hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, set->d_tilebm, nrb, ncb, CW, full ? 1 : 0, set->d_tiles, set->d_spctl);
-    hipLaunchKernelGGL(sp_decide_kernel, dim3(1), dim3(1), 0, s, set->d_spctl, (uint32_t)std::min<size_t>(cand, 0xFFFFFFFFu));
+    const uint32_t cand32 = (uint32_t)std::min<size_t>(cand, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, set->d_tilebm, nrb, ncb, CW, full ? 1 : 0, set->d_tiles, set->d_spctl, cand32);
     hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, 256), (size_t)ctx->num_cus * 16)), dim3(256), 0, s,
-                       out_words, cnt, store, (uint32_t)set->S, set->d_spctl);
+                       out_words, cnt, store, (uint32_t)set->S, set->d_spctl, cand32);
     SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
-             set->d_sperm, set->d_rowpos, set->d_tiles, set->d_spctl, ncb};
-    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ntile * 4, (size_t)ctx->num_cus * 7));
-    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(BS_THREADS), 0, s, a, sh, store);
+             set->d_sperm, set->d_rowpos, set->d_tiles, set->d_spctl, ncb, cand32};
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ntile * 4, (size_t)ctx->num_cus * (28 / D2G_SP_KS)));
+    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store);
     if (dsh.nvalid_total)
         hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
-                           set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, dsh, store, (const uint32_t *)set->d_spctl);
+                           set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, dsh, store, (const uint32_t *)set->d_spctl, cand32);
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -1346,7 +1367,7 @@ int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store st
     if (int rc = d2g_bitslice_ensure_natural(ctx, set, s)) return rc;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
     hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
-                       set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, sh, store, (const uint32_t *)nullptr);
+                       set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, sh, store, (const uint32_t *)nullptr, 0u);
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -1588,10 +1609,12 @@ int d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1
 int d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint32_t *out4) {
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
     if (!set->srt_valid || !set->d_spctl) { D2G_HIP(ctx, hipStreamSynchronize(s)); return D2G_OK; }
-    uint32_t c[4] = {0, 0, 0, 0};
+    uint32_t c[4] = {0, 0, 0, 0}, kept = 0;
     D2G_HIP(ctx, hipMemcpyAsync(c, set->d_spctl, sizeof c, hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipMemcpyAsync(&kept, set->d_order, sizeof kept, hipMemcpyDeviceToHost, s));
     D2G_HIP(ctx, hipStreamSynchronize(s));
-    out4[0] = 1; out4[1] = c[0]; out4[2] = c[1]; out4[3] = c[2];
+    c[2] = kept;
+    out4[0] = 1; out4[1] = c[0]; out4[2] = (c[1] & 1u) | (((c[1] & 1u) || (size_t)c[0] * 5 > (size_t)c[3] * 2) ? 2u : 0u); out4[3] = c[2];
     return D2G_OK;
 }
 

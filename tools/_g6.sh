@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for n in 2048 4096 8192 16384 25000; do
-  for sp in 1 0; do echo -n "N=$n sparse=$sp "; N=$n D2G_BS_SPARSE=$sp D2G_BS_SPARSE_MIN_N=1 MATRIX=stated python tools/k2_time.py 2>/dev/null | grep step | cut -c1-42; done
-done
+D2G_BS_SPARSE_MIN_N=1 timeout 1200 python -m pytest tests/test_gpu_k2.py -x -q 2>&1 | tail -3
+MATRIX=stated tools/kstats.sh r04_x python $GRAFT_REPO_ROOT/tools/k2_time.py > /dev/null 2>&1
+echo "c3"; grep -h "step" /tmp/ks_r04_x.out | cut -c1-60; head -22 gpurun_out/r04_x_kernel_stats.txt | cut -c1-60,92-150
+N=50000 MATRIX=stated tools/kstats.sh r04_x python $GRAFT_REPO_ROOT/tools/k2_time.py > /dev/null 2>&1
+echo "c4"; grep -h "step" /tmp/ks_r04_x.out | cut -c1-60; head -12 gpurun_out/r04_x_kernel_stats.txt | cut -c1-60,92-150

@@ -46,7 +46,10 @@ def main():
     sk0 = ctx.sketcher()
     fails = 0
     while time.time() - t0 < budget:
-        which = rng.choice(["k0", "k1", "k2", "k3", "k3", "byseq", "wsets", "mgpu"])
+        kinds = ["k0", "k1", "k2", "k3", "k3", "byseq", "wsets", "mgpu"]
+        if os.environ.get("D2G_FUZZ_ONLY"):                        # e.g. D2G_FUZZ_ONLY=k2: a campaign over one path
+            kinds = os.environ["D2G_FUZZ_ONLY"].split(",")
+        which = rng.choice(kinds)
         try:
             if which == "k0":
                 # device FASTA parser (K0) -> K1 / K3 on the ingested stream, vs the oracle on the same bytes
@@ -83,16 +86,36 @@ def main():
                     er, es, ec, _ = O.sketch_buffer(f, k=k, canon=canon, xormask=xm, S=S)
                     assert np.array_equal(regs[i], er) and np.array_equal(sig[i].view(np.uint64), es.view(np.uint64)) and card[i] == ec
             elif which == "k2":
-                N = int(rng.integers(2, 700)); S = int(rng.choice([32, 64, 100, 128, 1000, 1024])); meas = int(rng.integers(0, 6))
+                N = int(rng.integers(2, 700)) if rng.random() < 0.8 else int(rng.integers(700, 2600))
+                S = int(rng.choice([32, 64, 100, 128, 1000, 1024])); meas = int(rng.integers(0, 6))
                 os.environ["D2G_BS_SORT"] = str(int(rng.integers(0, 2)))                    # column plan on / off
-                if rng.random() < 0.3:
+                # sparse tiles (round 4): forced on for these small matrices half of the time, with 0-2 labelling rounds; the other half
+                # takes the default (dense walk below 8192 sketches)
+                if rng.random() < 0.5:
+                    os.environ["D2G_BS_SPARSE_MIN_N"] = "1"
+                    os.environ["D2G_BS_LABEL_ROUNDS"] = str(int(rng.integers(0, 3)))
+                else:
+                    os.environ.pop("D2G_BS_SPARSE_MIN_N", None)
+                    os.environ.pop("D2G_BS_LABEL_ROUNDS", None)
+                r = rng.random()
+                if r < 0.25:
                     regs = synth.skewed_registers(N, S, seed=int(rng.integers(0, 1 << 30)), max_shared=int(rng.choice([4, 64, 300])))
+                elif r < 0.35:
+                    regs = synth.paired_registers(N - (N & 1), S, seed=int(rng.integers(0, 1 << 30)))[:N]
+                    N = regs.shape[0]
+                elif r < 0.42:
+                    regs = synth.unrelated_registers(N, S, seed=int(rng.integers(0, 1 << 30)))
                 else:
                     regs = synth.synthetic_registers(N, S, nclusters=int(rng.integers(1, 12)), seed=int(rng.integers(0, 1 << 30)))
                 sig, card = D.oph_finalize(regs, S)
                 multiset = bool(rng.integers(0, 2))
                 got = ctx.cmp_dist_ut(sig.view(np.uint64), card, measure=meas, k=int(rng.integers(1, 33)) if False else 31,
                                       multiset_space=multiset, algo=int(rng.choice([D.CMP_AUTO, D.CMP_DIRECT, D.CMP_BITSLICE])))
+                if N > 3 and rng.random() < 0.5:                                             # a row range of the triangle (a shard / a CLI batch)
+                    a = int(rng.integers(0, N - 1)); b = int(rng.integers(a + 1, N + 1))
+                    part = ctx.cmp_dist_ut(sig.view(np.uint64), card, measure=meas, k=31, multiset_space=multiset, r0=a, r1=b, algo=D.CMP_BITSLICE if (multiset or S & (S - 1) == 0) else D.CMP_AUTO)
+                    o0 = D.ut_count(N, 0, a)
+                    assert np.array_equal(part.view(np.uint32), got[o0:o0 + part.size].view(np.uint32))
                 if multiset:
                     neq = O.eqcounts_ut(sig)
                     iu = np.triu_indices(N, 1)
