@@ -60,7 +60,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py: the fallback when rocprofv3 cannot run here
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py: the fallback when rocprofv3 cannot run here
 
 
 def parse_args():
