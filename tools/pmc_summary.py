@@ -23,7 +23,7 @@ def main():
     for k, cs in agg.items():
         import re
         short = re.split(r"[(<]", re.sub(r"^void\s+", "", k).replace("(anonymous namespace)::", ""), 1)[0].strip()
-        if not any(x in k for x in ("k0_", "k1_oph", "k2_", "bs_rank", "bs_planes", "bs_colplan", "bs_derive", "k3_", "k3c_", "mg_pack")):
+        if not any(x in k for x in ("k0_", "k1_oph", "k2_", "bs_rank", "bs_planes", "bs_colplan", "bs_derive", "k3_", "k3c_", "mg_pack", "sp_")):
             continue
         e = {c: sum(v) / len(v) for c, v in cs.items()}
         e["dispatches"] = max(len(v) for v in cs.values())
