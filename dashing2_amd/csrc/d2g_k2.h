@@ -54,6 +54,8 @@ struct d2g_cmp_set {
     uint32_t *d_rowk = nullptr;       // [Npad]    launch row of sketch j (0xFFFFFFFF = not a row of this launch)
     uint32_t *d_rowstream = nullptr;  // [planes][Nstride] row-coded words of the launch rows, gathered (partial launches)
     uint32_t *d_tilebm = nullptr, *d_tiles = nullptr, *d_spctl = nullptr;   // tile bitmap, worklist, {ntiles, flags}
+    uint32_t *d_gbm = nullptr;        // 8 control words + the tile bitmap over ALL sorted row blocks: marked once per prepare (first launch), partial launches derive theirs from it
+    bool gbm_valid = false;
     uint32_t *d_order = nullptr;      // [1] 1 = the last prepare kept the caller's order (one label held most sketches)
     uint32_t *d_slots = nullptr;      // [S][tile bitmap] one copy per register column (sp_mark_kernel), folded by sp_or_kernel
     size_t tilebm_words = 0, tiles_cap = 0;

@@ -1039,16 +1039,32 @@ __global__ __launch_bounds__(256) void sp_or_kernel(const uint32_t *__restrict__
     if (acc) atomicOr(&tilebm[x], acc);
 }
 
+// tile bitmap of a PARTIAL launch from the global one: a block of 32 launch rows may meet what any of the sorted row blocks its rows
+// come from may meet (a superset of the exact marks of those rows: still no tile with a match is missed)
+__global__ __launch_bounds__(256) void sp_rowbm_kernel(const uint32_t *__restrict__ gbm, const uint32_t *__restrict__ rowpos, uint32_t nrb, uint32_t CW,
+                                                       uint32_t *__restrict__ tilebm) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= nrb * CW) return;
+    const uint32_t rb = x / CW, cw = x - rb * CW;
+    uint32_t acc = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) { const uint32_t p = rowpos[rb * 32 + i]; if (p != SP_NONE) acc |= gbm[(size_t)(p >> 5) * CW + cw]; }
+    tilebm[x] = acc;
+}
+
 // the marked tiles as a work list (any order: a workgroup reserves the range of its tiles with one atomic).  full: rows are ALL
 // sorted positions and a pair is computed where row position < column position, so tiles entirely below that diagonal are not
 // candidates.  ctl[0] = tiles listed, ctl[3] = candidates (what the dense / sparse decision compares it with).
 __global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
-                                                       uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t cand) {
+                                                       uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t cand, const uint32_t *__restrict__ gflags) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) ctl[3] = cand;                  // for d2g_cmp_set_sparse_info
-    if (sp_ld(&ctl[1]) & 1u) return;                                    // everything is marked: the dense kernel runs instead
+    if (gflags[1] & 1u) {                                           // the (global) marking gave up: the dense kernel runs instead
+        if (blockIdx.x == 0 && tid == 0) atomicOr(&ctl[1], 1u);
+        return;
+    }
     const size_t ntile = (size_t)nrb * ncb;
     const size_t a = ((size_t)blockIdx.x * 1024 + tid) * 8, b = min(ntile, a + 8);
     uint32_t n = 0, mask = 0;
@@ -1157,7 +1173,8 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     constexpr int IW = BS_IW;
     constexpr int WC = BS_CB / (64 * JR);
     constexpr int KS = D2G_SP_KS;                                   // waves per sub-tile = splits of the group range
-    __shared__ uint32_t red[IW][64 * JR];
+    static_assert(JR == 2, "the LDS reduction packs a lane's two column groups into one word");
+    __shared__ uint32_t red[IW][64];                                // per row and lane: mismatches of column group 0 | group 1 << 16 (a sum stays below 2^16: S < 65536 asserted by the host)
     if (sp_dense_mode(a.ctl, a.cand)) return;                       // dense mode
     const uint32_t nsub = a.ctl[0] * 4u;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1171,7 +1188,7 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
         const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
         if (full && k0 > c0 + 64 * JR - 1) continue;                             // entirely below the diagonal of sorted positions (uniform for the workgroup)
-        for (int x = threadIdx.x; x < IW * 64 * JR; x += 64 * KS) (&red[0][0])[x] = 0;
+        for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
         __syncthreads();
         uint32_t acc[IW][JR];
 #pragma unroll
@@ -1196,9 +1213,7 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         // (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
         // work while the other three wait
 #pragma unroll
-        for (int i = 0; i < IW; ++i)
-#pragma unroll
-            for (int c = 0; c < JR; ++c) if (acc[i][c]) atomicAdd(&red[i][lane + 64 * c], acc[i][c]);
+        for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][lane], v); }
         __syncthreads();
         {
             uint32_t oj[JR];
@@ -1211,7 +1226,7 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
                 const uint32_t oi = a.sperm[rpos];                                    // uniform
 #pragma unroll
                 for (int c = 0; c < JR; ++c) {
-                    const uint32_t mm = red[i][lane + 64 * c];
+                    const uint32_t mm = (red[i][lane] >> (16 * c)) & 0xFFFFu;
                     if (mm == a.S || oj[c] == SP_NONE) continue;
                     const bool want = full ? rpos < (uint32_t)(c0 + lane + 64 * c) : oj[c] > oi;
                     if (!want) continue;
@@ -1255,6 +1270,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_spctl, (8 + set->tilebm_words) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_gbm, (8 + set->tilebm_words) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_slots, set->S * set->tilebm_words * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_tiles, std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_order, 4)) != hipSuccess) {
@@ -1267,7 +1283,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 
 void sp_free(d2g_cmp_set *set) {
     for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_lcnt, &set->d_gmin, &set->d_rowpos, &set->d_rowk,
-                         &set->d_rowstream, &set->d_slots, &set->d_tiles, &set->d_spctl, &set->d_order}) { (void)hipFree(*p); *p = nullptr; }
+                         &set->d_rowstream, &set->d_slots, &set->d_tiles, &set->d_spctl, &set->d_gbm, &set->d_order}) { (void)hipFree(*p); *p = nullptr; }
     set->d_tilebm = nullptr;
 }
 
@@ -1310,45 +1326,49 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     PairShape dsh = sh;                                                                 // the dense walk of the same launch, behind the gate
     if (int rc = finish_shape(ctx, dsh, BS_JR == 2 ? 32u : 64u)) return rc;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
-    const uint32_t RW = (nrb + 31) / 32, CW = (ncb + 31) / 32;                          // words of a value's row-block / column-block bit set
-    // ONE memset: d_spctl is the 8 words in front of the bitmap.  ctl[0] = tiles listed, ctl[1] = flags (bit 0 ALL: marking gave up),
-    // [2] = the prepare kept the caller's order -- re-written below, it sits inside the cleared range --, [3] = candidates (the list kernel)
-    D2G_HIP(ctx, hipMemsetAsync(set->d_spctl, 0, (8 + (size_t)nrb * CW + 1) * 4, s));
-    if (!full) {
-        hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk);
-        hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)div_up<size_t>(nrows_pad, 256), (unsigned)(set->ntb * set->nbits_cap)), dim3(256), 0, s,
-                           set->d_stream_s, set->Nstride, set->d_meta, set->ntb, set->d_rowpos, (uint32_t)nrows_pad, set->d_rowstream, set->Nstride);
-    }
-    const size_t ntile = (size_t)nrb * ncb;
-    // candidates: every tile of a partial launch; the tiles on or above the diagonal of sorted positions of a full one
-    size_t cand = ntile;
-    if (full) { cand = 0; for (uint32_t cb = 0; cb < ncb; ++cb) cand += std::min<size_t>(nrb, ((size_t)cb * 256 + 255) / 32 + 1); }
-    {
-        const uint32_t W = RW + CW;
+    const uint32_t CW = (ncb + 31) / 32;                                                // words of a bitmap row (column blocks)
+    const uint32_t nrbG = (uint32_t)(Npad / 32);                                        // all sorted row blocks
+    if (!set->gbm_valid) {
+        // ONCE per prepare: the tiles that hold a pair with a shared value, over all sorted positions (d_gbm: 8 control words + bitmap)
+        const uint32_t RW = (nrbG + 31) / 32, W = RW + CW;
+        D2G_HIP(ctx, hipMemsetAsync(set->d_gbm, 0, (8 + (size_t)nrbG * CW + 1) * 4, s));
         // LDS: the column's copy of the tile bitmap (when it is small) + the bit sets; 36 KB in all: four columns per CU
-        uint32_t lbm_words = nrb * CW;
+        uint32_t lbm_words = nrbG * CW;
         int lbm_max = 4096;                                                            // words (16 KB)
         if (const char *e = std::getenv("D2G_SP_LOCALBM")) lbm_max = std::atoi(e);       // experiments: 0 = build it in the slot
         if ((int)lbm_words > lbm_max) lbm_words = 0;
         // (36 KB, not 40: with the kernel's few static bytes on top a 40 KB request fits only three times into the CU's 160 KB.)  Wide bit
-        // sets (N above ~20 000: 56 words per value at N = 50 000) take 76 KB and 512 threads, two columns per CU: one pass over the
-        // sketches where three were needed (measured: 637 -> see profiles)
+        // sets (N above ~20 000: 56 words per value at N = 50 000) take 76 KB and 512 threads, two columns per CU: fewer passes over the sketches
         const bool wide = W > 24;
         const uint32_t budget = wide ? 19456u : 9216u;
         const uint32_t gm = std::max(1u, std::min(2048u, (budget - lbm_words) / W));
         const size_t lds = ((size_t)gm * W + lbm_words) * 4;
         D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_mark_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)set->S), dim3(wide ? 512 : 256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
-                           full ? (const uint32_t *)nullptr : set->d_rowk, gm, RW, CW, nrb, ncb, lbm_words, set->d_slots, set->d_spctl, set->d_order);
-        hipLaunchKernelGGL(sp_or_kernel, dim3((unsigned)div_up<size_t>((size_t)nrb * CW, 256), SP_OR_SPLIT), dim3(256), 0, s, set->d_slots, nrb * CW, (uint32_t)set->S,
-                           set->d_tilebm, set->d_spctl);
+                           (const uint32_t *)nullptr, gm, RW, CW, nrbG, ncb, lbm_words, set->d_slots, set->d_gbm, set->d_order);
+        hipLaunchKernelGGL(sp_or_kernel, dim3((unsigned)div_up<size_t>((size_t)nrbG * CW, 256), SP_OR_SPLIT), dim3(256), 0, s, set->d_slots, nrbG * CW, (uint32_t)set->S,
+                           set->d_gbm + 8, set->d_gbm);
+        set->gbm_valid = true;
     }
+    // per launch: 8 control words (ctl[0] = tiles listed, ctl[1] = flags (bit 0 ALL: marking gave up), [3] = candidates) + a partial launch's bitmap
+    D2G_HIP(ctx, hipMemsetAsync(set->d_spctl, 0, 8 * 4, s));
+    if (!full) {
+        hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk);
+        hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)div_up<size_t>(nrows_pad, 256), (unsigned)(set->ntb * set->nbits_cap)), dim3(256), 0, s,
+                           set->d_stream_s, set->Nstride, set->d_meta, set->ntb, set->d_rowpos, (uint32_t)nrows_pad, set->d_rowstream, set->Nstride);
+        hipLaunchKernelGGL(sp_rowbm_kernel, dim3((unsigned)div_up<size_t>((size_t)nrb * CW, 256)), dim3(256), 0, s, set->d_gbm + 8, set->d_rowpos, nrb, CW, set->d_tilebm);
+    }
+    const size_t ntile = (size_t)nrb * ncb;
+    // candidates: every tile of a partial launch; the tiles on or above the diagonal of sorted positions of a full one
+    size_t cand = ntile;
+    if (full) { cand = 0; for (uint32_t cb = 0; cb < ncb; ++cb) cand += std::min<size_t>(nrb, ((size_t)cb * 256 + 255) / 32 + 1); }
     const uint32_t cand32 = (uint32_t)std::min<size_t>(cand, 0xFFFFFFFFu);
-    hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, set->d_tilebm, nrb, ncb, CW, full ? 1 : 0, set->d_tiles, set->d_spctl, cand32);
-    hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, 256), (size_t)ctx->num_cus * 16)), dim3(256), 0, s,
-                       out_words, cnt, store, (uint32_t)set->S, set->d_spctl, cand32);
+    hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, full ? set->d_gbm + 8 : set->d_tilebm, nrb, ncb, CW, full ? 1 : 0,
+                       set->d_tiles, set->d_spctl, cand32, set->d_gbm);
     SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
              set->d_sperm, set->d_rowpos, set->d_tiles, set->d_spctl, ncb, cand32};
+    hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, 256), (size_t)ctx->num_cus * 16)), dim3(256), 0, s,
+                       out_words, cnt, store, (uint32_t)set->S, set->d_spctl, cand32);
     const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ntile * 4, (size_t)ctx->num_cus * (28 / D2G_SP_KS)));
     hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store);
     if (dsh.nvalid_total)
@@ -1457,7 +1477,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
     if (int rc = d2g_bitslice_alloc_stream(ctx, set)) { d2g_bitslice_free(set); return rc; }
-    set->sparse_ok = sparse_enabled(set->N) && set->S * (set->Npad / 32) * ((set->Npad / BS_CB + 31) / 32) * 4 <= ((size_t)1 << 30);   // the columns' tile bitmaps: <= 1 GiB
+    set->sparse_ok = sparse_enabled(set->N) && set->S < 65536 && set->S * (set->Npad / 32) * ((set->Npad / BS_CB + 31) / 32) * 4 <= ((size_t)1 << 30);   // the columns' tile bitmaps: <= 1 GiB
     if (set->sparse_ok) if (int rc = sp_alloc(ctx, set)) { d2g_bitslice_free(set); return rc; }
     return D2G_OK;
 }
@@ -1495,11 +1515,13 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         // sparse path: the stream in label order (section 4); the caller's-order stream is only built if a launch asks for it
         // (gathering the ids through d_sperm inside bs_planes_kernel was measured: 74 us instead of 18 at config 3 -- 1024 columns of
         // uncoalesced 4-byte loads; permuting the finished stream touches 256 rows of words and leaves the caller's-order stream valid)
+        // (a second queue for the caller's-order planes beside the labelling, and for the fill beside the marking, was measured: the
+        // kernels slow each other down by what the overlap hides -- mark 28 -> 57 us next to the fill -- and the events cost more: dropped)
         if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
         hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
                            set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
         hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm);
-        set->srt_valid = true; set->nat_valid = true;
+        set->srt_valid = true; set->nat_valid = true; set->gbm_valid = false;
         D2G_HIP(ctx, hipGetLastError());
         return D2G_OK;
     }

@@ -9,6 +9,8 @@ so there is no reduction.  Each rank writes its slab at its own offset of the bi
 
 Launch:  python -m dashing2_amd.dist cmp --presketched stack.bin --cmpout dist.bin [--distance] [-k 31]
              (one process: the C++ CLI drives every visible GPU through libd2g's RCCL communicator)
+         python -m dashing2_amd.dist sketch -F files.txt -o stack.bin [...]
+             (one process: `D2G_DEVICES=all dashing2 sketch`, a pair of device threads per GPU -- the product path since round 4)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
              -m dashing2_amd.dist sketch -F files.txt -o stack.bin [-k 31 -S 1024 --multiset ...]
 The torch.distributed classes below (sharded_allpairs, RowShardedAllPairs) are the same exchange written against
@@ -368,6 +370,14 @@ def sketch_main(argv):
     ap.add_argument("-F", "--ffile", required=True)
     ap.add_argument("-o", "--outfile", required=True)
     args, passthrough = ap.parse_known_args(argv)
+    if "WORLD_SIZE" not in os.environ:
+        # no launcher: the product path -- ONE `dashing2 sketch` process whose C++ host deals the input groups to a pair of device
+        # threads per GPU (D2G_DEVICES; dashing2_main.cpp: sketch_core).  The rank-per-GPU form below is what runs under a launcher.
+        import subprocess
+        exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "dashing2")
+        env = dict(os.environ)
+        env.setdefault("D2G_DEVICES", "all")
+        return subprocess.call([exe, "sketch", "-F", args.ffile, "-o", args.outfile] + passthrough, env=env)
     dist = _dist()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

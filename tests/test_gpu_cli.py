@@ -394,6 +394,12 @@ def test_dist_sketch_tool_single_rank(genomes, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     assert a.read_bytes() == b.read_bytes()
     assert open(str(a) + ".names.txt").read() == open(str(b) + ".names.txt").read()
+    # the rank-per-GPU form (what runs under a launcher), world 1
+    c = tmp_path / "c.bin"
+    r = subprocess.run([sys.executable, "-m", "dashing2_amd.dist", "sketch", "-F", str(lst), "-o", str(c), "-k", "21", "-S", "128"],
+                       capture_output=True, cwd=ROOT, env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert a.read_bytes() == c.read_bytes()
 
 
 def test_cli_multiset_shapes_and_measures(oracle, genomes, tmp_path):
