@@ -707,6 +707,12 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
 constexpr int SP_GCAP = 1024;                   // shared values per column that take part in the labelling
 constexpr int SP_LABEL_TSPLIT = 32;
+#ifndef D2G_SP_WIDE_U
+#define D2G_SP_WIDE_U 8          // sketches per thread and step of the wide mark kernel (measured at N = 50 000: 8 -> 532 us, 16 -> 856 us)
+#endif
+#ifndef D2G_SP_WIDE_FOLD
+#define D2G_SP_WIDE_FOLD 0       // 0: a thread per row block ORs the values' sets into its bitmap row (532 us); 1: a work item per value and row word, atomicOr into the slot (777 us)
+#endif
 #ifndef D2G_SP_KS
 #define D2G_SP_KS 4
 #endif
@@ -910,6 +916,7 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restri
 // The marks of a column go to the column's OWN copy of the tile bitmap (`slots`), which sp_or_kernel folds into one afterwards:
 // every column marks the same few hundred tiles, and 1024 workgroups testing / setting the same 2.5 KB through device-scope
 // operations all queue at one memory channel (measured: 48 of the kernel's 70 us at config 3).
+template <int U>
 __global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
                                                       const uint32_t *__restrict__ sinv, const uint32_t *__restrict__ rowk, uint32_t gm, uint32_t RW, uint32_t CW,
                                                       uint32_t nrb, uint32_t ncb, uint32_t lbm_words, uint32_t *__restrict__ slots, uint32_t *__restrict__ ctl,
@@ -941,8 +948,7 @@ __global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict
         for (uint32_t x = threadIdx.x; x < n * W; x += T) sp_lds[x] = 0;
         __syncthreads();
         if (s_stop) return;
-        // 2048 sketches per step, eight per thread; the loads of the next step are issued before this step's bit sets are updated
-        constexpr int U = 8;
+        // U sketches per thread and step; the loads of the next step are issued before this step's bit sets are updated
         uint32_t w[U], k[U], c[U];
         auto load = [&](size_t j0) {
 #pragma unroll
@@ -996,9 +1002,8 @@ __global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict
                 }
             }
         } else {
-            // fold into the global slot, one thread per ROW BLOCK: its bitmap row |= the column-block sets of every value that occurs in
-            // the row block.  No atomics: a row of the bitmap belongs to one thread, pass after pass.
-            for (uint32_t rb = threadIdx.x; rb < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : nrb); rb += T) {
+#if D2G_SP_WIDE_FOLD == 0
+            for (uint32_t rb = threadIdx.x; rb < nrb; rb += T) {
                 const uint32_t rw = rb >> 5, rbit = 1u << (rb & 31);
                 for (uint32_t cw0 = 0; cw0 < CW; cw0 += 8) {
                     uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1014,6 +1019,25 @@ __global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict
                 }
             }
         }
+#else
+            // fold into the global slot (large N), one work item per value and row word: atomicOr without a return value into the column's
+            // OWN slot (nobody else touches it; zeroed + fenced above).  (One thread per row block reading all values' row words from
+            // LDS was measured at N = 50 000: 96 us of the workgroup's 250.)
+            for (uint32_t it = threadIdx.x; it < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : n * RW); it += T) {
+                const uint32_t q = it / RW, rw = it - q * RW;
+                const uint32_t *bits = sp_lds + (size_t)q * W;
+                uint32_t rbits = bits[rw];
+                while (rbits) {
+                    const uint32_t rb = rw * 32 + (uint32_t)__ffs(rbits) - 1;
+                    rbits &= rbits - 1;
+                    for (uint32_t cw = 0; cw < CW; ++cw) {
+                        const uint32_t cbits = bits[RW + cw];
+                        if (cbits) (void)__hip_atomic_fetch_or(&slot[(size_t)rb * CW + cw], cbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        }
+#endif
         __syncthreads();
     }
     for (uint32_t x = threadIdx.x; x < lbm_words; x += T) slot[x] = lbm[x];
@@ -1343,8 +1367,9 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
         const uint32_t budget = wide ? 19456u : 9216u;
         const uint32_t gm = std::max(1u, std::min(2048u, (budget - lbm_words) / W));
         const size_t lds = ((size_t)gm * W + lbm_words) * 4;
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_mark_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        hipLaunchKernelGGL(sp_mark_kernel, dim3((unsigned)set->S), dim3(wide ? 512 : 256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
+        auto mark = wide ? sp_mark_kernel<D2G_SP_WIDE_U> : sp_mark_kernel<8>;
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)mark, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        hipLaunchKernelGGL(mark, dim3((unsigned)set->S), dim3(wide ? 512 : 256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
                            (const uint32_t *)nullptr, gm, RW, CW, nrbG, ncb, lbm_words, set->d_slots, set->d_gbm, set->d_order);
         hipLaunchKernelGGL(sp_or_kernel, dim3((unsigned)div_up<size_t>((size_t)nrbG * CW, 256), SP_OR_SPLIT), dim3(256), 0, s, set->d_slots, nrbG * CW, (uint32_t)set->S,
                            set->d_gbm + 8, set->d_gbm);
