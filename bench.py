@@ -1591,9 +1591,9 @@ def main():
     args = parse_args()
     if args.pmc_child:
         return pmc_child(args)
+    if args.worker:                      # a measuring child of the supervisor (tests also run one directly at world size 1)
+        return run_multi(args)
     if args.gpus > 1:
-        if args.worker:
-            return run_multi(args)
         raise SystemExit(supervise(args))
     run_single(args)
 

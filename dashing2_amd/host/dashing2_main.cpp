@@ -832,6 +832,14 @@ void rect_epilogue(const Options &o, const CmpShape &sh, size_t r0, size_t r1, c
         }
 }
 
+// what the sparse-tile path did on the last upper-triangle launch of the set (include/d2g.h: d2g_cmp_set_sparse_info)
+std::string sparse_json(d2g_ctx *ctx, const d2g_cmp_set *set) {
+    uint32_t i4[4] = {0, 0, 0, 0};
+    if (d2g_cmp_set_sparse_info(ctx, set, nullptr, i4) != D2G_OK) return "null";
+    return std::string("{\"sorted_operand\": ") + (i4[0] ? "true" : "false") + ", \"tiles_listed_last_launch\": " + std::to_string(i4[1]) + ", \"marking_gave_up\": " +
+           ((i4[2] & 1) ? "true" : "false") + ", \"dense_kernel_ran\": " + ((i4[2] & 2) ? "true" : "false") + ", \"callers_order_kept\": " + (i4[3] ? "true" : "false") + "}";
+}
+
 std::string planes_json(d2g_ctx *ctx, const d2g_cmp_set *set) {
     unsigned md = 0; int nb = 0; float mean = 0;
     if (d2g_cmp_set_planes(ctx, set, nullptr, &md, &nb, &mean) != D2G_OK) return "null";
@@ -1075,7 +1083,7 @@ void cmp_core(const Options &o, Result &res, d2g_ctx *ctx) {      // src/cmp_cor
         const bool bs = d2g_cmp_set_algo(set) == D2G_CMP_BITSLICE;
         g_stats.raw("cmp", std::string("{\"sketches\": ") + std::to_string(ns) + ", \"sketchsize\": " + std::to_string(S) + ", \"values\": " + std::to_string(sh.total_vals) +
                     ", \"shape\": " + (sh.symmetric ? "\"upper triangle\"" : o.ok == PANEL ? "\"panel\"" : "\"square\"") + ", \"algo\": " + (bs ? "\"bitslice\"" : "\"direct\"") +
-                    ", \"bit_planes\": " + (bs ? planes_json(ctx, set) : std::string("null")) +
+                    ", \"bit_planes\": " + (bs ? planes_json(ctx, set) : std::string("null")) + ", \"sparse_tiles\": " + (bs ? sparse_json(ctx, set) : std::string("null")) +
                     ", \"algorithmic_bytes\": " + Stats::numstr(8.0 * double(S) * double(ns) + 4.0 * double(sh.total_vals)) + ", \"batches\": " + std::to_string(nbatches) +
                     ", \"slot_values\": " + std::to_string(cap) +
                     ", \"devices\": [{\"index\": " + std::to_string(o.device) + ", \"name\": " + Stats::esc(device_label(o.device)) + ", \"k2\": " + Stats::kernel_json(ctx, "k2") +

@@ -398,3 +398,37 @@ def test_allpairs_phase_times_cover_the_step(d2g, oracle):
         c.close()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("engine", ["cabi", "torch", "broadcast"])
+def test_bench_ranked_rungs_at_world_size_one(d2g, engine, tmp_path):
+    """The ranked rungs of bench.py's N > 1 ladder cannot form a clique of two on a 1-GPU box (RCCL refuses one device twice), but their
+    worker code can run at world size 1: process group (gloo for `cabi`, nccl for the others), libd2g's communicator from a unique id
+    (a real one-member RCCL communicator), the engine, the whole-slab check against a single-GPU computation, both bases, the phase
+    times, the timed region and the JSON line -- everything but a second rank."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from dashing2_amd import synth
+    N, S = 2600, 1024
+    regs = synth.synthetic_registers(N, S, nclusters=17, seed=5)
+    sig, cards = d2g.oph_finalize(regs, S, nthreads=4)
+    np.save(tmp_path / "sig.npy", sig.view(np.uint64))
+    np.save(tmp_path / "cards.npy", cards)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--worker", "--engine", engine, "--gpus", "1", "--sketches", str(N), "--steps", "3", "--warmup", "1",
+                        "--sig-file", str(tmp_path / "sig.npy"), "--cards-file", str(tmp_path / "cards.npy")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "valid" not in line and "WHOLE slab equals" in line["config"]["slab_check"]
+    assert line["scaling_base"]["base_1gpu_same_config_pairs_per_s"] > 0 and line["per_rank"][0]["pairs"] == N * (N - 1) // 2
+    if engine == "cabi":
+        assert {p[0] for p in line["phases"]["per_rank"][0]} == {"pack", "x1", "prepare", "x2", "derive", "pair"}
+        assert line["stream_of_matrices"]["outputs_identical_to_the_one_job_step"] is True
