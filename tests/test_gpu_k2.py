@@ -521,3 +521,56 @@ def test_k2_column_plan_large_sketch_sizes(gpu_ctx, d2g, oracle, S):
     md, nb, mean = cs.planes()
     assert 1 <= nb <= 6 and mean <= nb
     cs.close()
+
+
+def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g, oracle):
+    """Round 4: from 8192 sketches on, an upper-triangle launch on a bit-sliced set walks only the tiles that hold a pair with a shared
+    register value (pre-filled output, order by shared-value labels, per-launch tile list), or -- decided on the device -- every tile.
+    Whatever it decides, the counts are those of the direct 64-bit kernel (itself pinned to the oracle elsewhere) and of sampled oracle
+    rows: a family collection (tiles listed, sparse kernel), an adversarial matrix (marking gives up, dense kernel), skewed columns
+    (caller's order kept), unrelated sketches (nothing listed: the fill alone); whole triangle and row ranges; and a set RE-LOADED with
+    another matrix (the cached order and tile marks of the first one must not survive)."""
+    import torch
+    N, S = 12_000, 96
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    mats = {"families": synth.synthetic_registers(N, S, nclusters=N // 150, seed=3).view(np.float64),
+            "paired": synth.paired_registers(N, S, seed=4).view(np.float64),
+            "skewed": synth.skewed_registers(N, S, seed=5).view(np.float64),
+            "unrelated": synth.unrelated_registers(N, S, seed=6).view(np.float64)}
+    npairs = N * (N - 1) // 2
+    out = torch.empty(npairs, dtype=torch.int32, device=dev)
+    ref = torch.empty(npairs, dtype=torch.int32, device=dev)
+    cs = None
+    seen = {}
+    off = np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
+    for name, m in mats.items():
+        bits = np.ascontiguousarray(m).view(np.uint64)
+        t_dev = torch.from_numpy(bits.view(np.int64)).to(dev)
+        if cs is None:
+            cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_BITSLICE, stream=stream)
+        else:
+            cs.update_dev(t_dev.data_ptr(), stream)                   # same set, another matrix
+        out.fill_(-1)
+        cs.eqcount_ut_dev(out.data_ptr(), 0, N, stream)
+        info = cs.sparse_info(stream)
+        seen[name] = info
+        dr = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_DIRECT, stream=stream)
+        dr.eqcount_ut_dev(ref.data_ptr(), 0, N, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), name
+        dr.close()
+        # row ranges (a shard, a CLI batch): the same values as the whole-triangle launch
+        host = out.cpu().numpy().view(np.uint32)
+        for r0, r1 in ((0, 1), (5, 700), (N // 3, N // 3 + 1111), (N - 300, N)):
+            np.testing.assert_array_equal(cs.eqcount_ut(r0, r1), host[off[r0]:off[r1]], err_msg=f"{name} rows {r0}:{r1}")
+        # and the oracle on a few rows
+        r0, r1 = 100, 103
+        want = np.concatenate([(m[i + 1:] == m[i]).sum(axis=1) for i in range(r0, r1)]).astype(np.uint32)
+        np.testing.assert_array_equal(host[off[r0]:off[r1]], want, err_msg=name)
+        del t_dev
+    cs.close()
+    assert seen["families"]["sorted_operand"] and seen["families"]["tiles_listed"] > 0 and not seen["families"]["dense_kernel_ran"]
+    assert seen["paired"]["dense_kernel_ran"] and seen["paired"]["marking_gave_up"]
+    assert seen["skewed"]["dense_kernel_ran"] and seen["skewed"]["callers_order_kept"]
+    assert seen["unrelated"]["tiles_listed"] == 0 and not seen["unrelated"]["dense_kernel_ran"]
