@@ -724,7 +724,8 @@ def test_cli_gpu_stats_json(genomes, tmp_path):
     n = len(genomes)
     assert cm["sketches"] == n and cm["values"] == n * (n - 1) // 2 and cm["algo"] == "bitslice" and cm["bit_planes"]["max"] >= 1
     assert cm["devices"][0]["k2"]["launches"] >= 1 and cm["devices"][0]["k2prep"]["launches"] >= 1
-    assert cm["sparse_tiles"]["sorted_operand"] is False          # 7 sketches: far below the size from which tiles are listed
+    # 7 sketches: far below the size from which tiles are listed -- unless the environment forces the sparse path on (the second GPU run of the suite)
+    assert cm["sparse_tiles"]["sorted_operand"] is (os.environ.get("D2G_BS_SPARSE_MIN_N") == "1")
     assert cm["algorithmic_bytes"] == 8 * S * n + 4 * cm["values"]
     ref_s, ref_c = o.read_bytes(), c.read_bytes()
     _run(["sketch", "-k", str(k), "-S", str(S), "-o", str(o), "--cmpout", str(c), "--binary-output"] + genomes)
