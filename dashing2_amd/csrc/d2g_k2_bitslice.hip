@@ -814,10 +814,18 @@ __device__ __forceinline__ uint32_t sp_block_scan(uint32_t v, uint32_t *wave_tot
 // now ~25).  One root holding more than half of the sketches (everything is connected) keeps the caller's order: order[0] = 1.
 __global__ __launch_bounds__(256) void sp_count_kernel(const uint32_t *__restrict__ label, uint32_t *__restrict__ root, size_t N, uint32_t *__restrict__ cnt) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    const uint32_t r = sp_root(label, j);
-    root[j] = r;
-    atomicAdd(&cnt[r], 1u);
+    const bool live = j < N;
+    const uint32_t r = live ? sp_root(label, j) : SP_NONE;
+    if (live) root[j] = r;
+    // when everything hangs together ONE counter takes all N increments (measured: 115 us at N = 10 000): the lanes that share the
+    // wave's first root add once; the others go one by one (matching every distinct root of a wave costs more than it saves when a
+    // wave holds 64 different ones: 64 rounds of ballot + shuffle, + 40-100 us on the family / unrelated matrices)
+    const unsigned long long alive = __ballot(live);
+    if (!alive) return;
+    const uint32_t lead = __shfl(r, __ffsll((long long)alive) - 1);
+    const unsigned long long m = __ballot(live && r == lead);
+    if (live && r == lead) { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[lead], (uint32_t)__popcll(m)); }
+    else if (live) atomicAdd(&cnt[r], 1u);
 }
 __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order) {
     // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
@@ -849,11 +857,24 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
 __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
                                                         uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j < N) {
-        const uint32_t p = order[0] ? (uint32_t)j : atomicAdd(&cnt[root[j]], 1u);
-        sperm[p] = (uint32_t)j;
-        sinv[j] = p;
-    } else if (j < Nstride) sperm[j] = SP_NONE;
+    const bool live = j < N;
+    if (!live && j < Nstride) sperm[j] = SP_NONE;
+    if (order[0]) { if (live) { sperm[j] = (uint32_t)j; sinv[j] = (uint32_t)j; } return; }
+    const uint32_t r = live ? root[j] : SP_NONE;
+    const int lane = threadIdx.x & 63;
+    uint32_t p = 0;
+    const unsigned long long alive = __ballot(live);
+    if (!alive) return;
+    // as in sp_count_kernel: the lanes that share the wave's first root move its cursor once (and keep their order), the others one by one
+    const uint32_t lead = __shfl(r, __ffsll((long long)alive) - 1);
+    const unsigned long long m = __ballot(live && r == lead);
+    const int first = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&cnt[lead], (uint32_t)__popcll(m));
+    base = __shfl(base, first);
+    if (live && r == lead) p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    else if (live) p = atomicAdd(&cnt[r], 1u);
+    if (live) { sperm[p] = (uint32_t)j; sinv[j] = p; }
 }
 
 // the sorted stream from the caller's-order stream: position p takes the words of sketch sperm[p].  Only the row-coded words and
