@@ -426,6 +426,8 @@ def run_rung(engine, args, tmp, extra_argv, timeout):
                                                                 "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS",
                                                                 "TORCH_NCCL_ASYNC_ERROR_HANDLING", "NCCL_ASYNC_ERROR_HANDLING"))}
     base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.path.isdir("/sys/class/net/lo"):
+        base_env.setdefault("GLOO_SOCKET_IFNAME", "lo")            # every rank is on this node: gloo must not depend on the hostname resolving
     base_env["OMP_NUM_THREADS"] = str(max(1, host_cores() // nproc))
     procs, files = [], []
     t0 = time.monotonic()
