@@ -355,6 +355,7 @@ def pack_genomes(D, synth, first, count, L, k, keep=0, nthreads=None):
 # N > 1: supervisor + watchdog ladder
 # ======================================================================================================================
 LADDER = ("cabi", "inproc", "torch", "broadcast")
+VISIBILITY_VARS = ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")
 # seconds a rung may take before its process group is killed; the first rung also pays the first `import torch` of N processes on a
 # fresh box (1-2 min).  D2G_BENCH_RUNG_TIMEOUT overrides all of them (tests).
 RUNG_TIMEOUT = {"cabi": 420.0, "inproc": 300.0, "torch": 300.0, "broadcast": 240.0}
@@ -499,6 +500,21 @@ def supervise(args):
     from dashing2_amd import synth
     skip_check = args.loopback or os.environ.get("D2G_BENCH_TEST_SKIP_DEVICE_CHECK") == "1"
     have = int(D.lib().d2g_device_count())
+    if have < args.gpus and not skip_check and any(v in os.environ for v in VISIBILITY_VARS):
+        # a launcher that pins each rank to its own GPU (HIP_VISIBLE_DEVICES = LOCAL_RANK and the like) hides the others from THIS rank, which
+        # supervises for all of them: count again without the mask, in a throw-away process, and start the workers without it
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if k not in VISIBILITY_VARS}
+        code = "import ctypes,sys; print(ctypes.CDLL(sys.argv[1]).d2g_device_count())"
+        try:
+            unmasked = int(subprocess.run([sys.executable, "-c", code, D.LIB_PATH], env=env, capture_output=True, text=True, timeout=120).stdout.strip() or 0)
+        except Exception:                                       # noqa: BLE001
+            unmasked = 0
+        if unmasked >= args.gpus:
+            for v in VISIBILITY_VARS:
+                os.environ.pop(v, None)
+            have = unmasked
+            launched_by += "; the launcher's device mask was dropped for the workers"
     if have < args.gpus and not skip_check:
         print(json.dumps(error_line(args, f"--gpus {args.gpus} requested but {have} HIP device(s) visible: refusing to "
                                           "measure a smaller job under that label")), flush=True)
