@@ -760,8 +760,9 @@ def run_multi(args):
 
             bdt = time_ref(ref)
             sp = ref.sparse_info(stream)
-            # the sharded engine's pair phase walks EVERY tile of the gathered operand (the sparse-tile path needs the register ids, which
-            # ranks do not exchange): the same job with the single-GPU path held to that algorithm is the base its scaling is read against
+            # the single-GPU path held to the dense walk (D2G_BS_SPARSE=0: every tile) beside the default: the sharded engine's pair phase runs
+            # whichever of the two the engine's gathered operand took (C-ABI engine: sparse tiles from N >= 8192, like a single GPU; the torch
+            # and broadcast rungs: see engine_sparse below), and `speedup` is read against the base that runs the SAME algorithm
             os.environ["D2G_BS_SPARSE"] = "0"
             try:
                 dense = d["ctx"].cmp_set_dev(full.data_ptr(), N, S, algo=algo, stream=stream)
@@ -769,13 +770,22 @@ def run_multi(args):
                 dense.close()
             finally:
                 os.environ.pop("D2G_BS_SPARSE", None)
-            base = {"base_1gpu_same_config_pairs_per_s": pairs_total / ddt, "base_1gpu_ms_per_step": ddt * 1e3,
-                    "best_1gpu_pairs_per_s": pairs_total / bdt, "best_1gpu_ms_per_step": bdt * 1e3, "best_1gpu_sparse": sp,
+            if eng_of:
+                esp = eng_of[0].sparse_info()
+            elif teng is not None:
+                esp = teng.full.sparse_info(stream)
+            else:
+                esp = L[0]["cs"].sparse_info(stream)
+            same = bdt if esp["sorted_operand"] else ddt
+            base = {"base_1gpu_same_config_pairs_per_s": pairs_total / same, "base_1gpu_ms_per_step": same * 1e3,
+                    "base_is": "best_1gpu (sparse tiles on both sides)" if esp["sorted_operand"] else "dense_walk_1gpu (every tile on both sides)",
+                    "dense_walk_1gpu_pairs_per_s": pairs_total / ddt, "dense_walk_1gpu_ms_per_step": ddt * 1e3,
+                    "best_1gpu_pairs_per_s": pairs_total / bdt, "best_1gpu_ms_per_step": bdt * 1e3, "best_1gpu_sparse": sp, "engine_sparse": esp,
                     "note": f"the SAME {N} x {S} job (prepare + compare over the whole triangle, sketches resident in HBM) on GPU 0 alone, mean of {reps} steps, "
-                            "timed in this run before the sharded steps.  base_1gpu_same_config = the single-GPU path walking every tile (D2G_BS_SPARSE=0): the "
-                            "algorithm the sharded engine's pair phase runs, so `speedup` is the scaling of that algorithm; best_1gpu = the single-GPU default "
-                            "(sparse tiles: only tiles with a shared register value are walked) -- on a block-structured matrix like this one a single GPU "
-                            "with it can beat the sharded dense walk; `speedup_vs_best_1gpu` says by how much"}
+                            "timed in this run before the sharded steps: best_1gpu = the single-GPU default (sparse tiles from N >= 8192: only tiles with a "
+                            "shared register value are walked), dense_walk_1gpu = the same with D2G_BS_SPARSE=0 (every tile).  base_1gpu_same_config is the one "
+                            "whose pair phase runs the algorithm rank 0's pair phase ran (engine_sparse); `speedup` is value / that, `speedup_vs_best_1gpu` "
+                            "value / best_1gpu"}
         ref.close()
         del ref, want
         if r not in full_dev:
@@ -844,6 +854,8 @@ def run_multi(args):
         alg_bytes = 8 * S * N + 4 * my_pairs
         achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
         kname = "k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2_direct_kernel"
+        if base is not None and base["engine_sparse"]["sorted_operand"] and not base["engine_sparse"]["dense_kernel_ran"]:
+            kname = "k2 sparse chain (rows + gather + list + fill + k2_bitslice_sparse_kernel over %d listed tiles of rank 0's rows)" % base["engine_sparse"]["tiles_listed"]
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None, "traffic_source": "not measured at N > 1 (the N = 1 line measures the same kernel's traffic in its own run)",
                     "kernel": kname, "kernel_ms": k2_ms, "algorithmic_bytes": alg_bytes, "prep_ms": prep_ms,

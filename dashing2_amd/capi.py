@@ -135,6 +135,7 @@ SIGNATURES = {
     "d2g_allpairs_chunks": (_int, [_vp]),
     "d2g_allpairs_set_phase_timing": (_int, [_vp, _int]),
     "d2g_allpairs_phase_times": (_int, [_vp, _int, C.POINTER(_int), _vp, _vp, _vp, _vp]),
+    "d2g_allpairs_sparse_info": (_int, [_vp, _vp]),
     "d2g_allpairs_step_lut_dev": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "d2g_allpairs_step_eqcount_dev": (_int, [_vp, _vp, _vp, _vp]),
     "d2g_allpairs_step_all": (_int, [C.POINTER(_vp), _int, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
@@ -721,7 +722,7 @@ class CmpSet:
         a = np.zeros(4, np.uint32)
         self.ctx._check(lib().d2g_cmp_set_sparse_info(self.ctx._h, self._h, stream, a.ctypes.data))
         return {"sorted_operand": bool(a[0]), "tiles_listed": int(a[1]), "marking_gave_up": bool(a[2] & 1), "dense_kernel_ran": bool(a[2] & 2),
-                "callers_order_kept": bool(a[3])}
+                "tiles_from_segments": bool(a[2] & 4), "callers_order_kept": bool(a[3])}
 
     def planes(self, stream=None):
         """-> (max shared values per column + 1, max id planes of a group, mean id planes); zeros for DIRECT"""
@@ -891,7 +892,7 @@ class AllPairs:
     def chunks(self):
         return lib().d2g_allpairs_chunks(self._h)
 
-    PHASE_NAMES = ("pack", "x1", "prepare", "x2", "derive", "pair")
+    PHASE_NAMES = ("pack", "x1", "prepare", "x2", "derive", "pair", "order")
 
     def set_phase_timing(self, on=True):
         """bracket every phase of the next prepare/step with timing events (switch off again for timed runs)"""
@@ -907,6 +908,13 @@ class AllPairs:
                                                        start.ctypes.data, dur.ctypes.data))
         return [{"phase": self.PHASE_NAMES[int(kind[i])], "chunk": int(chunk[i]), "start_ms": float(start[i]), "ms": float(dur[i])}
                 for i in range(n.value)]
+
+    def sparse_info(self):
+        """-> dict of the sparse-tile path in this rank's last pair phase (synchronises the device); keys as CmpSet.sparse_info"""
+        a = np.zeros(4, np.uint32)
+        self.ctx._check(lib().d2g_allpairs_sparse_info(self._h, a.ctypes.data))
+        return {"sorted_operand": bool(a[0]), "tiles_listed": int(a[1]), "marking_gave_up": bool(a[2] & 1), "dense_kernel_ran": bool(a[2] & 2),
+                "tiles_from_segments": bool(a[2] & 4), "callers_order_kept": bool(a[3])}
 
     def step_lut_dev(self, rows_ptr, lut_ptr, out_ptr, stream=None):
         self.ctx._check(lib().d2g_allpairs_step_lut_dev(self._h, rows_ptr, lut_ptr, out_ptr, stream))

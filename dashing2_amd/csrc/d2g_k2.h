@@ -42,6 +42,8 @@ struct d2g_cmp_set {
     // shared value (every other pair has 0 matches: the output is pre-filled with the value of 0).  Exact for any input; what the
     // order and the tile list cost is paid back when similarity is block-structured (collections of related genomes).
     bool sparse_ok = false;       // eligible and enabled (D2G_BS_SPARSE, D2G_BS_SPARSE_MIN_N)
+    size_t ncols = 0;             // register columns the sparse path walks: S, or all ntb * 32 register slots of an engine-managed gathered operand
+    bool ids_owned = false;       // engine-managed gathered operands: d_ids / d_colcnt were allocated for the sparse path (ids re-derived from the planes)
     bool srt_valid = false;       // d_stream_s / d_sperm describe the operand last prepared
     bool nat_valid = false;       // d_stream (caller's order; rectangular launches, dense launches) is up to date
     uint32_t *d_stream_s = nullptr;   // plane stream in sorted order
@@ -49,7 +51,6 @@ struct d2g_cmp_set {
     uint32_t *d_sinv = nullptr;       // [Npad]    sorted position of sketch j
     uint32_t *d_label = nullptr;      // [2][Npad] labels (two buffers: pointer jumping)
     uint32_t *d_lcnt = nullptr;       // [Npad+1]  counting sort: sketches per label, then their start positions
-    uint32_t *d_gmin = nullptr;       // [S][SP_GCAP] smallest key among the sketches that hold shared value r of column t
     uint32_t *d_rowpos = nullptr;     // [Nstride] launch rows: sorted position of launch row k
     uint32_t *d_rowk = nullptr;       // [Npad]    launch row of sketch j (0xFFFFFFFF = not a row of this launch)
     uint32_t *d_rowstream = nullptr;  // [planes][Nstride] row-coded words of the launch rows, gathered (partial launches)
@@ -73,6 +74,10 @@ int  d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 void d2g_bitslice_free(d2g_cmp_set *set);
 int  d2g_bitslice_alloc_stream(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_ensure_natural(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s);   // caller's-order stream of a sparse set, on demand
+// engine-managed gathered operands (d2g_mgpu.hip): buffers for the sparse-tile path, and the call that says "every group has arrived and
+// its plane stream is derived": ids are re-derived from the planes, the sketches ordered, the sorted stream written
+int  d2g_bitslice_managed_sparse_alloc(d2g_ctx *ctx, d2g_cmp_set *set);
+int  d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 int  d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint32_t *out4);
 int  d2g_bitslice_status(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s);   // synchronises; D2G_ERR_INTERNAL on overflow
 // exporter set over an N x S_local column slice (no operand of its own); d2g_bitslice_prepare_slice transposes + prepares it

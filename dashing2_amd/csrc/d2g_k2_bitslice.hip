@@ -447,6 +447,7 @@ __global__ __launch_bounds__(BS_PLAN_THREADS) void bs_colplan_kernel(uint32_t *_
 //                                        pointer simply advances by one block per plane (no per-plane address selection).
 // Register slot x of group tb holds column perm[32 tb + x] (bs_colplan_kernel).
 constexpr int BS_FORM_STREAM = 1, BS_FORM_EXCHANGE = 2;
+constexpr size_t BS_SLACK = 64;          // words behind position Npad of every plane (Nstride = Npad + BS_SLACK)
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad,
                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
@@ -490,7 +491,14 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
             sdst[(size_t)(2 * b + 1) * Nstride] = w | u;   // column coding: unique = all ones
         }
     }
-    if (ex) dst[(size_t)nbits_cap * Nstride] = u;
+    // the 64 slack words behind position Npad of a plane are never read as sketches: in the exchanged form the first 32 of the unique
+    // plane's carry D2 of the group's 32 register slots (what the sparse-tile path of a rank that only receives planes sizes its bit
+    // sets with: sp_unpack_kernel)
+    if (ex) {
+        uint32_t uw = u;
+        if (jpos >= Npad && jpos < Npad + 32) { const uint32_t t = perm[tb * 32 + (jpos - Npad)]; uw = t != BS_NOCOL ? colcnt[(size_t)t * BS_CC_STRIDE + 4] : 0u; }
+        dst[(size_t)nbits_cap * Nstride] = uw;
+    }
 }
 
 // plane stream of an operand that arrived in the exchanged form (the gathered operand of the multi-GPU path,
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(256) void bs_derive_kernel(const uint32_t *__restri
     const int nbits = live_planes(meta, (int)tb);
     const uint32_t *src = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
     uint32_t *sdst = stream + stream_slot(meta, (int)tb) * 2 * Nstride + j;
-    const uint32_t u = src[(size_t)nbits_cap * Nstride];
+    const uint32_t u = j + BS_SLACK < Nstride ? src[(size_t)nbits_cap * Nstride] : 0u;     // the slack words of the unique plane carry D2 per slot, not sketches
     for (int b = 0; b < nbits; ++b) {
         const uint32_t w = src[(size_t)b * Nstride];
         sdst[(size_t)(2 * b) * Nstride] = w;
@@ -705,8 +713,6 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
 // only decides how FEW tiles get marked.  If one label would take more than half of the sketches (everything is connected) the
 // caller's order is kept.  Rows of a partial launch [r0, r1) are gathered (in sorted order) into a row operand of their own.
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
-constexpr int SP_GCAP = 1024;                   // shared values per column that take part in the labelling
-constexpr int SP_LABEL_TSPLIT = 32;
 #ifndef D2G_SP_WIDE_U
 #define D2G_SP_WIDE_U 8          // sketches per thread and step of the wide mark kernel (measured at N = 50 000: 8 -> 532 us, 16 -> 856 us)
 #endif
@@ -725,60 +731,102 @@ __device__ __forceinline__ uint32_t sp_rank(uint32_t w, const uint32_t *__restri
     return split ? (w & BS_RANK_MASK) + colcnt[t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)] : w;
 }
 
-__global__ __launch_bounds__(256) void sp_init_kernel(uint32_t *__restrict__ label, size_t N, uint32_t *__restrict__ cnt) {
+__global__ __launch_bounds__(256) void sp_init_kernel(uint32_t *__restrict__ label, size_t N, uint32_t *__restrict__ cnt, uint32_t *__restrict__ order, uint32_t inexact) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j == 0) order[1] = inexact;
     if (j < N) { label[j] = (uint32_t)j; cnt[j] = 0; }
 }
 
-// gmin[t][r-1] = min over the holders j of shared value r of column t of key[j]
-__global__ __launch_bounds__(256) void sp_gmin_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt,
-                                                      int split, const uint32_t *__restrict__ key, uint32_t *__restrict__ gmin) {
-    __shared__ uint32_t g[SP_GCAP];
-    const size_t t = blockIdx.x;
-    for (int r = threadIdx.x; r < SP_GCAP; r += 256) g[r] = SP_NONE;
-    __syncthreads();
-    const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
-    if (d2) {
-        for (size_t j0 = 0; j0 < N; j0 += 2048) {           // eight sketches per thread in flight
+__device__ __forceinline__ uint32_t sp_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Label propagation, one workgroup walking SEVERAL columns one after the other: per column, the smallest LIVE label among the holders of
+// each shared value (LDS), then every holder takes it.  The columns a workgroup walks later see what all workgroups wrote before, so one
+// launch does the work of several synchronous rounds: a family whose first member shares registers with only some of the others is under
+// one root after it, where one synchronous round (min over frozen labels, then a gather per sketch: rounds 1-3 of this file) left two.
+// Labels are written with PLAIN stores: a label is only ever replaced by a smaller index of the same family (v <= the holder's own label
+// <= its index), so whichever of two racing stores lands last -- or whichever XCD's L2 writes its copy of the line back last -- the array
+// still holds, per sketch, a member of its family that is no later than itself: all the sort needs (it hops to the root), and the tiles
+// are checked (sp_check_kernel) or marked exactly afterwards whatever the order.  (atomicMin instead: every column moves every holder's
+// label through a device-scope atomic on one 40 KB array: 46 us instead of 17 at config 3.)
+__global__ __launch_bounds__(1024) void sp_prop_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt,
+                                                       int split, uint32_t cap, uint32_t *__restrict__ label) {
+    extern __shared__ uint32_t sp_g[];
+    const uint32_t T = blockDim.x;
+    for (size_t t = blockIdx.x; t < ncols; t += gridDim.x) {
+        const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
+        if (d2 == 0) continue;
+        const uint32_t nv = min(d2, cap);                              // values beyond the table take no part (the order is a heuristic; exactness is checked later)
+        for (uint32_t r = threadIdx.x; r < nv; r += T) sp_g[r] = SP_NONE;
+        __syncthreads();
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
             uint32_t w[8], kk[8];
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
-                const size_t j = j0 + (size_t)x * 256 + threadIdx.x;
+                const size_t j = j0 + (size_t)x * T + threadIdx.x;
                 w[x] = j < N ? ids[t * Npad + j] : 0u;
-                kk[x] = j < N ? key[j] : SP_NONE;
+                kk[x] = j < N ? sp_ld(&label[j]) : SP_NONE;
             }
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
                 const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
-                if (r && r <= SP_GCAP) atomicMin(&g[r - 1], kk[x]);
+                if (r && r <= nv) atomicMin(&sp_g[r - 1], kk[x]);
             }
         }
+        __syncthreads();
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
+            uint32_t w[8], kk[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const size_t j = j0 + (size_t)x * T + threadIdx.x;
+                w[x] = j < N ? ids[t * Npad + j] : 0u;
+                kk[x] = j < N ? sp_ld(&label[j]) : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
+                if (!r || r > nv) continue;
+                const uint32_t v = sp_g[r - 1];
+                if (v < kk[x]) label[j0 + (size_t)x * T + threadIdx.x] = v;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int r = threadIdx.x; r < SP_GCAP; r += 256) gmin[t * SP_GCAP + r] = g[r];
 }
 
-__global__ __launch_bounds__(256) void sp_label_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, size_t S, const uint32_t *__restrict__ colcnt,
-                                                       int split, const uint32_t *__restrict__ gmin, uint32_t *__restrict__ label) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    const size_t t0 = S * blockIdx.y / SP_LABEL_TSPLIT, t1 = S * (blockIdx.y + 1) / SP_LABEL_TSPLIT;
-    uint32_t lab = SP_NONE;
-    size_t t = t0;
-    for (; t + 4 <= t1; t += 4) {                   // four columns in flight: the loop is bound by the latency of its two dependent loads
-        uint32_t w[4], r[4];
+// the same for N <= 1024 U sketches: a thread keeps its U ids and labels of a column in registers between the two passes (one round of
+// loads per column instead of two times ceil(N / 8192))
+template <int U>
+__global__ __launch_bounds__(1024) void sp_prop_reg_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt,
+                                                           int split, uint32_t cap, uint32_t *__restrict__ label) {
+    extern __shared__ uint32_t sp_g[];
+    for (size_t t = blockIdx.x; t < ncols; t += gridDim.x) {
+        const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
+        if (d2 == 0) continue;
+        const uint32_t nv = min(d2, cap);
+        uint32_t w[U], kk[U];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) w[x] = ids[(t + x) * Npad + j];
+        for (int x = 0; x < U; ++x) {
+            const size_t j = (size_t)x * 1024 + threadIdx.x;
+            w[x] = j < N ? ids[t * Npad + j] : 0u;
+            kk[x] = j < N ? sp_ld(&label[j]) : SP_NONE;
+        }
+        for (uint32_t r = threadIdx.x; r < nv; r += 1024) sp_g[r] = SP_NONE;
+        __syncthreads();
 #pragma unroll
-        for (int x = 0; x < 4; ++x) r[x] = sp_rank(w[x], colcnt, t + x, split != 0);
+        for (int x = 0; x < U; ++x) {
+            w[x] = sp_rank(w[x], colcnt, t, split != 0);
+            if (w[x] > nv) w[x] = 0;
+            if (w[x]) atomicMin(&sp_g[w[x] - 1], kk[x]);
+        }
+        __syncthreads();
 #pragma unroll
-        for (int x = 0; x < 4; ++x) if (r[x] && r[x] <= SP_GCAP) lab = min(lab, gmin[(t + x) * SP_GCAP + r[x] - 1]);
+        for (int x = 0; x < U; ++x) {
+            if (!w[x]) continue;
+            const uint32_t v = sp_g[w[x] - 1];
+            if (v < kk[x]) label[(size_t)x * 1024 + threadIdx.x] = v;
+        }
+        __syncthreads();
     }
-    for (; t < t1; ++t) {
-        const uint32_t r = sp_rank(ids[t * Npad + j], colcnt, t, split != 0);
-        if (r && r <= SP_GCAP) lab = min(lab, gmin[t * SP_GCAP + r - 1]);
-    }
-    if (lab != SP_NONE) atomicMin(&label[j], lab);
 }
 
 __global__ __launch_bounds__(256) void sp_jump_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t N) {
@@ -786,13 +834,13 @@ __global__ __launch_bounds__(256) void sp_jump_kernel(const uint32_t *__restrict
     if (j < N) out[j] = in[in[j]];
 }
 
-// pointer jumping: label[] maps a sketch to the smallest sketch it shares a value with; four hops reach the root of most chains
+// label[] maps a sketch to an earlier (or the same) sketch of its family; the root is where that stops.  Most chains end after one or two
+// hops; the propagation's racing stores and the union pass's hooks can leave longer ones
 __device__ __forceinline__ uint32_t sp_root(const uint32_t *__restrict__ label, size_t j) {
     uint32_t l = label[j];
-    l = label[l]; l = label[l]; l = label[l];
+    for (;;) { const uint32_t n = label[l]; if (n == l) break; l = n; }  // label[l] < l off the root: ends.  The TRUE root, always: the segments are exact only then
     return l;
 }
-__device__ __forceinline__ uint32_t sp_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, *total = the sum
 __device__ __forceinline__ uint32_t sp_block_scan(uint32_t v, uint32_t *wave_tot, uint32_t *total) {
@@ -827,13 +875,14 @@ __global__ __launch_bounds__(256) void sp_count_kernel(const uint32_t *__restric
     if (live && r == lead) { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[lead], (uint32_t)__popcll(m)); }
     else if (live) atomicAdd(&cnt[r], 1u);
 }
-__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order) {
+__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t seg_tile_limit) {
     // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t tile[8192];
-    __shared__ uint32_t s_big, s_run;
+    __shared__ uint32_t s_big, s_run, s_est;
     const int tid = threadIdx.x;
-    if (tid == 0) { s_big = 0; s_run = 0; }
+    if (tid == 0) { s_big = 0; s_run = 0; s_est = 0; }
+    uint32_t est = 0;                                                  // tiles the segments would cover (both triangles), saturating
     __syncthreads();
     for (size_t base = 0; base < N; base += 8192) {
         const uint32_t n = (uint32_t)min((size_t)8192, N - base);
@@ -841,18 +890,29 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
         __syncthreads();
         uint32_t v[8], sum = 0, big = 0;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) { v[x] = tile[tid * 8 + x]; sum += v[x]; big = max(big, v[x]); }
+        for (int x = 0; x < 8; ++x) {
+            v[x] = tile[tid * 8 + x]; sum += v[x]; big = max(big, v[x]);
+            // in sixteenths of a tile: a segment of c >= 32 sketches covers at most (rows + 1) x (columns + 1) tiles; smaller ones share their
+            // row block with their neighbours (two column tiles for c / 32 of a row block)
+            const uint32_t c = min(v[x], 32768u);                    // (a segment that long is past any limit by itself)
+            est += c >= 32 ? 16u * ((c + 31) / 32 + 1) * ((c + 255) / 256 + 1) : (c >= 2 ? c : 0u);
+        }
+        est = min(est, 0x0FFFFFFFu);
         if ((size_t)big * 2 > N) s_big = 1;
         uint32_t total;
         uint32_t run = sp_block_scan(sum, wave_tot, &total) + s_run;
 #pragma unroll
         for (int x = 0; x < 8; ++x) { tile[tid * 8 + x] = run; run += v[x]; }
         __syncthreads();
-        for (uint32_t x = tid; x < n; x += 1024) cnt[base + x] = tile[x];
+        for (uint32_t x = tid; x < n; x += 1024) { cnt[base + x] = tile[x]; start[base + x] = tile[x]; }   // cnt becomes the placing cursor (-> segment end), start stays
         if (tid == 0) s_run += total;
         __syncthreads();
     }
-    if (tid == 0) order[0] = s_big;
+    est = min(est, 0x3FFFFFu) / 16 + 1;                                 // 1024 threads x 2^18: no overflow
+    for (int o = 32; o > 0; o >>= 1) est += __shfl_down(est, o);
+    if ((tid & 63) == 0) atomicAdd(&s_est, est);
+    __syncthreads();
+    if (tid == 0) { order[0] = s_big; if (s_big || s_est > seg_tile_limit + 1024) order[1] = 1; }
 }
 __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
                                                         uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order) {
@@ -931,6 +991,21 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restri
     rowstream[q * rstride + k] = p != SP_NONE ? stream[2 * q * Nstride + p] : 0u;
 }
 
+// sorted position p: the first position of (its segment x its row block) sets the tiles of that row block against the segment's column blocks
+__device__ __forceinline__ void sp_segtiles(size_t p, const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ root, const uint32_t *__restrict__ start,
+                                            const uint32_t *__restrict__ end, size_t N, uint32_t CW, uint32_t *__restrict__ gbm) {
+    if (p >= N) return;
+    const uint32_t r = root[sperm[p]];
+    const uint32_t a = start[r], b = end[r];
+    if (b - a < 2 || !(p == a || (p & 31) == 0)) return;              // a sketch alone under its root shares nothing with anybody
+    const uint32_t rb = (uint32_t)(p >> 5), cb0 = a >> 8, cb1 = (b - 1) >> 8;
+    for (uint32_t cw = cb0 >> 5; cw <= cb1 >> 5; ++cw) {
+        const uint32_t lo = cw == (cb0 >> 5) ? (cb0 & 31) : 0u, hi = cw == (cb1 >> 5) ? (cb1 & 31) : 31u;
+        const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+        atomicOr(&gbm[(size_t)rb * CW + cw], m);
+    }
+}
+
 // Per register column: every shared value marks the tiles its holders meet in.  LDS: for `gm` values at a time, a bit set of the
 // launch-row blocks (32 rows) and one of the column blocks (256 sorted positions) the value occurs in.  A value whose holders
 // meet in more than a quarter of all tiles says the matrix is not sparse: it raises the ALL flag (ctl[1] bit 0) and marking stops.
@@ -941,7 +1016,8 @@ template <int U>
 __global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
                                                       const uint32_t *__restrict__ sinv, const uint32_t *__restrict__ rowk, uint32_t gm, uint32_t RW, uint32_t CW,
                                                       uint32_t nrb, uint32_t ncb, uint32_t lbm_words, uint32_t *__restrict__ slots, uint32_t *__restrict__ ctl,
-                                                      const uint32_t *__restrict__ order_kept) {
+                                                      const uint32_t *__restrict__ order_kept, const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ root,
+                                                      const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, uint32_t *__restrict__ segbm) {
     extern __shared__ uint32_t sp_lds_all[];
     __shared__ uint32_t s_stop;
     // lbm_words != 0: the column's bitmap is built in LDS and stored once; otherwise (large N) it is built in the slot with atomics
@@ -951,6 +1027,11 @@ __global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict
     const uint32_t T = blockDim.x;                                    // 256, or 512 with a bigger share of the LDS (large N)
     const uint32_t words = nrb * CW;
     uint32_t *slot = slots + t * (size_t)words;
+    if (!order_kept[1]) {                                             // the sort's segments give the tiles (sp_union_kernel): no marking, the grid's threads
+        if (segbm)                                                    // share the sorted positions instead
+            for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (size_t)gridDim.x * blockDim.x) sp_segtiles(p, sperm, root, seg_start, seg_end, N, CW, segbm);
+        return;
+    }
     const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
     // one family holds most sketches (the prepare kept the caller's order), or this column's shared values have fewer than four holders
     // on average (pairs, not families), or it would take more than 32 passes of bit sets: not a matrix the tile list can help
@@ -1064,12 +1145,75 @@ __global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict
     for (uint32_t x = threadIdx.x; x < lbm_words; x += T) slot[x] = lbm[x];
 }
 
+// ---- tiles from the sort's segments.  After the propagation, ONE pass over every column unites whatever roots the holders of one shared
+// value still sit under (lock-free union-find on the label array: a root is hooked under a smaller one with a compare-and-swap; a pass
+// over every "edge" of the shares-a-value graph leaves exactly its connected components, no iteration).  The sort then puts every
+// component's sketches side by side, every pair with a shared value lies inside one segment, and the tiles a segment's rows and columns
+// meet in are a superset of the tiles that hold such a pair -- without the marking pass and its two bit sets per value (config 3:
+// 29 + 5 us -> 12 + 5; config 4: 531 + 9 -> 63 + 5).  The propagation has done nearly all the uniting with plain stores; this pass mostly
+// confirms (few compare-and-swaps).  order[1] != 0 ("inexact": a column has more shared values than the LDS table holds, the caller's
+// order was kept, or the segments would cover more than an eighth of all tiles -- components that are large but sparse inside, where
+// exact marks list far fewer tiles) sends the launches to the exact marking instead.
+__device__ __forceinline__ uint32_t sp_find(uint32_t *label, uint32_t l) {
+    for (int h = 0; h < 64; ++h) { const uint32_t n = sp_ld(&label[l]); if (n == l) break; l = n; }
+    return l;
+}
+__device__ __forceinline__ bool sp_union(uint32_t *label, uint32_t a, uint32_t b) {
+    for (int it = 0; it < 64; ++it) {
+        a = sp_find(label, a); b = sp_find(label, b);
+        if (a == b) return true;
+        if (a < b) { const uint32_t x = a; a = b; b = x; }              // the larger root goes under the smaller one
+        if (atomicCAS(&label[a], a, b) == a) return true;               // a was still a root: hooked
+    }
+    return false;
+}
+// every label straight at its root before the union pass compares labels (racing with itself is harmless: a label is only ever replaced
+// by an ancestor)
+__global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t N) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    uint32_t l = sp_ld(&label[j]);
+    for (;;) { const uint32_t n = sp_ld(&label[l]); if (n == l) break; l = n; }
+    label[j] = l;
+}
+__global__ void sp_union_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
+                                uint32_t *label, uint32_t cap, uint32_t *__restrict__ order) {
+    extern __shared__ uint32_t sp_chk[];
+    const size_t t = blockIdx.x;
+    const uint32_t T = blockDim.x;
+    const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
+    if (d2 == 0) return;
+    if (d2 > cap) { if (threadIdx.x == 0) atomicOr(&order[1], 1u); return; }
+    for (uint32_t r = threadIdx.x; r < d2; r += T) sp_chk[r] = SP_NONE;
+    __syncthreads();
+    bool bad = false;
+    for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
+        uint32_t w[8], rt[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const size_t j = j0 + (size_t)x * T + threadIdx.x;
+            w[x] = j < N ? ids[t * Npad + j] : 0u;
+            rt[x] = j < N ? sp_ld(&label[j]) : 0u;
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
+            if (!r) continue;
+            // the value's first holder leaves its label; a holder with the same label is under the same root without looking (the usual
+            // case after the propagation); only a different label costs the walk to the roots
+            const uint32_t old = atomicCAS(&sp_chk[r - 1], SP_NONE, rt[x]);
+            if (old != SP_NONE && old != rt[x]) bad |= !sp_union(label, old, rt[x]);
+        }
+    }
+    if (bad) atomicOr(&order[1], 1u);
+}
+
 // tile bitmap = OR over the columns' copies.  grid (words / 256, SP_OR_SPLIT): a thread folds S / SP_OR_SPLIT copies of one word.
 constexpr int SP_OR_SPLIT = 32;
 __global__ __launch_bounds__(256) void sp_or_kernel(const uint32_t *__restrict__ slots, uint32_t words, uint32_t S, uint32_t *__restrict__ tilebm,
-                                                    const uint32_t *__restrict__ ctl) {
+                                                    const uint32_t *__restrict__ ctl, const uint32_t *__restrict__ order) {
     const uint32_t x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= words || (ctl[1] & 1u)) return;
+    if (x >= words || (ctl[1] & 1u) || !order[1]) return;
     const uint32_t t0 = (uint32_t)((size_t)S * blockIdx.y / SP_OR_SPLIT), t1 = (uint32_t)((size_t)S * (blockIdx.y + 1) / SP_OR_SPLIT);
     uint32_t acc = 0;
     uint32_t t = t0;
@@ -1311,14 +1455,13 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMalloc((void **)&set->d_sinv, Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_label, 2 * Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_lcnt, (Npad + 1) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_gmin, set->S * SP_GCAP * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_spctl, (8 + set->tilebm_words) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_gbm, (8 + set->tilebm_words) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_slots, set->S * set->tilebm_words * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_slots, set->ncols * set->tilebm_words * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_tiles, std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_order, 4)) != hipSuccess) {
+        (e = hipMalloc((void **)&set->d_order, 16)) != hipSuccess) {
         ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
@@ -1327,32 +1470,78 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 }
 
 void sp_free(d2g_cmp_set *set) {
-    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_lcnt, &set->d_gmin, &set->d_rowpos, &set->d_rowk,
+    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_lcnt, &set->d_rowpos, &set->d_rowk,
                          &set->d_rowstream, &set->d_slots, &set->d_tiles, &set->d_spctl, &set->d_gbm, &set->d_order}) { (void)hipFree(*p); *p = nullptr; }
     set->d_tilebm = nullptr;
 }
 
 // labels -> counting sort -> d_sperm / d_sinv.  All on `s`, no host round trip.
 int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
-    const size_t N = set->N, Npad = set->Npad, S = set->S;
+    const size_t N = set->N, Npad = set->Npad, S = set->ncols;
     const unsigned nb = (unsigned)div_up<size_t>(N, 256);
     int rounds = 1;
     if (const char *e = std::getenv("D2G_BS_LABEL_ROUNDS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) rounds = v; }
     uint32_t *la = set->d_label, *lb = set->d_label + Npad;
-    hipLaunchKernelGGL(sp_init_kernel, dim3(std::max(nb, 1u)), dim3(256), 0, s, la, N, set->d_lcnt);
+    const char *se = std::getenv("D2G_SP_SEGMENTS");                     // "0": always the exact marking (experiments, tests)
+    const bool segs = !(se && se[0] == '0');
+    hipLaunchKernelGGL(sp_init_kernel, dim3(std::max(nb, 1u)), dim3(256), 0, s, la, N, set->d_lcnt, set->d_order, (segs && rounds > 0) ? 0u : 1u);
+    int gens = 4;                                                        // columns a workgroup walks one after the other
+    if (const char *e = std::getenv("D2G_SP_PROP_GENS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) gens = v; }
+    const uint32_t pcap = (uint32_t)std::min<size_t>(N / 2 + 1, 16384);
+    auto propk = N <= 4096 ? sp_prop_reg_kernel<4> : N <= 10240 ? sp_prop_reg_kernel<10> : N <= 16384 ? sp_prop_reg_kernel<16> : sp_prop_kernel;
+    D2G_HIP(ctx, hipFuncSetAttribute((const void *)propk, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
     for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(sp_gmin_kernel, dim3((unsigned)S), dim3(256), 0, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, la, set->d_gmin);
-        hipLaunchKernelGGL(sp_label_kernel, dim3(nb, SP_LABEL_TSPLIT), dim3(256), 0, s, set->d_ids, N, Npad, S, set->d_colcnt, split ? 1 : 0, set->d_gmin, la);
+        hipLaunchKernelGGL(propk, dim3((unsigned)std::max<size_t>(1, div_up<size_t>(S, (size_t)gens))), dim3(1024), (size_t)pcap * 4, s, set->d_ids, N, Npad, (uint32_t)S,
+                           set->d_colcnt, split ? 1 : 0, pcap, la);
         if (r + 1 < rounds) {                          // more rounds: the next one starts from the roots (the sort kernel hops by itself)
             hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, la, lb, N);
             hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, lb, la, N);
         }
     }
+    if (segs && rounds > 0) {
+        const uint32_t cap = (uint32_t)std::min<size_t>(N / 2 + 1, 36864);               // shared values of a column: at most N / 2; 144 KB of LDS at most
+        const unsigned cthreads = cap > 10240 ? 1024 : 256;                              // a big table leaves one workgroup per CU: a wide one
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_union_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
+        hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
+        hipLaunchKernelGGL(sp_union_kernel, dim3((unsigned)S), dim3(cthreads), (size_t)cap * 4, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, la, cap, set->d_order);
+    }
+    const size_t ntile_all = (Npad / 32) * (Npad / BS_CB);
+    size_t seg_div = 8;                                                  // segments may cover an eighth of all tiles; beyond, exact marks are worth their pass
+    if (const char *e = std::getenv("D2G_SP_SEG_DIV")) { const long v = std::atol(e); if (v >= 1 && v <= 1024) seg_div = (size_t)v; }
+    const uint32_t seg_limit = (uint32_t)std::min<size_t>(ntile_all / seg_div, 0x3FFFFFFF);
     hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt);
-    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order);
+    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, seg_limit);    // la (labels) is dead after the count kernel: it keeps the segment starts
     hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
+}
+
+// ids of an operand that arrived as bit planes (the multi-GPU engine's gathered operand: ranks exchange planes, not ids): the inverse
+// of bs_planes_kernel's bit transpose.  Every register SLOT of the operand is a column here (slot 32 tb + x = whatever column the
+// preparing rank's plan put there; padding slots hold id 0 everywhere).  colcnt[slot][4] = the number of the slot's shared values
+// (carried by the slack words of the group's unique plane: bs_planes_kernel).
+__global__ __launch_bounds__(256) void sp_unpack_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta,
+                                                        size_t N, size_t Npad, uint32_t *__restrict__ ids, uint32_t *__restrict__ colcnt) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;          // < Npad: the grid covers Npad exactly
+    const size_t tb = blockIdx.y;
+    const int nbits = live_planes(meta, (int)tb);
+    const uint32_t *src = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
+    if (j < 32) colcnt[(tb * 32 + j) * BS_CC_STRIDE + 4] = planes[tb * (size_t)(nbits_cap + 1) * Nstride + (size_t)nbits_cap * Nstride + Npad + j];
+    uint32_t id[32];
+#pragma unroll
+    for (int x = 0; x < 32; ++x) id[x] = 0;
+    if (j < N) {
+        for (int b = 0; b < nbits; ++b) {
+            const uint32_t w = src[(size_t)b * Nstride];
+#pragma unroll
+            for (int x = 0; x < 32; ++x) id[x] |= ((w >> x) & 1u) << b;
+        }
+        const uint32_t u = src[(size_t)nbits_cap * Nstride];
+#pragma unroll
+        for (int x = 0; x < 32; ++x) if ((u >> x) & 1u) id[x] = BS_UNIQ;
+    }
+#pragma unroll
+    for (int x = 0; x < 32; ++x) ids[(tb * 32 + x) * Npad + j] = id[x];
 }
 
 template <class Store>
@@ -1363,7 +1552,7 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     const bool full = r0 == 0 && r1 == N;
     const size_t nrows = r1 - r0, nrows_pad = full ? Npad : div_up<size_t>(nrows, 32) * 32;
     const uint32_t nrb = (uint32_t)(nrows_pad / 32), ncb = (uint32_t)(Npad / BS_CB);
-    const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
+    const bool split = !set->borrowed && set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
     const size_t cnt = d2g_ut_count(N, r0, r1);
     if (!cnt) return D2G_OK;
     if (!full && !set->d_rowstream)
@@ -1388,12 +1577,15 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
         const uint32_t budget = wide ? 19456u : 9216u;
         const uint32_t gm = std::max(1u, std::min(2048u, (budget - lbm_words) / W));
         const size_t lds = ((size_t)gm * W + lbm_words) * 4;
+        // order[1] == 0 (the prepare united every shared value's holders: the sort's segments are the families): the mark kernel's threads set the
+        // segments' tiles and the folding kernel returns at once
         auto mark = wide ? sp_mark_kernel<D2G_SP_WIDE_U> : sp_mark_kernel<8>;
         D2G_HIP(ctx, hipFuncSetAttribute((const void *)mark, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        hipLaunchKernelGGL(mark, dim3((unsigned)set->S), dim3(wide ? 512 : 256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
-                           (const uint32_t *)nullptr, gm, RW, CW, nrbG, ncb, lbm_words, set->d_slots, set->d_gbm, set->d_order);
-        hipLaunchKernelGGL(sp_or_kernel, dim3((unsigned)div_up<size_t>((size_t)nrbG * CW, 256), SP_OR_SPLIT), dim3(256), 0, s, set->d_slots, nrbG * CW, (uint32_t)set->S,
-                           set->d_gbm + 8, set->d_gbm);
+        hipLaunchKernelGGL(mark, dim3((unsigned)set->ncols), dim3(wide ? 512 : 256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
+                           (const uint32_t *)nullptr, gm, RW, CW, nrbG, ncb, lbm_words, set->d_slots, set->d_gbm, set->d_order, set->d_sperm, set->d_label + Npad, set->d_label,
+                           set->d_lcnt, set->d_gbm + 8);
+        hipLaunchKernelGGL(sp_or_kernel, dim3((unsigned)div_up<size_t>((size_t)nrbG * CW, 256), SP_OR_SPLIT), dim3(256), 0, s, set->d_slots, nrbG * CW, (uint32_t)set->ncols,
+                           set->d_gbm + 8, set->d_gbm, set->d_order);
         set->gbm_valid = true;
     }
     // per launch: 8 control words (ctl[0] = tiles listed, ctl[1] = flags (bit 0 ALL: marking gave up), [3] = candidates) + a partial launch's bitmap
@@ -1459,7 +1651,7 @@ void d2g_bitslice_geometry(d2g_cmp_set *set) {
     set->nbits_cap = 1;
     while ((1ull << set->nbits_cap) < set->N / 2 + 2) ++set->nbits_cap;
     set->ntb = (int)div_up<size_t>(set->S, 32);
-    set->Nstride = set->Npad + 64;
+    set->Nstride = set->Npad + BS_SLACK;
 }
 
 // the plane stream: at most nbits_cap live planes per group, two codings each, + one block of slack (the
@@ -1523,6 +1715,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
     if (int rc = d2g_bitslice_alloc_stream(ctx, set)) { d2g_bitslice_free(set); return rc; }
+    set->ncols = set->S;
     set->sparse_ok = sparse_enabled(set->N) && set->S < 65536 && set->S * (set->Npad / 32) * ((set->Npad / BS_CB + 31) / 32) * 4 <= ((size_t)1 << 30);   // the columns' tile bitmaps: <= 1 GiB
     if (set->sparse_ok) if (int rc = sp_alloc(ctx, set)) { d2g_bitslice_free(set); return rc; }
     return D2G_OK;
@@ -1658,7 +1851,7 @@ int d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, 
                     float *fout, hipStream_t s) {
     PairShape sh{};
     sh.N = set->N; sh.i_lo = r0; sh.i_hi = r1; sh.j_lo = r0 + 1 < set->N ? r0 + 1 : set->N; sh.j_hi = set->N; sh.ut = 1;
-    if (set->srt_valid && !set->borrowed) {
+    if (set->srt_valid) {
         if (eq_out) return launch_sparse(ctx, set, sh, StoreEq{eq_out}, eq_out, s);
         return launch_sparse(ctx, set, sh, StoreLut{fout, lut}, reinterpret_cast<uint32_t *>(fout), s);
     }
@@ -1673,16 +1866,48 @@ int d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1
     return launch_bitslice(ctx, set, sh, StoreEq{eq_out}, s);
 }
 
+// ---- sparse tiles on the multi-GPU engine's gathered operand (replicated: every rank orders and marks the whole operand itself --
+// the pair phase of a block-structured matrix shrinks by the fraction of tiles listed, the fixed costs stay per rank)
+int d2g_bitslice_managed_sparse_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
+    if (!set->borrowed || set->sparse_ok) return D2G_OK;
+    set->ncols = (size_t)set->ntb * 32;
+    if (!(sparse_enabled(set->N) && set->S < 65536 && set->ncols * (set->Npad / 32) * ((set->Npad / BS_CB + 31) / 32) * 4 <= ((size_t)1 << 30))) return D2G_OK;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&set->d_ids, set->ncols * set->Npad * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_colcnt, set->ncols * BS_CC_STRIDE * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMemset(set->d_colcnt, 0, set->ncols * BS_CC_STRIDE * sizeof(uint32_t))) != hipSuccess) {
+        ctx->last_error = std::string("bitslice sparse alloc (gathered operand): ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
+    }
+    set->ids_owned = true;
+    if (int rc = sp_alloc(ctx, set)) return rc;
+    set->sparse_ok = true;
+    return D2G_OK;
+}
+
+int d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
+    if (!set->borrowed || !set->sparse_ok) return D2G_OK;
+    dim3 grid((unsigned)div_up<size_t>(set->Npad, 256), (unsigned)set->ntb);
+    hipLaunchKernelGGL(sp_unpack_kernel, grid, dim3(256), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->N, set->Npad, set->d_ids, set->d_colcnt);
+    if (int rc = sp_prepare_order(ctx, set, false, s)) return rc;
+    dim3 pgrid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
+    hipLaunchKernelGGL(sp_permute_kernel, pgrid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm);
+    D2G_HIP(ctx, hipGetLastError());
+    set->srt_valid = true; set->gbm_valid = false;
+    return D2G_OK;
+}
+
 // diagnostics of the sparse path's LAST launch on this set (synchronises `s`): see d2g.h
 int d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint32_t *out4) {
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
     if (!set->srt_valid || !set->d_spctl) { D2G_HIP(ctx, hipStreamSynchronize(s)); return D2G_OK; }
-    uint32_t c[4] = {0, 0, 0, 0}, kept = 0;
+    uint32_t c[4] = {0, 0, 0, 0}, ord[2] = {0, 1}, g[4] = {0, 0, 0, 0};
     D2G_HIP(ctx, hipMemcpyAsync(c, set->d_spctl, sizeof c, hipMemcpyDeviceToHost, s));
-    D2G_HIP(ctx, hipMemcpyAsync(&kept, set->d_order, sizeof kept, hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipMemcpyAsync(ord, set->d_order, sizeof ord, hipMemcpyDeviceToHost, s));
     D2G_HIP(ctx, hipStreamSynchronize(s));
-    c[2] = kept;
-    out4[0] = 1; out4[1] = c[0]; out4[2] = (c[1] & 1u) | (((c[1] & 1u) || (size_t)c[0] * 5 > (size_t)c[3] * 2) ? 2u : 0u); out4[3] = c[2];
+    c[2] = ord[0]; g[2] = ord[1] ? 1u : 0u;
+    // [2]: bit 0 marking gave up, bit 1 the dense kernel ran, bit 2 the tiles came from the sort's segments (no marking pass)
+    out4[0] = 1; out4[1] = c[0]; out4[2] = (c[1] & 1u) | (((c[1] & 1u) || (size_t)c[0] * 5 > (size_t)c[3] * 2) ? 2u : 0u) | ((g[2] & 1u) ? 0u : 4u); out4[3] = c[2];
     return D2G_OK;
 }
 

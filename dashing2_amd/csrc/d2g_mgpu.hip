@@ -262,7 +262,7 @@ int eng_alloc_buffer(d2g_allpairs *e, int b) {
     e->full[b]->managed = true;                                             // the engine derives the plane stream, chunk by chunk
     e->full[b]->status_words = e->d_meta[b] + e->ng;
     e->full[b]->n_status = (int)nstat;
-    return D2G_OK;
+    return d2g_bitslice_managed_sparse_alloc(ctx, e->full[b]);      // N >= 8192: buffers of the sparse-tile path (ids, order, tile bitmaps)
 }
 
 // phase timing: begin/end bracket a phase's enqueue on stream s (no-ops unless enabled)
@@ -405,6 +405,14 @@ int prepare_many(d2g_allpairs **es, int n, const uint64_t *const *rows, const in
             MG_TRY(d2g_bitslice_derive_groups(e->ctx, e->full[bufs[i]], (int)e->chunk_g0[c], (int)e->chunk_g0[c + 1], cs[i]));
             MG_TRY(pt_end(e, D2G_PHASE_DERIVE, c, cs[i]));
         }
+    for (int i = 0; i < n; ++i) {                                       // every group is here: the operand ordered for the sparse-tile pair phase
+        d2g_allpairs *e = es[i];
+        if (!e->full[bufs[i]]->sparse_ok) continue;
+        D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+        MG_TRY(pt_begin(e, D2G_PHASE_ORDER, 0, cs[i]));
+        MG_TRY(d2g_bitslice_managed_ready(e->ctx, e->full[bufs[i]], cs[i]));
+        MG_TRY(pt_end(e, D2G_PHASE_ORDER, 0, cs[i]));
+    }
     for (int i = 0; i < n; ++i) es[i]->last = bufs[i];
     return D2G_OK;
 }
@@ -731,6 +739,15 @@ int d2g_allpairs_phase_times(d2g_allpairs *e, int cap, int *n_out, int *kind, in
     }
     *n_out = n;
     return D2G_OK;
+}
+
+int d2g_allpairs_sparse_info(d2g_allpairs *e, uint32_t *info4) {
+    if (!e || !info4) return D2G_ERR_INVALID;
+    info4[0] = info4[1] = info4[2] = info4[3] = 0;
+    D2G_HIP(e->ctx, hipSetDevice(e->ctx->device));
+    D2G_HIP(e->ctx, hipDeviceSynchronize());
+    if (e->last < 0 || !e->full[e->last]) return D2G_OK;
+    return d2g_bitslice_sparse_info(e->ctx, e->full[e->last], nullptr, info4);
 }
 
 int d2g_allpairs_prepare_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, void *const *streams) {

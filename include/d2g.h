@@ -331,7 +331,8 @@ int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsi
  * with a shared value, after pre-filling the output with the value of "0 equal" -- or, when most tiles are marked, the plain kernel
  * (decided on the device, no host round trip).  Results are identical either way.  info4 of the LAST upper-triangle launch on the
  * set (synchronises `stream`): [0] 1 = the set has a sorted operand, [1] tiles listed, [2] flags (bit 0: marking gave up, bit 1:
- * the dense kernel ran), [3] 1 = the caller's order was kept (one family holds most sketches). */
+ * the dense kernel ran, bit 2: the tiles came from the sort's segments -- no shared value straddles two of them, so the marking pass
+ * was skipped; D2G_SP_SEGMENTS=0 always marks), [3] 1 = the caller's order was kept (one family holds most sketches). */
 int  d2g_cmp_set_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, uint32_t *info4);
 /* ---- sharded prepare (multi-GPU).  The bit-sliced operand is an array of independent
  * 32-register groups of `group_words` u32 each (+ one u32 of meta per group) whose geometry depends
@@ -444,9 +445,14 @@ int  d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *ro
 #define D2G_PHASE_X2      3   /* bit-plane groups to everyone ("all-gather-v"), per chunk */
 #define D2G_PHASE_DERIVE  4   /* plane stream of a gathered chunk */
 #define D2G_PHASE_PAIR    5   /* the pair kernel over this rank's rows (d2g_allpairs_step_* only) */
+#define D2G_PHASE_ORDER   6   /* sparse tiles on the gathered operand (N >= 8192): ids from the planes, sketch order, sorted stream */
 int  d2g_allpairs_set_phase_timing(d2g_allpairs *eng, int on);
 int  d2g_allpairs_phase_times(d2g_allpairs *eng, int cap, int *n_out, int *kind /* [cap] */, int *chunk /* [cap] */,
                               float *start_ms /* [cap] */, float *dur_ms /* [cap] */);
+/* what the sparse-tile path did in this engine's LAST pair phase (device-synchronising): info4 as d2g_cmp_set_sparse_info --
+ * [0] the gathered operand was ordered (N >= 8192), [1] tiles listed, [2] bit 0 marking gave up / bit 1 the dense kernel ran / bit 2 tiles from the sort's segments,
+ * [3] the gathered order was kept (one family holds most sketches). */
+int  d2g_allpairs_sparse_info(d2g_allpairs *eng, uint32_t *info4);
 /* software-pipelined step for a stream of matrices: the exchange + prepare of this call overlap the pair kernel
  * of the previous call (own stream, two operand buffers); results land in out_dev in call order on `stream`.
  * input_ready != 0: my_rows_dev is already complete (no dependency on work queued on `stream`).

@@ -523,21 +523,31 @@ def test_k2_column_plan_large_sketch_sizes(gpu_ctx, d2g, oracle, S):
     cs.close()
 
 
-def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g, oracle):
+@pytest.mark.parametrize("segments", ["default", "0"])
+def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g, oracle, monkeypatch, segments):
     """Round 4: from 8192 sketches on, an upper-triangle launch on a bit-sliced set walks only the tiles that hold a pair with a shared
     register value (pre-filled output, order by shared-value labels, per-launch tile list), or -- decided on the device -- every tile.
     Whatever it decides, the counts are those of the direct 64-bit kernel (itself pinned to the oracle elsewhere) and of sampled oracle
     rows: a family collection (tiles listed, sparse kernel), an adversarial matrix (marking gives up, dense kernel), skewed columns
     (caller's order kept), unrelated sketches (nothing listed: the fill alone); whole triangle and row ranges; and a set RE-LOADED with
-    another matrix (the cached order and tile marks of the first one must not survive)."""
+    another matrix (the cached order and tile marks of the first one must not survive).  The tiles come from the sort's segments when no
+    segments cover few tiles (families; chains, whose neighbours share one register each: the union pass closes what the propagation left
+    open), from the marking pass otherwise or always (D2G_SP_SEGMENTS=0)."""
     import torch
+    if segments != "default":
+        monkeypatch.setenv("D2G_SP_SEGMENTS", segments)
     N, S = 12_000, 96
+    rng = np.random.default_rng(11)
+    chains = rng.random((N, S))
+    for i in range(N - 1):
+        if (i + 1) % 50:
+            chains[i + 1, i % S] = chains[i, i % S]
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
     mats = {"families": synth.synthetic_registers(N, S, nclusters=N // 150, seed=3).view(np.float64),
             "paired": synth.paired_registers(N, S, seed=4).view(np.float64),
             "skewed": synth.skewed_registers(N, S, seed=5).view(np.float64),
-            "unrelated": synth.unrelated_registers(N, S, seed=6).view(np.float64)}
+            "unrelated": synth.unrelated_registers(N, S, seed=6).view(np.float64), "chains": chains}
     npairs = N * (N - 1) // 2
     out = torch.empty(npairs, dtype=torch.int32, device=dev)
     ref = torch.empty(npairs, dtype=torch.int32, device=dev)
@@ -571,6 +581,8 @@ def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g
         del t_dev
     cs.close()
     assert seen["families"]["sorted_operand"] and seen["families"]["tiles_listed"] > 0 and not seen["families"]["dense_kernel_ran"]
-    assert seen["paired"]["dense_kernel_ran"] and seen["paired"]["marking_gave_up"]
+    assert seen["families"]["tiles_from_segments"] == (segments == "default")
+    assert seen["paired"]["dense_kernel_ran"] and seen["paired"]["marking_gave_up"]          # a random pairing per column: everything hangs together
+    assert seen["chains"]["tiles_from_segments"] == (segments == "default") and seen["chains"]["tiles_listed"] > 0 and not seen["chains"]["dense_kernel_ran"]
     assert seen["skewed"]["dense_kernel_ran"] and seen["skewed"]["callers_order_kept"]
     assert seen["unrelated"]["tiles_listed"] == 0 and not seen["unrelated"]["dense_kernel_ran"]

@@ -320,6 +320,66 @@ def test_allpairs_config4_shape_world8_vs_single_gpu(d2g, gpu_ctx):
         x.close()
 
 
+@pytest.mark.parametrize("W,N,S,kind", [(2, 2600, 512, "families"), (3, 1900, 256, "families"), (4, 1500, 1024, "families"), (2, 900, 128, "planted"), (3, 1100, 128, "one_family")])
+def test_allpairs_sparse_tiles_on_the_gathered_operand(d2g, oracle, monkeypatch, W, N, S, kind):
+    """The engine's pair phase over the gathered operand takes the sparse-tile path (production: N >= 8192; forced here): every rank
+    re-derives ids from the exchanged planes, orders the sketches by shared-value labels, marks tiles and runs the listed tiles (or
+    the dense walk behind the gate) -- every rank's whole slab against the oracle, both epilogues, twice in a row (the second step
+    re-orders a re-gathered operand), and the path reported by d2g_allpairs_sparse_info."""
+    monkeypatch.setenv("D2G_BS_SPARSE_MIN_N", "1")
+    rng = np.random.default_rng(N + W)
+    if kind == "families":                                            # families of ~40 sketches sharing most registers, strangers otherwise
+        fam = rng.integers(0, max(2, N // 40), N)
+        base = rng.random((fam.max() + 1, S))
+        sigs = np.where(rng.random((N, S)) < 0.7, base[fam], rng.random((N, S)))
+    elif kind == "one_family":
+        base = rng.random(S)
+        sigs = np.where(rng.random((N, S)) < 0.5, base[None, :], rng.random((N, S)))
+    else:
+        sigs = _planted(rng, N, S)
+    bits = np.ascontiguousarray(sigs).view(np.uint64)
+    exp = oracle.eqcounts_ut(sigs)
+    lut = d2g.epilogue_lut(S, d2g.SIMILARITY, 31)
+    ctxs = [d2g.Context(0) for _ in range(W)]
+    comms = d2g.Comm.create_all(ctxs)
+    engs = [d2g.AllPairs(ctxs[r], comms[r], N, S) for r in range(W)]
+    rows = [_upload(ctxs[r], bits[engs[r].rows_held[0]:engs[r].rows_held[1]]) for r in range(W)]
+    outs = [ctxs[r].malloc(max(d2g.ut_count(N, *engs[r].rows_computed), 1) * 4) for r in range(W)]
+    luts = [_upload(ctxs[r], lut) for r in range(W)]
+    for e in engs:
+        e.set_phase_timing(True)
+    for rnd, use_lut in enumerate((False, True, False)):
+        d2g.allpairs_step_all(engs, rows, luts if use_lut else None, outs)
+        for r in range(W):
+            ctxs[r].sync()
+            engs[r].status()
+            r0, r1 = engs[r].rows_computed
+            n = d2g.ut_count(N, r0, r1)
+            if not n:
+                continue
+            a = d2g.ut_count(N, 0, r0)
+            if use_lut:
+                got = np.empty(n, np.float32)
+                ctxs[r].d2h(got, outs[r])
+                np.testing.assert_array_equal(got.view(np.uint32), lut[exp[a:a + n]].view(np.uint32), err_msg=f"round {rnd} rank {r}")
+            else:
+                got = np.empty(n, np.uint32)
+                ctxs[r].d2h(got, outs[r])
+                np.testing.assert_array_equal(got, exp[a:a + n], err_msg=f"round {rnd} rank {r}")
+            info = engs[r].sparse_info()
+            assert info["sorted_operand"]
+            if kind == "families":
+                assert info["tiles_listed"] > 0 and not info["marking_gave_up"]
+            if kind == "one_family":
+                assert info["dense_kernel_ran"]
+    assert "order" in {p["phase"] for p in engs[0].phase_times()}
+    for r in range(W):
+        for p in (rows[r], outs[r], luts[r]):
+            ctxs[r].free(p)
+    for x in engs + comms + ctxs:
+        x.close()
+
+
 def _run_bench(*argv, env=None, timeout=900):
     import json
     import os
@@ -352,11 +412,11 @@ def test_bench_inprocess_rung_over_loopback(d2g, W):
     C = cfg["exchange_chunks"]
     assert len(ph["per_rank"]) == W
     for rec in ph["per_rank"]:
-        kinds = [(p[0], p[1]) for p in rec]
+        kinds = [(p[0], p[1]) for p in rec if p[0] != "order"]          # "order": only when the sparse-tile path is on at this N
         want = [("pack", 0)] + [(k, c) for k in ("x1", "prepare", "x2", "derive") for c in range(C)] + [("pair", 0)]
         assert sorted(kinds) == sorted(want), kinds
         assert all(p[3] >= 0 and p[2] >= 0 for p in rec)
-    assert set(ph["max_over_ranks_ms"]) == {"pack", "x1", "prepare", "x2", "derive", "pair"}
+    assert set(ph["max_over_ranks_ms"]) - {"order"} == {"pack", "x1", "prepare", "x2", "derive", "pair"}
     assert len(line["per_rank"]) == W and sum(p["pairs"] for p in line["per_rank"]) == cfg["pairs"]
 
 
@@ -381,7 +441,7 @@ def test_allpairs_phase_times_cover_the_step(d2g, oracle):
     for r, e in enumerate(engs):
         recs = e.phase_times()
         assert [p["phase"] for p in recs][-1] == "pair" and recs[0]["phase"] == "pack"
-        assert sorted((p["phase"], p["chunk"]) for p in recs) == sorted([("pack", 0), ("pair", 0)] + [(k, c) for k in ("x1", "prepare", "x2", "derive") for c in range(C)])
+        assert sorted((p["phase"], p["chunk"]) for p in recs if p["phase"] != "order") == sorted([("pack", 0), ("pair", 0)] + [(k, c) for k in ("x1", "prepare", "x2", "derive") for c in range(C)])
         assert all(p["ms"] >= 0 and p["start_ms"] >= 0 for p in recs)
         e.set_phase_timing(False)
         assert e.phase_times() == []
@@ -430,5 +490,5 @@ def test_bench_ranked_rungs_at_world_size_one(d2g, engine, tmp_path):
     assert line["n_gpus"] == 1 and line["value"] > 0 and "valid" not in line and "WHOLE slab equals" in line["config"]["slab_check"]
     assert line["scaling_base"]["base_1gpu_same_config_pairs_per_s"] > 0 and line["per_rank"][0]["pairs"] == N * (N - 1) // 2
     if engine == "cabi":
-        assert {p[0] for p in line["phases"]["per_rank"][0]} == {"pack", "x1", "prepare", "x2", "derive", "pair"}
+        assert {p[0] for p in line["phases"]["per_rank"][0]} - {"order"} == {"pack", "x1", "prepare", "x2", "derive", "pair"}
         assert line["stream_of_matrices"]["outputs_identical_to_the_one_job_step"] is True

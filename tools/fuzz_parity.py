@@ -94,9 +94,11 @@ def main():
                 if rng.random() < 0.5:
                     os.environ["D2G_BS_SPARSE_MIN_N"] = "1"
                     os.environ["D2G_BS_LABEL_ROUNDS"] = str(int(rng.integers(0, 3)))
+                    os.environ["D2G_SP_SEGMENTS"] = str(int(rng.random() < 0.7))            # tiles from the sort's segments where they are exact / always marked
                 else:
                     os.environ.pop("D2G_BS_SPARSE_MIN_N", None)
                     os.environ.pop("D2G_BS_LABEL_ROUNDS", None)
+                    os.environ.pop("D2G_SP_SEGMENTS", None)
                 r = rng.random()
                 if r < 0.25:
                     regs = synth.skewed_registers(N, S, seed=int(rng.integers(0, 1 << 30)), max_shared=int(rng.choice([4, 64, 300])))

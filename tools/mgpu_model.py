@@ -5,7 +5,8 @@ W contexts on device 0 run exactly the pack / exchange lists / sharded chunked p
 kernels that W GPUs run; on one device they run one after the other, so every kernel's duration (rocprofv3
 --kernel-trace) is what it takes on a GPU of its own.  The report replays ONE rank's step as the engine schedules
 it -- two in-order queues, the compute stream and the exchange stream, tied by the engine's events:
-    compute:  pack | prep(chunk 0) .. prep(chunk C-1) | derive(0) .. derive(C-1) | pair
+    compute:  pack | prep(chunk 0) .. prep(chunk C-1) | derive(0) .. derive(C-1) | order | pair
+              (order = the sparse-tile path's ordering of the gathered operand, N >= 8192; pair = its tile marking + listed tiles)
     exchange: x1(0) .. x1(C-1) | x2(0) .. x2(C-1)            x1(c) before prep(c) before x2(c) before derive(c)
 with the kernels at their measured durations and every exchange at (bytes a rank moves over its busiest link) /
 (ASSUMED link rate).  A prediction to hold against the driver's SCALE run, not a measurement of it.
@@ -99,7 +100,7 @@ def replay(W, C, t, x1_ms, x2_ms):
         x2_done.append(ex)
     for c in range(C):
         comp = max(comp, x2_done[c]) + t["derive_chunk"] + gap
-    comp += t["pair"] + gap
+    comp += t["order"] + t["order_launches"] * gap + t["pair"] + t["pair_launches"] * gap
     return comp
 
 
@@ -128,21 +129,31 @@ def report(d, N, S):
             return sum(v) / steps / 1e3 if v else 0.0           # ms per rank-step
 
         prep_kernels = ("k2_transpose_kernel", "bs_rank_kernel", "bs_colplan_kernel", "bs_planes_kernel")
+        order_kernels = ("sp_unpack_kernel", "sp_init_kernel", "sp_prop_kernel", "sp_prop_reg_kernel", "sp_flatten_kernel", "sp_union_kernel", "sp_jump_kernel", "sp_count_kernel", "sp_scan_kernel",
+                         "sp_place_kernel", "sp_permute_kernel")
+        pair_kernels = ("sp_mark_kernel", "sp_or_kernel", "sp_rows_kernel", "sp_gather_kernel", "sp_rowbm_kernel", "sp_list_kernel", "sp_fill_kernel",
+                        "k2_bitslice_sparse_kernel", "k2_bitslice_kernel")
+
+        def launches(names):
+            return sum(len(kt.get(k, [])) for k in names) / steps
+
         t = {"pack": per_step("mg_pack_kernel"), "prep_chunk": sum(per_step(k) for k in prep_kernels) / C,
-             "derive_chunk": per_step("bs_derive_kernel") / C, "pair": per_step("k2_bitslice_kernel")}
+             "derive_chunk": per_step("bs_derive_kernel") / C, "pair": sum(per_step(k) for k in pair_kernels), "pair_launches": max(1.0, launches(pair_kernels)),
+             "order": sum(per_step(k) for k in order_kernels), "order_launches": launches(order_kernels)}
         a2a = (N / W) * S * 8 * (W - 1) / W                     # bytes a rank sends (= receives) in the row->column exchange
         gat = (ng - ng / W) * gw * 4                            # bytes a rank receives in the gather
         links = max(W - 1, 1)
         x1 = a2a / links / C / (LINK_GBS * 1e9) * 1e3 if W > 1 else 0.0
         x2 = gat / links / C / (LINK_GBS * 1e9) * 1e3 if W > 1 else 0.0
         step = replay(W, C, t, x1, x2)
-        serial = t["pack"] + C * (t["prep_chunk"] + t["derive_chunk"]) + t["pair"] + C * (x1 + x2)
+        serial = t["pack"] + C * (t["prep_chunk"] + t["derive_chunk"]) + t["order"] + t["pair"] + C * (x1 + x2)
         if base is None:
             base = step
-        print(f"W={W} (C={C} chunks): per rank  pack {t['pack']:.3f}  prepare {C}x{t['prep_chunk']:.3f}  derive {C}x{t['derive_chunk']:.3f}  pair {t['pair']:.3f} ms;  "
+        print(f"W={W} (C={C} chunks): per rank  pack {t['pack']:.3f}  prepare {C}x{t['prep_chunk']:.3f}  derive {C}x{t['derive_chunk']:.3f}  order {t['order']:.3f} ({t['order_launches']:.0f} launches)  pair {t['pair']:.3f} ({t['pair_launches']:.0f} launches) ms;  "
               f"moves {a2a / 1e6:6.1f} MB out+in (rows->columns) + {gat / 1e6:6.1f} MB in (gather) over {links} link(s): {C}x{x1:.3f} + {C}x{x2:.3f} ms;  "
               f"ONE-JOB step {step:.3f} ms = {pairs / (step * 1e-3):.3e} pairs/s ({base / step:.2f}x of W=1)  [no overlap inside the step: {serial:.3f} ms, {base / serial:.2f}x];  "
               f"loopback wall {wall:.2f} ms for all {W} ranks on one device")
+        print("      kernels (us per rank-step): " + "  ".join(f"{k.replace('_kernel', '')} {per_step(k) * 1e3:.0f}" for k in order_kernels + pair_kernels if kt.get(k)))
 
 
 if __name__ == "__main__":
