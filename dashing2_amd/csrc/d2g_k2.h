@@ -42,6 +42,7 @@ struct d2g_cmp_set {
     // shared value (every other pair has 0 matches: the output is pre-filled with the value of 0).  Exact for any input; what the
     // order and the tile list cost is paid back when similarity is block-structured (collections of related genomes).
     bool sparse_ok = false;       // eligible and enabled (D2G_BS_SPARSE, D2G_BS_SPARSE_MIN_N)
+    unsigned sp_launch = 0;       // sparse launches so far: the control words are double-buffered (a launch zeroes the next one's)
     size_t ncols = 0;             // register columns the sparse path walks: S, or all ntb * 32 register slots of an engine-managed gathered operand
     bool ids_owned = false;       // engine-managed gathered operands: d_ids / d_colcnt were allocated for the sparse path (ids re-derived from the planes)
     bool srt_valid = false;       // d_stream_s / d_sperm describe the operand last prepared

@@ -447,15 +447,28 @@ __global__ __launch_bounds__(BS_PLAN_THREADS) void bs_colplan_kernel(uint32_t *_
 //                                        pointer simply advances by one block per plane (no per-plane address selection).
 // Register slot x of group tb holds column perm[32 tb + x] (bs_colplan_kernel).
 constexpr int BS_FORM_STREAM = 1, BS_FORM_EXCHANGE = 2;
+// start-of-prepare work of the sparse-tile path (section 4) carried by a kernel that runs anyway (bs_planes_kernel, sp_unpack_kernel)
+// instead of a launch and a memset of its own: label[j] = j, cnt[j] = 0, order[1] = `inexact`, `zwords` words at `zero` cleared
+struct SpInit {
+    uint32_t *label = nullptr, *cnt = nullptr, *order = nullptr, *zero = nullptr;
+    uint32_t n = 0, inexact = 0, zwords = 0;
+};
+__device__ __forceinline__ void sp_init_part(const SpInit &si, size_t lin, size_t nthreads) {
+    if (!si.label) return;
+    if (lin < si.n) { si.label[lin] = (uint32_t)lin; si.cnt[lin] = 0; }
+    if (lin == 0) si.order[1] = si.inexact;
+    for (size_t x = lin; x < si.zwords; x += nthreads) si.zero[x] = 0;
+}
 constexpr size_t BS_SLACK = 64;          // words behind position Npad of every plane (Nstride = Npad + BS_SLACK)
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad,
                                                         uint32_t *__restrict__ planes, uint32_t *__restrict__ stream,
                                                         size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta, int forms,
                                                         const uint32_t *__restrict__ perm, const uint32_t *__restrict__ colcnt,
-                                                        const uint32_t *__restrict__ sperm) {
+                                                        const uint32_t *__restrict__ sperm, SpInit si) {
     const size_t jpos = (size_t)blockIdx.x * 256 + threadIdx.x;   // position in the operand
     const size_t tb = blockIdx.y;
+    sp_init_part(si, tb * ((size_t)gridDim.x * 256) + jpos, (size_t)gridDim.x * 256 * gridDim.y);
     if (jpos >= Nstride) return;
     // sperm: the operand is written in the sparse path's sorted order -- position p holds sketch sperm[p] (stream form only)
     const size_t j = sperm ? (size_t)sperm[jpos] : jpos;          // 0xFFFFFFFF (padding) fails j < N below
@@ -731,12 +744,6 @@ __device__ __forceinline__ uint32_t sp_rank(uint32_t w, const uint32_t *__restri
     return split ? (w & BS_RANK_MASK) + colcnt[t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)] : w;
 }
 
-__global__ __launch_bounds__(256) void sp_init_kernel(uint32_t *__restrict__ label, size_t N, uint32_t *__restrict__ cnt, uint32_t *__restrict__ order, uint32_t inexact) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j == 0) order[1] = inexact;
-    if (j < N) { label[j] = (uint32_t)j; cnt[j] = 0; }
-}
-
 __device__ __forceinline__ uint32_t sp_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Label propagation, one workgroup walking SEVERAL columns one after the other: per column, the smallest LIVE label among the holders of
@@ -962,23 +969,37 @@ __global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restr
     }
 }
 
-// launch rows: the sorted positions whose sketch lies in [r0, r1), in sorted order (stable compaction, one workgroup)
+// launch rows: the sorted positions whose sketch lies in [r0, r1), in sorted order (stable compaction, one workgroup; 8192 positions at
+// a time through LDS so that the loads are coalesced and a thread still owns eight consecutive positions: N = 50 000 80 -> ~12 us)
 __global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restrict__ sperm, size_t N, uint32_t r0, uint32_t r1, uint32_t nrows_pad,
                                                        uint32_t *__restrict__ rowpos, uint32_t *__restrict__ rowk) {
     __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t tile[8192];
+    __shared__ uint32_t s_run;
     const int tid = threadIdx.x;
-    const size_t per = (N + 1023) / 1024, a = (size_t)tid * per, b = min(N, a + per);
-    uint32_t n = 0;
-    for (size_t p = a; p < b; ++p) { const uint32_t j = sperm[p]; n += (j >= r0 && j < r1) ? 1u : 0u; }
-    uint32_t total;
-    uint32_t k = sp_block_scan(n, wave_tot, &total);
-    for (size_t p = a; p < b; ++p) {
-        const uint32_t j = sperm[p];
-        const bool w = j >= r0 && j < r1;
-        rowk[j] = w ? k : SP_NONE;
-        if (w) rowpos[k++] = (uint32_t)p;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (size_t base = 0; base < N; base += 8192) {
+        const uint32_t n = (uint32_t)min((size_t)8192, N - base);
+        for (uint32_t x = tid; x < 8192; x += 1024) tile[x] = x < n ? sperm[base + x] : SP_NONE;
+        __syncthreads();
+        uint32_t jv[8], cnt = 0;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { jv[x] = tile[tid * 8 + x]; cnt += (jv[x] >= r0 && jv[x] < r1) ? 1u : 0u; }   // SP_NONE (beyond N) is in no range
+        uint32_t total;
+        uint32_t k = sp_block_scan(cnt, wave_tot, &total) + s_run;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            if (jv[x] == SP_NONE) continue;
+            const bool w = jv[x] >= r0 && jv[x] < r1;
+            rowk[jv[x]] = w ? k : SP_NONE;
+            if (w) rowpos[k++] = (uint32_t)(base + tid * 8 + x);
+        }
+        __syncthreads();
+        if (tid == 0) s_run += total;
+        __syncthreads();
     }
-    for (uint32_t x = total + tid; x < nrows_pad; x += 1024) rowpos[x] = SP_NONE;
+    for (uint32_t x = s_run + tid; x < nrows_pad; x += 1024) rowpos[x] = SP_NONE;
 }
 
 __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb,
@@ -1245,10 +1266,12 @@ __global__ __launch_bounds__(256) void sp_rowbm_kernel(const uint32_t *__restric
 // sorted positions and a pair is computed where row position < column position, so tiles entirely below that diagonal are not
 // candidates.  ctl[0] = tiles listed, ctl[3] = candidates (what the dense / sparse decision compares it with).
 __global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
-                                                       uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t cand, const uint32_t *__restrict__ gflags) {
+                                                       uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t cand, const uint32_t *__restrict__ gflags,
+                                                       uint32_t *__restrict__ ctl_next) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t s_base;
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid < 8) ctl_next[tid] = 0;                // the next launch's control words (nobody else touches them during this launch)
     if (blockIdx.x == 0 && tid == 0) ctl[3] = cand;                  // for d2g_cmp_set_sparse_info
     if (gflags[1] & 1u) {                                           // the (global) marking gave up: the dense kernel runs instead
         if (blockIdx.x == 0 && tid == 0) atomicOr(&ctl[1], 1u);
@@ -1457,7 +1480,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMalloc((void **)&set->d_lcnt, (Npad + 1) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_spctl, (8 + set->tilebm_words) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_spctl, (16 + set->tilebm_words) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_gbm, (8 + set->tilebm_words) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_slots, set->ncols * set->tilebm_words * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_tiles, std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
@@ -1465,7 +1488,9 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
-    set->d_tilebm = set->d_spctl + 8;
+    set->d_tilebm = set->d_spctl + 16;
+    if ((e = hipMemset(set->d_spctl, 0, 16 * 4)) != hipSuccess) { ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e); return D2G_ERR_HIP; }
+    set->sp_launch = 0;
     return D2G_OK;
 }
 
@@ -1475,16 +1500,28 @@ void sp_free(d2g_cmp_set *set) {
     set->d_tilebm = nullptr;
 }
 
+int sp_label_rounds() {
+    int rounds = 1;
+    if (const char *e = std::getenv("D2G_BS_LABEL_ROUNDS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) rounds = v; }
+    return rounds;
+}
+bool sp_segments_on() { const char *se = std::getenv("D2G_SP_SEGMENTS"); return !(se && se[0] == '0'); }   // "0": always the exact marking (experiments, tests)
+// what the kernel in front of sp_prepare_order initialises for it (and for the first launch after it: the global tile bitmap + its control words)
+SpInit sp_init_of(const d2g_cmp_set *set) {
+    SpInit si;
+    si.label = set->d_label; si.cnt = set->d_lcnt; si.order = set->d_order; si.zero = set->d_gbm;
+    si.n = (uint32_t)set->N; si.inexact = (sp_segments_on() && sp_label_rounds() > 0) ? 0u : 1u;
+    si.zwords = (uint32_t)(8 + set->tilebm_words);
+    return si;
+}
+
 // labels -> counting sort -> d_sperm / d_sinv.  All on `s`, no host round trip.
 int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
     const size_t N = set->N, Npad = set->Npad, S = set->ncols;
     const unsigned nb = (unsigned)div_up<size_t>(N, 256);
-    int rounds = 1;
-    if (const char *e = std::getenv("D2G_BS_LABEL_ROUNDS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) rounds = v; }
+    const int rounds = sp_label_rounds();
     uint32_t *la = set->d_label, *lb = set->d_label + Npad;
-    const char *se = std::getenv("D2G_SP_SEGMENTS");                     // "0": always the exact marking (experiments, tests)
-    const bool segs = !(se && se[0] == '0');
-    hipLaunchKernelGGL(sp_init_kernel, dim3(std::max(nb, 1u)), dim3(256), 0, s, la, N, set->d_lcnt, set->d_order, (segs && rounds > 0) ? 0u : 1u);
+    const bool segs = sp_segments_on() && rounds > 0;                    // (labels, counters, order[1] and the tile bitmap were initialised by the caller's kernel: sp_init_of)
     int gens = 4;                                                        // columns a workgroup walks one after the other
     if (const char *e = std::getenv("D2G_SP_PROP_GENS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) gens = v; }
     const uint32_t pcap = (uint32_t)std::min<size_t>(N / 2 + 1, 16384);
@@ -1498,7 +1535,7 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
             hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, lb, la, N);
         }
     }
-    if (segs && rounds > 0) {
+    if (segs) {
         const uint32_t cap = (uint32_t)std::min<size_t>(N / 2 + 1, 36864);               // shared values of a column: at most N / 2; 144 KB of LDS at most
         const unsigned cthreads = cap > 10240 ? 1024 : 256;                              // a big table leaves one workgroup per CU: a wide one
         D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_union_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
@@ -1521,9 +1558,10 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
 // preparing rank's plan put there; padding slots hold id 0 everywhere).  colcnt[slot][4] = the number of the slot's shared values
 // (carried by the slack words of the group's unique plane: bs_planes_kernel).
 __global__ __launch_bounds__(256) void sp_unpack_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta,
-                                                        size_t N, size_t Npad, uint32_t *__restrict__ ids, uint32_t *__restrict__ colcnt) {
+                                                        size_t N, size_t Npad, uint32_t *__restrict__ ids, uint32_t *__restrict__ colcnt, SpInit si) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;          // < Npad: the grid covers Npad exactly
     const size_t tb = blockIdx.y;
+    sp_init_part(si, tb * ((size_t)gridDim.x * 256) + j, (size_t)gridDim.x * 256 * gridDim.y);
     const int nbits = live_planes(meta, (int)tb);
     const uint32_t *src = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
     if (j < 32) colcnt[(tb * 32 + j) * BS_CC_STRIDE + 4] = planes[tb * (size_t)(nbits_cap + 1) * Nstride + (size_t)nbits_cap * Nstride + Npad + j];
@@ -1565,7 +1603,7 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     if (!set->gbm_valid) {
         // ONCE per prepare: the tiles that hold a pair with a shared value, over all sorted positions (d_gbm: 8 control words + bitmap)
         const uint32_t RW = (nrbG + 31) / 32, W = RW + CW;
-        D2G_HIP(ctx, hipMemsetAsync(set->d_gbm, 0, (8 + (size_t)nrbG * CW + 1) * 4, s));
+        // (d_gbm -- control words + bitmap -- was cleared by the prepare: sp_init_of)
         // LDS: the column's copy of the tile bitmap (when it is small) + the bit sets; 36 KB in all: four columns per CU
         uint32_t lbm_words = nrbG * CW;
         int lbm_max = 4096;                                                            // words (16 KB)
@@ -1589,7 +1627,9 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
         set->gbm_valid = true;
     }
     // per launch: 8 control words (ctl[0] = tiles listed, ctl[1] = flags (bit 0 ALL: marking gave up), [3] = candidates) + a partial launch's bitmap
-    D2G_HIP(ctx, hipMemsetAsync(set->d_spctl, 0, 8 * 4, s));
+    // double-buffered: this launch's list kernel clears the other set for the next launch (both start cleared: sp_alloc)
+    uint32_t *const ctl = set->d_spctl + 8 * (set->sp_launch & 1u), *const ctl_next = set->d_spctl + 8 * ((set->sp_launch + 1) & 1u);
+    ++set->sp_launch;
     if (!full) {
         hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk);
         hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)div_up<size_t>(nrows_pad, 256), (unsigned)(set->ntb * set->nbits_cap)), dim3(256), 0, s,
@@ -1602,16 +1642,16 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     if (full) { cand = 0; for (uint32_t cb = 0; cb < ncb; ++cb) cand += std::min<size_t>(nrb, ((size_t)cb * 256 + 255) / 32 + 1); }
     const uint32_t cand32 = (uint32_t)std::min<size_t>(cand, 0xFFFFFFFFu);
     hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, full ? set->d_gbm + 8 : set->d_tilebm, nrb, ncb, CW, full ? 1 : 0,
-                       set->d_tiles, set->d_spctl, cand32, set->d_gbm);
+                       set->d_tiles, ctl, cand32, set->d_gbm, ctl_next);
     SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
-             set->d_sperm, set->d_rowpos, set->d_tiles, set->d_spctl, ncb, cand32};
+             set->d_sperm, set->d_rowpos, set->d_tiles, ctl, ncb, cand32};
     hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, 256), (size_t)ctx->num_cus * 16)), dim3(256), 0, s,
-                       out_words, cnt, store, (uint32_t)set->S, set->d_spctl, cand32);
+                       out_words, cnt, store, (uint32_t)set->S, ctl, cand32);
     const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ntile * 4, (size_t)ctx->num_cus * (28 / D2G_SP_KS)));
     hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store);
     if (dsh.nvalid_total)
         hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
-                           set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, dsh, store, (const uint32_t *)set->d_spctl, cand32);
+                           set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, dsh, store, (const uint32_t *)ctl, cand32);
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -1756,9 +1796,10 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         // uncoalesced 4-byte loads; permuting the finished stream touches 256 rows of words and leaves the caller's-order stream valid)
         // (a second queue for the caller's-order planes beside the labelling, and for the fill beside the marking, was measured: the
         // kernels slow each other down by what the overlap hides -- mark 28 -> 57 us next to the fill -- and the events cost more: dropped)
-        if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
+        // (the planes kernel also initialises the ordering's arrays and clears the tile bitmap of the first launch: no launch / memset of their own)
         hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
-                           set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
+                           set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr, sp_init_of(set));
+        if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
         hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm);
         set->srt_valid = true; set->nat_valid = true; set->gbm_valid = false;
         D2G_HIP(ctx, hipGetLastError());
@@ -1767,7 +1808,7 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const int forms = set->export_only ? BS_FORM_EXCHANGE : (BS_FORM_STREAM | (set->want_exchange ? BS_FORM_EXCHANGE : 0));
     hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
                        set->export_only ? set->ex_planes : set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, forms,
-                       set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
+                       set->d_perm, set->d_colcnt, (const uint32_t *)nullptr, SpInit{});
     set->srt_valid = false; set->nat_valid = true;
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -1780,7 +1821,7 @@ int d2g_bitslice_ensure_natural(d2g_ctx *ctx, const d2g_cmp_set *cset, hipStream
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
     hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, set->N, set->Npad,
-                       set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
+                       set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr, SpInit{});
     D2G_HIP(ctx, hipGetLastError());
     set->nat_valid = true;
     return D2G_OK;
@@ -1793,7 +1834,7 @@ int d2g_bitslice_export(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
     hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, set->N, set->Npad,
-                       set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr);
+                       set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_EXCHANGE, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr, SpInit{});
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
@@ -1888,7 +1929,7 @@ int d2g_bitslice_managed_sparse_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 int d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     if (!set->borrowed || !set->sparse_ok) return D2G_OK;
     dim3 grid((unsigned)div_up<size_t>(set->Npad, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(sp_unpack_kernel, grid, dim3(256), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->N, set->Npad, set->d_ids, set->d_colcnt);
+    hipLaunchKernelGGL(sp_unpack_kernel, grid, dim3(256), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->N, set->Npad, set->d_ids, set->d_colcnt, sp_init_of(set));
     if (int rc = sp_prepare_order(ctx, set, false, s)) return rc;
     dim3 pgrid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     hipLaunchKernelGGL(sp_permute_kernel, pgrid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm);
@@ -1902,7 +1943,7 @@ int d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
     if (!set->srt_valid || !set->d_spctl) { D2G_HIP(ctx, hipStreamSynchronize(s)); return D2G_OK; }
     uint32_t c[4] = {0, 0, 0, 0}, ord[2] = {0, 1}, g[4] = {0, 0, 0, 0};
-    D2G_HIP(ctx, hipMemcpyAsync(c, set->d_spctl, sizeof c, hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipMemcpyAsync(c, set->d_spctl + 8 * ((set->sp_launch + 1) & 1u), sizeof c, hipMemcpyDeviceToHost, s));   // the set the last launch used
     D2G_HIP(ctx, hipMemcpyAsync(ord, set->d_order, sizeof ord, hipMemcpyDeviceToHost, s));
     D2G_HIP(ctx, hipStreamSynchronize(s));
     c[2] = ord[0]; g[2] = ord[1] ? 1u : 0u;
