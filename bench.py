@@ -363,13 +363,14 @@ ENGINE_NAME = {"cabi": "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv group
                "inproc": "libd2g (d2g_comm_create_all + d2g_allpairs_step_all), ONE process driving every GPU",
                "torch": "torch.distributed (dashing2_amd.dist.RowShardedAllPairs), one process per GPU",
                "broadcast": "whole-matrix torch.distributed broadcast per step + single-GPU prepare on every rank"}
-# profiles/r03_mgpu_model.txt (tools/mgpu_model.sh): ONE rank's step of BASELINE config 4 replayed from loopback kernel durations +
+# profiles/r04_mgpu_model.txt (tools/mgpu_model.sh): ONE rank's step of BASELINE config 4 replayed from loopback kernel durations +
 # every exchange at (bytes over the busiest link) / 50 GB/s + 6 us per enqueued operation.  ms per phase INSTANCE (a chunked phase
-# runs `chunks` times); step_ms = the replayed one-job step; speedup vs the model's own 1-GPU step (15.602 ms).
-MODEL_R03 = {
-    2: {"chunks": 4, "pack": 0.090, "x1": 0.512, "prepare": 0.188, "x2": 0.257, "derive": 0.014, "pair": 6.769, "step_ms": 10.016, "speedup": 1.56},
-    4: {"chunks": 4, "pack": 0.049, "x1": 0.128, "prepare": 0.107, "x2": 0.129, "derive": 0.016, "pair": 3.430, "step_ms": 4.587, "speedup": 3.40},
-    8: {"chunks": 2, "pack": 0.026, "x1": 0.064, "prepare": 0.103, "x2": 0.129, "derive": 0.023, "pair": 1.745, "step_ms": 2.278, "speedup": 6.85},
+# runs `chunks` times; order = the sparse-tile path's ordering of the gathered operand, pair = tile list + fill + listed tiles);
+# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.500 ms; the plain single-GPU path: 3.1 ms).
+MODEL_R04 = {
+    2: {"chunks": 4, "pack": 0.097, "x1": 0.512, "prepare": 0.189, "x2": 0.257, "derive": 0.015, "order": 0.381, "pair": 0.994, "step_ms": 4.726, "speedup": 0.74},
+    4: {"chunks": 4, "pack": 0.053, "x1": 0.128, "prepare": 0.100, "x2": 0.129, "derive": 0.014, "order": 0.387, "pair": 0.555, "step_ms": 2.198, "speedup": 1.59},
+    8: {"chunks": 2, "pack": 0.027, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.024, "order": 0.385, "pair": 0.329, "step_ms": 1.344, "speedup": 2.61},
 }
 
 
@@ -812,7 +813,7 @@ def run_multi(args):
                 worst[ph][c] = max(worst[ph][c], ms)
         phases = {"per_rank": allp, "fields": ["phase", "chunk", "start_ms (after the step's first enqueue reached the GPU)", "ms"],
                   "max_over_ranks_ms": {ph: [worst[ph][c] for c in sorted(worst[ph])] for ph in worst},
-                  "note": "one untimed step with timing events around every phase on the stream it runs on (compute stream: pack, prepare, derive, pair; "
+                  "note": "one untimed step with timing events around every phase on the stream it runs on (compute stream: pack, prepare, derive, order, pair; "
                           "exchange stream: x1 = rows -> column slices, x2 = bit-plane groups to everyone); an exchange's time includes waiting for "
                           "the slowest peer" + ("; ONE process enqueues all ranks here, so start_ms also carries the enqueue order" if not ranked else "")}
 
@@ -868,9 +869,9 @@ def run_multi(args):
             base["speedup"] = value / base["base_1gpu_same_config_pairs_per_s"]
             base["speedup_vs_best_1gpu"] = value / base["best_1gpu_pairs_per_s"]
         model = None
-        if (N, S) == (50000, 1024) and W in MODEL_R03 and eng_of:
-            m = MODEL_R03[W]
-            model = dict(m, source="profiles/r03_mgpu_model.txt (loopback kernel durations + exchanges at 50 GB/s per link + 6 us per enqueue)",
+        if (N, S) == (50000, 1024) and W in MODEL_R04 and eng_of:
+            m = MODEL_R04[W]
+            model = dict(m, source="profiles/r04_mgpu_model.txt (loopback kernel durations + exchanges at 50 GB/s per link + 6 us per enqueue)",
                          note="ms per phase instance; compare with phases.max_over_ranks_ms term by term")
         line = {
             "metric": "all-pairs sketch comparison throughput (pairs/s)", "value": value, "unit": "pairs/s",
@@ -878,7 +879,7 @@ def run_multi(args):
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{workload}: {N} pre-built OPH sketches, S={S}, all-pairs cmp only, {pairs_total} pairs, float32 Jaccard",
                        "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if algo_used == D.CMP_BITSLICE else "direct",
-                       "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + pair kernel w/ fused epilogue; "
+                       "step": ("all-to-all rows->column slices + per-rank prepare of S/W columns + all-gather of bit planes + (N >= 8192) ordering of the gathered operand and tile list on every rank + pair kernel w/ fused epilogue over this rank's rows; "
                                 "row-sharded sketches resident in HBM" if engine != "broadcast" else
                                 "RCCL broadcast of the whole matrix + prepare + pair kernel w/ fused epilogue on every rank"),
                        "parallelism": f"upper-triangle rows sharded over {W} GPU(s) by pair count",
