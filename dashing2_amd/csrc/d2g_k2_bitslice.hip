@@ -885,8 +885,9 @@ __global__ __launch_bounds__(256) void sp_count_kernel(const uint32_t *__restric
 __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t seg_tile_limit) {
     // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t tile[8192];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
     __shared__ uint32_t s_big, s_run, s_est;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     if (tid == 0) { s_big = 0; s_run = 0; s_est = 0; }
     uint32_t est = 0;                                                  // tiles the segments would cover (both triangles), saturating
@@ -896,9 +897,13 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
         for (uint32_t x = tid; x < 8192; x += 1024) tile[x] = x < n ? cnt[base + x] : 0u;
         __syncthreads();
         uint32_t v[8], sum = 0, big = 0;
+        {   // a thread's eight counters as two 16-byte LDS reads (one word at a time: stride 8 words, an 8-way bank conflict)
+            const u32x4 a = reinterpret_cast<const u32x4 *>(tile)[tid * 2], b = reinterpret_cast<const u32x4 *>(tile)[tid * 2 + 1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
-            v[x] = tile[tid * 8 + x]; sum += v[x]; big = max(big, v[x]);
+            sum += v[x]; big = max(big, v[x]);
             // in sixteenths of a tile: a segment of c >= 32 sketches covers at most (rows + 1) x (columns + 1) tiles; smaller ones share their
             // row block with their neighbours (two column tiles for c / 32 of a row block)
             const uint32_t c = min(v[x], 32768u);                    // (a segment that long is past any limit by itself)
@@ -908,8 +913,13 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
         if ((size_t)big * 2 > N) s_big = 1;
         uint32_t total;
         uint32_t run = sp_block_scan(sum, wave_tot, &total) + s_run;
+        {
+            uint32_t o[8];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) { tile[tid * 8 + x] = run; run += v[x]; }
+            for (int x = 0; x < 8; ++x) { o[x] = run; run += v[x]; }
+            reinterpret_cast<u32x4 *>(tile)[tid * 2] = u32x4{o[0], o[1], o[2], o[3]};
+            reinterpret_cast<u32x4 *>(tile)[tid * 2 + 1] = u32x4{o[4], o[5], o[6], o[7]};
+        }
         __syncthreads();
         for (uint32_t x = tid; x < n; x += 1024) { cnt[base + x] = tile[x]; start[base + x] = tile[x]; }   // cnt becomes the placing cursor (-> segment end), start stays
         if (tid == 0) s_run += total;
@@ -948,10 +958,10 @@ __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restric
 // ONE column-coded word per group are gathered (the unique plane is their difference in any plane: r ^ c = u where the register
 // is column-unique, 0 elsewhere); both codings are written.
 __global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restrict__ nat, uint32_t *__restrict__ srt, size_t Nstride, const uint32_t *__restrict__ meta,
-                                                         const uint32_t *__restrict__ sperm) {
+                                                         const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ order) {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int tb = blockIdx.y;
-    if (p >= Nstride) return;
+    if (p >= Nstride || order[0]) return;                             // the caller's order was kept: every launch walks the caller's-order stream (dense), nobody reads this one
     const int nbits = live_planes(meta, tb);
     const size_t slot = stream_slot(meta, tb);
     const uint32_t j = sperm[p];
@@ -974,8 +984,9 @@ __global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restr
 __global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restrict__ sperm, size_t N, uint32_t r0, uint32_t r1, uint32_t nrows_pad,
                                                        uint32_t *__restrict__ rowpos, uint32_t *__restrict__ rowk) {
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t tile[8192];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
     __shared__ uint32_t s_run;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     if (tid == 0) s_run = 0;
     __syncthreads();
@@ -984,8 +995,12 @@ __global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restric
         for (uint32_t x = tid; x < 8192; x += 1024) tile[x] = x < n ? sperm[base + x] : SP_NONE;
         __syncthreads();
         uint32_t jv[8], cnt = 0;
+        {
+            const u32x4 a = reinterpret_cast<const u32x4 *>(tile)[tid * 2], b = reinterpret_cast<const u32x4 *>(tile)[tid * 2 + 1];
+            jv[0] = a.x; jv[1] = a.y; jv[2] = a.z; jv[3] = a.w; jv[4] = b.x; jv[5] = b.y; jv[6] = b.z; jv[7] = b.w;
+        }
 #pragma unroll
-        for (int x = 0; x < 8; ++x) { jv[x] = tile[tid * 8 + x]; cnt += (jv[x] >= r0 && jv[x] < r1) ? 1u : 0u; }   // SP_NONE (beyond N) is in no range
+        for (int x = 0; x < 8; ++x) cnt += (jv[x] >= r0 && jv[x] < r1) ? 1u : 0u;   // SP_NONE (beyond N) is in no range
         uint32_t total;
         uint32_t k = sp_block_scan(cnt, wave_tot, &total) + s_run;
 #pragma unroll
@@ -1800,7 +1815,7 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
                            set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr, sp_init_of(set));
         if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
-        hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm);
+        hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm, set->d_order);
         set->srt_valid = true; set->nat_valid = true; set->gbm_valid = false;
         D2G_HIP(ctx, hipGetLastError());
         return D2G_OK;
@@ -1932,7 +1947,7 @@ int d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     hipLaunchKernelGGL(sp_unpack_kernel, grid, dim3(256), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->N, set->Npad, set->d_ids, set->d_colcnt, sp_init_of(set));
     if (int rc = sp_prepare_order(ctx, set, false, s)) return rc;
     dim3 pgrid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(sp_permute_kernel, pgrid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm);
+    hipLaunchKernelGGL(sp_permute_kernel, pgrid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm, set->d_order);
     D2G_HIP(ctx, hipGetLastError());
     set->srt_valid = true; set->gbm_valid = false;
     return D2G_OK;
