@@ -456,7 +456,7 @@ struct SpInit {
 __device__ __forceinline__ void sp_init_part(const SpInit &si, size_t lin, size_t nthreads) {
     if (!si.label) return;
     if (lin < si.n) { si.label[lin] = (uint32_t)lin; si.cnt[lin] = 0; }
-    if (lin == 0) si.order[1] = si.inexact;
+    if (lin == 0) { si.order[1] = si.inexact; si.order[2] = 0; }
     for (size_t x = lin; x < si.zwords; x += nthreads) si.zero[x] = 0;
 }
 constexpr size_t BS_SLACK = 64;          // words behind position Npad of every plane (Nstride = Npad + BS_SLACK)
@@ -841,11 +841,19 @@ __global__ __launch_bounds__(256) void sp_jump_kernel(const uint32_t *__restrict
     if (j < N) out[j] = in[in[j]];
 }
 
-// label[] maps a sketch to an earlier (or the same) sketch of its family; the root is where that stops.  Most chains end after one or two
-// hops; the propagation's racing stores and the union pass's hooks can leave longer ones
-__device__ __forceinline__ uint32_t sp_root(const uint32_t *__restrict__ label, size_t j) {
-    uint32_t l = label[j];
-    for (;;) { const uint32_t n = label[l]; if (n == l) break; l = n; }  // label[l] < l off the root: ends.  The TRUE root, always: the segments are exact only then
+// label[] maps a sketch to an earlier (or the same) sketch of its family; the root is where that stops -- the TRUE root, always: the
+// segments are exact only then.  Most chains end after one or two hops; the union pass's hooks can leave long ones (a collection that is
+// one chain hooks i + 1 under i for every i), so the walk halves the path behind it like sp_flatten_kernel (label[l] < l off the root: it ends)
+__device__ __forceinline__ uint32_t sp_root(uint32_t *label, size_t j) {
+    // (plain loads: nobody hooks roots while this runs, and a stale label is still an ancestor -- a device-scope load per hop costs 3-4x as much)
+    uint32_t l = (uint32_t)j;
+    for (;;) {
+        const uint32_t p = label[l];
+        if (p == l) break;
+        const uint32_t g = label[p];
+        if (g != p) label[l] = g;
+        l = p;
+    }
     return l;
 }
 
@@ -867,9 +875,10 @@ __device__ __forceinline__ uint32_t sp_block_scan(uint32_t v, uint32_t *wave_tot
 // prefix, then one thread per sketch again).  The roots of a family collection are few and their counters hot, but with a thread
 // per sketch every thread waits for ONE atomic; a single workgroup walking all sketches waited for ten in a row (N = 50 000: 225 us,
 // now ~25).  One root holding more than half of the sketches (everything is connected) keeps the caller's order: order[0] = 1.
-__global__ __launch_bounds__(256) void sp_count_kernel(const uint32_t *__restrict__ label, uint32_t *__restrict__ root, size_t N, uint32_t *__restrict__ cnt) {
+__global__ __launch_bounds__(256) void sp_count_kernel(uint32_t *label, uint32_t *__restrict__ root, size_t N, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ order) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = j < N;
+    if (order[2]) { if (live) root[j] = (uint32_t)j; return; }        // deep chains: no walks; the scan keeps the caller's order
     const uint32_t r = live ? sp_root(label, j) : SP_NONE;
     if (live) root[j] = r;
     // when everything hangs together ONE counter takes all N increments (measured: 115 us at N = 10 000): the lanes that share the
@@ -929,7 +938,7 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
     for (int o = 32; o > 0; o >>= 1) est += __shfl_down(est, o);
     if ((tid & 63) == 0) atomicAdd(&s_est, est);
     __syncthreads();
-    if (tid == 0) { order[0] = s_big; if (s_big || s_est > seg_tile_limit + 1024) order[1] = 1; }
+    if (tid == 0) { const uint32_t keep = s_big | (order[2] ? 1u : 0u); order[0] = keep; if (keep || s_est > seg_tile_limit + 1024) order[1] = 1; }
 }
 __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
                                                         uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order) {
@@ -1191,7 +1200,13 @@ __global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict
 // order was kept, or the segments would cover more than an eighth of all tiles -- components that are large but sparse inside, where
 // exact marks list far fewer tiles) sends the launches to the exact marking instead.
 __device__ __forceinline__ uint32_t sp_find(uint32_t *label, uint32_t l) {
-    for (int h = 0; h < 64; ++h) { const uint32_t n = sp_ld(&label[l]); if (n == l) break; l = n; }
+    for (int h = 0; h < 64; ++h) {                                    // bounded: sp_union retries, and gives up (-> exact marks) in the end
+        const uint32_t p = sp_ld(&label[l]);
+        if (p == l) break;
+        const uint32_t g = sp_ld(&label[p]);
+        if (g != p) label[l] = g;                                     // path halving: only a non-root's label moves, to one of its ancestors
+        l = p;
+    }
     return l;
 }
 __device__ __forceinline__ bool sp_union(uint32_t *label, uint32_t a, uint32_t b) {
@@ -1203,13 +1218,25 @@ __device__ __forceinline__ bool sp_union(uint32_t *label, uint32_t a, uint32_t b
     }
     return false;
 }
-// every label straight at its root before the union pass compares labels (racing with itself is harmless: a label is only ever replaced
-// by an ancestor)
-__global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t N) {
+// every label straight at its root before the union pass compares labels; the walk halves the path behind it.  Families leave chains of two
+// or three labels.  A chain that is not at its root after SP_MAX_HOPS hops means long strings of sketches that share registers with their
+// neighbours only (a time series; the extreme, ONE chain of N sketches, costs N / 2 dependent loads in the last thread: 0.7 ms at N = 12 000):
+// one big component in all likelihood, and nothing the tile list could help -- order[2] is raised, the union pass and the sort's root walks are
+// skipped, the caller's order is kept and the launches walk every tile (the same outcome as "one family holds most sketches", found early).
+// Racing with itself is harmless: a label is only ever replaced by an ancestor.  (plain loads, as in sp_root)
+constexpr int SP_MAX_HOPS = 64;
+__global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t N, uint32_t *__restrict__ order) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
-    uint32_t l = sp_ld(&label[j]);
-    for (;;) { const uint32_t n = sp_ld(&label[l]); if (n == l) break; l = n; }
+    uint32_t l = (uint32_t)j;
+    for (int h = 0;; ++h) {
+        const uint32_t p = label[l];
+        if (p == l) break;
+        if (h == SP_MAX_HOPS) { order[2] = 1; return; }
+        const uint32_t g = label[p];
+        if (g != p) label[l] = g;
+        l = p;
+    }
     label[j] = l;
 }
 __global__ void sp_union_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
@@ -1218,7 +1245,7 @@ __global__ void sp_union_kernel(const uint32_t *__restrict__ ids, size_t N, size
     const size_t t = blockIdx.x;
     const uint32_t T = blockDim.x;
     const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
-    if (d2 == 0) return;
+    if (d2 == 0 || order[2]) return;                                  // order[2]: deep chains (sp_flatten_kernel): the caller's order will be kept
     if (d2 > cap) { if (threadIdx.x == 0) atomicOr(&order[1], 1u); return; }
     for (uint32_t r = threadIdx.x; r < d2; r += T) sp_chk[r] = SP_NONE;
     __syncthreads();
@@ -1554,18 +1581,18 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
             hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, lb, la, N);
         }
     }
+    if (rounds > 0) hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N, set->d_order);   // (also the guard against deep chains)
     if (segs) {
         const uint32_t cap = (uint32_t)std::min<size_t>(N / 2 + 1, 36864);               // shared values of a column: at most N / 2; 144 KB of LDS at most
         const unsigned cthreads = cap > 10240 ? 1024 : 256;                              // a big table leaves one workgroup per CU: a wide one
         D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_union_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
-        hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
         hipLaunchKernelGGL(sp_union_kernel, dim3((unsigned)S), dim3(cthreads), (size_t)cap * 4, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, la, cap, set->d_order);
     }
     const size_t ntile_all = (Npad / 32) * (Npad / BS_CB);
     size_t seg_div = 8;                                                  // segments may cover an eighth of all tiles; beyond, exact marks are worth their pass
     if (const char *e = std::getenv("D2G_SP_SEG_DIV")) { const long v = std::atol(e); if (v >= 1 && v <= 1024) seg_div = (size_t)v; }
     const uint32_t seg_limit = (uint32_t)std::min<size_t>(ntile_all / seg_div, 0x3FFFFFFF);
-    hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt);
+    hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order);
     hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, seg_limit);    // la (labels) is dead after the count kernel: it keeps the segment starts
     hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order);
     D2G_HIP(ctx, hipGetLastError());

@@ -539,7 +539,9 @@ def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g
     N, S = 12_000, 96
     rng = np.random.default_rng(11)
     chains = rng.random((N, S))
+    one_chain = rng.random((N, S))                                     # sketch i shares one register with i + 1, for every i: label chains of depth ~N
     for i in range(N - 1):
+        one_chain[i + 1, i % S] = one_chain[i, i % S]
         if (i + 1) % 50:
             chains[i + 1, i % S] = chains[i, i % S]
     dev = torch.device("cuda", 0)
@@ -547,7 +549,7 @@ def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g
     mats = {"families": synth.synthetic_registers(N, S, nclusters=N // 150, seed=3).view(np.float64),
             "paired": synth.paired_registers(N, S, seed=4).view(np.float64),
             "skewed": synth.skewed_registers(N, S, seed=5).view(np.float64),
-            "unrelated": synth.unrelated_registers(N, S, seed=6).view(np.float64), "chains": chains}
+            "unrelated": synth.unrelated_registers(N, S, seed=6).view(np.float64), "chains": chains, "one_chain": one_chain}
     npairs = N * (N - 1) // 2
     out = torch.empty(npairs, dtype=torch.int32, device=dev)
     ref = torch.empty(npairs, dtype=torch.int32, device=dev)
@@ -583,6 +585,7 @@ def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g
     assert seen["families"]["sorted_operand"] and seen["families"]["tiles_listed"] > 0 and not seen["families"]["dense_kernel_ran"]
     assert seen["families"]["tiles_from_segments"] == (segments == "default")
     assert seen["paired"]["dense_kernel_ran"] and seen["paired"]["marking_gave_up"]          # a random pairing per column: everything hangs together
+    assert seen["one_chain"]["callers_order_kept"] and seen["one_chain"]["dense_kernel_ran"]     # deep label chains: found early, the caller's order kept
     assert seen["chains"]["tiles_from_segments"] == (segments == "default") and seen["chains"]["tiles_listed"] > 0 and not seen["chains"]["dense_kernel_ran"]
     assert seen["skewed"]["dense_kernel_ran"] and seen["skewed"]["callers_order_kept"]
     assert seen["unrelated"]["tiles_listed"] == 0 and not seen["unrelated"]["dense_kernel_ran"]

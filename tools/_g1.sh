@@ -1,0 +1,7 @@
+for L in 50 1000 12000; do CHAIN=$L timeout 300 python tools/chain_time.py 2>&1 | tail -1 | cut -c1-250; done
+N=50000 CHAIN=50000 timeout 300 python tools/chain_time.py 2>&1 | tail -1 | cut -c1-100
+for m in stated skewed paired; do MATRIX=$m timeout 300 python tools/k2_time.py 2>&1 | tail -2 | head -1 | cut -c1-60; done
+N=50000 timeout 300 python tools/k2_time.py 2>&1 | tail -2 | head -1 | cut -c1-60
+timeout 1500 python -m pytest tests/test_gpu_k2.py tests/test_gpu_mgpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed"
+D2G_BS_SPARSE_MIN_N=1 D2G_SP_SEG_DIV=1 timeout 1500 python -m pytest tests/test_gpu_k2.py tests/test_gpu_mgpu.py tests/test_gpu_cli.py -x -q -m gpu -k "not config4" 2>&1 | grep -E "passed|failed"
+D2G_FUZZ_ONLY=k2,mgpu timeout 400 python tools/fuzz_parity.py 100 2>&1 | tail -1
