@@ -366,11 +366,11 @@ ENGINE_NAME = {"cabi": "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv group
 # profiles/r04_mgpu_model.txt (tools/mgpu_model.sh): ONE rank's step of BASELINE config 4 replayed from loopback kernel durations +
 # every exchange at (bytes over the busiest link) / 50 GB/s + 6 us per enqueued operation.  ms per phase INSTANCE (a chunked phase
 # runs `chunks` times; order = the sparse-tile path's ordering of the gathered operand, pair = tile list + fill + listed tiles);
-# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.500 ms; the plain single-GPU path: 3.1 ms).
+# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.169 ms; the plain single-GPU path: 2.8 ms).
 MODEL_R04 = {
-    2: {"chunks": 4, "pack": 0.097, "x1": 0.512, "prepare": 0.189, "x2": 0.257, "derive": 0.015, "order": 0.381, "pair": 0.994, "step_ms": 4.726, "speedup": 0.74},
-    4: {"chunks": 4, "pack": 0.053, "x1": 0.128, "prepare": 0.100, "x2": 0.129, "derive": 0.014, "order": 0.387, "pair": 0.555, "step_ms": 2.198, "speedup": 1.59},
-    8: {"chunks": 2, "pack": 0.027, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.024, "order": 0.385, "pair": 0.329, "step_ms": 1.344, "speedup": 2.61},
+    2: {"chunks": 4, "pack": 0.092, "x1": 0.512, "prepare": 0.187, "x2": 0.257, "derive": 0.015, "order": 0.375, "pair": 0.824, "step_ms": 4.546, "speedup": 0.70},
+    4: {"chunks": 4, "pack": 0.051, "x1": 0.128, "prepare": 0.101, "x2": 0.129, "derive": 0.016, "order": 0.386, "pair": 0.489, "step_ms": 2.130, "speedup": 1.49},
+    8: {"chunks": 2, "pack": 0.027, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.024, "order": 0.385, "pair": 0.308, "step_ms": 1.322, "speedup": 2.40},
 }
 
 
@@ -1202,7 +1202,11 @@ def run_single(args):
                          "with the value of 0 equal registers; kernel_ms is the whole compare launch (fill, tile marking, list, pair kernel); D2G_BS_SPARSE=0 walks every tile"
                          if sparse_ran else "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute")}
 
-    def valu(pairs, mean_planes, ms):
+    def valu(pairs, mean_planes, ms, sp=None):
+        """lane-ops per second of the launch.  The dense walk compares every pair; a sparse-tile launch only the pairs of its listed
+        32 x 256 tiles (the rest of the output is a fill): its lane-ops are counted over those, so the fraction stays a fraction"""
+        if sp and sp.get("sorted_operand") and not sp.get("dense_kernel_ran"):
+            pairs = min(pairs, sp.get("tiles_listed", 0) * 32 * 256)
         if algo_used == D.CMP_BITSLICE:
             ops = pairs * ((S + 31) // 32) * (mean_planes + ops_extra)
         else:
@@ -1210,9 +1214,11 @@ def run_single(args):
         a = ops / (ms * 1e-3) if ms > 0 else 0.0
         return a, a / VALU_PEAK_LANEOPS
 
-    va, vf = valu(my_pairs, mean_nbits, k2_ms)
+    va, vf = valu(my_pairs, mean_nbits, k2_ms, sparse_info)
     compute = {"bound": "valu", "unit": "lane-ops/s", "achieved": va, "peak": VALU_PEAK_LANEOPS, "frac": vf,
-               "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct, "sparse": sparse_info}
+               "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct, "sparse": sparse_info,
+               "note": ("lane-ops of the pairs of the LISTED tiles (tiles_listed x 32 x 256) over the whole compare launch (fill, list and pair kernel): the sparse path "
+                        "executes nothing for the other pairs" if sparse_ran else "lane-ops of every pair of the triangle over the pair kernel")}
 
     def measure_matrix(bits_np, n, steps=5):
         """prepare + pair kernel of an n x S matrix on this GPU, whole triangle; returns a small dict"""
@@ -1244,7 +1250,7 @@ def run_single(args):
         return {"sketches": n, "pairs_per_s": npairs / d, "ms_per_step": d * 1e3, "kernel_ms": kms, "prep_ms": pms,
                 "bit_planes_max": nb, "bit_planes_mean": mean, "max_shared_values_per_column_plus1": md,
                 "hbm_frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else 0.0,
-                "valu_frac": valu(npairs, mean, kms)[1], "sparse": sp}
+                "valu_frac": valu(npairs, mean, kms, sp)[1], "sparse": sp}
 
     config4 = None
     if True:
