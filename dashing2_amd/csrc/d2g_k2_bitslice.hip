@@ -716,15 +716,18 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
 // ------------------------------------------------------------------ 4. sparse tiles
 // An equality count is zero unless the two sketches share a value in at least one register column.  In a collection of related
 // genomes most pairs share nothing (different species), and the ones that do come in families.  So:
-//   prepare  labels: label[j] = smallest sketch index among the sketches that share a value with j (one sweep over the ids, then
-//            pointer jumping); the sketches are counting-sorted by label and the plane stream is written in THAT order
-//            (bs_planes_kernel gathers its ids through d_sperm) -- families become runs of adjacent positions;
-//   launch   per register column, every shared value marks the (32-row block x 256-column block) tiles its holders meet in
-//            (sp_mark_kernel: bit sets per value in LDS); the marked tiles become a work list; the output is pre-filled with the
-//            value of "0 equal registers"; the pair kernel walks the listed tiles only and stores where the count is not 0.
-// Nothing here is approximate: an unmarked tile holds no pair with a common value, whatever the labels look like -- the order
-// only decides how FEW tiles get marked.  If one label would take more than half of the sketches (everything is connected) the
-// caller's order is kept.  Rows of a partial launch [r0, r1) are gathered (in sorted order) into a row operand of their own.
+//   prepare  FAMILIES = the connected components of "shares a value in some column": label propagation (sp_prop*: a label is an earlier
+//            member of the sketch's family) and ONE lock-free union-find pass over every column (sp_flatten / sp_union: exact components,
+//            no iteration); the sketches are counting-sorted by root (sp_count / scan / place) and the finished plane stream is permuted
+//            into THAT order (sp_permute) -- a family becomes a run of adjacent positions, a "segment";
+//   launch   the 32-row x 256-column tiles a segment's rows and columns meet in become a work list (every pair with a shared value lies
+//            inside one segment); when the segments would cover too much -- families that are large but sparse inside -- every shared
+//            value marks the tiles its holders meet in instead (sp_mark_kernel: bit sets per value in LDS); the output is pre-filled with
+//            the value of "0 equal registers"; the pair kernel walks the listed tiles only and stores where the count is not 0.
+// Nothing here is approximate: a tile that is not listed holds no pair with a common value -- by the components being exact in the
+// first case, by construction of the marks (whatever the order looks like) in the second.  If one family would take more than half of
+// the sketches (everything is connected), or the labels form long chains, the caller's order is kept and every tile is walked.  Rows of
+// a partial launch [r0, r1) are gathered (in sorted order) into a row operand of their own.
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
 #ifndef D2G_SP_WIDE_U
 #define D2G_SP_WIDE_U 8          // sketches per thread and step of the wide mark kernel (measured at N = 50 000: 8 -> 532 us, 16 -> 856 us)
