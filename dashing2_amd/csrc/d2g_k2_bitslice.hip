@@ -904,10 +904,17 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
     if (tid == 0) { s_big = 0; s_run = 0; s_est = 0; }
     uint32_t est = 0;                                                  // tiles the segments would cover (both triangles), saturating
     __syncthreads();
+    // the next tile's counters are requested before this tile is scanned (one workgroup: nothing else hides the round trip)
+    uint32_t pre[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const size_t x = (size_t)k * 1024 + tid; pre[k] = x < N ? cnt[x] : 0u; }
     for (size_t base = 0; base < N; base += 8192) {
         const uint32_t n = (uint32_t)min((size_t)8192, N - base);
-        for (uint32_t x = tid; x < 8192; x += 1024) tile[x] = x < n ? cnt[base + x] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[k * 1024 + tid] = pre[k];
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const size_t x = base + 8192 + (size_t)k * 1024 + tid; pre[k] = x < N ? cnt[x] : 0u; }
         uint32_t v[8], sum = 0, big = 0;
         {   // a thread's eight counters as two 16-byte LDS reads (one word at a time: stride 8 words, an 8-way bank conflict)
             const u32x4 a = reinterpret_cast<const u32x4 *>(tile)[tid * 2], b = reinterpret_cast<const u32x4 *>(tile)[tid * 2 + 1];
@@ -1002,10 +1009,15 @@ __global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restric
     const int tid = threadIdx.x;
     if (tid == 0) s_run = 0;
     __syncthreads();
+    uint32_t pre[8];                                                   // the next tile is requested before this one is compacted (as in sp_scan_kernel)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const size_t x = (size_t)k * 1024 + tid; pre[k] = x < N ? sperm[x] : SP_NONE; }
     for (size_t base = 0; base < N; base += 8192) {
-        const uint32_t n = (uint32_t)min((size_t)8192, N - base);
-        for (uint32_t x = tid; x < 8192; x += 1024) tile[x] = x < n ? sperm[base + x] : SP_NONE;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[k * 1024 + tid] = pre[k];
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const size_t x = base + 8192 + (size_t)k * 1024 + tid; pre[k] = x < N ? sperm[x] : SP_NONE; }
         uint32_t jv[8], cnt = 0;
         {
             const u32x4 a = reinterpret_cast<const u32x4 *>(tile)[tid * 2], b = reinterpret_cast<const u32x4 *>(tile)[tid * 2 + 1];
