@@ -366,11 +366,11 @@ ENGINE_NAME = {"cabi": "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv group
 # profiles/r04_mgpu_model.txt (tools/mgpu_model.sh): ONE rank's step of BASELINE config 4 replayed from loopback kernel durations +
 # every exchange at (bytes over the busiest link) / 50 GB/s + 6 us per enqueued operation.  ms per phase INSTANCE (a chunked phase
 # runs `chunks` times; order = the sparse-tile path's ordering of the gathered operand, pair = tile list + fill + listed tiles);
-# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.169 ms; the plain single-GPU path: 2.8 ms).
+# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.206 ms; the plain single-GPU path: 2.8 ms).
 MODEL_R04 = {
-    2: {"chunks": 4, "pack": 0.092, "x1": 0.512, "prepare": 0.187, "x2": 0.257, "derive": 0.015, "order": 0.375, "pair": 0.824, "step_ms": 4.546, "speedup": 0.70},
-    4: {"chunks": 4, "pack": 0.051, "x1": 0.128, "prepare": 0.101, "x2": 0.129, "derive": 0.016, "order": 0.386, "pair": 0.489, "step_ms": 2.130, "speedup": 1.49},
-    8: {"chunks": 2, "pack": 0.027, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.024, "order": 0.385, "pair": 0.308, "step_ms": 1.322, "speedup": 2.40},
+    2: {"chunks": 4, "pack": 0.091, "x1": 0.512, "prepare": 0.185, "x2": 0.257, "derive": 0.014, "order": 0.357, "pair": 0.801, "step_ms": 4.502, "speedup": 0.71},
+    4: {"chunks": 4, "pack": 0.051, "x1": 0.128, "prepare": 0.102, "x2": 0.129, "derive": 0.016, "order": 0.367, "pair": 0.461, "step_ms": 2.084, "speedup": 1.54},
+    8: {"chunks": 2, "pack": 0.027, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.023, "order": 0.368, "pair": 0.293, "step_ms": 1.288, "speedup": 2.49},
 }
 
 
