@@ -128,6 +128,16 @@ def pmc_traffic(kernel_substr, wide_loads):
     return rd + e["largest_dispatch_hbm_write_bytes"]
 
 
+def set_switch(ctxs, name, value):
+    """libd2g reads its D2G_* switches once per context: change one for an A/B leg and make the context(s) read it"""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = value
+    for c in (ctxs if isinstance(ctxs, (list, tuple)) else [ctxs]):
+        c.reload_tuning()
+
+
 def host_cores():
     """CPUs this process may actually use: the visible CPUs, cut by the affinity mask and by the cgroup CPU quota (a GPU box
     of this pool shows 256 CPUs and grants 16 of them; 256 threads under a 16-CPU quota only throttle each other)."""
@@ -764,13 +774,13 @@ def run_multi(args):
             # the single-GPU path held to the dense walk (D2G_BS_SPARSE=0: every tile) beside the default: the sharded engine's pair phase runs
             # whichever of the two the engine's gathered operand took (C-ABI engine: sparse tiles from N >= 8192, like a single GPU; the torch
             # and broadcast rungs: see engine_sparse below), and `speedup` is read against the base that runs the SAME algorithm
-            os.environ["D2G_BS_SPARSE"] = "0"
+            set_switch(d["ctx"], "D2G_BS_SPARSE", "0")
             try:
                 dense = d["ctx"].cmp_set_dev(full.data_ptr(), N, S, algo=algo, stream=stream)
                 ddt = time_ref(dense)
                 dense.close()
             finally:
-                os.environ.pop("D2G_BS_SPARSE", None)
+                set_switch(d["ctx"], "D2G_BS_SPARSE", None)
             if eng_of:
                 esp = eng_of[0].sparse_info()
             elif teng is not None:
@@ -1012,7 +1022,7 @@ def pmc_child(args):
         tw3 = torch.empty((nb,), dtype=torch.float64, device=dev)
         plan = plan_for(nb, 21)
         for compact in ("0", "1"):
-            os.environ["D2G_K3_COMPACT"] = compact
+            set_switch(ctx, "D2G_K3_COMPACT", compact)
             ctx.bmh_sketch_dev(plan, packed.data_ptr(), 2048, sig3.data_ptr(), tw3.data_ptr(), stream=None)
             torch.cuda.synchronize()
             print("PMC-CHILD k3 compact=%s done" % compact, flush=True)     # a marker per call; the CSV keeps dispatch order
@@ -1023,7 +1033,13 @@ K3_DEFAULT = ("k3_hist_kernel", "k3_scan_kernel", "k3_scatter_kernel", "k3_refin
 K3_COMPACT_ONLY = ("k3c_hist", "k3c_scan", "k3c_scatter")
 
 
-def measure_traffic(args, which=("k2", "k1", "k3"), timeout=240.0):
+def re_short(name):
+    import re
+    n = re.sub(r"^void\s+", "", name).replace("(anonymous namespace)::", "")
+    return re.split(r"[(<]", n, 1)[0][:60] or n[:60]
+
+
+def measure_traffic(args, which=("k2", "k1", "k3"), timeout=300.0):
     """-> {"k2": bytes, "k2_prepare": bytes, "k1": bytes, "k3": bytes, "k3_compact": bytes, "seconds": s} measured now, or
     {"error": why}.  FETCH_SIZE and WRITE_SIZE cannot share a pass (MI355X_MICROARCH.md: TCC has 4 slots, they cost 3 + 2): two
     passes of the same child, counters only beside --kernel-trace.  rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies wide
@@ -1040,7 +1056,8 @@ def measure_traffic(args, which=("k2", "k1", "k3"), timeout=240.0):
     tmp = tempfile.mkdtemp(prefix="d2g_pmc_", dir="/tmp")
     rows = {}                                                   # counter -> [(kernel name, dispatch id, value)]
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        ctrs = ["FETCH_SIZE", "WRITE_SIZE"] + (["SQ_INSTS_VALU"] if "k1" in which else [])      # one counter per pass
+        for ctr in ctrs:
             od = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-f", "csv", "-d", od, "--", sys.executable, os.path.abspath(__file__),
                    "--pmc-child", ",".join(which), "--sketches", str(args.sketches or 10000), "--sketchsize", str(args.sketchsize),
@@ -1059,7 +1076,7 @@ def measure_traffic(args, which=("k2", "k1", "k3"), timeout=240.0):
             for f in sorted(glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True)):
                 for rec in csv.DictReader(open(f)):
                     if rec.get("Counter_Name") == ctr:
-                        got.append((rec["Kernel_Name"], int(rec.get("Dispatch_Id", 0) or 0), float(rec["Counter_Value"]) * 1024.0))
+                        got.append((rec["Kernel_Name"], int(rec.get("Dispatch_Id", 0) or 0), float(rec["Counter_Value"]) * (1.0 if ctr.startswith("SQ_") else 1024.0)))
             if not got:
                 return {"error": f"no {ctr} rows in rocprofv3's output"}
             rows[ctr] = sorted(got, key=lambda x: x[1])
@@ -1084,13 +1101,28 @@ def measure_traffic(args, which=("k2", "k1", "k3"), timeout=240.0):
 
     res = {"seconds": round(time.monotonic() - t0, 1)}
     if "k2" in which:
-        # ONE compare launch in the child: the pair kernel, or -- sparse tiles -- the kernels of its chain together
-        res["k2"] = both(lambda k: any(x in k for x in ("k2_bitslice_kernel", "k2_direct_kernel", "k2_bitslice_sparse_kernel", "sp_fill", "sp_mark", "sp_or_",
-                                                         "sp_list", "sp_decide", "sp_rows", "sp_gather")))
-        res["k2_prepare"] = both(lambda k: any(x in k for x in ("bs_transpose", "bs_rank", "bs_colplan", "bs_planes", "k2_transpose", "sp_init", "sp_gmin", "sp_label",
-                                                                 "sp_jump", "sp_sort", "sp_permute")))
+        # the child runs ONE prepare (set creation) and ONE compare launch of the config-3 matrix: every K2 kernel once
+        COMPARE = ("k2_bitslice_kernel", "k2_direct_kernel", "k2_bitslice_sparse_kernel", "sp_fill", "sp_list", "sp_rows", "sp_gather", "sp_rowbm", "sp_patch")
+        is_k2 = lambda k: any(x in k for x in ("k2_", "bs_", "sp_"))                          # noqa: E731
+        is_cmp = lambda k: any(x in k for x in COMPARE)                                       # noqa: E731
+        res["k2"] = both(is_cmp)
+        res["k2_prepare"] = both(lambda k: is_k2(k) and not is_cmp(k))
+        rd, wr = total("FETCH_SIZE", is_k2), total("WRITE_SIZE", is_k2)
+        # calibration on the transpose kernel, whose traffic is known: it reads the N x S matrix once (8 S N bytes, 8-byte loads) and
+        # writes the padded copy once (8 S Npad): FETCH_SIZE tallies some loads at half their bytes on gfx950 (MI355X_MICROARCH.md)
+        N_, S_ = (args.sketches or 10000), args.sketchsize
+        t_rd, t_wr = total("FETCH_SIZE", lambda k: "k2_transpose" in k), total("WRITE_SIZE", lambda k: "k2_transpose" in k)
+        cal = None
+        if t_rd and t_wr:
+            cal = {"kernel": "k2_transpose_kernel", "known_read_bytes": 8 * S_ * N_, "counter_read_bytes_raw": t_rd, "read_scale": 8 * S_ * N_ / t_rd,
+                   "known_write_bytes": 8 * S_ * ((N_ + 255) // 256 * 256), "counter_write_bytes": t_wr, "write_scale": 8 * S_ * ((N_ + 255) // 256 * 256) / t_wr}
+        if rd is not None and wr is not None:
+            res["k2_step"] = {"read_raw": rd, "read_x2": 2 * rd, "write": wr, "raw_total": rd + wr, "x2_total": 2 * rd + wr, "calibration": cal,
+                              "per_kernel": {re_short(k): {"read_raw": total("FETCH_SIZE", lambda q, k=k: q == k), "write": total("WRITE_SIZE", lambda q, k=k: q == k)}
+                                             for k in sorted({k for (k, _, _) in rows["FETCH_SIZE"] if is_k2(k)})}}
     if "k1" in which:
         res["k1"] = both(lambda k: "k1_oph_kernel" in k, wide=True, largest=True)
+        res["k1_valu_wave_insts"] = total("SQ_INSTS_VALU", lambda k: "k1_oph_kernel" in k, largest=True) if "SQ_INSTS_VALU" in rows else None
     if "k3" in which:
         # the child makes ONE default call, then ONE compact call: split the k3 dispatches at the first compact-only kernel
         def split(ctr):
@@ -1132,8 +1164,10 @@ def run_single(args):
     stream = torch.cuda.current_stream().cuda_stream
     ncores = host_cores()
 
-    def make_sketches(n, seed=20260928):
+    def make_sketches(n, seed=20260928, collisions=0):
         regs = synth.synthetic_registers(n, S, nclusters=max(8, n // 150), seed=seed)
+        if collisions:
+            regs = synth.add_chance_collisions(regs, collisions, seed=seed + 1)
         return D.oph_finalize(regs, S, nthreads=ncores)
 
     # ---- synthetic pre-built sketches, resident in HBM before the timed region
@@ -1181,25 +1215,29 @@ def run_single(args):
 
     # ---- roofline of the dominant kernel (the pair kernel), rank 0's launch
     alg_bytes = 8 * S * N + 4 * my_pairs          # each sketch read once + one float per pair
-    achieved = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
+    compare_only = alg_bytes / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
     sparse_ran = bool(sparse_info.get("sorted_operand")) and not sparse_info.get("dense_kernel_ran")
-    kname = ("k2 sparse chain (sp_fill + sp_mark + sp_or + sp_list + k2_bitslice_sparse_kernel over %d listed tiles)" % sparse_info.get("tiles_listed", 0) if sparse_ran
-             else "k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2_direct_kernel")
-    pmc_ok = (algo_used == D.CMP_BITSLICE and N == 10000 and S == 1024 and not sparse_ran)
-    with_prep = alg_bytes / ((k2_ms + prep_ms) * 1e-3) / 1e9 if (k2_ms + prep_ms) > 0 else 0.0
+    kname = ("k2 step = prepare chain (transpose, rank, column plan, planes, families, pair list, sorted stream) + compare launch (tile list, fill, "
+             "k2_bitslice_sparse_kernel over %d listed tiles, %d pair-list entries)" % (sparse_info.get("tiles_listed", 0), sparse_info.get("pairs_listed", 0)) if sparse_ran
+             else "k2 step = prepare chain + k2_bitslice_kernel" if algo_used == D.CMP_BITSLICE else "k2 step = transpose + k2_direct_kernel")
+    # the 8 S N bytes of the sketches are read by the PREPARE chain and the 4-byte outputs are written by the compare launch, so
+    # the roofline figure of this job divides its algorithmic bytes by BOTH (hipEvents: the prepare chain bracketed on the warm-up steps, the
+    # compare launch on every timed step); the compare launch on its own is the named secondary `compare_launch`
+    step_ev_ms = k2_ms + prep_ms
+    achieved = alg_bytes / (step_ev_ms * 1e-3) / 1e9 if step_ev_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                # the 8 S N bytes of the sketches are read by the PREPARE chain, not by the pair kernel: the same algorithmic
-                # bytes over pair kernel + prepare
-                "frac_with_prepare": with_prep / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(kname, False) if pmc_ok else None,          # replaced below by this run's own counter passes
-                "traffic_source": ("profiles/" + os.path.basename(PMC_FILE) + " (committed)") if pmc_ok else None,
-                "traffic_note": "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE (separate passes), the config-3-sized (largest) dispatch of the pair kernel; "
-                                "dword loads: read side raw/uncalibrated",
-                "kernel": kname, "kernel_ms": k2_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
-                "prep_ms": prep_ms,
-                "note": ("sparse tiles: only the 32 x 256 tiles that hold a pair with a shared register value are walked, the rest of the output is a fill "
-                         "with the value of 0 equal registers; kernel_ms is the whole compare launch (fill, tile marking, list, pair kernel); D2G_BS_SPARSE=0 walks every tile"
+                "frac_of_wall_clock_step": alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "compare_launch": {"kernel_ms": k2_ms, "achieved": compare_only, "frac": compare_only / HBM_PEAK_GBS,
+                                   "note": "the same algorithmic bytes over the compare launch alone (round 4's headline figure; the sketches' 8 S N bytes are NOT read by it)"},
+                "traffic": None, "traffic_source": None,                            # this run's own counter passes, below
+                "traffic_note": "HBM bytes of ONE whole step (every kernel of the prepare chain + the compare launch): rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE "
+                                "(separate passes).  `traffic` = read side x read_scale + write side, read_scale calibrated in the same run on the transpose "
+                                "kernel (known 8 S N bytes in); traffic_detail has the raw and the x2 figures and the per-kernel table",
+                "kernel": kname, "kernel_ms": step_ev_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
+                "prep_ms": prep_ms, "compare_ms": k2_ms,
+                "note": ("sparse tiles + pair list: only the 32 x 256 tiles a family's rows and columns meet in are walked, pairs of different families that share a value "
+                         "come from a list, the rest of the output is a fill with the value of 0 equal registers; D2G_BS_SPARSE=0 walks every tile (dense_walk below)"
                          if sparse_ran else "equality counting is VALU-bound, not HBM-bound (SURVEY 8d); see compute")}
 
     def valu(pairs, mean_planes, ms, sp=None):
@@ -1249,7 +1287,7 @@ def run_single(args):
         ab = 8 * S * n + 4 * npairs
         return {"sketches": n, "pairs_per_s": npairs / d, "ms_per_step": d * 1e3, "kernel_ms": kms, "prep_ms": pms,
                 "bit_planes_max": nb, "bit_planes_mean": mean, "max_shared_values_per_column_plus1": md,
-                "hbm_frac": ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if kms > 0 else 0.0,
+                "hbm_frac": ab / ((kms + pms) * 1e-3) / 1e9 / HBM_PEAK_GBS if (kms + pms) > 0 else 0.0,
                 "valu_frac": valu(npairs, mean, kms, sp)[1], "sparse": sp}
 
     config4 = None
@@ -1264,7 +1302,21 @@ def run_single(args):
                 mats["stated (clustered collection, %d clusters)" % max(8, N // 150)] = {
                     "sketches": N, "pairs_per_s": value, "ms_per_step": ms_per_step, "kernel_ms": k2_ms, "prep_ms": prep_ms,
                     "bit_planes_max": nbits, "bit_planes_mean": mean_nbits, "max_shared_values_per_column_plus1": max_distinct,
-                    "hbm_frac": achieved / HBM_PEAK_GBS, "valu_frac": vf}
+                    "hbm_frac": achieved / HBM_PEAK_GBS, "valu_frac": vf, "sparse": sparse_info}
+                # the SAME matrix with every tile walked (D2G_BS_SPARSE=0: round 3's algorithm): what the headline owes to the matrix's block structure
+                set_switch(ctx, "D2G_BS_SPARSE", "0")
+                try:
+                    dense_walk = measure_matrix(sig_np.view(np.uint64), N)
+                finally:
+                    set_switch(ctx, "D2G_BS_SPARSE", None)
+                dense_walk["note"] = "the stated matrix, D2G_BS_SPARSE=0: every 32 x 256 tile walked by k2_bitslice_kernel"
+                mats["stated, dense walk (D2G_BS_SPARSE=0)"] = dense_walk
+                # the stated families + c chance collisions per sketch with random strangers (about half of them with values the stranger shares with
+                # its whole family): the case real collections present (conserved k-mers across genera).  Round 4 listed nearly every tile at c = 10.
+                for c in (1, 10, 100):
+                    sg, _ = make_sketches(N, collisions=c)
+                    mats["stated + %d chance collisions per sketch" % c] = measure_matrix(sg.view(np.uint64), N)
+                    del sg
                 mats["unrelated (no value shared by two sketches)"] = measure_matrix(synth.unrelated_registers(N, S), N)
                 mats["adversarial (every value occurs exactly twice in its column)"] = measure_matrix(synth.paired_registers(N, S), N)
                 # columns that share between 0 and 64 values (log-uniform): which column lands in which 32-register group matters,
@@ -1272,11 +1324,11 @@ def run_single(args):
                 # plane class before grouping, the default) and with the caller's column order (D2G_BS_SORT=0).
                 sk = synth.skewed_registers(N, S)
                 mats["skewed (columns share 0..64 values, log-uniform)"] = measure_matrix(sk, N)
-                os.environ["D2G_BS_SORT"] = "0"
+                set_switch(ctx, "D2G_BS_SORT", "0")
                 try:
                     mats["skewed, columns left in the caller's order (D2G_BS_SORT=0)"] = measure_matrix(sk, N)
                 finally:
-                    os.environ.pop("D2G_BS_SORT", None)
+                    set_switch(ctx, "D2G_BS_SORT", None)
                 del sk
             except Exception as e:                               # noqa: BLE001 - reported in the line
                 mats["error"] = f"{type(e).__name__}: {e}"
@@ -1511,16 +1563,16 @@ def run_single(args):
             except (OSError, ValueError, KeyError, ZeroDivisionError):
                 return None
 
-        os.environ.pop("D2G_K3_COMPACT", None)
+        set_switch(ctx, "D2G_K3_COMPACT", None)
         mdt, ncalls, k3_ms = k3_measure()
         sig_default = sig3.clone()
         # the low-traffic variant of the same chain (4-byte stored words + tile-sorted split, D2G_K3_COMPACT=1): identical results
-        os.environ["D2G_K3_COMPACT"] = "1"
+        set_switch(ctx, "D2G_K3_COMPACT", "1")
         try:
             cdt, _, ck3_ms = k3_measure()
             same = bool(torch.equal(sig3.view(torch.int64), sig_default.view(torch.int64)))
         finally:
-            os.environ.pop("D2G_K3_COMPACT", None)
+            set_switch(ctx, "D2G_K3_COMPACT", None)
         del sig_default
         k3_bytes = nb * ((L + 3) // 4 + 8 * S3 + 8)
         ach = k3_bytes / (k3_ms * 1e-3) / 1e9 if k3_ms > 0 else 0.0
@@ -1573,11 +1625,28 @@ def run_single(args):
                 rf["traffic"], rf["traffic_source"] = tm[key], src_ok
             elif rf.get("traffic") is not None:
                 rf["traffic_source"] = src_bad
-        put(roofline, "k2")
-        if tm.get("k2_prepare"):
-            roofline["traffic_prepare_chain"] = tm["k2_prepare"]
+        st = tm.get("k2_step")
+        if isinstance(st, dict):
+            cal = st.get("calibration") or {}
+            scale = cal.get("read_scale") or 1.0
+            roofline["traffic"] = st["read_raw"] * scale + st["write"]
+            roofline["traffic_over_algorithmic"] = roofline["traffic"] / alg_bytes
+            roofline["traffic_detail"] = dict(st, compare_launch_raw=tm.get("k2"), prepare_chain_raw=tm.get("k2_prepare"))
+            roofline["traffic_source"] = src_ok
+        else:
+            roofline["traffic_source"] = "not measured: " + str(tm.get("error", "no K2 rows in the counter output"))
         if isinstance(sketch, dict) and "roofline" in sketch:
             put(sketch["roofline"], "k1")
+            wi = tm.get("k1_valu_wave_insts")
+            if wi and sketch["roofline"].get("kernel_ms"):
+                # SQ_INSTS_VALU of the ONE 1000-genome dispatch (wave-instructions; x 64 lanes) over that launch's duration against the VALU
+                # peak, and per base: the "VALU-bound at ~125 issue slots per base" claim, checkable from the line
+                lane = wi * 64.0
+                bases_l = args.sketch_genomes * args.sketch_len
+                sketch["roofline"]["valu"] = {"wave_insts": wi, "lane_ops": lane, "achieved": lane / (sketch["roofline"]["kernel_ms"] * 1e-3), "peak": VALU_PEAK_LANEOPS,
+                                              "unit": "lane-ops/s", "frac": lane / (sketch["roofline"]["kernel_ms"] * 1e-3) / VALU_PEAK_LANEOPS,
+                                              "valu_wave_insts_per_base_per_lane": wi * 64.0 / bases_l,
+                                              "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU, the 1000-genome k1_oph_kernel dispatch"}
         if isinstance(multiset, dict) and "roofline" in multiset:
             put(multiset["roofline"], "k3")
             if isinstance(multiset.get("low_traffic_variant"), dict):
@@ -1598,6 +1667,8 @@ def run_single(args):
                        "step": "prepare + pair kernel w/ fused epilogue; sketches resident in HBM",
                        "parallelism": "one GPU"},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "config4_1gpu": config4,
+            "dense_walk": (compute.get("matrices") or {}).get("stated, dense walk (D2G_BS_SPARSE=0)"),
+            "tuning": ctx.tuning(),
             "sketch": sketch, "multiset_sketch": multiset,
         }
         # compact copies of the two secondary legs INSIDE roofline / cpu_baseline: these two objects are what the driver's

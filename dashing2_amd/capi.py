@@ -47,6 +47,8 @@ SIGNATURES = {
     "d2g_ctx_destroy": (None, [_vp]),
     "d2g_last_error": (_cp, [_vp]),
     "d2g_ctx_device": (_int, [_vp]),
+    "d2g_ctx_reload_tuning": (_int, [_vp]),
+    "d2g_ctx_tuning": (_int, [_vp, C.c_char_p, _sz]),
     "d2g_sync": (_int, [_vp, _vp]),
     "d2g_malloc": (_int, [_vp, _sz, C.POINTER(_vp)]),
     "d2g_free": (_int, [_vp, _vp]),
@@ -155,6 +157,12 @@ SIGNATURES = {
     "d2g_cmp_dist_ut": (_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _int, _int, _int, _int, _int, _vp]),
     "d2g_ut_partition": (_int, [_sz, _int, C.POINTER(_sz)]),
 }
+
+
+def sparse_info_dict(a):
+    """info4 of d2g_cmp_set_sparse_info / d2g_allpairs_sparse_info as a dict"""
+    return {"sorted_operand": bool(a[0]), "tiles_listed": int(a[1]), "dense_decided_by_prepare": bool(a[2] & 1), "dense_kernel_ran": bool(a[2] & 2),
+            "tiles_and_pair_list": bool(a[2] & 4), "callers_order_kept": bool(a[2] & 8), "pairs_listed": int(a[3])}
 
 
 def lib():
@@ -380,6 +388,18 @@ class Context:
 
     def sync(self, stream=None):
         self._check(lib().d2g_sync(self._h, stream))
+
+    def reload_tuning(self):
+        """the D2G_* switches are read once, at context creation: read them again (tests that change one between calls)"""
+        self._check(lib().d2g_ctx_reload_tuning(self._h))
+
+    def tuning(self):
+        """-> dict of the D2G_* switches this context resolved (only those that were set)"""
+        import json
+        n = lib().d2g_ctx_tuning(self._h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib().d2g_ctx_tuning(self._h, buf, n + 1)
+        return json.loads(buf.value.decode())
 
     def set_timing(self, on=True):
         """True / False, or an OR of TIME_K1 / TIME_K2 / TIME_K2PREP / TIME_K3 (time only what is reported: an event pair in
@@ -721,8 +741,7 @@ class CmpSet:
         """-> dict of the sparse path's last upper-triangle launch (synchronises)"""
         a = np.zeros(4, np.uint32)
         self.ctx._check(lib().d2g_cmp_set_sparse_info(self.ctx._h, self._h, stream, a.ctypes.data))
-        return {"sorted_operand": bool(a[0]), "tiles_listed": int(a[1]), "marking_gave_up": bool(a[2] & 1), "dense_kernel_ran": bool(a[2] & 2),
-                "tiles_from_segments": bool(a[2] & 4), "callers_order_kept": bool(a[3])}
+        return sparse_info_dict(a)
 
     def planes(self, stream=None):
         """-> (max shared values per column + 1, max id planes of a group, mean id planes); zeros for DIRECT"""
@@ -913,8 +932,7 @@ class AllPairs:
         """-> dict of the sparse-tile path in this rank's last pair phase (synchronises the device); keys as CmpSet.sparse_info"""
         a = np.zeros(4, np.uint32)
         self.ctx._check(lib().d2g_allpairs_sparse_info(self._h, a.ctypes.data))
-        return {"sorted_operand": bool(a[0]), "tiles_listed": int(a[1]), "marking_gave_up": bool(a[2] & 1), "dense_kernel_ran": bool(a[2] & 2),
-                "tiles_from_segments": bool(a[2] & 4), "callers_order_kept": bool(a[3])}
+        return sparse_info_dict(a)
 
     def step_lut_dev(self, rows_ptr, lut_ptr, out_ptr, stream=None):
         self.ctx._check(lib().d2g_allpairs_step_lut_dev(self._h, rows_ptr, lut_ptr, out_ptr, stream))

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <string>
+#include <utility>
 
 #include <vector>
 // every timed launch appends a (start, stop) pair; nothing synchronises until the caller asks
@@ -11,8 +12,22 @@ struct d2g_evlog {
     std::vector<hipEvent_t> a, b;
 };
 
+// Every D2G_* switch that selects a kernel, a threshold or a test hook inside the library is read from the environment ONCE per context
+// (d2g_ctx_create; again only on d2g_ctx_reload_tuning) and used from this snapshot: a run's timing does not depend on who changed
+// the environment in between, d2g_ctx_tuning reports the resolved set, and the multi-GPU engine compares it across ranks.
+struct d2g_tuning {
+    std::vector<std::pair<std::string, std::string>> kv;      // the switches that were set, in the order of d2g_tuning_names()
+    const char *get(const char *name) const {                 // nullptr = not set
+        for (const auto &p : kv) if (p.first == name) return p.second.c_str();
+        return nullptr;
+    }
+};
+void d2g_tuning_load(d2g_tuning &t);
+uint64_t d2g_tuning_hash(const d2g_tuning &t, const char *prefix_a, const char *prefix_b);   // FNV-1a over the switches whose name starts with either prefix
+
 struct d2g_ctx {
     int device = -1;
+    d2g_tuning tune;
     int num_cus = 0;
     std::string last_error;
     int timing = 0;                         // D2G_TIME_* mask (d2g_set_timing)

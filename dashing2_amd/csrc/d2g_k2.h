@@ -36,11 +36,10 @@ struct d2g_cmp_set {
     // points the set at the status words every rank's prepare contributed
     bool managed = false;
     const uint32_t *status_words = nullptr; int n_status = 0;
-    // ---- sparse tiles (d2g_k2_bitslice.hip section 4; owning sets only).  The sketches are put in an order that brings sketches
-    // which share register values next to each other (labels = smallest sketch index reachable over shared values), the plane
-    // stream is built in THAT order, and an upper-triangle launch only walks the 32 x 256 tiles that hold at least one pair with a
-    // shared value (every other pair has 0 matches: the output is pre-filled with the value of 0).  Exact for any input; what the
-    // order and the tile list cost is paid back when similarity is block-structured (collections of related genomes).
+    // ---- sparse tiles + pair list (d2g_k2_sparse.h).  The sketches are put in an order that makes a family -- sketches that agree in
+    // many registers -- a run of adjacent positions, the plane stream is built in THAT order, and an upper-triangle launch walks only
+    // the 32 x 256 tiles a family's rows and columns meet in; pairs of DIFFERENT families that share a value by chance are counted from
+    // a pair list; every other pair has 0 matches (the output is pre-filled with the value of 0).  Exact for any input.
     bool sparse_ok = false;       // eligible and enabled (D2G_BS_SPARSE, D2G_BS_SPARSE_MIN_N)
     unsigned sp_launch = 0;       // sparse launches so far: the control words are double-buffered (a launch zeroes the next one's)
     size_t ncols = 0;             // register columns the sparse path walks: S, or all ntb * 32 register slots of an engine-managed gathered operand
@@ -50,16 +49,24 @@ struct d2g_cmp_set {
     uint32_t *d_stream_s = nullptr;   // plane stream in sorted order
     uint32_t *d_sperm = nullptr;      // [Nstride] sketch at sorted position p (0xFFFFFFFF = padding)
     uint32_t *d_sinv = nullptr;       // [Npad]    sorted position of sketch j
-    uint32_t *d_label = nullptr;      // [2][Npad] labels (two buffers: pointer jumping)
-    uint32_t *d_lcnt = nullptr;       // [Npad+1]  counting sort: sketches per label, then their start positions
+    uint32_t *d_label = nullptr;      // [2][Npad] union-find labels (-> segment starts after the sort) | root of every sketch
+    uint32_t *d_hint = nullptr;       // [2][Npad] per sketch the smallest holder of a value it shares (even / odd column pairs), 0xFFFFFFFF = none
+    uint32_t *d_spz = nullptr;        // ONE block the prepare clears: the five arrays below
+    size_t spz_words = 0;
+    uint32_t *d_lcnt = nullptr;       // [Npad+1]  counting sort: sketches per root, then the placing cursors (= segment ends)
+    uint32_t *d_linked = nullptr;     // [Npad]    1 = some column pair united this sketch with another
+    uint32_t *d_gbm = nullptr;        // 8 control words + the tile bitmap over ALL sorted row blocks (the segments' tiles); partial launches derive theirs from it
+    uint32_t *d_order = nullptr;      // [8] [0] 1 = the launches walk every tile of the caller's-order operand (dense), [2] deep label chains
+    uint32_t *d_plctl = nullptr;      // [8] [0] entries emitted into the pair list
     uint32_t *d_rowpos = nullptr;     // [Nstride] launch rows: sorted position of launch row k
     uint32_t *d_rowk = nullptr;       // [Npad]    launch row of sketch j (0xFFFFFFFF = not a row of this launch)
     uint32_t *d_rowstream = nullptr;  // [planes][Nstride] row-coded words of the launch rows, gathered (partial launches)
-    uint32_t *d_tilebm = nullptr, *d_tiles = nullptr, *d_spctl = nullptr;   // tile bitmap, worklist, {ntiles, flags}
-    uint32_t *d_gbm = nullptr;        // 8 control words + the tile bitmap over ALL sorted row blocks: marked once per prepare (first launch), partial launches derive theirs from it
-    bool gbm_valid = false;
-    uint32_t *d_order = nullptr;      // [1] 1 = the last prepare kept the caller's order (one label held most sketches)
-    uint32_t *d_slots = nullptr;      // [S][tile bitmap] one copy per register column (sp_mark_kernel), folded by sp_or_kernel
+    uint32_t *d_tilebm = nullptr, *d_tiles = nullptr, *d_spctl = nullptr;   // a partial launch's tile bitmap, work list, 2 x 8 control words {tiles listed, flags, -, candidates}
+    uint32_t *d_tiles_full = nullptr, *d_fullctl = nullptr;   // work lists + control words of a whole-triangle launch, left by the prepare (sp_permute_kernel)
+    bool full_list_valid = false;
+    const uint32_t *last_ctl = nullptr;   // control words of the last sparse launch (d2g_cmp_set_sparse_info)
+    unsigned long long *d_plist = nullptr;   // pair list: (i | j << 32), i < j caller's indices, one entry per (pair in different segments, shared value)
+    size_t plist_cap = 0;
     size_t tilebm_words = 0, tiles_cap = 0;
 };
 constexpr int BS_CC_STRIDE = 8;

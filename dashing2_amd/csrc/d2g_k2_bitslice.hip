@@ -447,16 +447,17 @@ __global__ __launch_bounds__(BS_PLAN_THREADS) void bs_colplan_kernel(uint32_t *_
 //                                        pointer simply advances by one block per plane (no per-plane address selection).
 // Register slot x of group tb holds column perm[32 tb + x] (bs_colplan_kernel).
 constexpr int BS_FORM_STREAM = 1, BS_FORM_EXCHANGE = 2;
-// start-of-prepare work of the sparse-tile path (section 4) carried by a kernel that runs anyway (bs_planes_kernel, sp_unpack_kernel)
-// instead of a launch and a memset of its own: label[j] = j, cnt[j] = 0, order[1] = `inexact`, `zwords` words at `zero` cleared
+// start-of-prepare work of the sparse path (section 4) carried by a kernel that runs anyway (bs_planes_kernel, sp_unpack_kernel)
+// instead of a launch and memsets of its own: label[j] = j, `owords` words at `ones` set to all-ones (the hints), `zwords` words at
+// `zero` cleared (counters, linked flags, tile bitmap + control words, order words, the pair list's cursor)
 struct SpInit {
-    uint32_t *label = nullptr, *cnt = nullptr, *order = nullptr, *zero = nullptr;
-    uint32_t n = 0, inexact = 0, zwords = 0;
+    uint32_t *label = nullptr, *ones = nullptr, *zero = nullptr;
+    uint32_t n = 0, owords = 0, zwords = 0;
 };
 __device__ __forceinline__ void sp_init_part(const SpInit &si, size_t lin, size_t nthreads) {
     if (!si.label) return;
-    if (lin < si.n) { si.label[lin] = (uint32_t)lin; si.cnt[lin] = 0; }
-    if (lin == 0) { si.order[1] = si.inexact; si.order[2] = 0; }
+    if (lin < si.n) si.label[lin] = (uint32_t)lin;
+    for (size_t x = lin; x < si.owords; x += nthreads) si.ones[x] = 0xFFFFFFFFu;
     for (size_t x = lin; x < si.zwords; x += nthreads) si.zero[x] = 0;
 }
 constexpr size_t BS_SLACK = 64;          // words behind position Npad of every plane (Nstride = Npad + BS_SLACK)
@@ -540,6 +541,7 @@ constexpr int BS_CB = 256;                // columns per workgroup tile (all var
 constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);   // mismatch accumulation
 
 __device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, uint32_t cand);   // section 4
+#include "d2g_k2_patch.h"
 
 // IW = 16 rows per wave (one s_load_dwordx16 per plane), JR = 64-column groups per lane,
 // WC = waves side by side along the columns (WC * JR * 64 = 256).  Per 32-register group: plane 0
@@ -637,12 +639,15 @@ __device__ __forceinline__ void bs_group(int nbits, const uint32_t *&ptr, uint32
 template <int JR, class Store>
 __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_kernel(
     const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb, uint32_t S, PairShape sh, Store store,
-    const uint32_t *__restrict__ gate, uint32_t gate_cand) {
+    const uint32_t *__restrict__ gate, uint32_t gate_cand, SpPatchArgs pa) {
     constexpr int IW = BS_IW;
     constexpr int WC = BS_CB / (64 * JR);          // waves along columns: 2 (JR=2)
     constexpr int WR = 4 / WC;                     // waves along rows
     constexpr int RB = WR * IW;                    // rows per workgroup tile
-    if (gate && !sp_dense_mode(gate, gate_cand)) return;   // launched behind the sparse path: only when that decided for the dense walk
+    if (gate && !sp_dense_mode(gate, gate_cand)) {           // launched behind the sparse path: the tile walk only when that decided for the dense walk;
+        sp_patch_lut(pa, sh, store, S, (size_t)blockIdx.x * BS_THREADS + threadIdx.x, (size_t)gridDim.x * BS_THREADS);   // otherwise the pair list's table epilogue
+        return;
+    }
     unsigned ct, rt;
     if (!tile_of_block(sh, blockIdx.x, ct, rt)) return;      // XCD-balanced, column-major wanted tiles
     const size_t i0 = sh.i_lo + (size_t)rt * RB;
@@ -713,804 +718,7 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
     }
 }
 
-// ------------------------------------------------------------------ 4. sparse tiles
-// An equality count is zero unless the two sketches share a value in at least one register column.  In a collection of related
-// genomes most pairs share nothing (different species), and the ones that do come in families.  So:
-//   prepare  FAMILIES = the connected components of "shares a value in some column": label propagation (sp_prop*: a label is an earlier
-//            member of the sketch's family) and ONE lock-free union-find pass over every column (sp_flatten / sp_union: exact components,
-//            no iteration); the sketches are counting-sorted by root (sp_count / scan / place) and the finished plane stream is permuted
-//            into THAT order (sp_permute) -- a family becomes a run of adjacent positions, a "segment";
-//   launch   the 32-row x 256-column tiles a segment's rows and columns meet in become a work list (every pair with a shared value lies
-//            inside one segment); when the segments would cover too much -- families that are large but sparse inside -- every shared
-//            value marks the tiles its holders meet in instead (sp_mark_kernel: bit sets per value in LDS); the output is pre-filled with
-//            the value of "0 equal registers"; the pair kernel walks the listed tiles only and stores where the count is not 0.
-// Nothing here is approximate: a tile that is not listed holds no pair with a common value -- by the components being exact in the
-// first case, by construction of the marks (whatever the order looks like) in the second.  If one family would take more than half of
-// the sketches (everything is connected), or the labels form long chains, the caller's order is kept and every tile is walked.  Rows of
-// a partial launch [r0, r1) are gathered (in sorted order) into a row operand of their own.
-constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
-#ifndef D2G_SP_WIDE_U
-#define D2G_SP_WIDE_U 8          // sketches per thread and step of the wide mark kernel (measured at N = 50 000: 8 -> 532 us, 16 -> 856 us)
-#endif
-#ifndef D2G_SP_WIDE_FOLD
-#define D2G_SP_WIDE_FOLD 0       // 0: a thread per row block ORs the values' sets into its bitmap row (532 us); 1: a work item per value and row word, atomicOr into the slot (777 us)
-#endif
-#ifndef D2G_SP_KS
-#define D2G_SP_KS 4
-#endif
-#ifndef SP_EXP_NO_GLOBAL_MARKS
-#define SP_EXP_NO_GLOBAL_MARKS 0       // timing experiment (tools/build_variant.sh): the mark kernel without its global phase
-#endif
-
-__device__ __forceinline__ uint32_t sp_rank(uint32_t w, const uint32_t *__restrict__ colcnt, size_t t, bool split) {
-    if ((w >> 31) || w == 0) return 0;          // unique (or padding): never equal to anything
-    return split ? (w & BS_RANK_MASK) + colcnt[t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)] : w;
-}
-
-__device__ __forceinline__ uint32_t sp_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// Label propagation, one workgroup walking SEVERAL columns one after the other: per column, the smallest LIVE label among the holders of
-// each shared value (LDS), then every holder takes it.  The columns a workgroup walks later see what all workgroups wrote before, so one
-// launch does the work of several synchronous rounds: a family whose first member shares registers with only some of the others is under
-// one root after it, where one synchronous round (min over frozen labels, then a gather per sketch: rounds 1-3 of this file) left two.
-// Labels are written with PLAIN stores: a label is only ever replaced by a smaller index of the same family (v <= the holder's own label
-// <= its index), so whichever of two racing stores lands last -- or whichever XCD's L2 writes its copy of the line back last -- the array
-// still holds, per sketch, a member of its family that is no later than itself: all the sort needs (it hops to the root), and the tiles
-// are checked (sp_check_kernel) or marked exactly afterwards whatever the order.  (atomicMin instead: every column moves every holder's
-// label through a device-scope atomic on one 40 KB array: 46 us instead of 17 at config 3.)
-__global__ __launch_bounds__(1024) void sp_prop_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt,
-                                                       int split, uint32_t cap, uint32_t *__restrict__ label) {
-    extern __shared__ uint32_t sp_g[];
-    const uint32_t T = blockDim.x;
-    for (size_t t = blockIdx.x; t < ncols; t += gridDim.x) {
-        const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
-        if (d2 == 0) continue;
-        const uint32_t nv = min(d2, cap);                              // values beyond the table take no part (the order is a heuristic; exactness is checked later)
-        for (uint32_t r = threadIdx.x; r < nv; r += T) sp_g[r] = SP_NONE;
-        __syncthreads();
-        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
-            uint32_t w[8], kk[8];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const size_t j = j0 + (size_t)x * T + threadIdx.x;
-                w[x] = j < N ? ids[t * Npad + j] : 0u;
-                kk[x] = j < N ? sp_ld(&label[j]) : SP_NONE;
-            }
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
-                if (r && r <= nv) atomicMin(&sp_g[r - 1], kk[x]);
-            }
-        }
-        __syncthreads();
-        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
-            uint32_t w[8], kk[8];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const size_t j = j0 + (size_t)x * T + threadIdx.x;
-                w[x] = j < N ? ids[t * Npad + j] : 0u;
-                kk[x] = j < N ? sp_ld(&label[j]) : 0u;
-            }
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
-                if (!r || r > nv) continue;
-                const uint32_t v = sp_g[r - 1];
-                if (v < kk[x]) label[j0 + (size_t)x * T + threadIdx.x] = v;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// the same for N <= 1024 U sketches: a thread keeps its U ids and labels of a column in registers between the two passes (one round of
-// loads per column instead of two times ceil(N / 8192))
-template <int U>
-__global__ __launch_bounds__(1024) void sp_prop_reg_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt,
-                                                           int split, uint32_t cap, uint32_t *__restrict__ label) {
-    extern __shared__ uint32_t sp_g[];
-    for (size_t t = blockIdx.x; t < ncols; t += gridDim.x) {
-        const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
-        if (d2 == 0) continue;
-        const uint32_t nv = min(d2, cap);
-        uint32_t w[U], kk[U];
-#pragma unroll
-        for (int x = 0; x < U; ++x) {
-            const size_t j = (size_t)x * 1024 + threadIdx.x;
-            w[x] = j < N ? ids[t * Npad + j] : 0u;
-            kk[x] = j < N ? sp_ld(&label[j]) : SP_NONE;
-        }
-        for (uint32_t r = threadIdx.x; r < nv; r += 1024) sp_g[r] = SP_NONE;
-        __syncthreads();
-#pragma unroll
-        for (int x = 0; x < U; ++x) {
-            w[x] = sp_rank(w[x], colcnt, t, split != 0);
-            if (w[x] > nv) w[x] = 0;
-            if (w[x]) atomicMin(&sp_g[w[x] - 1], kk[x]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int x = 0; x < U; ++x) {
-            if (!w[x]) continue;
-            const uint32_t v = sp_g[w[x] - 1];
-            if (v < kk[x]) label[(size_t)x * 1024 + threadIdx.x] = v;
-        }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void sp_jump_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t N) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j < N) out[j] = in[in[j]];
-}
-
-// label[] maps a sketch to an earlier (or the same) sketch of its family; the root is where that stops -- the TRUE root, always: the
-// segments are exact only then.  Most chains end after one or two hops; the union pass's hooks can leave long ones (a collection that is
-// one chain hooks i + 1 under i for every i), so the walk halves the path behind it like sp_flatten_kernel (label[l] < l off the root: it ends)
-__device__ __forceinline__ uint32_t sp_root(uint32_t *label, size_t j) {
-    // (plain loads: nobody hooks roots while this runs, and a stale label is still an ancestor -- a device-scope load per hop costs 3-4x as much)
-    uint32_t l = (uint32_t)j;
-    for (;;) {
-        const uint32_t p = label[l];
-        if (p == l) break;
-        const uint32_t g = label[p];
-        if (g != p) label[l] = g;
-        l = p;
-    }
-    return l;
-}
-
-// block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, *total = the sum
-__device__ __forceinline__ uint32_t sp_block_scan(uint32_t v, uint32_t *wave_tot, uint32_t *total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
-    __syncthreads();
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) { const uint32_t x = wave_tot[w]; if (w < wave) woff += x; tot += x; }
-    *total = tot;
-    return woff + incl - v;
-}
-
-// counting sort of the sketches by the root of their label, three small kernels (one thread per sketch, then one workgroup for the
-// prefix, then one thread per sketch again).  The roots of a family collection are few and their counters hot, but with a thread
-// per sketch every thread waits for ONE atomic; a single workgroup walking all sketches waited for ten in a row (N = 50 000: 225 us,
-// now ~25).  One root holding more than half of the sketches (everything is connected) keeps the caller's order: order[0] = 1.
-__global__ __launch_bounds__(256) void sp_count_kernel(uint32_t *label, uint32_t *__restrict__ root, size_t N, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ order) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = j < N;
-    if (order[2]) { if (live) root[j] = (uint32_t)j; return; }        // deep chains: no walks; the scan keeps the caller's order
-    const uint32_t r = live ? sp_root(label, j) : SP_NONE;
-    if (live) root[j] = r;
-    // when everything hangs together ONE counter takes all N increments (measured: 115 us at N = 10 000): the lanes that share the
-    // wave's first root add once; the others go one by one (matching every distinct root of a wave costs more than it saves when a
-    // wave holds 64 different ones: 64 rounds of ballot + shuffle, + 40-100 us on the family / unrelated matrices)
-    const unsigned long long alive = __ballot(live);
-    if (!alive) return;
-    const uint32_t lead = __shfl(r, __ffsll((long long)alive) - 1);
-    const unsigned long long m = __ballot(live && r == lead);
-    if (live && r == lead) { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[lead], (uint32_t)__popcll(m)); }
-    else if (live) atomicAdd(&cnt[r], 1u);
-}
-__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t seg_tile_limit) {
-    // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
-    __shared__ uint32_t wave_tot[16];
-    __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
-    __shared__ uint32_t s_big, s_run, s_est;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x;
-    if (tid == 0) { s_big = 0; s_run = 0; s_est = 0; }
-    uint32_t est = 0;                                                  // tiles the segments would cover (both triangles), saturating
-    __syncthreads();
-    // the next tile's counters are requested before this tile is scanned (one workgroup: nothing else hides the round trip)
-    uint32_t pre[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { const size_t x = (size_t)k * 1024 + tid; pre[k] = x < N ? cnt[x] : 0u; }
-    for (size_t base = 0; base < N; base += 8192) {
-        const uint32_t n = (uint32_t)min((size_t)8192, N - base);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tile[k * 1024 + tid] = pre[k];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const size_t x = base + 8192 + (size_t)k * 1024 + tid; pre[k] = x < N ? cnt[x] : 0u; }
-        uint32_t v[8], sum = 0, big = 0;
-        {   // a thread's eight counters as two 16-byte LDS reads (one word at a time: stride 8 words, an 8-way bank conflict)
-            const u32x4 a = reinterpret_cast<const u32x4 *>(tile)[tid * 2], b = reinterpret_cast<const u32x4 *>(tile)[tid * 2 + 1];
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            sum += v[x]; big = max(big, v[x]);
-            // in sixteenths of a tile: a segment of c >= 32 sketches covers at most (rows + 1) x (columns + 1) tiles; smaller ones share their
-            // row block with their neighbours (two column tiles for c / 32 of a row block)
-            const uint32_t c = min(v[x], 32768u);                    // (a segment that long is past any limit by itself)
-            est += c >= 32 ? 16u * ((c + 31) / 32 + 1) * ((c + 255) / 256 + 1) : (c >= 2 ? c : 0u);
-        }
-        est = min(est, 0x0FFFFFFFu);
-        if ((size_t)big * 2 > N) s_big = 1;
-        uint32_t total;
-        uint32_t run = sp_block_scan(sum, wave_tot, &total) + s_run;
-        {
-            uint32_t o[8];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) { o[x] = run; run += v[x]; }
-            reinterpret_cast<u32x4 *>(tile)[tid * 2] = u32x4{o[0], o[1], o[2], o[3]};
-            reinterpret_cast<u32x4 *>(tile)[tid * 2 + 1] = u32x4{o[4], o[5], o[6], o[7]};
-        }
-        __syncthreads();
-        for (uint32_t x = tid; x < n; x += 1024) { cnt[base + x] = tile[x]; start[base + x] = tile[x]; }   // cnt becomes the placing cursor (-> segment end), start stays
-        if (tid == 0) s_run += total;
-        __syncthreads();
-    }
-    est = min(est, 0x3FFFFFu) / 16 + 1;                                 // 1024 threads x 2^18: no overflow
-    for (int o = 32; o > 0; o >>= 1) est += __shfl_down(est, o);
-    if ((tid & 63) == 0) atomicAdd(&s_est, est);
-    __syncthreads();
-    if (tid == 0) { const uint32_t keep = s_big | (order[2] ? 1u : 0u); order[0] = keep; if (keep || s_est > seg_tile_limit + 1024) order[1] = 1; }
-}
-__global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
-                                                        uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = j < N;
-    if (!live && j < Nstride) sperm[j] = SP_NONE;
-    if (order[0]) { if (live) { sperm[j] = (uint32_t)j; sinv[j] = (uint32_t)j; } return; }
-    const uint32_t r = live ? root[j] : SP_NONE;
-    const int lane = threadIdx.x & 63;
-    uint32_t p = 0;
-    const unsigned long long alive = __ballot(live);
-    if (!alive) return;
-    // as in sp_count_kernel: the lanes that share the wave's first root move its cursor once (and keep their order), the others one by one
-    const uint32_t lead = __shfl(r, __ffsll((long long)alive) - 1);
-    const unsigned long long m = __ballot(live && r == lead);
-    const int first = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == first) base = atomicAdd(&cnt[lead], (uint32_t)__popcll(m));
-    base = __shfl(base, first);
-    if (live && r == lead) p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-    else if (live) p = atomicAdd(&cnt[r], 1u);
-    if (live) { sperm[p] = (uint32_t)j; sinv[j] = p; }
-}
-
-// the sorted stream from the caller's-order stream: position p takes the words of sketch sperm[p].  Only the row-coded words and
-// ONE column-coded word per group are gathered (the unique plane is their difference in any plane: r ^ c = u where the register
-// is column-unique, 0 elsewhere); both codings are written.
-__global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restrict__ nat, uint32_t *__restrict__ srt, size_t Nstride, const uint32_t *__restrict__ meta,
-                                                         const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ order) {
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int tb = blockIdx.y;
-    if (p >= Nstride || order[0]) return;                             // the caller's order was kept: every launch walks the caller's-order stream (dense), nobody reads this one
-    const int nbits = live_planes(meta, tb);
-    const size_t slot = stream_slot(meta, tb);
-    const uint32_t j = sperm[p];
-    uint32_t *dst = srt + slot * 2 * Nstride + p;
-    if (j == SP_NONE) {
-        for (int b = 0; b < nbits; ++b) { dst[(size_t)(2 * b) * Nstride] = 0; dst[(size_t)(2 * b + 1) * Nstride] = 0; }
-        return;
-    }
-    const uint32_t *src = nat + slot * 2 * Nstride + j;
-    const uint32_t u = src[0] ^ src[Nstride];
-    for (int b = 0; b < nbits; ++b) {
-        const uint32_t w = src[(size_t)(2 * b) * Nstride];
-        dst[(size_t)(2 * b) * Nstride] = w;
-        dst[(size_t)(2 * b + 1) * Nstride] = w | u;
-    }
-}
-
-// launch rows: the sorted positions whose sketch lies in [r0, r1), in sorted order (stable compaction, one workgroup; 8192 positions at
-// a time through LDS so that the loads are coalesced and a thread still owns eight consecutive positions: N = 50 000 80 -> ~12 us)
-__global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restrict__ sperm, size_t N, uint32_t r0, uint32_t r1, uint32_t nrows_pad,
-                                                       uint32_t *__restrict__ rowpos, uint32_t *__restrict__ rowk) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
-    __shared__ uint32_t s_run;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int tid = threadIdx.x;
-    if (tid == 0) s_run = 0;
-    __syncthreads();
-    uint32_t pre[8];                                                   // the next tile is requested before this one is compacted (as in sp_scan_kernel)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { const size_t x = (size_t)k * 1024 + tid; pre[k] = x < N ? sperm[x] : SP_NONE; }
-    for (size_t base = 0; base < N; base += 8192) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) tile[k * 1024 + tid] = pre[k];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { const size_t x = base + 8192 + (size_t)k * 1024 + tid; pre[k] = x < N ? sperm[x] : SP_NONE; }
-        uint32_t jv[8], cnt = 0;
-        {
-            const u32x4 a = reinterpret_cast<const u32x4 *>(tile)[tid * 2], b = reinterpret_cast<const u32x4 *>(tile)[tid * 2 + 1];
-            jv[0] = a.x; jv[1] = a.y; jv[2] = a.z; jv[3] = a.w; jv[4] = b.x; jv[5] = b.y; jv[6] = b.z; jv[7] = b.w;
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x) cnt += (jv[x] >= r0 && jv[x] < r1) ? 1u : 0u;   // SP_NONE (beyond N) is in no range
-        uint32_t total;
-        uint32_t k = sp_block_scan(cnt, wave_tot, &total) + s_run;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            if (jv[x] == SP_NONE) continue;
-            const bool w = jv[x] >= r0 && jv[x] < r1;
-            rowk[jv[x]] = w ? k : SP_NONE;
-            if (w) rowpos[k++] = (uint32_t)(base + tid * 8 + x);
-        }
-        __syncthreads();
-        if (tid == 0) s_run += total;
-        __syncthreads();
-    }
-    for (uint32_t x = s_run + tid; x < nrows_pad; x += 1024) rowpos[x] = SP_NONE;
-}
-
-__global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb,
-                                                        const uint32_t *__restrict__ rowpos, uint32_t nrows_pad, uint32_t *__restrict__ rowstream, size_t rstride) {
-    const size_t q = blockIdx.y;
-    if (q >= stream_slot(meta, ntb)) return;
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= nrows_pad) return;
-    const uint32_t p = rowpos[k];
-    rowstream[q * rstride + k] = p != SP_NONE ? stream[2 * q * Nstride + p] : 0u;
-}
-
-// sorted position p: the first position of (its segment x its row block) sets the tiles of that row block against the segment's column blocks
-__device__ __forceinline__ void sp_segtiles(size_t p, const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ root, const uint32_t *__restrict__ start,
-                                            const uint32_t *__restrict__ end, size_t N, uint32_t CW, uint32_t *__restrict__ gbm) {
-    if (p >= N) return;
-    const uint32_t r = root[sperm[p]];
-    const uint32_t a = start[r], b = end[r];
-    if (b - a < 2 || !(p == a || (p & 31) == 0)) return;              // a sketch alone under its root shares nothing with anybody
-    const uint32_t rb = (uint32_t)(p >> 5), cb0 = a >> 8, cb1 = (b - 1) >> 8;
-    for (uint32_t cw = cb0 >> 5; cw <= cb1 >> 5; ++cw) {
-        const uint32_t lo = cw == (cb0 >> 5) ? (cb0 & 31) : 0u, hi = cw == (cb1 >> 5) ? (cb1 & 31) : 31u;
-        const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-        atomicOr(&gbm[(size_t)rb * CW + cw], m);
-    }
-}
-
-// Per register column: every shared value marks the tiles its holders meet in.  LDS: for `gm` values at a time, a bit set of the
-// launch-row blocks (32 rows) and one of the column blocks (256 sorted positions) the value occurs in.  A value whose holders
-// meet in more than a quarter of all tiles says the matrix is not sparse: it raises the ALL flag (ctl[1] bit 0) and marking stops.
-// The marks of a column go to the column's OWN copy of the tile bitmap (`slots`), which sp_or_kernel folds into one afterwards:
-// every column marks the same few hundred tiles, and 1024 workgroups testing / setting the same 2.5 KB through device-scope
-// operations all queue at one memory channel (measured: 48 of the kernel's 70 us at config 3).
-template <int U>
-__global__ __launch_bounds__(512) void sp_mark_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
-                                                      const uint32_t *__restrict__ sinv, const uint32_t *__restrict__ rowk, uint32_t gm, uint32_t RW, uint32_t CW,
-                                                      uint32_t nrb, uint32_t ncb, uint32_t lbm_words, uint32_t *__restrict__ slots, uint32_t *__restrict__ ctl,
-                                                      const uint32_t *__restrict__ order_kept, const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ root,
-                                                      const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, uint32_t *__restrict__ segbm) {
-    extern __shared__ uint32_t sp_lds_all[];
-    __shared__ uint32_t s_stop;
-    // lbm_words != 0: the column's bitmap is built in LDS and stored once; otherwise (large N) it is built in the slot with atomics
-    uint32_t *lbm = sp_lds_all;
-    uint32_t *sp_lds = sp_lds_all + lbm_words;
-    const size_t t = blockIdx.x;
-    const uint32_t T = blockDim.x;                                    // 256, or 512 with a bigger share of the LDS (large N)
-    const uint32_t words = nrb * CW;
-    uint32_t *slot = slots + t * (size_t)words;
-    if (!order_kept[1]) {                                             // the sort's segments give the tiles (sp_union_kernel): no marking, the grid's threads
-        if (segbm)                                                    // share the sorted positions instead
-            for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < N; p += (size_t)gridDim.x * blockDim.x) sp_segtiles(p, sperm, root, seg_start, seg_end, N, CW, segbm);
-        return;
-    }
-    const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
-    // one family holds most sketches (the prepare kept the caller's order), or this column's shared values have fewer than four holders
-    // on average (pairs, not families), or it would take more than 32 passes of bit sets: not a matrix the tile list can help
-    if (d2 && (order_kept[0] || (size_t)d2 * 4 > N || d2 > 32 * gm)) { if (threadIdx.x == 0) atomicOr(&ctl[1], 1u); return; }
-    if (d2 == 0 || !lbm_words) {
-        for (uint32_t x = threadIdx.x; x < words; x += T) slot[x] = 0;
-        if (d2 == 0) return;
-        __threadfence();
-    }
-    const uint32_t W = RW + CW;
-    const uint32_t dense_limit = max(16u, (uint32_t)(((size_t)nrb * ncb) / 4));
-    for (uint32_t x = threadIdx.x; x < lbm_words; x += T) lbm[x] = 0;
-    for (uint32_t base = 0; base < d2; base += gm) {
-        if (threadIdx.x == 0) s_stop = sp_ld(&ctl[1]) & 1u;            // marking stops for everybody once somebody gave up
-        const uint32_t n = min(gm, d2 - base);
-        for (uint32_t x = threadIdx.x; x < n * W; x += T) sp_lds[x] = 0;
-        __syncthreads();
-        if (s_stop) return;
-        // U sketches per thread and step; the loads of the next step are issued before this step's bit sets are updated
-        uint32_t w[U], k[U], c[U];
-        auto load = [&](size_t j0) {
-#pragma unroll
-            for (int x = 0; x < U; ++x) {
-                const size_t j = j0 + (size_t)x * T + threadIdx.x;
-                w[x] = j < N ? ids[t * Npad + j] : 0u;
-                c[x] = j < N ? sinv[j] : 0u;
-                k[x] = j < N ? (rowk ? rowk[j] : c[x]) : SP_NONE;
-            }
-        };
-        load(0);
-        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * U) {
-            uint32_t cw_[U], ck[U], cc[U];
-#pragma unroll
-            for (int x = 0; x < U; ++x) { cw_[x] = w[x]; ck[x] = k[x]; cc[x] = c[x]; }
-            if (j0 + (size_t)T * U < N) load(j0 + (size_t)T * U);
-#pragma unroll
-            for (int x = 0; x < U; ++x) {
-                const uint32_t r = sp_rank(cw_[x], colcnt, t, split != 0);
-                if (!r || r - 1 < base || r - 1 >= base + n) continue;
-                uint32_t *bits = sp_lds + (size_t)(r - 1 - base) * W;
-#if SP_EXP_NO_GLOBAL_MARKS == 2
-                if (ck[x] == 0x12345678u) atomicOr(&bits[0], cc[x]);          // timing experiment: the loop without its LDS atomics
-#else
-                if (ck[x] != SP_NONE) atomicOr(&bits[ck[x] >> 10], 1u << ((ck[x] >> 5) & 31));
-                atomicOr(&bits[RW + (cc[x] >> 13)], 1u << ((cc[x] >> 8) & 31));
-#endif
-            }
-        }
-        __syncthreads();
-        // density guard, one thread per value
-        for (uint32_t q = threadIdx.x; q < n; q += T) {
-            const uint32_t *bits = sp_lds + (size_t)q * W;
-            uint32_t nr = 0, nc = 0;
-            for (uint32_t rw = 0; rw < RW; ++rw) nr += __popc(bits[rw]);
-            for (uint32_t cw = 0; cw < CW; ++cw) nc += __popc(bits[RW + cw]);
-            if (nr * nc > dense_limit) atomicOr(&ctl[1], 1u);
-        }
-        if (lbm_words) {
-            // fold into the LDS bitmap, one thread per value: row bits x column words, ds_or (typed LDS pointer: through a generic
-            // pointer that could also be the global slot these were flat atomics and cost 47 of the kernel's 69 us at config 3)
-            // (one work item per value AND row word: 66 values alone would leave three of the four waves idle)
-            for (uint32_t it = threadIdx.x; it < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : n * RW); it += T) {
-                const uint32_t q = it / RW, rw = it - q * RW;
-                const uint32_t *bits = sp_lds + (size_t)q * W;
-                uint32_t rbits = bits[rw];
-                while (rbits) {
-                    const uint32_t rb = rw * 32 + (uint32_t)__ffs(rbits) - 1;
-                    rbits &= rbits - 1;
-                    for (uint32_t cw = 0; cw < CW; ++cw) { const uint32_t cbits = bits[RW + cw]; if (cbits) atomicOr(&lbm[(size_t)rb * CW + cw], cbits); }
-                }
-            }
-        } else {
-#if D2G_SP_WIDE_FOLD == 0
-            for (uint32_t rb = threadIdx.x; rb < nrb; rb += T) {
-                const uint32_t rw = rb >> 5, rbit = 1u << (rb & 31);
-                for (uint32_t cw0 = 0; cw0 < CW; cw0 += 8) {
-                    uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    const uint32_t ncw = min(8u, CW - cw0);
-                    for (uint32_t q = 0; q < n; ++q) {
-                        const uint32_t *bits = sp_lds + (size_t)q * W;
-                        if (!(bits[rw] & rbit)) continue;
-#pragma unroll
-                        for (uint32_t x = 0; x < 8; ++x) if (x < ncw) acc[x] |= bits[RW + cw0 + x];
-                    }
-#pragma unroll
-                    for (uint32_t x = 0; x < 8; ++x) if (x < ncw && acc[x]) slot[(size_t)rb * CW + cw0 + x] |= acc[x];
-                }
-            }
-        }
-#else
-            // fold into the global slot (large N), one work item per value and row word: atomicOr without a return value into the column's
-            // OWN slot (nobody else touches it; zeroed + fenced above).  (One thread per row block reading all values' row words from
-            // LDS was measured at N = 50 000: 96 us of the workgroup's 250.)
-            for (uint32_t it = threadIdx.x; it < (SP_EXP_NO_GLOBAL_MARKS == 1 ? 0u : n * RW); it += T) {
-                const uint32_t q = it / RW, rw = it - q * RW;
-                const uint32_t *bits = sp_lds + (size_t)q * W;
-                uint32_t rbits = bits[rw];
-                while (rbits) {
-                    const uint32_t rb = rw * 32 + (uint32_t)__ffs(rbits) - 1;
-                    rbits &= rbits - 1;
-                    for (uint32_t cw = 0; cw < CW; ++cw) {
-                        const uint32_t cbits = bits[RW + cw];
-                        if (cbits) (void)__hip_atomic_fetch_or(&slot[(size_t)rb * CW + cw], cbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-        }
-#endif
-        __syncthreads();
-    }
-    for (uint32_t x = threadIdx.x; x < lbm_words; x += T) slot[x] = lbm[x];
-}
-
-// ---- tiles from the sort's segments.  After the propagation, ONE pass over every column unites whatever roots the holders of one shared
-// value still sit under (lock-free union-find on the label array: a root is hooked under a smaller one with a compare-and-swap; a pass
-// over every "edge" of the shares-a-value graph leaves exactly its connected components, no iteration).  The sort then puts every
-// component's sketches side by side, every pair with a shared value lies inside one segment, and the tiles a segment's rows and columns
-// meet in are a superset of the tiles that hold such a pair -- without the marking pass and its two bit sets per value (config 3:
-// 29 + 5 us -> 12 + 5; config 4: 531 + 9 -> 63 + 5).  The propagation has done nearly all the uniting with plain stores; this pass mostly
-// confirms (few compare-and-swaps).  order[1] != 0 ("inexact": a column has more shared values than the LDS table holds, the caller's
-// order was kept, or the segments would cover more than an eighth of all tiles -- components that are large but sparse inside, where
-// exact marks list far fewer tiles) sends the launches to the exact marking instead.
-__device__ __forceinline__ uint32_t sp_find(uint32_t *label, uint32_t l) {
-    for (int h = 0; h < 64; ++h) {                                    // bounded: sp_union retries, and gives up (-> exact marks) in the end
-        const uint32_t p = sp_ld(&label[l]);
-        if (p == l) break;
-        const uint32_t g = sp_ld(&label[p]);
-        if (g != p) label[l] = g;                                     // path halving: only a non-root's label moves, to one of its ancestors
-        l = p;
-    }
-    return l;
-}
-__device__ __forceinline__ bool sp_union(uint32_t *label, uint32_t a, uint32_t b) {
-    for (int it = 0; it < 64; ++it) {
-        a = sp_find(label, a); b = sp_find(label, b);
-        if (a == b) return true;
-        if (a < b) { const uint32_t x = a; a = b; b = x; }              // the larger root goes under the smaller one
-        if (atomicCAS(&label[a], a, b) == a) return true;               // a was still a root: hooked
-    }
-    return false;
-}
-// every label straight at its root before the union pass compares labels; the walk halves the path behind it.  Families leave chains of two
-// or three labels.  A chain that is not at its root after SP_MAX_HOPS hops means long strings of sketches that share registers with their
-// neighbours only (a time series; the extreme, ONE chain of N sketches, costs N / 2 dependent loads in the last thread: 0.7 ms at N = 12 000):
-// one big component in all likelihood, and nothing the tile list could help -- order[2] is raised, the union pass and the sort's root walks are
-// skipped, the caller's order is kept and the launches walk every tile (the same outcome as "one family holds most sketches", found early).
-// Racing with itself is harmless: a label is only ever replaced by an ancestor.  (plain loads, as in sp_root)
-constexpr int SP_MAX_HOPS = 64;
-__global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t N, uint32_t *__restrict__ order) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    uint32_t l = (uint32_t)j;
-    for (int h = 0;; ++h) {
-        const uint32_t p = label[l];
-        if (p == l) break;
-        if (h == SP_MAX_HOPS) { order[2] = 1; return; }
-        const uint32_t g = label[p];
-        if (g != p) label[l] = g;
-        l = p;
-    }
-    label[j] = l;
-}
-__global__ void sp_union_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, const uint32_t *__restrict__ colcnt, int split,
-                                uint32_t *label, uint32_t cap, uint32_t *__restrict__ order) {
-    extern __shared__ uint32_t sp_chk[];
-    const size_t t = blockIdx.x;
-    const uint32_t T = blockDim.x;
-    const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
-    if (d2 == 0 || order[2]) return;                                  // order[2]: deep chains (sp_flatten_kernel): the caller's order will be kept
-    if (d2 > cap) { if (threadIdx.x == 0) atomicOr(&order[1], 1u); return; }
-    for (uint32_t r = threadIdx.x; r < d2; r += T) sp_chk[r] = SP_NONE;
-    __syncthreads();
-    bool bad = false;
-    for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
-        uint32_t w[8], rt[8];
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const size_t j = j0 + (size_t)x * T + threadIdx.x;
-            w[x] = j < N ? ids[t * Npad + j] : 0u;
-            rt[x] = j < N ? sp_ld(&label[j]) : 0u;
-        }
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
-            if (!r) continue;
-            // the value's first holder leaves its label; a holder with the same label is under the same root without looking (the usual
-            // case after the propagation); only a different label costs the walk to the roots
-            const uint32_t old = atomicCAS(&sp_chk[r - 1], SP_NONE, rt[x]);
-            if (old != SP_NONE && old != rt[x]) bad |= !sp_union(label, old, rt[x]);
-        }
-    }
-    if (bad) atomicOr(&order[1], 1u);
-}
-
-// tile bitmap = OR over the columns' copies.  grid (words / 256, SP_OR_SPLIT): a thread folds S / SP_OR_SPLIT copies of one word.
-constexpr int SP_OR_SPLIT = 32;
-__global__ __launch_bounds__(256) void sp_or_kernel(const uint32_t *__restrict__ slots, uint32_t words, uint32_t S, uint32_t *__restrict__ tilebm,
-                                                    const uint32_t *__restrict__ ctl, const uint32_t *__restrict__ order) {
-    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= words || (ctl[1] & 1u) || !order[1]) return;
-    const uint32_t t0 = (uint32_t)((size_t)S * blockIdx.y / SP_OR_SPLIT), t1 = (uint32_t)((size_t)S * (blockIdx.y + 1) / SP_OR_SPLIT);
-    uint32_t acc = 0;
-    uint32_t t = t0;
-    for (; t + 8 <= t1; t += 8) {
-        uint32_t v[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = slots[(size_t)(t + i) * words + x];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc |= v[i];
-    }
-    for (; t < t1; ++t) acc |= slots[(size_t)t * words + x];
-    if (acc) atomicOr(&tilebm[x], acc);
-}
-
-// tile bitmap of a PARTIAL launch from the global one: a block of 32 launch rows may meet what any of the sorted row blocks its rows
-// come from may meet (a superset of the exact marks of those rows: still no tile with a match is missed)
-__global__ __launch_bounds__(256) void sp_rowbm_kernel(const uint32_t *__restrict__ gbm, const uint32_t *__restrict__ rowpos, uint32_t nrb, uint32_t CW,
-                                                       uint32_t *__restrict__ tilebm) {
-    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= nrb * CW) return;
-    const uint32_t rb = x / CW, cw = x - rb * CW;
-    uint32_t acc = 0;
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) { const uint32_t p = rowpos[rb * 32 + i]; if (p != SP_NONE) acc |= gbm[(size_t)(p >> 5) * CW + cw]; }
-    tilebm[x] = acc;
-}
-
-// the marked tiles as a work list (any order: a workgroup reserves the range of its tiles with one atomic).  full: rows are ALL
-// sorted positions and a pair is computed where row position < column position, so tiles entirely below that diagonal are not
-// candidates.  ctl[0] = tiles listed, ctl[3] = candidates (what the dense / sparse decision compares it with).
-__global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
-                                                       uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t cand, const uint32_t *__restrict__ gflags,
-                                                       uint32_t *__restrict__ ctl_next) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t s_base;
-    const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid < 8) ctl_next[tid] = 0;                // the next launch's control words (nobody else touches them during this launch)
-    if (blockIdx.x == 0 && tid == 0) ctl[3] = cand;                  // for d2g_cmp_set_sparse_info
-    if (gflags[1] & 1u) {                                           // the (global) marking gave up: the dense kernel runs instead
-        if (blockIdx.x == 0 && tid == 0) atomicOr(&ctl[1], 1u);
-        return;
-    }
-    const size_t ntile = (size_t)nrb * ncb;
-    const size_t a = ((size_t)blockIdx.x * 1024 + tid) * 8, b = min(ntile, a + 8);
-    uint32_t n = 0, mask = 0;
-    for (size_t x = a; x < b; ++x) {
-        const uint32_t rb = (uint32_t)(x / ncb), cb = (uint32_t)(x % ncb);
-        if (full && (size_t)rb * 32 > (size_t)cb * 256 + 255) continue;
-        if ((tilebm[(size_t)rb * CW + (cb >> 5)] >> (cb & 31)) & 1u) { mask |= 1u << (x - a); ++n; }
-    }
-    uint32_t total;
-    uint32_t o = sp_block_scan(n, wave_tot, &total);
-    if (tid == 0) s_base = total ? atomicAdd(&ctl[0], total) : 0u;
-    __syncthreads();
-    o += s_base;
-    for (uint32_t x = 0; x < 8; ++x) if ((mask >> x) & 1u) tiles[o++] = (uint32_t)(a + x);
-}
-
-// dense or sparse?  DENSE: the plain pair kernel walks every tile (and writes every output itself); otherwise the output is
-// pre-filled and the sparse kernel walks the list.  Dense when marking gave up (ALL) or when more than `cand * 0.4` tiles are
-// listed -- the sparse kernel pays for its generality with a per-element epilogue.
-// evaluated by every consumer of the list (fill, sparse kernel, gated dense kernel) from the same two words: no kernel of its own
-__device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, uint32_t cand) {
-    return (ctl[1] & 1u) != 0 || (size_t)ctl[0] * 5 > (size_t)cand * 2;
-}
-
-constexpr int SP_FILL_PER_THREAD = 8, SP_FILL_THREADS = 256;
-template <class Store>
-__global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__restrict__ out, size_t cnt, Store store, uint32_t S, const uint32_t *__restrict__ ctl, uint32_t cand) {
-    if (sp_dense_mode(ctl, cand)) return;                           // dense mode: the pair kernel writes every output
-    const uint32_t v = store.value_from_mismatches(S, S);           // the value of "no register equal"
-    const size_t n4 = cnt / 4;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    // the output pointer of a slab is only 4-byte aligned in general: head, 16-byte body, tail
-    const size_t head = min(cnt, (size_t)((16 - ((uintptr_t)out & 15)) & 15) / 4);
-    u32x4 *body = reinterpret_cast<u32x4 *>(out + head);
-    const size_t nb = (cnt - head) / 4;
-    (void)n4;
-    // a workgroup writes ONE contiguous 32 KB piece (8 x 256 16-byte stores), the workgroups in dispatch order: a streaming write
-    const size_t base = (size_t)blockIdx.x * (SP_FILL_THREADS * SP_FILL_PER_THREAD) + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < SP_FILL_PER_THREAD; ++k) { const size_t i = base + (size_t)k * SP_FILL_THREADS; if (i < nb) body[i] = u32x4{v, v, v, v}; }
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < head) out[threadIdx.x] = v;
-        const size_t tail0 = head + nb * 4;
-        if (tail0 + threadIdx.x < cnt) out[tail0 + threadIdx.x] = v;
-    }
-}
-
-// two-pointer operand fetch: 16 row words at a uniform pointer of the (possibly gathered) row operand, column words at a uniform
-// pointer + lane offset of the sorted stream's column coding
-template <int JR>
-__device__ __forceinline__ BsOperands<JR> sp_fetch(const uint32_t *&rp, size_t rstep, const uint32_t *&cp, uint32_t coff, size_t cstep) {
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_sched_barrier(0);
-    BsOperands<JR> o;
-    typedef const u32x16_u __attribute__((address_space(4))) *row_words_ptr;
-    o.sa = *(row_words_ptr)(uintptr_t)rp;
-    uint32_t co = coff;
-    asm volatile("" : "+v"(co));
-#pragma unroll
-    for (int c = 0; c < JR; ++c)
-        o.vb[c] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(cp) + co + 256 * c);
-    rp += rstep;
-    cp += cstep;
-    return o;
-}
-
-template <int JR>
-__device__ __forceinline__ void sp_group(int nbits, const uint32_t *&rp, size_t rstep, const uint32_t *&cp, uint32_t coff, size_t cstep, BsOperands<JR> &a,
-                                         uint32_t (&acc)[BS_IW][JR]) {
-    uint32_t z[BS_IW][JR];
-    BsOperands<JR> b = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
-    bs_plane<JR, true>(a, z);
-    const int rest = nbits - 1;
-    for (int k = rest >> 1; k > 0; --k) {
-        a = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
-        bs_plane<JR, false>(b, z);
-        b = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
-        bs_plane<JR, false>(a, z);
-    }
-    if (rest & 1) {
-        a = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
-        bs_plane<JR, false>(b, z);
-    } else {
-        a = b;
-    }
-#pragma unroll
-    for (int i = 0; i < BS_IW; ++i)
-#pragma unroll
-        for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);
-}
-
-struct SpArgs {
-    const uint32_t *stream;       // sorted plane stream
-    size_t Nstride;
-    const uint32_t *rowstream;    // gathered row words of a partial launch, or nullptr: the rows are all sorted positions
-    size_t rstride;
-    const uint32_t *meta;
-    int ntb;
-    uint32_t S, N;
-    const uint32_t *sperm, *rowpos, *tiles, *ctl;
-    uint32_t ncb, cand;
-};
-
-// The sparse pair kernel.  A listed tile (32 launch rows x 256 sorted columns) is four 16 x 128 sub-tiles; a workgroup takes ONE
-// sub-tile and its four waves each walk a quarter of the 32-register groups, then add their mismatch counts in LDS.  (The dense
-// kernel gives every wave a sub-tile and all groups: with a few hundred listed tiles that leaves one or two waves per SIMD, each
-// waiting out the latency of every plane's loads -- measured 87 us for 432 tiles at config 3, 411 us for 2122 at config 4.)
-template <int JR, class Store>
-__global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_sparse_kernel(SpArgs a, PairShape sh, Store store) {
-    constexpr int IW = BS_IW;
-    constexpr int WC = BS_CB / (64 * JR);
-    constexpr int KS = D2G_SP_KS;                                   // waves per sub-tile = splits of the group range
-    static_assert(JR == 2, "the LDS reduction packs a lane's two column groups into one word");
-    __shared__ uint32_t red[IW][64];                                // per row and lane: mismatches of column group 0 | group 1 << 16 (a sum stays below 2^16: S < 65536 asserted by the host)
-    if (sp_dense_mode(a.ctl, a.cand)) return;                       // dense mode
-    const uint32_t nsub = a.ctl[0] * 4u;
-    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const bool full = a.rowstream == nullptr;
-    const int g0 = a.ntb * ks / KS, g1 = a.ntb * (ks + 1) / KS;
-    const size_t slot0 = stream_slot(a.meta, g0);
-    for (uint32_t si = blockIdx.x; si < nsub; si += gridDim.x) {
-        const uint32_t tile = a.tiles[si >> 2], sub = si & 3u;
-        const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
-        const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
-        const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
-        if (full && k0 > c0 + 64 * JR - 1) continue;                             // entirely below the diagonal of sorted positions (uniform for the workgroup)
-        for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
-        __syncthreads();
-        uint32_t acc[IW][JR];
-#pragma unroll
-        for (int i = 0; i < IW; ++i)
-#pragma unroll
-            for (int c = 0; c < JR; ++c) acc[i][c] = 0;
-        if (g1 > g0) {
-            const size_t rstep = full ? 2 * a.Nstride : a.rstride;
-            const size_t cstep = 2 * a.Nstride;
-            const uint32_t *rp = (full ? a.stream : a.rowstream) + k0 + slot0 * rstep;
-            const uint32_t *cp = a.stream + a.Nstride + c0 + slot0 * cstep;
-            const uint32_t coff = (uint32_t)lane * 4u;
-            BsOperands<JR> nx = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
-            int nbits_nx = live_planes(a.meta, g0);
-            for (int tb = g0; tb < g1; ++tb) {
-                const int nbits = nbits_nx;
-                nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
-                sp_group<JR>(nbits, rp, rstep, cp, coff, cstep, nx, acc);
-            }
-        }
-        // every wave adds its share of the mismatch counts in LDS; afterwards wave ks finishes rows [ks IW/KS, (ks+1) IW/KS) -- the epilogue
-        // (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
-        // work while the other three wait
-#pragma unroll
-        for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][lane], v); }
-        __syncthreads();
-        {
-            uint32_t oj[JR];
-#pragma unroll
-            for (int c = 0; c < JR; ++c) oj[c] = a.sperm[c0 + lane + 64 * c];
-            for (int i = ks * IW / KS; i < (ks + 1) * IW / KS; ++i) {
-                const size_t k = k0 + i;
-                const uint32_t rpos = full ? (uint32_t)k : a.rowpos[k];               // uniform
-                if (rpos == SP_NONE || rpos >= a.N) continue;
-                const uint32_t oi = a.sperm[rpos];                                    // uniform
-#pragma unroll
-                for (int c = 0; c < JR; ++c) {
-                    const uint32_t mm = (red[i][lane] >> (16 * c)) & 0xFFFFu;
-                    if (mm == a.S || oj[c] == SP_NONE) continue;
-                    const bool want = full ? rpos < (uint32_t)(c0 + lane + 64 * c) : oj[c] > oi;
-                    if (!want) continue;
-                    const uint32_t lo = min(oi, oj[c]), hi = max(oi, oj[c]);
-                    store.put(out_pos(sh, lo, hi), store.value_from_mismatches(a.S, mm));
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
+#include "d2g_k2_sparse.h"
 
 // gathered (caller-owned) operands carry the row coding + the unique plane only: derive the column coding.
 // Done before EVERY launch on such a set -- the library cannot know when the caller re-gathered into the
@@ -1520,206 +728,6 @@ int refresh_borrowed(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s) {
     return d2g_bitslice_derive_groups(ctx, set, 0, set->ntb, s);
 }
 
-bool sparse_enabled(size_t N) {
-    const char *e = std::getenv("D2G_BS_SPARSE");             // "0": every launch walks every tile (A/B measurements, tests)
-    if (e && e[0] == '0') return false;
-    size_t min_n = 8192;                                        // below ~6000 sketches the extra launches cost more than the tiles they skip (measured: N = 4096 0.19 vs 0.15 ms, N = 8192 0.31 vs 0.37 ms)
-    if (const char *m = std::getenv("D2G_BS_SPARSE_MIN_N")) min_n = (size_t)std::atoll(m);
-    return N >= 2 && N >= min_n;
-}
-
-int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
-    const size_t Npad = set->Npad, Nstride = set->Nstride;
-    const size_t nrb = Npad / 32, ncb = Npad / BS_CB;
-    set->tilebm_words = nrb * ((ncb + 31) / 32) + 1;
-    set->tiles_cap = nrb * ncb;
-    hipError_t e;
-    if ((e = hipMalloc((void **)&set->d_stream_s, ((size_t)set->ntb * set->nbits_cap + 1) * 2 * Nstride * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_sperm, Nstride * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_sinv, Npad * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_label, 2 * Npad * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_lcnt, (Npad + 1) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_spctl, (16 + set->tilebm_words) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_gbm, (8 + set->tilebm_words) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_slots, set->ncols * set->tilebm_words * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_tiles, std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_order, 16)) != hipSuccess) {
-        ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e);
-        return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
-    }
-    set->d_tilebm = set->d_spctl + 16;
-    if ((e = hipMemset(set->d_spctl, 0, 16 * 4)) != hipSuccess) { ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e); return D2G_ERR_HIP; }
-    set->sp_launch = 0;
-    return D2G_OK;
-}
-
-void sp_free(d2g_cmp_set *set) {
-    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_lcnt, &set->d_rowpos, &set->d_rowk,
-                         &set->d_rowstream, &set->d_slots, &set->d_tiles, &set->d_spctl, &set->d_gbm, &set->d_order}) { (void)hipFree(*p); *p = nullptr; }
-    set->d_tilebm = nullptr;
-}
-
-int sp_label_rounds() {
-    int rounds = 1;
-    if (const char *e = std::getenv("D2G_BS_LABEL_ROUNDS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) rounds = v; }
-    return rounds;
-}
-bool sp_segments_on() { const char *se = std::getenv("D2G_SP_SEGMENTS"); return !(se && se[0] == '0'); }   // "0": always the exact marking (experiments, tests)
-// what the kernel in front of sp_prepare_order initialises for it (and for the first launch after it: the global tile bitmap + its control words)
-SpInit sp_init_of(const d2g_cmp_set *set) {
-    SpInit si;
-    si.label = set->d_label; si.cnt = set->d_lcnt; si.order = set->d_order; si.zero = set->d_gbm;
-    si.n = (uint32_t)set->N; si.inexact = (sp_segments_on() && sp_label_rounds() > 0) ? 0u : 1u;
-    si.zwords = (uint32_t)(8 + set->tilebm_words);
-    return si;
-}
-
-// labels -> counting sort -> d_sperm / d_sinv.  All on `s`, no host round trip.
-int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
-    const size_t N = set->N, Npad = set->Npad, S = set->ncols;
-    const unsigned nb = (unsigned)div_up<size_t>(N, 256);
-    const int rounds = sp_label_rounds();
-    uint32_t *la = set->d_label, *lb = set->d_label + Npad;
-    const bool segs = sp_segments_on() && rounds > 0;                    // (labels, counters, order[1] and the tile bitmap were initialised by the caller's kernel: sp_init_of)
-    int gens = 4;                                                        // columns a workgroup walks one after the other
-    if (const char *e = std::getenv("D2G_SP_PROP_GENS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) gens = v; }
-    const uint32_t pcap = (uint32_t)std::min<size_t>(N / 2 + 1, 16384);
-    auto propk = N <= 4096 ? sp_prop_reg_kernel<4> : N <= 10240 ? sp_prop_reg_kernel<10> : N <= 16384 ? sp_prop_reg_kernel<16> : sp_prop_kernel;
-    D2G_HIP(ctx, hipFuncSetAttribute((const void *)propk, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
-    for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(propk, dim3((unsigned)std::max<size_t>(1, div_up<size_t>(S, (size_t)gens))), dim3(1024), (size_t)pcap * 4, s, set->d_ids, N, Npad, (uint32_t)S,
-                           set->d_colcnt, split ? 1 : 0, pcap, la);
-        if (r + 1 < rounds) {                          // more rounds: the next one starts from the roots (the sort kernel hops by itself)
-            hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, la, lb, N);
-            hipLaunchKernelGGL(sp_jump_kernel, dim3(nb), dim3(256), 0, s, lb, la, N);
-        }
-    }
-    if (rounds > 0) hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N, set->d_order);   // (also the guard against deep chains)
-    if (segs) {
-        const uint32_t cap = (uint32_t)std::min<size_t>(N / 2 + 1, 36864);               // shared values of a column: at most N / 2; 144 KB of LDS at most
-        const unsigned cthreads = cap > 10240 ? 1024 : 256;                              // a big table leaves one workgroup per CU: a wide one
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_union_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 36864 * 4));
-        hipLaunchKernelGGL(sp_union_kernel, dim3((unsigned)S), dim3(cthreads), (size_t)cap * 4, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, la, cap, set->d_order);
-    }
-    const size_t ntile_all = (Npad / 32) * (Npad / BS_CB);
-    size_t seg_div = 8;                                                  // segments may cover an eighth of all tiles; beyond, exact marks are worth their pass
-    if (const char *e = std::getenv("D2G_SP_SEG_DIV")) { const long v = std::atol(e); if (v >= 1 && v <= 1024) seg_div = (size_t)v; }
-    const uint32_t seg_limit = (uint32_t)std::min<size_t>(ntile_all / seg_div, 0x3FFFFFFF);
-    hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order);
-    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, seg_limit);    // la (labels) is dead after the count kernel: it keeps the segment starts
-    hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order);
-    D2G_HIP(ctx, hipGetLastError());
-    return D2G_OK;
-}
-
-// ids of an operand that arrived as bit planes (the multi-GPU engine's gathered operand: ranks exchange planes, not ids): the inverse
-// of bs_planes_kernel's bit transpose.  Every register SLOT of the operand is a column here (slot 32 tb + x = whatever column the
-// preparing rank's plan put there; padding slots hold id 0 everywhere).  colcnt[slot][4] = the number of the slot's shared values
-// (carried by the slack words of the group's unique plane: bs_planes_kernel).
-__global__ __launch_bounds__(256) void sp_unpack_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta,
-                                                        size_t N, size_t Npad, uint32_t *__restrict__ ids, uint32_t *__restrict__ colcnt, SpInit si) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;          // < Npad: the grid covers Npad exactly
-    const size_t tb = blockIdx.y;
-    sp_init_part(si, tb * ((size_t)gridDim.x * 256) + j, (size_t)gridDim.x * 256 * gridDim.y);
-    const int nbits = live_planes(meta, (int)tb);
-    const uint32_t *src = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
-    if (j < 32) colcnt[(tb * 32 + j) * BS_CC_STRIDE + 4] = planes[tb * (size_t)(nbits_cap + 1) * Nstride + (size_t)nbits_cap * Nstride + Npad + j];
-    uint32_t id[32];
-#pragma unroll
-    for (int x = 0; x < 32; ++x) id[x] = 0;
-    if (j < N) {
-        for (int b = 0; b < nbits; ++b) {
-            const uint32_t w = src[(size_t)b * Nstride];
-#pragma unroll
-            for (int x = 0; x < 32; ++x) id[x] |= ((w >> x) & 1u) << b;
-        }
-        const uint32_t u = src[(size_t)nbits_cap * Nstride];
-#pragma unroll
-        for (int x = 0; x < 32; ++x) if ((u >> x) & 1u) id[x] = BS_UNIQ;
-    }
-#pragma unroll
-    for (int x = 0; x < 32; ++x) ids[(tb * 32 + x) * Npad + j] = id[x];
-}
-
-template <class Store>
-int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store store, uint32_t *out_words, hipStream_t s) {
-    d2g_cmp_set *set = const_cast<d2g_cmp_set *>(cset);
-    const size_t N = set->N, Npad = set->Npad, r0 = sh.i_lo, r1 = sh.i_hi;
-    if (r1 <= r0) return D2G_OK;
-    const bool full = r0 == 0 && r1 == N;
-    const size_t nrows = r1 - r0, nrows_pad = full ? Npad : div_up<size_t>(nrows, 32) * 32;
-    const uint32_t nrb = (uint32_t)(nrows_pad / 32), ncb = (uint32_t)(Npad / BS_CB);
-    const bool split = !set->borrowed && set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
-    const size_t cnt = d2g_ut_count(N, r0, r1);
-    if (!cnt) return D2G_OK;
-    if (!full && !set->d_rowstream)
-        D2G_HIP(ctx, hipMalloc((void **)&set->d_rowstream, ((size_t)set->ntb * set->nbits_cap + 1) * set->Nstride * sizeof(uint32_t)));
-    PairShape dsh = sh;                                                                 // the dense walk of the same launch, behind the gate
-    if (int rc = finish_shape(ctx, dsh, BS_JR == 2 ? 32u : 64u)) return rc;
-    d2g_timer tm(ctx, &ctx->ev_k2, s);
-    const uint32_t CW = (ncb + 31) / 32;                                                // words of a bitmap row (column blocks)
-    const uint32_t nrbG = (uint32_t)(Npad / 32);                                        // all sorted row blocks
-    if (!set->gbm_valid) {
-        // ONCE per prepare: the tiles that hold a pair with a shared value, over all sorted positions (d_gbm: 8 control words + bitmap)
-        const uint32_t RW = (nrbG + 31) / 32, W = RW + CW;
-        // (d_gbm -- control words + bitmap -- was cleared by the prepare: sp_init_of)
-        // LDS: the column's copy of the tile bitmap (when it is small) + the bit sets; 36 KB in all: four columns per CU
-        uint32_t lbm_words = nrbG * CW;
-        int lbm_max = 4096;                                                            // words (16 KB)
-        if (const char *e = std::getenv("D2G_SP_LOCALBM")) lbm_max = std::atoi(e);       // experiments: 0 = build it in the slot
-        if ((int)lbm_words > lbm_max) lbm_words = 0;
-        // (36 KB, not 40: with the kernel's few static bytes on top a 40 KB request fits only three times into the CU's 160 KB.)  Wide bit
-        // sets (N above ~20 000: 56 words per value at N = 50 000) take 76 KB and 512 threads, two columns per CU: fewer passes over the sketches
-        const bool wide = W > 24;
-        const uint32_t budget = wide ? 19456u : 9216u;
-        const uint32_t gm = std::max(1u, std::min(2048u, (budget - lbm_words) / W));
-        const size_t lds = ((size_t)gm * W + lbm_words) * 4;
-        // order[1] == 0 (the prepare united every shared value's holders: the sort's segments are the families): the mark kernel's threads set the
-        // segments' tiles and the folding kernel returns at once
-        auto mark = wide ? sp_mark_kernel<D2G_SP_WIDE_U> : sp_mark_kernel<8>;
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)mark, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        hipLaunchKernelGGL(mark, dim3((unsigned)set->ncols), dim3(wide ? 512 : 256), lds, s, set->d_ids, N, Npad, set->d_colcnt, split ? 1 : 0, set->d_sinv,
-                           (const uint32_t *)nullptr, gm, RW, CW, nrbG, ncb, lbm_words, set->d_slots, set->d_gbm, set->d_order, set->d_sperm, set->d_label + Npad, set->d_label,
-                           set->d_lcnt, set->d_gbm + 8);
-        hipLaunchKernelGGL(sp_or_kernel, dim3((unsigned)div_up<size_t>((size_t)nrbG * CW, 256), SP_OR_SPLIT), dim3(256), 0, s, set->d_slots, nrbG * CW, (uint32_t)set->ncols,
-                           set->d_gbm + 8, set->d_gbm, set->d_order);
-        set->gbm_valid = true;
-    }
-    // per launch: 8 control words (ctl[0] = tiles listed, ctl[1] = flags (bit 0 ALL: marking gave up), [3] = candidates) + a partial launch's bitmap
-    // double-buffered: this launch's list kernel clears the other set for the next launch (both start cleared: sp_alloc)
-    uint32_t *const ctl = set->d_spctl + 8 * (set->sp_launch & 1u), *const ctl_next = set->d_spctl + 8 * ((set->sp_launch + 1) & 1u);
-    ++set->sp_launch;
-    if (!full) {
-        hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk);
-        hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)div_up<size_t>(nrows_pad, 256), (unsigned)(set->ntb * set->nbits_cap)), dim3(256), 0, s,
-                           set->d_stream_s, set->Nstride, set->d_meta, set->ntb, set->d_rowpos, (uint32_t)nrows_pad, set->d_rowstream, set->Nstride);
-        hipLaunchKernelGGL(sp_rowbm_kernel, dim3((unsigned)div_up<size_t>((size_t)nrb * CW, 256)), dim3(256), 0, s, set->d_gbm + 8, set->d_rowpos, nrb, CW, set->d_tilebm);
-    }
-    const size_t ntile = (size_t)nrb * ncb;
-    // candidates: every tile of a partial launch; the tiles on or above the diagonal of sorted positions of a full one
-    size_t cand = ntile;
-    if (full) { cand = 0; for (uint32_t cb = 0; cb < ncb; ++cb) cand += std::min<size_t>(nrb, ((size_t)cb * 256 + 255) / 32 + 1); }
-    const uint32_t cand32 = (uint32_t)std::min<size_t>(cand, 0xFFFFFFFFu);
-    hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, full ? set->d_gbm + 8 : set->d_tilebm, nrb, ncb, CW, full ? 1 : 0,
-                       set->d_tiles, ctl, cand32, set->d_gbm, ctl_next);
-    SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
-             set->d_sperm, set->d_rowpos, set->d_tiles, ctl, ncb, cand32};
-    // contiguous 32 KB per workgroup, workgroups in dispatch order: a streaming write (6.1 TB/s at N = 50 000: 825 us; the grid-stride loop over 16
-    // workgroups per CU it replaces, whose iterations lie 16 MB apart, reached 4.6: 1105 us).  One store per thread is faster still (722-760 us) but when
-    // the launch turns out dense all of its 19 M waves start only to return: 254 us instead of 34
-    hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, SP_FILL_THREADS * SP_FILL_PER_THREAD), (size_t)0x7FFFFFFF)), dim3(SP_FILL_THREADS), 0, s,
-                       out_words, cnt, store, (uint32_t)set->S, ctl, cand32);
-    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>(ntile * 4, (size_t)ctx->num_cus * (28 / D2G_SP_KS)));
-    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store);
-    if (dsh.nvalid_total)
-        hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
-                           set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, dsh, store, (const uint32_t *)ctl, cand32);
-    tm.stop();
-    D2G_HIP(ctx, hipGetLastError());
-    return D2G_OK;
-}
 
 template <class Store>
 int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store store, hipStream_t s) {
@@ -1729,7 +737,7 @@ int launch_bitslice(d2g_ctx *ctx, const d2g_cmp_set *set, PairShape sh, Store st
     if (int rc = d2g_bitslice_ensure_natural(ctx, set, s)) return rc;
     d2g_timer tm(ctx, &ctx->ev_k2, s);
     hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(sh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
-                       set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, sh, store, (const uint32_t *)nullptr, 0u);
+                       set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, sh, store, (const uint32_t *)nullptr, 0u, SpPatchArgs{});
     tm.stop();
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -1784,7 +792,7 @@ int alloc_prepare_workspace(d2g_ctx *ctx, d2g_cmp_set *set) {
         const uint32_t nparts = set->T >> BS_LOG_TLDS_MAX;
         int want = 1;
         while (want < 4 && (uint32_t)want * 2 <= nparts && S * (size_t)want < (size_t)std::max(ctx->num_cus, 1)) want *= 2;
-        if (const char *e = std::getenv("D2G_BS_NSPLIT")) {                 // tests / experiments
+        if (const char *e = ctx->tune.get("D2G_BS_NSPLIT")) {                 // tests / experiments
             const int v = std::atoi(e);
             if ((v == 1 || v == 2 || v == 4) && (uint32_t)v <= nparts) want = v;
         }
@@ -1803,8 +811,8 @@ int alloc_prepare_workspace(d2g_ctx *ctx, d2g_cmp_set *set) {
     }
     return D2G_OK;
 }
-bool sort_columns() {
-    const char *e = std::getenv("D2G_BS_SORT");       // "0": keep the caller's column order (A/B measurements, tests)
+bool sort_columns(const d2g_ctx *ctx) {
+    const char *e = ctx->tune.get("D2G_BS_SORT");     // "0": keep the caller's column order (A/B measurements, tests)
     return !(e && e[0] == '0');
 }
 }  // namespace
@@ -1820,7 +828,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     }
     if (int rc = d2g_bitslice_alloc_stream(ctx, set)) { d2g_bitslice_free(set); return rc; }
     set->ncols = set->S;
-    set->sparse_ok = sparse_enabled(set->N) && set->S < 65536 && set->S * (set->Npad / 32) * ((set->Npad / BS_CB + 31) / 32) * 4 <= ((size_t)1 << 30);   // the columns' tile bitmaps: <= 1 GiB
+    set->sparse_ok = sparse_enabled(ctx, set->N) && set->S < 65536;          // (the sparse kernel packs two mismatch counts into one LDS word)
     if (set->sparse_ok) if (int rc = sp_alloc(ctx, set)) { d2g_bitslice_free(set); return rc; }
     return D2G_OK;
 }
@@ -1839,7 +847,7 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         if (multi) kern = bs_rank_kernel<true, false>;
         else if (N <= (size_t)12 * BS_RANK_THREADS) kern = bs_rank_kernel<false, true>;     // PF * BS_RANK_THREADS
         int tagbits_max = 31;
-        if (const char *e = std::getenv("D2G_BS_TAGBITS")) { const int v = std::atoi(e); if (v >= 0 && v < 31) tagbits_max = v; }   // tests
+        if (const char *e = ctx->tune.get("D2G_BS_TAGBITS")) { const int v = std::atoi(e); if (v >= 0 && v < 31) tagbits_max = v; }   // tests
         if (lds > 48 * 1024)
             D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int nsplit = multi ? set->nsplit : 1;
@@ -1850,22 +858,23 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)(S * nsplit)), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
                            set->d_ids, set->d_colcnt, set->d_meta + set->ntb, tagbits_max, (uint32_t)S, nsplit);
         hipLaunchKernelGGL(bs_colplan_kernel, dim3(1), dim3(BS_PLAN_THREADS), 0, s, set->d_colcnt, (uint32_t)S, set->ntb, nsplit, set->d_perm,
-                           set->d_meta, set->d_meta + set->ntb, set->ex_meta, set->ex_status, sort_columns() ? 1 : 0);
+                           set->d_meta, set->d_meta + set->ntb, set->ex_meta, set->ex_status, sort_columns(ctx) ? 1 : 0);
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
     if (set->sparse_ok && !set->export_only && !set->want_exchange) {
-        // sparse path: the stream in label order (section 4); the caller's-order stream is only built if a launch asks for it
+        // sparse path (section 4): the caller's-order stream first (the dense walk and rectangular launches read it), then the families,
+        // the pair list and the stream in family order
         // (gathering the ids through d_sperm inside bs_planes_kernel was measured: 74 us instead of 18 at config 3 -- 1024 columns of
         // uncoalesced 4-byte loads; permuting the finished stream touches 256 rows of words and leaves the caller's-order stream valid)
-        // (a second queue for the caller's-order planes beside the labelling, and for the fill beside the marking, was measured: the
-        // kernels slow each other down by what the overlap hides -- mark 28 -> 57 us next to the fill -- and the events cost more: dropped)
-        // (the planes kernel also initialises the ordering's arrays and clears the tile bitmap of the first launch: no launch / memset of their own)
+        // (a second queue for the caller's-order planes beside the ordering, and for the fill beside the tile list, was measured in round 4:
+        // the kernels slow each other down by what the overlap hides and the events cost more: dropped)
+        // (the planes kernel also initialises the ordering's arrays and clears the tile bitmap: no launch / memset of their own)
         hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
                            set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr, sp_init_of(set));
         if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
-        hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm, set->d_order);
-        set->srt_valid = true; set->nat_valid = true; set->gbm_valid = false;
+        if (int rc = sp_permute(ctx, set, s)) return rc;
+        set->srt_valid = true; set->nat_valid = true;
         D2G_HIP(ctx, hipGetLastError());
         return D2G_OK;
     }
@@ -1976,7 +985,7 @@ int d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1
 int d2g_bitslice_managed_sparse_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     if (!set->borrowed || set->sparse_ok) return D2G_OK;
     set->ncols = (size_t)set->ntb * 32;
-    if (!(sparse_enabled(set->N) && set->S < 65536 && set->ncols * (set->Npad / 32) * ((set->Npad / BS_CB + 31) / 32) * 4 <= ((size_t)1 << 30))) return D2G_OK;
+    if (!(sparse_enabled(ctx, set->N) && set->S < 65536)) return D2G_OK;
     hipError_t e;
     if ((e = hipMalloc((void **)&set->d_ids, set->ncols * set->Npad * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_colcnt, set->ncols * BS_CC_STRIDE * sizeof(uint32_t))) != hipSuccess ||
@@ -1995,10 +1004,9 @@ int d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     dim3 grid((unsigned)div_up<size_t>(set->Npad, 256), (unsigned)set->ntb);
     hipLaunchKernelGGL(sp_unpack_kernel, grid, dim3(256), 0, s, set->d_planes, set->Nstride, set->nbits_cap, set->d_meta, set->N, set->Npad, set->d_ids, set->d_colcnt, sp_init_of(set));
     if (int rc = sp_prepare_order(ctx, set, false, s)) return rc;
-    dim3 pgrid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
-    hipLaunchKernelGGL(sp_permute_kernel, pgrid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm, set->d_order);
+    if (int rc = sp_permute(ctx, set, s)) return rc;
     D2G_HIP(ctx, hipGetLastError());
-    set->srt_valid = true; set->gbm_valid = false;
+    set->srt_valid = true;
     return D2G_OK;
 }
 
@@ -2006,13 +1014,16 @@ int d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
 int d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint32_t *out4) {
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
     if (!set->srt_valid || !set->d_spctl) { D2G_HIP(ctx, hipStreamSynchronize(s)); return D2G_OK; }
-    uint32_t c[4] = {0, 0, 0, 0}, ord[2] = {0, 1}, g[4] = {0, 0, 0, 0};
-    D2G_HIP(ctx, hipMemcpyAsync(c, set->d_spctl + 8 * ((set->sp_launch + 1) & 1u), sizeof c, hipMemcpyDeviceToHost, s));   // the set the last launch used
+    uint32_t c[4] = {0, 0, 0, 0}, ord[4] = {0, 0, 0, 0}, pl = 0;
+    if (!set->last_ctl) { D2G_HIP(ctx, hipStreamSynchronize(s)); out4[0] = 1; return D2G_OK; }   // prepared, never launched
+    D2G_HIP(ctx, hipMemcpyAsync(c, set->last_ctl, sizeof c, hipMemcpyDeviceToHost, s));   // the control words the last launch used
     D2G_HIP(ctx, hipMemcpyAsync(ord, set->d_order, sizeof ord, hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipMemcpyAsync(&pl, set->d_plctl, sizeof pl, hipMemcpyDeviceToHost, s));
     D2G_HIP(ctx, hipStreamSynchronize(s));
-    c[2] = ord[0]; g[2] = ord[1] ? 1u : 0u;
-    // [2]: bit 0 marking gave up, bit 1 the dense kernel ran, bit 2 the tiles came from the sort's segments (no marking pass)
-    out4[0] = 1; out4[1] = c[0]; out4[2] = (c[1] & 1u) | (((c[1] & 1u) || (size_t)c[0] * 5 > (size_t)c[3] * 2) ? 2u : 0u) | ((g[2] & 1u) ? 0u : 4u); out4[3] = c[2];
+    const bool dense = (c[1] & 1u) || (size_t)c[0] * 5 > (size_t)c[3] * 2;
+    // [2]: bit 0 the prepare decided for the dense walk, bit 1 the dense kernel ran, bit 2 tiles + pair list were used, bit 3 the caller's order was kept
+    out4[0] = 1; out4[1] = c[0]; out4[2] = (ord[0] ? 1u : 0u) | (dense ? 2u : 4u) | (ord[0] ? 8u : 0u);
+    out4[3] = ord[0] ? 0u : (uint32_t)std::min<size_t>(pl, set->plist_cap);
     return D2G_OK;
 }
 

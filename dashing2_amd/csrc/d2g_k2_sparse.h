@@ -1,0 +1,1125 @@
+// d2g_k2_sparse.h -- internal: section 4 of d2g_k2_bitslice.hip (included there, inside its anonymous namespace).
+//
+// ------------------------------------------------------------------ 4. sparse tiles + pair list
+// An equality count (reference src/cmp_core.cpp:461,506; only the count matters, :465) is zero unless the two sketches share a value in
+// at least one register column.  In a collection of related genomes most pairs share nothing, the pairs that share MANY values come in
+// families, and a few pairs share one or two values by chance (a conserved k-mer that is the bucket minimum in two genera).  So an
+// upper-triangle launch computes
+//     family pairs      in 32 x 256 TILES of the bit-sliced operand, put into an order that makes a family a run of adjacent positions;
+//     chance pairs      from a PAIR LIST: one entry per (pair, shared value) -- the equality count of a pair outside the listed tiles is
+//                       the number of its entries;
+//     everything else   by a streaming fill with the value of "0 equal registers".
+// Nothing is approximate, whatever the families look like: the PARTITION of the sketches into segments (runs of adjacent sorted positions)
+// is a heuristic, and exactness rests on two facts that hold for ANY partition:
+//     (a) every pair inside one segment lies in a listed tile (sp_segtiles: the tiles a segment's row blocks and column blocks meet in),
+//         and a listed tile is computed exactly for all of its pairs by the pair kernel;
+//     (b) sp_emit_kernel walks EVERY shared value of EVERY column and emits every pair of its holders that lie in different segments;
+//         the patch kernel adds an entry to the output only where the pair's tile is not listed.
+// A good partition makes both cheap; a bad one makes the list long, and a list that outgrows its buffer (or segments that cover too many
+// tiles, or one family that holds most sketches) sends the launches to the plain pair kernel over every tile (order[0]).
+//
+// prepare  sp_link    ROBUST families: one workgroup per PAIR of adjacent columns; two sketches are united (lock-free union-find on
+//                     label[]) only where they agree in BOTH columns -- a family's members do so in many column pairs, a stranger that
+//                     shares one chance value with a family does not, so one chance collision no longer welds two families together
+//                     (round 4 united over single columns: ten collisions per sketch put every sketch into one component);
+//          sp_attach  a sketch no column pair linked joins the family TWO independent hints point to (the smallest holder of a value
+//                     it shares, recorded by even and by odd column pairs): a weak family member, or families of two;
+//          sp_count / scan / place   counting sort by root -> sperm / sinv, the segments, keep-the-caller's-order decision;
+//          sp_emit    (b) above + the segments' tiles;
+//          sp_permute the finished plane stream in sorted order.
+// launch   sp_list -> sp_fill -> k2_bitslice_sparse_kernel (listed tiles; stores the non-zero counts) -> sp_patch_add (list entries
+//          outside listed tiles: atomicAdd of 1 onto the filled word; the first adder of a position is its leader) -> sp_patch_lut (table
+//          epilogue: the leader turns the count into the float) -> the plain pair kernel, which runs only in dense mode.
+constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
+#ifndef D2G_SP_KS
+#define D2G_SP_KS 4
+#endif
+
+__device__ __forceinline__ uint32_t sp_rank(uint32_t w, const uint32_t *__restrict__ colcnt, size_t t, bool split) {
+    if ((w >> 31) || w == 0) return 0;          // unique (or padding): never equal to anything
+    return split ? (w & BS_RANK_MASK) + colcnt[t * BS_CC_STRIDE + (w >> BS_SPLIT_SHIFT)] : w;
+}
+
+__device__ __forceinline__ uint32_t sp_ld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- lock-free union-find on label[]: label[j] <= j always; a root is hooked under a smaller root with a compare-and-swap
+__device__ __forceinline__ uint32_t sp_find(uint32_t *label, uint32_t l) {
+    for (int h = 0; h < 64; ++h) {                                    // bounded: sp_union retries, and gives up in the end (the partition is a heuristic)
+        const uint32_t p = sp_ld(&label[l]);
+        if (p == l) break;
+        const uint32_t g = sp_ld(&label[p]);
+        if (g != p) label[l] = g;                                     // path halving: only a non-root's label moves, to one of its ancestors
+        l = p;
+    }
+    return l;
+}
+__device__ __forceinline__ bool sp_union(uint32_t *label, uint32_t a, uint32_t b) {
+    for (int it = 0; it < 64; ++it) {
+        a = sp_find(label, a); b = sp_find(label, b);
+        if (a == b) return true;
+        if (a < b) { const uint32_t x = a; a = b; b = x; }              // the larger root goes under the smaller one
+        if (atomicCAS(&label[a], a, b) == a) return true;               // a was still a root: hooked
+    }
+    return false;
+}
+
+// One workgroup per pair of adjacent columns (t1, t2) = (2g, 2g + 1), launched twice.  LDS, per shared value r1 of column t1 (ranks 1 .. nv):
+//   r2[r1]   the rank in column t2 of the first holder of r1 that has a shared value there too (claimed with a compare-and-swap); the
+//            holders of r1 whose t2 rank equals r2[r1] MATCH: they agree in both columns;
+//   MODE 0 (propagate)  mn[r1] = the smallest label among the matchers; every matcher takes it with a PLAIN store.  A label is only
+//            ever replaced by a smaller index of the same family, so whichever racing store lands last the array still holds, per
+//            sketch, an earlier member of its family.  This does nearly all the uniting without a single global atomic (letting every
+//            matcher run the union-find below from identity labels was measured: 264 us at config 3 -- 1.6 million root walks and
+//            compare-and-swaps for the 9 934 hooks the families need);
+//   MODE 1 (unite)      a matcher whose label still differs from mn[r1] runs the lock-free union with it (few do: labels are loaded in
+//            batches up front -- comparing with a representative's label through a second device-scope load per matcher cost 55 us);
+//            any[r1] = the smallest sketch among ALL holders of r1: the hint a holder that did not match takes away.
+// Values beyond the table (nv = min(D2, cap)) take no part: the partition is a heuristic, sp_emit_kernel keeps the result exact.
+constexpr uint32_t SP_PLURAL = 0x80000000u, SP_R2MASK = 0x7FFFFFFFu;      // r2[]: bit 31 = the value has two or more matchers (ranks stay below 2^30)
+template <int MODE>
+__global__ __launch_bounds__(1024) void sp_link_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt,
+                                                       int split, uint32_t cap, uint32_t *label, uint32_t *__restrict__ hint, uint32_t *__restrict__ linked) {
+    extern __shared__ uint32_t sp_l[];
+    const size_t t1 = 2 * (size_t)blockIdx.x, t2 = t1 + 1;
+    if (t2 >= ncols) return;
+    const uint32_t d2 = colcnt[t1 * BS_CC_STRIDE + 4];
+    if (d2 == 0) return;
+    const uint32_t nv = min(d2, cap), T = blockDim.x;
+    uint32_t *r2 = sp_l, *x1 = sp_l + nv, *x2 = sp_l + 2 * (size_t)nv;          // x1: mn; x2: any (MODE 1)
+    for (uint32_t r = threadIdx.x; r < (MODE ? 3u : 2u) * nv; r += T) sp_l[r] = SP_NONE;
+    __syncthreads();
+    constexpr int U = 4;
+    for (size_t j0 = 0; j0 < N; j0 += (size_t)T * U) {
+        uint32_t w1[U], w2[U], lb[U];
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const size_t j = j0 + (size_t)x * T + threadIdx.x;
+            w1[x] = j < N ? ids[t1 * Npad + j] : 0u;
+            w2[x] = j < N ? ids[t2 * Npad + j] : 0u;
+            lb[x] = j < N ? sp_ld(&label[j]) : SP_NONE;
+        }
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const uint32_t j = (uint32_t)(j0 + (size_t)x * T + threadIdx.x);
+            const uint32_t a = sp_rank(w1[x], colcnt, t1, split != 0), b = sp_rank(w2[x], colcnt, t2, split != 0);
+            if (!a || a > nv) continue;
+            if (MODE) atomicMin(&x2[a - 1], j);
+            if (!b) continue;
+            const uint32_t old = atomicCAS(&r2[a - 1], SP_NONE, b);
+            if (old == SP_NONE || (old & SP_R2MASK) == b) {
+                atomicMin(&x1[a - 1], lb[x]);
+                if (MODE && old == b) atomicOr(&r2[a - 1], SP_PLURAL);   // a second matcher (set once: later ones see the bit)
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *myhint = hint + (size_t)(blockIdx.x & 1u) * Npad;
+    for (size_t j0 = 0; j0 < N; j0 += (size_t)T * U) {
+        uint32_t w1[U], w2[U], lb[U];
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const size_t j = j0 + (size_t)x * T + threadIdx.x;
+            w1[x] = j < N ? ids[t1 * Npad + j] : 0u;
+            w2[x] = j < N ? ids[t2 * Npad + j] : 0u;
+            lb[x] = j < N ? sp_ld(&label[j]) : 0u;
+        }
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+            const uint32_t j = (uint32_t)(j0 + (size_t)x * T + threadIdx.x);
+            const uint32_t a = sp_rank(w1[x], colcnt, t1, split != 0), b = sp_rank(w2[x], colcnt, t2, split != 0);
+            if (!a || a > nv) continue;
+            const uint32_t rr = r2[a - 1];
+            const bool match = b && rr != SP_NONE && (rr & SP_R2MASK) == b;
+            if (MODE == 0) {
+                if (match) { const uint32_t m = x1[a - 1]; if (m < lb[x]) label[j] = m; }
+            } else if (match) {
+                // every matcher of a value with two or more of them marks ITSELF linked (all of them writing one representative's flag
+                // put thousands of stores on one address per family)
+                if (rr & SP_PLURAL) linked[j] = 1;
+                // the matchers' smallest label: after the propagation and the flatten pass it is nearly always this sketch's own
+                const uint32_t m = x1[a - 1];
+                if (m != lb[x]) (void)sp_union(label, j, m);
+            } else {
+                const uint32_t h = x2[a - 1];
+                if (h != j) myhint[j] = h;
+            }
+        }
+    }
+}
+
+// every label straight at its root (the walk halves the path behind it; plain loads and stores: a label is only ever replaced by an
+// ancestor, so racing with itself is harmless).  Between the two link passes: the uniting pass compares LABELS, and two members of a
+// family the propagation has put under one root still carry different earlier members until this ran (without it every matcher walked
+// to the roots through device-scope loads: 140 us at config 3 instead of 15).
+__global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t N) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    uint32_t l = (uint32_t)j;
+    for (int h = 0; h < 64; ++h) {
+        const uint32_t p = label[l];
+        if (p == l) break;
+        const uint32_t g = label[p];
+        if (g != p) label[l] = g;
+        l = p;
+    }
+    if (label[l] == l) label[j] = l;
+}
+
+// a sketch that no column pair linked joins the root its hints lead to: both hints when it has two (they must agree: a sketch whose
+// shared values all lie with DIFFERENT strangers -- the adversarial matrix -- stays alone and goes to the pair list), the one it has
+// otherwise (a weak family member, families of two, chains)
+__global__ __launch_bounds__(256) void sp_attach_kernel(uint32_t *label, const uint32_t *__restrict__ hint, const uint32_t *__restrict__ linked, size_t N, size_t Npad) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N || linked[j]) return;
+    const uint32_t a = hint[j], b = hint[Npad + j];
+    if (a == SP_NONE && b == SP_NONE) return;
+    const uint32_t ra = a != SP_NONE ? sp_find(label, a) : SP_NONE, rb = b != SP_NONE ? sp_find(label, b) : SP_NONE;
+    if (ra != SP_NONE && rb != SP_NONE && ra != rb) return;
+    (void)sp_union(label, (uint32_t)j, ra != SP_NONE ? ra : rb);
+}
+
+// block-wide exclusive scan of one value per thread (NW waves); returns the exclusive prefix, *total = the sum
+template <int NW = 16>
+__device__ __forceinline__ uint32_t sp_block_scan(uint32_t v, uint32_t *wave_tot, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int w = 0; w < NW; ++w) { const uint32_t x = wave_tot[w]; if (w < wave) woff += x; tot += x; }
+    *total = tot;
+    return woff + incl - v;
+}
+
+// tiles a segment of c sketches covers at most, in sixteenths of a tile: (rows + 1) x (columns + 1) tiles from 32 sketches on; smaller
+// ones share their row block with their neighbours (two column tiles for c / 32 of a row block)
+__device__ __forceinline__ uint32_t sp_seg_est(uint32_t c) {
+    c = min(c, 32768u);                                                // (a segment that long is past any limit by itself)
+    return c >= 32 ? 16u * ((c + 31) / 32 + 1) * ((c + 255) / 256 + 1) : (c >= 2 ? c : 0u);
+}
+
+// counting sort of the sketches by the root of their label, three small kernels (one thread per sketch, then one workgroup for the
+// prefix, then one thread per sketch again).  The root walk halves the path behind it (plain loads: nobody hooks roots while this runs,
+// and a stale label is still an ancestor); a chain that is not at its root after SP_MAX_HOPS hops (long strings of sketches each united
+// with its neighbour only; one chain of 12 000 cost 0.7 ms in its last thread) raises order[2]: the caller's order is kept.
+constexpr int SP_MAX_HOPS = 64;
+__global__ __launch_bounds__(256) void sp_count_kernel(uint32_t *label, uint32_t *__restrict__ root, size_t N, uint32_t *__restrict__ cnt, uint32_t *__restrict__ order) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < N;
+    uint32_t r = SP_NONE;
+    if (live) {
+        uint32_t l = (uint32_t)j;
+        for (int h = 0;; ++h) {
+            const uint32_t p = label[l];
+            if (p == l) break;
+            if (h == SP_MAX_HOPS) { order[2] = 1; l = (uint32_t)j; break; }
+            const uint32_t g = label[p];
+            if (g != p) label[l] = g;
+            l = p;
+        }
+        r = l;
+        root[j] = r;
+    }
+    // when everything hangs together ONE counter takes all N increments (measured: 115 us at N = 10 000): the lanes that share the
+    // wave's first root add once; the others go one by one
+    const unsigned long long alive = __ballot(live);
+    if (!alive) return;
+    const uint32_t lead = __shfl(r, __ffsll((long long)alive) - 1);
+    const unsigned long long m = __ballot(live && r == lead);
+    if (live && r == lead) { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(&cnt[lead], (uint32_t)__popcll(m)); }
+    else if (live) atomicAdd(&cnt[r], 1u);
+}
+// order[0] = 1: the launches walk every tile of the caller's-order operand (one root holds more than half of the sketches, deep label
+// chains, or the segments would cover more than seg_tile_limit tiles -- the sparse kernel costs about twice the plain one per tile)
+__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t seg_tile_limit) {
+    // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
+    __shared__ uint32_t wave_tot[16];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
+    __shared__ uint32_t s_big, s_run, s_est;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_big = 0; s_run = 0; s_est = 0; }
+    uint32_t est = 0;                                                  // tiles the segments would cover (both triangles), saturating
+    __syncthreads();
+    // the next tile's counters are requested before this tile is scanned (one workgroup: nothing else hides the round trip)
+    uint32_t pre[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const size_t x = (size_t)k * 1024 + tid; pre[k] = x < N ? cnt[x] : 0u; }
+    for (size_t base = 0; base < N; base += 8192) {
+        const uint32_t n = (uint32_t)min((size_t)8192, N - base);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[k * 1024 + tid] = pre[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const size_t x = base + 8192 + (size_t)k * 1024 + tid; pre[k] = x < N ? cnt[x] : 0u; }
+        uint32_t v[8], sum = 0, big = 0;
+        {   // a thread's eight counters as two 16-byte LDS reads (one word at a time: stride 8 words, an 8-way bank conflict)
+            const u32x4 a = reinterpret_cast<const u32x4 *>(tile)[tid * 2], b = reinterpret_cast<const u32x4 *>(tile)[tid * 2 + 1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            sum += v[x]; big = max(big, v[x]);
+            est += sp_seg_est(v[x]);
+        }
+        est = min(est, 0x0FFFFFFFu);
+        if ((size_t)big * 2 > N) s_big = 1;
+        uint32_t total;
+        uint32_t run = sp_block_scan(sum, wave_tot, &total) + s_run;
+        {
+            uint32_t o[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) { o[x] = run; run += v[x]; }
+            reinterpret_cast<u32x4 *>(tile)[tid * 2] = u32x4{o[0], o[1], o[2], o[3]};
+            reinterpret_cast<u32x4 *>(tile)[tid * 2 + 1] = u32x4{o[4], o[5], o[6], o[7]};
+        }
+        __syncthreads();
+        for (uint32_t x = tid; x < n; x += 1024) { cnt[base + x] = tile[x]; start[base + x] = tile[x]; }   // cnt becomes the placing cursor (-> segment end), start stays
+        if (tid == 0) s_run += total;
+        __syncthreads();
+    }
+    est = min(est, 0x3FFFFFu) / 16 + 1;                                 // 1024 threads x 2^18: no overflow
+    for (int o = 32; o > 0; o >>= 1) est += __shfl_down(est, o);
+    if ((tid & 63) == 0) atomicAdd(&s_est, est);
+    __syncthreads();
+    if (tid == 0) order[0] = (s_big || order[2] || s_est > seg_tile_limit + 1024) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
+                                                        uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < N;
+    if (!live && j < Nstride) sperm[j] = SP_NONE;
+    if (order[0]) { if (live) { sperm[j] = (uint32_t)j; sinv[j] = (uint32_t)j; } return; }
+    const uint32_t r = live ? root[j] : SP_NONE;
+    const int lane = threadIdx.x & 63;
+    uint32_t p = 0;
+    const unsigned long long alive = __ballot(live);
+    if (!alive) return;
+    // as in sp_count_kernel: the lanes that share the wave's first root move its cursor once (and keep their order), the others one by one
+    const uint32_t lead = __shfl(r, __ffsll((long long)alive) - 1);
+    const unsigned long long m = __ballot(live && r == lead);
+    const int first = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == first) base = atomicAdd(&cnt[lead], (uint32_t)__popcll(m));
+    base = __shfl(base, first);
+    if (live && r == lead) p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    else if (live) p = atomicAdd(&cnt[r], 1u);
+    if (live) { sperm[p] = (uint32_t)j; sinv[j] = p; }
+}
+
+// the three sort kernels in ONE single-workgroup launch for N <= 16 384 (counters in LDS): count 5 + scan 7.5 + place 6 us -> one
+// kernel; a thread owns 16 consecutive counters in the prefix and 16 strided sketches in the walks
+constexpr int SP_SORT_SMALL_U = 16;
+__global__ __launch_bounds__(1024) void sp_sort_small_kernel(uint32_t *label, uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ ends,
+                                                             uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, uint32_t *__restrict__ order, uint32_t seg_tile_limit) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];     // [ceil16(N)] counters -> cursors
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t s_big, s_deep, s_est, s_keep;
+    constexpr int U = SP_SORT_SMALL_U;
+    const int tid = threadIdx.x;
+    const uint32_t n16 = (uint32_t)((N + 15) / 16 * 16);
+    for (uint32_t x = tid; x < n16; x += 1024) cnt[x] = 0;
+    if (tid == 0) { s_big = 0; s_deep = 0; s_est = 0; }
+    __syncthreads();
+    // the 16 walks of a thread advance TOGETHER, one hop of each per round: 16 loads in flight instead of one (a walk at a time made
+    // this kernel 28 us: 16 x 2-3 dependent round trips)
+    uint32_t r[U];
+    uint32_t open = 0;
+#pragma unroll
+    for (int k = 0; k < U; ++k) { const size_t j = (size_t)k * 1024 + tid; r[k] = j < N ? (uint32_t)j : SP_NONE; if (j < N) open |= 1u << k; }
+    for (int h = 0; open; ++h) {
+        uint32_t p[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) p[k] = (open >> k) & 1u ? label[r[k]] : 0u;
+        if (h == SP_MAX_HOPS) {
+            s_deep = 1;
+#pragma unroll
+            for (int k = 0; k < U; ++k) if ((open >> k) & 1u) r[k] = (uint32_t)((size_t)k * 1024 + tid);
+            break;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (!((open >> k) & 1u)) continue;
+            if (p[k] == r[k]) open &= ~(1u << k); else r[k] = p[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const size_t j = (size_t)k * 1024 + tid;
+        if (j >= N) continue;
+        root[j] = r[k];
+        atomicAdd(&cnt[r[k]], 1u);
+    }
+    __syncthreads();                                                   // (every label has been read: the array is free for the segment starts)
+    uint32_t v[U], sum = 0, big = 0, est = 0;
+#pragma unroll
+    for (int x = 0; x < U; ++x) {
+        const uint32_t i = (uint32_t)tid * U + x;
+        v[x] = i < n16 ? cnt[i] : 0u;
+        sum += v[x]; big = max(big, v[x]);
+        est += sp_seg_est(v[x]);
+    }
+    if ((size_t)big * 2 > N) s_big = 1;
+    uint32_t total;
+    uint32_t run = sp_block_scan(sum, wave_tot, &total);
+    est = min(est, 0x3FFFFFu) / 16 + 1;
+    for (int o = 32; o > 0; o >>= 1) est += __shfl_down(est, o);
+    if ((tid & 63) == 0) atomicAdd(&s_est, est);
+#pragma unroll
+    for (int x = 0; x < U; ++x) {
+        const uint32_t i = (uint32_t)tid * U + x;
+        if (i < N) { cnt[i] = run; label[i] = run; ends[i] = run + v[x]; }     // label[] becomes the segment starts (as in sp_scan_kernel)
+        run += v[x];
+    }
+    __syncthreads();
+    if (tid == 0) { const uint32_t keep = (s_big || s_deep || s_est > seg_tile_limit + 1024) ? 1u : 0u; order[0] = keep; order[2] = s_deep; s_keep = keep; }
+    __syncthreads();
+    const bool keep = s_keep != 0;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const size_t j = (size_t)k * 1024 + tid;
+        if (j >= N) continue;
+        const uint32_t p = keep ? (uint32_t)j : atomicAdd(&cnt[r[k]], 1u);
+        sperm[p] = (uint32_t)j; sinv[j] = p;
+    }
+    for (size_t x = N + tid; x < Nstride; x += 1024) sperm[x] = SP_NONE;
+}
+
+// sorted position p: the first position of (its segment x its row block) sets the tiles of that row block against the segment's column blocks
+__device__ __forceinline__ void sp_segtiles(size_t p, const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ root, const uint32_t *__restrict__ start,
+                                            const uint32_t *__restrict__ end, size_t N, uint32_t CW, uint32_t *__restrict__ gbm) {
+    if (p >= N) return;
+    const uint32_t r = root[sperm[p]];
+    const uint32_t a = start[r], b = end[r];
+    if (b - a < 2 || !(p == a || (p & 31) == 0)) return;              // a sketch alone in its segment has no pair inside it
+    const uint32_t rb = (uint32_t)(p >> 5), cb0 = a >> 8, cb1 = (b - 1) >> 8;
+    for (uint32_t cw = cb0 >> 5; cw <= cb1 >> 5; ++cw) {
+        const uint32_t lo = cw == (cb0 >> 5) ? (cb0 & 31) : 0u, hi = cw == (cb1 >> 5) ? (cb1 & 31) : 31u;
+        const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+        atomicOr(&gbm[(size_t)rb * CW + cw], m);
+    }
+}
+
+// (b): every shared value of every column; the pairs of its holders that lie in different segments go to the pair list.  One workgroup
+// per column; the column's shared values are walked in ranges of at most `vcap` ranks:
+//   pass A  first[r] = segment of the first holder of value r (compare-and-swap); another segment among its holders marks r MIXED.
+//           A range without a mixed value -- every clean family column -- is done after this pass.
+//   pass B  the holders of mixed values become entries (sketch, segment, next) of per-value chains in LDS (first[] turns into the
+//           chains' heads).  More than `ecap` entries: the range is halved and walked again.
+//   pass C  an entry pairs with every later entry of its chain that lies in another segment: counted, one reservation per workgroup and
+//           range in the global list, written.  A list that is full raises order[0] (dense walk): the list is then longer than a quarter
+//           of all pairs -- not a sparse matrix.
+// The grid's threads also set the segments' tiles (sp_segtiles).
+// A list that will not fit is noticed EARLY: every workgroup adds its column's pair count to plctl[2] and bumps plctl[3]; once 32
+// columns are in, (pairs so far / columns so far) x columns > 1.5 x capacity raises order[0] and everybody stops at its next range.
+constexpr uint32_t SP_EMIT_VCAP = 2048, SP_EMIT_ECAP = 2048, SP_EMIT_T = 512;      // 32 KB of LDS: four workgroups per CU
+__global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
+                                                            const uint32_t *__restrict__ seg, uint32_t *__restrict__ order, const uint32_t *__restrict__ sperm,
+                                                            const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, uint32_t CW, uint32_t *__restrict__ gbm,
+                                                            unsigned long long *__restrict__ plist, uint32_t *__restrict__ plctl, uint32_t plcap) {
+    __shared__ uint32_t first[SP_EMIT_VCAP];
+    __shared__ uint32_t mixed[SP_EMIT_VCAP / 32];
+    __shared__ uint32_t ej[SP_EMIT_ECAP], eseg[SP_EMIT_ECAP], enext[SP_EMIT_ECAP];
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t s_nent, s_any, s_base, s_stop;
+    if (order[0]) return;
+    constexpr uint32_t T = SP_EMIT_T;
+    const uint32_t tid = threadIdx.x;
+    for (size_t p = (size_t)blockIdx.x * T + tid; p < N; p += (size_t)gridDim.x * T) sp_segtiles(p, sperm, seg, seg_start, seg_end, N, CW, gbm);
+    const size_t t = blockIdx.x;
+    const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
+    if (d2 == 0) return;
+    uint32_t curlen = SP_EMIT_VCAP, colpairs = 0;
+    bool voted = false;
+    for (uint32_t lo = 0; lo < d2;) {
+        const uint32_t len = min(curlen, d2 - lo);
+        for (uint32_t x = tid; x < len; x += T) first[x] = SP_NONE;
+        for (uint32_t x = tid; x < (len + 31) / 32; x += T) mixed[x] = 0;
+        if (tid == 0) { s_nent = 0; s_any = 0; s_stop = sp_ld(&order[0]); }
+        __syncthreads();
+        if (s_stop) return;                                           // somebody found that the list will not fit
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
+            uint32_t w[8], sg[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const size_t j = j0 + (size_t)x * T + tid;
+                w[x] = j < N ? ids[t * Npad + j] : 0u;
+                sg[x] = j < N ? seg[j] : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
+                if (r <= lo || r > lo + len) continue;                // (r == 0: unique)
+                const uint32_t old = atomicCAS(&first[r - 1 - lo], SP_NONE, sg[x]);
+                if (old != SP_NONE && old != sg[x]) { atomicOr(&mixed[(r - 1 - lo) >> 5], 1u << ((r - 1 - lo) & 31)); s_any = 1; }
+            }
+        }
+        __syncthreads();
+        if (!s_any) { lo += len; continue; }                          // (uniform: read by everybody after the barrier, reset behind the next one)
+        for (uint32_t x = tid; x < len; x += T) first[x] = SP_NONE;   // now the chains' heads
+        __syncthreads();
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
+            uint32_t w[8], sg[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const size_t j = j0 + (size_t)x * T + tid;
+                w[x] = j < N ? ids[t * Npad + j] : 0u;
+                sg[x] = j < N ? seg[j] : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
+                if (r <= lo || r > lo + len) continue;
+                const uint32_t q = r - 1 - lo;
+                if (!((mixed[q >> 5] >> (q & 31)) & 1u)) continue;
+                const uint32_t k = atomicAdd(&s_nent, 1u);
+                if (k < SP_EMIT_ECAP) { ej[k] = (uint32_t)(j0 + (size_t)x * T + tid); eseg[k] = sg[x]; enext[k] = atomicExch(&first[q], k); }
+            }
+        }
+        __syncthreads();
+        const uint32_t nent = s_nent;
+        if (nent > SP_EMIT_ECAP) {
+            __syncthreads();                                          // (everybody has read s_nent before it is reset)
+            if (len == 1) { if (tid == 0) order[0] = 1; return; }     // ONE value with thousands of holders spread over segments: not sparse
+            // the holders that did not fit are a lower bound of what is still to come: (h - 1) pairs at least for h holders of one value
+            if (tid == 0 && (size_t)nent * ncols > (size_t)plcap * 8) order[0] = 1;
+            curlen = len / 2;
+            continue;
+        }
+        // a chain is walked from an entry towards the entries inserted before it: every unordered pair of a chain is seen once
+        uint32_t mine = 0;
+        for (uint32_t k = tid; k < nent; k += T) {
+            const uint32_t s = eseg[k];
+            for (uint32_t e = enext[k]; e != SP_NONE; e = enext[e]) mine += eseg[e] != s;
+        }
+        uint32_t total;
+        uint32_t off = sp_block_scan<T / 64>(mine, wave_tot, &total);
+        if (tid == 0) s_base = total ? atomicAdd(&plctl[0], total) : 0u;
+        __syncthreads();
+        if (total) {
+            const uint32_t base = s_base;
+            if ((size_t)base + total > plcap) { if (tid == 0) order[0] = 1; return; }
+            colpairs += total;
+            off += base;
+            for (uint32_t k = tid; k < nent; k += T) {
+                const uint32_t s = eseg[k], a = ej[k];
+                for (uint32_t e = enext[k]; e != SP_NONE; e = enext[e]) {
+                    if (eseg[e] == s) continue;
+                    const uint32_t b = ej[e];
+                    plist[off++] = (unsigned long long)min(a, b) | ((unsigned long long)max(a, b) << 32);
+                }
+            }
+        }
+        __syncthreads();
+        lo += len;
+        // this column's pairs so far, scaled to all of its values and all columns: 1.25 times the capacity says the list will not fit.
+        // Eight columns must say so (one odd column must not send a sparse matrix to the dense walk).
+        if (tid == 0 && colpairs && !voted && (size_t)colpairs * d2 / lo * ncols > (size_t)plcap + plcap / 4) {
+            voted = true;
+            if (atomicAdd(&plctl[4], 1u) + 1u >= 8u) order[0] = 1;
+        }
+    }
+    if (tid == 0 && colpairs) {
+        const uint32_t tot = atomicAdd(&plctl[2], colpairs) + colpairs, done = atomicAdd(&plctl[3], 1u) + 1u;
+        if (done >= 32 && (size_t)tot / done * ncols > (size_t)plcap + plcap / 2) order[0] = 1;
+    }
+}
+
+// launch rows: the sorted positions whose sketch lies in [r0, r1), in sorted order (stable compaction, one workgroup; 8192 positions at
+// a time through LDS so that the loads are coalesced and a thread still owns eight consecutive positions: N = 50 000 80 -> ~12 us)
+__global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restrict__ sperm, size_t N, uint32_t r0, uint32_t r1, uint32_t nrows_pad,
+                                                       uint32_t *__restrict__ rowpos, uint32_t *__restrict__ rowk) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
+    __shared__ uint32_t s_run;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    uint32_t pre[8];                                                   // the next tile is requested before this one is compacted (as in sp_scan_kernel)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const size_t x = (size_t)k * 1024 + tid; pre[k] = x < N ? sperm[x] : SP_NONE; }
+    for (size_t base = 0; base < N; base += 8192) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[k * 1024 + tid] = pre[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const size_t x = base + 8192 + (size_t)k * 1024 + tid; pre[k] = x < N ? sperm[x] : SP_NONE; }
+        uint32_t jv[8], cnt = 0;
+        {
+            const u32x4 a = reinterpret_cast<const u32x4 *>(tile)[tid * 2], b = reinterpret_cast<const u32x4 *>(tile)[tid * 2 + 1];
+            jv[0] = a.x; jv[1] = a.y; jv[2] = a.z; jv[3] = a.w; jv[4] = b.x; jv[5] = b.y; jv[6] = b.z; jv[7] = b.w;
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) cnt += (jv[x] >= r0 && jv[x] < r1) ? 1u : 0u;   // SP_NONE (beyond N) is in no range
+        uint32_t total;
+        uint32_t k = sp_block_scan(cnt, wave_tot, &total) + s_run;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            if (jv[x] == SP_NONE) continue;
+            const bool w = jv[x] >= r0 && jv[x] < r1;
+            rowk[jv[x]] = w ? k : SP_NONE;
+            if (w) rowpos[k++] = (uint32_t)(base + tid * 8 + x);
+        }
+        __syncthreads();
+        if (tid == 0) s_run += total;
+        __syncthreads();
+    }
+    for (uint32_t x = s_run + tid; x < nrows_pad; x += 1024) rowpos[x] = SP_NONE;
+}
+
+__global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb,
+                                                        const uint32_t *__restrict__ rowpos, uint32_t nrows_pad, uint32_t *__restrict__ rowstream, size_t rstride) {
+    const size_t q = blockIdx.y;
+    if (q >= stream_slot(meta, ntb)) return;
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nrows_pad) return;
+    const uint32_t p = rowpos[k];
+    rowstream[q * rstride + k] = p != SP_NONE ? stream[2 * q * Nstride + p] : 0u;
+}
+
+// tile bitmap of a PARTIAL launch from the global one: a block of 32 launch rows may meet what any of the sorted row blocks its rows
+// come from may meet (a superset of the tiles of those rows' own segments: still no pair inside a segment is missed)
+__global__ __launch_bounds__(256) void sp_rowbm_kernel(const uint32_t *__restrict__ gbm, const uint32_t *__restrict__ rowpos, uint32_t nrb, uint32_t CW,
+                                                       uint32_t *__restrict__ tilebm) {
+    const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= nrb * CW) return;
+    const uint32_t rb = x / CW, cw = x - rb * CW;
+    uint32_t acc = 0;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) { const uint32_t p = rowpos[rb * 32 + i]; if (p != SP_NONE) acc |= gbm[(size_t)(p >> 5) * CW + cw]; }
+    tilebm[x] = acc;
+}
+
+// the marked tiles as EIGHT work lists, one per XCD: list q holds the tiles whose column block cb has cb % 8 == q, and the workgroups
+// that run on XCD q (blockIdx % 8 == q) walk it -- every sub-tile that reads a column block's words runs on one XCD, whose L2 then
+// fetches them once (a single list handed the four sub-tiles of a tile to four XCDs).  Any order inside a list: a workgroup reserves
+// the ranges of its tiles with one atomic per list.  full: rows are ALL sorted positions and a pair is computed where row position <
+// column position, so tiles entirely below that diagonal are not candidates.
+// ctl[0] = tiles listed, ctl[1] bit 0 = dense walk, ctl[3] = candidates, ctl[8 + q] = tiles in list q (list q starts at tiles + q * cap).
+constexpr int SP_CTL_WORDS = 16;
+// workgroup `wg` of `NW` waves lists tiles [wg * 512 NW, (wg + 1) * 512 NW)
+template <int NW>
+__device__ __forceinline__ void sp_list_body(uint32_t wg, const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
+                                             uint32_t *__restrict__ tiles, uint32_t cap, uint32_t *__restrict__ ctl, uint32_t cand, const uint32_t *__restrict__ order,
+                                             uint32_t *__restrict__ ctl_next) {
+    __shared__ unsigned long long wave_tot[2][NW];
+    __shared__ uint32_t s_base[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wg == 0 && ctl_next && tid < SP_CTL_WORDS) ctl_next[tid] = 0;   // the next launch's control words (nobody else touches them during this launch)
+    if (wg == 0 && tid == 0) ctl[3] = cand;                          // for d2g_cmp_set_sparse_info
+    if (order[0]) {                                                  // the prepare decided for the dense walk
+        if (wg == 0 && tid == 0) atomicOr(&ctl[1], 1u);
+        return;
+    }
+    const size_t ntile = (size_t)nrb * ncb;
+    const size_t a = ((size_t)wg * (64 * NW) + tid) * 8, b = min(ntile, a + 8);
+    uint32_t mask = 0;
+    unsigned long long cnt[2] = {0, 0};                               // eight 16-bit counters: lists 0-3 | lists 4-7 (a workgroup lists at most 8192 tiles)
+    for (size_t x = a; x < b; ++x) {
+        const uint32_t rb = (uint32_t)(x / ncb), cb = (uint32_t)(x % ncb);
+        if (full && (size_t)rb * 32 > (size_t)cb * 256 + 255) continue;
+        if ((tilebm[(size_t)rb * CW + (cb >> 5)] >> (cb & 31)) & 1u) { mask |= 1u << (x - a); cnt[(cb >> 2) & 1] += 1ull << (16 * (cb & 3)); }
+    }
+    // block-wide exclusive prefix of the eight counters, two packed scans
+    unsigned long long ex[2], tot[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long incl = cnt[h];
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+        if (lane == 63) wave_tot[h][wave] = incl;
+        ex[h] = incl - cnt[h];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        unsigned long long woff = 0, t = 0;
+        for (int w = 0; w < NW; ++w) { const unsigned long long x = wave_tot[h][w]; if (w < wave) woff += x; t += x; }
+        ex[h] += woff; tot[h] = t;
+    }
+    if (tid < 8) {
+        const uint32_t n = (uint32_t)(tot[tid >> 2] >> (16 * (tid & 3))) & 0xFFFFu;
+        s_base[tid] = n ? atomicAdd(&ctl[8 + tid], n) : 0u;
+        if (n) atomicAdd(&ctl[0], n);
+    }
+    __syncthreads();
+    for (uint32_t x = 0; x < 8; ++x) {
+        if (!((mask >> x) & 1u)) continue;
+        const uint32_t q = (uint32_t)((a + x) % ncb) & 7u;
+        const uint32_t o = s_base[q] + ((uint32_t)(ex[q >> 2] >> (16 * (q & 3))) & 0xFFFFu);
+        tiles[(size_t)q * cap + o] = (uint32_t)(a + x);
+        ex[q >> 2] += 1ull << (16 * (q & 3));
+    }
+}
+// a partial launch's lists (its own tile bitmap); a whole-triangle launch uses the lists the prepare left (sp_permute_kernel)
+__global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
+                                                       uint32_t *__restrict__ tiles, uint32_t cap, uint32_t *__restrict__ ctl, uint32_t cand, const uint32_t *__restrict__ order,
+                                                       uint32_t *__restrict__ ctl_next) {
+    sp_list_body<16>(blockIdx.x, tilebm, nrb, ncb, CW, full, tiles, cap, ctl, cand, order, ctl_next);
+}
+
+// the sorted stream from the caller's-order stream: position p takes the words of sketch sperm[p].  Only the row-coded words and
+// ONE column-coded word per group are gathered (the unique plane is their difference in any plane: r ^ c = u where the register
+// is column-unique, 0 elsewhere); both codings are written.
+// Its first workgroups also leave the work lists of a whole-triangle launch (the segments' tiles are final once sp_emit_kernel is done):
+// such a launch starts with the fill, no list kernel of its own.
+struct SpFullList { const uint32_t *bm; uint32_t nrb, ncb, CW; uint32_t *tiles; uint32_t cap; uint32_t *ctl; uint32_t cand, nwg; };
+__global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restrict__ nat, uint32_t *__restrict__ srt, size_t Nstride, const uint32_t *__restrict__ meta,
+                                                         const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ order, SpFullList fl) {
+    {
+        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if (lin < fl.nwg) sp_list_body<4>(lin, fl.bm, fl.nrb, fl.ncb, fl.CW, 1, fl.tiles, fl.cap, fl.ctl, fl.cand, order, nullptr);
+    }
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int tb = blockIdx.y;
+    if (p >= Nstride || order[0]) return;                             // the caller's order was kept: every launch walks the caller's-order stream (dense), nobody reads this one
+    const int nbits = live_planes(meta, tb);
+    const size_t slot = stream_slot(meta, tb);
+    const uint32_t j = sperm[p];
+    uint32_t *dst = srt + slot * 2 * Nstride + p;
+    if (j == SP_NONE) {
+        for (int b = 0; b < nbits; ++b) { dst[(size_t)(2 * b) * Nstride] = 0; dst[(size_t)(2 * b + 1) * Nstride] = 0; }
+        return;
+    }
+    const uint32_t *src = nat + slot * 2 * Nstride + j;
+    const uint32_t u = src[0] ^ src[Nstride];
+    // four planes' words in flight at a time (a loop over a run-time plane count otherwise waits out one round trip per plane)
+    int b = 0;
+    for (; b + 4 <= nbits; b += 4) {
+        uint32_t w[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) w[x] = src[(size_t)(2 * (b + x)) * Nstride];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { dst[(size_t)(2 * (b + x)) * Nstride] = w[x]; dst[(size_t)(2 * (b + x) + 1) * Nstride] = w[x] | u; }
+    }
+    for (; b < nbits; ++b) {
+        const uint32_t w = src[(size_t)(2 * b) * Nstride];
+        dst[(size_t)(2 * b) * Nstride] = w;
+        dst[(size_t)(2 * b + 1) * Nstride] = w | u;
+    }
+}
+
+// dense or sparse?  DENSE: the plain pair kernel walks every tile of the caller's-order operand (and writes every output itself);
+// otherwise the output is pre-filled, the sparse kernel walks the list and the pair list is applied.  Dense when the prepare said so
+// (order[0], latched into ctl[1] by the list kernel) or when more than `cand * 0.4` tiles are listed -- the sparse kernel pays for its
+// generality with a per-element epilogue.  Evaluated by every consumer from the same two words: no kernel of its own.
+__device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, uint32_t cand) {
+    return (ctl[1] & 1u) != 0 || (size_t)ctl[0] * 5 > (size_t)cand * 2;
+}
+
+constexpr int SP_FILL_PER_THREAD = 8, SP_FILL_THREADS = 256;
+template <class Store>
+__global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__restrict__ out, size_t cnt, Store store, uint32_t S, const uint32_t *__restrict__ ctl, uint32_t cand) {
+    if (sp_dense_mode(ctl, cand)) return;                           // dense mode: the pair kernel writes every output
+    const uint32_t v = store.value_from_mismatches(S, S);           // the value of "no register equal"
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // the output pointer of a slab is only 4-byte aligned in general: head, 16-byte body, tail
+    const size_t head = min(cnt, (size_t)((16 - ((uintptr_t)out & 15)) & 15) / 4);
+    u32x4 *body = reinterpret_cast<u32x4 *>(out + head);
+    const size_t nb = (cnt - head) / 4;
+    // a workgroup writes ONE contiguous 32 KB piece (8 x 256 16-byte stores), the workgroups in dispatch order: a streaming write
+    const size_t base = (size_t)blockIdx.x * (SP_FILL_THREADS * SP_FILL_PER_THREAD) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < SP_FILL_PER_THREAD; ++k) { const size_t i = base + (size_t)k * SP_FILL_THREADS; if (i < nb) body[i] = u32x4{v, v, v, v}; }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) out[threadIdx.x] = v;
+        const size_t tail0 = head + nb * 4;
+        if (tail0 + threadIdx.x < cnt) out[tail0 + threadIdx.x] = v;
+    }
+}
+
+// two-pointer operand fetch: 16 row words at a uniform pointer of the (possibly gathered) row operand, column words at a uniform
+// pointer + lane offset of the sorted stream's column coding
+template <int JR>
+__device__ __forceinline__ BsOperands<JR> sp_fetch(const uint32_t *&rp, size_t rstep, const uint32_t *&cp, uint32_t coff, size_t cstep) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_sched_barrier(0);
+    BsOperands<JR> o;
+    typedef const u32x16_u __attribute__((address_space(4))) *row_words_ptr;
+    o.sa = *(row_words_ptr)(uintptr_t)rp;
+    uint32_t co = coff;
+    asm volatile("" : "+v"(co));
+#pragma unroll
+    for (int c = 0; c < JR; ++c)
+        o.vb[c] = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(cp) + co + 256 * c);
+    rp += rstep;
+    cp += cstep;
+    return o;
+}
+
+template <int JR>
+__device__ __forceinline__ void sp_group(int nbits, const uint32_t *&rp, size_t rstep, const uint32_t *&cp, uint32_t coff, size_t cstep, BsOperands<JR> &a,
+                                         uint32_t (&acc)[BS_IW][JR]) {
+    uint32_t z[BS_IW][JR];
+    BsOperands<JR> b = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+    bs_plane<JR, true>(a, z);
+    const int rest = nbits - 1;
+    for (int k = rest >> 1; k > 0; --k) {
+        a = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+        bs_plane<JR, false>(b, z);
+        b = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+        bs_plane<JR, false>(a, z);
+    }
+    if (rest & 1) {
+        a = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+        bs_plane<JR, false>(b, z);
+    } else {
+        a = b;
+    }
+#pragma unroll
+    for (int i = 0; i < BS_IW; ++i)
+#pragma unroll
+        for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);
+}
+
+struct SpArgs {
+    const uint32_t *stream;       // sorted plane stream
+    size_t Nstride;
+    const uint32_t *rowstream;    // gathered row words of a partial launch, or nullptr: the rows are all sorted positions
+    size_t rstride;
+    const uint32_t *meta;
+    int ntb;
+    uint32_t S, N;
+    const uint32_t *sperm, *rowpos, *tiles, *ctl;
+    uint32_t ncb, cand, tiles_cap;
+    int prefetch;                 // D2G_SP_PREFETCH (default 1): touch a sub-tile's operands once before the plane walk
+};
+
+// The sparse pair kernel.  A listed tile (32 launch rows x 256 sorted columns) is four 16 x 128 sub-tiles; a workgroup takes ONE
+// sub-tile and its four waves each walk a quarter of the 32-register groups, then add their mismatch counts in LDS.  (The dense
+// kernel gives every wave a sub-tile and all groups: with a few hundred listed tiles that leaves one or two waves per SIMD, each
+// waiting out the latency of every plane's loads -- measured 87 us for 432 tiles at config 3, 411 us for 2122 at config 4.)
+template <int JR, class Store>
+__global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_sparse_kernel(SpArgs a, PairShape sh, Store store, SpPatchArgs pa) {
+    constexpr int IW = BS_IW;
+    constexpr int WC = BS_CB / (64 * JR);
+    constexpr int KS = D2G_SP_KS;                                   // waves per sub-tile = splits of the group range
+    static_assert(JR == 2, "the LDS reduction packs a lane's two column groups into one word");
+    __shared__ uint32_t red[IW][64];                                // per row and lane: mismatches of column group 0 | group 1 << 16 (a sum stays below 2^16: S < 65536 asserted by the host)
+    if (sp_dense_mode(a.ctl, a.cand)) return;                       // dense mode
+    // the workgroups of XCD q (blockIdx % 8: the hardware deals workgroups to the XCDs round-robin) walk list q
+    const uint32_t xq = blockIdx.x & 7u;
+    const uint32_t nsub = a.ctl[8 + xq] * 4u;
+    const uint32_t *mytiles = a.tiles + (size_t)xq * a.tiles_cap;
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool full = a.rowstream == nullptr;
+    const int g0 = a.ntb * ks / KS, g1 = a.ntb * (ks + 1) / KS;
+    const size_t slot0 = stream_slot(a.meta, g0);
+    const uint32_t nq = (uint32_t)(stream_slot(a.meta, g1) - slot0);                 // planes this wave walks per sub-tile
+    for (uint32_t si = blockIdx.x >> 3; si < nsub; si += gridDim.x >> 3) {
+        const uint32_t tile = mytiles[si >> 2], sub = si & 3u;
+        const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
+        const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
+        const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
+        if (full && k0 > c0 + 64 * JR - 1) continue;                             // entirely below the diagonal of sorted positions (uniform for the workgroup)
+        for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
+        if (a.prefetch && g1 > g0 && nq && a.Nstride < ((size_t)1 << 20)) {
+            // Every plane's operands of this sub-tile touched once, all requests in flight together: ONE exposed round trip to memory,
+            // after which the plane walk below finds its words in the XCD's L2.  (The walk keeps one plane ahead -- scalar loads return
+            // out of order, so there is no waiting for the older of two -- and waited out a trip to HBM per plane: 56 planes x ~0.9 us per
+            // wave at config 3.)  One dword per 64-byte segment: 8 segments of column words and 1 of row words per plane; a lane's
+            // segment index is clamped, not predicated (a branch per load otherwise).
+            const size_t rstep = full ? 2 * a.Nstride : a.rstride, cstep = 2 * a.Nstride;
+            const char *cbase = reinterpret_cast<const char *>(a.stream + a.Nstride + c0 + slot0 * cstep);
+            const char *rbase = reinterpret_cast<const char *>((full ? a.stream : a.rowstream) + k0 + slot0 * rstep);
+            const uint32_t nseg = nq * 8u - 1u;
+            uint32_t ln = (uint32_t)lane;
+            asm volatile("" : "+v"(ln));                               // the per-lane offsets are recomputed per sub-tile (hoisted out of the loop they were spilled)
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const uint32_t x = min(ln + 64u * i, nseg), q = x >> 3, part = x & 7u;
+                v[i] = *reinterpret_cast<const uint32_t *>(cbase + (q * (uint32_t)cstep + part * 16u) * 4u);   // < 2^32: Nstride < 2^20, <= ~128 planes
+            }
+            v[7] = *reinterpret_cast<const uint32_t *>(rbase + min(ln, nq - 1u) * (uint32_t)rstep * 4u);
+            uint32_t sink = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sink |= v[i];
+            asm volatile("" ::"v"(sink));
+        }
+        __syncthreads();
+        uint32_t acc[IW][JR];
+#pragma unroll
+        for (int i = 0; i < IW; ++i)
+#pragma unroll
+            for (int c = 0; c < JR; ++c) acc[i][c] = 0;
+        if (g1 > g0) {
+            const size_t rstep = full ? 2 * a.Nstride : a.rstride;
+            const size_t cstep = 2 * a.Nstride;
+            const uint32_t *rp = (full ? a.stream : a.rowstream) + k0 + slot0 * rstep;
+            const uint32_t *cp = a.stream + a.Nstride + c0 + slot0 * cstep;
+            const uint32_t coff = (uint32_t)lane * 4u;
+            BsOperands<JR> nx = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
+            int nbits_nx = live_planes(a.meta, g0);
+            for (int tb = g0; tb < g1; ++tb) {
+                const int nbits = nbits_nx;
+                nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
+                sp_group<JR>(nbits, rp, rstep, cp, coff, cstep, nx, acc);
+            }
+        }
+        // every wave adds its share of the mismatch counts in LDS; afterwards wave ks finishes rows [ks IW/KS, (ks+1) IW/KS) -- the epilogue
+        // (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
+        // work while the other three wait
+#pragma unroll
+        for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][lane], v); }
+        __syncthreads();
+        {
+            uint32_t el = (uint32_t)lane;
+            asm volatile("" : "+v"(el));                               // what the epilogue derives from the lane is computed here, not carried through the plane walk
+            uint32_t oj[JR];
+#pragma unroll
+            for (int c = 0; c < JR; ++c) oj[c] = a.sperm[c0 + el + 64 * c];
+            for (int i = ks * IW / KS; i < (ks + 1) * IW / KS; ++i) {
+                const size_t k = k0 + i;
+                const uint32_t rpos = full ? (uint32_t)k : a.rowpos[k];               // uniform
+                if (rpos == SP_NONE || rpos >= a.N) continue;
+                const uint32_t oi = a.sperm[rpos];                                    // uniform
+#pragma unroll
+                for (int c = 0; c < JR; ++c) {
+                    const uint32_t mm = (red[i][el] >> (16 * c)) & 0xFFFFu;
+                    if (mm == a.S || oj[c] == SP_NONE) continue;
+                    const bool want = full ? rpos < (uint32_t)(c0 + el + 64 * c) : oj[c] > oi;
+                    if (!want) continue;
+                    const uint32_t lo = min(oi, oj[c]), hi = max(oi, oj[c]);
+                    store.put(out_pos(sh, lo, hi), store.value_from_mismatches(a.S, mm));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the pair list's entries, spread over all workgroups of the launch (those without a tile start here at once)
+    sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)gridDim.x * (64 * KS));
+}
+
+// ---- host side
+struct SpTuning {
+    bool sparse = true;                 // D2G_BS_SPARSE: 0 = every launch walks every tile
+    size_t min_n = 8192;                // D2G_BS_SPARSE_MIN_N: below ~6000 sketches the extra launches cost more than the tiles they skip
+    int link = 1;                       // D2G_SP_LINK: 0 = no families (every sketch its own segment: the pair list alone; tests)
+    int attach = 1;                     // D2G_SP_ATTACH: 0 = no second chance for sketches no column pair linked
+    double tile_frac = 0.35;            // D2G_SP_TILE_FRAC: the segments may cover this fraction of all tiles before the dense walk is cheaper
+    int prefetch = 1;                   // D2G_SP_PREFETCH: 0 = the sparse pair kernel does not touch its operands ahead of the plane walk
+    size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
+    size_t list_div = 16;               // D2G_SP_LIST_DIV: the pair list holds at most pairs / list_div entries (and at most 2^27): an entry costs ~130 ps (emit + two patch passes), a pair of the dense walk ~9
+};
+SpTuning sp_tuning(const d2g_ctx *ctx) {
+    SpTuning v;
+    if (const char *e = ctx->tune.get("D2G_BS_SPARSE")) v.sparse = !(e[0] == '0');
+    if (const char *e = ctx->tune.get("D2G_BS_SPARSE_MIN_N")) v.min_n = (size_t)std::atoll(e);
+    if (const char *e = ctx->tune.get("D2G_SP_LINK")) v.link = std::atoi(e) != 0;
+    if (const char *e = ctx->tune.get("D2G_SP_ATTACH")) v.attach = std::atoi(e) != 0;
+    if (const char *e = ctx->tune.get("D2G_SP_TILE_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.tile_frac = f; }
+    if (const char *e = ctx->tune.get("D2G_SP_PREFETCH")) v.prefetch = std::atoi(e) != 0;
+    if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
+    if (const char *e = ctx->tune.get("D2G_SP_LIST_DIV")) { const long d = std::atol(e); if (d >= 1 && d <= (1 << 20)) v.list_div = (size_t)d; }
+    return v;
+}
+
+bool sparse_enabled(const d2g_ctx *ctx, size_t N) { const SpTuning t = sp_tuning(ctx); return t.sparse && N >= 2 && N >= t.min_n; }
+
+size_t sp_list_cap(const d2g_ctx *ctx, size_t N) {
+    const size_t pairs = N * (N - 1) / 2;
+    return std::max<size_t>(std::min<size_t>(pairs / sp_tuning(ctx).list_div, (size_t)1 << 27), 1024);
+}
+
+int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
+    const size_t Npad = set->Npad, Nstride = set->Nstride;
+    const size_t nrb = Npad / 32, ncb = Npad / BS_CB;
+    set->tilebm_words = nrb * ((ncb + 31) / 32) + 1;
+    set->tiles_cap = nrb * ((ncb + 7) / 8);                            // per list: the tiles of every eighth column block
+    set->plist_cap = sp_list_cap(ctx, set->N);
+    // one zero-initialised block per prepare: [counters Npad + 1 | linked Npad | 8 global control words + tile bitmap | order 8 | list control 8 | control words of a whole-triangle launch 16]
+    set->spz_words = (Npad + 1) + Npad + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS;
+    const size_t planes_words = (size_t)set->ntb * set->nbits_cap + 1;
+    hipError_t e;
+    if ((e = hipMalloc((void **)&set->d_stream_s, planes_words * 2 * Nstride * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_rowstream, planes_words * Nstride * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_sperm, Nstride * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_sinv, Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_label, 2 * Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_hint, 2 * Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_spz, set->spz_words * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_spctl, (2 * SP_CTL_WORDS + set->tilebm_words) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_tiles, 8 * std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_tiles_full, 8 * std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_plist, set->plist_cap * sizeof(unsigned long long))) != hipSuccess) {
+        ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
+    }
+    set->d_lcnt = set->d_spz;
+    set->d_linked = set->d_lcnt + (Npad + 1);
+    set->d_gbm = set->d_linked + Npad;
+    set->d_order = set->d_gbm + 8 + set->tilebm_words;
+    set->d_plctl = set->d_order + 8;
+    set->d_fullctl = set->d_plctl + 8;
+    set->d_tilebm = set->d_spctl + 2 * SP_CTL_WORDS;
+    if ((e = hipMemset(set->d_spctl, 0, 2 * SP_CTL_WORDS * 4)) != hipSuccess) { ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e); return D2G_ERR_HIP; }
+    set->sp_launch = 0;
+    return D2G_OK;
+}
+
+void sp_free(d2g_cmp_set *set) {
+    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_hint, &set->d_spz, &set->d_rowpos, &set->d_rowk,
+                         &set->d_rowstream, &set->d_tiles, &set->d_tiles_full, &set->d_spctl}) { (void)hipFree(*p); *p = nullptr; }
+    (void)hipFree(set->d_plist); set->d_plist = nullptr;
+    set->d_tilebm = set->d_lcnt = set->d_linked = set->d_gbm = set->d_order = set->d_plctl = set->d_fullctl = nullptr;
+}
+
+// what the kernel in front of sp_prepare_order initialises for it: label[j] = j, the hints, and the zero block (counters, linked flags,
+// tile bitmap + global control words, order words, list cursor)
+SpInit sp_init_of(const d2g_cmp_set *set) {
+    SpInit si;
+    si.label = set->d_label; si.n = (uint32_t)set->N;
+    si.ones = set->d_hint; si.owords = (uint32_t)(2 * set->Npad);
+    si.zero = set->d_spz; si.zwords = (uint32_t)set->spz_words;
+    return si;
+}
+
+// labels -> counting sort -> d_sperm / d_sinv -> pair list + segment tiles.  All on `s`, no host round trip.
+int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
+    const size_t N = set->N, Npad = set->Npad, S = set->ncols;
+    const unsigned nb = (unsigned)div_up<size_t>(N, 256);
+    uint32_t *la = set->d_label, *lb = set->d_label + Npad;
+    const SpTuning tu = sp_tuning(ctx);
+    if (tu.link && S >= 2) {
+        const uint32_t cap = (uint32_t)std::min<size_t>(N / 2 + 1, 12288);              // shared values of a column that take part: 3 words each, 144 KB of LDS at most
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8));
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12));
+        hipLaunchKernelGGL(sp_link_kernel<0>, dim3((unsigned)(S / 2)), dim3(1024), (size_t)cap * 8, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap,
+                           la, set->d_hint, set->d_linked);
+        hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
+        hipLaunchKernelGGL(sp_link_kernel<1>, dim3((unsigned)(S / 2)), dim3(1024), (size_t)cap * 12, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap,
+                           la, set->d_hint, set->d_linked);
+        if (tu.attach) hipLaunchKernelGGL(sp_attach_kernel, dim3(nb), dim3(256), 0, s, la, set->d_hint, set->d_linked, N, Npad);
+    }
+    const size_t ntile_all = (Npad / 32) * (Npad / BS_CB);
+    const uint32_t seg_limit = (uint32_t)std::min<size_t>((size_t)((double)ntile_all * tu.tile_frac), 0x3FFFFFFF);
+    if (N <= (size_t)SP_SORT_SMALL_U * 1024) {
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_sort_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_SORT_SMALL_U * 1024 * 4));
+        hipLaunchKernelGGL(sp_sort_small_kernel, dim3(1), dim3(1024), div_up<size_t>(N, 16) * 16 * 4, s, la, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order, seg_limit);
+    } else {
+        hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order);
+        hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, seg_limit);    // la (labels) is dead after the count kernel: it keeps the segment starts
+        hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order);
+    }
+    const uint32_t CW = (uint32_t)((Npad / BS_CB + 31) / 32);
+    hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)S), dim3(SP_EMIT_T), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, lb, set->d_order, set->d_sperm, la, set->d_lcnt, CW,
+                       set->d_gbm + 8, set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu));
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+// candidate tiles of a whole-triangle launch: the tiles on or above the diagonal of sorted positions
+size_t sp_full_candidates(size_t Npad) {
+    const size_t nrb = Npad / 32, ncb = Npad / BS_CB;
+    size_t cand = 0;
+    for (size_t cb = 0; cb < ncb; ++cb) cand += std::min<size_t>(nrb, (cb * 256 + 255) / 32 + 1);
+    return cand;
+}
+
+// the sorted stream + (in the same launch) the work lists of whole-triangle launches
+int sp_permute(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
+    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
+    const size_t nrb = set->Npad / 32, ncb = set->Npad / BS_CB, ntile = nrb * ncb;
+    SpFullList fl{set->d_gbm + 8, (uint32_t)nrb, (uint32_t)ncb, (uint32_t)((ncb + 31) / 32), set->d_tiles_full, (uint32_t)set->tiles_cap, set->d_fullctl,
+                  (uint32_t)std::min<size_t>(sp_full_candidates(set->Npad), 0xFFFFFFFFu), (uint32_t)div_up<size_t>(ntile, 2048)};
+    set->full_list_valid = (size_t)fl.nwg <= (size_t)grid.x * grid.y;
+    if (!set->full_list_valid) fl.nwg = 0;                              // (a huge N with a tiny sketch size: the launch lists its tiles itself)
+    hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm, set->d_order, fl);
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
+// ids of an operand that arrived as bit planes (the multi-GPU engine's gathered operand: ranks exchange planes, not ids): the inverse
+// of bs_planes_kernel's bit transpose.  Every register SLOT of the operand is a column here (slot 32 tb + x = whatever column the
+// preparing rank's plan put there; padding slots hold id 0 everywhere).  colcnt[slot][4] = the number of the slot's shared values
+// (carried by the slack words of the group's unique plane: bs_planes_kernel).
+__global__ __launch_bounds__(256) void sp_unpack_kernel(const uint32_t *__restrict__ planes, size_t Nstride, int nbits_cap, const uint32_t *__restrict__ meta,
+                                                        size_t N, size_t Npad, uint32_t *__restrict__ ids, uint32_t *__restrict__ colcnt, SpInit si) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;          // < Npad: the grid covers Npad exactly
+    const size_t tb = blockIdx.y;
+    sp_init_part(si, tb * ((size_t)gridDim.x * 256) + j, (size_t)gridDim.x * 256 * gridDim.y);
+    const int nbits = live_planes(meta, (int)tb);
+    const uint32_t *src = planes + tb * (size_t)(nbits_cap + 1) * Nstride + j;
+    if (j < 32) colcnt[(tb * 32 + j) * BS_CC_STRIDE + 4] = planes[tb * (size_t)(nbits_cap + 1) * Nstride + (size_t)nbits_cap * Nstride + Npad + j];
+    uint32_t id[32];
+#pragma unroll
+    for (int x = 0; x < 32; ++x) id[x] = 0;
+    if (j < N) {
+        for (int b = 0; b < nbits; ++b) {
+            const uint32_t w = src[(size_t)b * Nstride];
+#pragma unroll
+            for (int x = 0; x < 32; ++x) id[x] |= ((w >> x) & 1u) << b;
+        }
+        const uint32_t u = src[(size_t)nbits_cap * Nstride];
+#pragma unroll
+        for (int x = 0; x < 32; ++x) if ((u >> x) & 1u) id[x] = BS_UNIQ;
+    }
+#pragma unroll
+    for (int x = 0; x < 32; ++x) ids[(tb * 32 + x) * Npad + j] = id[x];
+}
+
+// One sparse launch on a set whose last prepare left a sorted operand.  The launch uses per-set scratch (work list, launch rows, control
+// words): launches on ONE set must be issued one after the other on ONE stream (include/d2g.h says so).
+template <class Store>
+int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store store, uint32_t *out_words, hipStream_t s) {
+    d2g_cmp_set *set = const_cast<d2g_cmp_set *>(cset);
+    const size_t N = set->N, Npad = set->Npad, r0 = sh.i_lo, r1 = sh.i_hi;
+    if (r1 <= r0) return D2G_OK;
+    const bool full = r0 == 0 && r1 == N;
+    const size_t nrows = r1 - r0, nrows_pad = full ? Npad : div_up<size_t>(nrows, 32) * 32;
+    const uint32_t nrb = (uint32_t)(nrows_pad / 32), ncb = (uint32_t)(Npad / BS_CB);
+    const size_t cnt = d2g_ut_count(N, r0, r1);
+    if (!cnt) return D2G_OK;
+    PairShape dsh = sh;                                                                 // the dense walk of the same launch, behind the gate
+    if (int rc = finish_shape(ctx, dsh, BS_JR == 2 ? 32u : 64u)) return rc;
+    d2g_timer tm(ctx, &ctx->ev_k2, s);
+    const uint32_t CW = (ncb + 31) / 32;                                                // words of a bitmap row (column blocks)
+    // per launch: 16 control words (ctl[0] = tiles listed, ctl[1] = flags (bit 0: dense walk), [3] = candidates, [8..15] tiles per XCD list) + a partial launch's bitmap
+    // double-buffered: this launch's list kernel clears the other set for the next launch (both start cleared: sp_alloc)
+    const bool own_list = !(full && set->full_list_valid);            // a whole-triangle launch walks the lists the prepare left (sp_permute)
+    uint32_t *const ctl = own_list ? set->d_spctl + SP_CTL_WORDS * (set->sp_launch & 1u) : set->d_fullctl;
+    uint32_t *const ctl_next = set->d_spctl + SP_CTL_WORDS * ((set->sp_launch + 1) & 1u);
+    if (own_list) ++set->sp_launch;
+    set->last_ctl = ctl;
+    if (!full) {
+        hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk);
+        hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)div_up<size_t>(nrows_pad, 256), (unsigned)(set->ntb * set->nbits_cap)), dim3(256), 0, s,
+                           set->d_stream_s, set->Nstride, set->d_meta, set->ntb, set->d_rowpos, (uint32_t)nrows_pad, set->d_rowstream, set->Nstride);
+        hipLaunchKernelGGL(sp_rowbm_kernel, dim3((unsigned)div_up<size_t>((size_t)nrb * CW, 256)), dim3(256), 0, s, set->d_gbm + 8, set->d_rowpos, nrb, CW, set->d_tilebm);
+    }
+    const size_t ntile = (size_t)nrb * ncb;
+    // candidates: every tile of a partial launch; the tiles on or above the diagonal of sorted positions of a full one
+    const size_t cand = full ? sp_full_candidates(Npad) : ntile;
+    const uint32_t cand32 = (uint32_t)std::min<size_t>(cand, 0xFFFFFFFFu);
+    const uint32_t *bm = full ? set->d_gbm + 8 : set->d_tilebm;
+    uint32_t *const tiles = own_list ? set->d_tiles : set->d_tiles_full;
+    if (own_list)
+        hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, bm, nrb, ncb, CW, full ? 1 : 0,
+                           tiles, (uint32_t)set->tiles_cap, ctl, cand32, set->d_order, ctl_next);
+    SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
+             set->d_sperm, set->d_rowpos, tiles, ctl, ncb, cand32, (uint32_t)set->tiles_cap, sp_tuning(ctx).prefetch};
+    // contiguous 32 KB per workgroup, workgroups in dispatch order: a streaming write (6.1 TB/s at N = 50 000: 825 us; the grid-stride loop over 16
+    // workgroups per CU it replaces, whose iterations lie 16 MB apart, reached 4.6: 1105 us).  One store per thread is faster still (722-760 us) but when
+    // the launch turns out dense all of its 19 M waves start only to return: 254 us instead of 34
+    hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, SP_FILL_THREADS * SP_FILL_PER_THREAD), (size_t)0x7FFFFFFF)), dim3(SP_FILL_THREADS), 0, s,
+                       out_words, cnt, store, (uint32_t)set->S, ctl, cand32);
+    // a multiple of 8 (every XCD's list gets the same number of workgroups), four times what is resident at once: the lists differ in
+    // length, and a workgroup that finds nothing at its index leaves at once -- the dispatcher evens the lists out sub-tile by sub-tile
+    // (exactly one resident wave of workgroups took as long as the longest list: 52 -> 85 us at config 3)
+    const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * 4, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * sp_tuning(ctx).grid_mult) / 8 * 8);
+    SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0};
+    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
+    // behind the gate: every tile of the caller's-order operand in dense mode; otherwise the second step of the pair list (table epilogue)
+    if (dsh.nvalid_total)
+        hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
+                           set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, dsh, store, (const uint32_t *)ctl, cand32, pa);
+    tm.stop();
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}

@@ -1257,13 +1257,13 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     // the compact path (4-byte stored words, tile-sorted split) halves the chain's HBM traffic but is ~11 % slower end to
     // end (one Wang mix per distinct k-mer moves into the issue-bound main pass): opt-in with D2G_K3_COMPACT=1, k <= 21
     kh.compact = false;
-    if (const char *e = std::getenv("D2G_K3_COMPACT")) if (e[0] == '1') kh.compact = kh.hb <= (uint32_t)K3C_MAXBBITS;
+    if (const char *e = ctx->tune.get("D2G_K3_COMPACT")) if (e[0] == '1') kh.compact = kh.hb <= (uint32_t)K3C_MAXBBITS;
     uint64_t tb = 0;
     uint64_t bucket_keys = K3_TARGET, sub_keys = K3_TARGET;
     kh.l1bits = K3_L1BITS; kh.l2_tb0.clear(); kh.l2_bits.clear(); kh.l2_start.assign(n + 1, 0);
-    if (const char *e = std::getenv("D2G_K3_L1BITS")) { const int v = std::atoi(e); if (v >= 0 && v <= K3_MAXBBITS) kh.l1bits = (uint32_t)v; }
-    if (const char *e = std::getenv("D2G_K3_BUCKET_KEYS")) { const long v = std::atol(e); if (v >= 1) bucket_keys = (uint64_t)v; }
-    if (const char *e = std::getenv("D2G_K3_SUB_KEYS")) { const long v = std::atol(e); if (v >= 1) sub_keys = (uint64_t)v; }
+    if (const char *e = ctx->tune.get("D2G_K3_L1BITS")) { const int v = std::atoi(e); if (v >= 0 && v <= K3_MAXBBITS) kh.l1bits = (uint32_t)v; }
+    if (const char *e = ctx->tune.get("D2G_K3_BUCKET_KEYS")) { const long v = std::atol(e); if (v >= 1) bucket_keys = (uint64_t)v; }
+    if (const char *e = ctx->tune.get("D2G_K3_SUB_KEYS")) { const long v = std::atol(e); if (v >= 1) sub_keys = (uint64_t)v; }
     for (size_t g = 0; g < n; ++g) {
         uint64_t nk = 0, chunks = 0;
         for (uint64_t r = genome_run_off[g]; r < genome_run_off[g + 1]; ++r) {
@@ -1298,7 +1298,7 @@ int k3_layout(d2g_ctx *ctx, const uint32_t *run_len, const uint64_t *genome_run_
     // table-sized sub-ranges: a table round that re-reads its whole key range made the main pass 55 % slower, and a
     // bucket staged in LDS for the rounds cost more in occupancy than it saved: 42 ms instead of 20)
     uint64_t split_min = kh.compact ? K3_ROUND_KEYS : K3_SPLIT_MIN;
-    if (const char *e = std::getenv("D2G_K3_SPLIT_MIN")) { const long v = std::atol(e); if (v >= 1) split_min = (uint64_t)v; }
+    if (const char *e = ctx->tune.get("D2G_K3_SPLIT_MIN")) { const long v = std::atol(e); if (v >= 1) split_min = (uint64_t)v; }
     kh.gsplit.assign(n, 0);
     kh.gsub.assign(n + 1, 0);
     for (size_t g = 0; g < n; ++g) {
@@ -1342,7 +1342,7 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
     bool pipeline = false;
     if (!kh.compact && !kh.any_split && !count_only && !D2G_K3_EXP && n >= 2 && kh.gblk[n] == nblk) {
         size_t want = (n >= 8 && kh.total >= 200000000ull) ? 4 : 1;
-        if (const char *e = std::getenv("D2G_K3_SUBBATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) want = (size_t)v; }
+        if (const char *e = ctx->tune.get("D2G_K3_SUBBATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) want = (size_t)v; }
         want = std::min(want, n);
         if (want > 1) {
             sub.assign(1, 0);
@@ -1428,7 +1428,7 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         hipLaunchKernelGGL(kh.compact ? k3_split_kernel<true> : k3_split_kernel<false>, dim3(gs), dim3(K3_THREADS), 0, s, b);
     }
     b.round_keys = K3_ROUND_KEYS;
-    if (const char *e = std::getenv("D2G_K3_ROUND_KEYS")) { const int v = std::atoi(e); if (v >= 1 && v <= K3_ROUND_KEYS) b.round_keys = (uint32_t)v; }
+    if (const char *e = ctx->tune.get("D2G_K3_ROUND_KEYS")) { const int v = std::atoi(e); if (v >= 1 && v <= K3_ROUND_KEYS) b.round_keys = (uint32_t)v; }
     if (count_only) {
         if (!distinct_only) {
             if (int rc = d2g_grow(ctx, &st->d_out_keys, &st->cap_ok, std::max<uint64_t>(kh.total, 1))) return rc;
@@ -1448,7 +1448,7 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         // first guess: with no count threshold the total weight IS the k-mer count; with one it is an
         // upper bound (a too small guess only costs a second pass, which then knows the exact weight)
         double scale = 1.0;
-        if (const char *e = std::getenv("D2G_K3_GUESS_SCALE")) { const double v = std::atof(e); if (v > 0.) scale = v; }   // tests force the redo path
+        if (const char *e = ctx->tune.get("D2G_K3_GUESS_SCALE")) { const double v = std::atof(e); if (v > 0.) scale = v; }   // tests force the redo path
         std::vector<uint64_t> guess(n);
         const double lnm = std::log((double)m);
         for (size_t g = 0; g < n; ++g) {
@@ -1465,17 +1465,17 @@ int k3_run(d2g_ctx *ctx, d2g_k3_state *st, hipStream_t s, const KmerArgs &km, si
         // to a second, three-quarters-empty round: 9.0 ms.  With many more, smaller ranges the hardware's dispatch evens the
         // tail out: 8.3 ms at 6 per CU, 7.9 at 12, 7.6 at 24, 7.3 at 48 and 64 (the survivor kernel follows: 1.9 -> 1.7 ms).
         size_t per_cu = 48;
-        if (const char *e = std::getenv("D2G_K3_GRID_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) per_cu = (size_t)v; }
+        if (const char *e = ctx->tune.get("D2G_K3_GRID_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) per_cu = (size_t)v; }
         const unsigned main_grid = (unsigned)std::min<size_t>(TB, (size_t)ctx->num_cus * per_cu);
         st->last_nredo = 0;
         // First pass in the light form: survivors go to per-workgroup regions of a queue in HBM.  A region holds twice the
         // survivors its buckets are expected to produce: genome g yields at most gk strips in all (an element of count c has
         // <= c strips) and about gk * guess of them survive, spread evenly over its buckets.
         bool light = TB > 0 && !D2G_K3_EXP;
-        if (const char *e = std::getenv("D2G_K3_LIGHT")) if (e[0] == '0') light = false;
+        if (const char *e = ctx->tune.get("D2G_K3_LIGHT")) if (e[0] == '0') light = false;
         double gq_scale = 2.0;
         uint64_t gq_slack = per_cu > 24 ? 256 : 1024;
-        if (const char *e = std::getenv("D2G_K3_GQ_SCALE")) { gq_scale = std::max(0.0, std::atof(e)); gq_slack = 1; }   // tests force the overflow path
+        if (const char *e = ctx->tune.get("D2G_K3_GQ_SCALE")) { gq_scale = std::max(0.0, std::atof(e)); gq_slack = 1; }   // tests force the overflow path
         if (light) {
             // batches of read-sized inputs: the bound of a tiny input is above 1 and every element survives -- a queue of
             // 24 bytes per k-mer would buy nothing; such batches keep the heavy form
@@ -1801,7 +1801,7 @@ int d2g_bmh_from_weighted_ids(d2g_ctx *ctx, const uint64_t *ids, const double *w
     std::vector<double> tw(nsets, 0.);
     const double lnm = std::log((double)m);
     double scale = 1.0;
-    if (const char *e = std::getenv("D2G_K3_GUESS_SCALE")) { const double v = std::atof(e); if (v > 0.) scale = v; }
+    if (const char *e = ctx->tune.get("D2G_K3_GUESS_SCALE")) { const double v = std::atof(e); if (v > 0.) scale = v; }
     for (size_t i = 0; i < nsets; ++i) {
         const uint64_t lo = set_off[i], hi = set_off[i + 1];
         double t = 0.;

@@ -612,7 +612,7 @@ int d2g_allpairs_create(d2g_ctx *ctx, d2g_comm *comm, size_t N, size_t S, d2g_al
     if (int rc = d2g_operand_layout(N, S, &e->gw, &e->ng)) { delete e; return rc; }
     // chunks per rank: at least two 32-register groups each, at most MG_MAX_CHUNKS (a function of the shape only: every rank agrees)
     e->C = e->W == 1 ? 1 : (int)std::min<size_t>(MG_MAX_CHUNKS, std::max<size_t>(1, e->ng / e->W / 2));
-    if (const char *env = std::getenv("D2G_MGPU_CHUNKS")) { const int v = std::atoi(env); if (v >= 1 && v <= MG_MAX_CHUNKS) e->C = v; }
+    if (const char *env = e->ctx->tune.get("D2G_MGPU_CHUNKS")) { const int v = std::atoi(env); if (v >= 1 && v <= MG_MAX_CHUNKS) e->C = v; }
     const int nb = e->W * e->C;
     const std::vector<size_t> grp_lo = even_split<size_t>(e->ng, e->W);
     e->blk_g.assign(nb + 1, e->ng);

@@ -1,9 +1,53 @@
 // d2g_runtime.hip -- context, device memory and timing plumbing of libd2g.
 #include "d2g_internal.h"
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
+// the library's run-time switches (DESIGN.md section 4 lists what each one does).  Host-side switches that need no context
+// (D2G_MAX_RUN and D2G_NO_AVX512 in d2g_host.cpp, D2G_RCCL_LIB, D2G_COMM_LOOPBACK) are read where they apply.
+static const char *const kTuningNames[] = {
+    "D2G_BS_SORT", "D2G_BS_NSPLIT", "D2G_BS_TAGBITS",
+    "D2G_BS_SPARSE", "D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_PREFETCH", "D2G_SP_GRID_MULT",
+    "D2G_MGPU_CHUNKS", "D2G_MGPU_ORDER", "D2G_MAX_RUN",
+    "D2G_K3_COMPACT", "D2G_K3_L1BITS", "D2G_K3_BUCKET_KEYS", "D2G_K3_SUB_KEYS", "D2G_K3_SPLIT_MIN", "D2G_K3_SUBBATCH", "D2G_K3_ROUND_KEYS",
+    "D2G_K3_GUESS_SCALE", "D2G_K3_GRID_PER_CU", "D2G_K3_LIGHT", "D2G_K3_GQ_SCALE",
+};
+void d2g_tuning_load(d2g_tuning &t) {
+    t.kv.clear();
+    for (const char *n : kTuningNames)
+        if (const char *v = std::getenv(n)) t.kv.emplace_back(n, v);
+}
+uint64_t d2g_tuning_hash(const d2g_tuning &t, const char *pa, const char *pb) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const std::string &x) { for (unsigned char c : x) { h ^= c; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
+    for (const auto &p : t.kv)
+        if ((pa && !p.first.compare(0, std::strlen(pa), pa)) || (pb && !p.first.compare(0, std::strlen(pb), pb))) { mix(p.first); mix(p.second); }
+    return h;
+}
+
 extern "C" {
+
+int d2g_ctx_reload_tuning(d2g_ctx *c) {
+    if (!c) return D2G_ERR_INVALID;
+    d2g_tuning_load(c->tune);
+    return D2G_OK;
+}
+
+// {"D2G_X": "value", ...} of the switches this context resolved; returns the length needed (excluding the terminator)
+int d2g_ctx_tuning(const d2g_ctx *c, char *buf, size_t cap) {
+    if (!c) return D2G_ERR_INVALID;
+    std::string j = "{";
+    for (size_t i = 0; i < c->tune.kv.size(); ++i) {
+        if (i) j += ", ";
+        j += "\"" + c->tune.kv[i].first + "\": \"";
+        for (char ch : c->tune.kv[i].second) { if (ch == '"' || ch == '\\') j += '\\'; if ((unsigned char)ch >= 0x20) j += ch; }
+        j += "\"";
+    }
+    j += "}";
+    if (buf && cap) { std::snprintf(buf, cap, "%s", j.c_str()); }
+    return (int)j.size();
+}
 
 int d2g_device_count(void) {
     int n = 0;
@@ -26,6 +70,7 @@ int d2g_ctx_create(int device, d2g_ctx **out) {
     if (!c) return D2G_ERR_NOMEM;
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
+    d2g_tuning_load(c->tune);
     *out = c;
     return D2G_OK;
 }
@@ -110,11 +155,11 @@ int d2g_warmup(d2g_ctx *c, int what) {
     if (what & D2G_WARM_COPY) {
         // the first host<->device copy of a process sets up the runtime's copy machinery (~30 ms on MI355X / ROCm 7: measured with any
         // size and with pinned or pageable memory alike; a 4 KB copy leaves part of it to the first large one, 1 MB does not)
-        static char src[1 << 20];
+        std::vector<char> src((size_t)1 << 20);                 // per call: two helper threads may warm two contexts at once
         void *d = nullptr;
-        D2G_HIP(c, hipMalloc(&d, sizeof src));
-        hipError_t e = hipMemcpy(d, src, sizeof src, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(src, d, 4096, hipMemcpyDeviceToHost);
+        D2G_HIP(c, hipMalloc(&d, src.size()));
+        hipError_t e = hipMemcpy(d, src.data(), src.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(src.data(), d, 4096, hipMemcpyDeviceToHost);
         (void)hipFree(d);
         D2G_HIP(c, e);
     }

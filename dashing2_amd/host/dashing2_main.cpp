@@ -836,8 +836,9 @@ void rect_epilogue(const Options &o, const CmpShape &sh, size_t r0, size_t r1, c
 std::string sparse_json(d2g_ctx *ctx, const d2g_cmp_set *set) {
     uint32_t i4[4] = {0, 0, 0, 0};
     if (d2g_cmp_set_sparse_info(ctx, set, nullptr, i4) != D2G_OK) return "null";
-    return std::string("{\"sorted_operand\": ") + (i4[0] ? "true" : "false") + ", \"tiles_listed_last_launch\": " + std::to_string(i4[1]) + ", \"marking_gave_up\": " +
-           ((i4[2] & 1) ? "true" : "false") + ", \"dense_kernel_ran\": " +  ((i4[2] & 2) ? "true" : "false") + ", \"tiles_from_segments\": " + ((i4[2] & 4) ? "true" : "false") + ", \"callers_order_kept\": " + (i4[3] ? "true" : "false") + "}";
+    return std::string("{\"sorted_operand\": ") + (i4[0] ? "true" : "false") + ", \"tiles_listed_last_launch\": " + std::to_string(i4[1]) + ", \"dense_decided_by_prepare\": " +
+           ((i4[2] & 1) ? "true" : "false") + ", \"dense_kernel_ran\": " +  ((i4[2] & 2) ? "true" : "false") + ", \"tiles_and_pair_list\": " + ((i4[2] & 4) ? "true" : "false") + ", \"callers_order_kept\": " + ((i4[2] & 8) ? "true" : "false") +
+           ", \"pairs_listed\": " + std::to_string(i4[3]) + "}";
 }
 
 std::string planes_json(d2g_ctx *ctx, const d2g_cmp_set *set) {

@@ -133,3 +133,22 @@ def skewed_registers(N, S, seed=97, max_shared=64, share=0.7):
     take = (rng.random((N, S)) < share) & (K[None, :] > 0)
     v = np.where(take, pick, own)
     return np.ascontiguousarray(v | np.arange(S, dtype=np.uint64)[None, :]) + np.uint64(1 << 50)
+
+
+def add_chance_collisions(regs, c, seed=4242):
+    """`c` chance collisions per sketch with random strangers: sketch j takes, in `c` random register columns, the value a random
+    OTHER sketch holds there (about half of those are values the stranger copied from its cluster parent, so the collision is with
+    every member of that family that kept the register; the rest are values only the stranger had).  What a collection of related
+    genomes looks like once a few conserved k-mers are shared across families: every 32 x 256 tile holds a pair with a common
+    value, although only the families' own pairs have many.  Returns a new matrix; column residues are preserved (a value moves
+    within its column)."""
+    rng = np.random.default_rng(seed)
+    N, S = regs.shape
+    out = regs.copy()
+    if c <= 0 or N < 2:
+        return out
+    cols = np.stack([rng.choice(S, size=min(c, S), replace=False) for _ in range(N)])        # [N][c]
+    other = rng.integers(0, N - 1, size=cols.shape)
+    other = other + (other >= np.arange(N)[:, None])                                          # != j
+    out[np.arange(N)[:, None], cols] = regs[other, cols]
+    return out

@@ -65,6 +65,11 @@ int         d2g_ctx_create(int device, d2g_ctx **out);
 void        d2g_ctx_destroy(d2g_ctx *ctx);
 const char *d2g_last_error(const d2g_ctx *ctx);
 int         d2g_ctx_device(const d2g_ctx *ctx);
+/* The library's D2G_* tuning switches and test hooks are read from the environment ONCE, when the context is
+ * created; d2g_ctx_reload_tuning reads them again (tests that change a switch between calls).  d2g_ctx_tuning writes the resolved
+ * set as a JSON object {"D2G_X": "value", ...} (only the switches that were set) into buf and returns the length it needs. */
+int         d2g_ctx_reload_tuning(d2g_ctx *ctx);
+int         d2g_ctx_tuning(const d2g_ctx *ctx, char *buf, size_t cap);
 int         d2g_sync(d2g_ctx *ctx, void *stream);
 int         d2g_malloc(d2g_ctx *ctx, size_t nbytes, void **dptr);
 int         d2g_free(d2g_ctx *ctx, void *dptr);
@@ -325,14 +330,19 @@ int  d2g_cmp_set_status(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream);
  * Synchronises `stream` and returns d2g_cmp_set_status's error, if any; all 0 for a DIRECT set. */
 int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsigned *max_distinct, int *nbits,
                         float *mean_nbits);
-/* Sparse tiles (bit-sliced sets of N >= 8192 sketches that own their operand; D2G_BS_SPARSE=0 switches it off, D2G_BS_SPARSE_MIN_N
- * moves the threshold): an equality count is 0 unless the two sketches share a value in some register column, so the prepare puts
- * the sketches in an order that brings sharers together and an upper-triangle launch walks only the 32 x 256 tiles that hold a pair
- * with a shared value, after pre-filling the output with the value of "0 equal" -- or, when most tiles are marked, the plain kernel
- * (decided on the device, no host round trip).  Results are identical either way.  info4 of the LAST upper-triangle launch on the
- * set (synchronises `stream`): [0] 1 = the set has a sorted operand, [1] tiles listed, [2] flags (bit 0: marking gave up, bit 1:
- * the dense kernel ran, bit 2: the tiles came from the sort's segments -- no shared value straddles two of them, so the marking pass
- * was skipped; D2G_SP_SEGMENTS=0 always marks), [3] 1 = the caller's order was kept (one family holds most sketches). */
+/* Sparse tiles + pair list (bit-sliced sets of N >= 8192 sketches, owning sets and the multi-GPU engine's gathered operand;
+ * D2G_BS_SPARSE=0 switches it off, D2G_BS_SPARSE_MIN_N moves the threshold): an equality count is 0 unless the two sketches share a
+ * value in some register column.  The prepare finds the families (sketches that agree in MANY registers; a single chance collision
+ * does not weld two families together), puts every family on adjacent positions and lists every pair of DIFFERENT families that
+ * shares a value; an upper-triangle launch pre-fills the output with the value of "0 equal", walks only the 32 x 256 tiles a family's
+ * rows and columns meet in and adds the listed pairs -- or, when that would not pay (one family holds most sketches, the families'
+ * tiles are more than a third of all tiles, the list outgrows pairs / 4 entries), the plain kernel over every tile; decided on the
+ * device, no host round trip.  Results are identical either way.
+ * A sparse launch uses scratch of the set (work list, launch rows, control words): upper-triangle launches on ONE set must be issued
+ * one after the other on ONE stream (rectangular launches and launches on different sets are independent).
+ * info4 of the LAST upper-triangle launch on the set (synchronises `stream`): [0] 1 = the set has a sorted operand, [1] tiles
+ * listed, [2] flags (bit 0: the prepare decided for the dense walk, bit 1: the dense kernel ran, bit 2: tiles + pair list were used,
+ * bit 3: the caller's order was kept), [3] entries of the pair list (one per pair of different families and shared value). */
 int  d2g_cmp_set_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, uint32_t *info4);
 /* ---- sharded prepare (multi-GPU).  The bit-sliced operand is an array of independent
  * 32-register groups of `group_words` u32 each (+ one u32 of meta per group) whose geometry depends
@@ -450,8 +460,8 @@ int  d2g_allpairs_set_phase_timing(d2g_allpairs *eng, int on);
 int  d2g_allpairs_phase_times(d2g_allpairs *eng, int cap, int *n_out, int *kind /* [cap] */, int *chunk /* [cap] */,
                               float *start_ms /* [cap] */, float *dur_ms /* [cap] */);
 /* what the sparse-tile path did in this engine's LAST pair phase (device-synchronising): info4 as d2g_cmp_set_sparse_info --
- * [0] the gathered operand was ordered (N >= 8192), [1] tiles listed, [2] bit 0 marking gave up / bit 1 the dense kernel ran / bit 2 tiles from the sort's segments,
- * [3] the gathered order was kept (one family holds most sketches). */
+ * [0] the gathered operand was ordered (N >= 8192), [1] tiles listed, [2] bit 0 dense walk decided by the ordering / bit 1 the dense kernel ran /
+ * bit 2 tiles + pair list used / bit 3 the gathered order was kept, [3] entries of the pair list. */
 int  d2g_allpairs_sparse_info(d2g_allpairs *eng, uint32_t *info4);
 /* software-pipelined step for a stream of matrices: the exchange + prepare of this call overlap the pair kernel
  * of the previous call (own stream, two operand buffers); results land in out_dev in call order on `stream`.

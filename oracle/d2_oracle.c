@@ -552,6 +552,15 @@ void d2o_allpairs_ut(const double *sigs, const double *cards, size_t N, size_t S
     d2o_allpairs_ut_rows(sigs, cards, N, S, measure, k, 0, N, out, nthreads, batch);
 }
 
+/* rows [r0, r1) of the condensed upper triangle (test infrastructure for the full-size parity tests: a few hundred rows of a
+ * 10 000- or 50 000-sketch matrix instead of all of them) */
+void d2o_eqcounts_ut_rows(const double *sigs, size_t N, size_t S, size_t r0, size_t r1, uint32_t *neq_out) {
+    size_t idx = 0;
+    for (size_t i = r0; i < r1 && i < N; ++i)
+        for (size_t j = i + 1; j < N; ++j)
+            neq_out[idx++] = (uint32_t)d2o_count_eq(sigs + S * i, sigs + S * j, S);
+}
+
 void d2o_eqcounts_ut(const double *sigs, size_t N, size_t S, uint32_t *neq_out) {
     size_t idx = 0;
     for (size_t i = 0; i < N; ++i)

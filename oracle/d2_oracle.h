@@ -125,6 +125,7 @@ void d2o_allpairs_ut_rows(const double *sigs, const double *cards, size_t N, siz
                           int k, size_t r0, size_t r1, float *out, int nthreads, size_t batch);
 /* integer equality counts for the condensed upper triangle (parity target for K2) */
 void d2o_eqcounts_ut(const double *sigs, size_t N, size_t S, uint32_t *neq_out);
+void d2o_eqcounts_ut_rows(const double *sigs, size_t N, size_t S, size_t r0, size_t r1, uint32_t *neq_out);
 /* cmp_main.cpp:370-388 default_batchsize */
 size_t d2o_default_batchsize(size_t batch_size, size_t S, unsigned nthreads);
 

@@ -65,6 +65,7 @@ def load(path=None):
         "d2o_allpairs_ut": (None, [pdbl, pdbl, sz, sz, i32, i32, pf32, i32, sz]),
         "d2o_allpairs_ut_rows": (None, [pdbl, pdbl, sz, sz, i32, i32, sz, sz, pf32, i32, sz]),
         "d2o_eqcounts_ut": (None, [pdbl, sz, sz, pu32]),
+        "d2o_eqcounts_ut_rows": (None, [pdbl, sz, sz, sz, sz, pu32]),
         "d2o_default_batchsize": (sz, [sz, sz, C.c_uint]),
         "d2o_dlog": (dbl, [dbl]),
         "d2o_bmh_create": (C.c_void_p, [sz]),
@@ -202,6 +203,15 @@ def eqcounts_ut(sigs):
     N, S = sigs.shape
     out = np.empty(N * (N - 1) // 2, np.uint32)
     load().d2o_eqcounts_ut(_p(sigs, C.c_double), N, S, _p(out, C.c_uint32))
+    return out
+
+
+def eqcounts_rows(sigs, r0, r1):
+    """rows [r0, r1) of the condensed upper triangle of equality counts"""
+    sigs = np.ascontiguousarray(sigs, np.float64)
+    N, S = sigs.shape
+    out = np.empty(sum(N - r - 1 for r in range(r0, min(r1, N))), np.uint32)
+    load().d2o_eqcounts_ut_rows(_p(sigs, C.c_double), N, S, r0, r1, _p(out, C.c_uint32))
     return out
 
 

@@ -49,3 +49,28 @@ def gpu_ctx(d2g):
     ctx = d2g.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(autouse=True)
+def _d2g_tuning_follows_the_environment(request, monkeypatch):
+    """libd2g reads its D2G_* switches once per context (d2g_ctx_create / d2g_ctx_reload_tuning).  The session's context starts every
+    GPU test from the test's own environment, and `monkeypatch.setenv("D2G_...")` inside a test re-reads them."""
+    if "gpu_ctx" not in request.fixturenames:
+        yield
+        return
+    ctx = request.getfixturevalue("gpu_ctx")
+    ctx.reload_tuning()
+    plain_set, plain_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        plain_set(name, value, *a, **k)
+        if name.startswith("D2G_"):
+            ctx.reload_tuning()
+
+    def delenv(name, *a, **k):
+        plain_del(name, *a, **k)
+        if name.startswith("D2G_"):
+            ctx.reload_tuning()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield

@@ -523,39 +523,57 @@ def test_k2_column_plan_large_sketch_sizes(gpu_ctx, d2g, oracle, S):
     cs.close()
 
 
-@pytest.mark.parametrize("segments", ["default", "0"])
-def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g, oracle, monkeypatch, segments):
-    """Round 4: from 8192 sketches on, an upper-triangle launch on a bit-sliced set walks only the tiles that hold a pair with a shared
-    register value (pre-filled output, order by shared-value labels, per-launch tile list), or -- decided on the device -- every tile.
-    Whatever it decides, the counts are those of the direct 64-bit kernel (itself pinned to the oracle elsewhere) and of sampled oracle
-    rows: a family collection (tiles listed, sparse kernel), an adversarial matrix (marking gives up, dense kernel), skewed columns
-    (caller's order kept), unrelated sketches (nothing listed: the fill alone); whole triangle and row ranges; and a set RE-LOADED with
-    another matrix (the cached order and tile marks of the first one must not survive).  The tiles come from the sort's segments when no
-    segments cover few tiles (families; chains, whose neighbours share one register each: the union pass closes what the propagation left
-    open), from the marking pass otherwise or always (D2G_SP_SEGMENTS=0)."""
+def _ut_offsets(N):
+    return np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
+
+
+@pytest.mark.parametrize("variant", ["default", "no_link", "no_attach", "short_list"])
+def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gpu_ctx, d2g, oracle, monkeypatch, variant):
+    """Round 5: from 8192 sketches on, an upper-triangle launch on a bit-sliced set fills the output with the value of "0 equal", walks
+    only the tiles of the FAMILIES the prepare found (sketches that agree in many registers) and adds a list of the pairs of different
+    families that share a value -- or, decided on the device, walks every tile.  Whatever it decides, the counts are those of the
+    direct 64-bit kernel (itself pinned to the oracle elsewhere) and of 64+ oracle rows per matrix: a family collection, the same with
+    1 / 10 / 100 chance collisions per sketch (round 4 listed every tile at 10), an adversarial matrix (a random pairing per column:
+    no families, the pair list alone), skewed columns (one family: dense walk), unrelated sketches (the fill alone), chains whose
+    neighbours share one register (pair list), one chain of N; whole triangle and row ranges, counts and the fused float epilogue; a
+    set RE-LOADED with another matrix.  Variants: no families at all (D2G_SP_LINK=0), no attach step, a pair list of pairs / 4096
+    entries (overflow -> dense walk)."""
     import torch
-    if segments != "default":
-        monkeypatch.setenv("D2G_SP_SEGMENTS", segments)
+    if variant == "no_link":
+        monkeypatch.setenv("D2G_SP_LINK", "0")
+        monkeypatch.setenv("D2G_SP_LIST_DIV", "2")                     # every equal register pair of the families becomes a list entry: ~20 million
+    elif variant == "no_attach":
+        monkeypatch.setenv("D2G_SP_ATTACH", "0")
+    elif variant == "short_list":
+        monkeypatch.setenv("D2G_SP_LIST_DIV", "4096")
     N, S = 12_000, 96
     rng = np.random.default_rng(11)
     chains = rng.random((N, S))
-    one_chain = rng.random((N, S))                                     # sketch i shares one register with i + 1, for every i: label chains of depth ~N
+    one_chain = rng.random((N, S))                                     # sketch i shares one register with i + 1, for every i
     for i in range(N - 1):
         one_chain[i + 1, i % S] = one_chain[i, i % S]
         if (i + 1) % 50:
             chains[i + 1, i % S] = chains[i, i % S]
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
-    mats = {"families": synth.synthetic_registers(N, S, nclusters=N // 150, seed=3).view(np.float64),
+    fam = synth.synthetic_registers(N, S, nclusters=N // 150, seed=3)
+    mats = {"families": fam.view(np.float64),
+            "families+1": synth.add_chance_collisions(fam, 1, seed=21).view(np.float64),
+            "families+10": synth.add_chance_collisions(fam, 10, seed=22).view(np.float64),
+            "families+100": synth.add_chance_collisions(fam, S, seed=23).view(np.float64),
             "paired": synth.paired_registers(N, S, seed=4).view(np.float64),
             "skewed": synth.skewed_registers(N, S, seed=5).view(np.float64),
             "unrelated": synth.unrelated_registers(N, S, seed=6).view(np.float64), "chains": chains, "one_chain": one_chain}
     npairs = N * (N - 1) // 2
     out = torch.empty(npairs, dtype=torch.int32, device=dev)
     ref = torch.empty(npairs, dtype=torch.int32, device=dev)
+    fout = torch.empty(npairs, dtype=torch.float32, device=dev)
+    lut_np = d2g.epilogue_lut(S, d2g.POISSON_LLR, 31, multiset_space=True)     # lut[0] = +inf: the filled word is not zero (S = 96: a table exists in multiset space)
+    lut = torch.from_numpy(lut_np).to(dev)
     cs = None
     seen = {}
-    off = np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
+    off = _ut_offsets(N)
+    sample = np.unique(np.concatenate([np.arange(0, 8), rng.integers(0, N - 1, 48), np.arange(N - 10, N - 1)]))
     for name, m in mats.items():
         bits = np.ascontiguousarray(m).view(np.uint64)
         t_dev = torch.from_numpy(bits.view(np.int64)).to(dev)
@@ -567,25 +585,83 @@ def test_k2_sparse_tiles_equal_the_dense_walk_and_the_direct_kernel(gpu_ctx, d2g
         cs.eqcount_ut_dev(out.data_ptr(), 0, N, stream)
         info = cs.sparse_info(stream)
         seen[name] = info
+        fout.fill_(-1.0)
+        cs.lut_ut_dev(lut.data_ptr(), fout.data_ptr(), 0, N, stream)
         dr = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_DIRECT, stream=stream)
         dr.eqcount_ut_dev(ref.data_ptr(), 0, N, stream)
         torch.cuda.synchronize()
         assert torch.equal(out, ref), name
+        assert torch.equal(fout.view(torch.int32), lut[ref.long()].view(torch.int32)), name     # the table epilogue after the counts: no leader flag survives
         dr.close()
         # row ranges (a shard, a CLI batch): the same values as the whole-triangle launch
         host = out.cpu().numpy().view(np.uint32)
         for r0, r1 in ((0, 1), (5, 700), (N // 3, N // 3 + 1111), (N - 300, N)):
             np.testing.assert_array_equal(cs.eqcount_ut(r0, r1), host[off[r0]:off[r1]], err_msg=f"{name} rows {r0}:{r1}")
-        # and the oracle on a few rows
-        r0, r1 = 100, 103
-        want = np.concatenate([(m[i + 1:] == m[i]).sum(axis=1) for i in range(r0, r1)]).astype(np.uint32)
-        np.testing.assert_array_equal(host[off[r0]:off[r1]], want, err_msg=name)
+        fpart = torch.empty(int(off[N // 3 + 1111] - off[N // 3]), dtype=torch.float32, device=dev)
+        cs.lut_ut_dev(lut.data_ptr(), fpart.data_ptr(), N // 3, N // 3 + 1111, stream)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(fpart.cpu().numpy().view(np.uint32), lut_np[host[off[N // 3]:off[N // 3 + 1111]]].view(np.uint32), err_msg=name)
+        # and the ORACLE on 64+ rows (first rows, random rows, last rows)
+        for i in sample:
+            want = oracle.eqcounts_rows(m, int(i), int(i) + 1)
+            np.testing.assert_array_equal(host[off[i]:off[i + 1]], want, err_msg=f"{name} row {i}")
         del t_dev
     cs.close()
-    assert seen["families"]["sorted_operand"] and seen["families"]["tiles_listed"] > 0 and not seen["families"]["dense_kernel_ran"]
-    assert seen["families"]["tiles_from_segments"] == (segments == "default")
-    assert seen["paired"]["dense_kernel_ran"] and seen["paired"]["marking_gave_up"]          # a random pairing per column: everything hangs together
-    assert seen["one_chain"]["callers_order_kept"] and seen["one_chain"]["dense_kernel_ran"]     # deep label chains: found early, the caller's order kept
-    assert seen["chains"]["tiles_from_segments"] == (segments == "default") and seen["chains"]["tiles_listed"] > 0 and not seen["chains"]["dense_kernel_ran"]
-    assert seen["skewed"]["dense_kernel_ran"] and seen["skewed"]["callers_order_kept"]
-    assert seen["unrelated"]["tiles_listed"] == 0 and not seen["unrelated"]["dense_kernel_ran"]
+    f = seen["families"]
+    assert f["sorted_operand"]
+    if variant != "short_list":                                        # (a list of pairs / 4096 entries may not even hold the families' stragglers)
+        assert not f["dense_kernel_ran"] and f["tiles_and_pair_list"]
+    if variant == "no_link":
+        assert f["tiles_listed"] == 0 and f["pairs_listed"] > 100_000                           # every equal register pair of the matrix is a list entry
+    elif variant != "short_list":
+        assert f["tiles_listed"] > 0
+    if variant == "default":
+        # ten chance collisions per sketch used to list every tile; now the families keep their tiles and the strangers go to the list
+        # (S = 96: one collision per sketch is 1 % of the registers, ten are 10 % -- heavy noise at this sketch size)
+        assert 0 < seen["families+1"]["tiles_listed"] <= 2 * f["tiles_listed"] and seen["families+1"]["pairs_listed"] > 10_000
+        assert not seen["families+1"]["dense_kernel_ran"]
+        # no families: (nearly) every equal register pair is a list entry -- a few pairs land in one segment by chance and come from tiles
+        assert seen["paired"]["tiles_and_pair_list"] and 0.99 * (N // 2 * S) <= seen["paired"]["pairs_listed"] <= N // 2 * S
+        assert seen["chains"]["pairs_listed"] > 0 and not seen["chains"]["dense_kernel_ran"]
+        assert seen["skewed"]["dense_kernel_ran"]                                                # one family takes everything
+        assert seen["unrelated"]["tiles_listed"] == 0 and seen["unrelated"]["pairs_listed"] == 0 and not seen["unrelated"]["dense_kernel_ran"]
+    if variant == "short_list":
+        assert seen["paired"]["dense_kernel_ran"] and seen["paired"]["dense_decided_by_prepare"]  # the list overflowed: dense walk, same counts
+
+
+def test_k2_bench_matrix_rows_vs_oracle(gpu_ctx, d2g, oracle):
+    """the EXACT matrix bench.py times (config 3: synthetic_registers(10000, 1024, nclusters=66, seed=20260928), finalised)
+    on the sparse path (asserted), ~200 rows -- first rows, the seams of an 8-way pair-balanced partition, random rows, last rows --
+    value for value against the oracle: equality counts and the fused float epilogue; then the same matrix with ten chance collisions
+    per sketch (bench.py's noise family)."""
+    import torch
+    N, S = 10_000, 1024
+    regs = synth.synthetic_registers(N, S, nclusters=66, seed=20260928)
+    off = _ut_offsets(N)
+    rng = np.random.default_rng(5)
+    seams = [int(x) for x in d2g.ut_partition(N, 8)]
+    rows = sorted(set(list(range(0, 24)) + [min(N - 2, max(0, b + d)) for b in seams for d in (-2, -1, 0, 1)] + [int(x) for x in rng.integers(0, N - 1, 120)] + list(range(N - 25, N - 1))))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for label, rr in (("stated", regs), ("stated + 10 collisions", synth.add_chance_collisions(regs, 10, seed=20260929))):
+        sig, cards = d2g.oph_finalize(rr, S, nthreads=8)
+        t_dev = torch.from_numpy(sig.view(np.int64)).to(dev)
+        cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_AUTO, stream=stream)
+        out = torch.empty(N * (N - 1) // 2, dtype=torch.int32, device=dev)
+        cs.eqcount_ut_dev(out.data_ptr(), 0, N, stream)
+        info = cs.sparse_info(stream)
+        assert info["sorted_operand"] and info["tiles_listed"] > 0 and info["tiles_and_pair_list"] and not info["dense_kernel_ran"], (label, info)
+        if label != "stated":
+            assert info["pairs_listed"] > 0
+        fout = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
+        lut = torch.from_numpy(d2g.epilogue_lut(S, d2g.SIMILARITY, 31)).to(dev)
+        cs.lut_ut_dev(lut.data_ptr(), fout.data_ptr(), 0, N, stream)
+        torch.cuda.synchronize()
+        host, fhost = out.cpu().numpy().view(np.uint32), fout.cpu().numpy()
+        for i in rows:
+            want = oracle.eqcounts_rows(sig, i, i + 1)
+            np.testing.assert_array_equal(host[off[i]:off[i + 1]], want, err_msg=f"{label} row {i}")
+            fwant = oracle.allpairs_ut(sig, cards, measure=oracle.SIMILARITY, k=31, r0=i, r1=i + 1, nthreads=4)
+            np.testing.assert_array_equal(fhost[off[i]:off[i + 1]].view(np.uint32), fwant.view(np.uint32), err_msg=f"{label} row {i}")
+        cs.close()
+        del t_dev, out, fout

@@ -323,7 +323,7 @@ def test_allpairs_config4_shape_world8_vs_single_gpu(d2g, gpu_ctx):
 @pytest.mark.parametrize("W,N,S,kind", [(2, 2600, 512, "families"), (3, 1900, 256, "families"), (4, 1500, 1024, "families"), (2, 900, 128, "planted"), (3, 1100, 128, "one_family")])
 def test_allpairs_sparse_tiles_on_the_gathered_operand(d2g, oracle, monkeypatch, W, N, S, kind):
     """The engine's pair phase over the gathered operand takes the sparse-tile path (production: N >= 8192; forced here): every rank
-    re-derives ids from the exchanged planes, orders the sketches by shared-value labels, marks tiles and runs the listed tiles (or
+    re-derives ids from the exchanged planes, finds the families, lists the pairs across families and runs the families' tiles (or
     the dense walk behind the gate) -- every rank's whole slab against the oracle, both epilogues, twice in a row (the second step
     re-orders a re-gathered operand), and the path reported by d2g_allpairs_sparse_info."""
     monkeypatch.setenv("D2G_BS_SPARSE_MIN_N", "1")
@@ -369,7 +369,7 @@ def test_allpairs_sparse_tiles_on_the_gathered_operand(d2g, oracle, monkeypatch,
             info = engs[r].sparse_info()
             assert info["sorted_operand"]
             if kind == "families":
-                assert info["tiles_listed"] > 0 and not info["marking_gave_up"]
+                assert info["tiles_listed"] > 0 and info["tiles_and_pair_list"] and not info["dense_decided_by_prepare"]
             if kind == "one_family":
                 assert info["dense_kernel_ran"]
     assert "order" in {p["phase"] for p in engs[0].phase_times()}

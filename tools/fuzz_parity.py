@@ -89,16 +89,21 @@ def main():
                 N = int(rng.integers(2, 700)) if rng.random() < 0.8 else int(rng.integers(700, 2600))
                 S = int(rng.choice([32, 64, 100, 128, 1000, 1024])); meas = int(rng.integers(0, 6))
                 os.environ["D2G_BS_SORT"] = str(int(rng.integers(0, 2)))                    # column plan on / off
-                # sparse tiles (round 4): forced on for these small matrices half of the time, with 0-2 labelling rounds; the other half
-                # takes the default (dense walk below 8192 sketches)
+                # sparse tiles + pair list (round 5): forced on for these small matrices half of the time -- families found or not
+                # (D2G_SP_LINK=0: the pair list alone), with or without the attach step, any tile budget, a short list (overflow ->
+                # dense walk); the other half takes the default (dense walk below 8192 sketches)
+                for var in ("D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV"):
+                    os.environ.pop(var, None)
                 if rng.random() < 0.5:
                     os.environ["D2G_BS_SPARSE_MIN_N"] = "1"
-                    os.environ["D2G_BS_LABEL_ROUNDS"] = str(int(rng.integers(0, 3)))
-                    os.environ["D2G_SP_SEGMENTS"] = str(int(rng.random() < 0.7))            # tiles from the sort's segments where they are exact / always marked
-                else:
-                    os.environ.pop("D2G_BS_SPARSE_MIN_N", None)
-                    os.environ.pop("D2G_BS_LABEL_ROUNDS", None)
-                    os.environ.pop("D2G_SP_SEGMENTS", None)
+                    if rng.random() < 0.2:
+                        os.environ["D2G_SP_LINK"] = "0"
+                    if rng.random() < 0.3:
+                        os.environ["D2G_SP_ATTACH"] = "0"
+                    os.environ["D2G_SP_TILE_FRAC"] = str(rng.choice([0.05, 0.35, 1.0]))
+                    if rng.random() < 0.2:
+                        os.environ["D2G_SP_LIST_DIV"] = str(int(rng.choice([1, 64, 4096])))
+                ctx.reload_tuning()
                 r = rng.random()
                 if r < 0.25:
                     regs = synth.skewed_registers(N, S, seed=int(rng.integers(0, 1 << 30)), max_shared=int(rng.choice([4, 64, 300])))
@@ -109,6 +114,8 @@ def main():
                     regs = synth.unrelated_registers(N, S, seed=int(rng.integers(0, 1 << 30)))
                 else:
                     regs = synth.synthetic_registers(N, S, nclusters=int(rng.integers(1, 12)), seed=int(rng.integers(0, 1 << 30)))
+                    if rng.random() < 0.5:                                                   # families + chance collisions with strangers
+                        regs = synth.add_chance_collisions(regs, int(rng.choice([1, 3, 10, 40])), seed=int(rng.integers(0, 1 << 30)))
                 sig, card = D.oph_finalize(regs, S)
                 multiset = bool(rng.integers(0, 2))
                 got = ctx.cmp_dist_ut(sig.view(np.uint64), card, measure=meas, k=int(rng.integers(1, 33)) if False else 31,
@@ -139,6 +146,7 @@ def main():
                         os.environ.pop(var, None)
                     else:
                         os.environ[var] = v
+                ctx.reload_tuning()
                 fa = [rand_fasta(rng, int(rng.choice([300, 5000, 80000, 400000]))) for _ in range(int(rng.integers(1, 6)))]
                 sp = D.SeqPack(k)
                 for f in fa:

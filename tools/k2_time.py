@@ -12,8 +12,10 @@ dev = torch.device("cuda", 0)
 which = os.environ.get("MATRIX", "stated")
 regs = {"stated": lambda: synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928),
         "unrelated": lambda: synth.unrelated_registers(N, S), "paired": lambda: synth.paired_registers(N, S),
-        "skewed": lambda: synth.skewed_registers(N, S)}[which]()
-sig = D.oph_finalize(regs, S, nthreads=32)[0] if which == "stated" else regs.view(np.float64)
+        "skewed": lambda: synth.skewed_registers(N, S),
+        # the stated families + C chance collisions per sketch with random strangers
+        "noise": lambda: synth.add_chance_collisions(synth.synthetic_registers(N, S, nclusters=max(8, N // 150), seed=20260928), int(os.environ.get("C", 10)), seed=20260929)}[which]()
+sig = D.oph_finalize(regs, S, nthreads=32)[0] if which in ("stated", "noise") else regs.view(np.float64)
 t = torch.from_numpy(sig.view(np.int64)).to(dev)
 lut = torch.from_numpy(D.epilogue_lut(S, D.SIMILARITY, 31)).to(dev)
 out = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
@@ -32,4 +34,4 @@ torch.cuda.synchronize()
 step_ms = (time.perf_counter() - t0) / 20 * 1e3
 n, ms, _ = ctx.kernel_ms("k2")
 print(f"step (prepare + compare) {step_ms:.4f} ms; sparse: {cs.sparse_info(st)}")
-print(f"{which} N={N} D2G_BS_EXP={os.environ.get('D2G_BS_EXP','0')} planes={cs.planes(st)} pair kernel {ms:.4f} ms over {n} launches")
+print(f"{which} C={os.environ.get('C','-')} N={N} D2G_BS_EXP={os.environ.get('D2G_BS_EXP','0')} planes={cs.planes(st)} pair kernel {ms:.4f} ms over {n} launches")
