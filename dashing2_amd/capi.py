@@ -911,7 +911,7 @@ class AllPairs:
     def chunks(self):
         return lib().d2g_allpairs_chunks(self._h)
 
-    PHASE_NAMES = ("pack", "x1", "prepare", "x2", "derive", "pair", "order")
+    PHASE_NAMES = ("pack", "x1", "prepare", "x2", "derive", "pair", "order", "fill")
 
     def set_phase_timing(self, on=True):
         """bracket every phase of the next prepare/step with timing events (switch off again for timed runs)"""

@@ -50,6 +50,7 @@ struct d2g_cmp_set {
     uint32_t *d_sperm = nullptr;      // [Nstride] sketch at sorted position p (0xFFFFFFFF = padding)
     uint32_t *d_sinv = nullptr;       // [Npad]    sorted position of sketch j
     uint32_t *d_label = nullptr;      // [2][Npad] union-find labels (-> segment starts after the sort) | root of every sketch
+    uint32_t *d_segend = nullptr;     // [Npad]    end of the segment of root r (the sort's scan)
     uint32_t *d_hint = nullptr;       // [2][Npad] per sketch the smallest holder of a value it shares (even / odd column pairs), 0xFFFFFFFF = none
     uint32_t *d_spz = nullptr;        // ONE block the prepare clears: the five arrays below
     size_t spz_words = 0;
@@ -64,6 +65,7 @@ struct d2g_cmp_set {
     uint32_t *d_tilebm = nullptr, *d_tiles = nullptr, *d_spctl = nullptr;   // a partial launch's tile bitmap, work list, 2 x 8 control words {tiles listed, flags, -, candidates}
     uint32_t *d_tiles_full = nullptr, *d_fullctl = nullptr;   // work lists + control words of a whole-triangle launch, left by the prepare (sp_permute_kernel)
     bool full_list_valid = false;
+    uint32_t *prefilled = nullptr;        // output the engine filled at the start of its step (d2g_bitslice_prefill): the next sparse launch into it skips its fill
     const uint32_t *last_ctl = nullptr;   // control words of the last sparse launch (d2g_cmp_set_sparse_info)
     unsigned long long *d_plist = nullptr;   // pair list: (i | j << 32), i < j caller's indices, one entry per (pair in different segments, shared value)
     size_t plist_cap = 0;
@@ -98,6 +100,8 @@ int  d2g_bitslice_derive_groups(d2g_ctx *ctx, const d2g_cmp_set *set, int g0, in
 // exactly one of (eq_out) or (lut,fout) is non-null
 int  d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out,
                      const float *lut, float *fout, hipStream_t s);
+// multi-GPU engine: the fill of a rank's slab enqueued at the start of the step (under the exchanges)
+int  d2g_bitslice_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout, hipStream_t s);
 int  d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1,
                        uint32_t *eq_out, hipStream_t s);
 

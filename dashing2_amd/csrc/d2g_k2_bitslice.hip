@@ -829,7 +829,7 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     if (int rc = d2g_bitslice_alloc_stream(ctx, set)) { d2g_bitslice_free(set); return rc; }
     set->ncols = set->S;
     set->sparse_ok = sparse_enabled(ctx, set->N) && set->S < 65536;          // (the sparse kernel packs two mismatch counts into one LDS word)
-    if (set->sparse_ok) if (int rc = sp_alloc(ctx, set)) { d2g_bitslice_free(set); return rc; }
+    if (set->sparse_ok && sp_alloc(ctx, set) != D2G_OK) { sp_free(set); (void)hipGetLastError(); set->sparse_ok = false; }   // no memory for the sparse path's buffers: the dense walk works without them
     return D2G_OK;
 }
 
@@ -973,6 +973,11 @@ int d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, 
     return launch_bitslice(ctx, set, sh, StoreLut{fout, lut}, s);
 }
 
+int d2g_bitslice_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout, hipStream_t s) {
+    if (eq_out) return sp_prefill(ctx, set, r0, r1, StoreEq{eq_out}, eq_out, s);
+    return sp_prefill(ctx, set, r0, r1, StoreLut{fout, lut}, reinterpret_cast<uint32_t *>(fout), s);
+}
+
 int d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1, uint32_t *eq_out,
                       hipStream_t s) {
     PairShape sh{};
@@ -990,11 +995,13 @@ int d2g_bitslice_managed_sparse_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     if ((e = hipMalloc((void **)&set->d_ids, set->ncols * set->Npad * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_colcnt, set->ncols * BS_CC_STRIDE * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMemset(set->d_colcnt, 0, set->ncols * BS_CC_STRIDE * sizeof(uint32_t))) != hipSuccess) {
-        ctx->last_error = std::string("bitslice sparse alloc (gathered operand): ") + hipGetErrorString(e);
-        return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
+        // not enough memory for the sparse path's buffers: the dense walk works without them
+        (void)hipFree(set->d_ids); (void)hipFree(set->d_colcnt); set->d_ids = set->d_colcnt = nullptr;
+        (void)hipGetLastError();
+        return D2G_OK;
     }
     set->ids_owned = true;
-    if (int rc = sp_alloc(ctx, set)) return rc;
+    if (sp_alloc(ctx, set) != D2G_OK) { sp_free(set); (void)hipGetLastError(); return D2G_OK; }
     set->sparse_ok = true;
     return D2G_OK;
 }

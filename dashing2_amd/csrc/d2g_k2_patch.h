@@ -14,6 +14,7 @@ struct SpPatchArgs {
     const uint32_t *ctl; uint32_t cand;
     const uint32_t *sinv, *rowk, *bm;     // bm: the launch's tile bitmap (full launches: over sorted row blocks; partial: over launch-row blocks)
     uint32_t CW, r0, r1; int full;
+    uint32_t nwg;                         // workgroups of the sparse pair kernel that share the entries (the others leave without looking at the list)
 };
 constexpr unsigned long long SP_LEADER = 0x80000000ull;               // in the low word of an entry (i < 2^30: d2g_bitslice_alloc refuses larger N)
 __device__ __forceinline__ bool sp_entry_wanted(const SpPatchArgs &a, uint32_t i, uint32_t j) {

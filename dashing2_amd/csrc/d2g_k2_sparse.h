@@ -25,7 +25,7 @@
 //          sp_attach  a sketch no column pair linked joins the family TWO independent hints point to (the smallest holder of a value
 //                     it shares, recorded by even and by odd column pairs): a weak family member, or families of two;
 //          sp_count / scan / place   counting sort by root -> sperm / sinv, the segments, keep-the-caller's-order decision;
-//          sp_emit    (b) above + the segments' tiles;
+//          sp_emit    (b) above (the segments' tiles are set by the sort's place kernel);
 //          sp_permute the finished plane stream in sorted order.
 // launch   sp_list -> sp_fill -> k2_bitslice_sparse_kernel (listed tiles; stores the non-zero counts) -> sp_patch_add (list entries
 //          outside listed tiles: atomicAdd of 1 onto the filled word; the first adder of a position is its leader) -> sp_patch_lut (table
@@ -63,30 +63,33 @@ __device__ __forceinline__ bool sp_union(uint32_t *label, uint32_t a, uint32_t b
     return false;
 }
 
-// One workgroup per pair of adjacent columns (t1, t2) = (2g, 2g + 1), launched twice.  LDS, per shared value r1 of column t1 (ranks 1 .. nv):
+// One workgroup per pair of adjacent columns (t1, t2) = (2g, 2g + 1).  LDS, per shared value r1 of column t1 (ranks 1 .. nv):
 //   r2[r1]   the rank in column t2 of the first holder of r1 that has a shared value there too (claimed with a compare-and-swap); the
 //            holders of r1 whose t2 rank equals r2[r1] MATCH: they agree in both columns;
-//   MODE 0 (propagate)  mn[r1] = the smallest label among the matchers; every matcher takes it with a PLAIN store.  A label is only
-//            ever replaced by a smaller index of the same family, so whichever racing store lands last the array still holds, per
-//            sketch, an earlier member of its family.  This does nearly all the uniting without a single global atomic (letting every
-//            matcher run the union-find below from identity labels was measured: 264 us at config 3 -- 1.6 million root walks and
-//            compare-and-swaps for the 9 934 hooks the families need);
-//   MODE 1 (unite)      a matcher whose label still differs from mn[r1] runs the lock-free union with it (few do: labels are loaded in
-//            batches up front -- comparing with a representative's label through a second device-scope load per matcher cost 55 us);
-//            any[r1] = the smallest sketch among ALL holders of r1: the hint a holder that did not match takes away.
+//   mn[r1]   the smallest label among the matchers.
+//   MODE 0 (every column pair: propagate)  every matcher takes mn with a PLAIN store.  A label is only ever replaced by a smaller index
+//            of the same family, so whichever racing store lands last the array still holds, per sketch, an earlier member of its
+//            family.  This does nearly all the uniting without a single global atomic (letting every matcher run the union-find below
+//            from identity labels was measured: 264 us at config 3 -- 1.6 million root walks and compare-and-swaps for the 9 934 hooks
+//            the families need).  Also here: any[r1] = some holder of r1 -- the hint a holder that did not match takes away --, and the
+//            `linked` flag of a root that matched somebody.
+//   MODE 1 (every `stride`-th column pair, behind sp_flatten_kernel: unite)  where a matcher's label still differs from mn, ONE
+//            matcher per value runs the lock-free union of the two trees: the safety net for families the racing stores left under two
+//            roots (every matcher doing so cost 40 us; a quarter of the column pairs still sees every family dozens of times).
 // Values beyond the table (nv = min(D2, cap)) take no part: the partition is a heuristic, sp_emit_kernel keeps the result exact.
-constexpr uint32_t SP_PLURAL = 0x80000000u, SP_R2MASK = 0x7FFFFFFFu;      // r2[]: bit 31 = the value has two or more matchers (ranks stay below 2^30)
+constexpr uint32_t SP_PLURAL = 0x80000000u, SP_UDONE = 0x40000000u, SP_R2MASK = 0x3FFFFFFFu;   // r2[]: bit 31 = the value has two or more matchers, bit 30 = one of them has run the union (ranks stay below 2^29: N < 2^30)
 template <int MODE>
 __global__ __launch_bounds__(1024) void sp_link_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt,
-                                                       int split, uint32_t cap, uint32_t *label, uint32_t *__restrict__ hint, uint32_t *__restrict__ linked) {
+                                                       int split, uint32_t cap, uint32_t stride, uint32_t *label, uint32_t *__restrict__ hint, uint32_t *__restrict__ linked) {
     extern __shared__ uint32_t sp_l[];
-    const size_t t1 = 2 * (size_t)blockIdx.x, t2 = t1 + 1;
+    const size_t pair = (size_t)blockIdx.x * stride;
+    const size_t t1 = 2 * pair, t2 = t1 + 1;
     if (t2 >= ncols) return;
     const uint32_t d2 = colcnt[t1 * BS_CC_STRIDE + 4];
     if (d2 == 0) return;
     const uint32_t nv = min(d2, cap), T = blockDim.x;
-    uint32_t *r2 = sp_l, *x1 = sp_l + nv, *x2 = sp_l + 2 * (size_t)nv;          // x1: mn; x2: any (MODE 1)
-    for (uint32_t r = threadIdx.x; r < (MODE ? 3u : 2u) * nv; r += T) sp_l[r] = SP_NONE;
+    uint32_t *r2 = sp_l, *mn = sp_l + nv, *any = sp_l + 2 * (size_t)nv;         // any: MODE 0 only
+    for (uint32_t r = threadIdx.x; r < (MODE ? 2u : 3u) * nv; r += T) sp_l[r] = SP_NONE;
     __syncthreads();
     constexpr int U = 4;
     for (size_t j0 = 0; j0 < N; j0 += (size_t)T * U) {
@@ -103,17 +106,17 @@ __global__ __launch_bounds__(1024) void sp_link_kernel(const uint32_t *__restric
             const uint32_t j = (uint32_t)(j0 + (size_t)x * T + threadIdx.x);
             const uint32_t a = sp_rank(w1[x], colcnt, t1, split != 0), b = sp_rank(w2[x], colcnt, t2, split != 0);
             if (!a || a > nv) continue;
-            if (MODE) atomicMin(&x2[a - 1], j);
+            if (MODE == 0) any[a - 1] = j;                            // (a plain LDS store: the lanes of a wave that share the value write once; a minimum cost 13 us)
             if (!b) continue;
             const uint32_t old = atomicCAS(&r2[a - 1], SP_NONE, b);
             if (old == SP_NONE || (old & SP_R2MASK) == b) {
-                atomicMin(&x1[a - 1], lb[x]);
-                if (MODE && old == b) atomicOr(&r2[a - 1], SP_PLURAL);   // a second matcher (set once: later ones see the bit)
+                atomicMin(&mn[a - 1], lb[x]);
+                if (MODE == 0 && old == b) atomicOr(&r2[a - 1], SP_PLURAL);   // a second matcher (set once: later ones see the bit)
             }
         }
     }
     __syncthreads();
-    uint32_t *myhint = hint + (size_t)(blockIdx.x & 1u) * Npad;
+    uint32_t *myhint = hint + (size_t)(pair & 1u) * Npad;
     for (size_t j0 = 0; j0 < N; j0 += (size_t)T * U) {
         uint32_t w1[U], w2[U], lb[U];
 #pragma unroll
@@ -131,17 +134,18 @@ __global__ __launch_bounds__(1024) void sp_link_kernel(const uint32_t *__restric
             const uint32_t rr = r2[a - 1];
             const bool match = b && rr != SP_NONE && (rr & SP_R2MASK) == b;
             if (MODE == 0) {
-                if (match) { const uint32_t m = x1[a - 1]; if (m < lb[x]) label[j] = m; }
+                if (match) {
+                    const uint32_t m = mn[a - 1];
+                    if (m < lb[x]) label[j] = m;
+                    // a ROOT that matched somebody is no singleton: sp_attach_kernel must leave it alone (non-roots it skips anyway)
+                    if ((rr & SP_PLURAL) && lb[x] == j) linked[j] = 1;
+                } else {
+                    const uint32_t h = any[a - 1];
+                    if (h != j) myhint[j] = h;
+                }
             } else if (match) {
-                // every matcher of a value with two or more of them marks ITSELF linked (all of them writing one representative's flag
-                // put thousands of stores on one address per family)
-                if (rr & SP_PLURAL) linked[j] = 1;
-                // the matchers' smallest label: after the propagation and the flatten pass it is nearly always this sketch's own
-                const uint32_t m = x1[a - 1];
-                if (m != lb[x]) (void)sp_union(label, j, m);
-            } else {
-                const uint32_t h = x2[a - 1];
-                if (h != j) myhint[j] = h;
+                const uint32_t m = mn[a - 1];
+                if (m != lb[x] && !(atomicOr(&r2[a - 1], SP_UDONE) & SP_UDONE)) (void)sp_union(label, lb[x], m);
             }
         }
     }
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t
 // otherwise (a weak family member, families of two, chains)
 __global__ __launch_bounds__(256) void sp_attach_kernel(uint32_t *label, const uint32_t *__restrict__ hint, const uint32_t *__restrict__ linked, size_t N, size_t Npad) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N || linked[j]) return;
+    if (j >= N || label[j] != (uint32_t)j || linked[j]) return;       // under somebody already, or a root that matched somebody
     const uint32_t a = hint[j], b = hint[Npad + j];
     if (a == SP_NONE && b == SP_NONE) return;
     const uint32_t ra = a != SP_NONE ? sp_find(label, a) : SP_NONE, rb = b != SP_NONE ? sp_find(label, b) : SP_NONE;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(256) void sp_count_kernel(uint32_t *label, uint32_t
 }
 // order[0] = 1: the launches walk every tile of the caller's-order operand (one root holds more than half of the sketches, deep label
 // chains, or the segments would cover more than seg_tile_limit tiles -- the sparse kernel costs about twice the plain one per tile)
-__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t seg_tile_limit) {
+__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t *__restrict__ segend, uint32_t seg_tile_limit) {
     // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
     __shared__ uint32_t wave_tot[16];
     __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
@@ -276,7 +280,10 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
             reinterpret_cast<u32x4 *>(tile)[tid * 2 + 1] = u32x4{o[4], o[5], o[6], o[7]};
         }
         __syncthreads();
-        for (uint32_t x = tid; x < n; x += 1024) { cnt[base + x] = tile[x]; start[base + x] = tile[x]; }   // cnt becomes the placing cursor (-> segment end), start stays
+        for (uint32_t x = tid; x < n; x += 1024) {                     // cnt becomes the placing cursor, start and segend stay (a segment ends where the next one starts)
+            cnt[base + x] = tile[x]; start[base + x] = tile[x];
+            segend[base + x] = x + 1 < n ? tile[x + 1] : s_run + total;
+        }
         if (tid == 0) s_run += total;
         __syncthreads();
     }
@@ -286,13 +293,27 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
     __syncthreads();
     if (tid == 0) order[0] = (s_big || order[2] || s_est > seg_tile_limit + 1024) ? 1u : 0u;
 }
+// a segment [a, b) of two or more sketches sets the tiles its row blocks (32 positions) and column blocks (256 positions) meet in: every
+// pair inside the segment lies in one of them (fact (a) of the header)
+__device__ __forceinline__ void sp_segtiles(uint32_t a, uint32_t b, uint32_t CW, uint32_t *__restrict__ gbm) {
+    if (b - a < 2) return;                                            // a sketch alone in its segment has no pair inside it
+    const uint32_t cb0 = a >> 8, cb1 = (b - 1) >> 8;
+    for (uint32_t rb = a >> 5; rb <= (b - 1) >> 5; ++rb)
+        for (uint32_t cw = cb0 >> 5; cw <= cb1 >> 5; ++cw) {
+            const uint32_t lo = cw == (cb0 >> 5) ? (cb0 & 31) : 0u, hi = cw == (cb1 >> 5) ? (cb1 & 31) : 31u;
+            const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            atomicOr(&gbm[(size_t)rb * CW + cw], m);
+        }
+}
 __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
-                                                        uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order) {
+                                                        uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order,
+                                                        const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, uint32_t CW, uint32_t *__restrict__ gbm) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = j < N;
     if (!live && j < Nstride) sperm[j] = SP_NONE;
     if (order[0]) { if (live) { sperm[j] = (uint32_t)j; sinv[j] = (uint32_t)j; } return; }
     const uint32_t r = live ? root[j] : SP_NONE;
+    if (live && r == (uint32_t)j) sp_segtiles(seg_start[j], seg_end[j], CW, gbm);     // the root's thread sets its segment's tiles
     const int lane = threadIdx.x & 63;
     uint32_t p = 0;
     const unsigned long long alive = __ballot(live);
@@ -309,99 +330,6 @@ __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restric
     if (live) { sperm[p] = (uint32_t)j; sinv[j] = p; }
 }
 
-// the three sort kernels in ONE single-workgroup launch for N <= 16 384 (counters in LDS): count 5 + scan 7.5 + place 6 us -> one
-// kernel; a thread owns 16 consecutive counters in the prefix and 16 strided sketches in the walks
-constexpr int SP_SORT_SMALL_U = 16;
-__global__ __launch_bounds__(1024) void sp_sort_small_kernel(uint32_t *label, uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ ends,
-                                                             uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, uint32_t *__restrict__ order, uint32_t seg_tile_limit) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];     // [ceil16(N)] counters -> cursors
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t s_big, s_deep, s_est, s_keep;
-    constexpr int U = SP_SORT_SMALL_U;
-    const int tid = threadIdx.x;
-    const uint32_t n16 = (uint32_t)((N + 15) / 16 * 16);
-    for (uint32_t x = tid; x < n16; x += 1024) cnt[x] = 0;
-    if (tid == 0) { s_big = 0; s_deep = 0; s_est = 0; }
-    __syncthreads();
-    // the 16 walks of a thread advance TOGETHER, one hop of each per round: 16 loads in flight instead of one (a walk at a time made
-    // this kernel 28 us: 16 x 2-3 dependent round trips)
-    uint32_t r[U];
-    uint32_t open = 0;
-#pragma unroll
-    for (int k = 0; k < U; ++k) { const size_t j = (size_t)k * 1024 + tid; r[k] = j < N ? (uint32_t)j : SP_NONE; if (j < N) open |= 1u << k; }
-    for (int h = 0; open; ++h) {
-        uint32_t p[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) p[k] = (open >> k) & 1u ? label[r[k]] : 0u;
-        if (h == SP_MAX_HOPS) {
-            s_deep = 1;
-#pragma unroll
-            for (int k = 0; k < U; ++k) if ((open >> k) & 1u) r[k] = (uint32_t)((size_t)k * 1024 + tid);
-            break;
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            if (!((open >> k) & 1u)) continue;
-            if (p[k] == r[k]) open &= ~(1u << k); else r[k] = p[k];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-        const size_t j = (size_t)k * 1024 + tid;
-        if (j >= N) continue;
-        root[j] = r[k];
-        atomicAdd(&cnt[r[k]], 1u);
-    }
-    __syncthreads();                                                   // (every label has been read: the array is free for the segment starts)
-    uint32_t v[U], sum = 0, big = 0, est = 0;
-#pragma unroll
-    for (int x = 0; x < U; ++x) {
-        const uint32_t i = (uint32_t)tid * U + x;
-        v[x] = i < n16 ? cnt[i] : 0u;
-        sum += v[x]; big = max(big, v[x]);
-        est += sp_seg_est(v[x]);
-    }
-    if ((size_t)big * 2 > N) s_big = 1;
-    uint32_t total;
-    uint32_t run = sp_block_scan(sum, wave_tot, &total);
-    est = min(est, 0x3FFFFFu) / 16 + 1;
-    for (int o = 32; o > 0; o >>= 1) est += __shfl_down(est, o);
-    if ((tid & 63) == 0) atomicAdd(&s_est, est);
-#pragma unroll
-    for (int x = 0; x < U; ++x) {
-        const uint32_t i = (uint32_t)tid * U + x;
-        if (i < N) { cnt[i] = run; label[i] = run; ends[i] = run + v[x]; }     // label[] becomes the segment starts (as in sp_scan_kernel)
-        run += v[x];
-    }
-    __syncthreads();
-    if (tid == 0) { const uint32_t keep = (s_big || s_deep || s_est > seg_tile_limit + 1024) ? 1u : 0u; order[0] = keep; order[2] = s_deep; s_keep = keep; }
-    __syncthreads();
-    const bool keep = s_keep != 0;
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-        const size_t j = (size_t)k * 1024 + tid;
-        if (j >= N) continue;
-        const uint32_t p = keep ? (uint32_t)j : atomicAdd(&cnt[r[k]], 1u);
-        sperm[p] = (uint32_t)j; sinv[j] = p;
-    }
-    for (size_t x = N + tid; x < Nstride; x += 1024) sperm[x] = SP_NONE;
-}
-
-// sorted position p: the first position of (its segment x its row block) sets the tiles of that row block against the segment's column blocks
-__device__ __forceinline__ void sp_segtiles(size_t p, const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ root, const uint32_t *__restrict__ start,
-                                            const uint32_t *__restrict__ end, size_t N, uint32_t CW, uint32_t *__restrict__ gbm) {
-    if (p >= N) return;
-    const uint32_t r = root[sperm[p]];
-    const uint32_t a = start[r], b = end[r];
-    if (b - a < 2 || !(p == a || (p & 31) == 0)) return;              // a sketch alone in its segment has no pair inside it
-    const uint32_t rb = (uint32_t)(p >> 5), cb0 = a >> 8, cb1 = (b - 1) >> 8;
-    for (uint32_t cw = cb0 >> 5; cw <= cb1 >> 5; ++cw) {
-        const uint32_t lo = cw == (cb0 >> 5) ? (cb0 & 31) : 0u, hi = cw == (cb1 >> 5) ? (cb1 & 31) : 31u;
-        const uint32_t m = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-        atomicOr(&gbm[(size_t)rb * CW + cw], m);
-    }
-}
-
 // (b): every shared value of every column; the pairs of its holders that lie in different segments go to the pair list.  One workgroup
 // per column; the column's shared values are walked in ranges of at most `vcap` ranks:
 //   pass A  first[r] = segment of the first holder of value r (compare-and-swap); another segment among its holders marks r MIXED.
@@ -411,13 +339,11 @@ __device__ __forceinline__ void sp_segtiles(size_t p, const uint32_t *__restrict
 //   pass C  an entry pairs with every later entry of its chain that lies in another segment: counted, one reservation per workgroup and
 //           range in the global list, written.  A list that is full raises order[0] (dense walk): the list is then longer than a quarter
 //           of all pairs -- not a sparse matrix.
-// The grid's threads also set the segments' tiles (sp_segtiles).
 // A list that will not fit is noticed EARLY: every workgroup adds its column's pair count to plctl[2] and bumps plctl[3]; once 32
 // columns are in, (pairs so far / columns so far) x columns > 1.5 x capacity raises order[0] and everybody stops at its next range.
 constexpr uint32_t SP_EMIT_VCAP = 2048, SP_EMIT_ECAP = 2048, SP_EMIT_T = 512;      // 32 KB of LDS: four workgroups per CU
 __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
-                                                            const uint32_t *__restrict__ seg, uint32_t *__restrict__ order, const uint32_t *__restrict__ sperm,
-                                                            const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, uint32_t CW, uint32_t *__restrict__ gbm,
+                                                            const uint32_t *__restrict__ seg, uint32_t *__restrict__ order,
                                                             unsigned long long *__restrict__ plist, uint32_t *__restrict__ plctl, uint32_t plcap) {
     __shared__ uint32_t first[SP_EMIT_VCAP];
     __shared__ uint32_t mixed[SP_EMIT_VCAP / 32];
@@ -427,10 +353,25 @@ __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__re
     if (order[0]) return;
     constexpr uint32_t T = SP_EMIT_T;
     const uint32_t tid = threadIdx.x;
-    for (size_t p = (size_t)blockIdx.x * T + tid; p < N; p += (size_t)gridDim.x * T) sp_segtiles(p, sperm, seg, seg_start, seg_end, N, CW, gbm);
     const size_t t = blockIdx.x;
     const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
     if (d2 == 0) return;
+    // fn(rank, segment, sketch) for every sketch of the column that holds a shared value
+    // (keeping a thread's 20 (rank, segment) pairs packed in registers instead of re-reading the column in the second pass was measured at
+    // N = 10 000: 89 VGPRs, two workgroups per CU instead of four, 37.9 vs 35.6 us)
+    auto for_each_holder = [&](auto &&fn) {
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
+            uint32_t w[8], sg[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const size_t j = j0 + (size_t)x * T + tid;
+                w[x] = j < N ? ids[t * Npad + j] : 0u;
+                sg[x] = j < N ? seg[j] : 0u;
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) { const uint32_t r = sp_rank(w[x], colcnt, t, split != 0); if (r) fn(r, sg[x], (uint32_t)(j0 + (size_t)x * T + tid)); }
+        }
+    };
     uint32_t curlen = SP_EMIT_VCAP, colpairs = 0;
     bool voted = false;
     for (uint32_t lo = 0; lo < d2;) {
@@ -440,44 +381,22 @@ __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__re
         if (tid == 0) { s_nent = 0; s_any = 0; s_stop = sp_ld(&order[0]); }
         __syncthreads();
         if (s_stop) return;                                           // somebody found that the list will not fit
-        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
-            uint32_t w[8], sg[8];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const size_t j = j0 + (size_t)x * T + tid;
-                w[x] = j < N ? ids[t * Npad + j] : 0u;
-                sg[x] = j < N ? seg[j] : 0u;
-            }
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
-                if (r <= lo || r > lo + len) continue;                // (r == 0: unique)
-                const uint32_t old = atomicCAS(&first[r - 1 - lo], SP_NONE, sg[x]);
-                if (old != SP_NONE && old != sg[x]) { atomicOr(&mixed[(r - 1 - lo) >> 5], 1u << ((r - 1 - lo) & 31)); s_any = 1; }
-            }
-        }
+        for_each_holder([&](uint32_t r, uint32_t sgv, uint32_t) {
+            if (r <= lo || r > lo + len) return;
+            const uint32_t old = atomicCAS(&first[r - 1 - lo], SP_NONE, sgv);
+            if (old != SP_NONE && old != sgv) { atomicOr(&mixed[(r - 1 - lo) >> 5], 1u << ((r - 1 - lo) & 31)); s_any = 1; }
+        });
         __syncthreads();
         if (!s_any) { lo += len; continue; }                          // (uniform: read by everybody after the barrier, reset behind the next one)
         for (uint32_t x = tid; x < len; x += T) first[x] = SP_NONE;   // now the chains' heads
         __syncthreads();
-        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
-            uint32_t w[8], sg[8];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const size_t j = j0 + (size_t)x * T + tid;
-                w[x] = j < N ? ids[t * Npad + j] : 0u;
-                sg[x] = j < N ? seg[j] : 0u;
-            }
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const uint32_t r = sp_rank(w[x], colcnt, t, split != 0);
-                if (r <= lo || r > lo + len) continue;
-                const uint32_t q = r - 1 - lo;
-                if (!((mixed[q >> 5] >> (q & 31)) & 1u)) continue;
-                const uint32_t k = atomicAdd(&s_nent, 1u);
-                if (k < SP_EMIT_ECAP) { ej[k] = (uint32_t)(j0 + (size_t)x * T + tid); eseg[k] = sg[x]; enext[k] = atomicExch(&first[q], k); }
-            }
-        }
+        for_each_holder([&](uint32_t r, uint32_t sgv, uint32_t j) {
+            if (r <= lo || r > lo + len) return;
+            const uint32_t q = r - 1 - lo;
+            if (!((mixed[q >> 5] >> (q & 31)) & 1u)) return;
+            const uint32_t k = atomicAdd(&s_nent, 1u);
+            if (k < SP_EMIT_ECAP) { ej[k] = j; eseg[k] = sgv; enext[k] = atomicExch(&first[q], k); }
+        });
         __syncthreads();
         const uint32_t nent = s_nent;
         if (nent > SP_EMIT_ECAP) {
@@ -712,7 +631,7 @@ __device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, 
 constexpr int SP_FILL_PER_THREAD = 8, SP_FILL_THREADS = 256;
 template <class Store>
 __global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__restrict__ out, size_t cnt, Store store, uint32_t S, const uint32_t *__restrict__ ctl, uint32_t cand) {
-    if (sp_dense_mode(ctl, cand)) return;                           // dense mode: the pair kernel writes every output
+    if (ctl && sp_dense_mode(ctl, cand)) return;                    // dense mode: the pair kernel writes every output (ctl == nullptr: an early fill, before the mode is known)
     const uint32_t v = store.value_from_mismatches(S, S);           // the value of "no register equal"
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // the output pointer of a slab is only 4-byte aligned in general: head, 16-byte body, tail
@@ -784,7 +703,6 @@ struct SpArgs {
     uint32_t S, N;
     const uint32_t *sperm, *rowpos, *tiles, *ctl;
     uint32_t ncb, cand, tiles_cap;
-    int prefetch;                 // D2G_SP_PREFETCH (default 1): touch a sub-tile's operands once before the plane walk
 };
 
 // The sparse pair kernel.  A listed tile (32 launch rows x 256 sorted columns) is four 16 x 128 sub-tiles; a workgroup takes ONE
@@ -807,8 +725,17 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     const int lane = threadIdx.x & 63;
     const bool full = a.rowstream == nullptr;
     const int g0 = a.ntb * ks / KS, g1 = a.ntb * (ks + 1) / KS;
-    const size_t slot0 = stream_slot(a.meta, g0);
-    const uint32_t nq = (uint32_t)(stream_slot(a.meta, g1) - slot0);                 // planes this wave walks per sub-tile
+    // first plane slot of this wave's groups: one wave-wide prefix over the groups' live plane counts (a scalar loop over up to 24
+    // dependent loads before the first tile otherwise).  (Touching a sub-tile's operands once before the plane walk, all requests in
+    // flight together, was measured: no gain -- the words are L2-resident already; the kernel runs at ~60 % of the dense kernel's issue rate.)
+    size_t slot0;
+    if (a.ntb <= 64) {
+        uint32_t incl = lane < a.ntb ? (uint32_t)live_planes(a.meta, lane) : 0u;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+        slot0 = __builtin_amdgcn_readfirstlane(g0 ? __shfl(incl, g0 - 1) : 0u);
+    } else {
+        slot0 = stream_slot(a.meta, g0);
+    }
     for (uint32_t si = blockIdx.x >> 3; si < nsub; si += gridDim.x >> 3) {
         const uint32_t tile = mytiles[si >> 2], sub = si & 3u;
         const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
@@ -816,30 +743,6 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
         if (full && k0 > c0 + 64 * JR - 1) continue;                             // entirely below the diagonal of sorted positions (uniform for the workgroup)
         for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
-        if (a.prefetch && g1 > g0 && nq && a.Nstride < ((size_t)1 << 20)) {
-            // Every plane's operands of this sub-tile touched once, all requests in flight together: ONE exposed round trip to memory,
-            // after which the plane walk below finds its words in the XCD's L2.  (The walk keeps one plane ahead -- scalar loads return
-            // out of order, so there is no waiting for the older of two -- and waited out a trip to HBM per plane: 56 planes x ~0.9 us per
-            // wave at config 3.)  One dword per 64-byte segment: 8 segments of column words and 1 of row words per plane; a lane's
-            // segment index is clamped, not predicated (a branch per load otherwise).
-            const size_t rstep = full ? 2 * a.Nstride : a.rstride, cstep = 2 * a.Nstride;
-            const char *cbase = reinterpret_cast<const char *>(a.stream + a.Nstride + c0 + slot0 * cstep);
-            const char *rbase = reinterpret_cast<const char *>((full ? a.stream : a.rowstream) + k0 + slot0 * rstep);
-            const uint32_t nseg = nq * 8u - 1u;
-            uint32_t ln = (uint32_t)lane;
-            asm volatile("" : "+v"(ln));                               // the per-lane offsets are recomputed per sub-tile (hoisted out of the loop they were spilled)
-            uint32_t v[8];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                const uint32_t x = min(ln + 64u * i, nseg), q = x >> 3, part = x & 7u;
-                v[i] = *reinterpret_cast<const uint32_t *>(cbase + (q * (uint32_t)cstep + part * 16u) * 4u);   // < 2^32: Nstride < 2^20, <= ~128 planes
-            }
-            v[7] = *reinterpret_cast<const uint32_t *>(rbase + min(ln, nq - 1u) * (uint32_t)rstep * 4u);
-            uint32_t sink = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) sink |= v[i];
-            asm volatile("" ::"v"(sink));
-        }
         __syncthreads();
         uint32_t acc[IW][JR];
 #pragma unroll
@@ -891,7 +794,7 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         __syncthreads();
     }
     // the pair list's entries, spread over all workgroups of the launch (those without a tile start here at once)
-    sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)gridDim.x * (64 * KS));
+    if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)pa.nwg * (64 * KS));
 }
 
 // ---- host side
@@ -901,7 +804,7 @@ struct SpTuning {
     int link = 1;                       // D2G_SP_LINK: 0 = no families (every sketch its own segment: the pair list alone; tests)
     int attach = 1;                     // D2G_SP_ATTACH: 0 = no second chance for sketches no column pair linked
     double tile_frac = 0.35;            // D2G_SP_TILE_FRAC: the segments may cover this fraction of all tiles before the dense walk is cheaper
-    int prefetch = 1;                   // D2G_SP_PREFETCH: 0 = the sparse pair kernel does not touch its operands ahead of the plane walk
+    size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
     size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
     size_t list_div = 16;               // D2G_SP_LIST_DIV: the pair list holds at most pairs / list_div entries (and at most 2^27): an entry costs ~130 ps (emit + two patch passes), a pair of the dense walk ~9
 };
@@ -912,7 +815,7 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_SP_LINK")) v.link = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_ATTACH")) v.attach = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_TILE_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.tile_frac = f; }
-    if (const char *e = ctx->tune.get("D2G_SP_PREFETCH")) v.prefetch = std::atoi(e) != 0;
+    if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_LIST_DIV")) { const long d = std::atol(e); if (d >= 1 && d <= (1 << 20)) v.list_div = (size_t)d; }
     return v;
@@ -941,6 +844,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMalloc((void **)&set->d_sinv, Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_label, 2 * Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_hint, 2 * Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_segend, Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_spz, set->spz_words * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
@@ -964,7 +868,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 }
 
 void sp_free(d2g_cmp_set *set) {
-    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_hint, &set->d_spz, &set->d_rowpos, &set->d_rowk,
+    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_hint, &set->d_segend, &set->d_spz, &set->d_rowpos, &set->d_rowk,
                          &set->d_rowstream, &set->d_tiles, &set->d_tiles_full, &set->d_spctl}) { (void)hipFree(*p); *p = nullptr; }
     (void)hipFree(set->d_plist); set->d_plist = nullptr;
     set->d_tilebm = set->d_lcnt = set->d_linked = set->d_gbm = set->d_order = set->d_plctl = set->d_fullctl = nullptr;
@@ -988,28 +892,27 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
     const SpTuning tu = sp_tuning(ctx);
     if (tu.link && S >= 2) {
         const uint32_t cap = (uint32_t)std::min<size_t>(N / 2 + 1, 12288);              // shared values of a column that take part: 3 words each, 144 KB of LDS at most
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8));
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12));
-        hipLaunchKernelGGL(sp_link_kernel<0>, dim3((unsigned)(S / 2)), dim3(1024), (size_t)cap * 8, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap,
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12));
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8));
+        const unsigned npair = (unsigned)(S / 2);
+        const uint32_t ustride = (uint32_t)std::max<size_t>(1, std::min<size_t>(tu.unite_stride, npair / 32));   // at least 32 column pairs take part in the uniting pass
+        hipLaunchKernelGGL(sp_link_kernel<0>, dim3(npair), dim3(1024), (size_t)cap * 12, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap, 1u,
                            la, set->d_hint, set->d_linked);
         hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
-        hipLaunchKernelGGL(sp_link_kernel<1>, dim3((unsigned)(S / 2)), dim3(1024), (size_t)cap * 12, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap,
+        hipLaunchKernelGGL(sp_link_kernel<1>, dim3(div_up<unsigned>(npair, ustride)), dim3(1024), (size_t)cap * 8, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap, ustride,
                            la, set->d_hint, set->d_linked);
         if (tu.attach) hipLaunchKernelGGL(sp_attach_kernel, dim3(nb), dim3(256), 0, s, la, set->d_hint, set->d_linked, N, Npad);
     }
     const size_t ntile_all = (Npad / 32) * (Npad / BS_CB);
     const uint32_t seg_limit = (uint32_t)std::min<size_t>((size_t)((double)ntile_all * tu.tile_frac), 0x3FFFFFFF);
-    if (N <= (size_t)SP_SORT_SMALL_U * 1024) {
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_sort_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_SORT_SMALL_U * 1024 * 4));
-        hipLaunchKernelGGL(sp_sort_small_kernel, dim3(1), dim3(1024), div_up<size_t>(N, 16) * 16 * 4, s, la, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order, seg_limit);
-    } else {
-        hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order);
-        hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, seg_limit);    // la (labels) is dead after the count kernel: it keeps the segment starts
-        hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order);
-    }
+    // (one single-workgroup kernel for count + scan + place with the counters in LDS was measured at N = 10 000: 25 us against 19 for the three)
+    hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order);
     const uint32_t CW = (uint32_t)((Npad / BS_CB + 31) / 32);
-    hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)S), dim3(SP_EMIT_T), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, lb, set->d_order, set->d_sperm, la, set->d_lcnt, CW,
-                       set->d_gbm + 8, set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu));
+    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, set->d_segend, seg_limit);    // la (labels) is dead after the count kernel: it keeps the segment starts
+    hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order,
+                       la, set->d_segend, CW, set->d_gbm + 8);
+    hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)S), dim3(SP_EMIT_T), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, lb, set->d_order,
+                       set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu));
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
@@ -1064,6 +967,19 @@ __global__ __launch_bounds__(256) void sp_unpack_kernel(const uint32_t *__restri
     for (int x = 0; x < 32; ++x) ids[(tb * 32 + x) * Npad + j] = id[x];
 }
 
+// the fill of rows [r0, r1) of the triangle, enqueued NOW (unconditionally: should the launch turn out dense, the pair kernel overwrites it);
+// the next sparse launch on the set that writes to the same output skips its own fill
+template <class Store>
+int sp_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, Store store, uint32_t *out_words, hipStream_t s) {
+    const size_t cnt = d2g_ut_count(set->N, r0, r1);
+    if (!cnt || !set->sparse_ok) return D2G_OK;
+    hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, SP_FILL_THREADS * SP_FILL_PER_THREAD), (size_t)0x7FFFFFFF)), dim3(SP_FILL_THREADS), 0, s,
+                       out_words, cnt, store, (uint32_t)set->S, (const uint32_t *)nullptr, 0u);
+    D2G_HIP(ctx, hipGetLastError());
+    set->prefilled = out_words;
+    return D2G_OK;
+}
+
 // One sparse launch on a set whose last prepare left a sorted operand.  The launch uses per-set scratch (work list, launch rows, control
 // words): launches on ONE set must be issued one after the other on ONE stream (include/d2g.h says so).
 template <class Store>
@@ -1103,17 +1019,20 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
         hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, bm, nrb, ncb, CW, full ? 1 : 0,
                            tiles, (uint32_t)set->tiles_cap, ctl, cand32, set->d_order, ctl_next);
     SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
-             set->d_sperm, set->d_rowpos, tiles, ctl, ncb, cand32, (uint32_t)set->tiles_cap, sp_tuning(ctx).prefetch};
+             set->d_sperm, set->d_rowpos, tiles, ctl, ncb, cand32, (uint32_t)set->tiles_cap};
     // contiguous 32 KB per workgroup, workgroups in dispatch order: a streaming write (6.1 TB/s at N = 50 000: 825 us; the grid-stride loop over 16
     // workgroups per CU it replaces, whose iterations lie 16 MB apart, reached 4.6: 1105 us).  One store per thread is faster still (722-760 us) but when
     // the launch turns out dense all of its 19 M waves start only to return: 254 us instead of 34
-    hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, SP_FILL_THREADS * SP_FILL_PER_THREAD), (size_t)0x7FFFFFFF)), dim3(SP_FILL_THREADS), 0, s,
-                       out_words, cnt, store, (uint32_t)set->S, ctl, cand32);
+    // (the multi-GPU engine fills a rank's slab at the START of its step, under the exchanges: d2g_bitslice_prefill)
+    if (set->prefilled != out_words)
+        hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, SP_FILL_THREADS * SP_FILL_PER_THREAD), (size_t)0x7FFFFFFF)), dim3(SP_FILL_THREADS), 0, s,
+                           out_words, cnt, store, (uint32_t)set->S, ctl, cand32);
+    set->prefilled = nullptr;
     // a multiple of 8 (every XCD's list gets the same number of workgroups), four times what is resident at once: the lists differ in
     // length, and a workgroup that finds nothing at its index leaves at once -- the dispatcher evens the lists out sub-tile by sub-tile
     // (exactly one resident wave of workgroups took as long as the longest list: 52 -> 85 us at config 3)
     const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * 4, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * sp_tuning(ctx).grid_mult) / 8 * 8);
-    SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0};
+    SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0, std::min<uint32_t>(grid, (uint32_t)ctx->num_cus * 8u)};
     hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
     // behind the gate: every tile of the caller's-order operand in dense mode; otherwise the second step of the pair list (table epilogue)
     if (dsh.nvalid_total)

@@ -235,6 +235,8 @@ struct d2g_allpairs {
     bool p_valid[2] = {false, false}, plain_valid = false;
     unsigned long long nsteps = 0;
     int last = 0;                        // buffer of the most recent prepare
+    // output of the step being enqueued (d2g_allpairs_step_*): its fill goes out right behind the pack, under the exchanges
+    void *pre_out = nullptr; const float *pre_lut = nullptr;
     // per-phase timing of ONE step (d2g_allpairs_set_phase_timing): timing-enabled event pairs around every phase, on the
     // stream the phase is enqueued on; nothing synchronises until d2g_allpairs_phase_times
     struct PhaseEv { hipEvent_t a, b; int kind, chunk; };
@@ -371,6 +373,13 @@ int prepare_many(d2g_allpairs **es, int n, const uint64_t *const *rows, const in
         MG_TRY(pt_end(e, D2G_PHASE_PACK, 0, cs[i]));
         D2G_HIP(e->ctx, hipEventRecord(e->ev_pack, cs[i]));
         D2G_HIP(e->ctx, hipStreamWaitEvent(e->xs, e->ev_pack, 0));
+        // the slab's fill (HBM-bound, depends on nothing) while the row -> column exchange is on the links
+        if (e->pre_out && e->full[bufs[i]] && e->full[bufs[i]]->sparse_ok) {
+            MG_TRY(pt_begin(e, D2G_PHASE_FILL, 0, cs[i]));
+            MG_TRY(d2g_bitslice_prefill(e->ctx, e->full[bufs[i]], e->r0, e->r1, e->pre_lut ? nullptr : (uint32_t *)e->pre_out, e->pre_lut, e->pre_lut ? (float *)e->pre_out : nullptr, cs[i]));
+            MG_TRY(pt_end(e, D2G_PHASE_FILL, 0, cs[i]));
+        }
+        e->pre_out = nullptr; e->pre_lut = nullptr;
     }
     for (int c = 0; c < C; ++c) {                                       // all row->column exchanges, back to back on xs
         for (int i = 0; i < n; ++i) MG_TRY(pt_begin(es[i], D2G_PHASE_X1, c, es[i]->xs));
@@ -428,7 +437,8 @@ int verify_shape_across_ranks(d2g_allpairs *e) {
     const int W = e->W;
     uint64_t *d_v = nullptr;
     std::vector<uint64_t> all((size_t)W * 4, 0);
-    const uint64_t mine[4] = {(uint64_t)e->N, (uint64_t)e->S, (uint64_t)e->W, (uint64_t)e->C};
+    // [3]: chunks in the low word, a hash of the K2 switches (D2G_BS_* / D2G_SP_*: which kernels a rank runs) in the high one
+    const uint64_t mine[4] = {(uint64_t)e->N, (uint64_t)e->S, (uint64_t)e->W, (uint64_t)e->C | (d2g_tuning_hash(e->ctx->tune, "D2G_BS_", "D2G_SP_") << 32)};
     D2G_HIP(ctx, hipMalloc((void **)&d_v, (size_t)W * 32));
     int rc = D2G_OK;
     auto fail = [&](int r) { (void)hipFree(d_v); return r; };
@@ -447,10 +457,11 @@ int verify_shape_across_ranks(d2g_allpairs *e) {
     for (int q = 0; q < W; ++q)
         if (std::memcmp(&all[(size_t)q * 4], mine, 32) != 0) {
             char buf[256];
-            std::snprintf(buf, sizeof buf, "allpairs: rank %d has (N=%llu, S=%llu, world=%llu, chunks=%llu), rank %d has (N=%llu, S=%llu, world=%llu, chunks=%llu)"
-                          " -- the same shape and D2G_MGPU_CHUNKS are required on every rank", e->rank, (unsigned long long)mine[0], (unsigned long long)mine[1],
-                          (unsigned long long)mine[2], (unsigned long long)mine[3], q, (unsigned long long)all[(size_t)q * 4], (unsigned long long)all[(size_t)q * 4 + 1],
-                          (unsigned long long)all[(size_t)q * 4 + 2], (unsigned long long)all[(size_t)q * 4 + 3]);
+            std::snprintf(buf, sizeof buf, "allpairs: rank %d has (N=%llu, S=%llu, world=%llu, chunks=%llu, switches=%08llx), rank %d has (N=%llu, S=%llu, world=%llu, chunks=%llu, switches=%08llx)"
+                          " -- the same shape, D2G_MGPU_CHUNKS and D2G_BS_* / D2G_SP_* switches are required on every rank", e->rank, (unsigned long long)mine[0], (unsigned long long)mine[1],
+                          (unsigned long long)mine[2], (unsigned long long)(mine[3] & 0xFFFFFFFFull), (unsigned long long)(mine[3] >> 32), q, (unsigned long long)all[(size_t)q * 4],
+                          (unsigned long long)all[(size_t)q * 4 + 1], (unsigned long long)all[(size_t)q * 4 + 2], (unsigned long long)(all[(size_t)q * 4 + 3] & 0xFFFFFFFFull),
+                          (unsigned long long)(all[(size_t)q * 4 + 3] >> 32));
             ctx->last_error = buf;
             return D2G_ERR_INVALID;
         }
@@ -462,6 +473,8 @@ int check_group(d2g_allpairs **es, int n) {
     for (int i = 0; i < n; ++i) {
         if (!es[i]) return D2G_ERR_INVALID;
         D2G_CHECK(es[i]->ctx, es[i]->N == es[0]->N && es[i]->S == es[0]->S && es[i]->W == es[0]->W && es[i]->C == es[0]->C, "allpairs: engines of different shapes");
+        D2G_CHECK(es[i]->ctx, d2g_tuning_hash(es[i]->ctx->tune, "D2G_BS_", "D2G_SP_") == d2g_tuning_hash(es[0]->ctx->tune, "D2G_BS_", "D2G_SP_"),
+                  "allpairs: the ranks' contexts resolved different D2G_BS_* / D2G_SP_* switches (d2g_ctx_tuning): every rank must run the same kernels");
     }
     return D2G_OK;
 }
@@ -659,8 +672,10 @@ int d2g_allpairs_create(d2g_ctx *ctx, d2g_comm *comm, size_t N, size_t S, d2g_al
             d2g_allpairs_destroy(e);
             return D2G_ERR_HIP;
         }
-    if (int rc = eng_alloc_buffer(e, 0)) { d2g_allpairs_destroy(e); return rc; }
+    // the exchange of (N, S, world, chunks, switches) comes BEFORE the large allocations: a rank that then runs out of memory returns
+    // without leaving its peers blocked in this (collective) call
     if (int rc = verify_shape_across_ranks(e)) { d2g_allpairs_destroy(e); return rc; }
+    if (int rc = eng_alloc_buffer(e, 0)) { d2g_allpairs_destroy(e); return rc; }
     *out = e;
     return D2G_OK;
 }
@@ -779,6 +794,8 @@ int d2g_allpairs_prepare_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, void 
 // one whole step per engine: exchange + sharded prepare + this rank's slab of pairs (rows_computed)
 int d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, const float *const *lut_dev,
                           void *const *out_dev, void *const *streams) {
+    if (int rc = check_group(engs, n)) return rc;
+    for (int i = 0; i < n; ++i) { engs[i]->pre_out = out_dev ? out_dev[i] : nullptr; engs[i]->pre_lut = (lut_dev && lut_dev[i]) ? lut_dev[i] : nullptr; }
     if (int rc = d2g_allpairs_prepare_all(engs, n, rows_dev, streams)) return rc;
     for (int i = 0; i < n; ++i) {
         d2g_allpairs *e = engs[i];

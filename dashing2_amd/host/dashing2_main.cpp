@@ -832,6 +832,16 @@ void rect_epilogue(const Options &o, const CmpShape &sh, size_t r0, size_t r1, c
         }
 }
 
+// the D2G_* switches the context resolved when it was created (include/d2g.h: d2g_ctx_tuning)
+std::string tuning_json(d2g_ctx *ctx) {
+    const int n = d2g_ctx_tuning(ctx, nullptr, 0);
+    if (n < 0) return "null";
+    std::string buf((size_t)n + 1, '\0');
+    d2g_ctx_tuning(ctx, &buf[0], buf.size());
+    buf.resize((size_t)n);
+    return buf;
+}
+
 // what the sparse-tile path did on the last upper-triangle launch of the set (include/d2g.h: d2g_cmp_set_sparse_info)
 std::string sparse_json(d2g_ctx *ctx, const d2g_cmp_set *set) {
     uint32_t i4[4] = {0, 0, 0, 0};
@@ -1130,7 +1140,7 @@ int sketch_main(int argc, char **argv) {                          // src/sketch_
     if (o.verbosity) std::fprintf(stderr, "[d2g] GPU context %.3fs + warm-up %.3fs on a helper thread, under the host ingest\n", lctx.t_create, lctx.t_warm);
     res.nq = o.nq;
     if (!o.cmpout.empty()) cmp_core(o, res, lctx.get());           // sketch_main.cpp:144-148
-    g_stats.raw("context", std::string("{\"create_s\": ") + Stats::numstr(lctx.t_create) + ", \"warmup_s\": " + Stats::numstr(lctx.t_warm) + "}");
+    g_stats.raw("context", std::string("{\"create_s\": ") + Stats::numstr(lctx.t_create) + ", \"warmup_s\": " + Stats::numstr(lctx.t_warm) + ", \"switches\": " + tuning_json(lctx.get()) + "}");
     return 0;
 }
 
@@ -1178,7 +1188,7 @@ int cmp_main(int argc, char **argv) {                             // src/cmp_mai
     if (o.verbosity) std::fprintf(stderr, "[d2g] inputs loaded in %.3fs; GPU context %.3fs + warm-up (first copy, code objects) %.3fs on a helper thread (%.3fs of it after the inputs were loaded)\n",
                                   t_wait - t_begin, lctx.t_create, lctx.t_warm, now() - t_wait);
     g_stats.raw("context", std::string("{\"create_s\": ") + Stats::numstr(lctx.t_create) + ", \"warmup_s\": " + Stats::numstr(lctx.t_warm) + ", \"inputs_loaded_s\": " + Stats::numstr(t_wait - t_begin) +
-                ", \"waited_for_context_s\": " + Stats::numstr(now() - t_wait) + "}");
+                ", \"waited_for_context_s\": " + Stats::numstr(now() - t_wait) + ", \"switches\": " + tuning_json(ctx) + "}");
     const double t_cmp = now();
     cmp_core(o, res, ctx);
     if (o.verbosity) std::fprintf(stderr, "[d2g] cmp_core %.3fs in all (densify, upload, batches, closing the output)\n", now() - t_cmp);

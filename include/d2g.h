@@ -456,6 +456,7 @@ int  d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *ro
 #define D2G_PHASE_DERIVE  4   /* plane stream of a gathered chunk */
 #define D2G_PHASE_PAIR    5   /* the pair kernel over this rank's rows (d2g_allpairs_step_* only) */
 #define D2G_PHASE_ORDER   6   /* sparse tiles on the gathered operand (N >= 8192): ids from the planes, sketch order, sorted stream */
+#define D2G_PHASE_FILL    7   /* the slab pre-filled with the value of "0 equal" at the start of the step, under the exchanges (sparse path) */
 int  d2g_allpairs_set_phase_timing(d2g_allpairs *eng, int on);
 int  d2g_allpairs_phase_times(d2g_allpairs *eng, int cap, int *n_out, int *kind /* [cap] */, int *chunk /* [cap] */,
                               float *start_ms /* [cap] */, float *dur_ms /* [cap] */);

@@ -716,6 +716,7 @@ def test_cli_gpu_stats_json(genomes, tmp_path):
     _run(["sketch", "-k", str(k), "-S", str(S), "-o", str(o), "--cmpout", str(c), "--binary-output", "--gpu-stats", str(st)] + genomes)
     j = json.loads(st.read_text())
     assert j["command"] == "sketch" and j["in_process_s"] > 0 and j["context"]["create_s"] > 0
+    assert isinstance(j["context"]["switches"], dict)                 # the D2G_* switches the context resolved (d2g_ctx_tuning)
     sk = j["sketch"]
     assert sk["inputs"] == len(genomes) and sk["k"] == k and sk["sketchsize"] == S and sk["bases"] > 500000
     assert sk["devices"][0]["k1"]["launches"] >= 1 and sk["devices"][0]["k1"]["total_ms"] > 0 and "gfx950" in sk["devices"][0]["name"]

@@ -223,6 +223,8 @@ def test_allpairs_status_reaches_every_rank(d2g, oracle, monkeypatch):
         with pytest.raises(d2g.D2GError):
             e.operand().status()
     monkeypatch.delenv("D2G_BS_TAGBITS")
+    for c in ctxs:
+        c.reload_tuning()                                             # a context reads its switches when it is created; these were created under the hook
     # the same engines recover on the next (clean) step: the status words are rewritten by every prepare
     held = [e.rows_held for e in engs]
     rows = [_upload(ctxs[r], sigs.view(np.uint64)[held[r][0]:held[r][1]]) for r in range(W)]
@@ -375,6 +377,38 @@ def test_allpairs_sparse_tiles_on_the_gathered_operand(d2g, oracle, monkeypatch,
     assert "order" in {p["phase"] for p in engs[0].phase_times()}
     for r in range(W):
         for p in (rows[r], outs[r], luts[r]):
+            ctxs[r].free(p)
+    for x in engs + comms + ctxs:
+        x.close()
+
+
+def test_allpairs_refuses_ranks_with_different_switches(d2g, monkeypatch):
+    """a context reads the library's D2G_* switches once, when it is created; the engines of one job must have resolved
+    the same D2G_BS_* / D2G_SP_* set (they select the kernels a rank runs).  Two loopback ranks whose contexts were created under
+    different environments: the step is refused with a message that names the switches; d2g_ctx_tuning shows what each resolved;
+    after a reload under one environment the same engines run."""
+    N, S, W = 300, 64, 2
+    rng = np.random.default_rng(3)
+    bits = np.ascontiguousarray(_planted(rng, N, S)).view(np.uint64)
+    ctx0 = d2g.Context(0)
+    monkeypatch.setenv("D2G_SP_LINK", "0")
+    ctx1 = d2g.Context(0)                                             # created under another switch
+    monkeypatch.delenv("D2G_SP_LINK")
+    assert ctx0.tuning().get("D2G_SP_LINK") is None and ctx1.tuning().get("D2G_SP_LINK") == "0"
+    ctxs = [ctx0, ctx1]
+    comms = d2g.Comm.create_all(ctxs)
+    engs = [d2g.AllPairs(ctxs[r], comms[r], N, S) for r in range(W)]
+    rows = [_upload(ctxs[r], bits[engs[r].rows_held[0]:engs[r].rows_held[1]]) for r in range(W)]
+    outs = [ctxs[r].malloc(max(d2g.ut_count(N, *engs[r].rows_computed), 1) * 4) for r in range(W)]
+    with pytest.raises(d2g.D2GError, match="D2G_BS_"):
+        d2g.allpairs_step_all(engs, rows, None, outs)
+    ctx1.reload_tuning()
+    assert ctx1.tuning().get("D2G_SP_LINK") is None
+    d2g.allpairs_step_all(engs, rows, None, outs)
+    for r in range(W):
+        ctxs[r].sync()
+        engs[r].status()
+        for p in (rows[r], outs[r]):
             ctxs[r].free(p)
     for x in engs + comms + ctxs:
         x.close()

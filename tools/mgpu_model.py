@@ -5,8 +5,10 @@ W contexts on device 0 run exactly the pack / exchange lists / sharded chunked p
 kernels that W GPUs run; on one device they run one after the other, so every kernel's duration (rocprofv3
 --kernel-trace) is what it takes on a GPU of its own.  The report replays ONE rank's step as the engine schedules
 it -- two in-order queues, the compute stream and the exchange stream, tied by the engine's events:
-    compute:  pack | prep(chunk 0) .. prep(chunk C-1) | derive(0) .. derive(C-1) | order | pair
-              (order = the sparse-tile path's ordering of the gathered operand, N >= 8192; pair = its tile marking + listed tiles)
+    compute:  pack | fill | prep(chunk 0) .. prep(chunk C-1) | derive(0) .. derive(C-1) | order | pair
+              (fill = the rank's slab pre-filled with the value of "0 equal", since round 5 at the START of the step, under the first exchange;
+               order = the sparse path on the gathered operand, N >= 8192: ids from the planes, families, sort, pair list, sorted stream;
+               pair = launch rows, listed tiles, pair list applied)
     exchange: x1(0) .. x1(C-1) | x2(0) .. x2(C-1)            x1(c) before prep(c) before x2(c) before derive(c)
 with the kernels at their measured durations and every exchange at (bytes a rank moves over its busiest link) /
 (ASSUMED link rate).  A prediction to hold against the driver's SCALE run, not a measurement of it.
@@ -88,6 +90,7 @@ def replay(W, C, t, x1_ms, x2_ms):
     prep = t["prep_chunk"]
     comp = t["pack"] + gap
     ex = comp                                   # x1(0) waits for pack
+    comp += t["fill"] + gap                     # the slab's fill right behind the pack, while x1 is on the links
     x1_done, prep_done, x2_done = [], [], []
     for c in range(C):
         ex += (x1_ms + gap) if W > 1 else gap
@@ -129,31 +132,37 @@ def report(d, N, S):
             return sum(v) / steps / 1e3 if v else 0.0           # ms per rank-step
 
         prep_kernels = ("k2_transpose_kernel", "bs_rank_kernel", "bs_colplan_kernel", "bs_planes_kernel")
-        order_kernels = ("sp_unpack_kernel", "sp_init_kernel", "sp_prop_kernel", "sp_prop_reg_kernel", "sp_flatten_kernel", "sp_union_kernel", "sp_jump_kernel", "sp_count_kernel", "sp_scan_kernel",
-                         "sp_place_kernel", "sp_permute_kernel")
-        pair_kernels = ("sp_mark_kernel", "sp_or_kernel", "sp_rows_kernel", "sp_gather_kernel", "sp_rowbm_kernel", "sp_list_kernel", "sp_fill_kernel",
-                        "k2_bitslice_sparse_kernel", "k2_bitslice_kernel")
+        order_kernels = ("sp_unpack_kernel", "sp_link_kernel", "sp_flatten_kernel", "sp_attach_kernel", "sp_count_kernel", "sp_scan_kernel",
+                         "sp_place_kernel", "sp_emit_kernel", "sp_permute_kernel")
+        pair_kernels = ("sp_rows_kernel", "sp_gather_kernel", "sp_rowbm_kernel", "sp_list_kernel", "k2_bitslice_sparse_kernel", "k2_bitslice_kernel")
 
         def launches(names):
             return sum(len(kt.get(k, [])) for k in names) / steps
 
         t = {"pack": per_step("mg_pack_kernel"), "prep_chunk": sum(per_step(k) for k in prep_kernels) / C,
              "derive_chunk": per_step("bs_derive_kernel") / C, "pair": sum(per_step(k) for k in pair_kernels), "pair_launches": max(1.0, launches(pair_kernels)),
-             "order": sum(per_step(k) for k in order_kernels), "order_launches": launches(order_kernels)}
+             "order": sum(per_step(k) for k in order_kernels), "order_launches": launches(order_kernels), "fill": per_step("sp_fill_kernel")}
         a2a = (N / W) * S * 8 * (W - 1) / W                     # bytes a rank sends (= receives) in the row->column exchange
         gat = (ng - ng / W) * gw * 4                            # bytes a rank receives in the gather
         links = max(W - 1, 1)
         x1 = a2a / links / C / (LINK_GBS * 1e9) * 1e3 if W > 1 else 0.0
         x2 = gat / links / C / (LINK_GBS * 1e9) * 1e3 if W > 1 else 0.0
         step = replay(W, C, t, x1, x2)
-        serial = t["pack"] + C * (t["prep_chunk"] + t["derive_chunk"]) + t["order"] + t["pair"] + C * (x1 + x2)
+        serial = t["pack"] + t["fill"] + C * (t["prep_chunk"] + t["derive_chunk"]) + t["order"] + t["pair"] + C * (x1 + x2)
         if base is None:
             base = step
-        print(f"W={W} (C={C} chunks): per rank  pack {t['pack']:.3f}  prepare {C}x{t['prep_chunk']:.3f}  derive {C}x{t['derive_chunk']:.3f}  order {t['order']:.3f} ({t['order_launches']:.0f} launches)  pair {t['pair']:.3f} ({t['pair_launches']:.0f} launches) ms;  "
+        print(f"W={W} (C={C} chunks): per rank  pack {t['pack']:.3f}  fill {t['fill']:.3f} (under x1)  prepare {C}x{t['prep_chunk']:.3f}  derive {C}x{t['derive_chunk']:.3f}  order {t['order']:.3f} ({t['order_launches']:.0f} launches)  pair {t['pair']:.3f} ({t['pair_launches']:.0f} launches) ms;  "
               f"moves {a2a / 1e6:6.1f} MB out+in (rows->columns) + {gat / 1e6:6.1f} MB in (gather) over {links} link(s): {C}x{x1:.3f} + {C}x{x2:.3f} ms;  "
               f"ONE-JOB step {step:.3f} ms = {pairs / (step * 1e-3):.3e} pairs/s ({base / step:.2f}x of W=1)  [no overlap inside the step: {serial:.3f} ms, {base / serial:.2f}x];  "
               f"loopback wall {wall:.2f} ms for all {W} ranks on one device")
-        print("      kernels (us per rank-step): " + "  ".join(f"{k.replace('_kernel', '')} {per_step(k) * 1e3:.0f}" for k in order_kernels + pair_kernels if kt.get(k)))
+        print("      kernels (us per rank-step): " + "  ".join(f"{k.replace('_kernel', '')} {per_step(k) * 1e3:.0f}" for k in order_kernels + pair_kernels + ("sp_fill_kernel",) if kt.get(k)))
+        if W == 8:
+            # what no schedule can go below on this design at this size: the two exchanges at the assumed link rate (the second needs the first
+            # chunk's prepare), the replicated part of the order phase (every rank needs the whole sorted operand: unpack + sort + pair list +
+            # permute), the pair phase; the slab's output write (fill) hides under the first exchange
+            floor = t["pack"] + x1 + t["prep_chunk"] + C * x2 + t["derive_chunk"] + t["order"] + t["pair"]
+            print(f"      floor of this design at W=8: pack {t['pack']:.3f} + first x1 {x1:.3f} + one chunk's prepare {t['prep_chunk']:.3f} + x2 {C}x{x2:.3f} + last derive {t['derive_chunk']:.3f} + order {t['order']:.3f} "
+                  f"+ pair {t['pair']:.3f} = {floor:.3f} ms ({base / floor:.2f}x of W=1): the order phase is REPLICATED (every rank needs the whole operand in family order) and does not shrink with W")
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools/mgpu_model.sh [N S]   (GPU box)  -> gpurun_out/r04_mgpu_model.txt
+# usage: tools/mgpu_model.sh [N S]   (GPU box)  -> gpurun_out/r05_mgpu_model.txt
 # one rocprofv3 --kernel-trace run per world size of tools/mgpu_model.py --worker (loopback transport on one GPU), then the report
 repo=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $repo/gpurun_out
@@ -9,4 +9,4 @@ for W in 1 2 4 8; do
   timeout 600 rocprofv3 --kernel-trace -f csv -d /tmp/mgpu_model/W$W -- python $repo/tools/mgpu_model.py --worker $W "$@" > /tmp/mgpu_model/W$W/worker.log 2>&1
   grep WORKER /tmp/mgpu_model/W$W/worker.log || tail -5 /tmp/mgpu_model/W$W/worker.log
 done
-python $repo/tools/mgpu_model.py --report /tmp/mgpu_model "$@" | tee $repo/gpurun_out/r04_mgpu_model.txt
+python $repo/tools/mgpu_model.py --report /tmp/mgpu_model "$@" | tee $repo/gpurun_out/r05_mgpu_model.txt
