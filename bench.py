@@ -373,14 +373,16 @@ ENGINE_NAME = {"cabi": "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv group
                "inproc": "libd2g (d2g_comm_create_all + d2g_allpairs_step_all), ONE process driving every GPU",
                "torch": "torch.distributed (dashing2_amd.dist.RowShardedAllPairs), one process per GPU",
                "broadcast": "whole-matrix torch.distributed broadcast per step + single-GPU prepare on every rank"}
-# profiles/r04_mgpu_model.txt (tools/mgpu_model.sh): ONE rank's step of BASELINE config 4 replayed from loopback kernel durations +
+# profiles/r05_mgpu_model.txt (tools/mgpu_model.sh): ONE rank's step of BASELINE config 4 replayed from loopback kernel durations +
 # every exchange at (bytes over the busiest link) / 50 GB/s + 6 us per enqueued operation.  ms per phase INSTANCE (a chunked phase
-# runs `chunks` times; order = the sparse-tile path's ordering of the gathered operand, pair = tile list + fill + listed tiles);
-# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.206 ms; the plain single-GPU path: 2.8 ms).
-MODEL_R04 = {
-    2: {"chunks": 4, "pack": 0.091, "x1": 0.512, "prepare": 0.185, "x2": 0.257, "derive": 0.014, "order": 0.357, "pair": 0.801, "step_ms": 4.502, "speedup": 0.71},
-    4: {"chunks": 4, "pack": 0.051, "x1": 0.128, "prepare": 0.102, "x2": 0.129, "derive": 0.016, "order": 0.367, "pair": 0.461, "step_ms": 2.084, "speedup": 1.54},
-    8: {"chunks": 2, "pack": 0.027, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.023, "order": 0.368, "pair": 0.293, "step_ms": 1.288, "speedup": 2.49},
+# runs `chunks` times; fill = the slab pre-filled at the start of the step, under the first exchange; order = the sparse path on the gathered
+# operand -- ids from the planes, families, sort, pair list, sorted stream: REPLICATED on every rank --; pair = launch rows + listed tiles + pair list);
+# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.33 ms; the plain single-GPU path: 2.9 ms);
+# floor_ms (W = 8) = what no schedule of this design goes below (first exchange + one chunk's prepare + the plane exchange + order + pair).
+MODEL_R05 = {
+    2: {"chunks": 4, "pack": 0.096, "fill": 0.436, "x1": 0.512, "prepare": 0.190, "x2": 0.257, "derive": 0.015, "order": 0.491, "pair": 0.346, "step_ms": 4.181, "speedup": 0.80},
+    4: {"chunks": 4, "pack": 0.055, "fill": 0.206, "x1": 0.128, "prepare": 0.102, "x2": 0.129, "derive": 0.016, "order": 0.490, "pair": 0.229, "step_ms": 1.974, "speedup": 1.69},
+    8: {"chunks": 2, "pack": 0.030, "fill": 0.098, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.024, "order": 0.464, "pair": 0.166, "step_ms": 1.289, "speedup": 2.58, "floor_ms": 1.105},
 }
 
 
@@ -879,9 +881,9 @@ def run_multi(args):
             base["speedup"] = value / base["base_1gpu_same_config_pairs_per_s"]
             base["speedup_vs_best_1gpu"] = value / base["best_1gpu_pairs_per_s"]
         model = None
-        if (N, S) == (50000, 1024) and W in MODEL_R04 and eng_of:
-            m = MODEL_R04[W]
-            model = dict(m, source="profiles/r04_mgpu_model.txt (loopback kernel durations + exchanges at 50 GB/s per link + 6 us per enqueue)",
+        if (N, S) == (50000, 1024) and W in MODEL_R05 and eng_of:
+            m = MODEL_R05[W]
+            model = dict(m, source="profiles/r05_mgpu_model.txt (loopback kernel durations + exchanges at 50 GB/s per link + 6 us per enqueue)",
                          note="ms per phase instance; compare with phases.max_over_ranks_ms term by term")
         line = {
             "metric": "all-pairs sketch comparison throughput (pairs/s)", "value": value, "unit": "pairs/s",

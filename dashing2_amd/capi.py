@@ -116,6 +116,7 @@ SIGNATURES = {
     "d2g_cmp_set_planes": (_int, [_vp, _vp, _vp, C.POINTER(C.c_uint), C.POINTER(_int), C.POINTER(_f32)]),
     "d2g_cmp_set_status": (_int, [_vp, _vp, _vp]),
     "d2g_cmp_set_sparse_info": (_int, [_vp, _vp, _vp, _vp]),
+    "d2g_cmp_set_debug_pairs": (_int, [_vp, _vp, _vp, _vp, _sz, C.POINTER(_sz), _vp]),
     "d2g_warmup": (_int, [_vp, _int]),
     "d2g_device_name": (_int, [_int, C.c_char_p, _sz]),
     "d2g_comm_unique_id": (_int, [_vp]),
@@ -162,7 +163,7 @@ SIGNATURES = {
 def sparse_info_dict(a):
     """info4 of d2g_cmp_set_sparse_info / d2g_allpairs_sparse_info as a dict"""
     return {"sorted_operand": bool(a[0]), "tiles_listed": int(a[1]), "dense_decided_by_prepare": bool(a[2] & 1), "dense_kernel_ran": bool(a[2] & 2),
-            "tiles_and_pair_list": bool(a[2] & 4), "callers_order_kept": bool(a[2] & 8), "pairs_listed": int(a[3])}
+            "tiles_and_pair_list": bool(a[2] & 4), "callers_order_kept": bool(a[2] & 8), "ordering_skipped": bool(a[2] & 16), "pairs_listed": int(a[3])}
 
 
 def lib():
@@ -742,6 +743,15 @@ class CmpSet:
         a = np.zeros(4, np.uint32)
         self.ctx._check(lib().d2g_cmp_set_sparse_info(self.ctx._h, self._h, stream, a.ctypes.data))
         return sparse_info_dict(a)
+
+    def debug_pairs(self, cap=1 << 24, stream=None):
+        """-> (pairs [n][2] uint32: the pair list of the last prepare (i < j), roots [N] uint32: the family root of every sketch)"""
+        buf = np.empty(cap, np.uint64)
+        roots = np.empty(self.N, np.uint32)
+        n = _sz()
+        self.ctx._check(lib().d2g_cmp_set_debug_pairs(self.ctx._h, self._h, stream, buf.ctypes.data, cap, C.byref(n), roots.ctypes.data))
+        e = buf[:n.value]
+        return np.stack([(e & np.uint64(0x7FFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)], axis=1), roots
 
     def planes(self, stream=None):
         """-> (max shared values per column + 1, max id planes of a group, mean id planes); zeros for DIRECT"""

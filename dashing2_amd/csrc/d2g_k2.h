@@ -50,12 +50,13 @@ struct d2g_cmp_set {
     uint32_t *d_sperm = nullptr;      // [Nstride] sketch at sorted position p (0xFFFFFFFF = padding)
     uint32_t *d_sinv = nullptr;       // [Npad]    sorted position of sketch j
     uint32_t *d_label = nullptr;      // [2][Npad] union-find labels (-> segment starts after the sort) | root of every sketch
+    uint32_t *d_owner = nullptr;      // [S][owner_stride] one holder of every shared value (rank r -> owner[r - 1]); single-partition owning sets only
+    size_t owner_stride = 0;
     uint32_t *d_segend = nullptr;     // [Npad]    end of the segment of root r (the sort's scan)
     uint32_t *d_hint = nullptr;       // [2][Npad] per sketch the smallest holder of a value it shares (even / odd column pairs), 0xFFFFFFFF = none
-    uint32_t *d_spz = nullptr;        // ONE block the prepare clears: the five arrays below
+    uint32_t *d_spz = nullptr;        // ONE block the prepare clears: the arrays below
     size_t spz_words = 0;
     uint32_t *d_lcnt = nullptr;       // [Npad+1]  counting sort: sketches per root, then the placing cursors (= segment ends)
-    uint32_t *d_linked = nullptr;     // [Npad]    1 = some column pair united this sketch with another
     uint32_t *d_gbm = nullptr;        // 8 control words + the tile bitmap over ALL sorted row blocks (the segments' tiles); partial launches derive theirs from it
     uint32_t *d_order = nullptr;      // [8] [0] 1 = the launches walk every tile of the caller's-order operand (dense), [2] deep label chains
     uint32_t *d_plctl = nullptr;      // [8] [0] entries emitted into the pair list
@@ -65,6 +66,8 @@ struct d2g_cmp_set {
     uint32_t *d_tilebm = nullptr, *d_tiles = nullptr, *d_spctl = nullptr;   // a partial launch's tile bitmap, work list, 2 x 8 control words {tiles listed, flags, -, candidates}
     uint32_t *d_tiles_full = nullptr, *d_fullctl = nullptr;   // work lists + control words of a whole-triangle launch, left by the prepare (sp_permute_kernel)
     bool full_list_valid = false;
+    uint32_t *h_gaveup = nullptr, *d_gaveup = nullptr;   // a word of mapped host memory: 1 = the last ordering raised order[0] (the next prepare skips the ordering)
+    unsigned sp_prepares = 0; bool sp_skipped = false;
     uint32_t *prefilled = nullptr;        // output the engine filled at the start of its step (d2g_bitslice_prefill): the next sparse launch into it skips its fill
     const uint32_t *last_ctl = nullptr;   // control words of the last sparse launch (d2g_cmp_set_sparse_info)
     unsigned long long *d_plist = nullptr;   // pair list: (i | j << 32), i < j caller's indices, one entry per (pair in different segments, shared value)
@@ -89,6 +92,7 @@ int  d2g_bitslice_ensure_natural(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream
 int  d2g_bitslice_managed_sparse_alloc(d2g_ctx *ctx, d2g_cmp_set *set);
 int  d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s);
 int  d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint32_t *out4);
+int  d2g_bitslice_debug_read(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint64_t *pairs_out, size_t cap, size_t *npairs, uint32_t *root_out);
 int  d2g_bitslice_status(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s);   // synchronises; D2G_ERR_INTERNAL on overflow
 // exporter set over an N x S_local column slice (no operand of its own); d2g_bitslice_prepare_slice transposes + prepares it
 // into the target last given to d2g_bitslice_set_export_target

@@ -334,6 +334,14 @@ int d2g_cmp_set_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, 
     return d2g_bitslice_sparse_info(ctx, set, as_stream(stream), info4);
 }
 
+int d2g_cmp_set_debug_pairs(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, uint64_t *pairs_out, size_t cap, size_t *npairs, uint32_t *root_out) {
+    if (!ctx || !set || !npairs) return D2G_ERR_INVALID;
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    *npairs = 0;
+    if (set->algo != D2G_CMP_BITSLICE) return D2G_OK;
+    return d2g_bitslice_debug_read(ctx, set, as_stream(stream), pairs_out, cap, npairs, root_out);
+}
+
 int d2g_cmp_set_status(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream) {
     if (!ctx) return D2G_ERR_INVALID;
     D2G_CHECK(ctx, set && set->ctx == ctx, "cmp_set_status: set belongs to another context");

@@ -66,7 +66,8 @@ constexpr uint32_t BS_SPLIT_SHIFT = 28, BS_RANK_MASK = (1u << BS_SPLIT_SHIFT) - 
 template <bool MULTI, bool FAST>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
                                                                   uint32_t T, int logT, uint32_t *ids_all, uint32_t *colcnt,
-                                                                  uint32_t *status, int tagbits_max, uint32_t S, int nsplit) {
+                                                                  uint32_t *status, int tagbits_max, uint32_t S, int nsplit,
+                                                                  uint32_t *__restrict__ owner_all, size_t ostride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t own[];        // Tl owner slots
     const uint32_t split = MULTI ? blockIdx.x / S : 0u;
     const size_t t = MULTI ? blockIdx.x - split * S : blockIdx.x;
@@ -83,6 +84,12 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
     __shared__ uint32_t nfix, fix_j[BS_MAXFIX], fix_h[BS_MAXFIX];
     if (tid == 0) { running = 1; nfix = 0; }                             // id 0 is reserved for singletons
     const int lane = tid & 63, wave = tid >> 6;
+    // owner_all (single-partition kernels of sets that take the sparse path): owner[t][r - 1] = the sketch that owns the slot of the value
+    // ranked r -- ONE holder of every shared value, for free: the sparse path's link passes (sp_olink_kernel) compare every holder with its
+    // value's owner instead of grouping the holders in LDS again
+    uint32_t *owner = (owner_all && nsplit == 1) ? owner_all + t * ostride : nullptr;      // (one workgroup per column: `running` numbers the column's shared values 1 .. D2)
+    const int ib0 = 32 - __clz((uint32_t)N);
+    const uint32_t ownmask = (ib0 >= 32 ? 0xFFFFFFFFu : (1u << ib0) - 1u) & ~BS_DUP;
 
     // the compaction of one table pass: slots whose value occurs >= 2 times get the next dense ranks,
     // singletons BS_UNIQ
@@ -107,7 +114,10 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         uint32_t r = running + woff + (incl - cnt);
         for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) {
             const uint32_t cur = own[h];
-            if (cur != BS_EMPTY) own[h] = (cur & BS_DUP) ? (r++ | htag) : BS_UNIQ;
+            if (cur != BS_EMPTY) {
+                if ((cur & BS_DUP) && owner) owner[r - 1] = cur & ownmask;
+                own[h] = (cur & BS_DUP) ? (r++ | htag) : BS_UNIQ;
+            }
         }
         __syncthreads();
         if (tid == 0) running += tot;
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
     const size_t tb = blockIdx.y;
     sp_init_part(si, tb * ((size_t)gridDim.x * 256) + jpos, (size_t)gridDim.x * 256 * gridDim.y);
     if (jpos >= Nstride) return;
-    // sperm: the operand is written in the sparse path's sorted order -- position p holds sketch sperm[p] (stream form only)
+    // sperm: the operand written in another order -- position p holds sketch sperm[p] (stream form only; unused: the sparse path permutes the finished stream)
     const size_t j = sperm ? (size_t)sperm[jpos] : jpos;          // 0xFFFFFFFF (padding) fails j < N below
     const int nbits = live_planes(meta, (int)tb);
     // the group's 32 columns: two s_load_dwordx16 (constant address space: never written while this kernel runs), all in
@@ -752,6 +762,7 @@ void d2g_bitslice_free(d2g_cmp_set *set) {
     (void)hipFree(set->d_ids);
     (void)hipFree(set->d_colcnt);
     (void)hipFree(set->d_perm);
+    (void)hipFree(set->d_owner); set->d_owner = nullptr;
     set->d_planes = set->d_stream = set->d_meta = set->d_ids = set->d_colcnt = set->d_perm = nullptr;
     sp_free(set);
 }
@@ -829,7 +840,11 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     if (int rc = d2g_bitslice_alloc_stream(ctx, set)) { d2g_bitslice_free(set); return rc; }
     set->ncols = set->S;
     set->sparse_ok = sparse_enabled(ctx, set->N) && set->S < 65536;          // (the sparse kernel packs two mismatch counts into one LDS word)
-    if (set->sparse_ok && sp_alloc(ctx, set) != D2G_OK) { sp_free(set); (void)hipGetLastError(); set->sparse_ok = false; }   // no memory for the sparse path's buffers: the dense walk works without them
+    if (set->sparse_ok && sp_alloc(ctx, set) != D2G_OK) { sp_free(set); (void)hipGetLastError(); set->sparse_ok = false; }
+    if (set->sparse_ok && set->nsplit == 1) {                            // one holder per shared value, left by the rank kernel (sp_olink_kernel)
+        set->owner_stride = set->N / 2 + 8;
+        if (hipMalloc((void **)&set->d_owner, set->S * set->owner_stride * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); set->d_owner = nullptr; }
+    }   // no memory for the sparse path's buffers: the dense walk works without them
     return D2G_OK;
 }
 
@@ -842,7 +857,7 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     {
         const int logTl = set->logT < BS_LOG_TLDS_MAX ? set->logT : BS_LOG_TLDS_MAX;
         const size_t lds = (size_t(1) << logTl) * sizeof(uint32_t);
-        void (*kern)(const uint64_t *, size_t, size_t, uint32_t, int, uint32_t *, uint32_t *, uint32_t *, int, uint32_t, int) = bs_rank_kernel<false, false>;
+        void (*kern)(const uint64_t *, size_t, size_t, uint32_t, int, uint32_t *, uint32_t *, uint32_t *, int, uint32_t, int, uint32_t *, size_t) = bs_rank_kernel<false, false>;
         const bool multi = set->logT > BS_LOG_TLDS_MAX;
         if (multi) kern = bs_rank_kernel<true, false>;
         else if (N <= (size_t)12 * BS_RANK_THREADS) kern = bs_rank_kernel<false, true>;     // PF * BS_RANK_THREADS
@@ -856,7 +871,7 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         // after step: ids[] starts from zero in every split prepare -- a few MB for the narrow column slices that are split
         if (nsplit > 1) D2G_HIP(ctx, hipMemsetAsync(set->d_ids, 0, S * Npad * sizeof(uint32_t), s));
         hipLaunchKernelGGL(kern, dim3((unsigned)(S * nsplit)), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
-                           set->d_ids, set->d_colcnt, set->d_meta + set->ntb, tagbits_max, (uint32_t)S, nsplit);
+                           set->d_ids, set->d_colcnt, set->d_meta + set->ntb, tagbits_max, (uint32_t)S, nsplit, nsplit == 1 ? set->d_owner : (uint32_t *)nullptr, set->owner_stride);
         hipLaunchKernelGGL(bs_colplan_kernel, dim3(1), dim3(BS_PLAN_THREADS), 0, s, set->d_colcnt, (uint32_t)S, set->ntb, nsplit, set->d_perm,
                            set->d_meta, set->d_meta + set->ntb, set->ex_meta, set->ex_status, sort_columns(ctx) ? 1 : 0);
     }
@@ -1028,9 +1043,24 @@ int d2g_bitslice_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s
     D2G_HIP(ctx, hipMemcpyAsync(&pl, set->d_plctl, sizeof pl, hipMemcpyDeviceToHost, s));
     D2G_HIP(ctx, hipStreamSynchronize(s));
     const bool dense = (c[1] & 1u) || (size_t)c[0] * 5 > (size_t)c[3] * 2;
-    // [2]: bit 0 the prepare decided for the dense walk, bit 1 the dense kernel ran, bit 2 tiles + pair list were used, bit 3 the caller's order was kept
-    out4[0] = 1; out4[1] = c[0]; out4[2] = (ord[0] ? 1u : 0u) | (dense ? 2u : 4u) | (ord[0] ? 8u : 0u);
+    // [2]: bit 0 the prepare decided for the dense walk, bit 1 the dense kernel ran, bit 2 tiles + pair list were used, bit 3 the caller's order was kept,
+    //      bit 4 the last prepare skipped the ordering (the one before had given up: sp_prepare_order)
+    out4[0] = 1; out4[1] = c[0]; out4[2] = (ord[0] ? 1u : 0u) | (dense ? 2u : 4u) | (ord[0] ? 8u : 0u) | (set->sp_skipped ? 16u : 0u);
     out4[3] = ord[0] ? 0u : (uint32_t)std::min<size_t>(pl, set->plist_cap);
+    return D2G_OK;
+}
+
+// diagnostics: the pair list and the sorted order of the last prepare, copied to the host (synchronises `s`)
+int d2g_bitslice_debug_read(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s, uint64_t *pairs_out, size_t cap, size_t *npairs, uint32_t *root_out /* [N] or null */) {
+    *npairs = 0;
+    if (!set->srt_valid || !set->d_plctl) { D2G_HIP(ctx, hipStreamSynchronize(s)); return D2G_OK; }
+    uint32_t n = 0;
+    D2G_HIP(ctx, hipMemcpyAsync(&n, set->d_plctl, 4, hipMemcpyDeviceToHost, s));
+    D2G_HIP(ctx, hipStreamSynchronize(s));
+    const size_t m = std::min<size_t>(std::min<size_t>(n, set->plist_cap), cap);
+    if (m && pairs_out) D2G_HIP(ctx, hipMemcpy(pairs_out, set->d_plist, m * 8, hipMemcpyDeviceToHost));
+    if (root_out) D2G_HIP(ctx, hipMemcpy(root_out, set->d_label + set->Npad, set->N * 4, hipMemcpyDeviceToHost));
+    *npairs = m;
     return D2G_OK;
 }
 

@@ -22,8 +22,8 @@
 //                     label[]) only where they agree in BOTH columns -- a family's members do so in many column pairs, a stranger that
 //                     shares one chance value with a family does not, so one chance collision no longer welds two families together
 //                     (round 4 united over single columns: ten collisions per sketch put every sketch into one component);
-//          sp_attach  a sketch no column pair linked joins the family TWO independent hints point to (the smallest holder of a value
-//                     it shares, recorded by even and by odd column pairs): a weak family member, or families of two;
+//          sp_flatten between the two link passes; sp_attach behind them: a sketch no column pair linked joins the family its hints -- some
+//                     holder of a value it shares, recorded by even and by odd column pairs -- point to (a weak member, families of two);
 //          sp_count / scan / place   counting sort by root -> sperm / sinv, the segments, keep-the-caller's-order decision;
 //          sp_emit    (b) above (the segments' tiles are set by the sort's place kernel);
 //          sp_permute the finished plane stream in sorted order.
@@ -71,16 +71,16 @@ __device__ __forceinline__ bool sp_union(uint32_t *label, uint32_t a, uint32_t b
 //            of the same family, so whichever racing store lands last the array still holds, per sketch, an earlier member of its
 //            family.  This does nearly all the uniting without a single global atomic (letting every matcher run the union-find below
 //            from identity labels was measured: 264 us at config 3 -- 1.6 million root walks and compare-and-swaps for the 9 934 hooks
-//            the families need).  Also here: any[r1] = some holder of r1 -- the hint a holder that did not match takes away --, and the
-//            `linked` flag of a root that matched somebody.
+//            the families need).  Also here: any[r1] = some holder of r1 -- the hint a holder that did not match takes away
+//            (sp_attach_kernel).
 //   MODE 1 (every `stride`-th column pair, behind sp_flatten_kernel: unite)  where a matcher's label still differs from mn, ONE
 //            matcher per value runs the lock-free union of the two trees: the safety net for families the racing stores left under two
 //            roots (every matcher doing so cost 40 us; a quarter of the column pairs still sees every family dozens of times).
 // Values beyond the table (nv = min(D2, cap)) take no part: the partition is a heuristic, sp_emit_kernel keeps the result exact.
-constexpr uint32_t SP_PLURAL = 0x80000000u, SP_UDONE = 0x40000000u, SP_R2MASK = 0x3FFFFFFFu;   // r2[]: bit 31 = the value has two or more matchers, bit 30 = one of them has run the union (ranks stay below 2^29: N < 2^30)
+constexpr uint32_t SP_UDONE = 0x40000000u, SP_R2MASK = 0x3FFFFFFFu;   // r2[]: bit 30 = one of the value's matchers has run the union (ranks stay below 2^29: N < 2^30)
 template <int MODE>
 __global__ __launch_bounds__(1024) void sp_link_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt,
-                                                       int split, uint32_t cap, uint32_t stride, uint32_t *label, uint32_t *__restrict__ hint, uint32_t *__restrict__ linked) {
+                                                       int split, uint32_t cap, uint32_t stride, uint32_t *label, uint32_t *__restrict__ hint) {
     extern __shared__ uint32_t sp_l[];
     const size_t pair = (size_t)blockIdx.x * stride;
     const size_t t1 = 2 * pair, t2 = t1 + 1;
@@ -111,7 +111,6 @@ __global__ __launch_bounds__(1024) void sp_link_kernel(const uint32_t *__restric
             const uint32_t old = atomicCAS(&r2[a - 1], SP_NONE, b);
             if (old == SP_NONE || (old & SP_R2MASK) == b) {
                 atomicMin(&mn[a - 1], lb[x]);
-                if (MODE == 0 && old == b) atomicOr(&r2[a - 1], SP_PLURAL);   // a second matcher (set once: later ones see the bit)
             }
         }
     }
@@ -137,8 +136,6 @@ __global__ __launch_bounds__(1024) void sp_link_kernel(const uint32_t *__restric
                 if (match) {
                     const uint32_t m = mn[a - 1];
                     if (m < lb[x]) label[j] = m;
-                    // a ROOT that matched somebody is no singleton: sp_attach_kernel must leave it alone (non-roots it skips anyway)
-                    if ((rr & SP_PLURAL) && lb[x] == j) linked[j] = 1;
                 } else {
                     const uint32_t h = any[a - 1];
                     if (h != j) myhint[j] = h;
@@ -147,6 +144,56 @@ __global__ __launch_bounds__(1024) void sp_link_kernel(const uint32_t *__restric
                 const uint32_t m = mn[a - 1];
                 if (m != lb[x] && !(atomicOr(&r2[a - 1], SP_UDONE) & SP_UDONE)) (void)sp_union(label, lb[x], m);
             }
+        }
+    }
+}
+
+// The same two passes WITHOUT tables, for sets whose rank kernel left one holder per shared value (owner[t][r - 1]; every set that owns its
+// operand unless its columns are split over workgroups): a sketch matches the OWNER of its value in column t1 when the owner holds the same
+// shared value as the sketch in column t2 too -- one thread per (column pair, four sketches), no LDS, no barrier: two coalesced loads and
+// three gathers per sketch instead of a workgroup per column pair walking the column twice behind barriers (config 3: 23 + 10 us -> TBD).
+// The owner is an arbitrary holder, so about half of a value's chances to link are lost (the owner must share in t2 as well); the members
+// that find no link take the owner as their hint and are attached afterwards.  MODE 1: the first matcher of a value whose label differs from the
+// owner's (bit 31 of the owner word, set with one atomic) unites the two trees.
+constexpr uint32_t SP_OWNER_MASK = 0x7FFFFFFFu;
+template <int MODE>
+__global__ __launch_bounds__(256) void sp_olink_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, uint32_t *__restrict__ owner, size_t ostride,
+                                                       uint32_t stride, uint32_t *label, uint32_t *__restrict__ hint) {
+    const size_t pair = (size_t)blockIdx.y * stride;
+    const size_t t1 = 2 * pair, t2 = t1 + 1;
+    if (t2 >= ncols) return;
+    const size_t j0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j0 >= N) return;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 w1 = *reinterpret_cast<const u32x4 *>(ids + t1 * Npad + j0);       // (Npad is a multiple of 256: aligned; the padding holds id 0)
+    const u32x4 w2 = *reinterpret_cast<const u32x4 *>(ids + t2 * Npad + j0);
+    const u32x4 lb = *reinterpret_cast<const u32x4 *>(label + j0);                  // plain loads: a stale label is still an earlier member of the family
+    uint32_t *myhint = hint + (size_t)(pair & 1u) * Npad;
+    uint32_t o[4], r2o[4], lo[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const uint32_t r1 = w1[x];
+        o[x] = (r1 && !(r1 >> 31) && j0 + x < N) ? owner[t1 * ostride + r1 - 1] & SP_OWNER_MASK : SP_NONE;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        const bool live = o[x] != SP_NONE && o[x] != (uint32_t)(j0 + x);
+        r2o[x] = live ? ids[t2 * Npad + o[x]] : 0u;
+        lo[x] = live ? label[o[x]] : 0u;
+        if (!live) o[x] = SP_NONE;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        if (o[x] == SP_NONE) continue;
+        const uint32_t j = (uint32_t)(j0 + x), r2 = w2[x];
+        const bool match = r2 && !(r2 >> 31) && r2 == r2o[x];
+        if (MODE == 0) {
+            if (match) {
+                if (lo[x] < lb[x]) label[j] = lo[x]; else if (lb[x] < lo[x]) label[o[x]] = lb[x];
+            } else myhint[j] = o[x];
+        } else if (match && lb[x] != lo[x]) {
+            uint32_t *ow = &owner[t1 * ostride + w1[x] - 1];
+            if (!(atomicOr(ow, ~SP_OWNER_MASK) & ~SP_OWNER_MASK)) (void)sp_union(label, lb[x], lo[x]);
         }
     }
 }
@@ -169,17 +216,28 @@ __global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t
     if (label[l] == l) label[j] = l;
 }
 
-// a sketch that no column pair linked joins the root its hints lead to: both hints when it has two (they must agree: a sketch whose
-// shared values all lie with DIFFERENT strangers -- the adversarial matrix -- stays alone and goes to the pair list), the one it has
-// otherwise (a weak family member, families of two, chains)
-__global__ __launch_bounds__(256) void sp_attach_kernel(uint32_t *label, const uint32_t *__restrict__ hint, const uint32_t *__restrict__ linked, size_t N, size_t Npad) {
+// Behind the count kernel (the roots are final, root[] and cnt[] say who is alone): a sketch ALONE under its root joins the family its hints
+// lead to -- both hints when it has two (they must agree: a sketch whose shared values all lie with DIFFERENT strangers -- the adversarial
+// matrix -- stays alone and goes to the pair list), the one it has otherwise (a weak family member) -- if that root holds a real family
+// (two or more sketches; singletons do not chain up: families of two and chains stay in the pair list).  Only root[] and the counters
+// change; the labels are dead by now.  (Judged BEFORE the uniting pass a weak member's two hints point into two fragments of its own
+// family and are refused; judged by a "matched somebody" flag instead of the counter, a sketch whose one link a racing store undid stayed
+// alone with 45 shared values: 28 resp. 19 stragglers at config 3, a mixed value in most columns.)
+__global__ __launch_bounds__(256) void sp_attach_kernel(uint32_t *__restrict__ root, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ hint, size_t N, size_t Npad,
+                                                        const uint32_t *__restrict__ order) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N || label[j] != (uint32_t)j || linked[j]) return;       // under somebody already, or a root that matched somebody
+    if (j >= N || order[2]) return;
+    if (root[j] != (uint32_t)j || sp_ld(&cnt[j]) != 1u) return;       // under somebody, or others are under it
     const uint32_t a = hint[j], b = hint[Npad + j];
     if (a == SP_NONE && b == SP_NONE) return;
-    const uint32_t ra = a != SP_NONE ? sp_find(label, a) : SP_NONE, rb = b != SP_NONE ? sp_find(label, b) : SP_NONE;
+    // (root[] of another singleton may be changing under us: it then reads as itself or as its new family -- either is a valid answer)
+    const uint32_t ra = a != SP_NONE ? sp_ld(&root[a]) : SP_NONE, rb = b != SP_NONE ? sp_ld(&root[b]) : SP_NONE;
     if (ra != SP_NONE && rb != SP_NONE && ra != rb) return;
-    (void)sp_union(label, (uint32_t)j, ra != SP_NONE ? ra : rb);
+    const uint32_t r = ra != SP_NONE ? ra : rb;
+    if (r == (uint32_t)j || sp_ld(&cnt[r]) < 2u) return;              // only real families take stragglers in
+    root[j] = r;
+    atomicAdd(&cnt[r], 1u);
+    cnt[j] = 0;
 }
 
 // block-wide exclusive scan of one value per thread (NW waves); returns the exclusive prefix, *total = the sum
@@ -237,7 +295,8 @@ __global__ __launch_bounds__(256) void sp_count_kernel(uint32_t *label, uint32_t
 }
 // order[0] = 1: the launches walk every tile of the caller's-order operand (one root holds more than half of the sketches, deep label
 // chains, or the segments would cover more than seg_tile_limit tiles -- the sparse kernel costs about twice the plain one per tile)
-__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t *__restrict__ segend, uint32_t seg_tile_limit) {
+__global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t *__restrict__ segend, uint32_t seg_tile_limit,
+                                                       uint32_t *__restrict__ gaveup) {
     // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
     __shared__ uint32_t wave_tot[16];
     __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
@@ -291,7 +350,7 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cn
     for (int o = 32; o > 0; o >>= 1) est += __shfl_down(est, o);
     if ((tid & 63) == 0) atomicAdd(&s_est, est);
     __syncthreads();
-    if (tid == 0) order[0] = (s_big || order[2] || s_est > seg_tile_limit + 1024) ? 1u : 0u;
+    if (tid == 0) { const uint32_t keep = (s_big || order[2] || s_est > seg_tile_limit + 1024) ? 1u : 0u; order[0] = keep; *gaveup = keep; }   // gaveup: a word in host memory (sp_prepare_order reads it before the NEXT prepare)
 }
 // a segment [a, b) of two or more sketches sets the tiles its row blocks (32 positions) and column blocks (256 positions) meet in: every
 // pair inside the segment lies in one of them (fact (a) of the header)
@@ -344,7 +403,7 @@ __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restric
 constexpr uint32_t SP_EMIT_VCAP = 2048, SP_EMIT_ECAP = 2048, SP_EMIT_T = 512;      // 32 KB of LDS: four workgroups per CU
 __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
                                                             const uint32_t *__restrict__ seg, uint32_t *__restrict__ order,
-                                                            unsigned long long *__restrict__ plist, uint32_t *__restrict__ plctl, uint32_t plcap) {
+                                                            unsigned long long *__restrict__ plist, uint32_t *__restrict__ plctl, uint32_t plcap, uint32_t *__restrict__ gaveup) {
     __shared__ uint32_t first[SP_EMIT_VCAP];
     __shared__ uint32_t mixed[SP_EMIT_VCAP / 32];
     __shared__ uint32_t ej[SP_EMIT_ECAP], eseg[SP_EMIT_ECAP], enext[SP_EMIT_ECAP];
@@ -401,9 +460,9 @@ __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__re
         const uint32_t nent = s_nent;
         if (nent > SP_EMIT_ECAP) {
             __syncthreads();                                          // (everybody has read s_nent before it is reset)
-            if (len == 1) { if (tid == 0) order[0] = 1; return; }     // ONE value with thousands of holders spread over segments: not sparse
+            if (len == 1) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }     // ONE value with thousands of holders spread over segments: not sparse
             // the holders that did not fit are a lower bound of what is still to come: (h - 1) pairs at least for h holders of one value
-            if (tid == 0 && (size_t)nent * ncols > (size_t)plcap * 8) order[0] = 1;
+            if (tid == 0 && (size_t)nent * ncols > (size_t)plcap * 8) { order[0] = 1; *gaveup = 1; }
             curlen = len / 2;
             continue;
         }
@@ -419,7 +478,7 @@ __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__re
         __syncthreads();
         if (total) {
             const uint32_t base = s_base;
-            if ((size_t)base + total > plcap) { if (tid == 0) order[0] = 1; return; }
+            if ((size_t)base + total > plcap) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }
             colpairs += total;
             off += base;
             for (uint32_t k = tid; k < nent; k += T) {
@@ -437,12 +496,12 @@ __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__re
         // Eight columns must say so (one odd column must not send a sparse matrix to the dense walk).
         if (tid == 0 && colpairs && !voted && (size_t)colpairs * d2 / lo * ncols > (size_t)plcap + plcap / 4) {
             voted = true;
-            if (atomicAdd(&plctl[4], 1u) + 1u >= 8u) order[0] = 1;
+            if (atomicAdd(&plctl[4], 1u) + 1u >= 8u) { order[0] = 1; *gaveup = 1; }
         }
     }
     if (tid == 0 && colpairs) {
         const uint32_t tot = atomicAdd(&plctl[2], colpairs) + colpairs, done = atomicAdd(&plctl[3], 1u) + 1u;
-        if (done >= 32 && (size_t)tot / done * ncols > (size_t)plcap + plcap / 2) order[0] = 1;
+        if (done >= 32 && (size_t)tot / done * ncols > (size_t)plcap + plcap / 2) { order[0] = 1; *gaveup = 1; }
     }
 }
 
@@ -804,6 +863,8 @@ struct SpTuning {
     int link = 1;                       // D2G_SP_LINK: 0 = no families (every sketch its own segment: the pair list alone; tests)
     int attach = 1;                     // D2G_SP_ATTACH: 0 = no second chance for sketches no column pair linked
     double tile_frac = 0.35;            // D2G_SP_TILE_FRAC: the segments may cover this fraction of all tiles before the dense walk is cheaper
+    int olink = 1;                      // D2G_SP_OLINK: 0 = the table form of the link passes even where the rank kernel left an owner per value (tests: the multi-GPU engine's form)
+    int remember = 1;                   // D2G_SP_REMEMBER: 0 = every prepare runs the ordering, whatever the last one decided
     size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
     size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
     size_t list_div = 16;               // D2G_SP_LIST_DIV: the pair list holds at most pairs / list_div entries (and at most 2^27): an entry costs ~130 ps (emit + two patch passes), a pair of the dense walk ~9
@@ -815,6 +876,8 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_SP_LINK")) v.link = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_ATTACH")) v.attach = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_TILE_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.tile_frac = f; }
+    if (const char *e = ctx->tune.get("D2G_SP_OLINK")) v.olink = std::atoi(e) != 0;
+    if (const char *e = ctx->tune.get("D2G_SP_REMEMBER")) v.remember = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_LIST_DIV")) { const long d = std::atol(e); if (d >= 1 && d <= (1 << 20)) v.list_div = (size_t)d; }
@@ -834,8 +897,8 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     set->tilebm_words = nrb * ((ncb + 31) / 32) + 1;
     set->tiles_cap = nrb * ((ncb + 7) / 8);                            // per list: the tiles of every eighth column block
     set->plist_cap = sp_list_cap(ctx, set->N);
-    // one zero-initialised block per prepare: [counters Npad + 1 | linked Npad | 8 global control words + tile bitmap | order 8 | list control 8 | control words of a whole-triangle launch 16]
-    set->spz_words = (Npad + 1) + Npad + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS;
+    // one zero-initialised block per prepare: [counters Npad + 1 | 8 global control words + tile bitmap | order 8 | list control 8 | control words of a whole-triangle launch 16]
+    set->spz_words = (Npad + 1) + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS;
     const size_t planes_words = (size_t)set->ntb * set->nbits_cap + 1;
     hipError_t e;
     if ((e = hipMalloc((void **)&set->d_stream_s, planes_words * 2 * Nstride * sizeof(uint32_t))) != hipSuccess ||
@@ -856,13 +919,15 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
     set->d_lcnt = set->d_spz;
-    set->d_linked = set->d_lcnt + (Npad + 1);
-    set->d_gbm = set->d_linked + Npad;
+    set->d_gbm = set->d_lcnt + (Npad + 1);
     set->d_order = set->d_gbm + 8 + set->tilebm_words;
     set->d_plctl = set->d_order + 8;
     set->d_fullctl = set->d_plctl + 8;
     set->d_tilebm = set->d_spctl + 2 * SP_CTL_WORDS;
     if ((e = hipMemset(set->d_spctl, 0, 2 * SP_CTL_WORDS * 4)) != hipSuccess) { ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e); return D2G_ERR_HIP; }
+    // one word of host memory the device can write: the remembered give-up (sp_prepare_order)
+    if (hipHostMalloc((void **)&set->h_gaveup, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void **)&set->d_gaveup, set->h_gaveup, 0) == hipSuccess) *set->h_gaveup = 0;
+    else { (void)hipGetLastError(); if (set->h_gaveup) (void)hipHostFree(set->h_gaveup); set->h_gaveup = nullptr; set->d_gaveup = set->d_order + 7; }   // (no mapped host memory: a spare device word, never read by the host)
     set->sp_launch = 0;
     return D2G_OK;
 }
@@ -871,10 +936,12 @@ void sp_free(d2g_cmp_set *set) {
     for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_hint, &set->d_segend, &set->d_spz, &set->d_rowpos, &set->d_rowk,
                          &set->d_rowstream, &set->d_tiles, &set->d_tiles_full, &set->d_spctl}) { (void)hipFree(*p); *p = nullptr; }
     (void)hipFree(set->d_plist); set->d_plist = nullptr;
-    set->d_tilebm = set->d_lcnt = set->d_linked = set->d_gbm = set->d_order = set->d_plctl = set->d_fullctl = nullptr;
+    if (set->h_gaveup) { (void)hipHostFree(set->h_gaveup); set->h_gaveup = nullptr; }
+    set->d_gaveup = nullptr;
+    set->d_tilebm = set->d_lcnt = set->d_gbm = set->d_order = set->d_plctl = set->d_fullctl = nullptr;
 }
 
-// what the kernel in front of sp_prepare_order initialises for it: label[j] = j, the hints, and the zero block (counters, linked flags,
+// what the kernel in front of sp_prepare_order initialises for it: label[j] = j, the hints, and the zero block (counters,
 // tile bitmap + global control words, order words, list cursor)
 SpInit sp_init_of(const d2g_cmp_set *set) {
     SpInit si;
@@ -882,39 +949,6 @@ SpInit sp_init_of(const d2g_cmp_set *set) {
     si.ones = set->d_hint; si.owords = (uint32_t)(2 * set->Npad);
     si.zero = set->d_spz; si.zwords = (uint32_t)set->spz_words;
     return si;
-}
-
-// labels -> counting sort -> d_sperm / d_sinv -> pair list + segment tiles.  All on `s`, no host round trip.
-int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
-    const size_t N = set->N, Npad = set->Npad, S = set->ncols;
-    const unsigned nb = (unsigned)div_up<size_t>(N, 256);
-    uint32_t *la = set->d_label, *lb = set->d_label + Npad;
-    const SpTuning tu = sp_tuning(ctx);
-    if (tu.link && S >= 2) {
-        const uint32_t cap = (uint32_t)std::min<size_t>(N / 2 + 1, 12288);              // shared values of a column that take part: 3 words each, 144 KB of LDS at most
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12));
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8));
-        const unsigned npair = (unsigned)(S / 2);
-        const uint32_t ustride = (uint32_t)std::max<size_t>(1, std::min<size_t>(tu.unite_stride, npair / 32));   // at least 32 column pairs take part in the uniting pass
-        hipLaunchKernelGGL(sp_link_kernel<0>, dim3(npair), dim3(1024), (size_t)cap * 12, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap, 1u,
-                           la, set->d_hint, set->d_linked);
-        hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
-        hipLaunchKernelGGL(sp_link_kernel<1>, dim3(div_up<unsigned>(npair, ustride)), dim3(1024), (size_t)cap * 8, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap, ustride,
-                           la, set->d_hint, set->d_linked);
-        if (tu.attach) hipLaunchKernelGGL(sp_attach_kernel, dim3(nb), dim3(256), 0, s, la, set->d_hint, set->d_linked, N, Npad);
-    }
-    const size_t ntile_all = (Npad / 32) * (Npad / BS_CB);
-    const uint32_t seg_limit = (uint32_t)std::min<size_t>((size_t)((double)ntile_all * tu.tile_frac), 0x3FFFFFFF);
-    // (one single-workgroup kernel for count + scan + place with the counters in LDS was measured at N = 10 000: 25 us against 19 for the three)
-    hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order);
-    const uint32_t CW = (uint32_t)((Npad / BS_CB + 31) / 32);
-    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, set->d_segend, seg_limit);    // la (labels) is dead after the count kernel: it keeps the segment starts
-    hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order,
-                       la, set->d_segend, CW, set->d_gbm + 8);
-    hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)S), dim3(SP_EMIT_T), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, lb, set->d_order,
-                       set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu));
-    D2G_HIP(ctx, hipGetLastError());
-    return D2G_OK;
 }
 
 // candidate tiles of a whole-triangle launch: the tiles on or above the diagonal of sorted positions
@@ -925,8 +959,73 @@ size_t sp_full_candidates(size_t Npad) {
     return cand;
 }
 
+// the whole ordering skipped: dense walk (see sp_prepare_order)
+__global__ void sp_giveup_kernel(uint32_t *__restrict__ order, uint32_t *__restrict__ fullctl, uint32_t cand) {
+    if (threadIdx.x == 0) { order[0] = 1; fullctl[1] = 1; fullctl[3] = cand; }
+}
+
+// labels -> counting sort -> d_sperm / d_sinv -> pair list + segment tiles.  All on `s`, no host round trip.
+// where the path does not pay (one family, heavy noise, adversarial columns) the ordering that finds it out costs 0.05-0.2 ms
+// per prepare.  The decision is REMEMBERED per set: the kernels that raise order[0] also write a word in host-visible memory; a later
+// prepare of the same set (CLI batches, re-loaded matrices) reads it -- no synchronisation: a prepare still in flight simply has not
+// written it yet -- and skips the ordering; every 16th prepare tries again (the matrix may have changed).  Exactness is not involved: the
+// dense walk is always right.
+int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
+    const size_t N = set->N, Npad = set->Npad, S = set->ncols;
+    ++set->sp_prepares;
+    if (sp_tuning(ctx).remember && set->h_gaveup && *(volatile uint32_t *)set->h_gaveup && (set->sp_prepares & 15u) != 0) {
+        hipLaunchKernelGGL(sp_giveup_kernel, dim3(1), dim3(64), 0, s, set->d_order, set->d_fullctl, (uint32_t)std::min<size_t>(sp_full_candidates(Npad), 0xFFFFFFFFu));
+        D2G_HIP(ctx, hipGetLastError());
+        set->sp_skipped = true;
+        return D2G_OK;
+    }
+    set->sp_skipped = false;
+    const unsigned nb = (unsigned)div_up<size_t>(N, 256);
+    uint32_t *la = set->d_label, *lb = set->d_label + Npad;
+    const SpTuning tu = sp_tuning(ctx);
+    if (tu.link && S >= 2) {
+        const uint32_t cap = (uint32_t)std::min<size_t>(N / 2 + 1, 12288);              // shared values of a column that take part: 3 words each, 144 KB of LDS at most
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12));
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8));
+        const unsigned npair = (unsigned)(S / 2);
+        const uint32_t ustride = (uint32_t)std::max<size_t>(1, std::min<size_t>(tu.unite_stride, npair / 32));   // at least 32 column pairs take part in the uniting pass
+        if (set->d_owner && !split && tu.olink) {                        // one holder per shared value at hand: the streaming form
+            const unsigned nx = (unsigned)div_up<size_t>(N, 1024);
+            hipLaunchKernelGGL(sp_olink_kernel<0>, dim3(nx, npair), dim3(256), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_owner, set->owner_stride, 1u, la, set->d_hint);
+            hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
+            hipLaunchKernelGGL(sp_olink_kernel<1>, dim3(nx, div_up<unsigned>(npair, ustride)), dim3(256), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_owner, set->owner_stride, ustride, la, set->d_hint);
+        } else {
+            hipLaunchKernelGGL(sp_link_kernel<0>, dim3(npair), dim3(1024), (size_t)cap * 12, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap, 1u,
+                               la, set->d_hint);
+            hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
+            hipLaunchKernelGGL(sp_link_kernel<1>, dim3(div_up<unsigned>(npair, ustride)), dim3(1024), (size_t)cap * 8, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap, ustride,
+                               la, set->d_hint);
+        }
+    }
+    const size_t ntile_all = (Npad / 32) * (Npad / BS_CB);
+    const uint32_t seg_limit = (uint32_t)std::min<size_t>((size_t)((double)ntile_all * tu.tile_frac), 0x3FFFFFFF);
+    // (one single-workgroup kernel for count + scan + place with the counters in LDS was measured at N = 10 000: 25 us against 19 for the three)
+    hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order);
+    if (tu.link && tu.attach && S >= 2) hipLaunchKernelGGL(sp_attach_kernel, dim3(nb), dim3(256), 0, s, lb, set->d_lcnt, set->d_hint, N, Npad, set->d_order);
+    const uint32_t CW = (uint32_t)((Npad / BS_CB + 31) / 32);
+    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, set->d_segend, seg_limit, set->d_gaveup);    // la (labels) is dead after the count kernel: it keeps the segment starts
+    hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order,
+                       la, set->d_segend, CW, set->d_gbm + 8);
+    // (a certificate pass in front -- one thread per (column, sketch) comparing the sketch's segment with that of its value's owner, so that
+    // columns where nothing crosses a segment need no workgroup here -- was measured: 17 us for the pass, and the 17 stragglers a clean
+    // collection of 10 000 leaves still put a mixed value into a hundred columns, whose workgroups take as long as before: 0.338 vs 0.329 ms)
+    hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)S), dim3(SP_EMIT_T), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, lb, set->d_order,
+                       set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), set->d_gaveup);
+    D2G_HIP(ctx, hipGetLastError());
+    return D2G_OK;
+}
+
 // the sorted stream + (in the same launch) the work lists of whole-triangle launches
 int sp_permute(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
+    if (set->sp_skipped) { set->full_list_valid = true; return D2G_OK; }   // the remembered give-up: sp_giveup_kernel left the control words of a dense launch
+    // (the sorted stream gathered straight from the ids -- one group per XCD so that the gathers hit its L2 -- instead of permuting the caller's-order
+    // stream was measured again in round 5: 42 us against planes 19 + permute 21 at config 3, 208 against 113 at N = 50 000; round 4 without the XCD
+    // mapping: 74)
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const size_t nrb = set->Npad / 32, ncb = set->Npad / BS_CB, ntile = nrb * ncb;
     SpFullList fl{set->d_gbm + 8, (uint32_t)nrb, (uint32_t)ncb, (uint32_t)((ncb + 31) / 32), set->d_tiles_full, (uint32_t)set->tiles_cap, set->d_fullctl,

@@ -473,8 +473,11 @@ int check_group(d2g_allpairs **es, int n) {
     for (int i = 0; i < n; ++i) {
         if (!es[i]) return D2G_ERR_INVALID;
         D2G_CHECK(es[i]->ctx, es[i]->N == es[0]->N && es[i]->S == es[0]->S && es[i]->W == es[0]->W && es[i]->C == es[0]->C, "allpairs: engines of different shapes");
-        D2G_CHECK(es[i]->ctx, d2g_tuning_hash(es[i]->ctx->tune, "D2G_BS_", "D2G_SP_") == d2g_tuning_hash(es[0]->ctx->tune, "D2G_BS_", "D2G_SP_"),
-                  "allpairs: the ranks' contexts resolved different D2G_BS_* / D2G_SP_* switches (d2g_ctx_tuning): every rank must run the same kernels");
+        if (d2g_tuning_hash(es[i]->ctx->tune, "D2G_BS_", "D2G_SP_") != d2g_tuning_hash(es[0]->ctx->tune, "D2G_BS_", "D2G_SP_")) {
+            const char *msg = "allpairs: the ranks' contexts resolved different D2G_BS_* / D2G_SP_* switches (d2g_ctx_tuning): every rank must run the same kernels";
+            es[i]->ctx->last_error = msg; es[0]->ctx->last_error = msg;       // whichever context the caller asks
+            return D2G_ERR_INVALID;
+        }
     }
     return D2G_OK;
 }

@@ -342,8 +342,13 @@ int  d2g_cmp_set_planes(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, unsi
  * one after the other on ONE stream (rectangular launches and launches on different sets are independent).
  * info4 of the LAST upper-triangle launch on the set (synchronises `stream`): [0] 1 = the set has a sorted operand, [1] tiles
  * listed, [2] flags (bit 0: the prepare decided for the dense walk, bit 1: the dense kernel ran, bit 2: tiles + pair list were used,
- * bit 3: the caller's order was kept), [3] entries of the pair list (one per pair of different families and shared value). */
+ * bit 3: the caller's order was kept, bit 4: the prepare skipped the ordering because the previous prepare of this set had given up --
+ * remembered per set, retried every 16th prepare, D2G_SP_REMEMBER=0 switches it off), [3] entries of the pair list (one per pair of
+ * different families and shared value). */
 int  d2g_cmp_set_sparse_info(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, uint32_t *info4);
+/* diagnostics of the last prepare (synchronises `stream`): up to `cap` entries of the pair list (i | j << 32, i < j) and, if root_out is not null, the family
+ * root of every sketch (sketches with equal roots sit in one segment).  Nothing in the product reads these back; tools/plist_stats.py does. */
+int  d2g_cmp_set_debug_pairs(d2g_ctx *ctx, const d2g_cmp_set *set, void *stream, uint64_t *pairs_out, size_t cap, size_t *npairs, uint32_t *root_out);
 /* ---- sharded prepare (multi-GPU).  The bit-sliced operand is an array of independent
  * 32-register groups of `group_words` u32 each (+ one u32 of meta per group) whose geometry depends
  * on N only, so ranks can each build the groups of their own column slice and all-gather them:

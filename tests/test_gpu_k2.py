@@ -527,7 +527,7 @@ def _ut_offsets(N):
     return np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
 
 
-@pytest.mark.parametrize("variant", ["default", "no_link", "no_attach", "short_list"])
+@pytest.mark.parametrize("variant", ["default", "table_link", "no_link", "no_attach", "short_list"])
 def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gpu_ctx, d2g, oracle, monkeypatch, variant):
     """Round 5: from 8192 sketches on, an upper-triangle launch on a bit-sliced set fills the output with the value of "0 equal", walks
     only the tiles of the FAMILIES the prepare found (sketches that agree in many registers) and adds a list of the pairs of different
@@ -539,6 +539,9 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
     set RE-LOADED with another matrix.  Variants: no families at all (D2G_SP_LINK=0), no attach step, a pair list of pairs / 4096
     entries (overflow -> dense walk)."""
     import torch
+    monkeypatch.setenv("D2G_SP_REMEMBER", "0")                         # nine different matrices through ONE set: every prepare decides afresh
+    if variant == "table_link":                                        # the form the multi-GPU engine's gathered operand takes: tables in LDS
+        monkeypatch.setenv("D2G_SP_OLINK", "0")
     if variant == "no_link":
         monkeypatch.setenv("D2G_SP_LINK", "0")
         monkeypatch.setenv("D2G_SP_LIST_DIV", "2")                     # every equal register pair of the families becomes a list entry: ~20 million
@@ -615,7 +618,7 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
         assert f["tiles_listed"] == 0 and f["pairs_listed"] > 100_000                           # every equal register pair of the matrix is a list entry
     elif variant != "short_list":
         assert f["tiles_listed"] > 0
-    if variant == "default":
+    if variant in ("default", "table_link"):
         # ten chance collisions per sketch used to list every tile; now the families keep their tiles and the strangers go to the list
         # (S = 96: one collision per sketch is 1 % of the registers, ten are 10 % -- heavy noise at this sketch size)
         assert 0 < seen["families+1"]["tiles_listed"] <= 2 * f["tiles_listed"] and seen["families+1"]["pairs_listed"] > 10_000
@@ -665,3 +668,38 @@ def test_k2_bench_matrix_rows_vs_oracle(gpu_ctx, d2g, oracle):
             np.testing.assert_array_equal(fhost[off[i]:off[i + 1]].view(np.uint32), fwant.view(np.uint32), err_msg=f"{label} row {i}")
         cs.close()
         del t_dev, out, fout
+
+
+def test_k2_sparse_give_up_is_remembered_per_set(gpu_ctx, d2g, oracle, monkeypatch):
+    """where the sparse path does not pay, the ordering that finds it out is not paid again by the next prepares of the same
+    set (CLI batches, a re-loaded matrix): the kernels that decide for the dense walk leave a word in host-visible memory, the next prepare
+    skips the ordering (retried every 16th prepare).  Results are those of the oracle either way; a family matrix loaded afterwards is
+    walked densely until the retry -- correct, only slower."""
+    import torch
+    monkeypatch.setenv("D2G_SP_LIST_DIV", "256")                       # a list of pairs / 256 entries: the adversarial matrix's N S / 2 = 288 000 do not fit, the families' few do
+    N, S = 9000, 64
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    paired = synth.paired_registers(N, S, seed=8)
+    fam = synth.synthetic_registers(N, S, nclusters=60, seed=9)
+    off = _ut_offsets(N)
+    out = torch.empty(N * (N - 1) // 2, dtype=torch.int32, device=dev)
+    t_dev = torch.from_numpy(paired.view(np.int64)).to(dev)
+    cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_BITSLICE, stream=stream)
+    seen = []
+    for step, m in enumerate([paired, paired, fam] + [fam] * 16):
+        t_dev.copy_(torch.from_numpy(m.view(np.int64)))
+        if step:
+            cs.update_dev(t_dev.data_ptr(), stream)
+        cs.eqcount_ut_dev(out.data_ptr(), 0, N, stream)
+        info = cs.sparse_info(stream)                                  # (synchronises: the word is written by now)
+        seen.append(info)
+        if step in (0, 1, 2, 18):
+            host = out.cpu().numpy().view(np.uint32)
+            for i in (0, 17, N // 2, N - 2):
+                np.testing.assert_array_equal(host[off[i]:off[i + 1]], oracle.eqcounts_rows(m.view(np.float64), i, i + 1), err_msg=f"step {step} row {i}")
+    cs.close()
+    assert seen[0]["dense_kernel_ran"] and not seen[0]["ordering_skipped"]      # the list does not fit: dense walk, found out by the ordering
+    assert seen[1]["ordering_skipped"] and seen[1]["dense_kernel_ran"]
+    assert seen[2]["ordering_skipped"] and seen[2]["dense_kernel_ran"]          # another matrix, same set: still remembered
+    assert any(not x["ordering_skipped"] and x["tiles_listed"] > 0 and not x["dense_kernel_ran"] for x in seen[3:])   # the 16th prepare tried again and found the families

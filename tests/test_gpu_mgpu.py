@@ -329,6 +329,7 @@ def test_allpairs_sparse_tiles_on_the_gathered_operand(d2g, oracle, monkeypatch,
     the dense walk behind the gate) -- every rank's whole slab against the oracle, both epilogues, twice in a row (the second step
     re-orders a re-gathered operand), and the path reported by d2g_allpairs_sparse_info."""
     monkeypatch.setenv("D2G_BS_SPARSE_MIN_N", "1")
+    monkeypatch.setenv("D2G_SP_TILE_FRAC", "1")                       # (matrices this small have few tiles: the families' share of them is large)
     rng = np.random.default_rng(N + W)
     if kind == "families":                                            # families of ~40 sketches sharing most registers, strangers otherwise
         fam = rng.integers(0, max(2, N // 40), N)
@@ -446,11 +447,11 @@ def test_bench_inprocess_rung_over_loopback(d2g, W):
     C = cfg["exchange_chunks"]
     assert len(ph["per_rank"]) == W
     for rec in ph["per_rank"]:
-        kinds = [(p[0], p[1]) for p in rec if p[0] != "order"]          # "order": only when the sparse-tile path is on at this N
+        kinds = [(p[0], p[1]) for p in rec if p[0] not in ("order", "fill")]   # "order" / "fill": only when the sparse path is on at this N
         want = [("pack", 0)] + [(k, c) for k in ("x1", "prepare", "x2", "derive") for c in range(C)] + [("pair", 0)]
         assert sorted(kinds) == sorted(want), kinds
         assert all(p[3] >= 0 and p[2] >= 0 for p in rec)
-    assert set(ph["max_over_ranks_ms"]) - {"order"} == {"pack", "x1", "prepare", "x2", "derive", "pair"}
+    assert set(ph["max_over_ranks_ms"]) - {"order", "fill"} == {"pack", "x1", "prepare", "x2", "derive", "pair"}
     assert len(line["per_rank"]) == W and sum(p["pairs"] for p in line["per_rank"]) == cfg["pairs"]
 
 
@@ -475,7 +476,7 @@ def test_allpairs_phase_times_cover_the_step(d2g, oracle):
     for r, e in enumerate(engs):
         recs = e.phase_times()
         assert [p["phase"] for p in recs][-1] == "pair" and recs[0]["phase"] == "pack"
-        assert sorted((p["phase"], p["chunk"]) for p in recs if p["phase"] != "order") == sorted([("pack", 0), ("pair", 0)] + [(k, c) for k in ("x1", "prepare", "x2", "derive") for c in range(C)])
+        assert sorted((p["phase"], p["chunk"]) for p in recs if p["phase"] not in ("order", "fill")) == sorted([("pack", 0), ("pair", 0)] + [(k, c) for k in ("x1", "prepare", "x2", "derive") for c in range(C)])
         assert all(p["ms"] >= 0 and p["start_ms"] >= 0 for p in recs)
         e.set_phase_timing(False)
         assert e.phase_times() == []
@@ -524,5 +525,5 @@ def test_bench_ranked_rungs_at_world_size_one(d2g, engine, tmp_path):
     assert line["n_gpus"] == 1 and line["value"] > 0 and "valid" not in line and "WHOLE slab equals" in line["config"]["slab_check"]
     assert line["scaling_base"]["base_1gpu_same_config_pairs_per_s"] > 0 and line["per_rank"][0]["pairs"] == N * (N - 1) // 2
     if engine == "cabi":
-        assert {p[0] for p in line["phases"]["per_rank"][0]} - {"order"} == {"pack", "x1", "prepare", "x2", "derive", "pair"}
+        assert {p[0] for p in line["phases"]["per_rank"][0]} - {"order", "fill"} == {"pack", "x1", "prepare", "x2", "derive", "pair"}
         assert line["stream_of_matrices"]["outputs_identical_to_the_one_job_step"] is True

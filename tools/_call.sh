@@ -1,5 +1,8 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/c10
-timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/c10/gpu_all.log 2>&1; tail -6 gpurun_out/c10/gpu_all.log
-D2G_BS_SPARSE_MIN_N=1 D2G_SP_TILE_FRAC=1 timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/c10/gpu_all_forced.log 2>&1; tail -6 gpurun_out/c10/gpu_all_forced.log
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/c10/bench.out 2> gpurun_out/c10/bench.err; tail -c 1500 gpurun_out/c10/bench.out; tail -3 gpurun_out/c10/bench.err
-tools/mgpu_model.sh > gpurun_out/c10/mm.log 2>&1; tail -12 gpurun_out/c10/mm.log | cut -c1-700
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/c15
+timeout 1500 python -m pytest tests/test_gpu_k2.py tests/test_gpu_mgpu.py -q -m gpu -x > gpurun_out/c15/k2.log 2>&1; tail -6 gpurun_out/c15/k2.log
+(for m in stated noise; do echo -n "$m: "; MATRIX=$m C=1 timeout 120 python tools/k2_time.py 2>&1 | grep step | cut -c1-330; done
+echo -n "stated cert=0: "; D2G_SP_CERT=0 timeout 120 python tools/k2_time.py 2>&1 | grep step | cut -c1-330
+echo -n "N=50000: "; N=50000 MATRIX=noise C=0 timeout 300 python tools/k2_time.py 2>&1 | grep step| cut -c1-330
+) > gpurun_out/c15/k2_times.txt 2>&1; cat gpurun_out/c15/k2_times.txt
+tools/kstats.sh c15_stated python $GRAFT_REPO_ROOT/tools/k2_time.py > /dev/null 2>&1; head -20 gpurun_out/c15_stated_kernel_stats.txt
+timeout 300 python tools/plist_stats.py > gpurun_out/c15/plist_stats.txt 2>&1; cat gpurun_out/c15/plist_stats.txt | cut -c1-700
