@@ -856,6 +856,152 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)pa.nwg * (64 * KS));
 }
 
+// EXPERIMENT (D2G_SP_PAIR_V2=1): the same kernel with the plane walk rebuilt around what bounds the one above -- the latency of ONE plane's
+// loads per step.  Scalar loads return out of order, so a wave cannot run two planes of row words ahead (waiting for the older means waiting
+// for both); here the row words of up to 64 planes are staged into wave-private LDS with vector loads (all in flight together) and read
+// back as broadcasts, and the column words -- vector loads, which return in order -- run FOUR planes ahead in a register ring.
+constexpr int SP2_RC = 64, SP2_D = 4;
+template <int JR, class Store>
+__global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(4))) void k2_bitslice_sparse2_kernel(SpArgs a, PairShape sh, Store store, SpPatchArgs pa) {
+    constexpr int IW = BS_IW;
+    constexpr int WC = BS_CB / (64 * JR);
+    constexpr int KS = D2G_SP_KS;
+    static_assert(JR == 2 && IW == 16, "layout of the staged row words and of the LDS reduction");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t red[IW][64];
+    __shared__ __attribute__((aligned(16))) uint32_t rows[KS][SP2_RC][IW];
+    if (sp_dense_mode(a.ctl, a.cand)) return;
+    const uint32_t xq = blockIdx.x & 7u;
+    const uint32_t nsub = a.ctl[8 + xq] * 4u;
+    const uint32_t *mytiles = a.tiles + (size_t)xq * a.tiles_cap;
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool full = a.rowstream == nullptr;
+    const int g0 = a.ntb * ks / KS, g1 = a.ntb * (ks + 1) / KS;
+    size_t slot0;
+    uint32_t nq;
+    if (a.ntb <= 64) {
+        uint32_t incl = lane < a.ntb ? (uint32_t)live_planes(a.meta, lane) : 0u;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+        const uint32_t p0 = g0 ? __shfl(incl, g0 - 1) : 0u, p1 = g1 ? __shfl(incl, g1 - 1) : 0u;
+        slot0 = __builtin_amdgcn_readfirstlane(p0);
+        nq = __builtin_amdgcn_readfirstlane(p1 - p0);
+    } else {
+        slot0 = stream_slot(a.meta, g0);
+        nq = (uint32_t)(stream_slot(a.meta, g1) - slot0);
+    }
+    for (uint32_t si = blockIdx.x >> 3; si < nsub; si += gridDim.x >> 3) {
+        const uint32_t tile = mytiles[si >> 2], sub = si & 3u;
+        const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
+        const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;
+        const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);
+        if (full && k0 > c0 + 64 * JR - 1) continue;
+        for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
+        __syncthreads();
+        uint32_t acc[IW][JR];
+#pragma unroll
+        for (int i = 0; i < IW; ++i)
+#pragma unroll
+            for (int c = 0; c < JR; ++c) acc[i][c] = 0;
+        if (nq) {
+            const size_t rstep = full ? 2 * a.Nstride : a.rstride;
+            const size_t cstep = 2 * a.Nstride;
+            const uint32_t *rp = (full ? a.stream : a.rowstream) + k0 + slot0 * rstep;
+            const uint32_t *cp = a.stream + a.Nstride + c0 + slot0 * cstep + lane;
+            uint32_t cw[SP2_D][JR];
+#pragma unroll
+            for (int d = 0; d < SP2_D; ++d)
+#pragma unroll
+                for (int c = 0; c < JR; ++c) cw[d][c] = (uint32_t)d < nq ? cp[(size_t)d * cstep + 64 * c] : 0u;
+            uint32_t z[IW][JR];
+            int tb = g0;
+            int left = live_planes(a.meta, tb);
+            int nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
+            bool first = true;
+            for (uint32_t qbase = 0; qbase < nq; qbase += SP2_RC) {
+                const uint32_t n = min((uint32_t)SP2_RC, nq - qbase);
+                {   // row words of this chunk: 16 loads per lane, all in flight, into the wave's own LDS rows
+                    uint32_t rv[IW];
+#pragma unroll
+                    for (int x = 0; x < IW; ++x) {
+                        const uint32_t idx = (uint32_t)x * 64u + (uint32_t)lane, pl = idx >> 4, w = idx & 15u;
+                        rv[x] = pl < n ? rp[(size_t)(qbase + pl) * rstep + w] : 0u;
+                    }
+#pragma unroll
+                    for (int x = 0; x < IW; ++x) { const uint32_t idx = (uint32_t)x * 64u + (uint32_t)lane; (&rows[ks][0][0])[idx] = rv[x]; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                for (uint32_t p = 0; p < n; p += SP2_D) {
+#pragma unroll
+                    for (int d = 0; d < SP2_D; ++d) {
+                        if (p + d >= n) break;
+                        const u32x4 *rr = reinterpret_cast<const u32x4 *>(&rows[ks][p + d][0]);
+                        const u32x4 r0 = rr[0], r1 = rr[1], r2 = rr[2], r3 = rr[3];
+                        const uint32_t rw[IW] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+                        uint32_t cv[JR];
+#pragma unroll
+                        for (int c = 0; c < JR; ++c) cv[c] = cw[d][c];
+                        const uint32_t qn = qbase + p + d + SP2_D;       // the plane that takes this ring slot
+#pragma unroll
+                        for (int c = 0; c < JR; ++c) cw[d][c] = qn < nq ? cp[(size_t)qn * cstep + 64 * c] : 0u;
+                        if (first) {
+#pragma unroll
+                            for (int i = 0; i < IW; ++i)
+#pragma unroll
+                                for (int c = 0; c < JR; ++c) z[i][c] = rw[i] ^ cv[c];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < IW; ++i)
+#pragma unroll
+                                for (int c = 0; c < JR; ++c) z[i][c] = __builtin_amdgcn_bitop3_b32(rw[i], cv[c], z[i][c], BITOP3_C_OR_A_XOR_B);
+                        }
+                        first = false;
+                        if (--left == 0) {
+#pragma unroll
+                            for (int i = 0; i < IW; ++i)
+#pragma unroll
+                                for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);
+                            ++tb;
+                            left = nbits_nx;
+                            nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
+                            first = true;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                           // the next chunk overwrites the rows this wave has just read
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][lane], v); }
+        __syncthreads();
+        {
+            uint32_t el = (uint32_t)lane;
+            asm volatile("" : "+v"(el));
+            uint32_t oj[JR];
+#pragma unroll
+            for (int c = 0; c < JR; ++c) oj[c] = a.sperm[c0 + el + 64 * c];
+            for (int i = ks * IW / KS; i < (ks + 1) * IW / KS; ++i) {
+                const size_t k = k0 + i;
+                const uint32_t rpos = full ? (uint32_t)k : a.rowpos[k];
+                if (rpos == SP_NONE || rpos >= a.N) continue;
+                const uint32_t oi = a.sperm[rpos];
+#pragma unroll
+                for (int c = 0; c < JR; ++c) {
+                    const uint32_t mm = (red[i][el] >> (16 * c)) & 0xFFFFu;
+                    if (mm == a.S || oj[c] == SP_NONE) continue;
+                    const bool want = full ? rpos < (uint32_t)(c0 + el + 64 * c) : oj[c] > oi;
+                    if (!want) continue;
+                    const uint32_t lo = min(oi, oj[c]), hi = max(oi, oj[c]);
+                    store.put(out_pos(sh, lo, hi), store.value_from_mismatches(a.S, mm));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)pa.nwg * (64 * KS));
+}
+
 // ---- host side
 struct SpTuning {
     bool sparse = true;                 // D2G_BS_SPARSE: 0 = every launch walks every tile
@@ -864,6 +1010,7 @@ struct SpTuning {
     int attach = 1;                     // D2G_SP_ATTACH: 0 = no second chance for sketches no column pair linked
     double tile_frac = 0.35;            // D2G_SP_TILE_FRAC: the segments may cover this fraction of all tiles before the dense walk is cheaper
     int olink = 1;                      // D2G_SP_OLINK: 0 = the table form of the link passes even where the rank kernel left an owner per value (tests: the multi-GPU engine's form)
+    int pair_v2 = 0;                    // D2G_SP_PAIR_V2: experiment -- the sparse pair kernel with LDS-staged row words and a 4-deep column ring
     int remember = 1;                   // D2G_SP_REMEMBER: 0 = every prepare runs the ordering, whatever the last one decided
     size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
     size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
@@ -877,6 +1024,7 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_SP_ATTACH")) v.attach = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_TILE_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.tile_frac = f; }
     if (const char *e = ctx->tune.get("D2G_SP_OLINK")) v.olink = std::atoi(e) != 0;
+    if (const char *e = ctx->tune.get("D2G_SP_PAIR_V2")) v.pair_v2 = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_REMEMBER")) v.remember = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
@@ -1132,7 +1280,8 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     // (exactly one resident wave of workgroups took as long as the longest list: 52 -> 85 us at config 3)
     const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * 4, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * sp_tuning(ctx).grid_mult) / 8 * 8);
     SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0, std::min<uint32_t>(grid, (uint32_t)ctx->num_cus * 8u)};
-    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
+    if (sp_tuning(ctx).pair_v2) hipLaunchKernelGGL((k2_bitslice_sparse2_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
+    else hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
     // behind the gate: every tile of the caller's-order operand in dense mode; otherwise the second step of the pair list (table epilogue)
     if (dsh.nvalid_total)
         hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
