@@ -53,6 +53,7 @@ struct d2g_cmp_set {
     uint32_t *d_owner = nullptr;      // [S][owner_stride] one holder of every shared value (rank r -> owner[r - 1]); single-partition owning sets only
     size_t owner_stride = 0;
     uint32_t *d_segend = nullptr;     // [Npad]    end of the segment of root r (the sort's scan)
+    uint32_t *d_posseg = nullptr;     // [Npad][2] (start, end) of the segment sorted position p lies in (sp_place_kernel; the sub-tile test of the pair kernel and the pair list)
     uint32_t *d_hint = nullptr;       // [2][Npad] per sketch the smallest holder of a value it shares (even / odd column pairs), 0xFFFFFFFF = none
     uint32_t *d_spz = nullptr;        // ONE block the prepare clears: the arrays below
     size_t spz_words = 0;

@@ -550,6 +550,16 @@ constexpr int BS_CB = 256;                // columns per workgroup tile (all var
 // v_bitop3_b32 truth table: src0 = 0xF0, src1 = 0xCC, src2 = 0xAA
 constexpr unsigned BITOP3_C_OR_A_XOR_B = 0xAA | (0xF0 ^ 0xCC);   // mismatch accumulation
 
+// (the pair kernel's tile shape, explained below: 16 rows per wave, JR 64-column groups per lane)
+#ifndef D2G_BS_WPE
+#define D2G_BS_WPE 7
+#endif
+#ifndef D2G_BS_JR
+#define D2G_BS_JR 2
+#endif
+constexpr int BS_IW = 16;
+constexpr int BS_JR = D2G_BS_JR;              // 64-column groups per lane: a wave owns 16 x (64*JR) pairs
+
 __device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, uint32_t cand);   // section 4
 #include "d2g_k2_patch.h"
 
@@ -570,14 +580,6 @@ __device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, 
 // Epilogue: interior tiles (every pair of the wave's 16 x 64*JR block is wanted and off the diagonal --
 // all but the ones on the triangle's edge) take a branch-free path: the row's output base is a scalar,
 // the lane adds its column, so an output costs one table gather and one store.
-#ifndef D2G_BS_WPE
-#define D2G_BS_WPE 7
-#endif
-#ifndef D2G_BS_JR
-#define D2G_BS_JR 2
-#endif
-constexpr int BS_IW = 16;
-constexpr int BS_JR = D2G_BS_JR;              // 64-column groups per lane: a wave owns 16 x (64*JR) pairs
 
 template <int JR>
 struct BsOperands {                         // the prefetched operands of one plane

@@ -12,18 +12,32 @@
 struct SpPatchArgs {
     unsigned long long *plist; const uint32_t *plctl; uint32_t plcap;
     const uint32_t *ctl; uint32_t cand;
-    const uint32_t *sinv, *rowk, *bm;     // bm: the launch's tile bitmap (full launches: over sorted row blocks; partial: over launch-row blocks)
+    const uint32_t *sinv, *rowk, *rowpos; const uint2 *posseg; uint32_t N;
+    const uint32_t *bm;                   // bm: the launch's tile bitmap (full launches: over sorted row blocks; partial: over launch-row blocks)
     uint32_t CW, r0, r1; int full;
     uint32_t nwg;                         // workgroups of the sparse pair kernel that share the entries (the others leave without looking at the list)
 };
+// A sub-tile -- BS_IW launch rows whose first and last sorted positions are pf and pl, 64 BS_JR sorted column positions from c0 -- holds a
+// pair of ONE segment only if the segment of its last row ends behind c0 and the segment of its first row starts before the sub-tile's
+// last column (segments are runs of sorted positions: their starts and ends grow with the position).  A listed tile's other sub-tiles
+// are not walked; the pair list's entries that fall into them count like those of a tile that is not listed (BOTH sides ask this function).
+__device__ __forceinline__ bool sp_sub_empty(const uint2 *__restrict__ posseg, uint32_t pf, uint32_t pl, uint32_t c0) {
+    return posseg[pl].y <= c0 || posseg[pf].x >= c0 + 64u * BS_JR;
+}
 constexpr unsigned long long SP_LEADER = 0x80000000ull;               // in the low word of an entry (i < 2^30: d2g_bitslice_alloc refuses larger N)
 __device__ __forceinline__ bool sp_entry_wanted(const SpPatchArgs &a, uint32_t i, uint32_t j) {
     if (i < a.r0 || i >= a.r1) return false;
     const uint32_t pi = a.sinv[i], pj = a.sinv[j];
-    uint32_t rb, cpos;
-    if (a.full) { rb = min(pi, pj) >> 5; cpos = max(pi, pj); }
-    else { rb = a.rowk[i] >> 5; cpos = pj; }
-    return !((a.bm[(size_t)rb * a.CW + (cpos >> 13)] >> ((cpos >> 8) & 31)) & 1u);
+    uint32_t k, cpos;                                                  // launch row, sorted column position
+    if (a.full) { k = min(pi, pj); cpos = max(pi, pj); }
+    else { k = a.rowk[i]; cpos = pj; }
+    if (!((a.bm[(size_t)(k >> 5) * a.CW + (cpos >> 13)] >> ((cpos >> 8) & 31)) & 1u)) return true;
+    // a listed tile: computed exactly -- but for the sub-tiles the pair kernel skips
+    const uint32_t k0 = k & ~(uint32_t)(BS_IW - 1), c0 = cpos & ~(64u * BS_JR - 1u);
+    uint32_t pf, pl;
+    if (a.full) { pf = k0; pl = min(k0 + (uint32_t)BS_IW - 1u, a.N - 1u); }
+    else { pf = a.rowpos[k0]; pl = a.rowpos[k0 + BS_IW - 1]; if (pl == 0xFFFFFFFFu) return false; }   // (the launch's last rows: walked)
+    return sp_sub_empty(a.posseg, pf, pl, c0);
 }
 template <class Store> struct SpStoreTraits;
 template <> struct SpStoreTraits<StoreEq> { static constexpr bool kLeader = false; };

@@ -366,7 +366,8 @@ __device__ __forceinline__ void sp_segtiles(uint32_t a, uint32_t b, uint32_t CW,
 }
 __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
                                                         uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order,
-                                                        const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, uint32_t CW, uint32_t *__restrict__ gbm) {
+                                                        const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, uint32_t CW, uint32_t *__restrict__ gbm,
+                                                        uint2 *__restrict__ posseg) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = j < N;
     if (!live && j < Nstride) sperm[j] = SP_NONE;
@@ -386,31 +387,37 @@ __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restric
     base = __shfl(base, first);
     if (live && r == lead) p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
     else if (live) p = atomicAdd(&cnt[r], 1u);
-    if (live) { sperm[p] = (uint32_t)j; sinv[j] = p; }
+    if (live) { sperm[p] = (uint32_t)j; sinv[j] = p; posseg[p] = uint2{seg_start[r], seg_end[r]}; }
 }
 
 // (b): every shared value of every column; the pairs of its holders that lie in different segments go to the pair list.  One workgroup
-// per column; the column's shared values are walked in ranges of at most `vcap` ranks:
-//   pass A  first[r] = segment of the first holder of value r (compare-and-swap); another segment among its holders marks r MIXED.
-//           A range without a mixed value -- every clean family column -- is done after this pass.
-//   pass B  the holders of mixed values become entries (sketch, segment, next) of per-value chains in LDS (first[] turns into the
-//           chains' heads).  More than `ecap` entries: the range is halved and walked again.
-//   pass C  an entry pairs with every later entry of its chain that lies in another segment: counted, one reservation per workgroup and
-//           range in the global list, written.  A list that is full raises order[0] (dense walk): the list is then longer than a quarter
-//           of all pairs -- not a sparse matrix.
+// per column; the column's shared values are walked in ranges of at most vcap ranks (2048; 1024 from N = 65 536 on, where the two
+// holder counts of a value no longer fit one word):
+//   pass A  first[q] = segment of the first holder of value q (compare-and-swap); every holder counts itself as INSIDE that segment
+//           or OUTSIDE it.  A value with an outsider is MIXED.  A range without a mixed value -- every clean family column -- is done
+//           after this pass.
+//   scan    the mixed values get consecutive places for their holders: insiders first, outsiders behind them (counts known from pass
+//           A: a range whose entries will not fit is halved BEFORE anything is placed).
+//   pass B  the holders of mixed values are placed: (sketch, segment) at the value's cursors.
+//   pairs   only an OUTSIDER has work: it pairs with every insider of its value (no comparison: they differ by construction) and with
+//           the later outsiders of another segment.  Counted, one reservation per workgroup and range in the global list, written.
+//           (Round 5's first form chained the holders of a value in LDS and let every entry walk the chain behind it: 150 dependent LDS
+//           loads per thread for a family of 150 and one stranger, walked twice -- 25-30 us for ANY column with one mixed value.)
+// A list that is full raises order[0] (dense walk): the list is then longer than a sixteenth of all pairs -- not a sparse matrix.
 // A list that will not fit is noticed EARLY: every workgroup adds its column's pair count to plctl[2] and bumps plctl[3]; once 32
 // columns are in, (pairs so far / columns so far) x columns > 1.5 x capacity raises order[0] and everybody stops at its next range.
-constexpr uint32_t SP_EMIT_VCAP = 2048, SP_EMIT_ECAP = 2048, SP_EMIT_T = 512;      // 32 KB of LDS: four workgroups per CU
-__global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
+constexpr uint32_t SP_EMIT_VCAP = 2048, SP_EMIT_ECAP = 2048, SP_EMIT_T = 512;      // 36 KB of LDS: four workgroups per CU
+__global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
                                                             const uint32_t *__restrict__ seg, uint32_t *__restrict__ order,
-                                                            unsigned long long *__restrict__ plist, uint32_t *__restrict__ plctl, uint32_t plcap, uint32_t *__restrict__ gaveup) {
+                                                            unsigned long long *__restrict__ plist, uint32_t *__restrict__ plctl, uint32_t plcap, uint32_t *__restrict__ gaveup, int big) {
     __shared__ uint32_t first[SP_EMIT_VCAP];
-    __shared__ uint32_t mixed[SP_EMIT_VCAP / 32];
-    __shared__ uint32_t ej[SP_EMIT_ECAP], eseg[SP_EMIT_ECAP], enext[SP_EMIT_ECAP];
+    __shared__ uint32_t cnt[SP_EMIT_VCAP];                // pass A: insiders | outsiders << 16 (big: [q] and [1024 + q]); then the two cursors
+    __shared__ uint32_t mrec[SP_EMIT_ECAP / 2 + 1];       // the range's mixed values: first entry | q << 16 (a mixed value has two entries at least)
+    __shared__ uint32_t ej[SP_EMIT_ECAP], eseg[SP_EMIT_ECAP];
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t s_nent, s_any, s_base, s_stop;
+    __shared__ uint32_t s_base, s_stop;
     if (order[0]) return;
-    constexpr uint32_t T = SP_EMIT_T;
+    constexpr uint32_t T = SP_EMIT_T, PER = SP_EMIT_VCAP / T, EPER = SP_EMIT_ECAP / T;
     const uint32_t tid = threadIdx.x;
     const size_t t = blockIdx.x;
     const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
@@ -431,48 +438,89 @@ __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__re
             for (int x = 0; x < 8; ++x) { const uint32_t r = sp_rank(w[x], colcnt, t, split != 0); if (r) fn(r, sg[x], (uint32_t)(j0 + (size_t)x * T + tid)); }
         }
     };
-    uint32_t curlen = SP_EMIT_VCAP, colpairs = 0;
+    const uint32_t vcap = big ? SP_EMIT_VCAP / 2 : SP_EMIT_VCAP;
+    uint32_t curlen = vcap, colpairs = 0;
     bool voted = false;
     for (uint32_t lo = 0; lo < d2;) {
         const uint32_t len = min(curlen, d2 - lo);
-        for (uint32_t x = tid; x < len; x += T) first[x] = SP_NONE;
-        for (uint32_t x = tid; x < (len + 31) / 32; x += T) mixed[x] = 0;
-        if (tid == 0) { s_nent = 0; s_any = 0; s_stop = sp_ld(&order[0]); }
+        for (uint32_t x = tid; x < SP_EMIT_VCAP; x += T) { first[x] = SP_NONE; cnt[x] = 0; }
+        if (tid == 0) s_stop = sp_ld(&order[0]);
         __syncthreads();
         if (s_stop) return;                                           // somebody found that the list will not fit
         for_each_holder([&](uint32_t r, uint32_t sgv, uint32_t) {
             if (r <= lo || r > lo + len) return;
-            const uint32_t old = atomicCAS(&first[r - 1 - lo], SP_NONE, sgv);
-            if (old != SP_NONE && old != sgv) { atomicOr(&mixed[(r - 1 - lo) >> 5], 1u << ((r - 1 - lo) & 31)); s_any = 1; }
+            const uint32_t q = r - 1 - lo;
+            const uint32_t old = atomicCAS(&first[q], SP_NONE, sgv);
+            const bool outside = old != SP_NONE && old != sgv;
+            if (big) atomicAdd(&cnt[outside ? SP_EMIT_VCAP / 2 + q : q], 1u);
+            else atomicAdd(&cnt[q], outside ? 0x10000u : 1u);
         });
         __syncthreads();
-        if (!s_any) { lo += len; continue; }                          // (uniform: read by everybody after the barrier, reset behind the next one)
-        for (uint32_t x = tid; x < len; x += T) first[x] = SP_NONE;   // now the chains' heads
+        // a thread's PER values: entries and mixed values, one packed scan (the sums are exact whenever the entries fit: a thread's entry
+        // count is clamped to ECAP + 1, 512 of those stay below 2^21; the 11 bits above count the mixed values -- 2048 of them wrap, with
+        // 4096 entries)
+        uint32_t n0[PER], nO[PER], ve = 0, vm = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < PER; ++x) {
+            const uint32_t q = tid * PER + x;
+            const uint32_t c = q < len ? cnt[q] : 0u;
+            n0[x] = big ? c : (c & 0xFFFFu);
+            nO[x] = q < len ? (big ? cnt[SP_EMIT_VCAP / 2 + q] : (c >> 16)) : 0u;
+            if (nO[x]) { ve = min(ve + min(n0[x], SP_EMIT_ECAP + 1u) + min(nO[x], SP_EMIT_ECAP + 1u), SP_EMIT_ECAP + 1u); ++vm; }
+        }
+        uint32_t total;
+        const uint32_t pre = sp_block_scan<T / 64>(ve | (vm << 21), wave_tot, &total);
+        const uint32_t nent = total & 0x1FFFFFu, nm = total >> 21;
+        if (nent == 0) { __syncthreads(); lo += len; continue; }      // (uniform; the barrier: wave_tot is written again by the next range's scan)
+        if (nent > SP_EMIT_ECAP) {
+            if (len == 1) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }     // ONE value with thousands of holders spread over segments: not sparse
+            // the holders that do not fit are a lower bound of what is still to come: (h - 1) pairs at least for h holders of one value
+            if (tid == 0 && (size_t)nent * ncols > (size_t)plcap * 8) { order[0] = 1; *gaveup = 1; }
+            curlen = len / 2;
+            __syncthreads();
+            continue;
+        }
+        {
+            uint32_t eoff = pre & 0x1FFFFFu, moff = pre >> 21;
+#pragma unroll
+            for (uint32_t x = 0; x < PER; ++x) {
+                const uint32_t q = tid * PER + x;
+                if (q >= len) continue;
+                if (!nO[x]) { cnt[q] = SP_NONE; continue; }           // (no cursor word looks like this: positions stay below 2049)
+                mrec[moff++] = eoff | (q << 16);
+                cnt[q] = eoff | ((eoff + n0[x]) << 16);
+                eoff += n0[x] + nO[x];
+            }
+        }
         __syncthreads();
         for_each_holder([&](uint32_t r, uint32_t sgv, uint32_t j) {
             if (r <= lo || r > lo + len) return;
             const uint32_t q = r - 1 - lo;
-            if (!((mixed[q >> 5] >> (q & 31)) & 1u)) return;
-            const uint32_t k = atomicAdd(&s_nent, 1u);
-            if (k < SP_EMIT_ECAP) { ej[k] = j; eseg[k] = sgv; enext[k] = atomicExch(&first[q], k); }
+            if (cnt[q] == SP_NONE) return;
+            const bool inside = first[q] == sgv;
+            const uint32_t old = atomicAdd(&cnt[q], inside ? 1u : 0x10000u);
+            const uint32_t pos = inside ? (old & 0xFFFFu) : (old >> 16);
+            ej[pos] = j; eseg[pos] = sgv;
         });
         __syncthreads();
-        const uint32_t nent = s_nent;
-        if (nent > SP_EMIT_ECAP) {
-            __syncthreads();                                          // (everybody has read s_nent before it is reset)
-            if (len == 1) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }     // ONE value with thousands of holders spread over segments: not sparse
-            // the holders that did not fit are a lower bound of what is still to come: (h - 1) pairs at least for h holders of one value
-            if (tid == 0 && (size_t)nent * ncols > (size_t)plcap * 8) { order[0] = 1; *gaveup = 1; }
-            curlen = len / 2;
-            continue;
-        }
-        // a chain is walked from an entry towards the entries inserted before it: every unordered pair of a chain is seen once
-        uint32_t mine = 0;
-        for (uint32_t k = tid; k < nent; k += T) {
+        // the outsiders among this thread's entries: (start, mid, end) of their value and the number of their pairs
+        uint32_t est[EPER], emid[EPER], eend[EPER], mine = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < EPER; ++x) {
+            const uint32_t k = tid + x * T;
+            est[x] = emid[x] = eend[x] = 0;
+            if (k >= nent) continue;
+            uint32_t a = 0, b = nm;                                   // the last mixed value that starts at or before k
+            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if ((mrec[m] & 0xFFFFu) <= k) a = m; else b = m; }
+            const uint32_t rec = mrec[a], c = cnt[rec >> 16];
+            const uint32_t mid = c & 0xFFFFu, end = c >> 16;
+            if (k < mid) continue;                                    // an insider
+            est[x] = rec & 0xFFFFu; emid[x] = mid; eend[x] = end;
+            uint32_t np = mid - est[x];
             const uint32_t s = eseg[k];
-            for (uint32_t e = enext[k]; e != SP_NONE; e = enext[e]) mine += eseg[e] != s;
+            for (uint32_t e = k + 1; e < end; ++e) np += eseg[e] != s;
+            mine += np;
         }
-        uint32_t total;
         uint32_t off = sp_block_scan<T / 64>(mine, wave_tot, &total);
         if (tid == 0) s_base = total ? atomicAdd(&plctl[0], total) : 0u;
         __syncthreads();
@@ -481,9 +529,15 @@ __global__ __launch_bounds__(SP_EMIT_T) void sp_emit_kernel(const uint32_t *__re
             if ((size_t)base + total > plcap) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }
             colpairs += total;
             off += base;
-            for (uint32_t k = tid; k < nent; k += T) {
-                const uint32_t s = eseg[k], a = ej[k];
-                for (uint32_t e = enext[k]; e != SP_NONE; e = enext[e]) {
+#pragma unroll
+            for (uint32_t x = 0; x < EPER; ++x) {
+                if (eend[x] == 0) continue;
+                const uint32_t k = tid + x * T, s = eseg[k], a = ej[k];
+                for (uint32_t e = est[x]; e < emid[x]; ++e) {
+                    const uint32_t b = ej[e];
+                    plist[off++] = (unsigned long long)min(a, b) | ((unsigned long long)max(a, b) << 32);
+                }
+                for (uint32_t e = k + 1; e < eend[x]; ++e) {
                     if (eseg[e] == s) continue;
                     const uint32_t b = ej[e];
                     plist[off++] = (unsigned long long)min(a, b) | ((unsigned long long)max(a, b) << 32);
@@ -762,6 +816,7 @@ struct SpArgs {
     uint32_t S, N;
     const uint32_t *sperm, *rowpos, *tiles, *ctl;
     uint32_t ncb, cand, tiles_cap;
+    const uint2 *posseg;          // (start, end) of the segment of every sorted position
 };
 
 // The sparse pair kernel.  A listed tile (32 launch rows x 256 sorted columns) is four 16 x 128 sub-tiles; a workgroup takes ONE
@@ -801,6 +856,12 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
         const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
         if (full && k0 > c0 + 64 * JR - 1) continue;                             // entirely below the diagonal of sorted positions (uniform for the workgroup)
+        {   // no row, or no pair of one segment in it (all uniform): the pair list has what the sub-tile holds (sp_entry_wanted asks the same)
+            const uint32_t pf = full ? (uint32_t)k0 : a.rowpos[k0];
+            if (pf == SP_NONE || pf >= a.N) continue;
+            const uint32_t pl = full ? min((uint32_t)k0 + IW - 1u, a.N - 1u) : a.rowpos[k0 + IW - 1];
+            if (pl != SP_NONE && sp_sub_empty(a.posseg, pf, pl, (uint32_t)c0)) continue;
+        }
         for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
         __syncthreads();
         uint32_t acc[IW][JR];
@@ -856,151 +917,9 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)pa.nwg * (64 * KS));
 }
 
-// EXPERIMENT (D2G_SP_PAIR_V2=1): the same kernel with the plane walk rebuilt around what bounds the one above -- the latency of ONE plane's
-// loads per step.  Scalar loads return out of order, so a wave cannot run two planes of row words ahead (waiting for the older means waiting
-// for both); here the row words of up to 64 planes are staged into wave-private LDS with vector loads (all in flight together) and read
-// back as broadcasts, and the column words -- vector loads, which return in order -- run FOUR planes ahead in a register ring.
-constexpr int SP2_RC = 64, SP2_D = 4;
-template <int JR, class Store>
-__global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(4))) void k2_bitslice_sparse2_kernel(SpArgs a, PairShape sh, Store store, SpPatchArgs pa) {
-    constexpr int IW = BS_IW;
-    constexpr int WC = BS_CB / (64 * JR);
-    constexpr int KS = D2G_SP_KS;
-    static_assert(JR == 2 && IW == 16, "layout of the staged row words and of the LDS reduction");
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t red[IW][64];
-    __shared__ __attribute__((aligned(16))) uint32_t rows[KS][SP2_RC][IW];
-    if (sp_dense_mode(a.ctl, a.cand)) return;
-    const uint32_t xq = blockIdx.x & 7u;
-    const uint32_t nsub = a.ctl[8 + xq] * 4u;
-    const uint32_t *mytiles = a.tiles + (size_t)xq * a.tiles_cap;
-    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const bool full = a.rowstream == nullptr;
-    const int g0 = a.ntb * ks / KS, g1 = a.ntb * (ks + 1) / KS;
-    size_t slot0;
-    uint32_t nq;
-    if (a.ntb <= 64) {
-        uint32_t incl = lane < a.ntb ? (uint32_t)live_planes(a.meta, lane) : 0u;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
-        const uint32_t p0 = g0 ? __shfl(incl, g0 - 1) : 0u, p1 = g1 ? __shfl(incl, g1 - 1) : 0u;
-        slot0 = __builtin_amdgcn_readfirstlane(p0);
-        nq = __builtin_amdgcn_readfirstlane(p1 - p0);
-    } else {
-        slot0 = stream_slot(a.meta, g0);
-        nq = (uint32_t)(stream_slot(a.meta, g1) - slot0);
-    }
-    for (uint32_t si = blockIdx.x >> 3; si < nsub; si += gridDim.x >> 3) {
-        const uint32_t tile = mytiles[si >> 2], sub = si & 3u;
-        const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
-        const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;
-        const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);
-        if (full && k0 > c0 + 64 * JR - 1) continue;
-        for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
-        __syncthreads();
-        uint32_t acc[IW][JR];
-#pragma unroll
-        for (int i = 0; i < IW; ++i)
-#pragma unroll
-            for (int c = 0; c < JR; ++c) acc[i][c] = 0;
-        if (nq) {
-            const size_t rstep = full ? 2 * a.Nstride : a.rstride;
-            const size_t cstep = 2 * a.Nstride;
-            const uint32_t *rp = (full ? a.stream : a.rowstream) + k0 + slot0 * rstep;
-            const uint32_t *cp = a.stream + a.Nstride + c0 + slot0 * cstep + lane;
-            uint32_t cw[SP2_D][JR];
-#pragma unroll
-            for (int d = 0; d < SP2_D; ++d)
-#pragma unroll
-                for (int c = 0; c < JR; ++c) cw[d][c] = (uint32_t)d < nq ? cp[(size_t)d * cstep + 64 * c] : 0u;
-            uint32_t z[IW][JR];
-            int tb = g0;
-            int left = live_planes(a.meta, tb);
-            int nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
-            bool first = true;
-            for (uint32_t qbase = 0; qbase < nq; qbase += SP2_RC) {
-                const uint32_t n = min((uint32_t)SP2_RC, nq - qbase);
-                {   // row words of this chunk: 16 loads per lane, all in flight, into the wave's own LDS rows
-                    uint32_t rv[IW];
-#pragma unroll
-                    for (int x = 0; x < IW; ++x) {
-                        const uint32_t idx = (uint32_t)x * 64u + (uint32_t)lane, pl = idx >> 4, w = idx & 15u;
-                        rv[x] = pl < n ? rp[(size_t)(qbase + pl) * rstep + w] : 0u;
-                    }
-#pragma unroll
-                    for (int x = 0; x < IW; ++x) { const uint32_t idx = (uint32_t)x * 64u + (uint32_t)lane; (&rows[ks][0][0])[idx] = rv[x]; }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                for (uint32_t p = 0; p < n; p += SP2_D) {
-#pragma unroll
-                    for (int d = 0; d < SP2_D; ++d) {
-                        if (p + d >= n) break;
-                        const u32x4 *rr = reinterpret_cast<const u32x4 *>(&rows[ks][p + d][0]);
-                        const u32x4 r0 = rr[0], r1 = rr[1], r2 = rr[2], r3 = rr[3];
-                        const uint32_t rw[IW] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
-                        uint32_t cv[JR];
-#pragma unroll
-                        for (int c = 0; c < JR; ++c) cv[c] = cw[d][c];
-                        const uint32_t qn = qbase + p + d + SP2_D;       // the plane that takes this ring slot
-#pragma unroll
-                        for (int c = 0; c < JR; ++c) cw[d][c] = qn < nq ? cp[(size_t)qn * cstep + 64 * c] : 0u;
-                        if (first) {
-#pragma unroll
-                            for (int i = 0; i < IW; ++i)
-#pragma unroll
-                                for (int c = 0; c < JR; ++c) z[i][c] = rw[i] ^ cv[c];
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < IW; ++i)
-#pragma unroll
-                                for (int c = 0; c < JR; ++c) z[i][c] = __builtin_amdgcn_bitop3_b32(rw[i], cv[c], z[i][c], BITOP3_C_OR_A_XOR_B);
-                        }
-                        first = false;
-                        if (--left == 0) {
-#pragma unroll
-                            for (int i = 0; i < IW; ++i)
-#pragma unroll
-                                for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);
-                            ++tb;
-                            left = nbits_nx;
-                            nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
-                            first = true;
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();                           // the next chunk overwrites the rows this wave has just read
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][lane], v); }
-        __syncthreads();
-        {
-            uint32_t el = (uint32_t)lane;
-            asm volatile("" : "+v"(el));
-            uint32_t oj[JR];
-#pragma unroll
-            for (int c = 0; c < JR; ++c) oj[c] = a.sperm[c0 + el + 64 * c];
-            for (int i = ks * IW / KS; i < (ks + 1) * IW / KS; ++i) {
-                const size_t k = k0 + i;
-                const uint32_t rpos = full ? (uint32_t)k : a.rowpos[k];
-                if (rpos == SP_NONE || rpos >= a.N) continue;
-                const uint32_t oi = a.sperm[rpos];
-#pragma unroll
-                for (int c = 0; c < JR; ++c) {
-                    const uint32_t mm = (red[i][el] >> (16 * c)) & 0xFFFFu;
-                    if (mm == a.S || oj[c] == SP_NONE) continue;
-                    const bool want = full ? rpos < (uint32_t)(c0 + el + 64 * c) : oj[c] > oi;
-                    if (!want) continue;
-                    const uint32_t lo = min(oi, oj[c]), hi = max(oi, oj[c]);
-                    store.put(out_pos(sh, lo, hi), store.value_from_mismatches(a.S, mm));
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)pa.nwg * (64 * KS));
-}
+// (measured in round 5 and dropped: the same kernel with the row words of a sub-tile staged through LDS and a 4-deep ring of column
+// words per wave -- 128 VGPRs, 20 KB of LDS, waves_per_eu 4 -- to get more plane loads in flight: 53.9 vs 53.8 us at config 3, 329 vs
+// 297 us at N = 50 000)
 
 // ---- host side
 struct SpTuning {
@@ -1010,7 +929,7 @@ struct SpTuning {
     int attach = 1;                     // D2G_SP_ATTACH: 0 = no second chance for sketches no column pair linked
     double tile_frac = 0.35;            // D2G_SP_TILE_FRAC: the segments may cover this fraction of all tiles before the dense walk is cheaper
     int olink = 1;                      // D2G_SP_OLINK: 0 = the table form of the link passes even where the rank kernel left an owner per value (tests: the multi-GPU engine's form)
-    int pair_v2 = 0;                    // D2G_SP_PAIR_V2: experiment -- the sparse pair kernel with LDS-staged row words and a 4-deep column ring
+    int emit_big = 0;                   // D2G_SP_EMIT_BIG: sp_emit_kernel counts with two words per value at every N (it does from N = 65 536 on; tests)
     int remember = 1;                   // D2G_SP_REMEMBER: 0 = every prepare runs the ordering, whatever the last one decided
     size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
     size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
@@ -1024,7 +943,7 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_SP_ATTACH")) v.attach = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_TILE_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.tile_frac = f; }
     if (const char *e = ctx->tune.get("D2G_SP_OLINK")) v.olink = std::atoi(e) != 0;
-    if (const char *e = ctx->tune.get("D2G_SP_PAIR_V2")) v.pair_v2 = std::atoi(e) != 0;
+    if (const char *e = ctx->tune.get("D2G_SP_EMIT_BIG")) v.emit_big = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_REMEMBER")) v.remember = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
@@ -1056,6 +975,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMalloc((void **)&set->d_label, 2 * Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_hint, 2 * Npad * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_segend, Npad * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_posseg, Npad * 8)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_spz, set->spz_words * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowpos, Nstride * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_rowk, Npad * 4)) != hipSuccess ||
@@ -1081,7 +1001,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 }
 
 void sp_free(d2g_cmp_set *set) {
-    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_hint, &set->d_segend, &set->d_spz, &set->d_rowpos, &set->d_rowk,
+    for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_hint, &set->d_segend, &set->d_posseg, &set->d_spz, &set->d_rowpos, &set->d_rowk,
                          &set->d_rowstream, &set->d_tiles, &set->d_tiles_full, &set->d_spctl}) { (void)hipFree(*p); *p = nullptr; }
     (void)hipFree(set->d_plist); set->d_plist = nullptr;
     if (set->h_gaveup) { (void)hipHostFree(set->h_gaveup); set->h_gaveup = nullptr; }
@@ -1158,12 +1078,12 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
     const uint32_t CW = (uint32_t)((Npad / BS_CB + 31) / 32);
     hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, set->d_segend, seg_limit, set->d_gaveup);    // la (labels) is dead after the count kernel: it keeps the segment starts
     hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order,
-                       la, set->d_segend, CW, set->d_gbm + 8);
+                       la, set->d_segend, CW, set->d_gbm + 8, reinterpret_cast<uint2 *>(set->d_posseg));
     // (a certificate pass in front -- one thread per (column, sketch) comparing the sketch's segment with that of its value's owner, so that
     // columns where nothing crosses a segment need no workgroup here -- was measured: 17 us for the pass, and the 17 stragglers a clean
     // collection of 10 000 leaves still put a mixed value into a hundred columns, whose workgroups take as long as before: 0.338 vs 0.329 ms)
     hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)S), dim3(SP_EMIT_T), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, lb, set->d_order,
-                       set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), set->d_gaveup);
+                       set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), set->d_gaveup, (N >= 65536 || tu.emit_big) ? 1 : 0);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
@@ -1266,7 +1186,7 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
         hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, bm, nrb, ncb, CW, full ? 1 : 0,
                            tiles, (uint32_t)set->tiles_cap, ctl, cand32, set->d_order, ctl_next);
     SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
-             set->d_sperm, set->d_rowpos, tiles, ctl, ncb, cand32, (uint32_t)set->tiles_cap};
+             set->d_sperm, set->d_rowpos, tiles, ctl, ncb, cand32, (uint32_t)set->tiles_cap, reinterpret_cast<const uint2 *>(set->d_posseg)};
     // contiguous 32 KB per workgroup, workgroups in dispatch order: a streaming write (6.1 TB/s at N = 50 000: 825 us; the grid-stride loop over 16
     // workgroups per CU it replaces, whose iterations lie 16 MB apart, reached 4.6: 1105 us).  One store per thread is faster still (722-760 us) but when
     // the launch turns out dense all of its 19 M waves start only to return: 254 us instead of 34
@@ -1279,9 +1199,8 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     // length, and a workgroup that finds nothing at its index leaves at once -- the dispatcher evens the lists out sub-tile by sub-tile
     // (exactly one resident wave of workgroups took as long as the longest list: 52 -> 85 us at config 3)
     const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * 4, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * sp_tuning(ctx).grid_mult) / 8 * 8);
-    SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0, std::min<uint32_t>(grid, (uint32_t)ctx->num_cus * 8u)};
-    if (sp_tuning(ctx).pair_v2) hipLaunchKernelGGL((k2_bitslice_sparse2_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
-    else hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
+    SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, set->d_rowpos, reinterpret_cast<const uint2 *>(set->d_posseg), (uint32_t)N, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0, std::min<uint32_t>(grid, (uint32_t)ctx->num_cus * 8u)};
+    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
     // behind the gate: every tile of the caller's-order operand in dense mode; otherwise the second step of the pair list (table epilogue)
     if (dsh.nvalid_total)
         hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,

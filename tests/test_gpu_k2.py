@@ -527,7 +527,7 @@ def _ut_offsets(N):
     return np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
 
 
-@pytest.mark.parametrize("variant", ["default", "table_link", "no_link", "no_attach", "short_list"])
+@pytest.mark.parametrize("variant", ["default", "table_link", "no_link", "no_attach", "short_list", "emit_big"])
 def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gpu_ctx, d2g, oracle, monkeypatch, variant):
     """Round 5: from 8192 sketches on, an upper-triangle launch on a bit-sliced set fills the output with the value of "0 equal", walks
     only the tiles of the FAMILIES the prepare found (sketches that agree in many registers) and adds a list of the pairs of different
@@ -537,7 +537,7 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
     no families, the pair list alone), skewed columns (one family: dense walk), unrelated sketches (the fill alone), chains whose
     neighbours share one register (pair list), one chain of N; whole triangle and row ranges, counts and the fused float epilogue; a
     set RE-LOADED with another matrix.  Variants: no families at all (D2G_SP_LINK=0), no attach step, a pair list of pairs / 4096
-    entries (overflow -> dense walk)."""
+    entries (overflow -> dense walk), the pair-list kernel with two count words per value."""
     import torch
     monkeypatch.setenv("D2G_SP_REMEMBER", "0")                         # nine different matrices through ONE set: every prepare decides afresh
     if variant == "table_link":                                        # the form the multi-GPU engine's gathered operand takes: tables in LDS
@@ -549,6 +549,8 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
         monkeypatch.setenv("D2G_SP_ATTACH", "0")
     elif variant == "short_list":
         monkeypatch.setenv("D2G_SP_LIST_DIV", "4096")
+    elif variant == "emit_big":                                        # the pair list's kernel in the form it takes from 65 536 sketches on
+        monkeypatch.setenv("D2G_SP_EMIT_BIG", "1")
     N, S = 12_000, 96
     rng = np.random.default_rng(11)
     chains = rng.random((N, S))
@@ -618,7 +620,7 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
         assert f["tiles_listed"] == 0 and f["pairs_listed"] > 100_000                           # every equal register pair of the matrix is a list entry
     elif variant != "short_list":
         assert f["tiles_listed"] > 0
-    if variant in ("default", "table_link"):
+    if variant in ("default", "table_link", "emit_big"):
         # ten chance collisions per sketch used to list every tile; now the families keep their tiles and the strangers go to the list
         # (S = 96: one collision per sketch is 1 % of the registers, ten are 10 % -- heavy noise at this sketch size)
         assert 0 < seen["families+1"]["tiles_listed"] <= 2 * f["tiles_listed"] and seen["families+1"]["pairs_listed"] > 10_000

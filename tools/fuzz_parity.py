@@ -92,7 +92,7 @@ def main():
                 # sparse tiles + pair list (round 5): forced on for these small matrices half of the time -- families found or not
                 # (D2G_SP_LINK=0: the pair list alone), with or without the attach step, any tile budget, a short list (overflow ->
                 # dense walk); the other half takes the default (dense walk below 8192 sketches)
-                for var in ("D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_OLINK", "D2G_SP_REMEMBER"):
+                for var in ("D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_OLINK", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG"):
                     os.environ.pop(var, None)
                 if rng.random() < 0.5:
                     os.environ["D2G_BS_SPARSE_MIN_N"] = "1"
@@ -105,6 +105,8 @@ def main():
                         os.environ["D2G_SP_LIST_DIV"] = str(int(rng.choice([1, 64, 4096])))
                     if rng.random() < 0.3:
                         os.environ["D2G_SP_OLINK"] = "0"                                      # the link passes in their table form
+                    if rng.random() < 0.3:
+                        os.environ["D2G_SP_EMIT_BIG"] = "1"                                   # the pair-list kernel's form for N >= 65 536
                     os.environ["D2G_SP_REMEMBER"] = "0"                                       # one-shot sets: every prepare decides afresh
                 ctx.reload_tuning()
                 r = rng.random()
