@@ -62,6 +62,11 @@ __device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
 // bs_planes_kernel adds the offset of split h (the shared values the splits before it found: colcnt[t][h] after
 // bs_colplan_kernel).  A column slice of N = 50 000 sketches x 64 registers -- one chunk of one rank of the 8-GPU
 // exchange -- is 64 workgroups of one per CU otherwise: a quarter of the chip.
+// (Measured in round 5 and dropped: a MULTI kernel that reads the column ONCE -- a thread keeps the high word of v * K of its <= 49 values
+// in registers, every partition pass claims / confirms / ranks from them and writes final ids, no pending words -- for N <= 50 176.
+// 128 VGPRs with ~320 spills, and the confirm step still fetches one owner value per candidate, four candidates in flight per thread:
+// 2.58 ms instead of 1.04 at N = 50 000, 1.00 instead of 0.36 at N = 30 000.  What bounds this kernel at that size is not the repeated
+// column read but the ~N gathers of 8 bytes per column that decide equality against the owner's value (51 million 64-byte sectors).)
 constexpr uint32_t BS_SPLIT_SHIFT = 28, BS_RANK_MASK = (1u << BS_SPLIT_SHIFT) - 1u;
 template <bool MULTI, bool FAST>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
