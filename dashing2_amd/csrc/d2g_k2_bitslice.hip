@@ -66,7 +66,11 @@ __device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
 // in registers, every partition pass claims / confirms / ranks from them and writes final ids, no pending words -- for N <= 50 176.
 // 128 VGPRs with ~320 spills, and the confirm step still fetches one owner value per candidate, four candidates in flight per thread:
 // 2.58 ms instead of 1.04 at N = 50 000, 1.00 instead of 0.36 at N = 30 000.  What bounds this kernel at that size is not the repeated
-// column read but the ~N gathers of 8 bytes per column that decide equality against the owner's value (51 million 64-byte sectors).)
+// column read but the ~N gathers of 8 bytes per column that decide equality against the owner's value (51 million 64-byte sectors).
+// Also measured and dropped: the values of a pass's partition COMPACTED into a queue in the LDS behind the table (block scan of the
+// per-thread counts, 2560 entries of (value, sketch)) so that claim / confirm run with every lane busy instead of under an execution
+// mask -- correct (all K2 / multi-GPU tests), 1.08 ms instead of 1.04 at N = 50 000, 0.43 instead of 0.36 at N = 30 000: the scan, the
+// queue traffic and four more barriers per batch cost what the idle lanes had cost.)
 constexpr uint32_t BS_SPLIT_SHIFT = 28, BS_RANK_MASK = (1u << BS_SPLIT_SHIFT) - 1u;
 template <bool MULTI, bool FAST>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,

@@ -509,6 +509,28 @@ def test_k2_split_rank_kernel(gpu_ctx, d2g, monkeypatch, N, S, nsplit):
     ref.close()
 
 
+@pytest.mark.parametrize("nsplit", ["1", "2"])
+def test_k2_multi_partition_rank_kernel_crowded_partitions(gpu_ctx, d2g, monkeypatch, nsplit):
+    """The multi-partition rank kernel compacts the values of a pass's hash partition into a queue in LDS (2560 entries) and ranks
+    from the queue.  Columns whose values crowd ONE partition -- a constant column, a column of two values, a column where every
+    value occurs twice -- fill the queue several times per batch of 8192 values; checked against DIRECT on row ranges."""
+    monkeypatch.setenv("D2G_BS_NSPLIT", nsplit)
+    N, S = 30_000, 32
+    rng = np.random.default_rng(77)
+    regs = rng.random((N, S))
+    regs[:, 0] = 0.25                                                   # one value: one partition, 30 000 repeats
+    regs[:, 1] = np.where(rng.random(N) < 0.5, 0.125, 0.375)           # two values
+    half = rng.random(N // 2)
+    regs[:, 2] = np.concatenate([half, half])[rng.permutation(N)]      # every value twice: the table at its fullest
+    regs[:, 3] = regs[rng.integers(0, 40, N), 3]                        # forty values
+    bits = np.ascontiguousarray(regs).view(np.uint64)
+    cs = gpu_ctx.cmp_set(bits, algo=d2g.CMP_BITSLICE)
+    ref = gpu_ctx.cmp_set(bits, algo=d2g.CMP_DIRECT)
+    for a, b in ((0, 200), (N // 2, N // 2 + 200), (N - 1500, N)):
+        np.testing.assert_array_equal(cs.eqcount_ut(a, b), ref.eqcount_ut(a, b))
+    cs.close(); ref.close()
+
+
 @pytest.mark.parametrize("S", [4096, 4100, 8200])
 def test_k2_column_plan_large_sketch_sizes(gpu_ctx, d2g, oracle, S):
     """the column plan sorts up to 4096 register slots in LDS; larger sketches keep the caller's column order (identity plan).
