@@ -60,7 +60,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py: the fallback when rocprofv3 cannot run here
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")   # tools/pmc_round.sh -> tools/pmc_summary.py: the fallback when rocprofv3 cannot run here
 
 
 def parse_args():
@@ -380,9 +380,9 @@ ENGINE_NAME = {"cabi": "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv group
 # step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.33 ms; the plain single-GPU path: 2.9 ms);
 # floor_ms (W = 8) = what no schedule of this design goes below (first exchange + one chunk's prepare + the plane exchange + order + pair).
 MODEL_R05 = {
-    2: {"chunks": 4, "pack": 0.096, "fill": 0.436, "x1": 0.512, "prepare": 0.190, "x2": 0.257, "derive": 0.015, "order": 0.491, "pair": 0.346, "step_ms": 4.181, "speedup": 0.80},
-    4: {"chunks": 4, "pack": 0.055, "fill": 0.206, "x1": 0.128, "prepare": 0.102, "x2": 0.129, "derive": 0.016, "order": 0.490, "pair": 0.229, "step_ms": 1.974, "speedup": 1.69},
-    8: {"chunks": 2, "pack": 0.030, "fill": 0.098, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.024, "order": 0.464, "pair": 0.166, "step_ms": 1.289, "speedup": 2.58, "floor_ms": 1.105},
+    2: {"chunks": 4, "pack": 0.097, "fill": 0.433, "x1": 0.512, "prepare": 0.191, "x2": 0.257, "derive": 0.015, "order": 0.443, "pair": 0.314, "step_ms": 4.101, "speedup": 0.79},
+    4: {"chunks": 4, "pack": 0.056, "fill": 0.208, "x1": 0.128, "prepare": 0.101, "x2": 0.129, "derive": 0.014, "order": 0.445, "pair": 0.206, "step_ms": 1.904, "speedup": 1.71},
+    8: {"chunks": 2, "pack": 0.030, "fill": 0.101, "x1": 0.064, "prepare": 0.102, "x2": 0.129, "derive": 0.024, "order": 0.437, "pair": 0.156, "step_ms": 1.257, "speedup": 2.59, "floor_ms": 1.070},
 }
 
 
