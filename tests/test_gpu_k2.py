@@ -656,6 +656,44 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
         assert seen["paired"]["dense_kernel_ran"] and seen["paired"]["dense_decided_by_prepare"]  # the list overflowed: dense walk, same counts
 
 
+def test_k2_sparse_path_beyond_65535_sketches(gpu_ctx, d2g, oracle):
+    """70 000 sketches: the sizes where 16-bit fields end -- the pair-list kernel counts with two words per value from 65 536 sketches
+    on, sorted positions, launch rows and segment ends no longer fit 16 bits, the rank kernel walks four hash partitions.  A family
+    collection with one chance collision per sketch: whole triangle (2.4 * 10^9 pairs) and row ranges against the direct 64-bit
+    kernel, 40 rows against the oracle; the sparse path must have been taken."""
+    import torch
+    N, S = 70_000, 64
+    fam = synth.synthetic_registers(N, S, nclusters=N // 150, seed=65)
+    m = synth.add_chance_collisions(fam, 1, seed=66).view(np.float64)
+    bits = np.ascontiguousarray(m).view(np.uint64)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    t_dev = torch.from_numpy(bits.view(np.int64)).to(dev)
+    npairs = N * (N - 1) // 2
+    out = torch.empty(npairs, dtype=torch.int32, device=dev)
+    ref = torch.empty(npairs, dtype=torch.int32, device=dev)
+    cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_BITSLICE, stream=stream)
+    out.fill_(-1)
+    cs.eqcount_ut_dev(out.data_ptr(), 0, N, stream)
+    info = cs.sparse_info(stream)
+    dr = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_DIRECT, stream=stream)
+    dr.eqcount_ut_dev(ref.data_ptr(), 0, N, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert info["sorted_operand"] and info["tiles_and_pair_list"] and not info["dense_kernel_ran"], info
+    assert info["tiles_listed"] > 0 and info["pairs_listed"] > N // 2, info
+    off = _ut_offsets(N)
+    for r0, r1 in ((0, 3), (65_530, 65_600), (N - 700, N)):
+        a = cs.eqcount_ut(r0, r1)
+        np.testing.assert_array_equal(a, dr.eqcount_ut(r0, r1), err_msg=f"rows {r0}:{r1}")
+    rng = np.random.default_rng(5)
+    host_rows = np.unique(np.concatenate([[0, 65_535, 65_536, N - 2], rng.integers(0, N - 1, 36)]))
+    for i in host_rows:
+        got = out[int(off[i]):int(off[i + 1])].cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(got, oracle.eqcounts_rows(m, int(i), int(i) + 1), err_msg=f"row {i}")
+    cs.close(); dr.close()
+
+
 def test_k2_bench_matrix_rows_vs_oracle(gpu_ctx, d2g, oracle):
     """the EXACT matrix bench.py times (config 3: synthetic_registers(10000, 1024, nclusters=66, seed=20260928), finalised)
     on the sparse path (asserted), ~200 rows -- first rows, the seams of an 8-way pair-balanced partition, random rows, last rows --
