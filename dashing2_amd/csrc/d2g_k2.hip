@@ -382,6 +382,17 @@ int d2g_cmp_lut_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r
     return launch_direct<false>(ctx, set, ut_shape(set, r0, r1), StoreLut{out, lut}, as_stream(stream));
 }
 
+// The fill of an upper-triangle launch, enqueued AHEAD of it (include/d2g.h): exactly one of neq_out / (lut, out) is given.
+int d2g_cmp_ut_prefill_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *neq_out, const float *lut, float *out, void *stream) {
+    if (!ctx) return D2G_ERR_INVALID;
+    if (int rc = check_rows(ctx, set, r0, r1)) return rc;
+    if (d2g_ut_count(set->N, r0, r1) == 0) return D2G_OK;
+    D2G_CHECK(ctx, (neq_out != nullptr) != (lut != nullptr && out != nullptr), "cmp prefill: give the count output, or the table and the float output");
+    if (set->algo != D2G_CMP_BITSLICE) return D2G_OK;                  // the direct kernel writes every output itself
+    D2G_HIP(ctx, hipSetDevice(ctx->device));
+    return d2g_bitslice_prefill(ctx, set, r0, r1, neq_out, lut, out, as_stream(stream));
+}
+
 int d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *gt, uint32_t *lt, void *stream) {
     if (!ctx) return D2G_ERR_INVALID;
     if (int rc = check_rows(ctx, set, r0, r1)) return rc;

@@ -995,6 +995,7 @@ int d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, 
         if (eq_out) return launch_sparse(ctx, set, sh, StoreEq{eq_out}, eq_out, s);
         return launch_sparse(ctx, set, sh, StoreLut{fout, lut}, reinterpret_cast<uint32_t *>(fout), s);
     }
+    const_cast<d2g_cmp_set *>(set)->prefilled = nullptr;               // (an early fill is void once a launch has written every output itself)
     if (eq_out) return launch_bitslice(ctx, set, sh, StoreEq{eq_out}, s);
     return launch_bitslice(ctx, set, sh, StoreLut{fout, lut}, s);
 }

@@ -372,6 +372,15 @@ int  d2g_cmp_eqcount_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, siz
 /* fused table epilogue: out = lut[neq] (lut_dev: S+1 floats, see d2g_epilogue_lut) */
 int  d2g_cmp_lut_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
                         const float *lut_dev, float *out_dev, void *stream);
+/* The FILL of an upper-triangle launch, ahead of the launch.  From 8192 sketches on, a bit-sliced set's launch first fills its output
+ * with the value of "no register equal" (200 MB at 10 000 sketches: 30 us at the HBM rate) and then writes the pairs that share
+ * something.  The fill depends on nothing: a caller that knows the output before the operand is ready --
+ * d2g_cmp_set_update_dev still to come, an exchange in flight -- enqueues it here, on ANY stream, and the NEXT upper-triangle launch
+ * on the set into the same output and rows skips its own.  The caller orders the two: the same stream, or an event the launch's stream
+ * waits for.  Exactly one of neq_out_dev / (lut_dev, out_dev) is given, as in the launch that follows.  A no-op for sets that would not
+ * fill (small sets, the direct kernel); harmless when the launch decides for the dense walk (every output is written again). */
+int  d2g_cmp_ut_prefill_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *neq_out_dev,
+                            const float *lut_dev, float *out_dev, void *stream);
 /* (#a>b, #a<b) counts per pair: needs a set created with D2G_CMP_DIRECT (the raw patterns);
  * required when S is not a power of two in set space */
 int  d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,

@@ -656,6 +656,71 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
         assert seen["paired"]["dense_kernel_ran"] and seen["paired"]["dense_decided_by_prepare"]  # the list overflowed: dense walk, same counts
 
 
+def test_k2_fill_ahead_of_the_launch(gpu_ctx, d2g):
+    """d2g_cmp_ut_prefill_dev: the fill of the next upper-triangle launch enqueued ahead of it -- before the operand is even prepared,
+    on a second stream -- and the launch skips its own.  Same output as the plain launch: counts and table values, whole triangle and
+    a row range; a launch that takes the dense walk after an early fill; a set too small to fill (no-op)."""
+    import torch
+    N, S = 9_000, 64
+    dev = torch.device("cuda", 0)
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    st = main.cuda_stream
+    fam = synth.synthetic_registers(N, S, nclusters=N // 150, seed=8)
+    mats = [fam, synth.skewed_registers(N, S, seed=9)]                   # the second one: dense walk decided on the device
+    lut_np = d2g.epilogue_lut(S, d2g.SIMILARITY, 31)
+    lut = torch.from_numpy(lut_np).to(dev)
+    npairs = N * (N - 1) // 2
+    want = torch.empty(npairs, dtype=torch.int32, device=dev)
+    got = torch.empty(npairs, dtype=torch.int32, device=dev)
+    fgot = torch.empty(npairs, dtype=torch.float32, device=dev)
+    cs = None
+    for k, m in enumerate(mats):
+        t_dev = torch.from_numpy(np.ascontiguousarray(m).view(np.int64)).to(dev)
+        if cs is None:
+            cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_BITSLICE, stream=st)
+        else:
+            cs.update_dev(t_dev.data_ptr(), st)
+        cs.eqcount_ut_dev(want.data_ptr(), 0, N, st)                      # the plain launch
+        info = cs.sparse_info(st)
+        assert info["dense_kernel_ran"] == (k == 1), info
+        torch.cuda.synchronize()
+        # fill first (second stream), then prepare again, then the launch
+        got.fill_(-1)
+        torch.cuda.synchronize()
+        ev = torch.cuda.Event()
+        cs.prefill_ut_dev(got.data_ptr(), 0, N, stream=side.cuda_stream)
+        ev.record(side)
+        cs.update_dev(t_dev.data_ptr(), st)
+        main.wait_event(ev)
+        cs.eqcount_ut_dev(got.data_ptr(), 0, N, st)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), k
+        # the table path, a row range, same stream
+        r0, r1 = N // 4, N // 4 + 1500
+        off = _ut_offsets(N)
+        cnt = int(off[r1] - off[r0])
+        fgot.fill_(-1.0)
+        cs.prefill_ut_dev(fgot.data_ptr(), r0, r1, lut_dev_ptr=lut.data_ptr(), stream=st)
+        cs.lut_ut_dev(lut.data_ptr(), fgot.data_ptr(), r0, r1, st)
+        torch.cuda.synchronize()
+        assert torch.equal(fgot[:cnt].view(torch.int32), lut[want[int(off[r0]):int(off[r1])].long()].view(torch.int32)), k
+        # and the launch after it fills for itself again
+        got.fill_(-1)
+        cs.eqcount_ut_dev(got.data_ptr(), 0, N, st)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), k
+        del t_dev
+    cs.close()
+    small = synth.synthetic_registers(300, S, nclusters=3, seed=1)
+    cs = gpu_ctx.cmp_set(small, algo=d2g.CMP_BITSLICE)
+    buf = torch.full((300 * 299 // 2,), -1, dtype=torch.int32, device=dev)
+    cs.prefill_ut_dev(buf.data_ptr(), 0, 300, stream=st)                  # below 8192 sketches nothing is filled
+    torch.cuda.synchronize()
+    assert int((buf != -1).sum()) == 0
+    cs.close()
+
+
 def test_k2_sparse_path_beyond_65535_sketches(gpu_ctx, d2g, oracle):
     """70 000 sketches: the sizes where 16-bit fields end -- the pair-list kernel counts with two words per value from 65 536 sketches
     on, sorted positions, launch rows and segment ends no longer fit 16 bits, the rank kernel walks four hash partitions.  A family

@@ -21,15 +21,32 @@ lut = torch.from_numpy(D.epilogue_lut(S, D.SIMILARITY, 31)).to(dev)
 out = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 cs = ctx.cmp_set_dev(t.data_ptr(), N, S, algo=D.CMP_BITSLICE, stream=st)
-for _ in range(3):
+PREFILL = os.environ.get("PREFILL", "0") == "1"       # the launch's fill on a second stream, beside the prepare chain (d2g_cmp_ut_prefill_dev)
+main = torch.cuda.current_stream()
+side = torch.cuda.Stream() if PREFILL else None
+ev_done, ev_fill = torch.cuda.Event(), torch.cuda.Event()
+
+
+def step():
+    if PREFILL:
+        side.wait_event(ev_done)                       # the last step's launch has finished with `out`
+        cs.prefill_ut_dev(out.data_ptr(), 0, N, lut_dev_ptr=lut.data_ptr(), stream=side.cuda_stream)
+        ev_fill.record(side)
     cs.update_dev(t.data_ptr(), st)
+    if PREFILL:
+        main.wait_event(ev_fill)
     cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), 0, N, st)
+    if PREFILL:
+        ev_done.record(main)
+
+
+for _ in range(3):
+    step()
 torch.cuda.synchronize()
 ctx.set_timing(True); ctx.kernel_ms("k2")
 t0 = time.perf_counter()
 for _ in range(20):
-    cs.update_dev(t.data_ptr(), st)
-    cs.lut_ut_dev(lut.data_ptr(), out.data_ptr(), 0, N, st)
+    step()
 torch.cuda.synchronize()
 step_ms = (time.perf_counter() - t0) / 20 * 1e3
 n, ms, _ = ctx.kernel_ms("k2")
