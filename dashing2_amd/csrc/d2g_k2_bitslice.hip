@@ -70,7 +70,12 @@ __device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
 // Also measured and dropped: the values of a pass's partition COMPACTED into a queue in the LDS behind the table (block scan of the
 // per-thread counts, 2560 entries of (value, sketch)) so that claim / confirm run with every lane busy instead of under an execution
 // mask -- correct (all K2 / multi-GPU tests), 1.08 ms instead of 1.04 at N = 50 000, 0.43 instead of 0.36 at N = 30 000: the scan, the
-// queue traffic and four more barriers per batch cost what the idle lanes had cost.)
+// queue traffic and four more barriers per batch cost what the idle lanes had cost.
+// And: the column BINNED by partition in global memory first (a kernel of its own: per-wave counts by ballot, then (value, sketch) runs at
+// per-wave cursors; 12 bytes per value), then ranked bin by bin from the dense lists with 16384-slot tables -- correct, but the binning
+// kernel alone took 0.54 ms at N = 50 000 (0.23 at 30 000) and the bin-ranking kernel 0.62 (0.36): 1.16 ms against 1.04.  The walking
+// kernel stays; what it costs is ~84 dependent round trips per workgroup (three per batch of eight values and pass) with one 128 KiB-table
+// workgroup per CU to hide them.)
 constexpr uint32_t BS_SPLIT_SHIFT = 28, BS_RANK_MASK = (1u << BS_SPLIT_SHIFT) - 1u;
 template <bool MULTI, bool FAST>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
