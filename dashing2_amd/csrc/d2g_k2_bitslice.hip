@@ -1082,3 +1082,10 @@ int d2g_bitslice_debug_read(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s,
 }
 
 void d2g_warm_k2_bitslice() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&bs_colplan_kernel)); }
+
+#ifdef D2G_SP_TRACE
+// variant builds only: the time stamps of the last sparse pair kernel (tools/sp_trace.py)
+extern "C" int d2g_debug_sp_trace(unsigned long long *out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_trace), std::min<size_t>(n, 16384 * 8) * 8) == hipSuccess ? 0 : -1;
+}
+#endif

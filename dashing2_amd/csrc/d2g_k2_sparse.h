@@ -633,10 +633,30 @@ __global__ __launch_bounds__(256) void sp_rowbm_kernel(const uint32_t *__restric
 // ctl[0] = tiles listed, ctl[1] bit 0 = dense walk, ctl[3] = candidates, ctl[8 + q] = tiles in list q (list q starts at tiles + q * cap).
 constexpr int SP_CTL_WORDS = 16;
 // workgroup `wg` of `NW` waves lists tiles [wg * 512 NW, (wg + 1) * 512 NW)
+// The lists hold SUB-TILES (tile * 4 + sub: 16 launch rows x 128 sorted columns, what one workgroup of the pair kernel walks), and only
+// those that can hold a pair of one segment (sp_tile_subs).  Round 5 first listed whole tiles and let the pair kernel's workgroups
+// find out that their sub-tile was empty: 40 % of them left at once, the CUs were dealt between two and seven WORKING workgroups, and
+// the kernel lasted as long as the fullest CU (per-workgroup time stamps: plane walk 18 us on average, 34-38 us on the fullest CUs;
+// kernel 45 us for a mean workgroup life of 29).  Dense lists deal the work evenly.
+__device__ __forceinline__ uint32_t sp_tile_subs(uint32_t rb, uint32_t cb, int full, uint32_t N, const uint32_t *__restrict__ rowpos, const uint2 *__restrict__ posseg) {
+    constexpr uint32_t WC = BS_CB / (64 * BS_JR);
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t sb = 0; sb < 4; ++sb) {
+        const uint32_t k0 = rb * 32u + (sb / WC) * BS_IW, c0 = cb * (uint32_t)BS_CB + (sb % WC) * (64u * BS_JR);
+        if (full && k0 > c0 + 64u * BS_JR - 1u) continue;            // entirely below the diagonal of sorted positions
+        const uint32_t pf = full ? k0 : rowpos[k0];
+        if (pf == SP_NONE || pf >= N) continue;                       // no row
+        const uint32_t pl = full ? min(k0 + (uint32_t)BS_IW - 1u, N - 1u) : rowpos[k0 + BS_IW - 1];
+        if (pl != SP_NONE && sp_sub_empty(posseg, pf, pl, c0)) continue;   // no pair of one segment: the pair list has what it holds (sp_entry_wanted asks the same)
+        m |= 1u << sb;
+    }
+    return m;
+}
 template <int NW>
 __device__ __forceinline__ void sp_list_body(uint32_t wg, const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
                                              uint32_t *__restrict__ tiles, uint32_t cap, uint32_t *__restrict__ ctl, uint32_t cand, const uint32_t *__restrict__ order,
-                                             uint32_t *__restrict__ ctl_next) {
+                                             uint32_t *__restrict__ ctl_next, uint32_t N, const uint32_t *__restrict__ rowpos, const uint2 *__restrict__ posseg) {
     __shared__ unsigned long long wave_tot[2][NW];
     __shared__ uint32_t s_base[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -646,15 +666,23 @@ __device__ __forceinline__ void sp_list_body(uint32_t wg, const uint32_t *__rest
         if (wg == 0 && tid == 0) atomicOr(&ctl[1], 1u);
         return;
     }
+    // ONE candidate tile per thread: bitmap word, then (listed tiles only) the segments of its rows -- two dependent round trips for the
+    // whole list (eight tiles per thread, one after the other, took ~25 us at config 3)
     const size_t ntile = (size_t)nrb * ncb;
-    const size_t a = ((size_t)wg * (64 * NW) + tid) * 8, b = min(ntile, a + 8);
-    uint32_t mask = 0;
-    unsigned long long cnt[2] = {0, 0};                               // eight 16-bit counters: lists 0-3 | lists 4-7 (a workgroup lists at most 8192 tiles)
-    for (size_t x = a; x < b; ++x) {
+    const size_t x = (size_t)wg * (64 * NW) + tid;
+    uint32_t sm = 0, ntl = 0, q = 0;                                   // sm: the tile's sub-tiles to walk
+    unsigned long long cnt[2] = {0, 0};                               // eight 16-bit counters: lists 0-3 | lists 4-7 (a workgroup lists at most 1024 tiles)
+    if (x < ntile) {
         const uint32_t rb = (uint32_t)(x / ncb), cb = (uint32_t)(x % ncb);
-        if (full && (size_t)rb * 32 > (size_t)cb * 256 + 255) continue;
-        if ((tilebm[(size_t)rb * CW + (cb >> 5)] >> (cb & 31)) & 1u) { mask |= 1u << (x - a); cnt[(cb >> 2) & 1] += 1ull << (16 * (cb & 3)); }
+        q = cb & 7u;
+        if (!(full && (size_t)rb * 32 > (size_t)cb * 256 + 255) && ((tilebm[(size_t)rb * CW + (cb >> 5)] >> (cb & 31)) & 1u)) {
+            sm = sp_tile_subs(rb, cb, full, N, rowpos, posseg);
+            ntl = 1;                                                  // (a listed tile counts as listed even when none of its sub-tiles is walked: sp_dense_mode, sparse_info)
+            cnt[(cb >> 2) & 1] = (unsigned long long)__popc(sm) << (16 * (cb & 3));
+        }
     }
+    for (int o = 32; o > 0; o >>= 1) ntl += __shfl_down(ntl, o);
+    if (lane == 0 && ntl) atomicAdd(&ctl[0], ntl);
     // block-wide exclusive prefix of the eight counters, two packed scans
     unsigned long long ex[2], tot[2];
 #pragma unroll
@@ -674,22 +702,20 @@ __device__ __forceinline__ void sp_list_body(uint32_t wg, const uint32_t *__rest
     if (tid < 8) {
         const uint32_t n = (uint32_t)(tot[tid >> 2] >> (16 * (tid & 3))) & 0xFFFFu;
         s_base[tid] = n ? atomicAdd(&ctl[8 + tid], n) : 0u;
-        if (n) atomicAdd(&ctl[0], n);
     }
     __syncthreads();
-    for (uint32_t x = 0; x < 8; ++x) {
-        if (!((mask >> x) & 1u)) continue;
-        const uint32_t q = (uint32_t)((a + x) % ncb) & 7u;
-        const uint32_t o = s_base[q] + ((uint32_t)(ex[q >> 2] >> (16 * (q & 3))) & 0xFFFFu);
-        tiles[(size_t)q * cap + o] = (uint32_t)(a + x);
-        ex[q >> 2] += 1ull << (16 * (q & 3));
+    if (sm) {
+        uint32_t o = s_base[q] + ((uint32_t)(ex[q >> 2] >> (16 * (q & 3))) & 0xFFFFu);
+#pragma unroll
+        for (uint32_t sb = 0; sb < 4; ++sb)
+            if ((sm >> sb) & 1u) tiles[(size_t)q * cap + o++] = (uint32_t)x * 4u + sb;
     }
 }
 // a partial launch's lists (its own tile bitmap); a whole-triangle launch uses the lists the prepare left (sp_permute_kernel)
 __global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restrict__ tilebm, uint32_t nrb, uint32_t ncb, uint32_t CW, int full,
                                                        uint32_t *__restrict__ tiles, uint32_t cap, uint32_t *__restrict__ ctl, uint32_t cand, const uint32_t *__restrict__ order,
-                                                       uint32_t *__restrict__ ctl_next) {
-    sp_list_body<16>(blockIdx.x, tilebm, nrb, ncb, CW, full, tiles, cap, ctl, cand, order, ctl_next);
+                                                       uint32_t *__restrict__ ctl_next, uint32_t N, const uint32_t *__restrict__ rowpos, const uint2 *__restrict__ posseg) {
+    sp_list_body<16>(blockIdx.x, tilebm, nrb, ncb, CW, full, tiles, cap, ctl, cand, order, ctl_next, N, rowpos, posseg);
 }
 
 // the sorted stream from the caller's-order stream: position p takes the words of sketch sperm[p].  Only the row-coded words and
@@ -697,12 +723,15 @@ __global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restric
 // is column-unique, 0 elsewhere); both codings are written.
 // Its first workgroups also leave the work lists of a whole-triangle launch (the segments' tiles are final once sp_emit_kernel is done):
 // such a launch starts with the fill, no list kernel of its own.
-struct SpFullList { const uint32_t *bm; uint32_t nrb, ncb, CW; uint32_t *tiles; uint32_t cap; uint32_t *ctl; uint32_t cand, nwg; };
+struct SpFullList { const uint32_t *bm; uint32_t nrb, ncb, CW; uint32_t *tiles; uint32_t cap; uint32_t *ctl; uint32_t cand, nwg; uint32_t N; const uint2 *posseg; uint32_t row0; };
 __global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restrict__ nat, uint32_t *__restrict__ srt, size_t Nstride, const uint32_t *__restrict__ meta,
                                                          const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ order, SpFullList fl) {
-    {
-        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
-        if (lin < fl.nwg) sp_list_body<4>(lin, fl.bm, fl.nrb, fl.ncb, fl.CW, 1, fl.tiles, fl.cap, fl.ctl, fl.cand, order, nullptr);
+    // the lists are built by workgroups of their OWN (the last rows of the grid), beside the permutation instead of in front of a few
+    // workgroups' share of it
+    if (blockIdx.y >= fl.row0) {
+        const uint32_t lw = (blockIdx.y - fl.row0) * gridDim.x + blockIdx.x;
+        if (lw < fl.nwg) sp_list_body<4>(lw, fl.bm, fl.nrb, fl.ncb, fl.CW, 1, fl.tiles, fl.cap, fl.ctl, fl.cand, order, nullptr, fl.N, nullptr, fl.posseg);
+        return;
     }
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int tb = blockIdx.y;
@@ -823,6 +852,14 @@ struct SpArgs {
 // sub-tile and its four waves each walk a quarter of the 32-register groups, then add their mismatch counts in LDS.  (The dense
 // kernel gives every wave a sub-tile and all groups: with a few hundred listed tiles that leaves one or two waves per SIMD, each
 // waiting out the latency of every plane's loads -- measured 87 us for 432 tiles at config 3, 411 us for 2122 at config 4.)
+#ifdef D2G_SP_TRACE
+// variant builds only (tools/build_variant.sh trace -DD2G_SP_TRACE; tools/sp_trace.py): per-workgroup time stamps of the sparse pair
+// kernel -- 0 start, 1 sub-tile found + LDS cleared, 2 plane walk done, 3 LDS reduction done, 4 epilogue done, 5 loop left, 6 tail done
+__device__ unsigned long long g_sp_trace[16384 * 8];
+#define SP_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) g_sp_trace[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SP_STAMP(k) do { } while (0)
+#endif
 template <int JR, class Store>
 __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_sparse_kernel(SpArgs a, PairShape sh, Store store, SpPatchArgs pa) {
     constexpr int IW = BS_IW;
@@ -830,10 +867,11 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     constexpr int KS = D2G_SP_KS;                                   // waves per sub-tile = splits of the group range
     static_assert(JR == 2, "the LDS reduction packs a lane's two column groups into one word");
     __shared__ uint32_t red[IW][64];                                // per row and lane: mismatches of column group 0 | group 1 << 16 (a sum stays below 2^16: S < 65536 asserted by the host)
+    SP_STAMP(0);
     if (sp_dense_mode(a.ctl, a.cand)) return;                       // dense mode
     // the workgroups of XCD q (blockIdx % 8: the hardware deals workgroups to the XCDs round-robin) walk list q
     const uint32_t xq = blockIdx.x & 7u;
-    const uint32_t nsub = a.ctl[8 + xq] * 4u;
+    const uint32_t nsub = a.ctl[8 + xq];                              // the list holds sub-tiles
     const uint32_t *mytiles = a.tiles + (size_t)xq * a.tiles_cap;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -842,8 +880,10 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     // first plane slot of this wave's groups: one wave-wide prefix over the groups' live plane counts (a scalar loop over up to 24
     // dependent loads before the first tile otherwise).  (Touching a sub-tile's operands once before the plane walk, all requests in
     // flight together, was measured: no gain -- the words are L2-resident already; the kernel runs at ~60 % of the dense kernel's issue rate.)
-    size_t slot0;
-    if (a.ntb <= 64) {
+    size_t slot0 = 0;
+    if ((blockIdx.x >> 3) >= nsub) {
+        // nothing in this workgroup's list at its index (the grid is oversubscribed): straight to the pair list's tail
+    } else if (a.ntb <= 64) {
         uint32_t incl = lane < a.ntb ? (uint32_t)live_planes(a.meta, lane) : 0u;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if (lane >= o) incl += x; }
         slot0 = __builtin_amdgcn_readfirstlane(g0 ? __shfl(incl, g0 - 1) : 0u);
@@ -851,19 +891,14 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         slot0 = stream_slot(a.meta, g0);
     }
     for (uint32_t si = blockIdx.x >> 3; si < nsub; si += gridDim.x >> 3) {
-        const uint32_t tile = mytiles[si >> 2], sub = si & 3u;
+        const uint32_t ent = mytiles[si], tile = ent >> 2, sub = ent & 3u;
         const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
         const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
         const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
-        if (full && k0 > c0 + 64 * JR - 1) continue;                             // entirely below the diagonal of sorted positions (uniform for the workgroup)
-        {   // no row, or no pair of one segment in it (all uniform): the pair list has what the sub-tile holds (sp_entry_wanted asks the same)
-            const uint32_t pf = full ? (uint32_t)k0 : a.rowpos[k0];
-            if (pf == SP_NONE || pf >= a.N) continue;
-            const uint32_t pl = full ? min((uint32_t)k0 + IW - 1u, a.N - 1u) : a.rowpos[k0 + IW - 1];
-            if (pl != SP_NONE && sp_sub_empty(a.posseg, pf, pl, (uint32_t)c0)) continue;
-        }
+        // (the list holds only sub-tiles with a row, on or above the diagonal of sorted positions, that can hold a pair of one segment: sp_tile_subs)
         for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
         __syncthreads();
+        SP_STAMP(1);
         uint32_t acc[IW][JR];
 #pragma unroll
         for (int i = 0; i < IW; ++i)
@@ -886,9 +921,11 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         // every wave adds its share of the mismatch counts in LDS; afterwards wave ks finishes rows [ks IW/KS, (ks+1) IW/KS) -- the epilogue
         // (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
         // work while the other three wait
+        SP_STAMP(2);
 #pragma unroll
         for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][lane], v); }
         __syncthreads();
+        SP_STAMP(3);
         {
             uint32_t el = (uint32_t)lane;
             asm volatile("" : "+v"(el));                               // what the epilogue derives from the lane is computed here, not carried through the plane walk
@@ -912,9 +949,12 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
             }
         }
         __syncthreads();
+        SP_STAMP(4);
     }
+    SP_STAMP(5);
     // the pair list's entries, spread over all workgroups of the launch (those without a tile start here at once)
     if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)pa.nwg * (64 * KS));
+    SP_STAMP(6);
 }
 
 // (measured in round 5 and dropped: the same kernel with the row words of a sub-tile staged through LDS and a 4-deep ring of column
@@ -962,7 +1002,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     const size_t Npad = set->Npad, Nstride = set->Nstride;
     const size_t nrb = Npad / 32, ncb = Npad / BS_CB;
     set->tilebm_words = nrb * ((ncb + 31) / 32) + 1;
-    set->tiles_cap = nrb * ((ncb + 7) / 8);                            // per list: the tiles of every eighth column block
+    set->tiles_cap = nrb * ((ncb + 7) / 8) * 4;                        // per list: the sub-tiles of the tiles of every eighth column block
     set->plist_cap = sp_list_cap(ctx, set->N);
     // one zero-initialised block per prepare: [counters Npad + 1 | 8 global control words + tile bitmap | order 8 | list control 8 | control words of a whole-triangle launch 16]
     set->spz_words = (Npad + 1) + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS;
@@ -1097,9 +1137,12 @@ int sp_permute(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const size_t nrb = set->Npad / 32, ncb = set->Npad / BS_CB, ntile = nrb * ncb;
     SpFullList fl{set->d_gbm + 8, (uint32_t)nrb, (uint32_t)ncb, (uint32_t)((ncb + 31) / 32), set->d_tiles_full, (uint32_t)set->tiles_cap, set->d_fullctl,
-                  (uint32_t)std::min<size_t>(sp_full_candidates(set->Npad), 0xFFFFFFFFu), (uint32_t)div_up<size_t>(ntile, 2048)};
-    set->full_list_valid = (size_t)fl.nwg <= (size_t)grid.x * grid.y;
-    if (!set->full_list_valid) fl.nwg = 0;                              // (a huge N with a tiny sketch size: the launch lists its tiles itself)
+                  (uint32_t)std::min<size_t>(sp_full_candidates(set->Npad), 0xFFFFFFFFu), (uint32_t)div_up<size_t>(ntile, 256), (uint32_t)set->N,
+                  reinterpret_cast<const uint2 *>(set->d_posseg), (uint32_t)set->ntb};
+    const size_t list_rows = div_up<size_t>(fl.nwg, grid.x);            // rows of workgroups that build the lists (one tile per thread)
+    set->full_list_valid = (size_t)set->ntb + list_rows <= 65535;
+    if (!set->full_list_valid) fl.nwg = 0;                              // (a huge N: the launch lists its tiles itself)
+    else grid.y += (unsigned)list_rows;
     hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm, set->d_order, fl);
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
@@ -1183,8 +1226,9 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     const uint32_t *bm = full ? set->d_gbm + 8 : set->d_tilebm;
     uint32_t *const tiles = own_list ? set->d_tiles : set->d_tiles_full;
     if (own_list)
-        hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 8192)), dim3(1024), 0, s, bm, nrb, ncb, CW, full ? 1 : 0,
-                           tiles, (uint32_t)set->tiles_cap, ctl, cand32, set->d_order, ctl_next);
+        hipLaunchKernelGGL(sp_list_kernel, dim3((unsigned)div_up<size_t>(ntile, 1024)), dim3(1024), 0, s, bm, nrb, ncb, CW, full ? 1 : 0,
+                           tiles, (uint32_t)set->tiles_cap, ctl, cand32, set->d_order, ctl_next, (uint32_t)N, full ? (const uint32_t *)nullptr : set->d_rowpos,
+                           reinterpret_cast<const uint2 *>(set->d_posseg));
     SpArgs a{set->d_stream_s, set->Nstride, full ? (const uint32_t *)nullptr : set->d_rowstream, set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, (uint32_t)N,
              set->d_sperm, set->d_rowpos, tiles, ctl, ncb, cand32, (uint32_t)set->tiles_cap, reinterpret_cast<const uint2 *>(set->d_posseg)};
     // contiguous 32 KB per workgroup, workgroups in dispatch order: a streaming write (6.1 TB/s at N = 50 000: 825 us; the grid-stride loop over 16
