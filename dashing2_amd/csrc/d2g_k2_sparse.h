@@ -871,7 +871,23 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     if (sp_dense_mode(a.ctl, a.cand)) return;                       // dense mode
     // the workgroups of XCD q (blockIdx % 8: the hardware deals workgroups to the XCDs round-robin) walk list q
     const uint32_t xq = blockIdx.x & 7u;
-    const uint32_t nsub = a.ctl[8 + xq];                              // the list holds sub-tiles
+    // The eight lists differ in length (119-136 sub-tiles at config 3) and a CU of a long list's XCD is dealt a FIFTH working workgroup, which
+    // -- everybody resident from the first cycle, the plane walk bound by VALU issue -- finishes 40 % later than the rest (time stamps: 40 us
+    // against 33).  So a list longer than the mean hands its surplus to the XCDs with shorter ones: everybody walks `even` = ceil(total / 8)
+    // places; a place behind the end of the own list takes the k-th handed-over sub-tile (k counted over the XCDs' free places in order).
+    uint32_t even, own = 0, before = 0;
+    {
+        uint32_t nq[8], total = 0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) { nq[p] = a.ctl[8 + p]; total += nq[p]; }
+        even = (total + 7u) >> 3;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if ((uint32_t)p == xq) own = min(nq[p], even);
+            if ((uint32_t)p < xq) before += even > nq[p] ? even - nq[p] : 0u;
+        }
+    }
+    const uint32_t nsub = even;                                       // places this XCD's workgroups walk (the lists hold sub-tiles)
     const uint32_t *mytiles = a.tiles + (size_t)xq * a.tiles_cap;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -891,7 +907,23 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         slot0 = stream_slot(a.meta, g0);
     }
     for (uint32_t si = blockIdx.x >> 3; si < nsub; si += gridDim.x >> 3) {
-        const uint32_t ent = mytiles[si], tile = ent >> 2, sub = ent & 3u;
+        uint32_t ent = 0;
+        if (si < own) ent = mytiles[si];
+        else {
+            uint32_t k = before + (si - own);
+            bool found = false;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {                             // (the eight lengths are read again here: held across the plane walk they cost eight SGPRs the kernel does not have)
+                const uint32_t np = a.ctl[8 + p];
+                const uint32_t surplus = np > even ? np - even : 0u;
+                if (!found) {
+                    if (k < surplus) { ent = a.tiles[(size_t)p * a.tiles_cap + even + k]; found = true; }
+                    else k -= surplus;
+                }
+            }
+            if (!found) continue;                                     // (more free places than sub-tiles handed over)
+        }
+        const uint32_t tile = ent >> 2, sub = ent & 3u;
         const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
         const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
         const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
@@ -932,11 +964,20 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
             uint32_t oj[JR];
 #pragma unroll
             for (int c = 0; c < JR; ++c) oj[c] = a.sperm[c0 + el + 64 * c];
-            for (int i = ks * IW / KS; i < (ks + 1) * IW / KS; ++i) {
-                const size_t k = k0 + i;
-                const uint32_t rpos = full ? (uint32_t)k : a.rowpos[k];               // uniform
+            // the rows' caller indices: all of this wave's scalar loads in flight together (one after the other they were four dependent
+            // round trips in front of the stores)
+            constexpr int RW = IW / KS;
+            uint32_t rps[RW], ois[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) { const size_t k = k0 + (size_t)(ks * RW + r); rps[r] = full ? (uint32_t)k : a.rowpos[k]; }
+#pragma unroll
+            for (int r = 0; r < RW; ++r) ois[r] = a.sperm[(rps[r] == SP_NONE || rps[r] >= a.N) ? 0u : rps[r]];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int i = ks * RW + r;
+                const uint32_t rpos = rps[r];                                         // uniform
                 if (rpos == SP_NONE || rpos >= a.N) continue;
-                const uint32_t oi = a.sperm[rpos];                                    // uniform
+                const uint32_t oi = ois[r];                                           // uniform
 #pragma unroll
                 for (int c = 0; c < JR; ++c) {
                     const uint32_t mm = (red[i][el] >> (16 * c)) & 0xFFFFu;
