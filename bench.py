@@ -380,9 +380,9 @@ ENGINE_NAME = {"cabi": "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv group
 # step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.33 ms; the plain single-GPU path: 2.9 ms);
 # floor_ms (W = 8) = what no schedule of this design goes below (first exchange + one chunk's prepare + the plane exchange + order + pair).
 MODEL_R05 = {
-    2: {"chunks": 4, "pack": 0.092, "fill": 0.423, "x1": 0.512, "prepare": 0.189, "x2": 0.257, "derive": 0.014, "order": 0.450, "pair": 0.312, "step_ms": 4.101, "speedup": 0.77},
-    4: {"chunks": 4, "pack": 0.054, "fill": 0.205, "x1": 0.128, "prepare": 0.103, "x2": 0.129, "derive": 0.015, "order": 0.452, "pair": 0.198, "step_ms": 1.902, "speedup": 1.66},
-    8: {"chunks": 2, "pack": 0.030, "fill": 0.100, "x1": 0.064, "prepare": 0.102, "x2": 0.129, "derive": 0.023, "order": 0.446, "pair": 0.147, "step_ms": 1.255, "speedup": 2.52, "floor_ms": 1.069},
+    2: {"chunks": 4, "pack": 0.092, "fill": 0.435, "x1": 0.512, "prepare": 0.190, "x2": 0.257, "derive": 0.015, "order": 0.451, "pair": 0.311, "step_ms": 4.103, "speedup": 0.79},
+    4: {"chunks": 4, "pack": 0.052, "fill": 0.206, "x1": 0.128, "prepare": 0.102, "x2": 0.129, "derive": 0.016, "order": 0.453, "pair": 0.196, "step_ms": 1.900, "speedup": 1.71},
+    8: {"chunks": 2, "pack": 0.030, "fill": 0.100, "x1": 0.064, "prepare": 0.102, "x2": 0.129, "derive": 0.023, "order": 0.445, "pair": 0.147, "step_ms": 1.253, "speedup": 2.59, "floor_ms": 1.067},
 }
 
 
