@@ -152,6 +152,7 @@ SIGNATURES = {
     "d2g_cmp_eqcount_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "d2g_cmp_lut_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "d2g_cmp_ut_prefill_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "d2g_cmp_ut_announce_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "d2g_cmp_gtlt_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "d2g_cmp_eqcount_rect_dev": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     "d2g_cmp_gtlt_rect_dev": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
@@ -775,6 +776,14 @@ class CmpSet:
             self.ctx._check(lib().d2g_cmp_ut_prefill_dev(self.ctx._h, self._h, r0, r1, out_dev_ptr, None, None, stream))
         else:
             self.ctx._check(lib().d2g_cmp_ut_prefill_dev(self.ctx._h, self._h, r0, r1, None, lut_dev_ptr, out_dev_ptr, stream))
+
+    def announce_ut_dev(self, out_dev_ptr, r0=0, r1=None, lut_dev_ptr=None):
+        """the output of the NEXT upper-triangle launch, told ahead of the update_dev that precedes it: the prepare carries the fill"""
+        r1 = self.N if r1 is None else r1
+        if lut_dev_ptr is None:
+            self.ctx._check(lib().d2g_cmp_ut_announce_dev(self.ctx._h, self._h, r0, r1, out_dev_ptr, None, None))
+        else:
+            self.ctx._check(lib().d2g_cmp_ut_announce_dev(self.ctx._h, self._h, r0, r1, None, lut_dev_ptr, out_dev_ptr))
 
     def gtlt_ut_dev(self, gt_dev_ptr, lt_dev_ptr, r0=0, r1=None, stream=None):
         r1 = self.N if r1 is None else r1

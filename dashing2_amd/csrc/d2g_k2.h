@@ -70,12 +70,23 @@ struct d2g_cmp_set {
     uint32_t *h_gaveup = nullptr, *d_gaveup = nullptr;   // a word of mapped host memory: 1 = the last ordering raised order[0] (the next prepare skips the ordering)
     unsigned sp_prepares = 0; bool sp_skipped = false;
     uint32_t *prefilled = nullptr;        // output the engine filled at the start of its step (d2g_bitslice_prefill): the next sparse launch into it skips its fill
+    size_t prefilled_cnt = 0;             // ... and how many outputs that fill covered
+    size_t prefilled_pieces = 0;          // ... and how many 32 KB pieces of it are written (all of them after an early fill; what rode on the prepare's kernels otherwise)
+    int ride_mask = 0;
+    // the output of the NEXT upper-triangle launch, announced ahead of the prepare (d2g_cmp_ut_announce_dev): the prepare's latency-bound
+    // kernels (column plan, flatten, count, attach, scan, place: one to forty workgroups each) carry the fill as extra workgroups
+    uint32_t *ride_out = nullptr; size_t ride_cnt = 0; const uint32_t *ride_vsrc = nullptr; uint32_t ride_vimm = 0;
+    uint32_t ride_next = 0, ride_total = 0;   // pieces of 32 KB handed out so far / in all (0: nothing rides in this prepare)
     const uint32_t *last_ctl = nullptr;   // control words of the last sparse launch (d2g_cmp_set_sparse_info)
     unsigned long long *d_plist = nullptr;   // pair list: (i | j << 32), i < j caller's indices, one entry per (pair in different segments, shared value)
     size_t plist_cap = 0;
     size_t tilebm_words = 0, tiles_cap = 0;
 };
 constexpr int BS_CC_STRIDE = 8;
+
+// part of an upper-triangle launch's fill, carried by a kernel of the prepare chain: the workgroups from `own` on write pieces
+// piece0 .. of 32 KB each (own = 0xFFFFFFFF: nobody rides)
+struct SpRider { uint32_t *out; size_t cnt; const uint32_t *vsrc; uint32_t vimm, own, piece0; };
 
 struct PairShape;
 int  finish_shape(d2g_ctx *ctx, PairShape &sh, unsigned rb);   // d2g_k2.hip
@@ -107,6 +118,8 @@ int  d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
                      const float *lut, float *fout, hipStream_t s);
 // multi-GPU engine: the fill of a rank's slab enqueued at the start of the step (under the exchanges)
 int  d2g_bitslice_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout, hipStream_t s);
+// the output of the next upper-triangle launch, announced before the prepare that precedes it: that prepare carries the fill
+int  d2g_bitslice_announce(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout);
 int  d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1,
                        uint32_t *eq_out, hipStream_t s);
 

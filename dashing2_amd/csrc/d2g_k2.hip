@@ -68,6 +68,15 @@ __global__ __launch_bounds__(256) void k2_transpose_kernel(const uint64_t *__res
     }
 }
 
+// (Measured in round 5 and dropped: 64 x 64 tiles, 8 bytes per lane, 16 independent loads per thread before the barrier, 512-byte runs
+// both ways -- 46.3 us on average (27.7 at best) against 42.7 (25.5) for the kernel above in the bench's step.  The average is not a
+// bytes-in-flight problem: the step before left 200 MB of freshly filled output behind, and whatever kernel comes next shares the HBM with
+// that write-back.)
+void launch_transpose(d2g_ctx *, const uint64_t *rows, uint64_t *cols, size_t N, size_t S, size_t Npad, uint32_t *zero2, hipStream_t s) {
+    dim3 grid((unsigned)div_up<size_t>(S, 32), (unsigned)div_up<size_t>(Npad, 32));
+    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, rows, cols, N, S, Npad, zero2);
+}
+
 // ---------------------------------------------------------------- direct compare kernel
 template <bool GTLT, class Store>
 __global__ __launch_bounds__(K2_THREADS) void k2_direct_kernel(const uint64_t *__restrict__ rows, const uint64_t *__restrict__ cols,
@@ -203,9 +212,7 @@ static int cmp_set_load(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits
     // only the DIRECT kernel reads the row-major operand; bit-sliced sets transpose straight from the caller's buffer
     if (set->d_rows) D2G_HIP(ctx, hipMemcpyAsync(set->d_rows, sig_bits_dev, N * S * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
     d2g_timer tm(ctx, &ctx->ev_k2prep, s);
-    dim3 grid((unsigned)div_up<size_t>(S, 32), (unsigned)div_up<size_t>(set->Npad, 32));
-    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, sig_bits_dev, set->d_cols, N, S, set->Npad,
-                       set->algo == D2G_CMP_BITSLICE ? set->d_meta + set->ntb : nullptr);
+    launch_transpose(ctx, sig_bits_dev, set->d_cols, N, S, set->Npad, set->algo == D2G_CMP_BITSLICE ? set->d_meta + set->ntb : nullptr, s);
     int rc = D2G_OK;
     if (set->algo == D2G_CMP_BITSLICE) rc = d2g_bitslice_prepare(ctx, set, s);
     tm.stop();
@@ -219,8 +226,7 @@ static int cmp_set_load(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits
 // exporter sets (d2g_mgpu.hip): transpose the N x S_local slice and prepare it into the export target; timed as "k2prep"
 int d2g_bitslice_prepare_slice(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *rows_dev, hipStream_t s) {
     d2g_timer tm(ctx, &ctx->ev_k2prep, s);
-    dim3 grid((unsigned)div_up<size_t>(set->S, 32), (unsigned)div_up<size_t>(set->Npad, 32));
-    hipLaunchKernelGGL(k2_transpose_kernel, grid, dim3(256), 0, s, rows_dev, set->d_cols, set->N, set->S, set->Npad, set->d_meta + set->ntb);
+    launch_transpose(ctx, rows_dev, set->d_cols, set->N, set->S, set->Npad, set->d_meta + set->ntb, s);
     const int rc = d2g_bitslice_prepare(ctx, set, s);
     tm.stop();
     if (rc) return rc;
@@ -391,6 +397,16 @@ int d2g_cmp_ut_prefill_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1,
     if (set->algo != D2G_CMP_BITSLICE) return D2G_OK;                  // the direct kernel writes every output itself
     D2G_HIP(ctx, hipSetDevice(ctx->device));
     return d2g_bitslice_prefill(ctx, set, r0, r1, neq_out, lut, out, as_stream(stream));
+}
+
+// The output of the next upper-triangle launch, announced AHEAD of the prepare (include/d2g.h): the prepare carries the fill.
+int d2g_cmp_ut_announce_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *neq_out, const float *lut, float *out) {
+    if (!ctx) return D2G_ERR_INVALID;
+    if (int rc = check_rows(ctx, set, r0, r1)) return rc;
+    if (d2g_ut_count(set->N, r0, r1) == 0) return D2G_OK;
+    D2G_CHECK(ctx, (neq_out != nullptr) != (lut != nullptr && out != nullptr), "cmp announce: give the count output, or the table and the float output");
+    if (set->algo != D2G_CMP_BITSLICE || set->borrowed) return D2G_OK;   // the direct kernel writes every output itself; a borrowed operand is never re-prepared
+    return d2g_bitslice_announce(ctx, set, r0, r1, neq_out, lut, out);
 }
 
 int d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *gt, uint32_t *lt, void *stream) {

@@ -362,6 +362,31 @@ __device__ __forceinline__ size_t stream_slot(const uint32_t *meta, int tb) {
     return q;
 }
 
+// ------------------------------------------------------------------ riders
+// The fill of an upper-triangle launch (every output = "no register equal", 4 bytes per pair: 200 MB at config 3, 31 us of pure HBM
+// writes) depends on nothing the prepare computes, and six kernels of the prepare chain are one to forty workgroups waiting out
+// dependent round trips on an otherwise idle chip (column plan, flatten, count, attach, scan, place: 36 us together at config 3).  When the
+// output is announced ahead of the prepare (d2g_cmp_ut_announce_dev) those kernels are launched with extra workgroups BEHIND their own --
+// the dispatcher starts workgroups in index order, the kernel's own work is never queued behind a rider -- each writing one 32 KB piece.
+// (The same fill on a second stream was measured in rounds 4 and 5: the two cross-stream dependencies cost more than the fill.)
+__device__ __forceinline__ void sp_ride(const SpRider &r) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t v = r.vsrc ? r.vsrc[0] : r.vimm;
+    const size_t piece = (size_t)r.piece0 + (blockIdx.x - r.own);
+    const size_t head = min(r.cnt, (size_t)((16 - ((uintptr_t)r.out & 15)) & 15) / 4);   // the output pointer is only 4-byte aligned in general
+    u32x4 *body = reinterpret_cast<u32x4 *>(r.out + head);
+    const size_t nb = (r.cnt - head) / 4;
+    const size_t end = min((piece + 1) * (size_t)2048, nb);
+    for (size_t i = piece * 2048 + threadIdx.x; i < end; i += blockDim.x) body[i] = u32x4{v, v, v, v};
+    if (piece == 0) {
+        if (threadIdx.x < head) r.out[threadIdx.x] = v;
+        const size_t tail0 = head + nb * 4;
+        if (tail0 + threadIdx.x < r.cnt) r.out[tail0 + threadIdx.x] = v;
+    }
+}
+#define SP_RIDE_OR_WORK(r) do { if (blockIdx.x >= (r).own) { sp_ride(r); return; } } while (0)
+constexpr SpRider SP_NO_RIDER{nullptr, 0, nullptr, 0u, 0xFFFFFFFFu, 0u};
+
 // ------------------------------------------------------------------ 1b. column plan
 // One workgroup, a kernel of its own.  (Letting the LAST workgroup of the rank kernel do this -- ticket counter -- was
 // measured: with an agent-scope fence per workgroup the rank kernel went 52 -> 111 us at config 3, every fence writes the
@@ -382,7 +407,8 @@ __device__ __forceinline__ int plane_class(uint32_t d2) { return d2 == 0 ? 1 : 3
 __global__ __launch_bounds__(BS_PLAN_THREADS) void bs_colplan_kernel(uint32_t *__restrict__ colcnt, uint32_t S, int ntb, int nsplit,
                                                                        uint32_t *__restrict__ perm, uint32_t *__restrict__ meta,
                                                                        const uint32_t *__restrict__ status, uint32_t *__restrict__ ex_meta,
-                                                                       uint32_t *__restrict__ ex_status, int sort) {
+                                                                       uint32_t *__restrict__ ex_status, int sort, SpRider rider) {
+    SP_RIDE_OR_WORK(rider);
     __shared__ uint32_t d2s[BS_PLAN_MAXS];
     __shared__ uint16_t perm_s[BS_PLAN_MAXS];
     __shared__ uint32_t cell[32 * (BS_PLAN_MAXS / 64)];   // (class, 64-slot chunk) counts, then their exclusive prefix
@@ -869,6 +895,14 @@ int d2g_bitslice_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
 // overflowed on some column -- see d2g_bitslice_status)
 int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const size_t N = set->N, S = set->S, Npad = set->Npad;
+    // an announced output (d2g_cmp_ut_announce_dev): this prepare's latency-bound kernels carry its fill -- unless the ordering is going to
+    // be skipped (the remembered give-up: the launch will be dense and fill nothing)
+    const bool sparse_path = set->sparse_ok && !set->export_only && !set->want_exchange;
+    set->ride_next = 0; set->ride_total = 0;
+    set->ride_mask = sp_tuning(ctx).ride;
+    if (set->ride_out && sparse_path && set->ride_mask && !sp_will_skip(ctx, set))
+        set->ride_total = (uint32_t)std::min<size_t>(sp_fill_pieces(set->ride_cnt), 0x7FFFFFFFu);
+    if (sp_fill_pieces(set->ride_cnt) > 0x7FFFFFFFu) set->ride_total = 0;
     // the status word meta[ntb] was zeroed by the transpose kernel that filled d_cols (no memset node in the chain)
     {
         const int logTl = set->logT < BS_LOG_TLDS_MAX ? set->logT : BS_LOG_TLDS_MAX;
@@ -888,12 +922,13 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         if (nsplit > 1) D2G_HIP(ctx, hipMemsetAsync(set->d_ids, 0, S * Npad * sizeof(uint32_t), s));
         hipLaunchKernelGGL(kern, dim3((unsigned)(S * nsplit)), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
                            set->d_ids, set->d_colcnt, set->d_meta + set->ntb, tagbits_max, (uint32_t)S, nsplit, nsplit == 1 ? set->d_owner : (uint32_t *)nullptr, set->owner_stride);
-        hipLaunchKernelGGL(bs_colplan_kernel, dim3(1), dim3(BS_PLAN_THREADS), 0, s, set->d_colcnt, (uint32_t)S, set->ntb, nsplit, set->d_perm,
-                           set->d_meta, set->d_meta + set->ntb, set->ex_meta, set->ex_status, sort_columns(ctx) ? 1 : 0);
+        unsigned g; const SpRider rd = sp_take_rider(set, 1, SP_RW_PLAN, false, &g, 1);
+        hipLaunchKernelGGL(bs_colplan_kernel, dim3(g), dim3(BS_PLAN_THREADS), 0, s, set->d_colcnt, (uint32_t)S, set->ntb, nsplit, set->d_perm,
+                           set->d_meta, set->d_meta + set->ntb, set->ex_meta, set->ex_status, sort_columns(ctx) ? 1 : 0, rd);
     }
     dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const bool split = set->logT > BS_LOG_TLDS_MAX && set->nsplit > 1;
-    if (set->sparse_ok && !set->export_only && !set->want_exchange) {
+    if (sparse_path) {
         // sparse path (section 4): the caller's-order stream first (the dense walk and rectangular launches read it), then the families,
         // the pair list and the stream in family order
         // (gathering the ids through d_sperm inside bs_planes_kernel was measured: 74 us instead of 18 at config 3 -- 1024 columns of
@@ -906,9 +941,12 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
         if (int rc = sp_permute(ctx, set, s)) return rc;
         set->srt_valid = true; set->nat_valid = true;
+        if (set->ride_total) { set->prefilled = set->ride_out; set->prefilled_cnt = set->ride_cnt; set->prefilled_pieces = set->ride_next; }   // (the launch fills what is left)
+        set->ride_out = nullptr; set->ride_total = 0;                       // an announcement serves ONE prepare
         D2G_HIP(ctx, hipGetLastError());
         return D2G_OK;
     }
+    set->ride_out = nullptr;
     const int forms = set->export_only ? BS_FORM_EXCHANGE : (BS_FORM_STREAM | (set->want_exchange ? BS_FORM_EXCHANGE : 0));
     hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
                        set->export_only ? set->ex_planes : set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, forms,
@@ -1008,6 +1046,18 @@ int d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, 
 int d2g_bitslice_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout, hipStream_t s) {
     if (eq_out) return sp_prefill(ctx, set, r0, r1, StoreEq{eq_out}, eq_out, s);
     return sp_prefill(ctx, set, r0, r1, StoreLut{fout, lut}, reinterpret_cast<uint32_t *>(fout), s);
+}
+
+int d2g_bitslice_announce(d2g_ctx *, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout) {
+    const size_t cnt = d2g_ut_count(set->N, r0, r1);
+    set->ride_out = nullptr;
+    if (!cnt || !set->sparse_ok) return D2G_OK;
+    // the fill value = Store::value_from_mismatches(S, S): the count 0, or lut[0] (read by the riders when they run)
+    set->ride_out = eq_out ? eq_out : reinterpret_cast<uint32_t *>(fout);
+    set->ride_vsrc = eq_out ? nullptr : reinterpret_cast<const uint32_t *>(lut);
+    set->ride_vimm = 0;
+    set->ride_cnt = cnt;
+    return D2G_OK;
 }
 
 int d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1, uint32_t *eq_out,

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void sp_olink_kernel(const uint32_t *__restric
 // ancestor, so racing with itself is harmless).  Between the two link passes: the uniting pass compares LABELS, and two members of a
 // family the propagation has put under one root still carry different earlier members until this ran (without it every matcher walked
 // to the roots through device-scope loads: 140 us at config 3 instead of 15).
-__global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t N) {
+__global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t N, SpRider rider) {
+    SP_RIDE_OR_WORK(rider);
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
     uint32_t l = (uint32_t)j;
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(256) void sp_flatten_kernel(uint32_t *label, size_t
 // family and are refused; judged by a "matched somebody" flag instead of the counter, a sketch whose one link a racing store undid stayed
 // alone with 45 shared values: 28 resp. 19 stragglers at config 3, a mixed value in most columns.)
 __global__ __launch_bounds__(256) void sp_attach_kernel(uint32_t *__restrict__ root, uint32_t *__restrict__ cnt, const uint32_t *__restrict__ hint, size_t N, size_t Npad,
-                                                        const uint32_t *__restrict__ order) {
+                                                        const uint32_t *__restrict__ order, SpRider rider) {
+    SP_RIDE_OR_WORK(rider);
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= N || order[2]) return;
     if (root[j] != (uint32_t)j || sp_ld(&cnt[j]) != 1u) return;       // under somebody, or others are under it
@@ -267,7 +269,8 @@ __device__ __forceinline__ uint32_t sp_seg_est(uint32_t c) {
 // and a stale label is still an ancestor); a chain that is not at its root after SP_MAX_HOPS hops (long strings of sketches each united
 // with its neighbour only; one chain of 12 000 cost 0.7 ms in its last thread) raises order[2]: the caller's order is kept.
 constexpr int SP_MAX_HOPS = 64;
-__global__ __launch_bounds__(256) void sp_count_kernel(uint32_t *label, uint32_t *__restrict__ root, size_t N, uint32_t *__restrict__ cnt, uint32_t *__restrict__ order) {
+__global__ __launch_bounds__(256) void sp_count_kernel(uint32_t *label, uint32_t *__restrict__ root, size_t N, uint32_t *__restrict__ cnt, uint32_t *__restrict__ order, SpRider rider) {
+    SP_RIDE_OR_WORK(rider);
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = j < N;
     uint32_t r = SP_NONE;
@@ -296,7 +299,8 @@ __global__ __launch_bounds__(256) void sp_count_kernel(uint32_t *label, uint32_t
 // order[0] = 1: the launches walk every tile of the caller's-order operand (one root holds more than half of the sketches, deep label
 // chains, or the segments would cover more than seg_tile_limit tiles -- the sparse kernel costs about twice the plain one per tile)
 __global__ __launch_bounds__(1024) void sp_scan_kernel(uint32_t *__restrict__ cnt, size_t N, uint32_t *__restrict__ order, uint32_t *__restrict__ start, uint32_t *__restrict__ segend, uint32_t seg_tile_limit,
-                                                       uint32_t *__restrict__ gaveup) {
+                                                       uint32_t *__restrict__ gaveup, SpRider rider) {
+    SP_RIDE_OR_WORK(rider);
     // exclusive prefix in place, 8192 counters at a time through LDS (coalesced both ways; a thread scans its eight in LDS)
     __shared__ uint32_t wave_tot[16];
     __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
@@ -367,7 +371,8 @@ __device__ __forceinline__ void sp_segtiles(uint32_t a, uint32_t b, uint32_t CW,
 __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restrict__ root, size_t N, size_t Nstride, uint32_t *__restrict__ cnt,
                                                         uint32_t *__restrict__ sperm, uint32_t *__restrict__ sinv, const uint32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ seg_start, const uint32_t *__restrict__ seg_end, uint32_t CW, uint32_t *__restrict__ gbm,
-                                                        uint2 *__restrict__ posseg) {
+                                                        uint2 *__restrict__ posseg, SpRider rider) {
+    SP_RIDE_OR_WORK(rider);
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = j < N;
     if (!live && j < Nstride) sperm[j] = SP_NONE;
@@ -772,7 +777,7 @@ __device__ __forceinline__ bool sp_dense_mode(const uint32_t *__restrict__ ctl, 
 
 constexpr int SP_FILL_PER_THREAD = 8, SP_FILL_THREADS = 256;
 template <class Store>
-__global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__restrict__ out, size_t cnt, Store store, uint32_t S, const uint32_t *__restrict__ ctl, uint32_t cand) {
+__global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__restrict__ out, size_t cnt, Store store, uint32_t S, const uint32_t *__restrict__ ctl, uint32_t cand, uint32_t piece0) {
     if (ctl && sp_dense_mode(ctl, cand)) return;                    // dense mode: the pair kernel writes every output (ctl == nullptr: an early fill, before the mode is known)
     const uint32_t v = store.value_from_mismatches(S, S);           // the value of "no register equal"
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -781,10 +786,10 @@ __global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__re
     u32x4 *body = reinterpret_cast<u32x4 *>(out + head);
     const size_t nb = (cnt - head) / 4;
     // a workgroup writes ONE contiguous 32 KB piece (8 x 256 16-byte stores), the workgroups in dispatch order: a streaming write
-    const size_t base = (size_t)blockIdx.x * (SP_FILL_THREADS * SP_FILL_PER_THREAD) + threadIdx.x;
+    const size_t base = ((size_t)blockIdx.x + piece0) * (SP_FILL_THREADS * SP_FILL_PER_THREAD) + threadIdx.x;   // (piece0: the pieces before it rode on the prepare's kernels)
 #pragma unroll
     for (int k = 0; k < SP_FILL_PER_THREAD; ++k) { const size_t i = base + (size_t)k * SP_FILL_THREADS; if (i < nb) body[i] = u32x4{v, v, v, v}; }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x + piece0 == 0) {
         if (threadIdx.x < head) out[threadIdx.x] = v;
         const size_t tail0 = head + nb * 4;
         if (tail0 + threadIdx.x < cnt) out[tail0 + threadIdx.x] = v;
@@ -1011,6 +1016,7 @@ struct SpTuning {
     double tile_frac = 0.35;            // D2G_SP_TILE_FRAC: the segments may cover this fraction of all tiles before the dense walk is cheaper
     int olink = 1;                      // D2G_SP_OLINK: 0 = the table form of the link passes even where the rank kernel left an owner per value (tests: the multi-GPU engine's form)
     int emit_big = 0;                   // D2G_SP_EMIT_BIG: sp_emit_kernel counts with two words per value at every N (it does from N = 65 536 on; tests)
+    int ride = 63;                      // D2G_SP_RIDE: which kernels of the prepare carry an announced output's fill (d2g_cmp_ut_announce_dev) -- 1 column plan, 2 flatten, 4 count, 8 attach, 16 scan, 32 place; 0 = none, the launch fills (measurements)
     int remember = 1;                   // D2G_SP_REMEMBER: 0 = every prepare runs the ordering, whatever the last one decided
     size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
     size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
@@ -1026,6 +1032,7 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_SP_OLINK")) v.olink = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_EMIT_BIG")) v.emit_big = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_REMEMBER")) v.remember = std::atoi(e) != 0;
+    if (const char *e = ctx->tune.get("D2G_SP_RIDE")) v.ride = std::atoi(e) & 63;
     if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_LIST_DIV")) { const long d = std::atol(e); if (d >= 1 && d <= (1 << 20)) v.list_div = (size_t)d; }
@@ -1113,6 +1120,26 @@ __global__ void sp_giveup_kernel(uint32_t *__restrict__ order, uint32_t *__restr
     if (threadIdx.x == 0) { order[0] = 1; fullctl[1] = 1; fullctl[3] = cand; }
 }
 
+// ---- riders (sp_ride): the share of an announced output's fill that one hosting kernel of the prepare chain carries.  The weights are the
+// hosts' own durations at config 3 (us): each hides about what it lasts; the last host (place) takes what is left.
+constexpr unsigned SP_RW_PLAN = 6, SP_RW_FLATTEN = 5, SP_RW_COUNT = 5, SP_RW_ATTACH = 5, SP_RW_SCAN = 8, SP_RW_ALL = 35;
+inline size_t sp_fill_pieces(size_t cnt) { return div_up<size_t>(cnt / 4 + 1, (size_t)SP_FILL_THREADS * SP_FILL_PER_THREAD); }
+SpRider sp_take_rider(d2g_cmp_set *set, unsigned own, unsigned weight, bool last, unsigned *grid, int bit) {
+    *grid = own;
+    if (set->ride_next >= set->ride_total || !(set->ride_mask & bit)) return SP_NO_RIDER;
+    const uint32_t left = set->ride_total - set->ride_next;
+    uint32_t n = last ? left : (uint32_t)std::min<uint64_t>(left, ((uint64_t)set->ride_total * weight + SP_RW_ALL - 1) / SP_RW_ALL);
+    n = std::min<uint32_t>(n, 0x7FFFFFFFu - own);
+    const SpRider r{set->ride_out, set->ride_cnt, set->ride_vsrc, set->ride_vimm, own, set->ride_next};
+    set->ride_next += n;
+    *grid = own + n;
+    return r;
+}
+// will the next sp_prepare_order skip the ordering (the remembered give-up)?  Asked BEFORE it, by the prepare that decides whether anything rides
+bool sp_will_skip(const d2g_ctx *ctx, const d2g_cmp_set *set) {
+    return sp_tuning(ctx).remember && set->h_gaveup && *(volatile uint32_t *)set->h_gaveup && ((set->sp_prepares + 1) & 15u) != 0;
+}
+
 // labels -> counting sort -> d_sperm / d_sinv -> pair list + segment tiles.  All on `s`, no host round trip.
 // where the path does not pay (one family, heavy noise, adversarial columns) the ordering that finds it out costs 0.05-0.2 ms
 // per prepare.  The decision is REMEMBERED per set: the kernels that raise order[0] also write a word in host-visible memory; a later
@@ -1121,8 +1148,9 @@ __global__ void sp_giveup_kernel(uint32_t *__restrict__ order, uint32_t *__restr
 // dense walk is always right.
 int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
     const size_t N = set->N, Npad = set->Npad, S = set->ncols;
+    const bool skip = sp_will_skip(ctx, set) && set->ride_total == 0;      // (a prepare that has handed out riders goes through: its place kernel carries the rest of the fill)
     ++set->sp_prepares;
-    if (sp_tuning(ctx).remember && set->h_gaveup && *(volatile uint32_t *)set->h_gaveup && (set->sp_prepares & 15u) != 0) {
+    if (skip) {
         hipLaunchKernelGGL(sp_giveup_kernel, dim3(1), dim3(64), 0, s, set->d_order, set->d_fullctl, (uint32_t)std::min<size_t>(sp_full_candidates(Npad), 0xFFFFFFFFu));
         D2G_HIP(ctx, hipGetLastError());
         set->sp_skipped = true;
@@ -1141,12 +1169,12 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
         if (set->d_owner && !split && tu.olink) {                        // one holder per shared value at hand: the streaming form
             const unsigned nx = (unsigned)div_up<size_t>(N, 1024);
             hipLaunchKernelGGL(sp_olink_kernel<0>, dim3(nx, npair), dim3(256), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_owner, set->owner_stride, 1u, la, set->d_hint);
-            hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
+            { unsigned g; const SpRider rd = sp_take_rider(set, nb, SP_RW_FLATTEN, false, &g, 2); hipLaunchKernelGGL(sp_flatten_kernel, dim3(g), dim3(256), 0, s, la, N, rd); }
             hipLaunchKernelGGL(sp_olink_kernel<1>, dim3(nx, div_up<unsigned>(npair, ustride)), dim3(256), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_owner, set->owner_stride, ustride, la, set->d_hint);
         } else {
             hipLaunchKernelGGL(sp_link_kernel<0>, dim3(npair), dim3(1024), (size_t)cap * 12, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap, 1u,
                                la, set->d_hint);
-            hipLaunchKernelGGL(sp_flatten_kernel, dim3(nb), dim3(256), 0, s, la, N);
+            { unsigned g; const SpRider rd = sp_take_rider(set, nb, SP_RW_FLATTEN, false, &g, 2); hipLaunchKernelGGL(sp_flatten_kernel, dim3(g), dim3(256), 0, s, la, N, rd); }
             hipLaunchKernelGGL(sp_link_kernel<1>, dim3(div_up<unsigned>(npair, ustride)), dim3(1024), (size_t)cap * 8, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, cap, ustride,
                                la, set->d_hint);
         }
@@ -1154,12 +1182,17 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
     const size_t ntile_all = (Npad / 32) * (Npad / BS_CB);
     const uint32_t seg_limit = (uint32_t)std::min<size_t>((size_t)((double)ntile_all * tu.tile_frac), 0x3FFFFFFF);
     // (one single-workgroup kernel for count + scan + place with the counters in LDS was measured at N = 10 000: 25 us against 19 for the three)
-    hipLaunchKernelGGL(sp_count_kernel, dim3(nb), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order);
-    if (tu.link && tu.attach && S >= 2) hipLaunchKernelGGL(sp_attach_kernel, dim3(nb), dim3(256), 0, s, lb, set->d_lcnt, set->d_hint, N, Npad, set->d_order);
+    { unsigned g; const SpRider rd = sp_take_rider(set, nb, SP_RW_COUNT, false, &g, 4); hipLaunchKernelGGL(sp_count_kernel, dim3(g), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order, rd); }
+    if (tu.link && tu.attach && S >= 2) {
+        unsigned g; const SpRider rd = sp_take_rider(set, nb, SP_RW_ATTACH, false, &g, 8);
+        hipLaunchKernelGGL(sp_attach_kernel, dim3(g), dim3(256), 0, s, lb, set->d_lcnt, set->d_hint, N, Npad, set->d_order, rd);
+    }
     const uint32_t CW = (uint32_t)((Npad / BS_CB + 31) / 32);
-    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, set->d_segend, seg_limit, set->d_gaveup);    // la (labels) is dead after the count kernel: it keeps the segment starts
-    hipLaunchKernelGGL(sp_place_kernel, dim3((unsigned)div_up<size_t>(set->Nstride, 256)), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order,
-                       la, set->d_segend, CW, set->d_gbm + 8, reinterpret_cast<uint2 *>(set->d_posseg));
+    { unsigned g; const SpRider rd = sp_take_rider(set, 1, SP_RW_SCAN, false, &g, 16);
+      hipLaunchKernelGGL(sp_scan_kernel, dim3(g), dim3(1024), 0, s, set->d_lcnt, N, set->d_order, la, set->d_segend, seg_limit, set->d_gaveup, rd); }    // la (labels) is dead after the count kernel: it keeps the segment starts
+    { unsigned g; const SpRider rd = sp_take_rider(set, (unsigned)div_up<size_t>(set->Nstride, 256), 0, true, &g, 32);
+      hipLaunchKernelGGL(sp_place_kernel, dim3(g), dim3(256), 0, s, lb, N, set->Nstride, set->d_lcnt, set->d_sperm, set->d_sinv, set->d_order,
+                         la, set->d_segend, CW, set->d_gbm + 8, reinterpret_cast<uint2 *>(set->d_posseg), rd); }
     // (a certificate pass in front -- one thread per (column, sketch) comparing the sketch's segment with that of its value's owner, so that
     // columns where nothing crosses a segment need no workgroup here -- was measured: 17 us for the pass, and the 17 stragglers a clean
     // collection of 10 000 leaves still put a mixed value into a hundred columns, whose workgroups take as long as before: 0.338 vs 0.329 ms)
@@ -1225,9 +1258,9 @@ int sp_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, Store store
     const size_t cnt = d2g_ut_count(set->N, r0, r1);
     if (!cnt || !set->sparse_ok) return D2G_OK;
     hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, SP_FILL_THREADS * SP_FILL_PER_THREAD), (size_t)0x7FFFFFFF)), dim3(SP_FILL_THREADS), 0, s,
-                       out_words, cnt, store, (uint32_t)set->S, (const uint32_t *)nullptr, 0u);
+                       out_words, cnt, store, (uint32_t)set->S, (const uint32_t *)nullptr, 0u, 0u);
     D2G_HIP(ctx, hipGetLastError());
-    set->prefilled = out_words;
+    set->prefilled = out_words; set->prefilled_cnt = cnt; set->prefilled_pieces = (size_t)-1;
     return D2G_OK;
 }
 
@@ -1276,9 +1309,14 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     // workgroups per CU it replaces, whose iterations lie 16 MB apart, reached 4.6: 1105 us).  One store per thread is faster still (722-760 us) but when
     // the launch turns out dense all of its 19 M waves start only to return: 254 us instead of 34
     // (the multi-GPU engine fills a rank's slab at the START of its step, under the exchanges: d2g_bitslice_prefill)
-    if (set->prefilled != out_words)
-        hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)std::min<size_t>(div_up<size_t>(cnt / 4 + 1, SP_FILL_THREADS * SP_FILL_PER_THREAD), (size_t)0x7FFFFFFF)), dim3(SP_FILL_THREADS), 0, s,
-                           out_words, cnt, store, (uint32_t)set->S, ctl, cand32);
+    {
+        // (pieces [0, prefilled_pieces) were written ahead of the launch: all of them by an early fill, some or all by the prepare's riders)
+        const size_t pieces = std::min<size_t>(sp_fill_pieces(cnt), (size_t)0x7FFFFFFF);
+        const size_t done = (set->prefilled == out_words && set->prefilled_cnt == cnt) ? std::min<size_t>(set->prefilled_pieces, pieces) : 0;
+        if (done < pieces)
+            hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)(pieces - done)), dim3(SP_FILL_THREADS), 0, s,
+                               out_words, cnt, store, (uint32_t)set->S, ctl, cand32, (uint32_t)done);
+    }
     set->prefilled = nullptr;
     // a multiple of 8 (every XCD's list gets the same number of workgroups), four times what is resident at once: the lists differ in
     // length, and a workgroup that finds nothing at its index leaves at once -- the dispatcher evens the lists out sub-tile by sub-tile

@@ -381,6 +381,15 @@ int  d2g_cmp_lut_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t 
  * fill (small sets, the direct kernel); harmless when the launch decides for the dense walk (every output is written again). */
 int  d2g_cmp_ut_prefill_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *neq_out_dev,
                             const float *lut_dev, float *out_dev, void *stream);
+/* The same fill with NO launch and NO stream of its own: the caller ANNOUNCES the output of the next upper-triangle launch before the
+ * d2g_cmp_set_update_dev that precedes it, and that prepare's latency-bound kernels (one to forty workgroups each on an idle chip: column
+ * plan, the counting sort of the families) carry the fill as extra workgroups behind their own.  Sequence per step:
+ *     d2g_cmp_ut_announce_dev(ctx, set, r0, r1, ...);  d2g_cmp_set_update_dev(ctx, set, sigs, stream);  d2g_cmp_lut_ut_dev(..., stream);
+ * The announcement serves exactly one prepare; the launch must follow on the prepare's stream with the same rows and output (any other
+ * launch simply fills for itself).  lut_dev must hold the table by the time the prepare runs on its stream.  Nothing is enqueued here.
+ * A no-op for sets that would not fill; D2G_SP_RIDE=0 turns the riding off (the launch fills as before). */
+int  d2g_cmp_ut_announce_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *neq_out_dev,
+                             const float *lut_dev, float *out_dev);
 /* (#a>b, #a<b) counts per pair: needs a set created with D2G_CMP_DIRECT (the raw patterns);
  * required when S is not a power of two in set space */
 int  d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,

@@ -722,6 +722,80 @@ def test_k2_fill_ahead_of_the_launch(gpu_ctx, d2g):
     cs.close()
 
 
+def test_k2_fill_carried_by_the_prepare(gpu_ctx, d2g, oracle):
+    """d2g_cmp_ut_announce_dev: the output of the next upper-triangle launch announced ahead of update_dev -- the prepare's latency-bound
+    kernels carry the fill as extra workgroups, the launch skips its own.  Same output as the plain launch (every word of a buffer
+    pre-set to garbage): counts and table values, a whole triangle and a row range (unaligned output pointer), oracle rows; a matrix
+    whose launch takes the dense walk; the remembered give-up (nothing rides, the launch writes everything); an announcement that the
+    launch does not match (other rows / other output) is simply not used; an announcement serves one prepare only."""
+    import torch
+    N, S = 9_000, 64
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    fam = synth.synthetic_registers(N, S, nclusters=N // 150, seed=18)
+    noisy = synth.add_chance_collisions(fam, 1, seed=19)
+    mats = [fam, noisy, synth.skewed_registers(N, S, seed=9)]           # the last one: dense walk decided on the device
+    lut_np = d2g.epilogue_lut(S, d2g.SIMILARITY, 31)
+    lut = torch.from_numpy(lut_np).to(dev)
+    npairs = N * (N - 1) // 2
+    want = torch.empty(npairs, dtype=torch.int32, device=dev)
+    got = torch.empty(npairs + 3, dtype=torch.int32, device=dev)
+    fgot = torch.empty(npairs + 3, dtype=torch.float32, device=dev)
+    off = _ut_offsets(N)
+    cs = None
+    for k, m in enumerate(mats):
+        bits = np.ascontiguousarray(m).view(np.uint64)
+        t_dev = torch.from_numpy(bits.view(np.int64)).to(dev)
+        if cs is None:
+            cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_BITSLICE, stream=st)
+        else:
+            cs.update_dev(t_dev.data_ptr(), st)
+        cs.eqcount_ut_dev(want.data_ptr(), 0, N, st)                      # the plain launch
+        info = cs.sparse_info(st)
+        assert info["dense_kernel_ran"] == (k == 2), info
+        torch.cuda.synchronize()
+        if k == 0:                                                        # pin the plain launch itself on oracle rows
+            w = want.cpu().numpy().view(np.uint32)
+            for r in (0, 1, 4_499, N - 2):
+                np.testing.assert_array_equal(w[off[r]:off[r + 1]], oracle.eqcounts_rows(bits.view(np.float64), r, r + 1), err_msg=f"row {r}")
+        for rep in range(3):                                              # (the third prepare of the skewed matrix has remembered the give-up)
+            # counts, whole triangle, output pointer 4 bytes past a 16-byte boundary
+            got.fill_(-1)
+            o1 = got[1:1 + npairs]
+            cs.announce_ut_dev(o1.data_ptr(), 0, N)
+            cs.update_dev(t_dev.data_ptr(), st)
+            cs.eqcount_ut_dev(o1.data_ptr(), 0, N, st)
+            torch.cuda.synchronize()
+            assert torch.equal(o1, want), (k, rep)
+            assert int(got[0]) == -1 and int(got[1 + npairs]) == -1, (k, rep)
+        # the table path, a row range
+        r0, r1 = N // 4, N // 4 + 1500
+        cnt = int(off[r1] - off[r0])
+        fgot.fill_(-1.0)
+        o2 = fgot[2:2 + cnt]
+        cs.announce_ut_dev(o2.data_ptr(), r0, r1, lut_dev_ptr=lut.data_ptr())
+        cs.update_dev(t_dev.data_ptr(), st)
+        cs.lut_ut_dev(lut.data_ptr(), o2.data_ptr(), r0, r1, st)
+        torch.cuda.synchronize()
+        assert torch.equal(o2.view(torch.int32), lut[want[int(off[r0]):int(off[r1])].long()].view(torch.int32)), k
+        assert float(fgot[1]) == -1.0 and float(fgot[2 + cnt]) == -1.0, k
+        # announced rows that the launch does not take: the launch fills for itself, and the announced range was (harmlessly) filled
+        got.fill_(-1)
+        cs.announce_ut_dev(got.data_ptr(), 0, 10)
+        cs.update_dev(t_dev.data_ptr(), st)
+        cs.eqcount_ut_dev(got.data_ptr(), 0, N, st)
+        torch.cuda.synchronize()
+        assert torch.equal(got[:npairs], want), k
+        # ... and the next prepare carries nothing: the launch after it still writes every output
+        got.fill_(-1)
+        cs.update_dev(t_dev.data_ptr(), st)
+        cs.eqcount_ut_dev(got.data_ptr(), 0, N, st)
+        torch.cuda.synchronize()
+        assert torch.equal(got[:npairs], want), k
+        del t_dev
+    cs.close()
+
+
 def test_k2_sparse_path_beyond_65535_sketches(gpu_ctx, d2g, oracle):
     """70 000 sketches: the sizes where 16-bit fields end -- the pair-list kernel counts with two words per value from 65 536 sketches
     on, sorted positions, launch rows and segment ends no longer fit 16 bits, the rank kernel walks four hash partitions.  A family

@@ -22,6 +22,7 @@ out = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 cs = ctx.cmp_set_dev(t.data_ptr(), N, S, algo=D.CMP_BITSLICE, stream=st)
 PREFILL = os.environ.get("PREFILL", "0") == "1"       # the launch's fill on a second stream, beside the prepare chain (d2g_cmp_ut_prefill_dev)
+ANNOUNCE = os.environ.get("ANNOUNCE", "1") == "1"     # the launch's output announced ahead of the prepare: its small kernels carry the fill (d2g_cmp_ut_announce_dev)
 main = torch.cuda.current_stream()
 side = torch.cuda.Stream() if PREFILL else None
 ev_done, ev_fill = torch.cuda.Event(), torch.cuda.Event()
@@ -32,6 +33,8 @@ def step():
         side.wait_event(ev_done)                       # the last step's launch has finished with `out`
         cs.prefill_ut_dev(out.data_ptr(), 0, N, lut_dev_ptr=lut.data_ptr(), stream=side.cuda_stream)
         ev_fill.record(side)
+    if ANNOUNCE and not PREFILL:
+        cs.announce_ut_dev(out.data_ptr(), 0, N, lut_dev_ptr=lut.data_ptr())
     cs.update_dev(t.data_ptr(), st)
     if PREFILL:
         main.wait_event(ev_fill)
@@ -45,10 +48,11 @@ for _ in range(3):
 torch.cuda.synchronize()
 ctx.set_timing(True); ctx.kernel_ms("k2")
 t0 = time.perf_counter()
-for _ in range(20):
+STEPS = int(os.environ.get("STEPS", 20))
+for _ in range(STEPS):
     step()
 torch.cuda.synchronize()
-step_ms = (time.perf_counter() - t0) / 20 * 1e3
+step_ms = (time.perf_counter() - t0) / STEPS * 1e3
 n, ms, _ = ctx.kernel_ms("k2")
-print(f"step (prepare + compare) {step_ms:.4f} ms; sparse: {cs.sparse_info(st)}")
+print(f"step (prepare + compare) {step_ms:.4f} ms announce={int(ANNOUNCE)} ride={os.environ.get('D2G_SP_RIDE','63')}; sparse: {cs.sparse_info(st)}")
 print(f"{which} C={os.environ.get('C','-')} N={N} D2G_BS_EXP={os.environ.get('D2G_BS_EXP','0')} planes={cs.planes(st)} pair kernel {ms:.4f} ms over {n} launches")
