@@ -92,7 +92,7 @@ def main():
                 # sparse tiles + pair list (round 5): forced on for these small matrices half of the time -- families found or not
                 # (D2G_SP_LINK=0: the pair list alone), with or without the attach step, any tile budget, a short list (overflow ->
                 # dense walk); the other half takes the default (dense walk below 8192 sketches)
-                for var in ("D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_OLINK", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG"):
+                for var in ("D2G_SP_RIDE", "D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_OLINK", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG"):
                     os.environ.pop(var, None)
                 if rng.random() < 0.5:
                     os.environ["D2G_BS_SPARSE_MIN_N"] = "1"
@@ -137,6 +137,35 @@ def main():
                 else:
                     exp = O.allpairs_ut(sig, card, measure=meas, k=31, nthreads=4)
                 assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+                if os.environ.get("D2G_BS_SPARSE_MIN_N") == "1" and N > 3 and rng.random() < 0.6:
+                    # the announced output (d2g_cmp_ut_announce_dev): any subset of the prepare's small kernels carries the fill, the
+                    # launch finishes it; a row range, a 4-byte aligned output, counts against the oracle; then a launch nobody announced
+                    os.environ["D2G_SP_RIDE"] = str(int(rng.integers(0, 64)))
+                    ctx.reload_tuning()
+                    bits = np.ascontiguousarray(sig.view(np.uint64))
+                    neq = O.eqcounts_ut(sig)
+                    a = int(rng.integers(0, N - 1)); b = int(rng.integers(a + 1, N + 1))
+                    o0, cnt = D.ut_count(N, 0, a), D.ut_count(N, a, b)
+                    off = 4 * int(rng.integers(0, 4))
+                    d_sig, d_out = ctx.malloc(bits.nbytes), ctx.malloc(4 * cnt + 32)
+                    try:
+                        ctx.h2d(d_sig, bits)
+                        cs = ctx.cmp_set_dev(d_sig, N, S, algo=D.CMP_BITSLICE)
+                        for announced in (True, False, True):
+                            ctx.h2d(d_out, np.full(cnt + 8, 0xDEADBEEF, np.uint32))
+                            if announced:
+                                cs.announce_ut_dev(d_out + off, a, b)
+                            cs.update_dev(d_sig)
+                            cs.eqcount_ut_dev(d_out + off, a, b)
+                            back = np.empty(cnt + 8, np.uint32)
+                            ctx.d2h(back, d_out)
+                            q = off // 4
+                            assert np.array_equal(back[q:q + cnt], neq[o0:o0 + cnt]), "announced output"
+                            assert np.all(back[:q] == 0xDEADBEEF) and np.all(back[q + cnt:] == 0xDEADBEEF), "announced output: wrote outside"
+                        cs.close()
+                    finally:
+                        ctx.free(d_sig); ctx.free(d_out)
+                    os.environ.pop("D2G_SP_RIDE", None)
             elif which == "k3":
                 k = int(rng.integers(3, 33)); S = int(rng.choice([16, 100, 256, 2048])); canon = bool(rng.integers(0, 2))
                 thr = float(rng.choice([0, 0, 1, 3]))
