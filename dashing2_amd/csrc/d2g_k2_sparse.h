@@ -767,6 +767,57 @@ __global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restr
     }
 }
 
+// The same permutation THROUGH LDS (round 5, the default): a workgroup takes ONE plane of the caller's-order stream -- (group, plane): its
+// row-coded and its column-coded words, 2 x Nstride -- reads it once, coalesced, into LDS, and every sorted position p fetches the word of sketch sperm[p] from there.  The kernel
+// above lets every wave gather 64 words from 64 different 64-byte sectors of a row no L2 holds for it (eight XCDs, an 18 MB stream): 148 MB of
+// sector traffic for 9 MB of words at config 3.  Planes larger than the LDS (N > ~16 000) are taken in H parts: part h holds the words of the
+// sketches [h part, (h + 1) part) and writes the positions whose sketch lies there.  Non-live planes leave at once (the grid is sized for
+// nbits_cap planes per group: the live count is on the device).  The whole-triangle work lists are built by the workgroups behind the last row.
+// BOTH (N <= ~20 000: both codings of a plane fit the LDS): one workgroup per (group, plane), one pass over sperm serves both codings, the
+// live workgroups of config 3 (224) are resident together -- 13 us against 21 for the gathers (17 with a workgroup per coding: the list
+// building raises the kernel to 80 VGPRs, one 1024-thread workgroup per CU, and 448 live workgroups took two rounds).  Otherwise one
+// workgroup per (group, plane, coding, part): N = 50 000, two parts: 113 us against 126 (both codings in four parts: 136).
+template <bool BOTH>
+__global__ __launch_bounds__(1024) void sp_permute_lds_kernel(const uint32_t *__restrict__ nat, uint32_t *__restrict__ srt, size_t Nstride, const uint32_t *__restrict__ meta,
+                                                              const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ order, SpFullList fl, uint32_t nperm,
+                                                              uint32_t nbits_cap, uint32_t H, uint32_t part) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sp_row[];
+    if (blockIdx.x >= nperm) {
+        const uint32_t lw = blockIdx.x - nperm;
+        if (lw < fl.nwg) sp_list_body<16>(lw, fl.bm, fl.nrb, fl.ncb, fl.CW, 1, fl.tiles, fl.cap, fl.ctl, fl.cand, order, nullptr, fl.N, nullptr, fl.posseg);
+        return;
+    }
+    if (order[0]) return;                                             // the caller's order was kept: nobody reads the sorted stream
+    uint32_t w = blockIdx.x;
+    const uint32_t h = w % H; w /= H;
+    uint32_t coding = 0;
+    if (!BOTH) { coding = w & 1u; w >>= 1; }
+    const int b = (int)(w % nbits_cap), tb = (int)(w / nbits_cap);
+    if (b >= live_planes(meta, tb)) return;
+    // the plane's row-coded words in sp_row[0, part), BOTH: the column-coded ones behind them
+    const size_t rowi = (stream_slot(meta, tb) + (size_t)b) * 2 + coding;
+    const uint32_t *src = nat + rowi * Nstride;
+    uint32_t *dst = srt + rowi * Nstride;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t lo = h * part, hi = (uint32_t)min((size_t)lo + part, Nstride);   // (part and Nstride are multiples of 4, rows start 16-byte aligned)
+    for (uint32_t i = lo + threadIdx.x * 4; i < hi; i += 4096) {
+        *reinterpret_cast<u32x4 *>(&sp_row[i - lo]) = *reinterpret_cast<const u32x4 *>(&src[i]);
+        if (BOTH) *reinterpret_cast<u32x4 *>(&sp_row[part + i - lo]) = *reinterpret_cast<const u32x4 *>(&src[Nstride + i]);
+    }
+    __syncthreads();
+    for (uint32_t p0 = threadIdx.x; p0 < Nstride; p0 += 4096) {
+        uint32_t j[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { const uint32_t p = p0 + x * 1024; j[x] = p < Nstride ? sperm[p] : SP_NONE - 1u; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const uint32_t p = p0 + x * 1024;
+            if (j[x] == SP_NONE) { if (h == 0) { dst[p] = 0; if (BOTH) dst[Nstride + p] = 0; } }
+            else if (j[x] >= lo && j[x] < hi) { dst[p] = sp_row[j[x] - lo]; if (BOTH) dst[Nstride + p] = sp_row[part + j[x] - lo]; }
+        }
+    }
+}
+
 // dense or sparse?  DENSE: the plain pair kernel walks every tile of the caller's-order operand (and writes every output itself);
 // otherwise the output is pre-filled, the sparse kernel walks the list and the pair list is applied.  Dense when the prepare said so
 // (order[0], latched into ctl[1] by the list kernel) or when more than `cand * 0.4` tiles are listed -- the sparse kernel pays for its
@@ -1017,6 +1068,7 @@ struct SpTuning {
     int olink = 1;                      // D2G_SP_OLINK: 0 = the table form of the link passes even where the rank kernel left an owner per value (tests: the multi-GPU engine's form)
     int emit_big = 0;                   // D2G_SP_EMIT_BIG: sp_emit_kernel counts with two words per value at every N (it does from N = 65 536 on; tests)
     int ride = 63;                      // D2G_SP_RIDE: which kernels of the prepare carry an announced output's fill (d2g_cmp_ut_announce_dev) -- 1 column plan, 2 flatten, 4 count, 8 attach, 16 scan, 32 place; 0 = none, the launch fills (measurements)
+    int permute_lds = 1;                // D2G_SP_PERMUTE_LDS: 0 = the sorted stream by per-lane gathers (sp_permute_kernel) instead of rows staged in LDS (measurements)
     int remember = 1;                   // D2G_SP_REMEMBER: 0 = every prepare runs the ordering, whatever the last one decided
     size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
     size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
@@ -1033,6 +1085,7 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_SP_EMIT_BIG")) v.emit_big = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_REMEMBER")) v.remember = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_RIDE")) v.ride = std::atoi(e) & 63;
+    if (const char *e = ctx->tune.get("D2G_SP_PERMUTE_LDS")) v.permute_lds = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_LIST_DIV")) { const long d = std::atol(e); if (d >= 1 && d <= (1 << 20)) v.list_div = (size_t)d; }
@@ -1208,8 +1261,27 @@ int sp_permute(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     // (the sorted stream gathered straight from the ids -- one group per XCD so that the gathers hit its L2 -- instead of permuting the caller's-order
     // stream was measured again in round 5: 42 us against planes 19 + permute 21 at config 3, 208 against 113 at N = 50 000; round 4 without the XCD
     // mapping: 74)
-    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     const size_t nrb = set->Npad / 32, ncb = set->Npad / BS_CB, ntile = nrb * ncb;
+    if (sp_tuning(ctx).permute_lds) {
+        const bool both = set->Nstride * 8 <= 159 * 1024;               // both codings of a plane in the LDS of one workgroup
+        constexpr size_t LDS_PART = 128 * 1024;                         // otherwise: one coding, in parts of at most this
+        const uint32_t H = both ? 1u : (uint32_t)div_up<size_t>(set->Nstride * 4, LDS_PART);
+        const uint32_t part = (uint32_t)(div_up<size_t>(div_up<size_t>(set->Nstride, H), 4) * 4);
+        SpFullList fl{set->d_gbm + 8, (uint32_t)nrb, (uint32_t)ncb, (uint32_t)((ncb + 31) / 32), set->d_tiles_full, (uint32_t)set->tiles_cap, set->d_fullctl,
+                      (uint32_t)std::min<size_t>(sp_full_candidates(set->Npad), 0xFFFFFFFFu), (uint32_t)div_up<size_t>(ntile, 1024), (uint32_t)set->N,
+                      reinterpret_cast<const uint2 *>(set->d_posseg), 0u};
+        const size_t nperm = (size_t)set->ntb * set->nbits_cap * (both ? 1 : 2) * H;
+        set->full_list_valid = nperm + fl.nwg < 0x7FFFFFFFu;
+        if (!set->full_list_valid) fl.nwg = 0;
+        const size_t lds = (size_t)part * (both ? 8 : 4);
+        auto kern = both ? sp_permute_lds_kernel<true> : sp_permute_lds_kernel<false>;
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nperm + fl.nwg)), dim3(1024), lds, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta,
+                           set->d_sperm, set->d_order, fl, (uint32_t)nperm, (uint32_t)set->nbits_cap, H, part);
+        D2G_HIP(ctx, hipGetLastError());
+        return D2G_OK;
+    }
+    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
     SpFullList fl{set->d_gbm + 8, (uint32_t)nrb, (uint32_t)ncb, (uint32_t)((ncb + 31) / 32), set->d_tiles_full, (uint32_t)set->tiles_cap, set->d_fullctl,
                   (uint32_t)std::min<size_t>(sp_full_candidates(set->Npad), 0xFFFFFFFFu), (uint32_t)div_up<size_t>(ntile, 256), (uint32_t)set->N,
                   reinterpret_cast<const uint2 *>(set->d_posseg), (uint32_t)set->ntb};

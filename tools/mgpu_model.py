@@ -133,7 +133,7 @@ def report(d, N, S):
 
         prep_kernels = ("k2_transpose_kernel", "bs_rank_kernel", "bs_colplan_kernel", "bs_planes_kernel")
         order_kernels = ("sp_unpack_kernel", "sp_link_kernel", "sp_flatten_kernel", "sp_attach_kernel", "sp_count_kernel", "sp_scan_kernel",
-                         "sp_place_kernel", "sp_emit_kernel", "sp_permute_kernel")
+                         "sp_place_kernel", "sp_emit_kernel", "sp_permute_kernel", "sp_permute_lds_kernel")
         pair_kernels = ("sp_rows_kernel", "sp_gather_kernel", "sp_rowbm_kernel", "sp_list_kernel", "k2_bitslice_sparse_kernel", "k2_bitslice_kernel")
 
         def launches(names):
