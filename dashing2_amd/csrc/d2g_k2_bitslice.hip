@@ -206,6 +206,9 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
                 hs[i] = h;
             }
         }
+        // (CB = 3 / 4 / 6 under amdgpu_waves_per_eu(8) with the slots packed two per register -- 64 VGPRs, 4-6 spilled -- measured in round 5:
+        // 53.1 -> 56.3 us for CB = 4, step 0.290 -> 0.294 ms.  Without a single candidate (a matrix of unrelated sketches) the kernel takes 38 us:
+        // the confirm phase costs 15 us for ten million candidates whatever its batch size)
         constexpr int CB = 2;                                             // owner fetches in flight per thread
         uint32_t redo = 0;
 #pragma unroll
@@ -360,6 +363,20 @@ __device__ __forceinline__ size_t stream_slot(const uint32_t *meta, int tb) {
     size_t q = 0;
     for (int t = 0; t < tb; ++t) q += (size_t)live_planes(meta, t);     // uniform scalar loop, ntb = S/32 is small
     return q;
+}
+
+// the same sum with ONE round trip: lane t of the calling wave takes group t, the wave adds up (the scalar loop above waits out one
+// scalar load per group: up to 31 dependent round trips in front of a kernel's first store).  Every lane of the wave must be here.
+__device__ __forceinline__ size_t stream_slot_wave(const uint32_t *meta, int tb) {
+    const int lane = threadIdx.x & 63;
+    uint32_t q = 0;
+    for (int t0 = 0; t0 < tb; t0 += 64) {
+        const int t = t0 + lane;
+        uint32_t v = t < tb ? (uint32_t)live_planes(meta, t) : 0u;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        q += v;
+    }
+    return (size_t)__builtin_amdgcn_readfirstlane(q);
 }
 
 // ------------------------------------------------------------------ riders
@@ -520,6 +537,7 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
     const size_t jpos = (size_t)blockIdx.x * 256 + threadIdx.x;   // position in the operand
     const size_t tb = blockIdx.y;
     sp_init_part(si, tb * ((size_t)gridDim.x * 256) + jpos, (size_t)gridDim.x * 256 * gridDim.y);
+    const size_t slot = (forms & BS_FORM_STREAM) ? stream_slot_wave(meta, (int)tb) : 0;     // (every lane still here)
     if (jpos >= Nstride) return;
     // sperm: the operand written in another order -- position p holds sketch sperm[p] (stream form only; unused: the sparse path permutes the finished stream)
     const size_t j = sperm ? (size_t)sperm[jpos] : jpos;          // 0xFFFFFFFF (padding) fails j < N below
@@ -544,7 +562,7 @@ __global__ __launch_bounds__(256) void bs_planes_kernel(const uint32_t *__restri
     // once somebody has asked for it (d2g_bitslice_export: 29 MB of stores per prepare at config 3 that a single GPU never reads)
     uint32_t *dst = planes + tb * (size_t)(nbits_cap + 1) * Nstride + jpos;
     const bool ex = forms & BS_FORM_EXCHANGE, st = forms & BS_FORM_STREAM;
-    uint32_t *sdst = st ? stream + stream_slot(meta, (int)tb) * 2 * Nstride + jpos : nullptr;
+    uint32_t *sdst = st ? stream + slot * 2 * Nstride + jpos : nullptr;
     for (int b = 0; b < nbits; ++b) {
         uint32_t w = 0;
 #pragma unroll

@@ -795,7 +795,7 @@ __global__ __launch_bounds__(1024) void sp_permute_lds_kernel(const uint32_t *__
     const int b = (int)(w % nbits_cap), tb = (int)(w / nbits_cap);
     if (b >= live_planes(meta, tb)) return;
     // the plane's row-coded words in sp_row[0, part), BOTH: the column-coded ones behind them
-    const size_t rowi = (stream_slot(meta, tb) + (size_t)b) * 2 + coding;
+    const size_t rowi = (stream_slot_wave(meta, tb) + (size_t)b) * 2 + coding;
     const uint32_t *src = nat + rowi * Nstride;
     uint32_t *dst = srt + rowi * Nstride;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
