@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k2_transpose_kernel(const uint64_t *__res
     const size_t n0 = (size_t)blockIdx.y * 32, s0 = (size_t)blockIdx.x * 32;
     for (int r = ty; r < 32; r += 8) {
         const size_t n = n0 + r, s = s0 + tx;
-        tile[r][tx] = (n < N && s < S) ? rows[n * S + s] : 0ull;
+        tile[r][tx] = (n < N && s < S) ? __builtin_nontemporal_load(&rows[n * S + s]) : 0ull;   // (read once: non-temporal, see sp_fill_kernel)
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {

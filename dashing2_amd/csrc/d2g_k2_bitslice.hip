@@ -394,7 +394,8 @@ __device__ __forceinline__ void sp_ride(const SpRider &r) {
     u32x4 *body = reinterpret_cast<u32x4 *>(r.out + head);
     const size_t nb = (r.cnt - head) / 4;
     const size_t end = min((piece + 1) * (size_t)2048, nb);
-    for (size_t i = piece * 2048 + threadIdx.x; i < end; i += blockDim.x) body[i] = u32x4{v, v, v, v};
+    // non-temporal stores (as in sp_fill_kernel): 200 MB of output nobody reads again must not push the prepare's working set out of the MALL
+    for (size_t i = piece * 2048 + threadIdx.x; i < end; i += blockDim.x) __builtin_nontemporal_store(u32x4{v, v, v, v}, &body[i]);
     if (piece == 0) {
         if (threadIdx.x < head) r.out[threadIdx.x] = v;
         const size_t tail0 = head + nb * 4;

@@ -61,24 +61,26 @@ __device__ __forceinline__ size_t out_row_base(const PairShape &sh, size_t i) {
     return (i - sh.i_lo) * (sh.j_hi - sh.j_lo) - sh.j_lo;
 }
 
+// (Non-temporal stores for the pair kernels' outputs were measured in round 5 beside the non-temporal fill: sparse pair kernel 42 -> 55 us,
+// step 0.267 -> 0.279 ms at config 3 -- the tiles' 512-byte runs end in partial lines that are merged where the line is cached.  Plain stores.)
 // Store functors: value(eq) is evaluated for all of a lane's outputs first (independent gathers
 // in flight together), put(pos, v) afterwards -- the table and the output never alias.
 struct StoreEq {
     uint32_t *__restrict__ out;
     __device__ __forceinline__ uint32_t value(uint32_t eq) const { return eq; }
     __device__ __forceinline__ void put(size_t pos, uint32_t v) const { out[pos] = v; }
+    __device__ __forceinline__ void put_row(size_t row_base, uint32_t j, uint32_t v) const { (out + row_base)[j] = v; }
     // interior-tile form: value from the mismatch count, store at (uniform row base) + (32-bit lane column)
     __device__ __forceinline__ uint32_t value_from_mismatches(uint32_t S, uint32_t mm) const { return S - mm; }
-    __device__ __forceinline__ void put_row(size_t row_base, uint32_t j, uint32_t v) const { (out + row_base)[j] = v; }
 };
 struct StoreLut {
     float *__restrict__ out; const float *__restrict__ lut;
     __device__ __forceinline__ uint32_t value(uint32_t eq) const { return __float_as_uint(lut[eq]); }
     __device__ __forceinline__ void put(size_t pos, uint32_t v) const { out[pos] = __uint_as_float(v); }
+    __device__ __forceinline__ void put_row(size_t row_base, uint32_t j, uint32_t v) const { (out + row_base)[j] = __uint_as_float(v); }
     __device__ __forceinline__ uint32_t value_from_mismatches(uint32_t S, uint32_t mm) const {
         return __float_as_uint(lut[S - mm]);
     }
-    __device__ __forceinline__ void put_row(size_t row_base, uint32_t j, uint32_t v) const { (out + row_base)[j] = __uint_as_float(v); }
 };
 struct StoreGtLt {
     uint32_t *__restrict__ gt, *__restrict__ lt; uint32_t S;

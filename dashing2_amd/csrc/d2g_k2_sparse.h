@@ -838,8 +838,13 @@ __global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__re
     const size_t nb = (cnt - head) / 4;
     // a workgroup writes ONE contiguous 32 KB piece (8 x 256 16-byte stores), the workgroups in dispatch order: a streaming write
     const size_t base = ((size_t)blockIdx.x + piece0) * (SP_FILL_THREADS * SP_FILL_PER_THREAD) + threadIdx.x;   // (piece0: the pieces before it rode on the prepare's kernels)
+    // NON-TEMPORAL stores (round 5): the fill is 200 MB at config 3 that nobody reads again; written through the MALL (256 MB) it pushed the
+    // prepare's working set out -- columns 82 MB, ids 41, plane streams 37 -- and the caller's matrix with it: the NEXT kernels paid (the transpose
+    // of the next step 46 us instead of 31).  With `nt` stores: step 0.287 -> 0.273 ms, + non-temporal loads of the caller's rows in the transpose 0.267
+    // (unrelated 0.173 -> 0.159, + 1 collision 0.356 -> 0.341, dense walk 0.523 -> 0.517; the sparse pair kernel pays 37 -> 42 us: its tiles' partial lines
+    // now merge in HBM)
 #pragma unroll
-    for (int k = 0; k < SP_FILL_PER_THREAD; ++k) { const size_t i = base + (size_t)k * SP_FILL_THREADS; if (i < nb) body[i] = u32x4{v, v, v, v}; }
+    for (int k = 0; k < SP_FILL_PER_THREAD; ++k) { const size_t i = base + (size_t)k * SP_FILL_THREADS; if (i < nb) __builtin_nontemporal_store(u32x4{v, v, v, v}, &body[i]); }
     if (blockIdx.x + piece0 == 0) {
         if (threadIdx.x < head) out[threadIdx.x] = v;
         const size_t tail0 = head + nb * 4;
