@@ -1239,7 +1239,8 @@ def run_single(args):
                 "traffic": None, "traffic_source": None,                            # this run's own counter passes, below
                 "traffic_note": "HBM bytes of ONE whole step (every kernel of the prepare chain + the compare launch): rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE "
                                 "(separate passes).  `traffic` = read side x read_scale + write side, read_scale calibrated in the same run on the transpose "
-                                "kernel (known 8 S N bytes in); traffic_detail has the raw and the x2 figures and the per-kernel table",
+                                "kernel (known 8 S N bytes in); traffic_detail has the raw and the x2 figures and the per-kernel table (the counter child prepares by CREATING its set, which "
+                                "cannot be announced to: its 200 MB fill shows as sp_fill_kernel there, the same bytes the timed step's riders write)",
                 "kernel": kname, "kernel_ms": step_ev_ms, "launches": nk2, "algorithmic_bytes": alg_bytes,
                 "prep_ms": prep_ms, "compare_ms": k2_ms,
                 "note": ("sparse tiles + pair list: only the 32 x 256 tiles a family's rows and columns meet in are walked, pairs of different families that share a value "
