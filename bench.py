@@ -377,12 +377,12 @@ ENGINE_NAME = {"cabi": "libd2g (d2g_allpairs over d2g_comm: RCCL send/recv group
 # every exchange at (bytes over the busiest link) / 50 GB/s + 6 us per enqueued operation.  ms per phase INSTANCE (a chunked phase
 # runs `chunks` times; fill = the slab pre-filled at the start of the step, under the first exchange; order = the sparse path on the gathered
 # operand -- ids from the planes, families, sort, pair list, sorted stream: REPLICATED on every rank --; pair = launch rows + listed tiles + pair list);
-# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.33 ms; the plain single-GPU path: 2.9 ms);
+# step_ms = the replayed one-job step; speedup vs the model's own 1-rank engine step (3.13 ms; the plain single-GPU path: 2.7 ms);
 # floor_ms (W = 8) = what no schedule of this design goes below (first exchange + one chunk's prepare + the plane exchange + order + pair).
 MODEL_R05 = {
-    2: {"chunks": 4, "pack": 0.092, "fill": 0.435, "x1": 0.512, "prepare": 0.190, "x2": 0.257, "derive": 0.015, "order": 0.451, "pair": 0.311, "step_ms": 4.103, "speedup": 0.79},
-    4: {"chunks": 4, "pack": 0.052, "fill": 0.206, "x1": 0.128, "prepare": 0.102, "x2": 0.129, "derive": 0.016, "order": 0.453, "pair": 0.196, "step_ms": 1.900, "speedup": 1.71},
-    8: {"chunks": 2, "pack": 0.030, "fill": 0.100, "x1": 0.064, "prepare": 0.102, "x2": 0.129, "derive": 0.023, "order": 0.445, "pair": 0.147, "step_ms": 1.253, "speedup": 2.59, "floor_ms": 1.067},
+    2: {"chunks": 4, "pack": 0.089, "fill": 0.455, "x1": 0.512, "prepare": 0.190, "x2": 0.257, "derive": 0.014, "order": 0.425, "pair": 0.311, "step_ms": 4.072, "speedup": 0.77},
+    4: {"chunks": 4, "pack": 0.048, "fill": 0.218, "x1": 0.128, "prepare": 0.101, "x2": 0.129, "derive": 0.014, "order": 0.432, "pair": 0.198, "step_ms": 1.874, "speedup": 1.67},
+    8: {"chunks": 2, "pack": 0.025, "fill": 0.110, "x1": 0.064, "prepare": 0.101, "x2": 0.129, "derive": 0.023, "order": 0.424, "pair": 0.148, "step_ms": 1.240, "speedup": 2.52, "floor_ms": 1.044},
 }
 
 
