@@ -1673,7 +1673,8 @@ def run_single(args):
             "data": "synthetic",
             "config": {"workload": f"{workload}: {N} pre-built OPH sketches, S={S}, all-pairs cmp only, {pairs_total} pairs, float32 Jaccard",
                        "sketches": N, "sketchsize": S, "pairs": pairs_total, "algo": "bitslice" if algo_used == D.CMP_BITSLICE else "direct",
-                       "step": "prepare + pair kernel w/ fused epilogue; sketches resident in HBM",
+                       "step": "announce the output (host-side) + prepare (its small kernels write the output's fill) + pair kernel w/ fused epilogue; "
+                               "sketches resident in HBM; every output word is written in every step",
                        "parallelism": "one GPU"},
             "roofline": roofline, "compute": compute, "cpu_baseline": cpu, "config4_1gpu": config4,
             "dense_walk": (compute.get("matrices") or {}).get("stated, dense walk (D2G_BS_SPARSE=0)"),
