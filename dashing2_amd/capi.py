@@ -153,6 +153,7 @@ SIGNATURES = {
     "d2g_cmp_lut_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "d2g_cmp_ut_prefill_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "d2g_cmp_ut_announce_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "d2g_cmp_set_forget": (_int, [_vp, _vp]),
     "d2g_cmp_gtlt_ut_dev": (_int, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "d2g_cmp_eqcount_rect_dev": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     "d2g_cmp_gtlt_rect_dev": (_int, [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]),
@@ -400,6 +401,8 @@ class Context:
         """-> dict of the D2G_* switches this context resolved (only those that were set)"""
         import json
         n = lib().d2g_ctx_tuning(self._h, None, 0)
+        if n < 0:
+            self._check(n)
         buf = C.create_string_buffer(n + 1)
         lib().d2g_ctx_tuning(self._h, buf, n + 1)
         return json.loads(buf.value.decode())
@@ -753,7 +756,8 @@ class CmpSet:
         n = _sz()
         self.ctx._check(lib().d2g_cmp_set_debug_pairs(self.ctx._h, self._h, stream, buf.ctypes.data, cap, C.byref(n), roots.ctypes.data))
         e = buf[:n.value]
-        return np.stack([(e & np.uint64(0x7FFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)], axis=1), roots
+        e = e[e != np.uint64(0xFFFFFFFFFFFFFFFF)]                     # empty slots (two outsiders of one value in one segment)
+        return np.stack([(e & np.uint64(0xFFFFFFFF)).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32)], axis=1), roots
 
     def planes(self, stream=None):
         """-> (max shared values per column + 1, max id planes of a group, mean id planes); zeros for DIRECT"""
@@ -776,6 +780,10 @@ class CmpSet:
             self.ctx._check(lib().d2g_cmp_ut_prefill_dev(self.ctx._h, self._h, r0, r1, out_dev_ptr, None, None, stream))
         else:
             self.ctx._check(lib().d2g_cmp_ut_prefill_dev(self.ctx._h, self._h, r0, r1, None, lut_dev_ptr, out_dev_ptr, stream))
+
+    def forget(self):
+        """the set's next prepare decides as the first prepare of a new set does (measurements)"""
+        self.ctx._check(lib().d2g_cmp_set_forget(self.ctx._h, self._h))
 
     def announce_ut_dev(self, out_dev_ptr, r0=0, r1=None, lut_dev_ptr=None):
         """the output of the NEXT upper-triangle launch, told ahead of the update_dev that precedes it: the prepare carries the fill"""

@@ -69,9 +69,12 @@ struct d2g_cmp_set {
     bool full_list_valid = false;
     uint32_t *h_gaveup = nullptr, *d_gaveup = nullptr;   // a word of mapped host memory: 1 = the last ordering raised order[0] (the next prepare skips the ordering)
     unsigned sp_prepares = 0; bool sp_skipped = false;
+    bool sp_big = true;               // this prepare enqueued the binned form of the pair list (sp_expect_long_list)
     uint32_t *prefilled = nullptr;        // output the engine filled at the start of its step (d2g_bitslice_prefill): the next sparse launch into it skips its fill
     size_t prefilled_cnt = 0;             // ... and how many outputs that fill covered
     size_t prefilled_pieces = 0;          // ... and how many 32 KB pieces of it are written (all of them after an early fill; what rode on the prepare's kernels otherwise)
+    const uint32_t *prefilled_src = nullptr;   // ... and WHAT was written: the table whose first entry is the fill value (nullptr: the count 0) -- a launch with another store fills for itself
+    bool prefilled_by_riders = false;     // ... by the riders of a prepare (void once another prepare has run) or by d2g_cmp_ut_prefill_dev (valid until the next upper-triangle launch)
     int ride_mask = 0;
     // the output of the NEXT upper-triangle launch, announced ahead of the prepare (d2g_cmp_ut_announce_dev): the prepare's latency-bound
     // kernels (column plan, flatten, count, attach, scan, place: one to forty workgroups each) carry the fill as extra workgroups
@@ -80,6 +83,13 @@ struct d2g_cmp_set {
     const uint32_t *last_ctl = nullptr;   // control words of the last sparse launch (d2g_cmp_set_sparse_info)
     unsigned long long *d_plist = nullptr;   // pair list: (i | j << 32), i < j caller's indices, one entry per (pair in different segments, shared value)
     size_t plist_cap = 0;
+    // the list BINNED by output region (band of 32 rows x chunk of 2^bin_cshift columns): what sp_compose_kernel reads
+    unsigned long long *d_plist2 = nullptr;
+    uint32_t *d_binc = nullptr;                       // [nbins] entries per bin (inside the block the prepare clears)
+    uint32_t *d_bstart = nullptr;                     // [nbins + 1] first entry of every bin in d_plist2
+    uint32_t *d_cw_ents = nullptr; unsigned long long *d_cw_vals = nullptr; size_t cw_ecap = 0, cw_vcap = 0;   // sp_emit_kernel -> sp_pairs_kernel: the holders of the mixed values, one record per value
+    uint32_t *d_hoff = nullptr;                       // [bin_nwg][nbins] where the entries a counting workgroup met go inside their bin (sp_hist_body -> sp_bin_kernel)
+    uint32_t nbins = 0, bin_nch = 0, bin_cshift = 10, bin_nwg = 1;
     size_t tilebm_words = 0, tiles_cap = 0;
 };
 constexpr int BS_CC_STRIDE = 8;
@@ -120,6 +130,7 @@ int  d2g_bitslice_ut(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
 int  d2g_bitslice_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout, hipStream_t s);
 // the output of the next upper-triangle launch, announced before the prepare that precedes it: that prepare carries the fill
 int  d2g_bitslice_announce(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout);
+void d2g_bitslice_forget(d2g_cmp_set *set);
 int  d2g_bitslice_rect(d2g_ctx *ctx, const d2g_cmp_set *set, size_t a0, size_t a1, size_t b0, size_t b1,
                        uint32_t *eq_out, hipStream_t s);
 

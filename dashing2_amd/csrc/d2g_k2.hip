@@ -404,9 +404,17 @@ int d2g_cmp_ut_announce_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1
     if (!ctx) return D2G_ERR_INVALID;
     if (int rc = check_rows(ctx, set, r0, r1)) return rc;
     if (d2g_ut_count(set->N, r0, r1) == 0) return D2G_OK;
-    D2G_CHECK(ctx, (neq_out != nullptr) != (lut != nullptr && out != nullptr), "cmp announce: give the count output, or the table and the float output");
     if (set->algo != D2G_CMP_BITSLICE || set->borrowed) return D2G_OK;   // the direct kernel writes every output itself; a borrowed operand is never re-prepared
+    if (!neq_out && !out) return d2g_bitslice_announce(ctx, set, r0, r1, nullptr, nullptr, nullptr);   // cancel: the set forgets the announced pointer
+    D2G_CHECK(ctx, (neq_out != nullptr) != (lut != nullptr && out != nullptr), "cmp announce: give the count output, or the table and the float output");
     return d2g_bitslice_announce(ctx, set, r0, r1, neq_out, lut, out);
+}
+
+int d2g_cmp_set_forget(d2g_ctx *ctx, d2g_cmp_set *set) {
+    if (!ctx) return D2G_ERR_INVALID;
+    D2G_CHECK(ctx, set && set->ctx == ctx, "cmp_set_forget: set belongs to another context");
+    if (set->algo == D2G_CMP_BITSLICE) d2g_bitslice_forget(set);
+    return D2G_OK;
 }
 
 int d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *gt, uint32_t *lt, void *stream) {

@@ -716,7 +716,7 @@ __global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(D2G_
     constexpr int WR = 4 / WC;                     // waves along rows
     constexpr int RB = WR * IW;                    // rows per workgroup tile
     if (gate && !sp_dense_mode(gate, gate_cand)) {           // launched behind the sparse path: the tile walk only when that decided for the dense walk;
-        sp_patch_lut(pa, sh, store, S, (size_t)blockIdx.x * BS_THREADS + threadIdx.x, (size_t)gridDim.x * BS_THREADS);   // otherwise the pair list's table epilogue
+        sp_patch_lut(pa, sh, store, S, (size_t)blockIdx.x * BS_THREADS + threadIdx.x, (size_t)gridDim.x * BS_THREADS);   // otherwise a short pair list's table epilogue
         return;
     }
     unsigned ct, rt;
@@ -960,7 +960,8 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
         if (int rc = sp_permute(ctx, set, s)) return rc;
         set->srt_valid = true; set->nat_valid = true;
-        if (set->ride_total) { set->prefilled = set->ride_out; set->prefilled_cnt = set->ride_cnt; set->prefilled_pieces = set->ride_next; }   // (the launch fills what is left)
+        if (set->ride_total) { set->prefilled = set->ride_out; set->prefilled_cnt = set->ride_cnt; set->prefilled_pieces = set->ride_next; set->prefilled_src = set->ride_vsrc; set->prefilled_by_riders = true; }   // (the launch fills what is left)
+        else if (set->prefilled_by_riders) set->prefilled = nullptr;        // what an EARLIER prepare's riders wrote is void once another prepare has run (the caller may have used the buffer in between)
         set->ride_out = nullptr; set->ride_total = 0;                       // an announcement serves ONE prepare
         D2G_HIP(ctx, hipGetLastError());
         return D2G_OK;
@@ -1070,6 +1071,7 @@ int d2g_bitslice_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, u
 int d2g_bitslice_announce(d2g_ctx *, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *eq_out, const float *lut, float *fout) {
     const size_t cnt = d2g_ut_count(set->N, r0, r1);
     set->ride_out = nullptr;
+    if (!eq_out && !fout) return D2G_OK;                               // the cancelling form: nothing rides on the next prepare
     if (!cnt || !set->sparse_ok) return D2G_OK;
     // the fill value = Store::value_from_mismatches(S, S): the count 0, or lut[0] (read by the riders when they run)
     set->ride_out = eq_out ? eq_out : reinterpret_cast<uint32_t *>(fout);
@@ -1116,6 +1118,12 @@ int d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     D2G_HIP(ctx, hipGetLastError());
     set->srt_valid = true;
     return D2G_OK;
+}
+
+// the set's remembered decisions forgotten: its next prepare decides as a new set's first prepare does (measurements: bench.py's first_step_ms)
+void d2g_bitslice_forget(d2g_cmp_set *set) {
+    if (set->h_gaveup) { set->h_gaveup[0] = 0; set->h_gaveup[1] = 0; }
+    set->sp_prepares = 0;
 }
 
 // diagnostics of the sparse path's LAST launch on this set (synchronises `s`): see d2g.h

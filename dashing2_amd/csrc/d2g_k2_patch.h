@@ -1,8 +1,12 @@
-// d2g_k2_patch.h -- internal: the pair list's two patch steps (d2g_k2_sparse.h), declared ahead of the kernels that carry them
-// (included by d2g_k2_bitslice.hip inside its anonymous namespace, before k2_bitslice_kernel).
-// ---- the pair list applied to the filled output.  An entry (i < j, caller's indices) belongs to the launch when i is one of its rows;
-// it counts only where the pair's tile is NOT listed (a listed tile was computed exactly, shared values across segments included).
-// Two steps, both folded into kernels the launch runs anyway:
+// d2g_k2_patch.h -- internal: the sub-tile test shared by the work lists and the pair kernel of the sparse path (d2g_k2_sparse.h), and the pair
+// list applied ENTRY BY ENTRY (the form for short lists); included by d2g_k2_bitslice.hip inside its anonymous namespace, before k2_bitslice_kernel.
+// ---- the pair list applied to the filled output, entry by entry.  Short lists only (a clean family collection leaves a few thousand entries,
+// its stragglers'): the host enqueues the binned form (d2g_k2_sparse.h: sp_hist_body / sp_bin_kernel / sp_compose_kernel -- three more kernels'
+// worth of fixed cost, 20 ps per entry) when the set's last prepare left a long list, and this form (no launch of its own, 78 ps per entry)
+// otherwise; plctl[7] says on the device which one applies, so a wrong guess costs time, never exactness.
+// An entry (i < j, caller's indices) belongs to the launch when i is one of its rows; it counts only where the pair's tile is NOT listed (a
+// listed tile is computed exactly by the pair kernel, shared values across segments included).  Two steps, both folded into kernels the
+// launch runs anyway:
 //   add   (tail of k2_bitslice_sparse_kernel: after the fill, beside the tile walk -- the two write disjoint positions)  atomicAdd of 1
 //         onto the filled word.  Store = StoreEq: the filled word is 0 and the sum of the entries IS the count.  Store = StoreLut: the
 //         filled word is the bit pattern of lut[0]; the adder that finds it untouched becomes the position's LEADER (flag in the entry);
@@ -17,6 +21,7 @@ struct SpPatchArgs {
     uint32_t CW, r0, r1; int full;
     uint32_t nwg;                         // workgroups of the sparse pair kernel that share the entries (the others leave without looking at the list)
 };
+constexpr int SP_PL_BINNED = 7;           // plctl[7] != 0: sp_bin_kernel has binned this prepare's list, sp_compose_kernel applies it
 // A sub-tile -- BS_IW launch rows whose first and last sorted positions are pf and pl, 64 BS_JR sorted column positions from c0 -- holds a
 // pair of ONE segment only if the segment of its last row ends behind c0 and the segment of its first row starts before the sub-tile's
 // last column (segments are runs of sorted positions: their starts and ends grow with the position).  A listed tile's other sub-tiles
@@ -44,11 +49,13 @@ template <> struct SpStoreTraits<StoreEq> { static constexpr bool kLeader = fals
 template <> struct SpStoreTraits<StoreLut> { static constexpr bool kLeader = true; };
 template <class Store>
 __device__ __forceinline__ void sp_patch_add(const SpPatchArgs &a, const PairShape &sh, const Store &store, uint32_t S, size_t first, size_t stride) {
+    if (a.plctl[SP_PL_BINNED]) return;                                   // the composed form has applied the list already
     const uint32_t fillv = store.value_from_mismatches(S, S);
     const uint32_t n = min(a.plctl[0], a.plcap);
     uint32_t *out = reinterpret_cast<uint32_t *>(store.out);
     for (size_t k = first; k < n; k += stride) {
         const unsigned long long e = a.plist[k];
+        if (e == ~0ull) continue;                                          // an empty slot (SP_NULL_ENTRY)
         const uint32_t i = (uint32_t)e & 0x7FFFFFFFu, j = (uint32_t)(e >> 32);
         if (!sp_entry_wanted(a, i, j)) continue;
         const uint32_t old = atomicAdd(&out[out_pos(sh, i, j)], 1u);
@@ -56,12 +63,13 @@ __device__ __forceinline__ void sp_patch_add(const SpPatchArgs &a, const PairSha
     }
 }
 __device__ __forceinline__ void sp_patch_lut(const SpPatchArgs &a, const PairShape &sh, const StoreLut &store, uint32_t S, size_t first, size_t stride) {
+    if (a.plctl[SP_PL_BINNED]) return;
     const uint32_t fillv = store.value_from_mismatches(S, S);
     const uint32_t n = min(a.plctl[0], a.plcap);
     uint32_t *out = reinterpret_cast<uint32_t *>(store.out);
     for (size_t k = first; k < n; k += stride) {
         const unsigned long long e = a.plist[k];
-        if (!(e & SP_LEADER)) continue;
+        if (!(e & SP_LEADER) || e == ~0ull) continue;                      // (an empty slot has every bit set)
         a.plist[k] = e & ~SP_LEADER;
         const uint32_t i = (uint32_t)e & 0x7FFFFFFFu, j = (uint32_t)(e >> 32);
         const size_t pos = out_pos(sh, i, j);

@@ -31,6 +31,7 @@
 //          outside listed tiles: atomicAdd of 1 onto the filled word; the first adder of a position is its leader) -> sp_patch_lut (table
 //          epilogue: the leader turns the count into the float) -> the plain pair kernel, which runs only in dense mode.
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
+constexpr unsigned long long SP_NULL_ENTRY = ~0ull;   // an empty slot of the pair list: two outsiders of one value that share a segment (sp_pairs_kernel); every reader skips it
 #ifndef D2G_SP_KS
 #define D2G_SP_KS 4
 #endif
@@ -257,6 +258,21 @@ __device__ __forceinline__ uint32_t sp_block_scan(uint32_t v, uint32_t *wave_tot
     return woff + incl - v;
 }
 
+// the same for three counters packed into 64 bits (sp_emit_kernel: outsiders | pairs with insiders | pairs among outsiders)
+template <int NW>
+__device__ __forceinline__ unsigned long long sp_block_scan64(unsigned long long v, unsigned long long *wave_tot, unsigned long long *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned long long woff = 0, tot = 0;
+    for (int w = 0; w < NW; ++w) { const unsigned long long x = wave_tot[w]; if (w < wave) woff += x; tot += x; }
+    *total = tot;
+    return woff + incl - v;
+}
+
 // tiles a segment of c sketches covers at most, in sixteenths of a tile: (rows + 1) x (columns + 1) tiles from 32 sketches on; smaller
 // ones share their row block with their neighbours (two column tiles for c / 32 of a row block)
 __device__ __forceinline__ uint32_t sp_seg_est(uint32_t c) {
@@ -395,34 +411,50 @@ __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restric
     if (live) { sperm[p] = (uint32_t)j; sinv[j] = p; posseg[p] = uint2{seg_start[r], seg_end[r]}; }
 }
 
+// what sp_emit_kernel hands to sp_pairs_kernel: the holders of every mixed value (the insiders, then the outsiders) in one stream, and one
+// record per value: (index of its first holder in the stream, place of its pairs in the list, insiders, outsiders)
+struct SpColWork { uint32_t *ents; uint4 *vals; uint32_t ecap, vcap; };
+
 // (b): every shared value of every column; the pairs of its holders that lie in different segments go to the pair list.  One workgroup
 // per column; the column's shared values are walked in ranges of at most vcap ranks (2048; 1024 from N = 65 536 on, where the two
 // holder counts of a value no longer fit one word):
 //   pass A  first[q] = segment of the first holder of value q (compare-and-swap); every holder counts itself as INSIDE that segment
 //           or OUTSIDE it.  A value with an outsider is MIXED.  A range without a mixed value -- every clean family column -- is done
-//           after this pass.
-//   scan    the mixed values get consecutive places for their holders: insiders first, outsiders behind them (counts known from pass
-//           A: a range whose entries will not fit is halved BEFORE anything is placed).
-//   pass B  the holders of mixed values are placed: (sketch, segment) at the value's cursors.
-//   pairs   only an OUTSIDER has work: it pairs with every insider of its value (no comparison: they differ by construction) and with
-//           the later outsiders of another segment.  Counted, one reservation per workgroup and range in the global list, written.
-//           (Round 5's first form chained the holders of a value in LDS and let every entry walk the chain behind it: 150 dependent LDS
-//           loads per thread for a family of 150 and one stranger, walked twice -- 25-30 us for ANY column with one mixed value.)
-// A list that is full raises order[0] (dense walk): the list is then longer than a sixteenth of all pairs -- not a sparse matrix.
+//           after this pass.  The counts stay in registers (four values per thread).
+//   scan    the mixed values get consecutive places for their holders: insiders first, outsiders behind them.  The first value whose holders
+//           no longer fit the entry buffer (3072) ends the STEP: the next one starts there, with pass A again (round 5 halved the range
+//           blindly: three A and two B passes per column at ten chance collisions per sketch, two and two now; keeping the counts in
+//           registers across steps -- one A -- was built and costs the kernel 13 VGPRs too many for four workgroups per CU).
+//   pass B  the holders of the step's mixed values are placed: the sketch at the value's cursors.
+//   hand-off  the step's values leave for sp_pairs_kernel: a record per mixed value (where its holders start in the entry stream, where its
+//           pairs go in the list: the places are reserved HERE, one atomic per step), its holders behind a header word.  The pairs
+//           themselves -- an OUTSIDER with every insider of its value, and with the later outsiders of another segment -- are written by
+//           that kernel, flat over all columns (round 5 let every outsider write its own run from inside this kernel's per-column latency
+//           chain: 64 eight-byte stores to 64 different lines per wave instruction, 50 ps per entry).
+// A list that is full raises order[0] (dense walk): the list is then longer than an eighth of all pairs -- not a sparse matrix.
 // A list that will not fit is noticed EARLY: every workgroup adds its column's pair count to plctl[2] and bumps plctl[3]; once 32
 // columns are in, (pairs so far / columns so far) x columns > 1.5 x capacity raises order[0] and everybody stops at its next range.
-constexpr uint32_t SP_EMIT_VCAP = 2048, SP_EMIT_ECAP = 2048, SP_EMIT_T = 512;      // 36 KB of LDS: four workgroups per CU
+#ifndef D2G_SP_EMIT_T
+#define D2G_SP_EMIT_T 512
+#endif
+// 36 KB of LDS, 64 VGPRs: four workgroups per CU.  The entries of a step do not live in LDS (pass B writes them to the stream): a step holds up to
+// 32 768 of them -- every column below 65 536 sketches is ONE step, pass A + pass B
+constexpr uint32_t SP_EMIT_VCAP = 1536, SP_EMIT_ECAP = 32768, SP_EMIT_T = D2G_SP_EMIT_T;
+constexpr uint32_t SP_SEG_MIXED = 0xFFFFFFFEu;     // second[]: the value's outsiders lie in two segments at least
 __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
                                                             const uint32_t *__restrict__ seg, uint32_t *__restrict__ order,
-                                                            unsigned long long *__restrict__ plist, uint32_t *__restrict__ plctl, uint32_t plcap, uint32_t *__restrict__ gaveup, int big) {
+                                                            SpColWork cw, uint32_t *__restrict__ plctl, uint32_t plcap, uint32_t *__restrict__ gaveup, int big) {
     __shared__ uint32_t first[SP_EMIT_VCAP];
-    __shared__ uint32_t cnt[SP_EMIT_VCAP];                // pass A: insiders | outsiders << 16 (big: [q] and [1024 + q]); then the two cursors
-    __shared__ uint32_t mrec[SP_EMIT_ECAP / 2 + 1];       // the range's mixed values: first entry | q << 16 (a mixed value has two entries at least)
-    __shared__ uint32_t ej[SP_EMIT_ECAP], eseg[SP_EMIT_ECAP];
+    __shared__ uint32_t cnt[SP_EMIT_VCAP];                // pass A: insiders | outsiders << 16 (big: [q] and [1024 + q]); in a round: the two cursors of a mixed value
+    __shared__ uint32_t mrec[SP_EMIT_VCAP];               // the step's mixed values: first entry | q << 16
+    __shared__ uint32_t vpre[SP_EMIT_VCAP];               // list slots of the step's mixed values before this one
+    __shared__ uint32_t second[SP_EMIT_VCAP];             // pass A: the second segment met; pass B: the segment of the value's first OUTSIDER, SP_SEG_MIXED once another outsider's differs
+    __shared__ uint32_t cntb[SP_EMIT_VCAP];               // pass A: holders in the second segment
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t s_base, s_stop;
+    __shared__ unsigned long long wave_tot64[16];
+    __shared__ uint32_t s_base, s_ebase, s_vbase, s_stop, s_cut, s_nent, s_nm;
     if (order[0]) return;
-    constexpr uint32_t T = SP_EMIT_T, PER = SP_EMIT_VCAP / T, EPER = SP_EMIT_ECAP / T;
+    constexpr uint32_t T = SP_EMIT_T, PER = (SP_EMIT_VCAP + T - 1) / T;
     const uint32_t tid = threadIdx.x;
     const size_t t = blockIdx.x;
     const uint32_t d2 = colcnt[t * BS_CC_STRIDE + 4];
@@ -430,25 +462,28 @@ __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8)
     // fn(rank, segment, sketch) for every sketch of the column that holds a shared value
     // (keeping a thread's 20 (rank, segment) pairs packed in registers instead of re-reading the column in the second pass was measured at
     // N = 10 000: 89 VGPRs, two workgroups per CU instead of four, 37.9 vs 35.6 us)
+    const uint32_t *__restrict__ col = ids + t * Npad;                 // (uniform base + 32-bit lane offset: N < 2^30)
+    const uint32_t n32 = (uint32_t)N;
     auto for_each_holder = [&](auto &&fn) {
-        for (size_t j0 = 0; j0 < N; j0 += (size_t)T * 8) {
+#pragma unroll 1
+        for (uint32_t j0 = 0; j0 < n32; j0 += T * 8) {
             uint32_t w[8], sg[8];
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
-                const size_t j = j0 + (size_t)x * T + tid;
-                w[x] = j < N ? ids[t * Npad + j] : 0u;
-                sg[x] = j < N ? seg[j] : 0u;
+                const uint32_t j = j0 + (uint32_t)x * T + tid;
+                w[x] = j < n32 ? col[j] : 0u;
+                sg[x] = j < n32 ? seg[j] : 0u;
             }
 #pragma unroll
-            for (int x = 0; x < 8; ++x) { const uint32_t r = sp_rank(w[x], colcnt, t, split != 0); if (r) fn(r, sg[x], (uint32_t)(j0 + (size_t)x * T + tid)); }
+            for (int x = 0; x < 8; ++x) { const uint32_t r = sp_rank(w[x], colcnt, t, split != 0); if (r) fn(r, sg[x], j0 + (uint32_t)x * T + tid); }
         }
     };
     const uint32_t vcap = big ? SP_EMIT_VCAP / 2 : SP_EMIT_VCAP;
-    uint32_t curlen = vcap, colpairs = 0;
+    uint32_t colpairs = 0;
     bool voted = false;
-    for (uint32_t lo = 0; lo < d2;) {
-        const uint32_t len = min(curlen, d2 - lo);
-        for (uint32_t x = tid; x < SP_EMIT_VCAP; x += T) { first[x] = SP_NONE; cnt[x] = 0; }
+    for (uint32_t lo = 0; lo < d2;) {                                // steps of whole values (uniform)
+        const uint32_t len = min(vcap, d2 - lo);
+        for (uint32_t x = tid; x < SP_EMIT_VCAP; x += T) { first[x] = SP_NONE; second[x] = SP_NONE; cnt[x] = 0; cntb[x] = 0; }
         if (tid == 0) s_stop = sp_ld(&order[0]);
         __syncthreads();
         if (s_stop) return;                                           // somebody found that the list will not fit
@@ -459,110 +494,211 @@ __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8)
             const bool outside = old != SP_NONE && old != sgv;
             if (big) atomicAdd(&cnt[outside ? SP_EMIT_VCAP / 2 + q : q], 1u);
             else atomicAdd(&cnt[q], outside ? 0x10000u : 1u);
+            if (outside) { const uint32_t o2 = atomicCAS(&second[q], SP_NONE, sgv); if (o2 == SP_NONE || o2 == sgv) atomicAdd(&cntb[q], 1u); }
         });
         __syncthreads();
-        // a thread's PER values: entries and mixed values, one packed scan (the sums are exact whenever the entries fit: a thread's entry
-        // count is clamped to ECAP + 1, 512 of those stay below 2^21; the 11 bits above count the mixed values -- 2048 of them wrap, with
-        // 4096 entries)
-        uint32_t n0[PER], nO[PER], ve = 0, vm = 0;
+        uint32_t n0[PER], nO[PER];
+        bool mixed_mine = false;
 #pragma unroll
         for (uint32_t x = 0; x < PER; ++x) {
             const uint32_t q = tid * PER + x;
             const uint32_t c = q < len ? cnt[q] : 0u;
             n0[x] = big ? c : (c & 0xFFFFu);
             nO[x] = q < len ? (big ? cnt[SP_EMIT_VCAP / 2 + q] : (c >> 16)) : 0u;
-            if (nO[x]) { ve = min(ve + min(n0[x], SP_EMIT_ECAP + 1u) + min(nO[x], SP_EMIT_ECAP + 1u), SP_EMIT_ECAP + 1u); ++vm; }
+            // the INSIDERS are the larger of the first two segments met (a stranger that happened to come first must not make the family its value's
+            // "outsiders": 75 outsiders are 2 775 candidate pairs among them as soon as a second stranger joins)
+            if (q < len && nO[x]) {
+                const uint32_t nb = cntb[q];
+                if (nb > n0[x]) { first[q] = second[q]; nO[x] += n0[x] - nb; n0[x] = nb; }
+                second[q] = SP_NONE;                                  // pass B: the first outsider's segment
+            }
+            mixed_mine |= nO[x] != 0;
         }
-        uint32_t total;
-        const uint32_t pre = sp_block_scan<T / 64>(ve | (vm << 21), wave_tot, &total);
-        const uint32_t nent = total & 0x1FFFFFu, nm = total >> 21;
-        if (nent == 0) { __syncthreads(); lo += len; continue; }      // (uniform; the barrier: wave_tot is written again by the next range's scan)
-        if (nent > SP_EMIT_ECAP) {
-            if (len == 1) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }     // ONE value with thousands of holders spread over segments: not sparse
-            // the holders that do not fit are a lower bound of what is still to come: (h - 1) pairs at least for h holders of one value
-            if (tid == 0 && (size_t)nent * ncols > (size_t)plcap * 8) { order[0] = 1; *gaveup = 1; }
-            curlen = len / 2;
-            __syncthreads();
-            continue;
-        }
+        if (!__syncthreads_or(mixed_mine)) { lo += len; continue; }   // no mixed value in this range: every clean family column ends here
         {
-            uint32_t eoff = pre & 0x1FFFFFu, moff = pre >> 21;
+            // my values: entries (a thread's sum clamped to ECAP + 1) | mixed values << 32
+            unsigned long long v = 0;
+            uint32_t ve = 0;
 #pragma unroll
             for (uint32_t x = 0; x < PER; ++x) {
-                const uint32_t q = tid * PER + x;
-                if (q >= len) continue;
-                if (!nO[x]) { cnt[q] = SP_NONE; continue; }           // (no cursor word looks like this: positions stay below 2049)
-                mrec[moff++] = eoff | (q << 16);
-                cnt[q] = eoff | ((eoff + n0[x]) << 16);
-                eoff += n0[x] + nO[x];
+                if (!nO[x]) continue;
+                ve = min(ve + min(n0[x], SP_EMIT_ECAP + 1u) + min(nO[x], SP_EMIT_ECAP + 1u), SP_EMIT_ECAP + 1u);
+                v += 1ull << 32;
             }
-        }
-        __syncthreads();
-        for_each_holder([&](uint32_t r, uint32_t sgv, uint32_t j) {
-            if (r <= lo || r > lo + len) return;
-            const uint32_t q = r - 1 - lo;
-            if (cnt[q] == SP_NONE) return;
-            const bool inside = first[q] == sgv;
-            const uint32_t old = atomicAdd(&cnt[q], inside ? 1u : 0x10000u);
-            const uint32_t pos = inside ? (old & 0xFFFFu) : (old >> 16);
-            ej[pos] = j; eseg[pos] = sgv;
-        });
-        __syncthreads();
-        // the outsiders among this thread's entries: (start, mid, end) of their value and the number of their pairs
-        uint32_t est[EPER], emid[EPER], eend[EPER], mine = 0;
+            v |= ve;
+            if (tid == 0) s_cut = len;
+            unsigned long long tot;
+            const unsigned long long run = sp_block_scan64<T / 64>(v, wave_tot64, &tot);
+            // the first value whose holders no longer fit ends the step (the prefix grows with the value: one minimum)
+            if ((uint32_t)tot > SP_EMIT_ECAP) {                        // (uniform; N < 65 536: never)
+                uint32_t e = (uint32_t)run;
 #pragma unroll
-        for (uint32_t x = 0; x < EPER; ++x) {
-            const uint32_t k = tid + x * T;
-            est[x] = emid[x] = eend[x] = 0;
-            if (k >= nent) continue;
-            uint32_t a = 0, b = nm;                                   // the last mixed value that starts at or before k
-            while (b - a > 1) { const uint32_t m = (a + b) >> 1; if ((mrec[m] & 0xFFFFu) <= k) a = m; else b = m; }
-            const uint32_t rec = mrec[a], c = cnt[rec >> 16];
-            const uint32_t mid = c & 0xFFFFu, end = c >> 16;
-            if (k < mid) continue;                                    // an insider
-            est[x] = rec & 0xFFFFu; emid[x] = mid; eend[x] = end;
-            uint32_t np = mid - est[x];
-            const uint32_t s = eseg[k];
-            for (uint32_t e = k + 1; e < end; ++e) np += eseg[e] != s;
-            mine += np;
-        }
-        uint32_t off = sp_block_scan<T / 64>(mine, wave_tot, &total);
-        if (tid == 0) s_base = total ? atomicAdd(&plctl[0], total) : 0u;
-        __syncthreads();
-        if (total) {
-            const uint32_t base = s_base;
-            if ((size_t)base + total > plcap) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }
-            colpairs += total;
-            off += base;
-#pragma unroll
-            for (uint32_t x = 0; x < EPER; ++x) {
-                if (eend[x] == 0) continue;
-                const uint32_t k = tid + x * T, s = eseg[k], a = ej[k];
-                for (uint32_t e = est[x]; e < emid[x]; ++e) {
-                    const uint32_t b = ej[e];
-                    plist[off++] = (unsigned long long)min(a, b) | ((unsigned long long)max(a, b) << 32);
-                }
-                for (uint32_t e = k + 1; e < eend[x]; ++e) {
-                    if (eseg[e] == s) continue;
-                    const uint32_t b = ej[e];
-                    plist[off++] = (unsigned long long)min(a, b) | ((unsigned long long)max(a, b) << 32);
+                for (uint32_t x = 0; x < PER; ++x) {
+                    if (!nO[x]) continue;
+                    e = min(e + min(n0[x], SP_EMIT_ECAP + 1u) + min(nO[x], SP_EMIT_ECAP + 1u), SP_EMIT_ECAP + 1u);
+                    if (e > SP_EMIT_ECAP) { atomicMin(&s_cut, tid * PER + x); break; }
                 }
             }
-        }
-        __syncthreads();
-        lo += len;
-        // this column's pairs so far, scaled to all of its values and all columns: 1.25 times the capacity says the list will not fit.
-        // Eight columns must say so (one odd column must not send a sparse matrix to the dense walk).
-        if (tid == 0 && colpairs && !voted && (size_t)colpairs * d2 / lo * ncols > (size_t)plcap + plcap / 4) {
-            voted = true;
-            if (atomicAdd(&plctl[4], 1u) + 1u >= 8u) { order[0] = 1; *gaveup = 1; }
+            __syncthreads();
+            const uint32_t ncut = s_cut;
+            // places and cursors of the step's mixed values, their pair counts (made a prefix below); the step's totals from whoever owns its end
+            {
+                uint32_t eoff = (uint32_t)run, moff = (uint32_t)(run >> 32);
+#pragma unroll
+                for (uint32_t x = 0; x < PER; ++x) {
+                    const uint32_t q = tid * PER + x;
+                    if (q == ncut) { s_nent = eoff; s_nm = moff; }
+                    if (q >= ncut) continue;
+                    if (!nO[x]) { cnt[q] = SP_NONE; continue; }       // (no cursor word looks like this: positions stay below 32 769)
+                    mrec[moff] = eoff | (q << 16);
+                    vpre[moff] = n0[x] * nO[x];                           // the pairs with insiders (sp_pairs_kernel finds the pairs among the outsiders itself)
+                    cnt[q] = eoff | ((eoff + n0[x]) << 16);
+                    ++moff; eoff += n0[x] + nO[x];
+                }
+                if (ncut >= len && tid == 0) { s_nent = (uint32_t)tot; s_nm = (uint32_t)(tot >> 32); }
+            }
+            __syncthreads();
+            const uint32_t nent = s_nent, nm = s_nm;
+            if (nent == 0) {                                          // (the step's first mixed value alone exceeds the buffer: ONE value with tens of thousands of
+                if (tid == 0) { order[0] = 1; *gaveup = 1; }          // holders spread over segments -- not sparse)
+                return;
+            }
+            if (tid == 0) { s_ebase = atomicAdd(&plctl[5], nent); s_vbase = atomicAdd(&plctl[6], nm); }   // the step's places in the entry stream and among the value records
+            __syncthreads();
+            const uint32_t ebase = s_ebase, vbase = s_vbase;
+            if ((size_t)ebase + nent > cw.ecap || (size_t)vbase + nm > cw.vcap) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }
+            for_each_holder([&](uint32_t r, uint32_t sgv, uint32_t j) {
+                if (r <= lo || r > lo + len) return;
+                const uint32_t q = r - 1 - lo;
+                if (q >= ncut || cnt[q] == SP_NONE) return;
+                const bool inside = first[q] == sgv;
+                const uint32_t old = atomicAdd(&cnt[q], inside ? 1u : 0x10000u);
+                if (!inside) { const uint32_t o2 = atomicCAS(&second[q], SP_NONE, sgv); if (o2 != SP_NONE && o2 != sgv) second[q] = SP_SEG_MIXED; }
+                cw.ents[ebase + (inside ? (old & 0xFFFFu) : (old >> 16))] = j;     // (the step's stream is a few KB written within microseconds: the lines fill up in L2)
+            });
+            __syncthreads();
+            // the list slots of the step's mixed values: the pairs with insiders, + one slot per pair of outsiders where those lie in two segments at
+            // least (sp_pairs_kernel fills such a slot with the pair or, where the two share a segment, with the NULL entry); vpre[m] -> slots before value m
+            uint32_t total;
+            {
+                uint32_t pv[PER], sum = 0;
+#pragma unroll
+                for (uint32_t x = 0; x < PER; ++x) {
+                    const uint32_t m = tid * PER + x;
+                    pv[x] = 0;
+                    if (m < nm) {
+                        const uint32_t q = mrec[m] >> 16, c = cnt[q], nO = (c >> 16) - (c & 0xFFFFu);     // (the cursors have reached the ends of their parts)
+                        pv[x] = vpre[m] + (second[q] == SP_SEG_MIXED ? nO * (nO - 1u) / 2u : 0u);
+                    }
+                    sum += pv[x];
+                }
+                uint32_t pre = sp_block_scan<T / 64>(sum, wave_tot, &total);
+#pragma unroll
+                for (uint32_t x = 0; x < PER; ++x) { const uint32_t m = tid * PER + x; if (m < nm) vpre[m] = pre; pre += pv[x]; }
+            }
+            if (tid == 0) s_base = atomicAdd(&plctl[0], total);
+            __syncthreads();
+            // the step's values leave for sp_pairs_kernel: one record per mixed value -- (first holder in the entry stream, first slot in the list, insiders, outsiders)
+            {
+                const uint32_t base = s_base;
+                if ((size_t)base + total > plcap) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }
+                colpairs += total;
+                for (uint32_t m = tid; m < nm; m += T) {
+                    const uint32_t rec = mrec[m], c = cnt[rec >> 16];
+                    const uint32_t st = rec & 0xFFFFu, mid = c & 0xFFFFu, end = c >> 16;
+                    // (bit 31 of the outsider count: they lie in two segments at least -- pairs among them have slots)
+                    cw.vals[vbase + m] = uint4{ebase + st, base + vpre[m], mid - st, (end - mid) | (second[rec >> 16] == SP_SEG_MIXED ? 0x80000000u : 0u)};
+                }
+            }
+            __syncthreads();
+            lo += ncut;                                               // the next step starts at the first value that did not fit (pass A again from there)
+            // this column's pairs so far, scaled to all of its values and all columns: 1.25 times the capacity says the list will not fit.
+            // Eight columns must say so (one odd column must not send a sparse matrix to the dense walk).
+            if (tid == 0 && colpairs && !voted && (size_t)colpairs * d2 / lo * ncols > (size_t)plcap + plcap / 4) {
+                voted = true;
+                if (atomicAdd(&plctl[4], 1u) + 1u >= 8u) { order[0] = 1; *gaveup = 1; }
+            }
         }
     }
     if (tid == 0 && colpairs) {
         const uint32_t tot = atomicAdd(&plctl[2], colpairs) + colpairs, done = atomicAdd(&plctl[3], 1u) + 1u;
-        if (done >= 32 && (size_t)tot / done * ncols > (size_t)plcap + plcap / 2) { order[0] = 1; *gaveup = 1; }
+        if (done >= 32 && (size_t)tot / done * ncols > (size_t)plcap + plcap / 4 * 2) { order[0] = 1; *gaveup = 1; }
     }
 }
+
+// The pairs of the mixed values sp_emit_kernel left (SpColWork), FLAT: a workgroup takes 32 value records at a time (a few hundred to a few
+// thousand pairs: enough workgroups for the stragglers of a clean collection too), one wave scans their pair counts, and pair p of the chunk
+// is found by a search over that prefix -- every thread writes entries, consecutive threads consecutive ones, whatever the values look like
+// (one family value with one stranger: 75 pairs; a value two strangers share: one).  Four pairs per thread are in flight together (their
+// holders come from the entry stream: two dependent gathers each).  A value's pairs:
+//   outsider o x insider i   at  the place sp_emit_kernel reserved + o * insiders + i     (no comparison: they differ by construction)
+//   outsiders u < v          only where their segments differ: counted here (the same flat walk over the chunk's candidate pairs), ONE
+//                            reservation per chunk, written by a second walk.  Rare -- unless the stranger was a value's FIRST holder and the
+//                            family its "outsiders": then 75 outsiders make 2 775 candidates and no pair.
+#ifndef D2G_SP_PAIRS_CHUNK
+#define D2G_SP_PAIRS_CHUNK 32
+#endif
+constexpr uint32_t SP_PAIRS_CHUNK = D2G_SP_PAIRS_CHUNK;
+struct SpPairs { SpColWork cw; const uint32_t *seg; uint32_t *plctl; unsigned long long *plist; uint32_t plcap; uint32_t *order, *gaveup, *fullctl; };
+// workgroup wg of nwg, NT threads (256 as a kernel of its own; 1024 as extra workgroups of the permute launch: short lists)
+template <uint32_t NT>
+__device__ __forceinline__ void sp_pairs_body(uint32_t wg, uint32_t nwg, const SpPairs &pp) {
+    __shared__ uint32_t pre[SP_PAIRS_CHUNK + 1];
+    __shared__ uint4 rec[SP_PAIRS_CHUNK];
+    const SpColWork &cw = pp.cw;
+    const uint32_t *__restrict__ seg = pp.seg;
+    const uint32_t *__restrict__ plctl = pp.plctl, *__restrict__ order = pp.order;
+    unsigned long long *__restrict__ plist = pp.plist;
+    if (order[0]) return;
+    const uint32_t nv = min(plctl[6], cw.vcap), tid = threadIdx.x;
+    for (uint32_t v0 = wg * SP_PAIRS_CHUNK; v0 < nv; v0 += nwg * SP_PAIRS_CHUNK) {     // (uniform)
+        if (tid < 64) {                                               // one wave: the chunk's records and the prefix of their slot counts
+            uint32_t np = 0;
+            if (tid < SP_PAIRS_CHUNK && v0 + tid < nv) {
+                const uint4 r = cw.vals[v0 + tid];
+                const uint32_t nO = r.w & 0x7FFFFFFFu;
+                rec[tid] = r; np = r.z * nO + ((r.w >> 31) ? nO * (nO - 1u) / 2u : 0u);
+            }
+            uint32_t ip = np;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(ip, o); if ((int)tid >= o) ip += x; }
+            if (tid < SP_PAIRS_CHUNK) pre[tid] = ip - np;
+            if (tid == SP_PAIRS_CHUNK - 1) pre[SP_PAIRS_CHUNK] = ip;
+        }
+        __syncthreads();
+        const uint32_t total = pre[SP_PAIRS_CHUNK];
+        for (uint32_t p0 = tid; p0 < total; p0 += NT * 4) {
+            uint32_t ja[4], jb[4], at[4];
+            bool oo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t p = p0 + NT * k;
+                at[k] = 0xFFFFFFFFu; oo[k] = false;
+                if (p >= total) continue;
+                uint32_t a = 0, b = SP_PAIRS_CHUNK;                   // the last value whose slots start at or before p
+                while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (pre[m] <= p) a = m; else b = m; }
+                const uint4 r = rec[a];
+                const uint32_t x = p - pre[a], nI = r.z, nO = r.w & 0x7FFFFFFFu;
+                at[k] = r.y + x;
+                if (x < nI * nO) {
+                    const uint32_t o = x / nI, i = x - o * nI;
+                    ja[k] = cw.ents[r.x + nI + o]; jb[k] = cw.ents[r.x + i];
+                } else {
+                    uint32_t y = x - nI * nO, u = 0;                  // the y-th pair u < v of the value's outsiders
+                    while (y >= nO - 1u - u) { y -= nO - 1u - u; ++u; }
+                    ja[k] = cw.ents[r.x + nI + u]; jb[k] = cw.ents[r.x + nI + u + 1u + y];
+                    oo[k] = true;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (at[k] != 0xFFFFFFFFu)
+                    plist[at[k]] = (oo[k] && seg[ja[k]] == seg[jb[k]]) ? SP_NULL_ENTRY : ((unsigned long long)min(ja[k], jb[k]) | ((unsigned long long)max(ja[k], jb[k]) << 32));
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_pairs_kernel(SpPairs pp) { sp_pairs_body<256>(blockIdx.x, gridDim.x, pp); }
 
 // launch rows: the sorted positions whose sketch lies in [r0, r1), in sorted order (stable compaction, one workgroup; 8192 positions at
 // a time through LDS so that the loads are coalesced and a thread still owns eight consecutive positions: N = 50 000 80 -> ~12 us)
@@ -723,68 +859,62 @@ __global__ __launch_bounds__(1024) void sp_list_kernel(const uint32_t *__restric
     sp_list_body<16>(blockIdx.x, tilebm, nrb, ncb, CW, full, tiles, cap, ctl, cand, order, ctl_next, N, rowpos, posseg);
 }
 
-// the sorted stream from the caller's-order stream: position p takes the words of sketch sperm[p].  Only the row-coded words and
-// ONE column-coded word per group are gathered (the unique plane is their difference in any plane: r ^ c = u where the register
-// is column-unique, 0 elsewhere); both codings are written.
-// Its first workgroups also leave the work lists of a whole-triangle launch (the segments' tiles are final once sp_emit_kernel is done):
-// such a launch starts with the fill, no list kernel of its own.
-struct SpFullList { const uint32_t *bm; uint32_t nrb, ncb, CW; uint32_t *tiles; uint32_t cap; uint32_t *ctl; uint32_t cand, nwg; uint32_t N; const uint2 *posseg; uint32_t row0; };
-__global__ __launch_bounds__(256) void sp_permute_kernel(const uint32_t *__restrict__ nat, uint32_t *__restrict__ srt, size_t Nstride, const uint32_t *__restrict__ meta,
-                                                         const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ order, SpFullList fl) {
-    // the lists are built by workgroups of their OWN (the last rows of the grid), beside the permutation instead of in front of a few
-    // workgroups' share of it
-    if (blockIdx.y >= fl.row0) {
-        const uint32_t lw = (blockIdx.y - fl.row0) * gridDim.x + blockIdx.x;
-        if (lw < fl.nwg) sp_list_body<4>(lw, fl.bm, fl.nrb, fl.ncb, fl.CW, 1, fl.tiles, fl.cap, fl.ctl, fl.cand, order, nullptr, fl.N, nullptr, fl.posseg);
-        return;
-    }
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int tb = blockIdx.y;
-    if (p >= Nstride || order[0]) return;                             // the caller's order was kept: every launch walks the caller's-order stream (dense), nobody reads this one
-    const int nbits = live_planes(meta, tb);
-    const size_t slot = stream_slot(meta, tb);
-    const uint32_t j = sperm[p];
-    uint32_t *dst = srt + slot * 2 * Nstride + p;
-    if (j == SP_NONE) {
-        for (int b = 0; b < nbits; ++b) { dst[(size_t)(2 * b) * Nstride] = 0; dst[(size_t)(2 * b + 1) * Nstride] = 0; }
-        return;
-    }
-    const uint32_t *src = nat + slot * 2 * Nstride + j;
-    const uint32_t u = src[0] ^ src[Nstride];
-    // four planes' words in flight at a time (a loop over a run-time plane count otherwise waits out one round trip per plane)
-    int b = 0;
-    for (; b + 4 <= nbits; b += 4) {
-        uint32_t w[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) w[x] = src[(size_t)(2 * (b + x)) * Nstride];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { dst[(size_t)(2 * (b + x)) * Nstride] = w[x]; dst[(size_t)(2 * (b + x) + 1) * Nstride] = w[x] | u; }
-    }
-    for (; b < nbits; ++b) {
-        const uint32_t w = src[(size_t)(2 * b) * Nstride];
-        dst[(size_t)(2 * b) * Nstride] = w;
-        dst[(size_t)(2 * b + 1) * Nstride] = w | u;
-    }
+// ---- the pair list, BINNED by where its entries land in the output (round 6).  Round 5 applied the list with one global atomicAdd per entry plus a
+// second "leader" pass for the table epilogue: 78 ps per entry (44 + 35), 0.31 ms for the 3.9 million entries of ten chance collisions per sketch at
+// config 3 -- 1 GB of scattered read-modify-write traffic.  Now the entries are grouped by output region, and ONE workgroup composes a region in LDS
+// and writes it with coalesced stores (sp_compose_kernel):
+//   bin(i, j) = (i >> 5) * nch + (j >> cshift)      band of 32 output rows (i = the smaller caller index = the output row) x chunk of 2^cshift columns
+//   sp_hist_body   (extra workgroups of the permute launch: the list is final once sp_emit_kernel is done)  entries per bin -> binc[]
+//   sp_bin_kernel  exclusive prefix of binc[] (every workgroup for itself, in LDS), then its slice of the list moved to plist2 bin by bin
+//                  (per 8192 entries: LDS counts, one global reservation per bin and workgroup, LDS cursors)
+//   sp_compose_kernel (launch)  one workgroup per bin of the launch's bands: 32 x 1024 counts in LDS (16 bits each), entries added with LDS
+//                  atomics, then every 64-word span that holds a count is written -- table value or count, the fill value beside it.
+// The compose kernel runs BEFORE the pair kernel, which STORES its tiles' non-zero counts: a cross-segment pair inside a walked sub-tile is
+// written twice with the same count (its entries ARE its equal registers, fact (b)), so no entry has to ask whether its tile is listed.
+struct SpBins { uint32_t *binc, *bstart; uint32_t nbins, nch, cshift; };
+__device__ __forceinline__ uint32_t sp_bin_of(const SpBins &bn, unsigned long long e) {
+    return ((uint32_t)e >> 5) * bn.nch + ((uint32_t)(e >> 32) >> bn.cshift);
+}
+// workgroup hw of nhw (1024 threads): its slice of the list counted into LDS, then one global add per bin it met -- whose RETURN value is the
+// place of this workgroup's entries inside the bin (hoff[hw][bin]): sp_bin_kernel's workgroup hw moves the same slice and needs no atomics of its own
+__device__ __forceinline__ uint32_t sp_slice(uint32_t n, uint32_t nhw) { return ((n + nhw - 1) / nhw + 1023u) & ~1023u; }
+__device__ __forceinline__ void sp_hist_body(uint32_t hw, uint32_t nhw, const unsigned long long *__restrict__ plist, const uint32_t *__restrict__ plctl, uint32_t plcap,
+                                             const SpBins &bn, uint32_t *__restrict__ hoff, uint32_t *lds) {
+    const uint32_t n = min(plctl[0], plcap);
+    const uint32_t per = sp_slice(n, nhw), lo = hw * per, hi = min(n, lo + per);
+    if (lo >= hi) return;
+    for (uint32_t b = threadIdx.x; b < bn.nbins; b += 1024) lds[b] = 0;
+    __syncthreads();
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 1024) { const unsigned long long e = plist[k]; if (e != SP_NULL_ENTRY) atomicAdd(&lds[sp_bin_of(bn, e)], 1u); }
+    __syncthreads();
+    uint32_t *mine = hoff + (size_t)hw * bn.nbins;
+    for (uint32_t b = threadIdx.x; b < bn.nbins; b += 1024) { const uint32_t c = lds[b]; if (c) mine[b] = atomicAdd(&bn.binc[b], c); }
 }
 
-// The same permutation THROUGH LDS (round 5, the default): a workgroup takes ONE plane of the caller's-order stream -- (group, plane): its
-// row-coded and its column-coded words, 2 x Nstride -- reads it once, coalesced, into LDS, and every sorted position p fetches the word of sketch sperm[p] from there.  The kernel
-// above lets every wave gather 64 words from 64 different 64-byte sectors of a row no L2 holds for it (eight XCDs, an 18 MB stream): 148 MB of
-// sector traffic for 9 MB of words at config 3.  Planes larger than the LDS (N > ~16 000) are taken in H parts: part h holds the words of the
+// the sorted stream from the caller's-order stream: position p takes the words of sketch sperm[p], THROUGH LDS: a workgroup takes ONE plane of the
+// caller's-order stream -- (group, plane): its row-coded and its column-coded words, 2 x Nstride -- reads it once, coalesced, into LDS, and every
+// sorted position p fetches the word of sketch sperm[p] from there (per-lane gathers from global memory pulled 148 MB of 64-byte sectors for 9 MB
+// of words at config 3: 21 us against 13).  Planes larger than the LDS (N > ~16 000) are taken in H parts: part h holds the words of the
 // sketches [h part, (h + 1) part) and writes the positions whose sketch lies there.  Non-live planes leave at once (the grid is sized for
-// nbits_cap planes per group: the live count is on the device).  The whole-triangle work lists are built by the workgroups behind the last row.
+// nbits_cap planes per group: the live count is on the device).
 // BOTH (N <= ~20 000: both codings of a plane fit the LDS): one workgroup per (group, plane), one pass over sperm serves both codings, the
-// live workgroups of config 3 (224) are resident together -- 13 us against 21 for the gathers (17 with a workgroup per coding: the list
-// building raises the kernel to 80 VGPRs, one 1024-thread workgroup per CU, and 448 live workgroups took two rounds).  Otherwise one
-// workgroup per (group, plane, coding, part): N = 50 000, two parts: 113 us against 126 (both codings in four parts: 136).
+// live workgroups of config 3 (224) are resident together.  Otherwise one workgroup per (group, plane, coding, part).
+// The workgroups behind the permuting ones (a) leave the work lists of a whole-triangle launch (the segments' tiles are final once
+// sp_emit_kernel is done: such a launch has no list kernel of its own) and (b) count the pair list's entries per output bin (sp_hist_body).
+struct SpFullList { const uint32_t *bm; uint32_t nrb, ncb, CW; uint32_t *tiles; uint32_t cap; uint32_t *ctl; uint32_t cand, nwg; uint32_t N; const uint2 *posseg; };
+struct SpHist { const unsigned long long *plist; const uint32_t *plctl; uint32_t plcap, nhw; SpBins bn; uint32_t *hoff; int big; uint32_t *stat_n; };   // big: the workgroups behind the list builders count the list per bin; otherwise they make the pairs (nhw of them)
 template <bool BOTH>
 __global__ __launch_bounds__(1024) void sp_permute_lds_kernel(const uint32_t *__restrict__ nat, uint32_t *__restrict__ srt, size_t Nstride, const uint32_t *__restrict__ meta,
                                                               const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ order, SpFullList fl, uint32_t nperm,
-                                                              uint32_t nbits_cap, uint32_t H, uint32_t part) {
+                                                              uint32_t nbits_cap, uint32_t H, uint32_t part, SpHist hs, SpPairs pp) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sp_row[];
     if (blockIdx.x >= nperm) {
         const uint32_t lw = blockIdx.x - nperm;
-        if (lw < fl.nwg) sp_list_body<16>(lw, fl.bm, fl.nrb, fl.ncb, fl.CW, 1, fl.tiles, fl.cap, fl.ctl, fl.cand, order, nullptr, fl.N, nullptr, fl.posseg);
+        if (lw < fl.nwg) {
+            if (lw == 0 && threadIdx.x == 0 && hs.stat_n) *hs.stat_n = order[0] ? 0xFFFFFFFFu : min(hs.plctl[0], hs.plcap);   // what the host learns for the set's NEXT prepare (mapped memory): the list's length
+            sp_list_body<16>(lw, fl.bm, fl.nrb, fl.ncb, fl.CW, 1, fl.tiles, fl.cap, fl.ctl, fl.cand, order, nullptr, fl.N, nullptr, fl.posseg);
+        } else if (!hs.big) sp_pairs_body<1024>(lw - fl.nwg, hs.nhw, pp);
+        else if (!order[0]) sp_hist_body(lw - fl.nwg, hs.nhw, hs.plist, hs.plctl, hs.plcap, hs.bn, hs.hoff, sp_row);
         return;
     }
     if (order[0]) return;                                             // the caller's order was kept: nobody reads the sorted stream
@@ -849,6 +979,110 @@ __global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__re
         if (threadIdx.x < head) out[threadIdx.x] = v;
         const size_t tail0 = head + nb * 4;
         if (tail0 + threadIdx.x < cnt) out[tail0 + threadIdx.x] = v;
+    }
+}
+
+// the pair list bin by bin (see SpBins).  Every workgroup scans binc[] for itself (<= 16 384 bins: 16 per thread), workgroup 0 leaves the prefix
+// for the compose kernel; then it moves the slice its counting twin (sp_hist_body, same index) counted: the place of an entry is the bin's start
+// + what the twin's atomic returned + an LDS cursor.  One pass, no global atomics.
+constexpr uint32_t SP_BIN_MAX = 16384;
+__global__ __launch_bounds__(1024) void sp_bin_kernel(const unsigned long long *__restrict__ plist, unsigned long long *__restrict__ plist2, uint32_t *__restrict__ plctl,
+                                                      uint32_t plcap, SpBins bn, const uint32_t *__restrict__ hoff, const uint32_t *__restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lc[];     // [nbins] cursors
+    __shared__ uint32_t wave_tot[16];
+    if (order[0]) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) plctl[SP_PL_BINNED] = 1; // the launches' compose kernel applies the list; the entry-by-entry form stands back
+    const uint32_t n = min(plctl[0], plcap);
+    if (n == 0) return;                                               // (binc[] is all zero: no compose workgroup looks at bstart[])
+    const uint32_t tid = threadIdx.x, nb = bn.nbins;
+    const uint32_t per = sp_slice(n, gridDim.x), lo = blockIdx.x * per, hi = min(n, lo + per);
+    if (lo >= hi && blockIdx.x) return;
+    {
+        constexpr uint32_t PER = SP_BIN_MAX / 1024;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (uint32_t x = 0; x < PER; ++x) { const uint32_t b = tid * PER + x; v[x] = b < nb ? bn.binc[b] : 0u; sum += v[x]; }
+        uint32_t total;
+        uint32_t run = sp_block_scan(sum, wave_tot, &total);
+        const uint32_t *mine = hoff + (size_t)blockIdx.x * nb;
+#pragma unroll
+        for (uint32_t x = 0; x < PER; ++x) {
+            const uint32_t b = tid * PER + x;
+            if (b < nb) { lc[b] = run + (v[x] ? mine[b] : 0u); if (blockIdx.x == 0) bn.bstart[b] = run; }   // (mine[b] is garbage where this workgroup met no entry of b: never used)
+            run += v[x];
+        }
+    }
+    __syncthreads();
+    for (uint32_t k0 = lo; k0 < hi; k0 += 4096) {
+        unsigned long long e[4];
+#pragma unroll
+        for (uint32_t x = 0; x < 4; ++x) { const uint32_t k = k0 + x * 1024 + tid; if (k < hi) e[x] = plist[k]; }
+#pragma unroll
+        for (uint32_t x = 0; x < 4; ++x) { const uint32_t k = k0 + x * 1024 + tid; if (k < hi && e[x] != SP_NULL_ENTRY) plist2[atomicAdd(&lc[sp_bin_of(bn, e[x])], 1u)] = e[x]; }
+    }
+}
+
+// One workgroup per (bin of the launch's bands, piece of TW columns of its chunk).  LDS: 32 rows x TW columns of 16-bit counts (a count stays
+// below 2^16: S < 65536); word [r][c mod TW/2] holds column c (low half) and column c + TW/2 (high half), so that the TW/2 threads of a row
+// parity write two coalesced streams.  The workgroup reads its bin's entries (they sit in L2; every piece of a chunk reads them: TW = 256 for
+// chunks of 1024 columns, 1024 for the wider chunks of large N), adds those of its piece with LDS atomics, then
+//   few entries    every entry's thread writes its pair's value (a pair with several entries: several threads, the same value);
+//   otherwise      every 64-word span that holds a count is written -- table value or count, the fill value beside it.
+// Entries of rows outside [r0, r1) -- the edge bands of a partial launch -- are skipped; words that hold no pair (j <= i, j >= N) are not stored.
+struct SpComposeArgs { const unsigned long long *plist2; SpBins bn; const uint32_t *ctl; uint32_t cand, N, S, r0, r1, band0, ppb; };
+template <int TW, class Store>
+__global__ __launch_bounds__(TW) void sp_compose_kernel(SpComposeArgs a, PairShape sh, Store store) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];   // 32 x TW / 2 words
+    __shared__ uint32_t s_cnt;
+    constexpr uint32_t HW = TW / 2;
+    if (sp_dense_mode(a.ctl, a.cand)) return;
+    const uint32_t piece = blockIdx.x % a.ppb, bi = blockIdx.x / a.ppb;
+    const uint32_t band = a.band0 + bi / a.bn.nch, ch = bi % a.bn.nch;
+    const uint32_t bin = band * a.bn.nch + ch;
+    const uint32_t nb = a.bn.binc[bin];
+    if (nb == 0) return;
+    const uint32_t i0 = band * 32u, c0 = (ch << a.bn.cshift) + piece * TW;
+    if (c0 >= a.N || c0 + (TW - 1u) <= i0) return;                    // no column, or every column at or below the band's first row: no pair
+    const unsigned long long *ent = a.plist2 + a.bn.bstart[bin];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t x = tid; x < 32 * HW; x += TW) tile[x] = 0;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t k = tid; k < nb; k += TW) {
+        const unsigned long long e = ent[k];
+        const uint32_t i = (uint32_t)e, c = (uint32_t)(e >> 32) - c0;
+        if (c < (uint32_t)TW && i >= a.r0 && i < a.r1) { atomicAdd(&tile[(i & 31u) * HW + (c % HW)], 1u << (16u * (c / HW))); ++mine; }
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((tid & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    const uint32_t total = s_cnt;
+    if (total == 0) return;
+    const uint32_t fillv = store.value_from_mismatches(a.S, a.S);
+    if (total <= (uint32_t)TW) {                                      // few: one store per entry
+        for (uint32_t k = tid; k < nb; k += TW) {
+            const unsigned long long e = ent[k];
+            const uint32_t i = (uint32_t)e, j = (uint32_t)(e >> 32), c = j - c0;
+            if (c < (uint32_t)TW && i >= a.r0 && i < a.r1) {
+                const uint32_t cnt = (tile[(i & 31u) * HW + (c % HW)] >> (16u * (c / HW))) & 0xFFFFu;
+                store.put_row(out_row_base(sh, i), j, store.value_from_mismatches(a.S, a.S - min(cnt, a.S)));
+            }
+        }
+        return;
+    }
+    const uint32_t par = tid / HW, cl = tid % HW;
+    for (uint32_t r = par; r < 32; r += 2) {
+        const uint32_t i = i0 + r;                                    // (uniform per wave)
+        if (i < a.r0 || i >= a.r1) continue;
+        const uint32_t w = tile[r * HW + cl];
+        const size_t rb = out_row_base(sh, i);
+#pragma unroll
+        for (uint32_t hh = 0; hh < 2; ++hh) {
+            const uint32_t cnt = (w >> (16u * hh)) & 0xFFFFu, j = c0 + cl + HW * hh;
+            if (__ballot(cnt != 0) == 0) continue;                    // nothing in this 64-word span: the fill stays
+            if (j > i && j < a.N) store.put_row(rb, j, cnt ? store.value_from_mismatches(a.S, a.S - min(cnt, a.S)) : fillv);
+        }
     }
 }
 
@@ -1054,7 +1288,8 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         SP_STAMP(4);
     }
     SP_STAMP(5);
-    // the pair list's entries, spread over all workgroups of the launch (those without a tile start here at once)
+    // a SHORT pair list, entry by entry, spread over all workgroups of the launch (those without a tile start here at once); a binned list was
+    // applied by sp_compose_kernel before this kernel
     if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)pa.nwg * (64 * KS));
     SP_STAMP(6);
 }
@@ -1073,11 +1308,12 @@ struct SpTuning {
     int olink = 1;                      // D2G_SP_OLINK: 0 = the table form of the link passes even where the rank kernel left an owner per value (tests: the multi-GPU engine's form)
     int emit_big = 0;                   // D2G_SP_EMIT_BIG: sp_emit_kernel counts with two words per value at every N (it does from N = 65 536 on; tests)
     int ride = 63;                      // D2G_SP_RIDE: which kernels of the prepare carry an announced output's fill (d2g_cmp_ut_announce_dev) -- 1 column plan, 2 flatten, 4 count, 8 attach, 16 scan, 32 place; 0 = none, the launch fills (measurements)
-    int permute_lds = 1;                // D2G_SP_PERMUTE_LDS: 0 = the sorted stream by per-lane gathers (sp_permute_kernel) instead of rows staged in LDS (measurements)
     int remember = 1;                   // D2G_SP_REMEMBER: 0 = every prepare runs the ordering, whatever the last one decided
     size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
     size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
-    size_t list_div = 16;               // D2G_SP_LIST_DIV: the pair list holds at most pairs / list_div entries (and at most 2^27): an entry costs ~130 ps (emit + two patch passes), a pair of the dense walk ~9
+    size_t long_list = 262144;          // D2G_SP_LONG_LIST: a pair list of this many entries or more is binned and composed (the last prepare's length decides)
+    int list_form = 0;                  // D2G_SP_LIST_FORM: 1 = always entry by entry, 2 = always binned (tests, measurements)
+    size_t list_div = 8;                // D2G_SP_LIST_DIV: the pair list holds at most pairs / list_div entries (and at most 2^27)
 };
 SpTuning sp_tuning(const d2g_ctx *ctx) {
     SpTuning v;
@@ -1090,9 +1326,10 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_SP_EMIT_BIG")) v.emit_big = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_REMEMBER")) v.remember = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_RIDE")) v.ride = std::atoi(e) & 63;
-    if (const char *e = ctx->tune.get("D2G_SP_PERMUTE_LDS")) v.permute_lds = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
+    if (const char *e = ctx->tune.get("D2G_SP_LONG_LIST")) { const long long d = std::atoll(e); if (d >= 0) v.long_list = (size_t)d; }
+    if (const char *e = ctx->tune.get("D2G_SP_LIST_FORM")) { const int d = std::atoi(e); if (d >= 0 && d <= 2) v.list_form = d; }
     if (const char *e = ctx->tune.get("D2G_SP_LIST_DIV")) { const long d = std::atol(e); if (d >= 1 && d <= (1 << 20)) v.list_div = (size_t)d; }
     return v;
 }
@@ -1110,8 +1347,18 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     set->tilebm_words = nrb * ((ncb + 31) / 32) + 1;
     set->tiles_cap = nrb * ((ncb + 7) / 8) * 4;                        // per list: the sub-tiles of the tiles of every eighth column block
     set->plist_cap = sp_list_cap(ctx, set->N);
-    // one zero-initialised block per prepare: [counters Npad + 1 | 8 global control words + tile bitmap | order 8 | list control 8 | control words of a whole-triangle launch 16]
-    set->spz_words = (Npad + 1) + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS;
+    // holders of mixed values: h holders make h - 1 pairs at least -- and a column has N holders at most; a record per mixed value: a pair at least each, N / 2 values per column at most
+    set->cw_ecap = std::min<size_t>(std::min<size_t>(2 * set->plist_cap, set->ncols * set->N), 0xFFFFFFF0u);
+    set->cw_vcap = std::min<size_t>(set->plist_cap, set->ncols * (set->N / 2 + 1));
+    // output bins of the pair list: bands of 32 rows x chunks of 2^cshift columns (1024, wider while there would be more than SP_BIN_MAX bins)
+    set->bin_cshift = 10;
+    while (div_up<size_t>(set->N, 32) * div_up<size_t>(set->N, (size_t)1 << set->bin_cshift) > SP_BIN_MAX) ++set->bin_cshift;
+    set->bin_nch = (uint32_t)div_up<size_t>(set->N, (size_t)1 << set->bin_cshift);
+    set->nbins = (uint32_t)(div_up<size_t>(set->N, 32) * set->bin_nch);
+    // one zero-initialised block per prepare: [counters Npad + 1 | 8 global control words + tile bitmap | order 8 | list control 8 | control words of a whole-triangle launch 16 | entries per bin | bin cursors]
+    set->spz_words = (Npad + 1) + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS + (size_t)set->nbins;
+    // the workgroups that count (and then move) the list's entries: one per ~16 384 entries of a full list, at most two per CU
+    set->bin_nwg = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, div_up<size_t>(set->plist_cap, 16384)));
     const size_t planes_words = (size_t)set->ntb * set->nbits_cap + 1;
     hipError_t e;
     if ((e = hipMalloc((void **)&set->d_stream_s, planes_words * 2 * Nstride * sizeof(uint32_t))) != hipSuccess ||
@@ -1128,7 +1375,12 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMalloc((void **)&set->d_spctl, (2 * SP_CTL_WORDS + set->tilebm_words) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_tiles, 8 * std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_tiles_full, 8 * std::max<size_t>(set->tiles_cap, 1) * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&set->d_plist, set->plist_cap * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc((void **)&set->d_plist, set->plist_cap * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_plist2, set->plist_cap * sizeof(unsigned long long))) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_bstart, ((size_t)set->nbins + 1) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_cw_ents, set->cw_ecap * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_cw_vals, set->cw_vcap * 16)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_hoff, (size_t)set->bin_nwg * set->nbins * 4)) != hipSuccess) {
         ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? D2G_ERR_NOMEM : D2G_ERR_HIP;
     }
@@ -1137,6 +1389,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     set->d_order = set->d_gbm + 8 + set->tilebm_words;
     set->d_plctl = set->d_order + 8;
     set->d_fullctl = set->d_plctl + 8;
+    set->d_binc = set->d_fullctl + SP_CTL_WORDS;
     set->d_tilebm = set->d_spctl + 2 * SP_CTL_WORDS;
     if ((e = hipMemset(set->d_spctl, 0, 2 * SP_CTL_WORDS * 4)) != hipSuccess) { ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e); return D2G_ERR_HIP; }
     // one word of host memory the device can write: the remembered give-up (sp_prepare_order)
@@ -1150,6 +1403,12 @@ void sp_free(d2g_cmp_set *set) {
     for (uint32_t **p : {&set->d_stream_s, &set->d_sperm, &set->d_sinv, &set->d_label, &set->d_hint, &set->d_segend, &set->d_posseg, &set->d_spz, &set->d_rowpos, &set->d_rowk,
                          &set->d_rowstream, &set->d_tiles, &set->d_tiles_full, &set->d_spctl}) { (void)hipFree(*p); *p = nullptr; }
     (void)hipFree(set->d_plist); set->d_plist = nullptr;
+    (void)hipFree(set->d_plist2); set->d_plist2 = nullptr;
+    (void)hipFree(set->d_bstart); set->d_bstart = nullptr;
+    (void)hipFree(set->d_hoff); set->d_hoff = nullptr;
+    (void)hipFree(set->d_cw_ents); set->d_cw_ents = nullptr;
+    (void)hipFree(set->d_cw_vals); set->d_cw_vals = nullptr;
+    set->d_binc = nullptr;
     if (set->h_gaveup) { (void)hipHostFree(set->h_gaveup); set->h_gaveup = nullptr; }
     set->d_gaveup = nullptr;
     set->d_tilebm = set->d_lcnt = set->d_gbm = set->d_order = set->d_plctl = set->d_fullctl = nullptr;
@@ -1193,6 +1452,24 @@ SpRider sp_take_rider(d2g_cmp_set *set, unsigned own, unsigned weight, bool last
     *grid = own + n;
     return r;
 }
+SpColWork sp_colwork_of(const d2g_cmp_set *set) {
+    return SpColWork{set->d_cw_ents, reinterpret_cast<uint4 *>(set->d_cw_vals), (uint32_t)std::min<size_t>(set->cw_ecap, 0xFFFFFFFFu), (uint32_t)std::min<size_t>(set->cw_vcap, 0xFFFFFFFFu)};
+}
+SpPairs sp_pairs_of(const d2g_cmp_set *set, const SpColWork &cw, const uint32_t *seg) {
+    return SpPairs{cw, seg, set->d_plctl, set->d_plist, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), set->d_order, set->d_gaveup, set->d_fullctl};
+}
+// long list or short list?  What the set's LAST prepare left (its length, written to mapped host memory by the permute launch) decides which form
+// THIS prepare enqueues: the binned one (pairs kernel, counting workgroups, sp_bin_kernel; the launches compose) from `long_list` entries on, the
+// entry-by-entry one (nothing enqueued for it) below.  A set without history takes the binned form.  Read without synchronisation, like the
+// remembered give-up: a prepare still in flight has not written yet and the one before it decides.  Both forms are exact for any list.
+bool sp_expect_long_list(const d2g_ctx *ctx, const d2g_cmp_set *set) {
+    const SpTuning t = sp_tuning(ctx);
+    if (t.list_form == 1) return false;
+    if (t.list_form == 2) return true;
+    if (!set->h_gaveup || set->sp_prepares == 0) return true;
+    const uint32_t n = ((volatile uint32_t *)set->h_gaveup)[1];
+    return n != 0xFFFFFFFFu && n >= t.long_list;
+}
 // will the next sp_prepare_order skip the ordering (the remembered give-up)?  Asked BEFORE it, by the prepare that decides whether anything rides
 bool sp_will_skip(const d2g_ctx *ctx, const d2g_cmp_set *set) {
     return sp_tuning(ctx).remember && set->h_gaveup && *(volatile uint32_t *)set->h_gaveup && ((set->sp_prepares + 1) & 15u) != 0;
@@ -1207,6 +1484,7 @@ bool sp_will_skip(const d2g_ctx *ctx, const d2g_cmp_set *set) {
 int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
     const size_t N = set->N, Npad = set->Npad, S = set->ncols;
     const bool skip = sp_will_skip(ctx, set) && set->ride_total == 0;      // (a prepare that has handed out riders goes through: its place kernel carries the rest of the fill)
+    set->sp_big = sp_expect_long_list(ctx, set);
     ++set->sp_prepares;
     if (skip) {
         hipLaunchKernelGGL(sp_giveup_kernel, dim3(1), dim3(64), 0, s, set->d_order, set->d_fullctl, (uint32_t)std::min<size_t>(sp_full_candidates(Npad), 0xFFFFFFFFu));
@@ -1254,47 +1532,48 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
     // (a certificate pass in front -- one thread per (column, sketch) comparing the sketch's segment with that of its value's owner, so that
     // columns where nothing crosses a segment need no workgroup here -- was measured: 17 us for the pass, and the 17 stragglers a clean
     // collection of 10 000 leaves still put a mixed value into a hundred columns, whose workgroups take as long as before: 0.338 vs 0.329 ms)
+    const SpColWork cw = sp_colwork_of(set);
     hipLaunchKernelGGL(sp_emit_kernel, dim3((unsigned)S), dim3(SP_EMIT_T), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_colcnt, split ? 1 : 0, lb, set->d_order,
-                       set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), set->d_gaveup, (N >= 65536 || tu.emit_big) ? 1 : 0);
+                       cw, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), set->d_gaveup, (N >= 65536 || tu.emit_big) ? 1 : 0);
+    // the pairs of the mixed values: a kernel of its own when the list is expected to be long (it must be complete before the workgroups that
+    // count it per bin, which ride on the permute launch); otherwise extra workgroups of the permute launch itself (sp_permute)
+    if (set->sp_big) hipLaunchKernelGGL(sp_pairs_kernel, dim3((unsigned)ctx->num_cus * 8), dim3(256), 0, s, sp_pairs_of(set, cw, lb));
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
 
 // the sorted stream + (in the same launch) the work lists of whole-triangle launches
+SpBins sp_bins_of(const d2g_cmp_set *set) { return SpBins{set->d_binc, set->d_bstart, set->nbins, set->bin_nch, set->bin_cshift}; }
+
 int sp_permute(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     if (set->sp_skipped) { set->full_list_valid = true; return D2G_OK; }   // the remembered give-up: sp_giveup_kernel left the control words of a dense launch
     // (the sorted stream gathered straight from the ids -- one group per XCD so that the gathers hit its L2 -- instead of permuting the caller's-order
     // stream was measured again in round 5: 42 us against planes 19 + permute 21 at config 3, 208 against 113 at N = 50 000; round 4 without the XCD
     // mapping: 74)
     const size_t nrb = set->Npad / 32, ncb = set->Npad / BS_CB, ntile = nrb * ncb;
-    if (sp_tuning(ctx).permute_lds) {
-        const bool both = set->Nstride * 8 <= 159 * 1024;               // both codings of a plane in the LDS of one workgroup
-        constexpr size_t LDS_PART = 128 * 1024;                         // otherwise: one coding, in parts of at most this
-        const uint32_t H = both ? 1u : (uint32_t)div_up<size_t>(set->Nstride * 4, LDS_PART);
-        const uint32_t part = (uint32_t)(div_up<size_t>(div_up<size_t>(set->Nstride, H), 4) * 4);
-        SpFullList fl{set->d_gbm + 8, (uint32_t)nrb, (uint32_t)ncb, (uint32_t)((ncb + 31) / 32), set->d_tiles_full, (uint32_t)set->tiles_cap, set->d_fullctl,
-                      (uint32_t)std::min<size_t>(sp_full_candidates(set->Npad), 0xFFFFFFFFu), (uint32_t)div_up<size_t>(ntile, 1024), (uint32_t)set->N,
-                      reinterpret_cast<const uint2 *>(set->d_posseg), 0u};
-        const size_t nperm = (size_t)set->ntb * set->nbits_cap * (both ? 1 : 2) * H;
-        set->full_list_valid = nperm + fl.nwg < 0x7FFFFFFFu;
-        if (!set->full_list_valid) fl.nwg = 0;
-        const size_t lds = (size_t)part * (both ? 8 : 4);
-        auto kern = both ? sp_permute_lds_kernel<true> : sp_permute_lds_kernel<false>;
-        D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(nperm + fl.nwg)), dim3(1024), lds, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta,
-                           set->d_sperm, set->d_order, fl, (uint32_t)nperm, (uint32_t)set->nbits_cap, H, part);
-        D2G_HIP(ctx, hipGetLastError());
-        return D2G_OK;
-    }
-    dim3 grid((unsigned)div_up<size_t>(set->Nstride, 256), (unsigned)set->ntb);
+    const bool both = set->Nstride * 8 <= 156 * 1024;               // both codings of a plane in the LDS of one workgroup
+    constexpr size_t LDS_PART = 128 * 1024;                         // otherwise: one coding, in parts of at most this
+    const uint32_t H = both ? 1u : (uint32_t)div_up<size_t>(set->Nstride * 4, LDS_PART);
+    const uint32_t part = (uint32_t)(div_up<size_t>(div_up<size_t>(set->Nstride, H), 4) * 4);
     SpFullList fl{set->d_gbm + 8, (uint32_t)nrb, (uint32_t)ncb, (uint32_t)((ncb + 31) / 32), set->d_tiles_full, (uint32_t)set->tiles_cap, set->d_fullctl,
-                  (uint32_t)std::min<size_t>(sp_full_candidates(set->Npad), 0xFFFFFFFFu), (uint32_t)div_up<size_t>(ntile, 256), (uint32_t)set->N,
-                  reinterpret_cast<const uint2 *>(set->d_posseg), (uint32_t)set->ntb};
-    const size_t list_rows = div_up<size_t>(fl.nwg, grid.x);            // rows of workgroups that build the lists (one tile per thread)
-    set->full_list_valid = (size_t)set->ntb + list_rows <= 65535;
-    if (!set->full_list_valid) fl.nwg = 0;                              // (a huge N: the launch lists its tiles itself)
-    else grid.y += (unsigned)list_rows;
-    hipLaunchKernelGGL(sp_permute_kernel, grid, dim3(256), 0, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta, set->d_sperm, set->d_order, fl);
+                  (uint32_t)std::min<size_t>(sp_full_candidates(set->Npad), 0xFFFFFFFFu), (uint32_t)div_up<size_t>(ntile, 1024), (uint32_t)set->N,
+                  reinterpret_cast<const uint2 *>(set->d_posseg)};
+    const size_t nperm = (size_t)set->ntb * set->nbits_cap * (both ? 1 : 2) * H;
+    const uint32_t plcap = (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu);
+    // behind the list builders: the workgroups that count a LONG list per output bin, or those that make the pairs of a short one
+    SpHist hs{set->d_plist, set->d_plctl, plcap, set->sp_big ? set->bin_nwg : (uint32_t)ctx->num_cus, sp_bins_of(set), set->d_hoff, set->sp_big ? 1 : 0,
+              set->h_gaveup ? set->d_gaveup + 1 : nullptr};
+    set->full_list_valid = nperm + fl.nwg + hs.nhw < 0x7FFFFFFFu;
+    if (!set->full_list_valid) { ctx->last_error = "bitslice sparse: the permute launch does not fit a grid"; return D2G_ERR_INTERNAL; }
+    const size_t lds = std::max<size_t>((size_t)part * (both ? 8 : 4), set->sp_big ? (size_t)set->nbins * 4 : 0);
+    auto kern = both ? sp_permute_lds_kernel<true> : sp_permute_lds_kernel<false>;
+    D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));   // (+ ~2 KB of static LDS: the list builders, the pairs of a short list)
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nperm + fl.nwg + hs.nhw)), dim3(1024), lds, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta,
+                       set->d_sperm, set->d_order, fl, (uint32_t)nperm, (uint32_t)set->nbits_cap, H, part, hs, sp_pairs_of(set, sp_colwork_of(set), set->d_label + set->Npad));
+    if (set->sp_big) {                                                  // the list, bin by bin (d_plist2): as many workgroups as the counting ones
+        D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_BIN_MAX * 4));
+        hipLaunchKernelGGL(sp_bin_kernel, dim3(hs.nhw), dim3(1024), (size_t)set->nbins * 4, s, set->d_plist, set->d_plist2, set->d_plctl, plcap, hs.bn, set->d_hoff, set->d_order);
+    }
     D2G_HIP(ctx, hipGetLastError());
     return D2G_OK;
 }
@@ -1328,6 +1607,10 @@ __global__ __launch_bounds__(256) void sp_unpack_kernel(const uint32_t *__restri
     for (int x = 0; x < 32; ++x) ids[(tb * 32 + x) * Npad + j] = id[x];
 }
 
+// what a store fills with: the table whose first entry is the value of "no register equal", or nullptr for the count 0
+inline const uint32_t *sp_fill_source(const StoreEq &) { return nullptr; }
+inline const uint32_t *sp_fill_source(const StoreLut &st) { return reinterpret_cast<const uint32_t *>(st.lut); }
+
 // the fill of rows [r0, r1) of the triangle, enqueued NOW (unconditionally: should the launch turn out dense, the pair kernel overwrites it);
 // the next sparse launch on the set that writes to the same output skips its own fill
 template <class Store>
@@ -1338,6 +1621,7 @@ int sp_prefill(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, Store store
                        out_words, cnt, store, (uint32_t)set->S, (const uint32_t *)nullptr, 0u, 0u);
     D2G_HIP(ctx, hipGetLastError());
     set->prefilled = out_words; set->prefilled_cnt = cnt; set->prefilled_pieces = (size_t)-1;
+    set->prefilled_src = sp_fill_source(store); set->prefilled_by_riders = false;
     return D2G_OK;
 }
 
@@ -1389,7 +1673,8 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     {
         // (pieces [0, prefilled_pieces) were written ahead of the launch: all of them by an early fill, some or all by the prepare's riders)
         const size_t pieces = std::min<size_t>(sp_fill_pieces(cnt), (size_t)0x7FFFFFFF);
-        const size_t done = (set->prefilled == out_words && set->prefilled_cnt == cnt) ? std::min<size_t>(set->prefilled_pieces, pieces) : 0;
+        // (the same output, the same rows AND the same fill value -- a count launch into a buffer that was pre-filled for a table launch fills again)
+        const size_t done = (set->prefilled == out_words && set->prefilled_cnt == cnt && set->prefilled_src == sp_fill_source(store)) ? std::min<size_t>(set->prefilled_pieces, pieces) : 0;
         if (done < pieces)
             hipLaunchKernelGGL((sp_fill_kernel<Store>), dim3((unsigned)(pieces - done)), dim3(SP_FILL_THREADS), 0, s,
                                out_words, cnt, store, (uint32_t)set->S, ctl, cand32, (uint32_t)done);
@@ -1399,9 +1684,23 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     // length, and a workgroup that finds nothing at its index leaves at once -- the dispatcher evens the lists out sub-tile by sub-tile
     // (exactly one resident wave of workgroups took as long as the longest list: 52 -> 85 us at config 3)
     const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * 4, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * sp_tuning(ctx).grid_mult) / 8 * 8);
+    // the pair list, composed region by region (before the pair kernel: that one STORES, see SpBins) -- when this set's prepare binned it
+    if (set->sp_big) {
+        const uint32_t band0 = (uint32_t)(r0 >> 5), nband = (uint32_t)((r1 - 1) >> 5) - band0 + 1u;
+        const bool wide = set->bin_cshift > 10;                       // (large N: chunks wider than 1024 columns take 1024-column pieces)
+        const uint32_t tw = wide ? 1024u : 256u, ppb = (1u << set->bin_cshift) / tw;
+        SpComposeArgs ca{set->d_plist2, sp_bins_of(set), ctl, cand32, (uint32_t)N, (uint32_t)set->S, (uint32_t)r0, (uint32_t)r1, band0, ppb};
+        const size_t nwg = (size_t)nband * set->bin_nch * ppb;
+        if (nwg >= 0x7FFFFFFFu) { ctx->last_error = "bitslice sparse: too many compose workgroups"; return D2G_ERR_UNSUPPORTED; }
+        if (wide) {
+            D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_compose_kernel<1024, Store>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            hipLaunchKernelGGL((sp_compose_kernel<1024, Store>), dim3((unsigned)nwg), dim3(1024), 64 * 1024, s, ca, sh, store);
+        } else hipLaunchKernelGGL((sp_compose_kernel<256, Store>), dim3((unsigned)nwg), dim3(256), 16 * 1024, s, ca, sh, store);
+    }
+    // (a short list is applied entry by entry: the pair kernel's tail adds, the gated launch behind it turns the sums into table values)
     SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, set->d_rowpos, reinterpret_cast<const uint2 *>(set->d_posseg), (uint32_t)N, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0, std::min<uint32_t>(grid, (uint32_t)ctx->num_cus * 8u)};
     hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
-    // behind the gate: every tile of the caller's-order operand in dense mode; otherwise the second step of the pair list (table epilogue)
+    // behind the gate: every tile of the caller's-order operand in dense mode; otherwise the second step of a short pair list (table epilogue)
     if (dsh.nvalid_total)
         hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
                            set->Nstride, set->d_meta, set->ntb, (uint32_t)set->S, dsh, store, (const uint32_t *)ctl, cand32, pa);

@@ -152,3 +152,44 @@ def add_chance_collisions(regs, c, seed=4242):
     other = other + (other >= np.arange(N)[:, None])                                          # != j
     out[np.arange(N)[:, None], cols] = regs[other, cols]
     return out
+
+
+def family_collection(nfam, per_fam, L, seed=0xFA17, rate_lo=0.0005, rate_hi=0.03, nseg=0, seg_len=1500, segs_per_family=0):
+    """A collection of RELATED GENOMES (not planted registers): `nfam` families of `per_fam` genomes of `L` bases.  A family is a random base genome
+    (random_genome) and its members are copies with per-base substitutions at a member-specific rate, log-uniform in [rate_lo, rate_hi] (mutate_sparse).
+    Conserved segments (nseg > 0): `nseg` random sequences of `seg_len` bases exist in the collection; every family's base genome carries `segs_per_family`
+    of them at random positions (drawn without replacement), so that genomes of DIFFERENT families share the k-mers of a segment they both carry -- what
+    mobile elements, rRNA operons and other conserved genes do to real collections.  Random 31-mers of different random genomes practically never
+    collide, so without segments the sketches of different families share nothing.
+    Yields (family index, name, genome as a uint8 ASCII array) in the order family 0 member 0, family 1 member 0, ... (families interleaved, the way
+    synthetic_registers deals its clusters)."""
+    rng = np.random.default_rng(seed)
+    segs = [random_genome(1_000_000 + s, seg_len, seed=seed) for s in range(nseg)]
+    bases = []
+    for f in range(nfam):
+        g = random_genome(f, L, seed=seed + 7).copy()
+        if nseg and segs_per_family:
+            for s in rng.choice(nseg, size=min(segs_per_family, nseg), replace=False):
+                p = int(rng.integers(0, max(1, L - seg_len)))
+                g[p:p + seg_len] = segs[s][:max(0, min(seg_len, L - p))]
+        bases.append(g)
+    rates = np.exp(rng.uniform(np.log(rate_lo), np.log(rate_hi), size=(per_fam, nfam)))
+    for m in range(per_fam):
+        for f in range(nfam):
+            yield f, "f%03d_m%03d" % (f, m), mutate_sparse(bases[f], float(rates[m, f]), seed=int(rng.integers(1 << 62)))
+
+
+def mutate_sparse(genome, rate, seed):
+    """per-base substitution with probability `rate` (always to a different base); draws the mutated POSITIONS (binomial count, then positions with
+    replacement: a position hit twice mutates once) instead of one uniform per base -- 200 kbp at 1 % in ~0.1 ms"""
+    rng = np.random.default_rng(seed)
+    g = genome.copy()
+    n = int(rng.binomial(g.size, rate))
+    if n == 0:
+        return g
+    pos = np.unique(rng.integers(0, g.size, size=n))
+    lut = np.zeros(256, np.uint8)
+    lut[list(b"ACGT")] = [0, 1, 2, 3]
+    codes = (lut[g[pos]] + rng.integers(1, 4, pos.size).astype(np.uint8)) & 3
+    g[pos] = np.frombuffer(b"ACGT", np.uint8)[codes]
+    return g

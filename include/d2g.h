@@ -387,9 +387,16 @@ int  d2g_cmp_ut_prefill_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1
  *     d2g_cmp_ut_announce_dev(ctx, set, r0, r1, ...);  d2g_cmp_set_update_dev(ctx, set, sigs, stream);  d2g_cmp_lut_ut_dev(..., stream);
  * The announcement serves exactly one prepare; the launch must follow on the prepare's stream with the same rows and output (any other
  * launch simply fills for itself).  lut_dev must hold the table by the time the prepare runs on its stream.  Nothing is enqueued here.
- * A no-op for sets that would not fill; D2G_SP_RIDE=0 turns the riding off (the launch fills as before). */
+ * A no-op for sets that would not fill; D2G_SP_RIDE=0 turns the riding off (the launch fills as before).
+ * The set keeps the announced pointer until its next prepare: a caller that frees the output before that prepare CANCELS the announcement
+ * with neq_out_dev = out_dev = NULL.  A launch skips its own fill only where the announced (or pre-filled) output, rows AND fill value --
+ * the count 0, or the table pointer -- are its own; a table whose first entry changes between the prepare and the launch is the caller's
+ * business, as is a buffer written between the two. */
 int  d2g_cmp_ut_announce_dev(d2g_ctx *ctx, d2g_cmp_set *set, size_t r0, size_t r1, uint32_t *neq_out_dev,
                              const float *lut_dev, float *out_dev);
+/* measurements: the set forgets what its earlier prepares learnt about its matrix (which path pays); its next prepare decides as the first
+ * prepare of a new set does */
+int  d2g_cmp_set_forget(d2g_ctx *ctx, d2g_cmp_set *set);
 /* (#a>b, #a<b) counts per pair: needs a set created with D2G_CMP_DIRECT (the raw patterns);
  * required when S is not a power of two in set space */
 int  d2g_cmp_gtlt_ut_dev(d2g_ctx *ctx, const d2g_cmp_set *set, size_t r0, size_t r1,
