@@ -327,6 +327,60 @@ def cpu_baseline_multiset(L, k, S):
                       f"Counter + BagMinHash (BMH-D2G spec), k={k}, S={S}, {march}"}
 
 
+def cross_family_stats(regs, fam):
+    """What decides between the sparse path's regimes (VERDICT r5 #1c, reference src/cmp_core.cpp:461-465: only the equality count matters): the register
+    values sketches of DIFFERENT families share, counted on the host from the u64 registers.  -> entries (= list entries an ideal family partition leaves:
+    one per cross-family pair and shared register; per sketch: 2 x entries / N), the registers a sketch shares with at least one stranger (a family value one
+    stranger joins counts for every member), entries per cross-family pair."""
+    N, S = regs.shape
+    entries = 0
+    shared_regs = np.zeros(N, np.int64)
+    for t in range(S):
+        v = regs[:, t]
+        order = np.lexsort((fam, v))
+        vs, fs = v[order], fam[order]
+        new_v = np.empty(N, bool); new_v[0] = True; np.not_equal(vs[1:], vs[:-1], out=new_v[1:])
+        new_f = new_v.copy(); new_f[1:] |= fs[1:] != fs[:-1]
+        vid = np.cumsum(new_v) - 1
+        fid = np.cumsum(new_f) - 1
+        h = np.bincount(vid)                      # holders per value
+        hf = np.bincount(fid)                     # holders per (value, family)
+        strangers = h[vid] - hf[fid]              # per holder: holders of its value in other families
+        shared_regs[order] += strangers > 0
+        entries += int(strangers.sum()) // 2
+    same = np.bincount(fam.astype(np.int64)).astype(np.float64)
+    cross_pairs_all = (N * (N - 1) - float((same * (same - 1)).sum())) / 2.0
+    return {"cross_family_entries": entries, "cross_family_entries_per_sketch": 2.0 * entries / N, "registers_shared_with_a_stranger_per_sketch_mean": float(shared_regs.mean()),
+            "registers_shared_with_a_stranger_per_sketch_max": int(shared_regs.max()), "cross_family_pairs": cross_pairs_all,
+            "entries_per_cross_family_pair": entries / max(cross_pairs_all, 1.0)}
+
+
+def k1_built_collection(D, synth, ctx, S, ncores, nfam, per_fam, L, k=31, **kw):
+    """VERDICT r5 #1c: a collection whose sketches come from GENOMES through the product's own K1 (not planted registers): `nfam` families of `per_fam`
+    mutated copies (synth.family_collection), optionally with conserved segments shared across families; FASTA -> d2g_seqpack -> k1_oph_kernel ->
+    d2g_oph_finalize.  -> (signatures, cardinalities, registers, family of every sketch)"""
+    regs, fam = [], []
+    batch, sp, nb = 500, None, 0
+    def flush():
+        nonlocal sp, nb
+        if sp is not None and nb:
+            regs.append(ctx.oph_sketch_seqpack(sp, S))
+            sp.close()
+        sp, nb = None, 0
+    for f, name, g in synth.family_collection(nfam, per_fam, L, **kw):
+        if sp is None:
+            sp = D.SeqPack(k)
+        sp.add_fastx(synth.fasta_bytes_fast(name, g))
+        fam.append(f)
+        nb += 1
+        if nb == batch:
+            flush()
+    flush()
+    regs = np.concatenate(regs)
+    sig, cards = D.oph_finalize(regs, S, nthreads=ncores)
+    return sig, cards, regs, np.asarray(fam, np.int32)
+
+
 def pack_genomes(D, synth, first, count, L, k, keep=0, nthreads=None):
     """`count` synthetic genomes (indices first..) -> FASTA bytes -> d2g_seqpack (the product's ingest), on
     all host cores; returns one merged packed run stream + the first `keep` FASTA buffers."""
@@ -1346,17 +1400,45 @@ def run_single(args):
                 mats["stated, dense walk (D2G_BS_SPARSE=0)"] = dense_walk
                 # the stated families + c chance collisions per sketch with random strangers (about half of them with values the stranger shares with
                 # its whole family): the case real collections present (conserved k-mers across genera).  Round 4 listed nearly every tile at c = 10.
-                for c in (1, 10, 100):
+                def with_dense_reference(bits):
+                    """the matrix on the default path, and beside it what D2G_BS_SPARSE=0 (every tile walked, no ordering) takes for its first and its steady
+                    step: `first_step_over_dense` is what a one-shot CLI cmp pays for the sparse path's look at a matrix it cannot help"""
+                    r = measure_matrix(bits, N)
+                    set_switch(ctx, "D2G_BS_SPARSE", "0")
+                    try:
+                        d = measure_matrix(bits, N, steps=3)
+                    finally:
+                        set_switch(ctx, "D2G_BS_SPARSE", None)
+                    r["dense_walk"] = {"ms_per_step": d["ms_per_step"], "first_step_ms": d["first_step_ms"], "single_step_ms": d["single_step_ms"]}
+                    r["first_step_over_dense"] = r["first_step_ms"] / d["first_step_ms"] if d["first_step_ms"] else None
+                    r["step_over_dense"] = r["ms_per_step"] / d["ms_per_step"] if d["ms_per_step"] else None
+                    return r
+                for c in (1, 3, 10, 30, 100):
                     sg, _ = make_sketches(N, collisions=c)
-                    mats["stated + %d chance collisions per sketch" % c] = measure_matrix(sg.view(np.uint64), N)
+                    mats["stated + %d chance collisions per sketch" % c] = with_dense_reference(sg.view(np.uint64))
                     del sg
+                # VERDICT r5 #1c: collections whose registers come from GENOMES through the product's K1: 66 families of 150 mutated copies of a 200 kbp genome
+                # (substitution rate log-uniform in [0.0005, 0.03]); without conserved segments random 31-mers of different families never collide; with 48
+                # conserved 1.5 kbp segments of which every family carries two, families that share a segment share the registers its k-mers win
+                if not args.no_sketch and N == 10000:
+                    for label, kw in (("K1-built: 66 families x 150 genomes of 200 kbp, no conserved segment", {}),
+                                      ("K1-built: the same + 48 conserved 1.5 kbp segments, two per family", {"nseg": 48, "seg_len": 1500, "segs_per_family": 2})):
+                        t0 = time.perf_counter()
+                        sg, _, rg, fam = k1_built_collection(D, synth, ctx, S, ncores, 66, N // 66 + 1, 200_000, **kw)
+                        sg, rg, fam = sg[:N], rg[:N], fam[:N]
+                        r = with_dense_reference(np.ascontiguousarray(sg).view(np.uint64))
+                        r["collection"] = dict(cross_family_stats(rg[:, :S], fam), build_s=time.perf_counter() - t0,
+                                               note="registers from the product's own K1 over synthetic genomes (FASTA -> d2g_seqpack -> k1_oph_kernel); the cross-family "
+                                                    "figures are counted on the host from the u64 registers and the generator's family labels")
+                        mats[label] = r
+                        del sg, rg
                 mats["unrelated (no value shared by two sketches)"] = measure_matrix(synth.unrelated_registers(N, S), N)
-                mats["adversarial (every value occurs exactly twice in its column)"] = measure_matrix(synth.paired_registers(N, S), N)
+                mats["adversarial (every value occurs exactly twice in its column)"] = with_dense_reference(synth.paired_registers(N, S))
                 # columns that share between 0 and 64 values (log-uniform): which column lands in which 32-register group matters,
                 # since a group walks the MAXIMUM plane count of its columns.  Measured with the column plan (columns sorted by
                 # plane class before grouping, the default) and with the caller's column order (D2G_BS_SORT=0).
                 sk = synth.skewed_registers(N, S)
-                mats["skewed (columns share 0..64 values, log-uniform)"] = measure_matrix(sk, N)
+                mats["skewed (columns share 0..64 values, log-uniform)"] = with_dense_reference(sk)
                 set_switch(ctx, "D2G_BS_SORT", "0")
                 try:
                     mats["skewed, columns left in the caller's order (D2G_BS_SORT=0)"] = measure_matrix(sk, N)

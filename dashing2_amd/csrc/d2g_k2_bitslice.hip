@@ -252,7 +252,7 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
             if (j < N && !(skip >> i & 1)) ids[j] = own[hs[i]];
         }
         for (uint32_t k = tid; k < nfix && k < BS_MAXFIX; k += BS_RANK_THREADS) ids[fix_j[k]] = own[fix_h[k]];
-        if (tid == 0) colcnt[t * BS_CC_STRIDE] = running - 1;             // #values shared by >= 2 sketches
+        if (tid == 0) { colcnt[t * BS_CC_STRIDE] = running - 1; colcnt[t * BS_CC_STRIDE + 5] = running - 1; }   // #values shared by >= 2 sketches ([5]: a copy the column plan leaves alone -- sp_sample_fin_kernel reads it beside that kernel)
         return;
     }
 
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         }
         __syncthreads();
     }
-    if (tid == 0) colcnt[t * BS_CC_STRIDE + split] = running - 1;          // #values shared by >= 2 sketches (this split's)
+    if (tid == 0) { colcnt[t * BS_CC_STRIDE + split] = running - 1; if (nsplit == 1) colcnt[t * BS_CC_STRIDE + 5] = running - 1; }   // #values shared by >= 2 sketches (this split's)
 }
 
 // ------------------------------------------------------------------ 2. 32 x nbits bit transpose
@@ -957,6 +957,9 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         // (the planes kernel also initialises the ordering's arrays and clears the tile bitmap: no launch / memset of their own)
         hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
                            set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr, sp_init_of(set));
+        // a set's first prepare looks at its matrix before it orders it (the sample was enqueued behind the rank kernel; ONE synchronisation here)
+        if (sp_sample_due(ctx, set)) { if (int rc = sp_sample_enqueue(ctx, set, s)) return rc; }
+        if (int rc = sp_sample_collect(ctx, set, s)) return rc;
         if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
         if (int rc = sp_permute(ctx, set, s)) return rc;
         set->srt_valid = true; set->nat_valid = true;
@@ -1123,7 +1126,7 @@ int d2g_bitslice_managed_ready(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
 // the set's remembered decisions forgotten: its next prepare decides as a new set's first prepare does (measurements: bench.py's first_step_ms)
 void d2g_bitslice_forget(d2g_cmp_set *set) {
     if (set->h_gaveup) { set->h_gaveup[0] = 0; set->h_gaveup[1] = 0; }
-    set->sp_prepares = 0;
+    set->sp_prepares = 0; set->pred_valid = false;
 }
 
 // diagnostics of the sparse path's LAST launch on this set (synchronises `s`): see d2g.h

@@ -31,6 +31,7 @@
 //          outside listed tiles: atomicAdd of 1 onto the filled word; the first adder of a position is its leader) -> sp_patch_lut (table
 //          epilogue: the leader turns the count into the float) -> the plain pair kernel, which runs only in dense mode.
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
+constexpr uint32_t SP_SAMPLE_ROWS = 16, SP_SAMPLE_FAM = 4, SP_SAMPLE_COLS = 32;   // the first look at a matrix (sp_sample_kernel)
 constexpr unsigned long long SP_NULL_ENTRY = ~0ull;   // an empty slot of the pair list: two outsiders of one value that share a segment (sp_pairs_kernel); every reader skips it
 #ifndef D2G_SP_KS
 #define D2G_SP_KS 4
@@ -1022,66 +1023,79 @@ __global__ __launch_bounds__(1024) void sp_bin_kernel(const unsigned long long *
     }
 }
 
-// One workgroup per (bin of the launch's bands, piece of TW columns of its chunk).  LDS: 32 rows x TW columns of 16-bit counts (a count stays
-// below 2^16: S < 65536); word [r][c mod TW/2] holds column c (low half) and column c + TW/2 (high half), so that the TW/2 threads of a row
-// parity write two coalesced streams.  The workgroup reads its bin's entries (they sit in L2; every piece of a chunk reads them: TW = 256 for
-// chunks of 1024 columns, 1024 for the wider chunks of large N), adds those of its piece with LDS atomics, then
+// One workgroup (256 threads) per (bin of the launch's bands, piece of 1024 columns of its chunk, group of 8 of the band's 32 rows).  LDS: 8 rows x
+// 1024 columns of 16-bit counts (a count stays below 2^16: S < 65536); word [r][w] holds column w (low half) and column w + 512 (high half).
+// The workgroup reads its bin's entries (they sit in L2; the four row groups -- and, for the wider chunks of large N, every piece -- read them),
+// adds its own with LDS atomics, then
 //   few entries    every entry's thread writes its pair's value (a pair with several entries: several threads, the same value);
-//   otherwise      every 64-word span that holds a count is written -- table value or count, the fill value beside it.
+//   otherwise      row by row, every 64-word span that holds a count is written -- table value or count, the fill value beside it: the four waves
+//                  write 4 KB of ONE output row together (32 x 256 regions left 1 KB runs 40 KB apart: 2.7 TB/s at ten chance collisions per sketch).
 // Entries of rows outside [r0, r1) -- the edge bands of a partial launch -- are skipped; words that hold no pair (j <= i, j >= N) are not stored.
 struct SpComposeArgs { const unsigned long long *plist2; SpBins bn; const uint32_t *ctl; uint32_t cand, N, S, r0, r1, band0, ppb; };
-template <int TW, class Store>
-__global__ __launch_bounds__(TW) void sp_compose_kernel(SpComposeArgs a, PairShape sh, Store store) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];   // 32 x TW / 2 words
+constexpr uint32_t SP_CMP_ROWS = 8, SP_CMP_COLS = 1024, SP_CMP_T = 256;
+template <class Store>
+__global__ __launch_bounds__(SP_CMP_T) void sp_compose_kernel(SpComposeArgs a, PairShape sh, Store store) {
+    __shared__ uint32_t tile[SP_CMP_ROWS * SP_CMP_COLS / 2];          // 16 KB
     __shared__ uint32_t s_cnt;
-    constexpr uint32_t HW = TW / 2;
+    constexpr uint32_t HW = SP_CMP_COLS / 2, T = SP_CMP_T, RG = 32 / SP_CMP_ROWS;
     if (sp_dense_mode(a.ctl, a.cand)) return;
-    const uint32_t piece = blockIdx.x % a.ppb, bi = blockIdx.x / a.ppb;
+    const uint32_t rg = blockIdx.x % RG, piece = (blockIdx.x / RG) % a.ppb, bi = blockIdx.x / (RG * a.ppb);
     const uint32_t band = a.band0 + bi / a.bn.nch, ch = bi % a.bn.nch;
     const uint32_t bin = band * a.bn.nch + ch;
     const uint32_t nb = a.bn.binc[bin];
     if (nb == 0) return;
-    const uint32_t i0 = band * 32u, c0 = (ch << a.bn.cshift) + piece * TW;
-    if (c0 >= a.N || c0 + (TW - 1u) <= i0) return;                    // no column, or every column at or below the band's first row: no pair
+    const uint32_t i0 = band * 32u + rg * SP_CMP_ROWS, c0 = (ch << a.bn.cshift) + piece * SP_CMP_COLS;
+    if (c0 >= a.N || c0 + (SP_CMP_COLS - 1u) <= i0 || i0 >= a.r1 || i0 + SP_CMP_ROWS <= a.r0) return;   // no column, every column at or below the first row, or no row of the launch
     const unsigned long long *ent = a.plist2 + a.bn.bstart[bin];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t x = tid; x < 32 * HW; x += TW) tile[x] = 0;
+    for (uint32_t x = tid; x < SP_CMP_ROWS * HW; x += T) tile[x] = 0;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     uint32_t mine = 0;
-    for (uint32_t k = tid; k < nb; k += TW) {
+    for (uint32_t k = tid; k < nb; k += T) {
         const unsigned long long e = ent[k];
-        const uint32_t i = (uint32_t)e, c = (uint32_t)(e >> 32) - c0;
-        if (c < (uint32_t)TW && i >= a.r0 && i < a.r1) { atomicAdd(&tile[(i & 31u) * HW + (c % HW)], 1u << (16u * (c / HW))); ++mine; }
+        const uint32_t i = (uint32_t)e, r = i - i0, c = (uint32_t)(e >> 32) - c0;
+        if (c < SP_CMP_COLS && r < SP_CMP_ROWS && i >= a.r0 && i < a.r1) { atomicAdd(&tile[r * HW + (c % HW)], 1u << (16u * (c / HW))); ++mine; }
     }
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
     if ((tid & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
     const uint32_t total = s_cnt;
     if (total == 0) return;
-    const uint32_t fillv = store.value_from_mismatches(a.S, a.S);
-    if (total <= (uint32_t)TW) {                                      // few: one store per entry
-        for (uint32_t k = tid; k < nb; k += TW) {
+    if (total <= T) {                                                 // few: one store per entry
+        for (uint32_t k = tid; k < nb; k += T) {
             const unsigned long long e = ent[k];
-            const uint32_t i = (uint32_t)e, j = (uint32_t)(e >> 32), c = j - c0;
-            if (c < (uint32_t)TW && i >= a.r0 && i < a.r1) {
-                const uint32_t cnt = (tile[(i & 31u) * HW + (c % HW)] >> (16u * (c / HW))) & 0xFFFFu;
+            const uint32_t i = (uint32_t)e, j = (uint32_t)(e >> 32), r = i - i0, c = j - c0;
+            if (c < SP_CMP_COLS && r < SP_CMP_ROWS && i >= a.r0 && i < a.r1) {
+                const uint32_t cnt = (tile[r * HW + (c % HW)] >> (16u * (c / HW))) & 0xFFFFu;
                 store.put_row(out_row_base(sh, i), j, store.value_from_mismatches(a.S, a.S - min(cnt, a.S)));
             }
         }
         return;
     }
-    const uint32_t par = tid / HW, cl = tid % HW;
-    for (uint32_t r = par; r < 32; r += 2) {
-        const uint32_t i = i0 + r;                                    // (uniform per wave)
+    for (uint32_t r = 0; r < SP_CMP_ROWS; ++r) {
+        const uint32_t i = i0 + r;                                    // (uniform)
         if (i < a.r0 || i >= a.r1) continue;
-        const uint32_t w = tile[r * HW + cl];
         const size_t rb = out_row_base(sh, i);
+        const uint32_t w0 = tile[r * HW + tid], w1 = tile[r * HW + tid + T];
+        // columns tid, tid + 256, tid + 512, tid + 768 of the piece: the four values first (table gathers in flight together: one after the other, each in
+        // front of its store, they were 32 dependent round trips per thread -- 72 us for the kernel at ten chance collisions per sketch), then the stores
+        uint32_t cnt[4], val[4];
 #pragma unroll
-        for (uint32_t hh = 0; hh < 2; ++hh) {
-            const uint32_t cnt = (w >> (16u * hh)) & 0xFFFFu, j = c0 + cl + HW * hh;
-            if (__ballot(cnt != 0) == 0) continue;                    // nothing in this 64-word span: the fill stays
-            if (j > i && j < a.N) store.put_row(rb, j, cnt ? store.value_from_mismatches(a.S, a.S - min(cnt, a.S)) : fillv);
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t w = (q & 1u) ? w1 : w0;
+            cnt[q] = (w >> (16u * (q >> 1))) & 0xFFFFu;
+            val[q] = store.value_from_mismatches(a.S, a.S - min(cnt[q], a.S));    // (count 0: the fill value)
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t j = c0 + tid + T * q;
+            if (__ballot(cnt[q] != 0) == 0) continue;                 // nothing in this 64-word span: the fill stays
+#ifdef D2G_CMP_NT
+            if (j > i && j < a.N) __builtin_nontemporal_store(val[q], reinterpret_cast<uint32_t *>(store.out) + rb + j);
+#else
+            if (j > i && j < a.N) store.put_row(rb, j, val[q]);
+#endif
         }
     }
 }
@@ -1311,7 +1325,9 @@ struct SpTuning {
     int remember = 1;                   // D2G_SP_REMEMBER: 0 = every prepare runs the ordering, whatever the last one decided
     size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
     size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
-    size_t long_list = 262144;          // D2G_SP_LONG_LIST: a pair list of this many entries or more is binned and composed (the last prepare's length decides)
+    size_t bin_wgs = 0;                 // D2G_SP_BIN_WGS: workgroups that count and move a long list (0: one per 16 384 entries of a full list, one per two CUs at most)
+    size_t long_list = 786432;          // D2G_SP_LONG_LIST: a pair list of this many entries or more is binned and composed (the last prepare's length decides)
+    int predict = 1;                    // D2G_SP_PREDICT: 0 = no sample before the ordering of a set's first prepare (the ordering finds out by itself, as in round 5)
     int list_form = 0;                  // D2G_SP_LIST_FORM: 1 = always entry by entry, 2 = always binned (tests, measurements)
     size_t list_div = 8;                // D2G_SP_LIST_DIV: the pair list holds at most pairs / list_div entries (and at most 2^27)
 };
@@ -1328,7 +1344,9 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_SP_RIDE")) v.ride = std::atoi(e) & 63;
     if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
+    if (const char *e = ctx->tune.get("D2G_SP_BIN_WGS")) { const long d = std::atol(e); if (d >= 1 && d <= 4096) v.bin_wgs = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_LONG_LIST")) { const long long d = std::atoll(e); if (d >= 0) v.long_list = (size_t)d; }
+    if (const char *e = ctx->tune.get("D2G_SP_PREDICT")) v.predict = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_LIST_FORM")) { const int d = std::atoi(e); if (d >= 0 && d <= 2) v.list_form = d; }
     if (const char *e = ctx->tune.get("D2G_SP_LIST_DIV")) { const long d = std::atol(e); if (d >= 1 && d <= (1 << 20)) v.list_div = (size_t)d; }
     return v;
@@ -1358,7 +1376,8 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     // one zero-initialised block per prepare: [counters Npad + 1 | 8 global control words + tile bitmap | order 8 | list control 8 | control words of a whole-triangle launch 16 | entries per bin | bin cursors]
     set->spz_words = (Npad + 1) + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS + (size_t)set->nbins;
     // the workgroups that count (and then move) the list's entries: one per ~16 384 entries of a full list, at most two per CU
-    set->bin_nwg = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)ctx->num_cus * 2, div_up<size_t>(set->plist_cap, 16384)));
+    set->bin_nwg = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)std::max(ctx->num_cus / 2, 1), div_up<size_t>(set->plist_cap, 16384)));   // (128 of them measured best at config 3: 64 / 128 / 512 / 1024 -> counting + moving 90 / 65 / 70 / 84 us)
+    if (sp_tuning(ctx).bin_wgs) set->bin_nwg = (uint32_t)sp_tuning(ctx).bin_wgs;
     const size_t planes_words = (size_t)set->ntb * set->nbits_cap + 1;
     hipError_t e;
     if ((e = hipMalloc((void **)&set->d_stream_s, planes_words * 2 * Nstride * sizeof(uint32_t))) != hipSuccess ||
@@ -1378,6 +1397,8 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
         (e = hipMalloc((void **)&set->d_plist, set->plist_cap * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_plist2, set->plist_cap * sizeof(unsigned long long))) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_bstart, ((size_t)set->nbins + 1) * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&set->d_samp, (SP_SAMPLE_ROWS * Npad + 8) * 4)) != hipSuccess ||
+        (e = hipMemset(set->d_samp, 0, (SP_SAMPLE_ROWS * Npad + 8) * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_cw_ents, set->cw_ecap * 4)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_cw_vals, set->cw_vcap * 16)) != hipSuccess ||
         (e = hipMalloc((void **)&set->d_hoff, (size_t)set->bin_nwg * set->nbins * 4)) != hipSuccess) {
@@ -1406,6 +1427,7 @@ void sp_free(d2g_cmp_set *set) {
     (void)hipFree(set->d_plist2); set->d_plist2 = nullptr;
     (void)hipFree(set->d_bstart); set->d_bstart = nullptr;
     (void)hipFree(set->d_hoff); set->d_hoff = nullptr;
+    (void)hipFree(set->d_samp); set->d_samp = nullptr;
     (void)hipFree(set->d_cw_ents); set->d_cw_ents = nullptr;
     (void)hipFree(set->d_cw_vals); set->d_cw_vals = nullptr;
     set->d_binc = nullptr;
@@ -1437,6 +1459,86 @@ __global__ void sp_giveup_kernel(uint32_t *__restrict__ order, uint32_t *__restr
     if (threadIdx.x == 0) { order[0] = 1; fullctl[1] = 1; fullctl[3] = cand; }
 }
 
+// ---- the first look at a matrix (VERDICT r5 #1b): which path pays is decided BEFORE the ordering, from a sample.  Sixteen sketches spread over the
+// collection are compared with every sketch, register by register, on the ids the rank kernel left (an equal id in a column = an equal register):
+//   a pair that shares fewer than SP_SAMPLE_FAM registers   chance / conserved k-mers: its shared registers are list entries   -> E
+//   a pair that shares more                                  family: a tile pair                                                -> F
+// scaled by N / 32 (a pair is seen from either end) these are the list length and the family pairs the ordering WOULD find.  A list beyond its
+// buffer, or families that cover a third of the triangle, mean the dense walk -- known after two small kernels (a few microseconds) and ONE
+// synchronisation, on the set's first prepare (and whenever a remembered give-up is due for its retry) instead of after link / sort / emit
+// (0.05-0.3 ms).  Later prepares of the set go by what is remembered.  A heuristic: whatever it says, the results are exact.
+struct SpSampleRows { uint32_t r[SP_SAMPLE_ROWS]; };
+__global__ __launch_bounds__(256) void sp_sample_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, SpSampleRows rows, uint32_t *__restrict__ cntm) {
+    __shared__ __attribute__((aligned(16))) uint32_t sm[SP_SAMPLE_COLS][SP_SAMPLE_ROWS];   // the sampled sketches' ids in this workgroup's columns
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t t0 = blockIdx.y * SP_SAMPLE_COLS, t1 = min(ncols, t0 + SP_SAMPLE_COLS);
+    for (uint32_t x = threadIdx.x; x < SP_SAMPLE_COLS * SP_SAMPLE_ROWS; x += 256) {
+        const uint32_t t = t0 + x / SP_SAMPLE_ROWS, k = x % SP_SAMPLE_ROWS;
+        const uint32_t w = t < t1 ? ids[(size_t)t * Npad + rows.r[k]] : 0u;
+        sm[x / SP_SAMPLE_ROWS][k] = (w != 0 && !(w >> 31)) ? w : 0xFFFFFFFFu;      // (a value nobody else holds matches nothing: never equal to a shared id)
+    }
+    __syncthreads();
+    uint32_t acc[SP_SAMPLE_ROWS];
+#pragma unroll
+    for (uint32_t k = 0; k < SP_SAMPLE_ROWS; ++k) acc[k] = 0;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll 4
+    for (uint32_t x = 0; x < SP_SAMPLE_COLS; ++x) {
+        const uint32_t wx = (j < N && t0 + x < t1) ? ids[(size_t)(t0 + x) * Npad + j] : 0u;      // (0 or bit 31: equal to no staged id)
+#pragma unroll
+        for (uint32_t q = 0; q < SP_SAMPLE_ROWS / 4; ++q) {
+            const u32x4 s4 = reinterpret_cast<const u32x4 *>(&sm[x][0])[q];
+            acc[4 * q] += wx == s4.x; acc[4 * q + 1] += wx == s4.y; acc[4 * q + 2] += wx == s4.z; acc[4 * q + 3] += wx == s4.w;
+        }
+    }
+    // four sampled sketches per word, a byte each, a column group's share capped at SP_SAMPLE_FAM (what counts is "fewer than that in all, or not":
+    // 32 groups x 4 stay below 256) -- a noisy matrix has a count for every (sample, sketch, group): a quarter of the atomics
+#pragma unroll
+    for (uint32_t q = 0; q < SP_SAMPLE_ROWS / 4; ++q) {
+        const uint32_t w = min(acc[4 * q], SP_SAMPLE_FAM) | (min(acc[4 * q + 1], SP_SAMPLE_FAM) << 8) | (min(acc[4 * q + 2], SP_SAMPLE_FAM) << 16) | (min(acc[4 * q + 3], SP_SAMPLE_FAM) << 24);
+        if (w) atomicAdd(&cntm[(size_t)q * Npad + j], w);
+    }
+}
+// the counts -> (E, F) in mapped host memory; the kernel cleans up behind itself (counters, its sums, the ticket)
+__global__ __launch_bounds__(256) void sp_sample_fin_kernel(uint32_t *__restrict__ cntm, size_t N, size_t Npad, SpSampleRows rows, uint32_t *__restrict__ acc3, uint32_t *__restrict__ host_out,
+                                                            const uint32_t *__restrict__ colcnt, uint32_t ncols, int nsplit) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t e = 0, f = 0;
+    // (the same grid also sums what the rank kernel left: the shared values of every column, and the id planes a column of that many needs -- the
+    // column plan groups columns of one plane class, so the mean over columns is the mean over groups)
+    uint32_t v = 0, pl = 0;
+    if (j < ncols) {
+        v = colcnt[j * BS_CC_STRIDE + 5];                             // (slot 5: the rank kernel's own total, untouched by the column plan)
+        pl = v == 0 ? 1u : 32u - __clz(v + 1u);
+    }
+    if (j < N) {
+#pragma unroll
+        for (uint32_t q = 0; q < SP_SAMPLE_ROWS / 4; ++q) {
+            const uint32_t w = cntm[(size_t)q * Npad + j];
+            if (!w) continue;
+            cntm[(size_t)q * Npad + j] = 0;
+#pragma unroll
+            for (uint32_t y = 0; y < 4; ++y) {
+                const uint32_t c = (w >> (8 * y)) & 0xFFu;
+                if (c && j != rows.r[4 * q + y]) { if (c >= SP_SAMPLE_FAM) ++f; else e += c; }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_down(e, o); f += __shfl_down(f, o); v += __shfl_down(v, o); pl += __shfl_down(pl, o); }
+    if ((threadIdx.x & 63) == 0) { if (e) atomicAdd(&acc3[0], e); if (f) atomicAdd(&acc3[1], f); if (v) atomicAdd(&acc3[3], v); if (pl) atomicAdd(&acc3[4], pl); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&acc3[2], 1u) + 1u == gridDim.x) {              // the last workgroup: everybody's sums are in (device-scope atomics)
+            host_out[0] = atomicExch(&acc3[0], 0u);
+            host_out[1] = atomicExch(&acc3[1], 0u);
+            host_out[2] = atomicExch(&acc3[3], 0u);
+            host_out[3] = atomicExch(&acc3[4], 0u);
+            acc3[2] = 0;
+        }
+    }
+}
+
 // ---- riders (sp_ride): the share of an announced output's fill that one hosting kernel of the prepare chain carries.  The weights are the
 // hosts' own durations at config 3 (us): each hides about what it lasts; the last host (place) takes what is left.
 constexpr unsigned SP_RW_PLAN = 6, SP_RW_FLATTEN = 5, SP_RW_COUNT = 5, SP_RW_ATTACH = 5, SP_RW_SCAN = 8, SP_RW_ALL = 35;
@@ -1466,13 +1568,63 @@ bool sp_expect_long_list(const d2g_ctx *ctx, const d2g_cmp_set *set) {
     const SpTuning t = sp_tuning(ctx);
     if (t.list_form == 1) return false;
     if (t.list_form == 2) return true;
+    if (set->pred_valid) return set->pred_entries >= (double)t.long_list;
     if (!set->h_gaveup || set->sp_prepares == 0) return true;
     const uint32_t n = ((volatile uint32_t *)set->h_gaveup)[1];
     return n != 0xFFFFFFFFu && n >= t.long_list;
 }
 // will the next sp_prepare_order skip the ordering (the remembered give-up)?  Asked BEFORE it, by the prepare that decides whether anything rides
+bool sp_retry_due(const d2g_cmp_set *set) { return ((set->sp_prepares + 1) & 15u) == 0; }
 bool sp_will_skip(const d2g_ctx *ctx, const d2g_cmp_set *set) {
-    return sp_tuning(ctx).remember && set->h_gaveup && *(volatile uint32_t *)set->h_gaveup && ((set->sp_prepares + 1) & 15u) != 0;
+    if (set->pred_valid) return set->pred_dense;                       // this prepare has looked at its matrix (sp_sample)
+    return sp_tuning(ctx).remember && set->h_gaveup && *(volatile uint32_t *)set->h_gaveup && !sp_retry_due(set);
+}
+// does this prepare look at its matrix first?  The set's first prepare, and the retry of a remembered give-up
+bool sp_sample_due(const d2g_ctx *ctx, const d2g_cmp_set *set) {
+    const SpTuning t = sp_tuning(ctx);
+    if (!t.predict || !set->d_samp || set->borrowed || set->nsplit > 1) return false;    // (a column several rank workgroups share has no single count of its shared values)
+    if (set->sp_prepares == 0) return true;
+    return t.remember && set->h_gaveup && *(volatile uint32_t *)set->h_gaveup && sp_retry_due(set);
+}
+
+// the sample (see sp_sample_kernel): SYNCHRONISES `s`.  Leaves the set's prediction (pred_valid, pred_dense, pred_entries) and the remembered word.
+// Two halves: sp_sample_enqueue (two small kernels: 18 + 8 us at config 3) and sp_sample_collect (the synchronisation).  (The kernels on a second
+// stream beside the column plan and the planes kernel were measured: no gain -- what the first look costs, ~50 us at config 3, is the
+// synchronisation itself and the launches behind it, which no longer run ahead of the device.)
+int sp_sample_enqueue(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
+    const size_t N = set->N, Npad = set->Npad;
+    if (!set->h_gaveup) return D2G_OK;                                   // (no mapped host memory: no sample)
+    SpSampleRows rows;
+    for (uint32_t k = 0; k < SP_SAMPLE_ROWS; ++k) rows.r[k] = (uint32_t)std::min<size_t>(N - 1, (size_t)(2 * k + 1) * N / (2 * SP_SAMPLE_ROWS));
+    uint32_t *acc3 = set->d_samp + SP_SAMPLE_ROWS * Npad;                // (the counters and the control words are zero: cleared at allocation, then by the kernel itself)
+    hipLaunchKernelGGL(sp_sample_kernel, dim3((unsigned)div_up<size_t>(N, 256), (unsigned)div_up<size_t>(set->ncols, SP_SAMPLE_COLS)), dim3(256), 0, s, set->d_ids, N, Npad, (uint32_t)set->ncols, rows, set->d_samp);
+    hipLaunchKernelGGL(sp_sample_fin_kernel, dim3((unsigned)div_up<size_t>(std::max(N, set->ncols), 256)), dim3(256), 0, s, set->d_samp, N, Npad, rows, acc3, set->d_gaveup + 2,
+                       set->d_colcnt, (uint32_t)set->ncols, set->nsplit);
+    D2G_HIP(ctx, hipGetLastError());
+    set->sample_pending = true;
+    return D2G_OK;
+}
+// SYNCHRONISES `s`.  Leaves the set's prediction (pred_valid, pred_dense, pred_entries) and the remembered word.
+int sp_sample_collect(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
+    if (!set->sample_pending) return D2G_OK;
+    set->sample_pending = false;
+    D2G_HIP(ctx, hipStreamSynchronize(s));
+    const size_t N = set->N;
+    volatile uint32_t *h = (volatile uint32_t *)set->h_gaveup;
+    const double scale = (double)N / (2.0 * SP_SAMPLE_ROWS), pairs = (double)N * (double)(N - 1) / 2.0;
+    set->pred_valid = true;
+    set->pred_entries = (double)h[2] * scale;
+    set->pred_family_pairs = (double)h[3] * scale;
+    const double values = (double)h[4], planes = set->ncols ? (double)h[5] / (double)set->ncols : 1.0;
+    // what each path would take, in nanoseconds (constants measured at config 3 on MI355X, round 6: profiles/r06_k2_experiments.txt): the dense walk
+    // costs 2 + 0.94 x planes ps per pair; the sparse path a longer prepare chain (16.5 ns per sketch more than the dense one), 55 ps per list entry (pairs, counting, moving, composing),
+    // 77 ps per shared value (grouping its holders, its record) and the family pairs' tiles at twice the dense rate
+    // (the per-plane and per-sketch terms are those of 32 register groups, S = 1024: they go with the group count)
+    const double g = (double)set->ntb / 32.0, per_pair = 0.002 + 0.00094 * planes * g;
+    const double dense_ns = pairs * per_pair, sparse_ns = (3.0 + 13.5 * g) * (double)N + 0.055 * set->pred_entries + 0.077 * values + 2.0 * per_pair * set->pred_family_pairs;
+    set->pred_dense = set->pred_entries > (double)set->plist_cap || sparse_ns > 0.97 * dense_ns;
+    set->h_gaveup[0] = set->pred_dense ? 1u : 0u;                      // what the next prepares go by (the device kernels that give up write the same word)
+    return D2G_OK;
 }
 
 // labels -> counting sort -> d_sperm / d_sinv -> pair list + segment tiles.  All on `s`, no host round trip.
@@ -1483,9 +1635,12 @@ bool sp_will_skip(const d2g_ctx *ctx, const d2g_cmp_set *set) {
 // dense walk is always right.
 int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) {
     const size_t N = set->N, Npad = set->Npad, S = set->ncols;
-    const bool skip = sp_will_skip(ctx, set) && set->ride_total == 0;      // (a prepare that has handed out riders goes through: its place kernel carries the rest of the fill)
+    // (a prepare that has handed out riders on a REMEMBERED give-up goes through: its place kernel carries the rest of the fill; one that has just
+    // looked at its matrix and found it dense skips -- the dense launch writes every output itself)
+    const bool skip = set->pred_valid ? set->pred_dense : (sp_will_skip(ctx, set) && set->ride_total == 0);
     set->sp_big = sp_expect_long_list(ctx, set);
     ++set->sp_prepares;
+    set->pred_valid = false;                                           // (a prediction serves the prepare that made it)
     if (skip) {
         hipLaunchKernelGGL(sp_giveup_kernel, dim3(1), dim3(64), 0, s, set->d_order, set->d_fullctl, (uint32_t)std::min<size_t>(sp_full_candidates(Npad), 0xFFFFFFFFu));
         D2G_HIP(ctx, hipGetLastError());
@@ -1687,15 +1842,11 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     // the pair list, composed region by region (before the pair kernel: that one STORES, see SpBins) -- when this set's prepare binned it
     if (set->sp_big) {
         const uint32_t band0 = (uint32_t)(r0 >> 5), nband = (uint32_t)((r1 - 1) >> 5) - band0 + 1u;
-        const bool wide = set->bin_cshift > 10;                       // (large N: chunks wider than 1024 columns take 1024-column pieces)
-        const uint32_t tw = wide ? 1024u : 256u, ppb = (1u << set->bin_cshift) / tw;
+        const uint32_t ppb = (1u << set->bin_cshift) / SP_CMP_COLS;    // pieces of 1024 columns per chunk (1 up to ~23 000 sketches)
         SpComposeArgs ca{set->d_plist2, sp_bins_of(set), ctl, cand32, (uint32_t)N, (uint32_t)set->S, (uint32_t)r0, (uint32_t)r1, band0, ppb};
-        const size_t nwg = (size_t)nband * set->bin_nch * ppb;
+        const size_t nwg = (size_t)nband * set->bin_nch * ppb * (32 / SP_CMP_ROWS);
         if (nwg >= 0x7FFFFFFFu) { ctx->last_error = "bitslice sparse: too many compose workgroups"; return D2G_ERR_UNSUPPORTED; }
-        if (wide) {
-            D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_compose_kernel<1024, Store>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-            hipLaunchKernelGGL((sp_compose_kernel<1024, Store>), dim3((unsigned)nwg), dim3(1024), 64 * 1024, s, ca, sh, store);
-        } else hipLaunchKernelGGL((sp_compose_kernel<256, Store>), dim3((unsigned)nwg), dim3(256), 16 * 1024, s, ca, sh, store);
+        hipLaunchKernelGGL((sp_compose_kernel<Store>), dim3((unsigned)nwg), dim3(SP_CMP_T), 0, s, ca, sh, store);
     }
     // (a short list is applied entry by entry: the pair kernel's tail adds, the gated launch behind it turns the sums into table values)
     SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, set->d_rowpos, reinterpret_cast<const uint2 *>(set->d_posseg), (uint32_t)N, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0, std::min<uint32_t>(grid, (uint32_t)ctx->num_cus * 8u)};

@@ -8,7 +8,7 @@
 // (D2G_MAX_RUN and D2G_NO_AVX512 in d2g_host.cpp, D2G_RCCL_LIB, D2G_COMM_LOOPBACK) are read where they apply.
 static const char *const kTuningNames[] = {
     "D2G_BS_SORT", "D2G_BS_NSPLIT", "D2G_BS_TAGBITS",
-    "D2G_BS_SPARSE", "D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_LONG_LIST", "D2G_SP_LIST_FORM", "D2G_SP_UNITE_STRIDE", "D2G_SP_GRID_MULT", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG", "D2G_SP_OLINK", "D2G_SP_RIDE",
+    "D2G_BS_SPARSE", "D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_LONG_LIST", "D2G_SP_LIST_FORM", "D2G_SP_PREDICT", "D2G_SP_BIN_WGS", "D2G_SP_UNITE_STRIDE", "D2G_SP_GRID_MULT", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG", "D2G_SP_OLINK", "D2G_SP_RIDE",
     "D2G_MGPU_CHUNKS", "D2G_MAX_RUN",
     "D2G_K3_COMPACT", "D2G_K3_L1BITS", "D2G_K3_BUCKET_KEYS", "D2G_K3_SUB_KEYS", "D2G_K3_SPLIT_MIN", "D2G_K3_SUBBATCH", "D2G_K3_ROUND_KEYS",
     "D2G_K3_GUESS_SCALE", "D2G_K3_GRID_PER_CU", "D2G_K3_LIGHT", "D2G_K3_GQ_SCALE",

@@ -549,7 +549,7 @@ def _ut_offsets(N):
     return np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
 
 
-@pytest.mark.parametrize("variant", ["default", "table_link", "no_link", "no_attach", "short_list", "emit_big"])
+@pytest.mark.parametrize("variant", ["default", "table_link", "no_link", "short_list", "emit_big", "entry_by_entry", "binned"])
 def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gpu_ctx, d2g, oracle, monkeypatch, variant):
     """Round 5: from 8192 sketches on, an upper-triangle launch on a bit-sliced set fills the output with the value of "0 equal", walks
     only the tiles of the FAMILIES the prepare found (sketches that agree in many registers) and adds a list of the pairs of different
@@ -558,8 +558,10 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
     1 / 10 / 100 chance collisions per sketch (round 4 listed every tile at 10), an adversarial matrix (a random pairing per column:
     no families, the pair list alone), skewed columns (one family: dense walk), unrelated sketches (the fill alone), chains whose
     neighbours share one register (pair list), one chain of N; whole triangle and row ranges, counts and the fused float epilogue; a
-    set RE-LOADED with another matrix.  Variants: no families at all (D2G_SP_LINK=0), no attach step, a pair list of pairs / 4096
-    entries (overflow -> dense walk), the pair-list kernel with two count words per value."""
+    set RE-LOADED with another matrix.  Variants: no families at all (D2G_SP_LINK=0), a pair list of pairs / 4096 entries (overflow ->
+    dense walk), the pair-list kernel with two count words per value, and the two forms the list is applied in (round 6): entry by entry
+    (short lists: atomic adds + a leader's table store) and binned by output region + composed in LDS (long lists) -- by default the
+    length of the set's last list picks one, here each is forced for every matrix."""
     import torch
     monkeypatch.setenv("D2G_SP_REMEMBER", "0")                         # nine different matrices through ONE set: every prepare decides afresh
     if variant == "table_link":                                        # the form the multi-GPU engine's gathered operand takes: tables in LDS
@@ -567,8 +569,10 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
     if variant == "no_link":
         monkeypatch.setenv("D2G_SP_LINK", "0")
         monkeypatch.setenv("D2G_SP_LIST_DIV", "2")                     # every equal register pair of the families becomes a list entry: ~20 million
-    elif variant == "no_attach":
-        monkeypatch.setenv("D2G_SP_ATTACH", "0")
+    elif variant == "entry_by_entry":
+        monkeypatch.setenv("D2G_SP_LIST_FORM", "1")
+    elif variant == "binned":
+        monkeypatch.setenv("D2G_SP_LIST_FORM", "2")
     elif variant == "short_list":
         monkeypatch.setenv("D2G_SP_LIST_DIV", "4096")
     elif variant == "emit_big":                                        # the pair list's kernel in the form it takes from 65 536 sketches on
@@ -642,7 +646,7 @@ def test_k2_sparse_tiles_and_pair_list_equal_the_direct_kernel_and_the_oracle(gp
         assert f["tiles_listed"] == 0 and f["pairs_listed"] > 100_000                           # every equal register pair of the matrix is a list entry
     elif variant != "short_list":
         assert f["tiles_listed"] > 0
-    if variant in ("default", "table_link", "emit_big"):
+    if variant in ("default", "table_link", "emit_big", "entry_by_entry", "binned"):
         # ten chance collisions per sketch used to list every tile; now the families keep their tiles and the strangers go to the list
         # (S = 96: one collision per sketch is 1 % of the registers, ten are 10 % -- heavy noise at this sketch size)
         assert 0 < seen["families+1"]["tiles_listed"] <= 2 * f["tiles_listed"] and seen["families+1"]["pairs_listed"] > 10_000
@@ -878,6 +882,7 @@ def test_k2_sparse_give_up_is_remembered_per_set(gpu_ctx, d2g, oracle, monkeypat
     skips the ordering (retried every 16th prepare).  Results are those of the oracle either way; a family matrix loaded afterwards is
     walked densely until the retry -- correct, only slower."""
     import torch
+    monkeypatch.setenv("D2G_SP_PREDICT", "0")                          # (the first look at the matrix would decide before the ordering: test_k2_first_look_decides_before_the_ordering)
     monkeypatch.setenv("D2G_SP_LIST_DIV", "256")                       # a list of pairs / 256 entries: the adversarial matrix's N S / 2 = 288 000 do not fit, the families' few do
     N, S = 9000, 64
     dev = torch.device("cuda", 0)
@@ -905,3 +910,79 @@ def test_k2_sparse_give_up_is_remembered_per_set(gpu_ctx, d2g, oracle, monkeypat
     assert seen[1]["ordering_skipped"] and seen[1]["dense_kernel_ran"]
     assert seen[2]["ordering_skipped"] and seen[2]["dense_kernel_ran"]          # another matrix, same set: still remembered
     assert any(not x["ordering_skipped"] and x["tiles_listed"] > 0 and not x["dense_kernel_ran"] for x in seen[3:])   # the 16th prepare tried again and found the families
+
+
+def test_k2_first_look_decides_before_the_ordering(gpu_ctx, d2g, oracle):
+    """VERDICT r5 #1b: a set's FIRST prepare looks at its matrix before it orders it -- sixteen sampled sketches against all, on the rank kernel's ids:
+    list entries and family pairs the ordering would find, scaled, into a cost model -- and a matrix the sparse path cannot help (a random pairing
+    per column, one family, a hundred chance collisions per sketch) goes to the dense walk without link / sort / emit (ordering_skipped on the very
+    first launch); a family collection, clean or with a few chance collisions, keeps its tiles and its list.  Whatever is decided, the counts are the
+    oracle's; d2g_cmp_set_forget makes the next prepare look again."""
+    import torch
+    N, S = 10_000, 1024                                                 # (config 3's shape: the cost model's constants were measured there)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    fam = synth.synthetic_registers(N, S, nclusters=N // 150, seed=31)
+    cases = [("families", fam, False), ("families+1", synth.add_chance_collisions(fam, 1, seed=32), False),
+             ("families+100", synth.add_chance_collisions(fam, 100, seed=33), True), ("paired", synth.paired_registers(N, S, seed=34), True),
+             ("skewed", synth.skewed_registers(N, S, seed=35), True)]
+    off = _ut_offsets(N)
+    out = torch.empty(N * (N - 1) // 2, dtype=torch.int32, device=dev)
+    rows = [0, 1, 77, N // 2, N - 3, N - 2]
+    for name, m, want_dense in cases:
+        bits = np.ascontiguousarray(m).view(np.uint64)
+        t_dev = torch.from_numpy(bits.view(np.int64)).to(dev)
+        cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_BITSLICE, stream=stream)     # the set's first prepare
+        out.fill_(-1)
+        cs.eqcount_ut_dev(out.data_ptr(), 0, N, stream)
+        info = cs.sparse_info(stream)
+        assert info["dense_kernel_ran"] == want_dense and info["ordering_skipped"] == want_dense, (name, info)
+        host = out.cpu().numpy().view(np.uint32)
+        for i in rows:
+            np.testing.assert_array_equal(host[off[i]:off[i + 1]], oracle.eqcounts_rows(bits.view(np.float64), i, i + 1), err_msg=f"{name} row {i}")
+        # later prepares go by what is remembered; after forget() the next one looks again (and decides the same)
+        cs.update_dev(t_dev.data_ptr(), stream)
+        cs.forget()
+        cs.update_dev(t_dev.data_ptr(), stream)
+        out.fill_(-1)
+        cs.eqcount_ut_dev(out.data_ptr(), 0, N, stream)
+        info2 = cs.sparse_info(stream)
+        assert info2["dense_kernel_ran"] == want_dense, (name, info2)
+        host = out.cpu().numpy().view(np.uint32)
+        for i in rows[:3]:
+            np.testing.assert_array_equal(host[off[i]:off[i + 1]], oracle.eqcounts_rows(bits.view(np.float64), i, i + 1), err_msg=f"{name} (again) row {i}")
+        cs.close()
+        del t_dev
+
+
+def test_k2_timed_sequence_at_config3_vs_oracle(gpu_ctx, d2g, oracle):
+    """exactly the sequence bench.py times -- announce_ut_dev -> update_dev -> lut_ut_dev on synthetic_registers(10000, 1024, 66, 20260928),
+    finalised -- three prepares in a row into a buffer pre-set to garbage, ~200 rows (first rows, the seams of an 8-way partition, random rows, last
+    rows) of the float output bit for bit against the oracle after every one."""
+    import torch
+    N, S = 10_000, 1024
+    regs = synth.synthetic_registers(N, S, nclusters=66, seed=20260928)
+    sig, cards = d2g.oph_finalize(regs, S, nthreads=8)
+    off = _ut_offsets(N)
+    rng = np.random.default_rng(6)
+    seams = [int(x) for x in d2g.ut_partition(N, 8)]
+    rows = sorted(set(list(range(0, 24)) + [min(N - 2, max(0, b + d)) for b in seams for d in (-2, -1, 0, 1)] + [int(x) for x in rng.integers(0, N - 1, 120)] + list(range(N - 25, N - 1))))
+    want = {i: oracle.allpairs_ut(sig, cards, measure=oracle.SIMILARITY, k=31, rows=(i, i + 1), nthreads=4).view(np.uint32) for i in rows}
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    t_dev = torch.from_numpy(sig.view(np.int64)).to(dev)
+    lut = torch.from_numpy(d2g.epilogue_lut(S, d2g.SIMILARITY, 31)).to(dev)
+    fout = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
+    cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_AUTO, stream=stream)
+    for rep in range(3):
+        fout.view(torch.int32).fill_(0x7FC12345)                          # garbage (a NaN pattern no table holds)
+        cs.announce_ut_dev(fout.data_ptr(), 0, N, lut_dev_ptr=lut.data_ptr())
+        cs.update_dev(t_dev.data_ptr(), stream)
+        cs.lut_ut_dev(lut.data_ptr(), fout.data_ptr(), 0, N, stream)
+        info = cs.sparse_info(stream)
+        assert info["sorted_operand"] and info["tiles_listed"] > 0 and not info["dense_kernel_ran"], (rep, info)
+        host = fout.cpu().numpy().view(np.uint32)
+        assert not (host == 0x7FC12345).any(), rep                        # every output word was written
+        for i in rows:
+            np.testing.assert_array_equal(host[off[i]:off[i + 1]], want[i], err_msg=f"prepare {rep} row {i}")
+    cs.close()
