@@ -23,7 +23,8 @@ struct d2g_tuning {
     }
 };
 void d2g_tuning_load(d2g_tuning &t);
-uint64_t d2g_tuning_hash(const d2g_tuning &t, const char *prefix_a, const char *prefix_b);   // FNV-1a over the switches whose name starts with either prefix
+std::string d2g_k2_tuning_json(const d2g_ctx *ctx);   // (d2g_k2_bitslice.hip) {"D2G_BS_SPARSE_MIN_N": 8192, ...}: the resolved values of the same switches
+uint64_t d2g_k2_tuning_hash(const d2g_ctx *ctx);   // (d2g_k2_bitslice.hip) FNV-1a over the RESOLVED values of the switches that select K2 kernels and thresholds: what the ranks of one job must agree on
 
 struct d2g_ctx {
     int device = -1;

@@ -454,7 +454,7 @@ int d2g_sketcher_ingest_fasta(d2g_sketcher *sk, const uint8_t *raw, size_t raw_b
     // d2g_seqpack::close_run_raw does), per-genome offsets and k-mer counts
     std::sort(starts.begin(), starts.end());
     uint32_t max_run = 1u << 30;
-    if (const char *e = ctx->tune.get("D2G_MAX_RUN")) { const long v = std::atol(e); if (v >= 64) max_run = (uint32_t)v; }
+    if (const char *e = std::getenv("D2G_MAX_RUN")) { const long v = std::atol(e); if (v >= 64) max_run = (uint32_t)v; }     // (the environment, as d2g_seqpack reads it: ONE source for the host packer and this table -- ADVICE r5)
     size_t si = 0;
     for (size_t g = 0; g < n; ++g) {
         uint64_t nk = 0;

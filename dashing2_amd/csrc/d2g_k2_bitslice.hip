@@ -77,6 +77,15 @@ __device__ __forceinline__ uint32_t bs_hash(uint64_t v, int logT) {
 // kernel stays; what it costs is ~84 dependent round trips per workgroup (three per batch of eight values and pass) with one 128 KiB-table
 // workgroup per CU to hide them.)
 constexpr uint32_t BS_SPLIT_SHIFT = 28, BS_RANK_MASK = (1u << BS_SPLIT_SHIFT) - 1u;
+#ifdef D2G_RANK_TRACE
+// variant builds only (tools/build_variant.sh ranktrace -DD2G_RANK_TRACE; tools/rank_trace.py): per-workgroup time stamps of the rank kernel --
+// FAST: 0 start, 1 values loaded + table cleared, 2 claims done, 3 confirms done, 4 compaction done, 5 ids stored;
+// general: 0 start, then per partition pass p (first four): 1+2p walk (load, claim, confirm, pending ids) done, 2+2p compaction + final ids done
+__device__ unsigned long long g_rank_trace[8192 * 16];
+#define RK_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && (k) < 16) g_rank_trace[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RK_STAMP(k) do { } while (0)
+#endif
 template <bool MULTI, bool FAST>
 __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t *__restrict__ cols, size_t N, size_t Npad,
                                                                   uint32_t T, int logT, uint32_t *ids_all, uint32_t *colcnt,
@@ -96,6 +105,7 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
     __shared__ uint32_t running;
     constexpr uint32_t BS_MAXFIX = 64;
     __shared__ uint32_t nfix, fix_j[BS_MAXFIX], fix_h[BS_MAXFIX];
+    RK_STAMP(0);
     if (tid == 0) { running = 1; nfix = 0; }                             // id 0 is reserved for singletons
     const int lane = tid & 63, wave = tid >> 6;
     // owner_all (single-partition kernels of sets that take the sparse path): owner[t][r - 1] = the sketch that owns the slot of the value
@@ -187,7 +197,11 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         }
         for (uint32_t h = tid; h < Tl; h += BS_RANK_THREADS) own[h] = BS_EMPTY;
         __syncthreads();
+        RK_STAMP(1);
         uint32_t candidate = 0;                                           // bit i: value i stopped at a tag match
+        // (round 6: per-workgroup time stamps -- tools/rank_trace.py, profiles/r06_rank_trace.txt -- put this claim phase at 10.7 of the workgroup's 21 us at
+        // config 3 (6.1 of 15.7 on unrelated sketches): a quarter of the LDS atomic rate, i.e. the dependent compare-and-swap round trips of waves whose
+        // every step waits for its slowest lane.  Two chains per thread in flight, interleaved, were measured: 13.2 us)
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const size_t j = (size_t)i * BS_RANK_THREADS + tid;
@@ -211,6 +225,10 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         // the confirm phase costs 15 us for ten million candidates whatever its batch size)
         constexpr int CB = 2;                                             // owner fetches in flight per thread
         uint32_t redo = 0;
+#ifdef D2G_RANK_TRACE
+        __syncthreads();
+        RK_STAMP(2);
+#endif
 #pragma unroll
         for (int c = 0; c < PF; c += CB) {
             uint32_t o[CB];
@@ -245,12 +263,18 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
             else atomicOr(status, 1u);                                    // cannot happen by chance; the host falls back to DIRECT
         }
         __syncthreads();
+        RK_STAMP(3);
         compact();
+        RK_STAMP(4);
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const size_t j = (size_t)i * BS_RANK_THREADS + tid;
             if (j < N && !(skip >> i & 1)) ids[j] = own[hs[i]];
         }
+#ifdef D2G_RANK_TRACE
+        __syncthreads();
+        RK_STAMP(5);
+#endif
         for (uint32_t k = tid; k < nfix && k < BS_MAXFIX; k += BS_RANK_THREADS) ids[fix_j[k]] = own[fix_h[k]];
         if (tid == 0) { colcnt[t * BS_CC_STRIDE] = running - 1; colcnt[t * BS_CC_STRIDE + 5] = running - 1; }   // #values shared by >= 2 sketches ([5]: a copy the column plan leaves alone -- sp_sample_fin_kernel reads it beside that kernel)
         return;
@@ -331,6 +355,7 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
             }
         }
         __syncthreads();
+        RK_STAMP(1 + 2 * (part - part_lo));
         compact();
         for (size_t j0 = 0; j0 < N; j0 += (size_t)PG * BS_RANK_THREADS) {
             uint32_t sl[PG];
@@ -347,6 +372,7 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
             }
         }
         __syncthreads();
+        RK_STAMP(2 + 2 * (part - part_lo));
     }
     if (tid == 0) { colcnt[t * BS_CC_STRIDE + split] = running - 1; if (nsplit == 1) colcnt[t * BS_CC_STRIDE + 5] = running - 1; }   // #values shared by >= 2 sketches (this split's)
 }
@@ -919,7 +945,9 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const bool sparse_path = set->sparse_ok && !set->export_only && !set->want_exchange;
     set->ride_next = 0; set->ride_total = 0;
     set->ride_mask = sp_tuning(ctx).ride;
-    if (set->ride_out && sparse_path && set->ride_mask && !sp_will_skip(ctx, set))
+    // (the remembered word is device-written host memory read without synchronisation: read ONCE per prepare -- ADVICE r5 -- and handed down)
+    set->skip_cached = sparse_path ? (sp_will_skip(ctx, set) ? 1 : 0) : -1;
+    if (set->ride_out && sparse_path && set->ride_mask && set->skip_cached != 1)
         set->ride_total = (uint32_t)std::min<size_t>(sp_fill_pieces(set->ride_cnt), 0x7FFFFFFFu);
     if (sp_fill_pieces(set->ride_cnt) > 0x7FFFFFFFu) set->ride_total = 0;
     // the status word meta[ntb] was zeroed by the transpose kernel that filled d_cols (no memset node in the chain)
@@ -1161,8 +1189,36 @@ int d2g_bitslice_debug_read(d2g_ctx *ctx, const d2g_cmp_set *set, hipStream_t s,
     return D2G_OK;
 }
 
+// what the engines of one multi-GPU job must agree on: the RESOLVED values (a rank with D2G_SP_LINK=1 and one that leaves it unset resolve the
+// same kernels -- ADVICE r5: the textual form refused them as different)
+uint64_t d2g_k2_tuning_hash(const d2g_ctx *ctx) {
+    const SpTuning t = sp_tuning(ctx);
+    long long tag = -1, nsplit = 0;
+    if (const char *e = ctx->tune.get("D2G_BS_TAGBITS")) tag = std::atoi(e);
+    if (const char *e = ctx->tune.get("D2G_BS_NSPLIT")) nsplit = std::atoi(e);
+    const long long v[] = {t.sparse, (long long)t.min_n, t.link, (long long)(t.tile_frac * 1e6), t.olink, t.emit_big, t.ride, t.remember, (long long)t.list_div, (long long)t.long_list,
+                           t.list_form, t.predict, sort_columns(ctx) ? 1 : 0, tag, nsplit};
+    uint64_t h = 1469598103934665603ull;
+    for (long long x : v) for (int b = 0; b < 8; ++b) { h ^= (uint64_t)(x >> (8 * b)) & 0xFF; h *= 1099511628211ull; }
+    return h;
+}
+
+std::string d2g_k2_tuning_json(const d2g_ctx *ctx) {
+    const SpTuning t = sp_tuning(ctx);
+    char b[640];
+    std::snprintf(b, sizeof b, "{\"D2G_BS_SPARSE\": %d, \"D2G_BS_SPARSE_MIN_N\": %zu, \"D2G_BS_SORT\": %d, \"D2G_SP_LINK\": %d, \"D2G_SP_OLINK\": %d, \"D2G_SP_TILE_FRAC\": %.3f, "
+                  "\"D2G_SP_LIST_DIV\": %zu, \"D2G_SP_LONG_LIST\": %zu, \"D2G_SP_LIST_FORM\": %d, \"D2G_SP_PREDICT\": %d, \"D2G_SP_REMEMBER\": %d, \"D2G_SP_RIDE\": %d, \"D2G_SP_EMIT_BIG\": %d}",
+                  t.sparse ? 1 : 0, t.min_n, sort_columns(ctx) ? 1 : 0, t.link, t.olink, t.tile_frac, t.list_div, t.long_list, t.list_form, t.predict, t.remember, t.ride, t.emit_big);
+    return b;
+}
+
 void d2g_warm_k2_bitslice() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&bs_colplan_kernel)); }
 
+#ifdef D2G_RANK_TRACE
+extern "C" int d2g_debug_rank_trace(unsigned long long *out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rank_trace), std::min<size_t>(n, 8192 * 16) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef D2G_SP_TRACE
 // variant builds only: the time stamps of the last sparse pair kernel (tools/sp_trace.py)
 extern "C" int d2g_debug_sp_trace(unsigned long long *out, size_t n) {

@@ -983,10 +983,10 @@ __global__ __launch_bounds__(SP_FILL_THREADS) void sp_fill_kernel(uint32_t *__re
     }
 }
 
-// the pair list bin by bin (see SpBins).  Every workgroup scans binc[] for itself (<= 16 384 bins: 16 per thread), workgroup 0 leaves the prefix
+// the pair list bin by bin (see SpBins).  Every workgroup scans binc[] for itself (<= 39 936 bins: 39 per thread), workgroup 0 leaves the prefix
 // for the compose kernel; then it moves the slice its counting twin (sp_hist_body, same index) counted: the place of an entry is the bin's start
 // + what the twin's atomic returned + an LDS cursor.  One pass, no global atomics.
-constexpr uint32_t SP_BIN_MAX = 16384;
+constexpr uint32_t SP_BIN_MAX = 39 * 1024;    // bins a set may have: their cursors live in the LDS of one workgroup (156 KB); 50 000 sketches: 1563 bands x 25 chunks of 2048 columns
 __global__ __launch_bounds__(1024) void sp_bin_kernel(const unsigned long long *__restrict__ plist, unsigned long long *__restrict__ plist2, uint32_t *__restrict__ plctl,
                                                       uint32_t plcap, SpBins bn, const uint32_t *__restrict__ hoff, const uint32_t *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lc[];     // [nbins] cursors
@@ -1313,19 +1313,17 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
 // 297 us at N = 50 000)
 
 // ---- host side
+constexpr size_t SP_UNITE_STRIDE = 4;     // every 4th column pair takes part in the uniting pass (all of them: 18 -> 10 us at config 3, round 5)
+constexpr size_t SP_GRID_MULT = 4;        // workgroups of the sparse pair kernel, in units of what is resident at once (exactly one resident wave of them: 52 -> 85 us)
 struct SpTuning {
     bool sparse = true;                 // D2G_BS_SPARSE: 0 = every launch walks every tile
     size_t min_n = 8192;                // D2G_BS_SPARSE_MIN_N: below ~6000 sketches the extra launches cost more than the tiles they skip
     int link = 1;                       // D2G_SP_LINK: 0 = no families (every sketch its own segment: the pair list alone; tests)
-    int attach = 1;                     // D2G_SP_ATTACH: 0 = no second chance for sketches no column pair linked
     double tile_frac = 0.35;            // D2G_SP_TILE_FRAC: the segments may cover this fraction of all tiles before the dense walk is cheaper
     int olink = 1;                      // D2G_SP_OLINK: 0 = the table form of the link passes even where the rank kernel left an owner per value (tests: the multi-GPU engine's form)
     int emit_big = 0;                   // D2G_SP_EMIT_BIG: sp_emit_kernel counts with two words per value at every N (it does from N = 65 536 on; tests)
     int ride = 63;                      // D2G_SP_RIDE: which kernels of the prepare carry an announced output's fill (d2g_cmp_ut_announce_dev) -- 1 column plan, 2 flatten, 4 count, 8 attach, 16 scan, 32 place; 0 = none, the launch fills (measurements)
     int remember = 1;                   // D2G_SP_REMEMBER: 0 = every prepare runs the ordering, whatever the last one decided
-    size_t unite_stride = 4;            // D2G_SP_UNITE_STRIDE: every n-th column pair takes part in the uniting pass (1 = all)
-    size_t grid_mult = 4;               // D2G_SP_GRID_MULT: workgroups of the sparse pair kernel, in units of what is resident at once
-    size_t bin_wgs = 0;                 // D2G_SP_BIN_WGS: workgroups that count and move a long list (0: one per 16 384 entries of a full list, one per two CUs at most)
     size_t long_list = 786432;          // D2G_SP_LONG_LIST: a pair list of this many entries or more is binned and composed (the last prepare's length decides)
     int predict = 1;                    // D2G_SP_PREDICT: 0 = no sample before the ordering of a set's first prepare (the ordering finds out by itself, as in round 5)
     int list_form = 0;                  // D2G_SP_LIST_FORM: 1 = always entry by entry, 2 = always binned (tests, measurements)
@@ -1336,15 +1334,11 @@ SpTuning sp_tuning(const d2g_ctx *ctx) {
     if (const char *e = ctx->tune.get("D2G_BS_SPARSE")) v.sparse = !(e[0] == '0');
     if (const char *e = ctx->tune.get("D2G_BS_SPARSE_MIN_N")) v.min_n = (size_t)std::atoll(e);
     if (const char *e = ctx->tune.get("D2G_SP_LINK")) v.link = std::atoi(e) != 0;
-    if (const char *e = ctx->tune.get("D2G_SP_ATTACH")) v.attach = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_TILE_FRAC")) { const double f = std::atof(e); if (f > 0 && f <= 1) v.tile_frac = f; }
     if (const char *e = ctx->tune.get("D2G_SP_OLINK")) v.olink = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_EMIT_BIG")) v.emit_big = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_REMEMBER")) v.remember = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_RIDE")) v.ride = std::atoi(e) & 63;
-    if (const char *e = ctx->tune.get("D2G_SP_UNITE_STRIDE")) { const long d = std::atol(e); if (d >= 1 && d <= 1024) v.unite_stride = (size_t)d; }
-    if (const char *e = ctx->tune.get("D2G_SP_GRID_MULT")) { const long d = std::atol(e); if (d >= 1 && d <= 64) v.grid_mult = (size_t)d; }
-    if (const char *e = ctx->tune.get("D2G_SP_BIN_WGS")) { const long d = std::atol(e); if (d >= 1 && d <= 4096) v.bin_wgs = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_LONG_LIST")) { const long long d = std::atoll(e); if (d >= 0) v.long_list = (size_t)d; }
     if (const char *e = ctx->tune.get("D2G_SP_PREDICT")) v.predict = std::atoi(e) != 0;
     if (const char *e = ctx->tune.get("D2G_SP_LIST_FORM")) { const int d = std::atoi(e); if (d >= 0 && d <= 2) v.list_form = d; }
@@ -1377,7 +1371,6 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     set->spz_words = (Npad + 1) + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS + (size_t)set->nbins;
     // the workgroups that count (and then move) the list's entries: one per ~16 384 entries of a full list, at most two per CU
     set->bin_nwg = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)std::max(ctx->num_cus / 2, 1), div_up<size_t>(set->plist_cap, 16384)));   // (128 of them measured best at config 3: 64 / 128 / 512 / 1024 -> counting + moving 90 / 65 / 70 / 84 us)
-    if (sp_tuning(ctx).bin_wgs) set->bin_nwg = (uint32_t)sp_tuning(ctx).bin_wgs;
     const size_t planes_words = (size_t)set->ntb * set->nbits_cap + 1;
     hipError_t e;
     if ((e = hipMalloc((void **)&set->d_stream_s, planes_words * 2 * Nstride * sizeof(uint32_t))) != hipSuccess ||
@@ -1637,7 +1630,9 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
     const size_t N = set->N, Npad = set->Npad, S = set->ncols;
     // (a prepare that has handed out riders on a REMEMBERED give-up goes through: its place kernel carries the rest of the fill; one that has just
     // looked at its matrix and found it dense skips -- the dense launch writes every output itself)
-    const bool skip = set->pred_valid ? set->pred_dense : (sp_will_skip(ctx, set) && set->ride_total == 0);
+    const bool remembered = set->skip_cached >= 0 ? set->skip_cached == 1 : sp_will_skip(ctx, set);      // (d2g_bitslice_prepare read the word already)
+    set->skip_cached = -1;
+    const bool skip = set->pred_valid ? set->pred_dense : (remembered && set->ride_total == 0);
     set->sp_big = sp_expect_long_list(ctx, set);
     ++set->sp_prepares;
     set->pred_valid = false;                                           // (a prediction serves the prepare that made it)
@@ -1656,7 +1651,7 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
         D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12));
         D2G_HIP(ctx, hipFuncSetAttribute((const void *)sp_link_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 8));
         const unsigned npair = (unsigned)(S / 2);
-        const uint32_t ustride = (uint32_t)std::max<size_t>(1, std::min<size_t>(tu.unite_stride, npair / 32));   // at least 32 column pairs take part in the uniting pass
+        const uint32_t ustride = (uint32_t)std::max<size_t>(1, std::min<size_t>(SP_UNITE_STRIDE, npair / 32));   // at least 32 column pairs take part in the uniting pass
         if (set->d_owner && !split && tu.olink) {                        // one holder per shared value at hand: the streaming form
             const unsigned nx = (unsigned)div_up<size_t>(N, 1024);
             hipLaunchKernelGGL(sp_olink_kernel<0>, dim3(nx, npair), dim3(256), 0, s, set->d_ids, N, Npad, (uint32_t)S, set->d_owner, set->owner_stride, 1u, la, set->d_hint);
@@ -1674,7 +1669,7 @@ int sp_prepare_order(d2g_ctx *ctx, d2g_cmp_set *set, bool split, hipStream_t s) 
     const uint32_t seg_limit = (uint32_t)std::min<size_t>((size_t)((double)ntile_all * tu.tile_frac), 0x3FFFFFFF);
     // (one single-workgroup kernel for count + scan + place with the counters in LDS was measured at N = 10 000: 25 us against 19 for the three)
     { unsigned g; const SpRider rd = sp_take_rider(set, nb, SP_RW_COUNT, false, &g, 4); hipLaunchKernelGGL(sp_count_kernel, dim3(g), dim3(256), 0, s, la, lb, N, set->d_lcnt, set->d_order, rd); }
-    if (tu.link && tu.attach && S >= 2) {
+    if (tu.link && S >= 2) {
         unsigned g; const SpRider rd = sp_take_rider(set, nb, SP_RW_ATTACH, false, &g, 8);
         hipLaunchKernelGGL(sp_attach_kernel, dim3(g), dim3(256), 0, s, lb, set->d_lcnt, set->d_hint, N, Npad, set->d_order, rd);
     }
@@ -1722,7 +1717,7 @@ int sp_permute(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     if (!set->full_list_valid) { ctx->last_error = "bitslice sparse: the permute launch does not fit a grid"; return D2G_ERR_INTERNAL; }
     const size_t lds = std::max<size_t>((size_t)part * (both ? 8 : 4), set->sp_big ? (size_t)set->nbins * 4 : 0);
     auto kern = both ? sp_permute_lds_kernel<true> : sp_permute_lds_kernel<false>;
-    D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));   // (+ ~2 KB of static LDS: the list builders, the pairs of a short list)
+    D2G_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 157 * 1024));   // (+ ~2 KB of static LDS: the list builders, the pairs of a short list)
     hipLaunchKernelGGL(kern, dim3((unsigned)(nperm + fl.nwg + hs.nhw)), dim3(1024), lds, s, set->d_stream, set->d_stream_s, set->Nstride, set->d_meta,
                        set->d_sperm, set->d_order, fl, (uint32_t)nperm, (uint32_t)set->nbits_cap, H, part, hs, sp_pairs_of(set, sp_colwork_of(set), set->d_label + set->Npad));
     if (set->sp_big) {                                                  // the list, bin by bin (d_plist2): as many workgroups as the counting ones
@@ -1838,7 +1833,7 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     // a multiple of 8 (every XCD's list gets the same number of workgroups), four times what is resident at once: the lists differ in
     // length, and a workgroup that finds nothing at its index leaves at once -- the dispatcher evens the lists out sub-tile by sub-tile
     // (exactly one resident wave of workgroups took as long as the longest list: 52 -> 85 us at config 3)
-    const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * 4, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * sp_tuning(ctx).grid_mult) / 8 * 8);
+    const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * 4, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * SP_GRID_MULT) / 8 * 8);
     // the pair list, composed region by region (before the pair kernel: that one STORES, see SpBins) -- when this set's prepare binned it
     if (set->sp_big) {
         const uint32_t band0 = (uint32_t)(r0 >> 5), nband = (uint32_t)((r1 - 1) >> 5) - band0 + 1u;

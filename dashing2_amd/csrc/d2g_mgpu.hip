@@ -438,7 +438,7 @@ int verify_shape_across_ranks(d2g_allpairs *e) {
     uint64_t *d_v = nullptr;
     std::vector<uint64_t> all((size_t)W * 4, 0);
     // [3]: chunks in the low word, a hash of the K2 switches (D2G_BS_* / D2G_SP_*: which kernels a rank runs) in the high one
-    const uint64_t mine[4] = {(uint64_t)e->N, (uint64_t)e->S, (uint64_t)e->W, (uint64_t)e->C | (d2g_tuning_hash(e->ctx->tune, "D2G_BS_", "D2G_SP_") << 32)};
+    const uint64_t mine[4] = {(uint64_t)e->N, (uint64_t)e->S, (uint64_t)e->W, (uint64_t)e->C | (d2g_k2_tuning_hash(e->ctx) << 32)};
     D2G_HIP(ctx, hipMalloc((void **)&d_v, (size_t)W * 32));
     int rc = D2G_OK;
     auto fail = [&](int r) { (void)hipFree(d_v); return r; };
@@ -473,7 +473,7 @@ int check_group(d2g_allpairs **es, int n) {
     for (int i = 0; i < n; ++i) {
         if (!es[i]) return D2G_ERR_INVALID;
         D2G_CHECK(es[i]->ctx, es[i]->N == es[0]->N && es[i]->S == es[0]->S && es[i]->W == es[0]->W && es[i]->C == es[0]->C, "allpairs: engines of different shapes");
-        if (d2g_tuning_hash(es[i]->ctx->tune, "D2G_BS_", "D2G_SP_") != d2g_tuning_hash(es[0]->ctx->tune, "D2G_BS_", "D2G_SP_")) {
+        if (d2g_k2_tuning_hash(es[i]->ctx) != d2g_k2_tuning_hash(es[0]->ctx)) {
             const char *msg = "allpairs: the ranks' contexts resolved different D2G_BS_* / D2G_SP_* switches (d2g_ctx_tuning): every rank must run the same kernels";
             es[i]->ctx->last_error = msg; es[0]->ctx->last_error = msg;       // whichever context the caller asks
             return D2G_ERR_INVALID;
@@ -798,6 +798,9 @@ int d2g_allpairs_prepare_dev(d2g_allpairs *e, const uint64_t *my_rows_dev, void 
 int d2g_allpairs_step_all(d2g_allpairs **engs, int n, const uint64_t *const *rows_dev, const float *const *lut_dev,
                           void *const *out_dev, void *const *streams) {
     if (int rc = check_group(engs, n)) return rc;
+    // (the announced slab is engine state only for the duration of this call -- whatever exit the prepare takes, a later
+    // d2g_allpairs_prepare_dev on the engine must not pre-fill a stale, possibly freed, pointer)
+    struct Clear { d2g_allpairs **e; int n; ~Clear() { for (int i = 0; i < n; ++i) { e[i]->pre_out = nullptr; e[i]->pre_lut = nullptr; } } } clear{engs, n};
     for (int i = 0; i < n; ++i) { engs[i]->pre_out = out_dev ? out_dev[i] : nullptr; engs[i]->pre_lut = (lut_dev && lut_dev[i]) ? lut_dev[i] : nullptr; }
     if (int rc = d2g_allpairs_prepare_all(engs, n, rows_dev, streams)) return rc;
     for (int i = 0; i < n; ++i) {

@@ -8,8 +8,8 @@
 // (D2G_MAX_RUN and D2G_NO_AVX512 in d2g_host.cpp, D2G_RCCL_LIB, D2G_COMM_LOOPBACK) are read where they apply.
 static const char *const kTuningNames[] = {
     "D2G_BS_SORT", "D2G_BS_NSPLIT", "D2G_BS_TAGBITS",
-    "D2G_BS_SPARSE", "D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_LONG_LIST", "D2G_SP_LIST_FORM", "D2G_SP_PREDICT", "D2G_SP_BIN_WGS", "D2G_SP_UNITE_STRIDE", "D2G_SP_GRID_MULT", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG", "D2G_SP_OLINK", "D2G_SP_RIDE",
-    "D2G_MGPU_CHUNKS", "D2G_MAX_RUN",
+    "D2G_BS_SPARSE", "D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_LONG_LIST", "D2G_SP_LIST_FORM", "D2G_SP_PREDICT", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG", "D2G_SP_OLINK", "D2G_SP_RIDE",
+    "D2G_MGPU_CHUNKS",
     "D2G_K3_COMPACT", "D2G_K3_L1BITS", "D2G_K3_BUCKET_KEYS", "D2G_K3_SUB_KEYS", "D2G_K3_SPLIT_MIN", "D2G_K3_SUBBATCH", "D2G_K3_ROUND_KEYS",
     "D2G_K3_GUESS_SCALE", "D2G_K3_GRID_PER_CU", "D2G_K3_LIGHT", "D2G_K3_GQ_SCALE",
 };
@@ -17,13 +17,6 @@ void d2g_tuning_load(d2g_tuning &t) {
     t.kv.clear();
     for (const char *n : kTuningNames)
         if (const char *v = std::getenv(n)) t.kv.emplace_back(n, v);
-}
-uint64_t d2g_tuning_hash(const d2g_tuning &t, const char *pa, const char *pb) {
-    uint64_t h = 1469598103934665603ull;
-    auto mix = [&](const std::string &x) { for (unsigned char c : x) { h ^= c; h *= 1099511628211ull; } h ^= 0xff; h *= 1099511628211ull; };
-    for (const auto &p : t.kv)
-        if ((pa && !p.first.compare(0, std::strlen(pa), pa)) || (pb && !p.first.compare(0, std::strlen(pb), pb))) { mix(p.first); mix(p.second); }
-    return h;
 }
 
 extern "C" {
@@ -44,6 +37,8 @@ int d2g_ctx_tuning(const d2g_ctx *c, char *buf, size_t cap) {
         for (char ch : c->tune.kv[i].second) { if (ch == '"' || ch == '\\') j += '\\'; if ((unsigned char)ch >= 0x20) j += ch; }
         j += "\"";
     }
+    // ... and what the switches that select K2's kernels and thresholds RESOLVED to, set or not (the bench line's `tuning` names the defaults)
+    j += std::string(c->tune.kv.empty() ? "" : ", ") + "\"resolved\": " + d2g_k2_tuning_json(c);
     j += "}";
     if (buf && cap) { std::snprintf(buf, cap, "%s", j.c_str()); }
     return (int)j.size();

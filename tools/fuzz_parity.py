@@ -89,17 +89,20 @@ def main():
                 N = int(rng.integers(2, 700)) if rng.random() < 0.8 else int(rng.integers(700, 2600))
                 S = int(rng.choice([32, 64, 100, 128, 1000, 1024])); meas = int(rng.integers(0, 6))
                 os.environ["D2G_BS_SORT"] = str(int(rng.integers(0, 2)))                    # column plan on / off
-                # sparse tiles + pair list (round 5): forced on for these small matrices half of the time -- families found or not
-                # (D2G_SP_LINK=0: the pair list alone), with or without the attach step, any tile budget, a short list (overflow ->
-                # dense walk); the other half takes the default (dense walk below 8192 sketches)
-                for var in ("D2G_SP_RIDE", "D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_ATTACH", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_OLINK", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG"):
+                # sparse tiles + pair list (rounds 5-6): forced on for these small matrices half of the time -- families found or not
+                # (D2G_SP_LINK=0: the pair list alone), any tile budget, a short list (overflow -> dense walk), the list applied entry by
+                # entry or binned + composed, with or without the first look at the matrix; the other half takes the default (dense walk
+                # below 8192 sketches)
+                for var in ("D2G_SP_RIDE", "D2G_BS_SPARSE_MIN_N", "D2G_SP_LINK", "D2G_SP_TILE_FRAC", "D2G_SP_LIST_DIV", "D2G_SP_OLINK", "D2G_SP_REMEMBER", "D2G_SP_EMIT_BIG",
+                            "D2G_SP_LIST_FORM", "D2G_SP_PREDICT"):
                     os.environ.pop(var, None)
                 if rng.random() < 0.5:
                     os.environ["D2G_BS_SPARSE_MIN_N"] = "1"
                     if rng.random() < 0.2:
                         os.environ["D2G_SP_LINK"] = "0"
-                    if rng.random() < 0.3:
-                        os.environ["D2G_SP_ATTACH"] = "0"
+                    os.environ["D2G_SP_LIST_FORM"] = str(int(rng.choice([0, 1, 2])))              # the list's two forms (0: the last list's length decides)
+                    if rng.random() < 0.5:
+                        os.environ["D2G_SP_PREDICT"] = "0"                                    # no sample before a set's first ordering
                     os.environ["D2G_SP_TILE_FRAC"] = str(rng.choice([0.05, 0.35, 1.0]))
                     if rng.random() < 0.2:
                         os.environ["D2G_SP_LIST_DIV"] = str(int(rng.choice([1, 64, 4096])))
