@@ -69,7 +69,7 @@ struct d2g_cmp_set {
     bool full_list_valid = false;
     uint32_t *h_gaveup = nullptr, *d_gaveup = nullptr;   // a word of mapped host memory: 1 = the last ordering raised order[0] (the next prepare skips the ordering)
     unsigned sp_prepares = 0; bool sp_skipped = false;
-    bool sample_pending = false;
+    bool sample_pending = false; uint32_t sample_ticket = 0;   // the first look's kernels are enqueued; the word (h_gaveup[6]) their last workgroup writes when the sums are in
     int skip_cached = -1;             // this prepare's reading of the remembered give-up (-1: not read yet)
     uint32_t *d_samp = nullptr;       // [16][Npad] + 2: the first look at a matrix (sp_sample): registers shared with sixteen sampled sketches
     bool pred_valid = false, pred_dense = false; double pred_entries = 0, pred_family_pairs = 0;   // what the sample of THIS prepare says (valid until its ordering has been enqueued)

@@ -21,6 +21,7 @@
 #include "d2g_internal.h"
 #include "d2g_k2.h"
 #include "d2g_k2_shape.h"
+#include <chrono>
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -292,6 +293,14 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
         // fast path: claim with LDS compare-and-swaps only, then confirm the candidates with their owner fetches in flight
         // together (with one 128 KiB-table workgroup per CU nothing else hides a round trip)
         constexpr int PG = 8;
+        // which of this thread's values the pass placed, a byte per batch (up to eight batches: 65 536 sketches): the pass's second loop then
+        // fetches only THEIR pending words instead of every id of the column (round 6: 1033 -> 992 us at 50 000 sketches).
+        // (Round 6 also measured HASHED later passes -- the first pass leaves the top 30 bits of every later value's hash product in ids[], the later
+        // passes walk those 4-byte words instead of the 8-byte values, only tag matches fetch their value: correct, and SLOWER -- first pass 47 -> 74 us,
+        // later ones 43 -> 48: the walk is not bound by the bytes it reads but by its claim / confirm round trips; profiles/r06_rank_trace.txt)
+        const bool mine_known = N <= (size_t)8 * PG * BS_RANK_THREADS;
+        unsigned long long mine_all = 0;
+        int batch = 0;
         for (size_t j0 = 0; j0 < N; j0 += (size_t)PG * BS_RANK_THREADS) {
             uint64_t v[PG];
             uint32_t hs[PG];
@@ -353,21 +362,25 @@ __global__ __launch_bounds__(BS_RANK_THREADS) void bs_rank_kernel(const uint64_t
                 const uint64_t vv = col[j];
                 ids[j] = insert(vv, (uint32_t)j, bs_hash(vv, logT) & mask) | (MULTI ? ptag : 0u);
             }
+            if (batch < 8) mine_all |= (unsigned long long)mineb << (8 * batch);
+            ++batch;
         }
         __syncthreads();
         RK_STAMP(1 + 2 * (part - part_lo));
         compact();
-        for (size_t j0 = 0; j0 < N; j0 += (size_t)PG * BS_RANK_THREADS) {
+        batch = 0;
+        for (size_t j0 = 0; j0 < N; j0 += (size_t)PG * BS_RANK_THREADS, ++batch) {
             uint32_t sl[PG];
+            const uint32_t mb = mine_known ? (uint32_t)(mine_all >> (8 * batch)) & 0xFFu : 0xFFu;
 #pragma unroll
             for (int i = 0; i < PG; ++i) {
                 const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
-                sl[i] = j < N ? ids[j] : 0;
+                sl[i] = (j < N && (mb >> i & 1)) ? ids[j] : 0;
             }
 #pragma unroll
             for (int i = 0; i < PG; ++i) {
                 const size_t j = j0 + (size_t)i * BS_RANK_THREADS + tid;
-                if (j < N && (!MULTI || (tagged ? (sl[i] & ~0x7FFFu) == ptag : (sl[i] & BS_PENDING) != 0)))
+                if (j < N && (mb >> i & 1) && (mine_known || !MULTI || (tagged ? (sl[i] & ~0x7FFFu) == ptag : (sl[i] & BS_PENDING) != 0)))
                     ids[j] = own[sl[i] & (tagged ? 0x7FFFu : ~BS_PENDING)];
             }
         }
@@ -969,6 +982,9 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         if (nsplit > 1) D2G_HIP(ctx, hipMemsetAsync(set->d_ids, 0, S * Npad * sizeof(uint32_t), s));
         hipLaunchKernelGGL(kern, dim3((unsigned)(S * nsplit)), dim3(BS_RANK_THREADS), lds, s, set->d_cols, N, Npad, set->T, set->logT,
                            set->d_ids, set->d_colcnt, set->d_meta + set->ntb, tagbits_max, (uint32_t)S, nsplit, nsplit == 1 ? set->d_owner : (uint32_t *)nullptr, set->owner_stride);
+        // a set's first prepare looks at its matrix before it orders it: the sample needs the ids only, so it stands HERE and the two kernels
+        // below run while the host waits for its word (sp_sample_collect)
+        if (sparse_path && sp_sample_due(ctx, set)) { if (int rc = sp_sample_enqueue(ctx, set, s)) return rc; }
         unsigned g; const SpRider rd = sp_take_rider(set, 1, SP_RW_PLAN, false, &g, 1);
         hipLaunchKernelGGL(bs_colplan_kernel, dim3(g), dim3(BS_PLAN_THREADS), 0, s, set->d_colcnt, (uint32_t)S, set->ntb, nsplit, set->d_perm,
                            set->d_meta, set->d_meta + set->ntb, set->ex_meta, set->ex_status, sort_columns(ctx) ? 1 : 0, rd);
@@ -985,9 +1001,7 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         // (the planes kernel also initialises the ordering's arrays and clears the tile bitmap: no launch / memset of their own)
         hipLaunchKernelGGL(split ? bs_planes_kernel<true> : bs_planes_kernel<false>, grid, dim3(256), 0, s, set->d_ids, N, Npad,
                            set->d_planes, set->d_stream, set->Nstride, set->nbits_cap, set->d_meta, BS_FORM_STREAM, set->d_perm, set->d_colcnt, (const uint32_t *)nullptr, sp_init_of(set));
-        // a set's first prepare looks at its matrix before it orders it (the sample was enqueued behind the rank kernel; ONE synchronisation here)
-        if (sp_sample_due(ctx, set)) { if (int rc = sp_sample_enqueue(ctx, set, s)) return rc; }
-        if (int rc = sp_sample_collect(ctx, set, s)) return rc;
+        if (int rc = sp_sample_collect(ctx, set, s)) return rc;         // (the first look, enqueued behind the rank kernel: the host waits for its word here)
         if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
         if (int rc = sp_permute(ctx, set, s)) return rc;
         set->srt_valid = true; set->nat_valid = true;

@@ -886,7 +886,14 @@ __device__ __forceinline__ void sp_hist_body(uint32_t hw, uint32_t nhw, const un
     if (lo >= hi) return;
     for (uint32_t b = threadIdx.x; b < bn.nbins; b += 1024) lds[b] = 0;
     __syncthreads();
-    for (uint32_t k = lo + threadIdx.x; k < hi; k += 1024) { const unsigned long long e = plist[k]; if (e != SP_NULL_ENTRY) atomicAdd(&lds[sp_bin_of(bn, e)], 1u); }
+    // (eight entries per thread in flight: a load behind every LDS atomic waited out its round trip -- 26 -> 22 us for the launch at ten chance collisions per sketch)
+    for (uint32_t k0 = lo + threadIdx.x; k0 < hi; k0 += 8 * 1024) {
+        unsigned long long e8[8];
+#pragma unroll
+        for (uint32_t x = 0; x < 8; ++x) { const uint32_t k = k0 + x * 1024; e8[x] = k < hi ? plist[k] : SP_NULL_ENTRY; }
+#pragma unroll
+        for (uint32_t x = 0; x < 8; ++x) if (e8[x] != SP_NULL_ENTRY) atomicAdd(&lds[sp_bin_of(bn, e8[x])], 1u);
+    }
     __syncthreads();
     uint32_t *mine = hoff + (size_t)hw * bn.nbins;
     for (uint32_t b = threadIdx.x; b < bn.nbins; b += 1024) { const uint32_t c = lds[b]; if (c) mine[b] = atomicAdd(&bn.binc[b], c); }
@@ -1052,10 +1059,16 @@ __global__ __launch_bounds__(SP_CMP_T) void sp_compose_kernel(SpComposeArgs a, P
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     uint32_t mine = 0;
-    for (uint32_t k = tid; k < nb; k += T) {
-        const unsigned long long e = ent[k];
-        const uint32_t i = (uint32_t)e, r = i - i0, c = (uint32_t)(e >> 32) - c0;
-        if (c < SP_CMP_COLS && r < SP_CMP_ROWS && i >= a.r0 && i < a.r1) { atomicAdd(&tile[r * HW + (c % HW)], 1u << (16u * (c / HW))); ++mine; }
+    // (eight entries per thread in flight, as in sp_hist_body: 68 -> 59 us at ten chance collisions per sketch)
+    for (uint32_t k0 = tid; k0 < nb; k0 += 8 * T) {
+        unsigned long long e8[8];
+#pragma unroll
+        for (uint32_t x = 0; x < 8; ++x) { const uint32_t k = k0 + x * T; e8[x] = k < nb ? ent[k] : SP_NULL_ENTRY; }
+#pragma unroll
+        for (uint32_t x = 0; x < 8; ++x) {
+            const uint32_t i = (uint32_t)e8[x], r = i - i0, c = (uint32_t)(e8[x] >> 32) - c0;
+            if (c < SP_CMP_COLS && r < SP_CMP_ROWS && i >= a.r0 && i < a.r1) { atomicAdd(&tile[r * HW + (c % HW)], 1u << (16u * (c / HW))); ++mine; }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
     if ((tid & 63) == 0 && mine) atomicAdd(&s_cnt, mine);
@@ -1200,6 +1213,10 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     const uint32_t *mytiles = a.tiles + (size_t)xq * a.tiles_cap;
     const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    // the lane number where it is needed again BEHIND the plane walk (zeroing, reduction, epilogue, tail): two instructions there instead of a
+    // register carried through the walk, which has none to spare (the kernel ran with 16 bytes of scratch per lane for such values; 8 are left:
+    // a 64-bit constant of the epilogue's position arithmetic, stored and reloaded once per sub-tile, outside the walk)
+    auto lane_again = []() -> uint32_t { uint32_t l; asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l)); return l; };
     const bool full = a.rowstream == nullptr;
     const int g0 = a.ntb * ks / KS, g1 = a.ntb * (ks + 1) / KS;
     // first plane slot of this wave's groups: one wave-wide prefix over the groups' live plane counts (a scalar loop over up to 24
@@ -1237,15 +1254,15 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
         const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
         // (the list holds only sub-tiles with a row, on or above the diagonal of sorted positions, that can hold a pair of one segment: sp_tile_subs)
-        for (int x = threadIdx.x; x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
+        for (int x = ks * 64 + (int)lane_again(); x < IW * 64; x += 64 * KS) (&red[0][0])[x] = 0;
         __syncthreads();
         SP_STAMP(1);
-        uint32_t acc[IW][JR];
-#pragma unroll
-        for (int i = 0; i < IW; ++i)
-#pragma unroll
-            for (int c = 0; c < JR; ++c) acc[i][c] = 0;
         if (g1 > g0) {
+            uint32_t acc[IW][JR];
+#pragma unroll
+            for (int i = 0; i < IW; ++i)
+#pragma unroll
+                for (int c = 0; c < JR; ++c) acc[i][c] = 0;
             const size_t rstep = full ? 2 * a.Nstride : a.rstride;
             const size_t cstep = 2 * a.Nstride;
             const uint32_t *rp = (full ? a.stream : a.rowstream) + k0 + slot0 * rstep;
@@ -1258,18 +1275,18 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
                 nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
                 sp_group<JR>(nbits, rp, rstep, cp, coff, cstep, nx, acc);
             }
-        }
-        // every wave adds its share of the mismatch counts in LDS; afterwards wave ks finishes rows [ks IW/KS, (ks+1) IW/KS) -- the epilogue
-        // (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
-        // work while the other three wait
-        SP_STAMP(2);
+            // every wave adds its share of the mismatch counts in LDS; afterwards wave ks finishes rows [ks IW/KS, (ks+1) IW/KS) -- the epilogue
+            // (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
+            // work while the other three wait
+            SP_STAMP(2);
+            const uint32_t rl = lane_again();
 #pragma unroll
-        for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][lane], v); }
+            for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][rl], v); }
+        }
         __syncthreads();
         SP_STAMP(3);
         {
-            uint32_t el = (uint32_t)lane;
-            asm volatile("" : "+v"(el));                               // what the epilogue derives from the lane is computed here, not carried through the plane walk
+            const uint32_t el = lane_again();                         // what the epilogue derives from the lane is computed here, not carried through the plane walk
             uint32_t oj[JR];
 #pragma unroll
             for (int c = 0; c < JR; ++c) oj[c] = a.sperm[c0 + el + 64 * c];
@@ -1304,7 +1321,7 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     SP_STAMP(5);
     // a SHORT pair list, entry by entry, spread over all workgroups of the launch (those without a tile start here at once); a binned list was
     // applied by sp_compose_kernel before this kernel
-    if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + threadIdx.x, (size_t)pa.nwg * (64 * KS));
+    if (blockIdx.x < pa.nwg) sp_patch_add(pa, sh, store, a.S, (size_t)blockIdx.x * (64 * KS) + ks * 64 + lane_again(), (size_t)pa.nwg * (64 * KS));
     SP_STAMP(6);
 }
 
@@ -1494,7 +1511,7 @@ __global__ __launch_bounds__(256) void sp_sample_kernel(const uint32_t *__restri
 }
 // the counts -> (E, F) in mapped host memory; the kernel cleans up behind itself (counters, its sums, the ticket)
 __global__ __launch_bounds__(256) void sp_sample_fin_kernel(uint32_t *__restrict__ cntm, size_t N, size_t Npad, SpSampleRows rows, uint32_t *__restrict__ acc3, uint32_t *__restrict__ host_out,
-                                                            const uint32_t *__restrict__ colcnt, uint32_t ncols, int nsplit) {
+                                                            const uint32_t *__restrict__ colcnt, uint32_t ncols, int nsplit, uint32_t ticket) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t e = 0, f = 0;
     // (the same grid also sums what the rank kernel left: the shared values of every column, and the id planes a column of that many needs -- the
@@ -1528,6 +1545,9 @@ __global__ __launch_bounds__(256) void sp_sample_fin_kernel(uint32_t *__restrict
             host_out[2] = atomicExch(&acc3[3], 0u);
             host_out[3] = atomicExch(&acc3[4], 0u);
             acc3[2] = 0;
+            // the host waits for THIS word (sp_sample_collect polls it: the kernels enqueued behind this one keep the device busy meanwhile)
+            __threadfence_system();
+            __hip_atomic_store(&host_out[4], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -1592,7 +1612,7 @@ int sp_sample_enqueue(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     uint32_t *acc3 = set->d_samp + SP_SAMPLE_ROWS * Npad;                // (the counters and the control words are zero: cleared at allocation, then by the kernel itself)
     hipLaunchKernelGGL(sp_sample_kernel, dim3((unsigned)div_up<size_t>(N, 256), (unsigned)div_up<size_t>(set->ncols, SP_SAMPLE_COLS)), dim3(256), 0, s, set->d_ids, N, Npad, (uint32_t)set->ncols, rows, set->d_samp);
     hipLaunchKernelGGL(sp_sample_fin_kernel, dim3((unsigned)div_up<size_t>(std::max(N, set->ncols), 256)), dim3(256), 0, s, set->d_samp, N, Npad, rows, acc3, set->d_gaveup + 2,
-                       set->d_colcnt, (uint32_t)set->ncols, set->nsplit);
+                       set->d_colcnt, (uint32_t)set->ncols, set->nsplit, ++set->sample_ticket);
     D2G_HIP(ctx, hipGetLastError());
     set->sample_pending = true;
     return D2G_OK;
@@ -1601,9 +1621,20 @@ int sp_sample_enqueue(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
 int sp_sample_collect(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     if (!set->sample_pending) return D2G_OK;
     set->sample_pending = false;
-    D2G_HIP(ctx, hipStreamSynchronize(s));
     const size_t N = set->N;
     volatile uint32_t *h = (volatile uint32_t *)set->h_gaveup;
+    // The two kernels stand right behind the rank kernel; the column plan and the planes kernel are enqueued behind them and run while the host
+    // waits for the sample's word and enqueues what it decides -- the device does not idle over the decision.  Polling the mapped word costs a
+    // few microseconds; hipStreamSynchronize would also wait for the kernels behind (and took ~50 us to return and refill the queue at
+    // config 3).  The wait is bounded: a device that takes longer than a quarter of a second gets the synchronisation.
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (__atomic_load_n(&set->h_gaveup[6], __ATOMIC_ACQUIRE) != set->sample_ticket) {
+            __builtin_ia32_pause();
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(250)) { D2G_HIP(ctx, hipStreamSynchronize(s)); break; }
+        }
+    }
     const double scale = (double)N / (2.0 * SP_SAMPLE_ROWS), pairs = (double)N * (double)(N - 1) / 2.0;
     set->pred_valid = true;
     set->pred_entries = (double)h[2] * scale;

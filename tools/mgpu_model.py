@@ -133,8 +133,8 @@ def report(d, N, S):
 
         prep_kernels = ("k2_transpose_kernel", "bs_rank_kernel", "bs_colplan_kernel", "bs_planes_kernel")
         order_kernels = ("sp_unpack_kernel", "sp_link_kernel", "sp_flatten_kernel", "sp_attach_kernel", "sp_count_kernel", "sp_scan_kernel",
-                         "sp_place_kernel", "sp_emit_kernel", "sp_permute_kernel", "sp_permute_lds_kernel")
-        pair_kernels = ("sp_rows_kernel", "sp_gather_kernel", "sp_rowbm_kernel", "sp_list_kernel", "k2_bitslice_sparse_kernel", "k2_bitslice_kernel")
+                         "sp_place_kernel", "sp_emit_kernel", "sp_pairs_kernel", "sp_permute_lds_kernel", "sp_bin_kernel")
+        pair_kernels = ("sp_rows_kernel", "sp_gather_kernel", "sp_rowbm_kernel", "sp_list_kernel", "sp_compose_kernel", "k2_bitslice_sparse_kernel", "k2_bitslice_kernel")
 
         def launches(names):
             return sum(len(kt.get(k, [])) for k in names) / steps
@@ -163,6 +163,7 @@ def report(d, N, S):
             floor = t["pack"] + x1 + t["prep_chunk"] + C * x2 + t["derive_chunk"] + t["order"] + t["pair"]
             print(f"      floor of this design at W=8: pack {t['pack']:.3f} + first x1 {x1:.3f} + one chunk's prepare {t['prep_chunk']:.3f} + x2 {C}x{x2:.3f} + last derive {t['derive_chunk']:.3f} + order {t['order']:.3f} "
                   f"+ pair {t['pair']:.3f} = {floor:.3f} ms ({base / floor:.2f}x of W=1): the order phase is REPLICATED (every rank needs the whole operand in family order) and does not shrink with W")
+            print(f"SUMMARY N={N} W8_step_ms={step:.3f} W1_engine_step_ms={base:.3f} W8_speedup_vs_engine_W1={base / step:.2f} floor_ms={floor:.3f}")
 
 
 if __name__ == "__main__":
