@@ -69,6 +69,8 @@ struct d2g_cmp_set {
     bool full_list_valid = false;
     uint32_t *h_gaveup = nullptr, *d_gaveup = nullptr;   // a word of mapped host memory: 1 = the last ordering raised order[0] (the next prepare skips the ordering)
     unsigned sp_prepares = 0; bool sp_skipped = false;
+    void *fill_stream = nullptr, *fill_fork = nullptr, *fill_join = nullptr;   // (hipStream_t / hipEvent_t) a LARGE announced output is filled beside the rank kernel (d2g_bitslice_prepare)
+    void *samp_stream = nullptr, *samp_event = nullptr;   // (hipStream_t / hipEvent_t) the first look runs beside the column plan and the planes kernel
     bool sample_pending = false; uint32_t sample_ticket = 0;   // the first look's kernels are enqueued; the word (h_gaveup[6]) their last workgroup writes when the sums are in
     int skip_cached = -1;             // this prepare's reading of the remembered give-up (-1: not read yet)
     uint32_t *d_samp = nullptr;       // [16][Npad] + 2: the first look at a matrix (sp_sample): registers shared with sixteen sampled sketches

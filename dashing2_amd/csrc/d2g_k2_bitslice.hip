@@ -442,6 +442,12 @@ __device__ __forceinline__ void sp_ride(const SpRider &r) {
     }
 }
 #define SP_RIDE_OR_WORK(r) do { if (blockIdx.x >= (r).own) { sp_ride(r); return; } } while (0)
+// A LARGE announced output (>= SP_SIDE_FILL_PIECES pieces: 1 GB, ~23 000 sketches) is filled by a kernel of its own on a second stream, beside the
+// rank kernel: that one waits on its LDS tables for 1.0 ms at 50 000 sketches with the HBM almost idle, while the 5 GB fill spread over the six
+// hosts made each of them last 110-180 us (0.75 ms together).  Two cross-stream dependencies (~10 us) that a 200 MB fill does not earn back
+// (measured in rounds 4 and 5) and a 5 GB one does many times over.
+__global__ __launch_bounds__(256) void sp_side_fill_kernel(SpRider r) { sp_ride(r); }
+constexpr uint32_t SP_SIDE_FILL_PIECES = 32768;
 constexpr SpRider SP_NO_RIDER{nullptr, 0, nullptr, 0u, 0xFFFFFFFFu, 0u};
 
 // ------------------------------------------------------------------ 1b. column plan
@@ -963,6 +969,26 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     if (set->ride_out && sparse_path && set->ride_mask && set->skip_cached != 1)
         set->ride_total = (uint32_t)std::min<size_t>(sp_fill_pieces(set->ride_cnt), 0x7FFFFFFFu);
     if (sp_fill_pieces(set->ride_cnt) > 0x7FFFFFFFu) set->ride_total = 0;
+    bool side_fill = false;
+    if (set->ride_total >= SP_SIDE_FILL_PIECES) {
+        if (!set->fill_stream) {
+            hipStream_t st = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess) { set->fill_stream = st; set->fill_fork = e0; set->fill_join = e1; }
+            else { (void)hipGetLastError(); if (st) (void)hipStreamDestroy(st); if (e0) (void)hipEventDestroy(e0); }
+        }
+        if (set->fill_stream) {
+            // behind everything already on `s` (the transpose of this update; whoever read the output last), beside everything this prepare enqueues
+            hipStream_t fs = (hipStream_t)set->fill_stream;
+            D2G_HIP(ctx, hipEventRecord((hipEvent_t)set->fill_fork, s));
+            D2G_HIP(ctx, hipStreamWaitEvent(fs, (hipEvent_t)set->fill_fork, 0));
+            const SpRider all{set->ride_out, set->ride_cnt, set->ride_vsrc, set->ride_vimm, 0u, 0u};
+            hipLaunchKernelGGL(sp_side_fill_kernel, dim3(set->ride_total), dim3(256), 0, fs, all);
+            D2G_HIP(ctx, hipEventRecord((hipEvent_t)set->fill_join, fs));
+            set->ride_next = set->ride_total;                            // nothing left for the riders
+            side_fill = true;
+        }
+    }
     // the status word meta[ntb] was zeroed by the transpose kernel that filled d_cols (no memset node in the chain)
     {
         const int logTl = set->logT < BS_LOG_TLDS_MAX ? set->logT : BS_LOG_TLDS_MAX;
@@ -1004,6 +1030,7 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         if (int rc = sp_sample_collect(ctx, set, s)) return rc;         // (the first look, enqueued behind the rank kernel: the host waits for its word here)
         if (int rc = sp_prepare_order(ctx, set, split, s)) return rc;
         if (int rc = sp_permute(ctx, set, s)) return rc;
+        if (side_fill) D2G_HIP(ctx, hipStreamWaitEvent(s, (hipEvent_t)set->fill_join, 0));     // the launch writes into the filled output
         set->srt_valid = true; set->nat_valid = true;
         if (set->ride_total) { set->prefilled = set->ride_out; set->prefilled_cnt = set->ride_cnt; set->prefilled_pieces = set->ride_next; set->prefilled_src = set->ride_vsrc; set->prefilled_by_riders = true; }   // (the launch fills what is left)
         else if (set->prefilled_by_riders) set->prefilled = nullptr;        // what an EARLIER prepare's riders wrote is void once another prepare has run (the caller may have used the buffer in between)

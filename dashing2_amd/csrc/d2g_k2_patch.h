@@ -22,12 +22,18 @@ struct SpPatchArgs {
     uint32_t nwg;                         // workgroups of the sparse pair kernel that share the entries (the others leave without looking at the list)
 };
 constexpr int SP_PL_BINNED = 7;           // plctl[7] != 0: sp_bin_kernel has binned this prepare's list, sp_compose_kernel applies it
-// A sub-tile -- BS_IW launch rows whose first and last sorted positions are pf and pl, 64 BS_JR sorted column positions from c0 -- holds a
+// A sub-tile -- BS_IW launch rows whose first and last sorted positions are pf and pl, SP_SUBW sorted column positions from c0 -- holds a
 // pair of ONE segment only if the segment of its last row ends behind c0 and the segment of its first row starts before the sub-tile's
 // last column (segments are runs of sorted positions: their starts and ends grow with the position).  A listed tile's other sub-tiles
 // are not walked; the pair list's entries that fall into them count like those of a tile that is not listed (BOTH sides ask this function).
+// The sparse pair kernel's sub-tile: BS_IW rows x 64 SP_JR columns.  SP_JR = 1 (one column word per lane: half the pairs per sub-tile, the listed
+// sub-tiles hug the diagonal of sorted positions) and more waves per sub-tile were measured in round 6 (profiles/r06_k2_experiments.txt, section 7):
+// 41.0 us (SP_JR 1) / 38.2 (1, eight waves) / 54.4 (1, sixteen) / 39.1 (2, eight) against 38.1 for two words and four waves at config 3, 201 / 233 /
+// 294 / 199 against 189 us at 50 000 sketches -- the kernel is bound neither by VALU issue nor by one round trip per plane.
+constexpr int SP_JR = BS_JR;
+constexpr uint32_t SP_SUBW = 64u * SP_JR, SP_WC = BS_CB / SP_SUBW, SP_SUBS = (32u / BS_IW) * SP_WC;     // columns of a sub-tile, sub-tiles across a tile, sub-tiles of a tile
 __device__ __forceinline__ bool sp_sub_empty(const uint2 *__restrict__ posseg, uint32_t pf, uint32_t pl, uint32_t c0) {
-    return posseg[pl].y <= c0 || posseg[pf].x >= c0 + 64u * BS_JR;
+    return posseg[pl].y <= c0 || posseg[pf].x >= c0 + SP_SUBW;
 }
 constexpr unsigned long long SP_LEADER = 0x80000000ull;               // in the low word of an entry (i < 2^30: d2g_bitslice_alloc refuses larger N)
 __device__ __forceinline__ bool sp_entry_wanted(const SpPatchArgs &a, uint32_t i, uint32_t j) {
@@ -38,7 +44,7 @@ __device__ __forceinline__ bool sp_entry_wanted(const SpPatchArgs &a, uint32_t i
     else { k = a.rowk[i]; cpos = pj; }
     if (!((a.bm[(size_t)(k >> 5) * a.CW + (cpos >> 13)] >> ((cpos >> 8) & 31)) & 1u)) return true;
     // a listed tile: computed exactly -- but for the sub-tiles the pair kernel skips
-    const uint32_t k0 = k & ~(uint32_t)(BS_IW - 1), c0 = cpos & ~(64u * BS_JR - 1u);
+    const uint32_t k0 = k & ~(uint32_t)(BS_IW - 1), c0 = cpos & ~(SP_SUBW - 1u);
     uint32_t pf, pl;
     if (a.full) { pf = k0; pl = min(k0 + (uint32_t)BS_IW - 1u, a.N - 1u); }
     else { pf = a.rowpos[k0]; pl = a.rowpos[k0 + BS_IW - 1]; if (pl == 0xFFFFFFFFu) return false; }   // (the launch's last rows: walked)

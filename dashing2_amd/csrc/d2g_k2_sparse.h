@@ -440,7 +440,7 @@ struct SpColWork { uint32_t *ents; uint4 *vals; uint32_t ecap, vcap; };
 #endif
 // 36 KB of LDS, 64 VGPRs: four workgroups per CU.  The entries of a step do not live in LDS (pass B writes them to the stream): a step holds up to
 // 32 768 of them -- every column below 65 536 sketches is ONE step, pass A + pass B
-constexpr uint32_t SP_EMIT_VCAP = 1536, SP_EMIT_ECAP = 32768, SP_EMIT_T = D2G_SP_EMIT_T;
+constexpr uint32_t SP_EMIT_T = D2G_SP_EMIT_T, SP_EMIT_VCAP = SP_EMIT_T >= 1024 ? 2560 : 1536, SP_EMIT_ECAP = 32768;
 constexpr uint32_t SP_SEG_MIXED = 0xFFFFFFFEu;     // second[]: the value's outsiders lie in two segments at least
 __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
                                                             const uint32_t *__restrict__ seg, uint32_t *__restrict__ order,
@@ -704,7 +704,10 @@ __global__ __launch_bounds__(256) void sp_pairs_kernel(SpPairs pp) { sp_pairs_bo
 // launch rows: the sorted positions whose sketch lies in [r0, r1), in sorted order (stable compaction, one workgroup; 8192 positions at
 // a time through LDS so that the loads are coalesced and a thread still owns eight consecutive positions: N = 50 000 80 -> ~12 us)
 __global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restrict__ sperm, size_t N, uint32_t r0, uint32_t r1, uint32_t nrows_pad,
-                                                       uint32_t *__restrict__ rowpos, uint32_t *__restrict__ rowk) {
+                                                       uint32_t *__restrict__ rowpos, uint32_t *__restrict__ rowk, const uint32_t *__restrict__ order) {
+    // (the dense walk was decided -- possibly before any ordering: a set's FIRST prepare may skip it after its first look, and sperm[] then holds
+    // whatever the allocation held: nothing of the sorted operand may be touched.  The list kernel and the pair kernel leave on the same word.)
+    if (order[0]) return;
     __shared__ uint32_t wave_tot[16];
     __shared__ __attribute__((aligned(16))) uint32_t tile[8192];
     __shared__ uint32_t s_run;
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restric
         uint32_t k = sp_block_scan(cnt, wave_tot, &total) + s_run;
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
-            if (jv[x] == SP_NONE) continue;
+            if (jv[x] >= N) continue;                                  // (SP_NONE: padding)
             const bool w = jv[x] >= r0 && jv[x] < r1;
             rowk[jv[x]] = w ? k : SP_NONE;
             if (w) rowpos[k++] = (uint32_t)(base + tid * 8 + x);
@@ -745,7 +748,9 @@ __global__ __launch_bounds__(1024) void sp_rows_kernel(const uint32_t *__restric
 }
 
 __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restrict__ stream, size_t Nstride, const uint32_t *__restrict__ meta, int ntb,
-                                                        const uint32_t *__restrict__ rowpos, uint32_t nrows_pad, uint32_t *__restrict__ rowstream, size_t rstride) {
+                                                        const uint32_t *__restrict__ rowpos, uint32_t nrows_pad, uint32_t *__restrict__ rowstream, size_t rstride,
+                                                        const uint32_t *__restrict__ order) {
+    if (order[0]) return;                                             // dense walk: no launch rows (sp_rows_kernel)
     const size_t q = blockIdx.y;
     if (q >= stream_slot(meta, ntb)) return;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
@@ -757,7 +762,8 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t *__restri
 // tile bitmap of a PARTIAL launch from the global one: a block of 32 launch rows may meet what any of the sorted row blocks its rows
 // come from may meet (a superset of the tiles of those rows' own segments: still no pair inside a segment is missed)
 __global__ __launch_bounds__(256) void sp_rowbm_kernel(const uint32_t *__restrict__ gbm, const uint32_t *__restrict__ rowpos, uint32_t nrb, uint32_t CW,
-                                                       uint32_t *__restrict__ tilebm) {
+                                                       uint32_t *__restrict__ tilebm, const uint32_t *__restrict__ order) {
+    if (order[0]) return;                                             // dense walk: no launch rows (sp_rows_kernel)
     const uint32_t x = blockIdx.x * 256 + threadIdx.x;
     if (x >= nrb * CW) return;
     const uint32_t rb = x / CW, cw = x - rb * CW;
@@ -781,12 +787,12 @@ constexpr int SP_CTL_WORDS = 16;
 // the kernel lasted as long as the fullest CU (per-workgroup time stamps: plane walk 18 us on average, 34-38 us on the fullest CUs;
 // kernel 45 us for a mean workgroup life of 29).  Dense lists deal the work evenly.
 __device__ __forceinline__ uint32_t sp_tile_subs(uint32_t rb, uint32_t cb, int full, uint32_t N, const uint32_t *__restrict__ rowpos, const uint2 *__restrict__ posseg) {
-    constexpr uint32_t WC = BS_CB / (64 * BS_JR);
+    constexpr uint32_t WC = SP_WC;
     uint32_t m = 0;
 #pragma unroll
-    for (uint32_t sb = 0; sb < 4; ++sb) {
-        const uint32_t k0 = rb * 32u + (sb / WC) * BS_IW, c0 = cb * (uint32_t)BS_CB + (sb % WC) * (64u * BS_JR);
-        if (full && k0 > c0 + 64u * BS_JR - 1u) continue;            // entirely below the diagonal of sorted positions
+    for (uint32_t sb = 0; sb < SP_SUBS; ++sb) {
+        const uint32_t k0 = rb * 32u + (sb / WC) * BS_IW, c0 = cb * (uint32_t)BS_CB + (sb % WC) * SP_SUBW;
+        if (full && k0 > c0 + SP_SUBW - 1u) continue;                // entirely below the diagonal of sorted positions
         const uint32_t pf = full ? k0 : rowpos[k0];
         if (pf == SP_NONE || pf >= N) continue;                       // no row
         const uint32_t pl = full ? min(k0 + (uint32_t)BS_IW - 1u, N - 1u) : rowpos[k0 + BS_IW - 1];
@@ -849,8 +855,8 @@ __device__ __forceinline__ void sp_list_body(uint32_t wg, const uint32_t *__rest
     if (sm) {
         uint32_t o = s_base[q] + ((uint32_t)(ex[q >> 2] >> (16 * (q & 3))) & 0xFFFFu);
 #pragma unroll
-        for (uint32_t sb = 0; sb < 4; ++sb)
-            if ((sm >> sb) & 1u) tiles[(size_t)q * cap + o++] = (uint32_t)x * 4u + sb;
+        for (uint32_t sb = 0; sb < SP_SUBS; ++sb)
+            if ((sm >> sb) & 1u) tiles[(size_t)q * cap + o++] = (uint32_t)x * SP_SUBS + sb;
     }
 }
 // a partial launch's lists (its own tile bitmap); a whole-triangle launch uses the lists the prepare left (sp_permute_kernel)
@@ -1187,7 +1193,8 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
     constexpr int IW = BS_IW;
     constexpr int WC = BS_CB / (64 * JR);
     constexpr int KS = D2G_SP_KS;                                   // waves per sub-tile = splits of the group range
-    static_assert(JR == 2, "the LDS reduction packs a lane's two column groups into one word");
+    static_assert(JR == 1 || JR == 2, "the LDS reduction holds one word per row and lane: one count, or two packed");
+    static_assert(JR == SP_JR, "the work lists are made of SP_JR-wide sub-tiles (sp_tile_subs)");
     __shared__ uint32_t red[IW][64];                                // per row and lane: mismatches of column group 0 | group 1 << 16 (a sum stays below 2^16: S < 65536 asserted by the host)
     SP_STAMP(0);
     if (sp_dense_mode(a.ctl, a.cand)) return;                       // dense mode
@@ -1249,7 +1256,7 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
             }
             if (!found) continue;                                     // (more free places than sub-tiles handed over)
         }
-        const uint32_t tile = ent >> 2, sub = ent & 3u;
+        const uint32_t tile = ent / SP_SUBS, sub = ent % SP_SUBS;
         const uint32_t rb = tile / a.ncb, cb = tile - rb * a.ncb;
         const size_t k0 = (size_t)rb * 32 + (size_t)(sub / WC) * IW;              // first launch row of this sub-tile
         const size_t c0 = (size_t)cb * BS_CB + (size_t)(sub % WC) * (64 * JR);   // first sorted column position
@@ -1281,7 +1288,7 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
             SP_STAMP(2);
             const uint32_t rl = lane_again();
 #pragma unroll
-            for (int i = 0; i < IW; ++i) { const uint32_t v = acc[i][0] | (acc[i][1] << 16); if (v) atomicAdd(&red[i][rl], v); }
+            for (int i = 0; i < IW; ++i) { const uint32_t v = JR == 2 ? (acc[i][0] | (acc[i][JR - 1] << 16)) : acc[i][0]; if (v) atomicAdd(&red[i][rl], v); }
         }
         __syncthreads();
         SP_STAMP(3);
@@ -1306,7 +1313,7 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
                 const uint32_t oi = ois[r];                                           // uniform
 #pragma unroll
                 for (int c = 0; c < JR; ++c) {
-                    const uint32_t mm = (red[i][el] >> (16 * c)) & 0xFFFFu;
+                    const uint32_t mm = JR == 2 ? (red[i][el] >> (16 * c)) & 0xFFFFu : red[i][el];
                     if (mm == a.S || oj[c] == SP_NONE) continue;
                     const bool want = full ? rpos < (uint32_t)(c0 + el + 64 * c) : oj[c] > oi;
                     if (!want) continue;
@@ -1374,7 +1381,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     const size_t Npad = set->Npad, Nstride = set->Nstride;
     const size_t nrb = Npad / 32, ncb = Npad / BS_CB;
     set->tilebm_words = nrb * ((ncb + 31) / 32) + 1;
-    set->tiles_cap = nrb * ((ncb + 7) / 8) * 4;                        // per list: the sub-tiles of the tiles of every eighth column block
+    set->tiles_cap = nrb * ((ncb + 7) / 8) * SP_SUBS;                        // per list: the sub-tiles of the tiles of every eighth column block
     set->plist_cap = sp_list_cap(ctx, set->N);
     // holders of mixed values: h holders make h - 1 pairs at least -- and a column has N holders at most; a record per mixed value: a pair at least each, N / 2 values per column at most
     set->cw_ecap = std::min<size_t>(std::min<size_t>(2 * set->plist_cap, set->ncols * set->N), 0xFFFFFFF0u);
@@ -1438,6 +1445,11 @@ void sp_free(d2g_cmp_set *set) {
     (void)hipFree(set->d_bstart); set->d_bstart = nullptr;
     (void)hipFree(set->d_hoff); set->d_hoff = nullptr;
     (void)hipFree(set->d_samp); set->d_samp = nullptr;
+    if (set->fill_stream) { (void)hipStreamDestroy((hipStream_t)set->fill_stream); set->fill_stream = nullptr; }
+    if (set->fill_fork) { (void)hipEventDestroy((hipEvent_t)set->fill_fork); set->fill_fork = nullptr; }
+    if (set->fill_join) { (void)hipEventDestroy((hipEvent_t)set->fill_join); set->fill_join = nullptr; }
+    if (set->samp_stream) { (void)hipStreamDestroy((hipStream_t)set->samp_stream); set->samp_stream = nullptr; }
+    if (set->samp_event) { (void)hipEventDestroy((hipEvent_t)set->samp_event); set->samp_event = nullptr; }
     (void)hipFree(set->d_cw_ents); set->d_cw_ents = nullptr;
     (void)hipFree(set->d_cw_vals); set->d_cw_vals = nullptr;
     set->d_binc = nullptr;
@@ -1607,9 +1619,24 @@ bool sp_sample_due(const d2g_ctx *ctx, const d2g_cmp_set *set) {
 int sp_sample_enqueue(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     const size_t N = set->N, Npad = set->Npad;
     if (!set->h_gaveup) return D2G_OK;                                   // (no mapped host memory: no sample)
+    { hipStreamCaptureStatus cs = hipStreamCaptureStatusNone; if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return D2G_OK; } }   // (a captured prepare cannot wait for the host)
     SpSampleRows rows;
     for (uint32_t k = 0; k < SP_SAMPLE_ROWS; ++k) rows.r[k] = (uint32_t)std::min<size_t>(N - 1, (size_t)(2 * k + 1) * N / (2 * SP_SAMPLE_ROWS));
     uint32_t *acc3 = set->d_samp + SP_SAMPLE_ROWS * Npad;                // (the counters and the control words are zero: cleared at allocation, then by the kernel itself)
+#ifndef D2G_SP_SAMPLE_INLINE
+    // on a stream of their own, behind the rank kernel: the column plan (ONE workgroup) and the planes kernel run beside them.  No join: the host
+    // waits for the sample's word before it enqueues anything else, and nothing the two kernels read is written before the set's next prepare.
+    if (!set->samp_stream) {
+        hipStream_t st = nullptr; hipEvent_t ev = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) { set->samp_stream = st; set->samp_event = ev; }
+        else { (void)hipGetLastError(); if (st) (void)hipStreamDestroy(st); }
+    }
+    if (set->samp_stream) {
+        D2G_HIP(ctx, hipEventRecord((hipEvent_t)set->samp_event, s));
+        D2G_HIP(ctx, hipStreamWaitEvent((hipStream_t)set->samp_stream, (hipEvent_t)set->samp_event, 0));
+        s = (hipStream_t)set->samp_stream;
+    }
+#endif
     hipLaunchKernelGGL(sp_sample_kernel, dim3((unsigned)div_up<size_t>(N, 256), (unsigned)div_up<size_t>(set->ncols, SP_SAMPLE_COLS)), dim3(256), 0, s, set->d_ids, N, Npad, (uint32_t)set->ncols, rows, set->d_samp);
     hipLaunchKernelGGL(sp_sample_fin_kernel, dim3((unsigned)div_up<size_t>(std::max(N, set->ncols), 256)), dim3(256), 0, s, set->d_samp, N, Npad, rows, acc3, set->d_gaveup + 2,
                        set->d_colcnt, (uint32_t)set->ncols, set->nsplit, ++set->sample_ticket);
@@ -1632,7 +1659,7 @@ int sp_sample_collect(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
         uint32_t spins = 0;
         while (__atomic_load_n(&set->h_gaveup[6], __ATOMIC_ACQUIRE) != set->sample_ticket) {
             __builtin_ia32_pause();
-            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(250)) { D2G_HIP(ctx, hipStreamSynchronize(s)); break; }
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(250)) { D2G_HIP(ctx, hipStreamSynchronize(set->samp_stream ? (hipStream_t)set->samp_stream : s)); break; }
         }
     }
     const double scale = (double)N / (2.0 * SP_SAMPLE_ROWS), pairs = (double)N * (double)(N - 1) / 2.0;
@@ -1830,10 +1857,10 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     if (own_list) ++set->sp_launch;
     set->last_ctl = ctl;
     if (!full) {
-        hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk);
+        hipLaunchKernelGGL(sp_rows_kernel, dim3(1), dim3(1024), 0, s, set->d_sperm, N, (uint32_t)r0, (uint32_t)r1, (uint32_t)nrows_pad, set->d_rowpos, set->d_rowk, set->d_order);
         hipLaunchKernelGGL(sp_gather_kernel, dim3((unsigned)div_up<size_t>(nrows_pad, 256), (unsigned)(set->ntb * set->nbits_cap)), dim3(256), 0, s,
-                           set->d_stream_s, set->Nstride, set->d_meta, set->ntb, set->d_rowpos, (uint32_t)nrows_pad, set->d_rowstream, set->Nstride);
-        hipLaunchKernelGGL(sp_rowbm_kernel, dim3((unsigned)div_up<size_t>((size_t)nrb * CW, 256)), dim3(256), 0, s, set->d_gbm + 8, set->d_rowpos, nrb, CW, set->d_tilebm);
+                           set->d_stream_s, set->Nstride, set->d_meta, set->ntb, set->d_rowpos, (uint32_t)nrows_pad, set->d_rowstream, set->Nstride, set->d_order);
+        hipLaunchKernelGGL(sp_rowbm_kernel, dim3((unsigned)div_up<size_t>((size_t)nrb * CW, 256)), dim3(256), 0, s, set->d_gbm + 8, set->d_rowpos, nrb, CW, set->d_tilebm, set->d_order);
     }
     const size_t ntile = (size_t)nrb * ncb;
     // candidates: every tile of a partial launch; the tiles on or above the diagonal of sorted positions of a full one
@@ -1864,7 +1891,7 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     // a multiple of 8 (every XCD's list gets the same number of workgroups), four times what is resident at once: the lists differ in
     // length, and a workgroup that finds nothing at its index leaves at once -- the dispatcher evens the lists out sub-tile by sub-tile
     // (exactly one resident wave of workgroups took as long as the longest list: 52 -> 85 us at config 3)
-    const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * 4, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * SP_GRID_MULT) / 8 * 8);
+    const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * SP_SUBS, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * SP_GRID_MULT) / 8 * 8);
     // the pair list, composed region by region (before the pair kernel: that one STORES, see SpBins) -- when this set's prepare binned it
     if (set->sp_big) {
         const uint32_t band0 = (uint32_t)(r0 >> 5), nband = (uint32_t)((r1 - 1) >> 5) - band0 + 1u;
@@ -1876,7 +1903,7 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     }
     // (a short list is applied entry by entry: the pair kernel's tail adds, the gated launch behind it turns the sums into table values)
     SpPatchArgs pa{set->d_plist, set->d_plctl, (uint32_t)std::min<size_t>(set->plist_cap, 0xFFFFFFFFu), ctl, cand32, set->d_sinv, set->d_rowk, set->d_rowpos, reinterpret_cast<const uint2 *>(set->d_posseg), (uint32_t)N, bm, CW, (uint32_t)r0, (uint32_t)r1, full ? 1 : 0, std::min<uint32_t>(grid, (uint32_t)ctx->num_cus * 8u)};
-    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<BS_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
+    hipLaunchKernelGGL((k2_bitslice_sparse_kernel<SP_JR, Store>), dim3(grid), dim3(64 * D2G_SP_KS), 0, s, a, sh, store, pa);
     // behind the gate: every tile of the caller's-order operand in dense mode; otherwise the second step of a short pair list (table epilogue)
     if (dsh.nvalid_total)
         hipLaunchKernelGGL((k2_bitslice_kernel<BS_JR, Store>), dim3(dsh.per_xcd * 8), dim3(BS_THREADS), 0, s, set->d_stream,
