@@ -440,7 +440,8 @@ struct SpColWork { uint32_t *ents; uint4 *vals; uint32_t ecap, vcap; };
 #endif
 // 36 KB of LDS, 64 VGPRs: four workgroups per CU.  The entries of a step do not live in LDS (pass B writes them to the stream): a step holds up to
 // 32 768 of them -- every column below 65 536 sketches is ONE step, pass A + pass B
-constexpr uint32_t SP_EMIT_T = D2G_SP_EMIT_T, SP_EMIT_VCAP = SP_EMIT_T >= 1024 ? 2560 : 1536, SP_EMIT_ECAP = 32768;
+// (1024 threads and 2560 values per step -- every column of config 3 ONE step, two workgroups per CU -- was measured: 35 us against 24 clean, 108 against 78 at c = 10)
+constexpr uint32_t SP_EMIT_VCAP = 1536, SP_EMIT_ECAP = 32768, SP_EMIT_T = D2G_SP_EMIT_T;
 constexpr uint32_t SP_SEG_MIXED = 0xFFFFFFFEu;     // second[]: the value's outsiders lie in two segments at least
 __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
                                                             const uint32_t *__restrict__ seg, uint32_t *__restrict__ order,
