@@ -425,10 +425,9 @@ __device__ __forceinline__ size_t stream_slot_wave(const uint32_t *meta, int tb)
 // output is announced ahead of the prepare (d2g_cmp_ut_announce_dev) those kernels are launched with extra workgroups BEHIND their own --
 // the dispatcher starts workgroups in index order, the kernel's own work is never queued behind a rider -- each writing one 32 KB piece.
 // (The same fill on a second stream was measured in rounds 4 and 5: the two cross-stream dependencies cost more than the fill.)
-__device__ __forceinline__ void sp_ride(const SpRider &r) {
+__device__ __forceinline__ void sp_ride_piece(const SpRider &r, size_t piece) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const uint32_t v = r.vsrc ? r.vsrc[0] : r.vimm;
-    const size_t piece = (size_t)r.piece0 + (blockIdx.x - r.own);
     const size_t head = min(r.cnt, (size_t)((16 - ((uintptr_t)r.out & 15)) & 15) / 4);   // the output pointer is only 4-byte aligned in general
     u32x4 *body = reinterpret_cast<u32x4 *>(r.out + head);
     const size_t nb = (r.cnt - head) / 4;
@@ -441,13 +440,26 @@ __device__ __forceinline__ void sp_ride(const SpRider &r) {
         if (tail0 + threadIdx.x < r.cnt) r.out[tail0 + threadIdx.x] = v;
     }
 }
+__device__ __forceinline__ void sp_ride(const SpRider &r) { sp_ride_piece(r, (size_t)r.piece0 + (blockIdx.x - r.own)); }
 #define SP_RIDE_OR_WORK(r) do { if (blockIdx.x >= (r).own) { sp_ride(r); return; } } while (0)
 // A LARGE announced output (>= SP_SIDE_FILL_PIECES pieces: 1 GB, ~23 000 sketches) is filled by a kernel of its own on a second stream, beside the
 // rank kernel: that one waits on its LDS tables for 1.0 ms at 50 000 sketches with the HBM almost idle, while the 5 GB fill spread over the six
 // hosts made each of them last 110-180 us (0.75 ms together).  Two cross-stream dependencies (~10 us) that a 200 MB fill does not earn back
 // (measured in rounds 4 and 5) and a 5 GB one does many times over.
-__global__ __launch_bounds__(256) void sp_side_fill_kernel(SpRider r) { sp_ride(r); }
+__global__ __launch_bounds__(256) void sp_side_fill_kernel(SpRider r, uint32_t pieces) {
+    for (size_t p = blockIdx.x; p < pieces; p += gridDim.x) sp_ride_piece(r, p);
+}
 constexpr uint32_t SP_SIDE_FILL_PIECES = 32768;
+// How hard the side fill may pull: unthrottled (one workgroup per 32 KB piece, 5.5 TB/s) it stretched the rank kernel beside it from 1.04 to 1.63 ms at
+// 50 000 sketches (step 2.54 ms); with persistent workgroups looping over the pieces -- 64 / 128 / 192 / 256 / 384 of them: 2.4 / 3.7 / 4.4 / 4.5 / 5.1 TB/s --
+// the two end together at 128 (rank 1.39, fill 1.36 ms: step 2.27 ms).  So: the fewest workgroups whose rate still finishes the fill within 1.3 x the rank
+// kernel's own time (21 ns per sketch at S = 1024, measured at 50 000), everything the chip has when even that is too slow (100 000 sketches on).
+inline unsigned sp_side_fill_grid(const d2g_ctx *ctx, uint32_t pieces, size_t words, size_t N, size_t S) {
+    const double need = (double)words * 4.0 / (1.3 * 21.0 * (double)N * ((double)S / 1024.0));     // bytes per ns = GB/s
+    const unsigned cus = (unsigned)ctx->num_cus;
+    const unsigned g = need <= 3700.0 ? cus / 2 : need <= 4400.0 ? cus * 3 / 4 : need <= 5000.0 ? cus * 3 / 2 : pieces;
+    return std::max(1u, std::min<unsigned>(pieces, g));
+}
 constexpr SpRider SP_NO_RIDER{nullptr, 0, nullptr, 0u, 0xFFFFFFFFu, 0u};
 
 // ------------------------------------------------------------------ 1b. column plan
@@ -983,7 +995,8 @@ int d2g_bitslice_prepare(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
             D2G_HIP(ctx, hipEventRecord((hipEvent_t)set->fill_fork, s));
             D2G_HIP(ctx, hipStreamWaitEvent(fs, (hipEvent_t)set->fill_fork, 0));
             const SpRider all{set->ride_out, set->ride_cnt, set->ride_vsrc, set->ride_vimm, 0u, 0u};
-            hipLaunchKernelGGL(sp_side_fill_kernel, dim3(set->ride_total), dim3(256), 0, fs, all);
+            const unsigned fgrid = sp_side_fill_grid(ctx, set->ride_total, set->ride_cnt, N, S);
+            hipLaunchKernelGGL(sp_side_fill_kernel, dim3(fgrid), dim3(256), 0, fs, all, set->ride_total);
             D2G_HIP(ctx, hipEventRecord((hipEvent_t)set->fill_join, fs));
             set->ride_next = set->ride_total;                            // nothing left for the riders
             side_fill = true;

@@ -1668,12 +1668,13 @@ int sp_sample_collect(d2g_ctx *ctx, d2g_cmp_set *set, hipStream_t s) {
     set->pred_entries = (double)h[2] * scale;
     set->pred_family_pairs = (double)h[3] * scale;
     const double values = (double)h[4], planes = set->ncols ? (double)h[5] / (double)set->ncols : 1.0;
-    // what each path would take, in nanoseconds (constants measured at config 3 on MI355X, round 6: profiles/r06_k2_experiments.txt): the dense walk
-    // costs 2 + 0.94 x planes ps per pair; the sparse path a longer prepare chain (16.5 ns per sketch more than the dense one), 55 ps per list entry (pairs, counting, moving, composing),
-    // 77 ps per shared value (grouping its holders, its record) and the family pairs' tiles at twice the dense rate
-    // (the per-plane and per-sketch terms are those of 32 register groups, S = 1024: they go with the group count)
+    // what each path would take BEYOND the prepare both share, in nanoseconds (constants measured at config 3 on MI355X, round 6: profiles/r06_k2_experiments.txt):
+    // the dense walk costs 2 + 0.94 x planes ps per pair (426 us at 7 planes); the sparse path a chain of ordering kernels and the fill (66 us on a matrix
+    // that shares nothing: 6.6 ns per sketch), 55 ps per list entry (pairs, counting, moving, composing), 77 ps per shared value (grouping its holders, its
+    // record) and 9 x the dense rate per family pair (their tiles in the latency-bound sparse pair kernel, their holders in the link and emit passes:
+    // ~100 us for 7.4e5 family pairs).  (the per-plane and per-sketch terms are those of 32 register groups, S = 1024: they go with the group count)
     const double g = (double)set->ntb / 32.0, per_pair = 0.002 + 0.00094 * planes * g;
-    const double dense_ns = pairs * per_pair, sparse_ns = (3.0 + 13.5 * g) * (double)N + 0.055 * set->pred_entries + 0.077 * values + 2.0 * per_pair * set->pred_family_pairs;
+    const double dense_ns = pairs * per_pair, sparse_ns = (3.0 + 3.6 * g) * (double)N + 0.055 * set->pred_entries + 0.077 * values + 9.0 * per_pair * set->pred_family_pairs;
     set->pred_dense = set->pred_entries > (double)set->plist_cap || sparse_ns > 0.97 * dense_ns;
     set->h_gaveup[0] = set->pred_dense ? 1u : 0u;                      // what the next prepares go by (the device kernels that give up write the same word)
     return D2G_OK;

@@ -924,8 +924,10 @@ def test_k2_first_look_decides_before_the_ordering(gpu_ctx, d2g, oracle):
     stream = torch.cuda.current_stream().cuda_stream
     fam = synth.synthetic_registers(N, S, nclusters=N // 150, seed=31)
     cases = [("families", fam, False), ("families+1", synth.add_chance_collisions(fam, 1, seed=32), False),
+             ("families+10", synth.add_chance_collisions(fam, 10, seed=36), False),
              ("families+100", synth.add_chance_collisions(fam, 100, seed=33), True), ("paired", synth.paired_registers(N, S, seed=34), True),
-             ("skewed", synth.skewed_registers(N, S, seed=35), True)]
+             ("skewed", synth.skewed_registers(N, S, seed=35), True),
+             ("unrelated", synth.unrelated_registers(N, S, seed=37), False)]     # (nothing shared: the fill alone -- the dense walk would cost a whole pair kernel)
     off = _ut_offsets(N)
     out = torch.empty(N * (N - 1) // 2, dtype=torch.int32, device=dev)
     rows = [0, 1, 77, N // 2, N - 3, N - 2]

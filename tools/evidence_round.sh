@@ -1,10 +1,11 @@
 # round-6 evidence on the final commit (GPU box): everything lands in gpurun_out/, the summaries are copied to profiles/ afterwards
 # usage: tools/evidence_round.sh [quick|rest]     quick = suites + bench + kernel stats + matrices; rest = counters, loopback lines, e2e CLI, fuzz
 set -x
+MODE=$1          # (the loops below use `set --`)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
-if [ "$1" != rest ]; then
+if [ "$MODE" != rest ]; then
 timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/r06_gputests.log 2>&1; tail -3 gpurun_out/r06_gputests.log
 D2G_BS_SPARSE_MIN_N=1 D2G_SP_TILE_FRAC=1 timeout 1500 python -m pytest tests -q -m gpu > gpurun_out/r06_gputests_sparse_forced.log 2>&1; tail -3 gpurun_out/r06_gputests_sparse_forced.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06_smoke.log 2>&1; tail -1 gpurun_out/r06_smoke.log
@@ -20,7 +21,7 @@ for c in 0 10; do if [ $c = 0 ]; then M=stated; else M=noise; fi; MATRIX=$M C=$c
 N=50000 MATRIX=stated timeout 600 tools/kstats.sh r06_k2_config4 python $R/tools/k2_time.py > /dev/null 2>&1
 for n in 10000 50000; do for m in stated unrelated; do N=$n MATRIX=$m D2G_LIB=$R/dashing2_amd/libd2g_ranktrace.so timeout 200 python3 tools/rank_trace.py 2>&1 | grep -v amdgpu.ids; done; done > gpurun_out/r06_rank_trace_final.txt
 fi
-[ "$1" = quick ] && exit 0
+[ "$MODE" = quick ] && exit 0
 timeout 900 tools/kstats.sh r06_bench_all_legs python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic > /dev/null 2>&1
 D2G_BS_SPARSE=0 timeout 600 tools/kstats.sh r06_bench_dense_walk python $R/bench.py --steps 20 --warmup 5 --no-config4 --no-matrices --no-cpu-baseline --no-sketch --no-multiset --no-traffic > /dev/null 2>&1
 timeout 1200 tools/pmc_round.sh $R/gpurun_out/r06_pmc.json > gpurun_out/pmc_round.log 2>&1; tail -3 gpurun_out/pmc_round.log
