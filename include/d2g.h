@@ -314,7 +314,8 @@ int  d2g_cmp_set_create_dev(d2g_ctx *ctx, const uint64_t *sig_bits_dev, size_t N
 int  d2g_cmp_set_create(d2g_ctx *ctx, const uint64_t *sig_bits_host, size_t N, size_t sketchsize,
                         int algo, d2g_cmp_set **out);
 /* re-load an existing set with a new N x S matrix of the same shape, reusing every device
- * buffer (no allocation, no host synchronisation: the whole prepare chain is enqueued on `stream`) */
+ * buffer (no allocation; the whole prepare chain is enqueued on `stream`.  The FIRST prepare of a BITSLICE set of 8192 sketches or more -- and the
+ * first after d2g_cmp_set_forget -- waits a few tens of microseconds for two small kernels that look at the matrix: INTEGRATION.md section 2) */
 int  d2g_cmp_set_update_dev(d2g_ctx *ctx, d2g_cmp_set *set, const uint64_t *sig_bits_dev, void *stream);
 /* The `_dev` prepare chain is asynchronous and cannot report a data-dependent failure when it is
  * enqueued.  The one such failure: a register column that puts more distinct values into one hash
