@@ -60,7 +60,7 @@ struct d2g_cmp_set {
     uint32_t *d_lcnt = nullptr;       // [Npad+1]  counting sort: sketches per root, then the placing cursors (= segment ends)
     uint32_t *d_gbm = nullptr;        // 8 control words + the tile bitmap over ALL sorted row blocks (the segments' tiles); partial launches derive theirs from it
     uint32_t *d_order = nullptr;      // [8] [0] 1 = the launches walk every tile of the caller's-order operand (dense), [2] deep label chains
-    uint32_t *d_plctl = nullptr;      // [8] [0] entries emitted into the pair list
+    uint32_t *d_plctl = nullptr;      // [12] [0] entries emitted into the pair list
     uint32_t *d_rowpos = nullptr;     // [Nstride] launch rows: sorted position of launch row k
     uint32_t *d_rowk = nullptr;       // [Npad]    launch row of sketch j (0xFFFFFFFF = not a row of this launch)
     uint32_t *d_rowstream = nullptr;  // [planes][Nstride] row-coded words of the launch rows, gathered (partial launches)

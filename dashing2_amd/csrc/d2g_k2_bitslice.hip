@@ -1275,6 +1275,9 @@ extern "C" int d2g_debug_rank_trace(unsigned long long *out, size_t n) {
 #endif
 #ifdef D2G_SP_TRACE
 // variant builds only: the time stamps of the last sparse pair kernel (tools/sp_trace.py)
+extern "C" int d2g_debug_emit_trace(unsigned long long *out, size_t n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_emit_trace), std::min<size_t>(n, 4096 * 16) * 8) == hipSuccess ? 0 : -1;
+}
 extern "C" int d2g_debug_sp_trace(unsigned long long *out, size_t n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_trace), std::min<size_t>(n, 16384 * 8) * 8) == hipSuccess ? 0 : -1;
 }

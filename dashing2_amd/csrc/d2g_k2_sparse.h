@@ -415,6 +415,9 @@ __global__ __launch_bounds__(256) void sp_place_kernel(const uint32_t *__restric
 // what sp_emit_kernel hands to sp_pairs_kernel: the holders of every mixed value (the insiders, then the outsiders) in one stream, and one
 // record per value: (index of its first holder in the stream, place of its pairs in the list, insiders, outsiders)
 struct SpColWork { uint32_t *ents; uint4 *vals; uint32_t ecap, vcap; };
+// the entry stream's and the value records' cursors as ONE aligned 64-bit word among plctl[8..10] (entries | records << 32): a step of sp_emit_kernel
+// reserves both with one atomic
+__device__ __forceinline__ unsigned long long *sp_pl_streams(uint32_t *plctl) { return reinterpret_cast<unsigned long long *>(plctl + 8 + (((uintptr_t)(plctl + 8) >> 2) & 1u)); }
 
 // (b): every shared value of every column; the pairs of its holders that lie in different segments go to the pair list.  One workgroup
 // per column; the column's shared values are walked in ranges of at most vcap ranks (2048; 1024 from N = 65 536 on, where the two
@@ -438,11 +441,18 @@ struct SpColWork { uint32_t *ents; uint4 *vals; uint32_t ecap, vcap; };
 #ifndef D2G_SP_EMIT_T
 #define D2G_SP_EMIT_T 512
 #endif
+#ifdef D2G_SP_TRACE
+// variant builds only (tools/emit_trace.py): per-workgroup time stamps of sp_emit_kernel's FIRST step -- 0 start, 1 LDS cleared, 2 pass A done, 3 counts read +
+// mixed vote, 4 scan + places, 5 stream places reserved (two global atomics), 6 pass B done, 7 slots scanned + list places reserved, 8 records written
+__device__ unsigned long long g_emit_trace[4096 * 16];
+#define EM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && lo == 0) g_emit_trace[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EM_STAMP(k) do { } while (0)
+#endif
 // 36 KB of LDS, 64 VGPRs: four workgroups per CU.  The entries of a step do not live in LDS (pass B writes them to the stream): a step holds up to
 // 32 768 of them -- every column below 65 536 sketches is ONE step, pass A + pass B
 // (1024 threads and 2560 values per step -- every column of config 3 ONE step, two workgroups per CU -- was measured: 35 us against 24 clean, 108 against 78 at c = 10)
 constexpr uint32_t SP_EMIT_VCAP = 1536, SP_EMIT_ECAP = 32768, SP_EMIT_T = D2G_SP_EMIT_T;
-constexpr uint32_t SP_SEG_MIXED = 0xFFFFFFFEu;     // second[]: the value's outsiders lie in two segments at least
 __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8))) void sp_emit_kernel(const uint32_t *__restrict__ ids, size_t N, size_t Npad, uint32_t ncols, const uint32_t *__restrict__ colcnt, int split,
                                                             const uint32_t *__restrict__ seg, uint32_t *__restrict__ order,
                                                             SpColWork cw, uint32_t *__restrict__ plctl, uint32_t plcap, uint32_t *__restrict__ gaveup, int big) {
@@ -450,9 +460,8 @@ __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8)
     __shared__ uint32_t cnt[SP_EMIT_VCAP];                // pass A: insiders | outsiders << 16 (big: [q] and [1024 + q]); in a round: the two cursors of a mixed value
     __shared__ uint32_t mrec[SP_EMIT_VCAP];               // the step's mixed values: first entry | q << 16
     __shared__ uint32_t vpre[SP_EMIT_VCAP];               // list slots of the step's mixed values before this one
-    __shared__ uint32_t second[SP_EMIT_VCAP];             // pass A: the second segment met; pass B: the segment of the value's first OUTSIDER, SP_SEG_MIXED once another outsider's differs
+    __shared__ uint32_t second[SP_EMIT_VCAP];             // pass A: the second segment met
     __shared__ uint32_t cntb[SP_EMIT_VCAP];               // pass A: holders in the second segment
-    __shared__ uint32_t wave_tot[16];
     __shared__ unsigned long long wave_tot64[16];
     __shared__ uint32_t s_base, s_ebase, s_vbase, s_stop, s_cut, s_nent, s_nm;
     if (order[0]) return;
@@ -484,11 +493,13 @@ __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8)
     uint32_t colpairs = 0;
     bool voted = false;
     for (uint32_t lo = 0; lo < d2;) {                                // steps of whole values (uniform)
+        EM_STAMP(0);
         const uint32_t len = min(vcap, d2 - lo);
         for (uint32_t x = tid; x < SP_EMIT_VCAP; x += T) { first[x] = SP_NONE; second[x] = SP_NONE; cnt[x] = 0; cntb[x] = 0; }
         if (tid == 0) s_stop = sp_ld(&order[0]);
         __syncthreads();
         if (s_stop) return;                                           // somebody found that the list will not fit
+        EM_STAMP(1);
         for_each_holder([&](uint32_t r, uint32_t sgv, uint32_t) {
             if (r <= lo || r > lo + len) return;
             const uint32_t q = r - 1 - lo;
@@ -499,7 +510,8 @@ __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8)
             if (outside) { const uint32_t o2 = atomicCAS(&second[q], SP_NONE, sgv); if (o2 == SP_NONE || o2 == sgv) atomicAdd(&cntb[q], 1u); }
         });
         __syncthreads();
-        uint32_t n0[PER], nO[PER];
+        EM_STAMP(2);
+        uint32_t n0[PER], nO[PER], oo = 0;                          // oo: bit x -- the outsiders of my value x lie in two segments at least
         bool mixed_mine = false;
 #pragma unroll
         for (uint32_t x = 0; x < PER; ++x) {
@@ -511,12 +523,15 @@ __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8)
             // "outsiders": 75 outsiders are 2 775 candidate pairs among them as soon as a second stranger joins)
             if (q < len && nO[x]) {
                 const uint32_t nb = cntb[q];
+                // a holder outside the first two segments met: whichever of the two holds the insiders, the outsiders lie in two segments at least --
+                // pairs among them get list slots (known HERE, before pass B: every reservation of the step is made in one place)
+                if (nO[x] > nb) oo |= 1u << x;
                 if (nb > n0[x]) { first[q] = second[q]; nO[x] += n0[x] - nb; n0[x] = nb; }
-                second[q] = SP_NONE;                                  // pass B: the first outsider's segment
             }
             mixed_mine |= nO[x] != 0;
         }
-        if (!__syncthreads_or(mixed_mine)) { lo += len; continue; }   // no mixed value in this range: every clean family column ends here
+        if (!__syncthreads_or(mixed_mine)) { EM_STAMP(3); lo += len; continue; }   // no mixed value in this range: every clean family column ends here
+        EM_STAMP(3);
         {
             // my values: entries (a thread's sum clamped to ECAP + 1) | mixed values << 32
             unsigned long long v = 0;
@@ -543,7 +558,21 @@ __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8)
             }
             __syncthreads();
             const uint32_t ncut = s_cut;
-            // places and cursors of the step's mixed values, their pair counts (made a prefix below); the step's totals from whoever owns its end
+            // the list slots of the step's mixed values: the pairs with insiders, + one slot per pair of outsiders where those lie in two segments at
+            // least (sp_pairs_kernel fills such a slot with the pair or, where the two share a segment, with the NULL entry)
+            unsigned long long pv[PER], stot;
+            unsigned long long srun;
+            {
+                unsigned long long sum = 0;
+#pragma unroll
+                for (uint32_t x = 0; x < PER; ++x) {
+                    pv[x] = 0;
+                    if (tid * PER + x < ncut && nO[x]) pv[x] = (unsigned long long)n0[x] * nO[x] + (((oo >> x) & 1u) ? (unsigned long long)nO[x] * (nO[x] - 1u) / 2u : 0ull);
+                    sum += pv[x];
+                }
+                srun = sp_block_scan64<T / 64>(sum, wave_tot64, &stot);
+            }
+            // places and cursors of the step's mixed values, the slots before each; the step's totals from whoever owns its end
             {
                 uint32_t eoff = (uint32_t)run, moff = (uint32_t)(run >> 32);
 #pragma unroll
@@ -552,67 +581,53 @@ __global__ __launch_bounds__(SP_EMIT_T) __attribute__((amdgpu_waves_per_eu(8, 8)
                     if (q == ncut) { s_nent = eoff; s_nm = moff; }
                     if (q >= ncut) continue;
                     if (!nO[x]) { cnt[q] = SP_NONE; continue; }       // (no cursor word looks like this: positions stay below 32 769)
-                    mrec[moff] = eoff | (q << 16);
-                    vpre[moff] = n0[x] * nO[x];                           // the pairs with insiders (sp_pairs_kernel finds the pairs among the outsiders itself)
+                    mrec[moff] = eoff | (q << 16) | (((oo >> x) & 1u) << 31);
+                    vpre[moff] = (uint32_t)srun;                        // (a step whose slots pass 2^32 is given up below: the list holds fewer)
                     cnt[q] = eoff | ((eoff + n0[x]) << 16);
-                    ++moff; eoff += n0[x] + nO[x];
+                    ++moff; eoff += n0[x] + nO[x]; srun += pv[x];
                 }
                 if (ncut >= len && tid == 0) { s_nent = (uint32_t)tot; s_nm = (uint32_t)(tot >> 32); }
             }
             __syncthreads();
+            EM_STAMP(4);
             const uint32_t nent = s_nent, nm = s_nm;
-            if (nent == 0) {                                          // (the step's first mixed value alone exceeds the buffer: ONE value with tens of thousands of
-                if (tid == 0) { order[0] = 1; *gaveup = 1; }          // holders spread over segments -- not sparse)
+            if (nent == 0 || stot > 0xFFFFFFFFull) {                  // (the step's first mixed value alone exceeds the buffer: ONE value with tens of thousands of
+                if (tid == 0) { order[0] = 1; *gaveup = 1; }          // holders spread over segments -- or more slots than any list has: not sparse)
                 return;
             }
-            if (tid == 0) { s_ebase = atomicAdd(&plctl[5], nent); s_vbase = atomicAdd(&plctl[6], nm); }   // the step's places in the entry stream and among the value records
+            const uint32_t total = (uint32_t)stot;
+            // the step's places in the entry stream and among the value records (ONE 64-bit atomic) and in the list -- the two in flight together.  Round 6's
+            // first form made three reservations one after the other, the third behind pass B: with all 1024 workgroups arriving together the same-address
+            // atomics cost a workgroup 14 + 4.5 us of its 54 at ten chance collisions per sketch (time stamps: profiles/r06_k2_experiments.txt, section 12)
+            if (tid == 0) { const unsigned long long o = atomicAdd(sp_pl_streams(plctl), (unsigned long long)nent | ((unsigned long long)nm << 32)); s_ebase = (uint32_t)o; s_vbase = (uint32_t)(o >> 32); }
+            if (tid == 64) s_base = atomicAdd(&plctl[0], total);
             __syncthreads();
-            const uint32_t ebase = s_ebase, vbase = s_vbase;
-            if ((size_t)ebase + nent > cw.ecap || (size_t)vbase + nm > cw.vcap) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }
+            EM_STAMP(5);
+            const uint32_t ebase = s_ebase, vbase = s_vbase, base = s_base;
+            if ((size_t)ebase + nent > cw.ecap || (size_t)vbase + nm > cw.vcap || (size_t)base + total > plcap) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }
             for_each_holder([&](uint32_t r, uint32_t sgv, uint32_t j) {
                 if (r <= lo || r > lo + len) return;
                 const uint32_t q = r - 1 - lo;
                 if (q >= ncut || cnt[q] == SP_NONE) return;
                 const bool inside = first[q] == sgv;
                 const uint32_t old = atomicAdd(&cnt[q], inside ? 1u : 0x10000u);
-                if (!inside) { const uint32_t o2 = atomicCAS(&second[q], SP_NONE, sgv); if (o2 != SP_NONE && o2 != sgv) second[q] = SP_SEG_MIXED; }
                 cw.ents[ebase + (inside ? (old & 0xFFFFu) : (old >> 16))] = j;     // (the step's stream is a few KB written within microseconds: the lines fill up in L2)
             });
             __syncthreads();
-            // the list slots of the step's mixed values: the pairs with insiders, + one slot per pair of outsiders where those lie in two segments at
-            // least (sp_pairs_kernel fills such a slot with the pair or, where the two share a segment, with the NULL entry); vpre[m] -> slots before value m
-            uint32_t total;
-            {
-                uint32_t pv[PER], sum = 0;
-#pragma unroll
-                for (uint32_t x = 0; x < PER; ++x) {
-                    const uint32_t m = tid * PER + x;
-                    pv[x] = 0;
-                    if (m < nm) {
-                        const uint32_t q = mrec[m] >> 16, c = cnt[q], nO = (c >> 16) - (c & 0xFFFFu);     // (the cursors have reached the ends of their parts)
-                        pv[x] = vpre[m] + (second[q] == SP_SEG_MIXED ? nO * (nO - 1u) / 2u : 0u);
-                    }
-                    sum += pv[x];
-                }
-                uint32_t pre = sp_block_scan<T / 64>(sum, wave_tot, &total);
-#pragma unroll
-                for (uint32_t x = 0; x < PER; ++x) { const uint32_t m = tid * PER + x; if (m < nm) vpre[m] = pre; pre += pv[x]; }
-            }
-            if (tid == 0) s_base = atomicAdd(&plctl[0], total);
-            __syncthreads();
+            EM_STAMP(6);
+            EM_STAMP(7);
             // the step's values leave for sp_pairs_kernel: one record per mixed value -- (first holder in the entry stream, first slot in the list, insiders, outsiders)
             {
-                const uint32_t base = s_base;
-                if ((size_t)base + total > plcap) { if (tid == 0) { order[0] = 1; *gaveup = 1; } return; }
                 colpairs += total;
                 for (uint32_t m = tid; m < nm; m += T) {
-                    const uint32_t rec = mrec[m], c = cnt[rec >> 16];
+                    const uint32_t rec = mrec[m], c = cnt[(rec >> 16) & 0x7FFFu];
                     const uint32_t st = rec & 0xFFFFu, mid = c & 0xFFFFu, end = c >> 16;
                     // (bit 31 of the outsider count: they lie in two segments at least -- pairs among them have slots)
-                    cw.vals[vbase + m] = uint4{ebase + st, base + vpre[m], mid - st, (end - mid) | (second[rec >> 16] == SP_SEG_MIXED ? 0x80000000u : 0u)};
+                    cw.vals[vbase + m] = uint4{ebase + st, base + vpre[m], mid - st, (end - mid) | (rec & 0x80000000u)};
                 }
             }
             __syncthreads();
+            EM_STAMP(8);
             lo += ncut;                                               // the next step starts at the first value that did not fit (pass A again from there)
             // this column's pairs so far, scaled to all of its values and all columns: 1.25 times the capacity says the list will not fit.
             // Eight columns must say so (one odd column must not send a sparse matrix to the dense walk).
@@ -649,10 +664,10 @@ __device__ __forceinline__ void sp_pairs_body(uint32_t wg, uint32_t nwg, const S
     __shared__ uint4 rec[SP_PAIRS_CHUNK];
     const SpColWork &cw = pp.cw;
     const uint32_t *__restrict__ seg = pp.seg;
-    const uint32_t *__restrict__ plctl = pp.plctl, *__restrict__ order = pp.order;
+    const uint32_t *__restrict__ order = pp.order;
     unsigned long long *__restrict__ plist = pp.plist;
     if (order[0]) return;
-    const uint32_t nv = min(plctl[6], cw.vcap), tid = threadIdx.x;
+    const uint32_t nv = min((uint32_t)(*sp_pl_streams(pp.plctl) >> 32), cw.vcap), tid = threadIdx.x;
     for (uint32_t v0 = wg * SP_PAIRS_CHUNK; v0 < nv; v0 += nwg * SP_PAIRS_CHUNK) {     // (uniform)
         if (tid < 64) {                                               // one wave: the chunk's records and the prefix of their slot counts
             uint32_t np = 0;
@@ -1393,7 +1408,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     set->bin_nch = (uint32_t)div_up<size_t>(set->N, (size_t)1 << set->bin_cshift);
     set->nbins = (uint32_t)(div_up<size_t>(set->N, 32) * set->bin_nch);
     // one zero-initialised block per prepare: [counters Npad + 1 | 8 global control words + tile bitmap | order 8 | list control 8 | control words of a whole-triangle launch 16 | entries per bin | bin cursors]
-    set->spz_words = (Npad + 1) + (8 + set->tilebm_words) + 8 + 8 + SP_CTL_WORDS + (size_t)set->nbins;
+    set->spz_words = (Npad + 1) + (8 + set->tilebm_words) + 8 + 12 + SP_CTL_WORDS + (size_t)set->nbins;
     // the workgroups that count (and then move) the list's entries: one per ~16 384 entries of a full list, at most two per CU
     set->bin_nwg = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)std::max(ctx->num_cus / 2, 1), div_up<size_t>(set->plist_cap, 16384)));   // (128 of them measured best at config 3: 64 / 128 / 512 / 1024 -> counting + moving 90 / 65 / 70 / 84 us)
     const size_t planes_words = (size_t)set->ntb * set->nbits_cap + 1;
@@ -1427,7 +1442,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     set->d_gbm = set->d_lcnt + (Npad + 1);
     set->d_order = set->d_gbm + 8 + set->tilebm_words;
     set->d_plctl = set->d_order + 8;
-    set->d_fullctl = set->d_plctl + 8;
+    set->d_fullctl = set->d_plctl + 12;
     set->d_binc = set->d_fullctl + SP_CTL_WORDS;
     set->d_tilebm = set->d_spctl + 2 * SP_CTL_WORDS;
     if ((e = hipMemset(set->d_spctl, 0, 2 * SP_CTL_WORDS * 4)) != hipSuccess) { ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e); return D2G_ERR_HIP; }
