@@ -841,8 +841,9 @@ def test_k2_sparse_path_beyond_65535_sketches(gpu_ctx, d2g, oracle):
 def test_k2_bench_matrix_rows_vs_oracle(gpu_ctx, d2g, oracle):
     """the EXACT matrix bench.py times (config 3: synthetic_registers(10000, 1024, nclusters=66, seed=20260928), finalised)
     on the sparse path (asserted), ~200 rows -- first rows, the seams of an 8-way pair-balanced partition, random rows, last rows --
-    value for value against the oracle: equality counts and the fused float epilogue; then the same matrix with three chance collisions
-    per sketch (bench.py's noise family; at ten the list would outgrow pairs / 16 entries and the device takes the dense walk)."""
+    value for value against the oracle: equality counts and the fused float epilogue; then the same matrix with three and with ten chance
+    collisions per sketch (bench.py's noise family; VERDICT r5 #1: at ten the list holds ~4 million entries and goes through the binned +
+    composed form -- asserted -- where round 5 took the dense walk)."""
     import torch
     N, S = 10_000, 1024
     regs = synth.synthetic_registers(N, S, nclusters=66, seed=20260928)
@@ -852,7 +853,8 @@ def test_k2_bench_matrix_rows_vs_oracle(gpu_ctx, d2g, oracle):
     rows = sorted(set(list(range(0, 24)) + [min(N - 2, max(0, b + d)) for b in seams for d in (-2, -1, 0, 1)] + [int(x) for x in rng.integers(0, N - 1, 120)] + list(range(N - 25, N - 1))))
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
-    for label, rr in (("stated", regs), ("stated + 3 collisions", synth.add_chance_collisions(regs, 3, seed=20260929))):
+    for label, rr in (("stated", regs), ("stated + 3 collisions", synth.add_chance_collisions(regs, 3, seed=20260929)),
+                      ("stated + 10 collisions", synth.add_chance_collisions(regs, 10, seed=20260929))):
         sig, cards = d2g.oph_finalize(rr, S, nthreads=8)
         t_dev = torch.from_numpy(sig.view(np.int64)).to(dev)
         cs = gpu_ctx.cmp_set_dev(t_dev.data_ptr(), N, S, algo=d2g.CMP_AUTO, stream=stream)
@@ -862,6 +864,8 @@ def test_k2_bench_matrix_rows_vs_oracle(gpu_ctx, d2g, oracle):
         assert info["sorted_operand"] and info["tiles_listed"] > 0 and info["tiles_and_pair_list"] and not info["dense_kernel_ran"], (label, info)
         if label != "stated":
             assert info["pairs_listed"] > 0
+        if label.endswith("10 collisions"):
+            assert info["pairs_listed"] > 786_432, info                 # (D2G_SP_LONG_LIST: the binned + composed form from here on)
         fout = torch.empty(N * (N - 1) // 2, dtype=torch.float32, device=dev)
         lut = torch.from_numpy(d2g.epilogue_lut(S, d2g.SIMILARITY, 31)).to(dev)
         cs.lut_ut_dev(lut.data_ptr(), fout.data_ptr(), 0, N, stream)
