@@ -22,6 +22,7 @@
 #include "d2g_k2.h"
 #include "d2g_k2_shape.h"
 #include <chrono>
+#include <cstring>
 #include <algorithm>
 #include <cstdlib>
 #include <vector>

@@ -1447,7 +1447,7 @@ int sp_alloc(d2g_ctx *ctx, d2g_cmp_set *set) {
     set->d_tilebm = set->d_spctl + 2 * SP_CTL_WORDS;
     if ((e = hipMemset(set->d_spctl, 0, 2 * SP_CTL_WORDS * 4)) != hipSuccess) { ctx->last_error = std::string("bitslice sparse alloc: ") + hipGetErrorString(e); return D2G_ERR_HIP; }
     // one word of host memory the device can write: the remembered give-up (sp_prepare_order)
-    if (hipHostMalloc((void **)&set->h_gaveup, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void **)&set->d_gaveup, set->h_gaveup, 0) == hipSuccess) *set->h_gaveup = 0;
+    if (hipHostMalloc((void **)&set->h_gaveup, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void **)&set->d_gaveup, set->h_gaveup, 0) == hipSuccess) std::memset(set->h_gaveup, 0, 64);   // (all 16 words: the first look's ticket word must not hold what an earlier owner of the page left)
     else { (void)hipGetLastError(); if (set->h_gaveup) (void)hipHostFree(set->h_gaveup); set->h_gaveup = nullptr; set->d_gaveup = set->d_order + 7; }   // (no mapped host memory: a spare device word, never read by the host)
     set->sp_launch = 0;
     return D2G_OK;
