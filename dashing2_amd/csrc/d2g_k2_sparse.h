@@ -420,21 +420,20 @@ struct SpColWork { uint32_t *ents; uint4 *vals; uint32_t ecap, vcap; };
 __device__ __forceinline__ unsigned long long *sp_pl_streams(uint32_t *plctl) { return reinterpret_cast<unsigned long long *>(plctl + 8 + (((uintptr_t)(plctl + 8) >> 2) & 1u)); }
 
 // (b): every shared value of every column; the pairs of its holders that lie in different segments go to the pair list.  One workgroup
-// per column; the column's shared values are walked in ranges of at most vcap ranks (2048; 1024 from N = 65 536 on, where the two
+// per column; the column's shared values are walked in ranges of at most vcap ranks (1536; 768 from N = 65 536 on, where the two
 // holder counts of a value no longer fit one word):
-//   pass A  first[q] = segment of the first holder of value q (compare-and-swap); every holder counts itself as INSIDE that segment
-//           or OUTSIDE it.  A value with an outsider is MIXED.  A range without a mixed value -- every clean family column -- is done
-//           after this pass.  The counts stay in registers (four values per thread).
-//   scan    the mixed values get consecutive places for their holders: insiders first, outsiders behind them.  The first value whose holders
-//           no longer fit the entry buffer (3072) ends the STEP: the next one starts there, with pass A again (round 5 halved the range
-//           blindly: three A and two B passes per column at ten chance collisions per sketch, two and two now; keeping the counts in
-//           registers across steps -- one A -- was built and costs the kernel 13 VGPRs too many for four workgroups per CU).
-//   pass B  the holders of the step's mixed values are placed: the sketch at the value's cursors.
+//   pass A  first[q] = segment of the first holder of value q, second[q] = the next segment met (compare-and-swap); every holder counts itself as
+//           INSIDE the first segment or OUTSIDE it, and the holders of the second segment are counted too.  A value with an outsider is MIXED; its
+//           INSIDERS are the larger of the two segments; its outsiders lie in two segments at least exactly when somebody holds it outside both.
+//           A range without a mixed value -- every clean family column -- is done after this pass.  The counts stay in registers (three values per thread).
+//   scans   the mixed values get consecutive places for their holders (insiders first, outsiders behind them) and for their list slots.  The first
+//           value whose holders no longer fit the entry buffer (32 768: never below 65 536 sketches) ends the STEP: the next one starts there, with
+//           pass A again.  The step then reserves its places in the entry stream, among the records and in the list: two atomics, in flight together.
+//   pass B  the holders of the step's mixed values are placed: the sketch at the value's cursors, straight into the entry stream.
 //   hand-off  the step's values leave for sp_pairs_kernel: a record per mixed value (where its holders start in the entry stream, where its
-//           pairs go in the list: the places are reserved HERE, one atomic per step), its holders behind a header word.  The pairs
-//           themselves -- an OUTSIDER with every insider of its value, and with the later outsiders of another segment -- are written by
-//           that kernel, flat over all columns (round 5 let every outsider write its own run from inside this kernel's per-column latency
-//           chain: 64 eight-byte stores to 64 different lines per wave instruction, 50 ps per entry).
+//           pairs go in the list).  The pairs themselves -- an OUTSIDER with every insider of its value, and with the later outsiders of another
+//           segment -- are written by that kernel, flat over all columns (round 5 let every outsider write its own run from inside this kernel's
+//           per-column latency chain: 64 eight-byte stores to 64 different lines per wave instruction, 50 ps per entry).
 // A list that is full raises order[0] (dense walk): the list is then longer than an eighth of all pairs -- not a sparse matrix.
 // A list that will not fit is noticed EARLY: every workgroup adds its column's pair count to plctl[2] and bumps plctl[3]; once 32
 // columns are in, (pairs so far / columns so far) x columns > 1.5 x capacity raises order[0] and everybody stops at its next range.
@@ -443,13 +442,13 @@ __device__ __forceinline__ unsigned long long *sp_pl_streams(uint32_t *plctl) { 
 #endif
 #ifdef D2G_SP_TRACE
 // variant builds only (tools/emit_trace.py): per-workgroup time stamps of sp_emit_kernel's FIRST step -- 0 start, 1 LDS cleared, 2 pass A done, 3 counts read +
-// mixed vote, 4 scan + places, 5 stream places reserved (two global atomics), 6 pass B done, 7 slots scanned + list places reserved, 8 records written
+// mixed vote, 4 scans + places, 5 places reserved (the step's two global atomics), 6 pass B done, 7 = 6 (the slots are scanned with the places since the merge), 8 records written
 __device__ unsigned long long g_emit_trace[4096 * 16];
 #define EM_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && lo == 0) g_emit_trace[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define EM_STAMP(k) do { } while (0)
 #endif
-// 36 KB of LDS, 64 VGPRs: four workgroups per CU.  The entries of a step do not live in LDS (pass B writes them to the stream): a step holds up to
+// 36 KB of LDS, 63 VGPRs: four workgroups per CU.  The entries of a step do not live in LDS (pass B writes them to the stream): a step holds up to
 // 32 768 of them -- every column below 65 536 sketches is ONE step, pass A + pass B
 // (1024 threads and 2560 values per step -- every column of config 3 ONE step, two workgroups per CU -- was measured: 35 us against 24 clean, 108 against 78 at c = 10)
 constexpr uint32_t SP_EMIT_VCAP = 1536, SP_EMIT_ECAP = 32768, SP_EMIT_T = D2G_SP_EMIT_T;
