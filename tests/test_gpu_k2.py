@@ -340,7 +340,8 @@ def test_k2_config4_size_vs_oracle(gpu_ctx, d2g, oracle):
     of output).  The whole triangle is checked through size-independent properties (checksum of checksums
     from per-column value counts; every per-row sum) and sampled row ranges are compared value for value
     with the ORACLE (equality counts through its float32 SIMILARITY = neq/1024, exact for S = 2^10):
-    the first rows, the seam between two of the 8 row shards, the middle, and the last rows."""
+    the first rows, the seam between two of the 8 row shards, the middle, and the last rows.  The whole output again through the announced
+    path (the 5 GB fill on a second stream)."""
     import torch
     N, S = 50_000, 1024
     regs = synth.synthetic_registers(N, S, nclusters=N // 150, seed=20260929)
@@ -364,7 +365,29 @@ def test_k2_config4_size_vs_oracle(gpu_ctx, d2g, oracle):
     assert int(out.max().item()) <= S
     off = np.concatenate([[0], np.cumsum(N - 1 - np.arange(N, dtype=np.int64))])
     neq = out.cpu().numpy().view(np.uint32)
-    del out
+    # the same through the ANNOUNCED path (round 6: an output of 1 GB and more is filled by a kernel on a second stream, beside the rank kernel,
+    # joined before the launch): announce -> update -> launch twice into a buffer pre-set to garbage, all 1 249 975 000 words equal to the first
+    # computation (which the checks below hold against the per-column totals and the oracle)
+    out2 = torch.empty(npairs, dtype=torch.int32, device=dev)
+    for rep in range(2):
+        out2.fill_(-7 - rep)
+        cs.announce_ut_dev(out2.data_ptr(), 0, N)
+        cs.update_dev(t_dev.data_ptr(), stream)
+        cs.eqcount_ut_dev(out2.data_ptr(), 0, N, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2), f"announced step {rep}"
+    del out2
+    # ... and the table form (the fill value comes from lut[0] on the device)
+    lut_dev = torch.from_numpy(d2g.epilogue_lut(S, d2g.SIMILARITY, 31)).to(dev)
+    fout = torch.full((npairs,), float("nan"), dtype=torch.float32, device=dev)
+    cs.announce_ut_dev(fout.data_ptr(), 0, N, lut_dev_ptr=lut_dev.data_ptr())
+    cs.update_dev(t_dev.data_ptr(), stream)
+    cs.lut_ut_dev(lut_dev.data_ptr(), fout.data_ptr(), 0, N, stream)
+    torch.cuda.synchronize()
+    CH = 1 << 28
+    for a in range(0, npairs, CH):
+        assert torch.equal(fout[a:a + CH].view(torch.int32), lut_dev[out[a:a + CH].to(torch.int64)].view(torch.int32)), f"announced table step, words from {a}"
+    del out, fout
     got_row = np.zeros(N, np.int64)
     cs_all = np.concatenate([[0], np.cumsum(neq, dtype=np.int64)])
     got_row[:N - 1] = cs_all[off[1:N]] - cs_all[off[:N - 1]]          # pairs (i, j>i)
