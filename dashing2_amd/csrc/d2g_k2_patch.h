@@ -27,10 +27,11 @@ constexpr int SP_PL_BINNED = 7;           // plctl[7] != 0: sp_bin_kernel has bi
 // last column (segments are runs of sorted positions: their starts and ends grow with the position).  A listed tile's other sub-tiles
 // are not walked; the pair list's entries that fall into them count like those of a tile that is not listed (BOTH sides ask this function).
 // The sparse pair kernel's sub-tile: BS_IW rows x 64 SP_JR columns, D2G_SP_KS waves each walking a share of the register groups.  Measured in round 6
-// with per-workgroup time stamps (profiles/r06_k2_experiments.txt, section 7): at config 3 the bench's families hold ~150 sketches, the listed sub-tiles are
-// mostly FULL, and a workgroup's life is prologue 3 + plane walk 19 + reduction 1 + epilogue 6 us, the walk one memory round trip per plane and wave
-// (104 planes x 180 ns).  One column word per lane (SP_JR 1): 1 429 sub-tiles instead of 1 013, walk 17.5 us -- nothing gained; eight waves per
-// sub-tile: walk 10.5 us but 72 VGPRs allow three such workgroups per CU, the 1 013 need two rounds -- 40.9 against 41.5 us.
+// with per-workgroup time stamps (profiles/r06_k2_experiments.txt, sections 7 and 13): at config 3 the bench's families hold ~150 sketches, the listed
+// sub-tiles are mostly FULL, and the plane walk is one memory round trip per plane and wave (four waves: 104 planes x 180 ns = 19 us of a workgroup's 30).
+// One column word per lane (SP_JR 1): 1 429 sub-tiles instead of 1 013, walk 17.5 us -- nothing gained.  Eight waves per sub-tile halve the walk, but with
+// the mismatch counts in registers (72 VGPRs) only three such workgroups fit a CU and the 1 013 sub-tiles needed two rounds (40.9 us); with the counts
+// added to LDS group by group (42 VGPRs, no scratch) four fit, every sub-tile is resident from the start: 35.7 us against 40.6 with four waves.
 constexpr int SP_JR = BS_JR;
 constexpr uint32_t SP_SUBW = 64u * SP_JR, SP_WC = BS_CB / SP_SUBW, SP_SUBS = (32u / BS_IW) * SP_WC;     // columns of a sub-tile, sub-tiles across a tile, sub-tiles of a tile
 __device__ __forceinline__ bool sp_sub_empty(const uint2 *__restrict__ posseg, uint32_t pf, uint32_t pl, uint32_t c0) {

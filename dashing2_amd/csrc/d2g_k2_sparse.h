@@ -34,7 +34,10 @@ constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
 constexpr uint32_t SP_SAMPLE_ROWS = 16, SP_SAMPLE_FAM = 4, SP_SAMPLE_COLS = 32;   // the first look at a matrix (sp_sample_kernel)
 constexpr unsigned long long SP_NULL_ENTRY = ~0ull;   // an empty slot of the pair list: two outsiders of one value that share a segment (sp_pairs_kernel); every reader skips it
 #ifndef D2G_SP_KS
-#define D2G_SP_KS 4
+#define D2G_SP_KS 8
+#endif
+#ifndef D2G_SP_WPE
+#define D2G_SP_WPE 8
 #endif
 
 __device__ __forceinline__ uint32_t sp_rank(uint32_t w, const uint32_t *__restrict__ colcnt, size_t t, bool split) {
@@ -1155,7 +1158,7 @@ __device__ __forceinline__ BsOperands<JR> sp_fetch(const uint32_t *&rp, size_t r
 
 template <int JR>
 __device__ __forceinline__ void sp_group(int nbits, const uint32_t *&rp, size_t rstep, const uint32_t *&cp, uint32_t coff, size_t cstep, BsOperands<JR> &a,
-                                         uint32_t (&acc)[BS_IW][JR]) {
+                                         uint32_t *red_lane) {
     uint32_t z[BS_IW][JR];
     BsOperands<JR> b = sp_fetch<JR>(rp, rstep, cp, coff, cstep);
     bs_plane<JR, true>(a, z);
@@ -1172,10 +1175,13 @@ __device__ __forceinline__ void sp_group(int nbits, const uint32_t *&rp, size_t 
     } else {
         a = b;
     }
+    // the group's mismatch counts go straight to the sub-tile's LDS words (red[i][lane]: group 0 | group 1 << 16): no accumulators carried through the
+    // walk -- 32 VGPRs less, which is what lets EIGHT waves share a sub-tile with four such workgroups resident per CU (see the kernel)
 #pragma unroll
-    for (int i = 0; i < BS_IW; ++i)
-#pragma unroll
-        for (int c = 0; c < JR; ++c) acc[i][c] += __builtin_popcount(z[i][c]);
+    for (int i = 0; i < BS_IW; ++i) {
+        const uint32_t v = JR == 2 ? ((uint32_t)__builtin_popcount(z[i][0]) | ((uint32_t)__builtin_popcount(z[i][JR - 1]) << 16)) : (uint32_t)__builtin_popcount(z[i][0]);
+        atomicAdd(&red_lane[i * 64], v);
+    }
 }
 
 struct SpArgs {
@@ -1192,7 +1198,7 @@ struct SpArgs {
 };
 
 // The sparse pair kernel.  A listed tile (32 launch rows x 256 sorted columns) is four 16 x 128 sub-tiles; a workgroup takes ONE
-// sub-tile and its four waves each walk a quarter of the 32-register groups, then add their mismatch counts in LDS.  (The dense
+// sub-tile and its eight waves (D2G_SP_KS) each walk an eighth of the 32-register groups, adding every group's mismatch counts in LDS.  (The dense
 // kernel gives every wave a sub-tile and all groups: with a few hundred listed tiles that leaves one or two waves per SIMD, each
 // waiting out the latency of every plane's loads -- measured 87 us for 432 tiles at config 3, 411 us for 2122 at config 4.)
 #ifdef D2G_SP_TRACE
@@ -1204,7 +1210,7 @@ __device__ unsigned long long g_sp_trace[16384 * 8];
 #define SP_STAMP(k) do { } while (0)
 #endif
 template <int JR, class Store>
-__global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(D2G_BS_WPE))) void k2_bitslice_sparse_kernel(SpArgs a, PairShape sh, Store store, SpPatchArgs pa) {
+__global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(D2G_SP_WPE))) void k2_bitslice_sparse_kernel(SpArgs a, PairShape sh, Store store, SpPatchArgs pa) {
     constexpr int IW = BS_IW;
     constexpr int WC = BS_CB / (64 * JR);
     constexpr int KS = D2G_SP_KS;                                   // waves per sub-tile = splits of the group range
@@ -1280,11 +1286,6 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
         __syncthreads();
         SP_STAMP(1);
         if (g1 > g0) {
-            uint32_t acc[IW][JR];
-#pragma unroll
-            for (int i = 0; i < IW; ++i)
-#pragma unroll
-                for (int c = 0; c < JR; ++c) acc[i][c] = 0;
             const size_t rstep = full ? 2 * a.Nstride : a.rstride;
             const size_t cstep = 2 * a.Nstride;
             const uint32_t *rp = (full ? a.stream : a.rowstream) + k0 + slot0 * rstep;
@@ -1295,15 +1296,12 @@ __global__ __launch_bounds__(64 * D2G_SP_KS) __attribute__((amdgpu_waves_per_eu(
             for (int tb = g0; tb < g1; ++tb) {
                 const int nbits = nbits_nx;
                 nbits_nx = live_planes(a.meta, tb + 1 < a.ntb ? tb + 1 : 0);
-                sp_group<JR>(nbits, rp, rstep, cp, coff, cstep, nx, acc);
+                sp_group<JR>(nbits, rp, rstep, cp, coff, cstep, nx, &red[0][0] + lane);
             }
-            // every wave adds its share of the mismatch counts in LDS; afterwards wave ks finishes rows [ks IW/KS, (ks+1) IW/KS) -- the epilogue
-            // (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
-            // work while the other three wait
+            // (every wave has added its groups' mismatch counts in LDS: sp_group); afterwards wave ks finishes rows [ks IW/KS, (ks+1) IW/KS) -- the
+            // epilogue (caller's indices, condensed position, table value, store) is ~45 instructions per pair and would otherwise be one wave's
+            // work while the others wait
             SP_STAMP(2);
-            const uint32_t rl = lane_again();
-#pragma unroll
-            for (int i = 0; i < IW; ++i) { const uint32_t v = JR == 2 ? (acc[i][0] | (acc[i][JR - 1] << 16)) : acc[i][0]; if (v) atomicAdd(&red[i][rl], v); }
         }
         __syncthreads();
         SP_STAMP(3);
@@ -1907,7 +1905,7 @@ int launch_sparse(d2g_ctx *ctx, const d2g_cmp_set *cset, PairShape sh, Store sto
     // a multiple of 8 (every XCD's list gets the same number of workgroups), four times what is resident at once: the lists differ in
     // length, and a workgroup that finds nothing at its index leaves at once -- the dispatcher evens the lists out sub-tile by sub-tile
     // (exactly one resident wave of workgroups took as long as the longest list: 52 -> 85 us at config 3)
-    const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * SP_SUBS, 8) * 8, (size_t)ctx->num_cus * (28 / D2G_SP_KS) * SP_GRID_MULT) / 8 * 8);
+    const unsigned grid = (unsigned)std::max<size_t>(8, std::min<size_t>(div_up<size_t>(ntile * SP_SUBS, 8) * 8, (size_t)ctx->num_cus * (4 * D2G_SP_WPE / D2G_SP_KS) * SP_GRID_MULT) / 8 * 8);
     // the pair list, composed region by region (before the pair kernel: that one STORES, see SpBins) -- when this set's prepare binned it
     if (set->sp_big) {
         const uint32_t band0 = (uint32_t)(r0 >> 5), nband = (uint32_t)((r1 - 1) >> 5) - band0 + 1u;
